@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Headline benchmark: VQA samples/sec of one CoR2 training step (forward + KLD-sum loss + backward +
+flat-gradient sum-all-reduce + clip 0.25 + Adam), batch 512 per GPU, 36x2048 regions, 2400-d question,
+fp32, dropout active -- BASELINE.json configs[1] (N=1) / configs[3] (N=8, global batch 4096).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 5
+
+Rank 0 prints ONE JSON line.  Inputs are synthetic and resident in HBM before the timed region.  The
+`roofline` object is for the dominant hand-written kernel (K4 forward, the fp32-MFMA low-rank bilinear
+fusion at M = 512*36 rows), timed live with HIP events on the launch stream inside the timed steps;
+`roofline_all` lists every hand-written kernel the step launches.  `cpu_baseline` times the oracle's
+reference-faithful torch-CPU port (oracle/reference_faithful.py) on a bounded sample on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_F32_PEAK_TF = 157.3   # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
+
+BATCH, REGIONS, FEAT, QDIM, ANSWERS = 512, 36, 2048, 2400, 2000
+LOW, HID, GLIMPSES, RANK = 310, 510, 4, 2
+
+
+def kernel_models(B, N=REGIONS, D=FEAT, G=GLIMPSES, L=LOW, H=HID, R=RANK):
+    """Algorithmic bytes / FLOPs per launch (SURVEY.md 8d per-sample figures x samples per launch)."""
+    f = 4
+    return {
+        "lowrank_bilinear_fusion_fwd": ("mfma", B * (2 * R * N * L * H + 2 * R * N * H)),
+        "lowrank_bilinear_fusion_bwd": ("mfma", B * (2 * 2 * R * N * L * H)),              # dx + dW1 contractions
+        "pairwise_relation_reduce_fwd": ("hbm", B * (2 * N * D + 2 * D + N) * f),          # 606 352 B/sample
+        "pairwise_relation_reduce_bwd": ("hbm", B * (2 * N * D + 4 * D + 2 * N) * f),      # v, g in; dq1,dq2,dalpha out
+        "softmax_attention_pool_fwd": ("hbm", B * (N * D + 2 * N * G + G * D) * f),        # 328 832 B/sample
+        "softmax_attention_pool_bwd": ("hbm", B * (N * D + G * D + 3 * N * G) * f),        # (+N*D when d_v is written)
+    }
+
+
+def roofline_entry(name, shape, launches, mean_ms, B):
+    bound, work = kernel_models(B)[name]
+    if name == "softmax_attention_pool_bwd" and shape[-1]:
+        work += B * REGIONS * FEAT * 4
+    if name == "lowrank_bilinear_fusion_bwd" and not shape[-1]:
+        work //= 2
+    sec = mean_ms * 1e-3
+    if bound == "hbm":
+        achieved, peak, unit = work / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+    else:
+        achieved, peak, unit = work / sec / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
+    return {"kernel": name, "shape": list(shape), "launches": launches, "mean_ms": round(mean_ms, 5), "bound": bound,
+            "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4), "traffic": None}
+
+
+def cpu_baseline(batch=32, steps=3):
+    """The reference cannot travel to the GPU box; time its op-for-op torch-CPU port (validated against the
+    reference's golden vectors in tests/) on all host cores: CoR2 fwd+bwd, dropout active."""
+    from oracle import reference_faithful as RF
+    from oracle import seeded
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = RF.CoR2Oracle(ANSWERS).train()
+    v, q, a = (torch.from_numpy(x) for x in seeded.seeded_inputs(batch, answers=ANSWERS, seed=3))
+
+    def one():
+        model.zero_grad(set_to_none=True)
+        RF.kld_sum_loss(model({"v": v, "q": q}), a).backward()
+
+    one()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(batch / dt, 2), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "CoR2 fwd+bwd (KLD-sum loss, dropout on), batch %d x %d steps after 1 warm-up, torch-CPU "
+                      "reference-faithful port (per-sample python loops, materialised [B,36,36,2048])" % (batch, steps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (BASELINE config: 512)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--relation-mode", type=int, default=1, help="K1: 0 = pairwise, 1 = factored")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from vqa_playground_pytorch_amd import CoR2Model, ops
+    from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
+
+    torch.manual_seed(1234)
+    model = CoR2Model(["PAD", "UNK"], ANSWERS, relation_mode=args.relation_mode).to(dev).train()
+    trainer = DataParallelTrainer(model, lr=1e-4, clip=0.25)
+    torch.manual_seed(100 + rank)  # per-rank dropout streams and data shards differ
+    B = args.batch
+    v = torch.randn(B, REGIONS, FEAT, device=dev)
+    q = torch.randn(B, QDIM, device=dev)
+    a = torch.softmax(2.0 * torch.randn(B, ANSWERS, device=dev), dim=1)
+    sample = {"v": v, "q_idxes": q}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(sample, a)
+    timer = ops.KernelTimer()
+    barrier()
+    ops.set_kernel_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = trainer.step(sample, a)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    assert torch.isfinite(loss).item(), "non-finite loss"
+
+    if rank == 0:
+        summary = timer.summary()
+        entries = [roofline_entry(name, shape, n, ms, B) for (name, shape), (n, ms) in summary.items()
+                   if shape[0] == B and (len(shape) < 2 or shape[1] == REGIONS)]
+        entries.sort(key=lambda e: -e["mean_ms"] * e["launches"])
+        dominant = next((e for e in entries if e["kernel"] == "lowrank_bilinear_fusion_fwd"), entries[0])
+        result = {
+            "metric": "VQA samples/sec (fwd+bwd), CoR2 batch 512, 36x2048 regions",
+            "value": round(world * B * args.steps / elapsed, 1),
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "CoR2 fwd+bwd fp32, batch %d per GPU, 36x2048 regions + 2400-d question, 2-step "
+                                   "reasoning chain, 2000 answers (BASELINE configs[1]; configs[3] at 8 GPUs)" % B,
+                       "global_batch": world * B, "step": "forward + KLD-sum loss + backward + grad sum-all-reduce "
+                       "+ clip 0.25 + Adam (dropout active)", "parallelism": "dp%d" % world,
+                       "relation_mode": "factored" if args.relation_mode == 1 else "pairwise"},
+            "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
+                                                  "mean_ms", "launches")},
+            "roofline_all": entries,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+"""Drop-in for the reference's ``config/CoR2.py``: the same module-level hyper-parameters
+(config/CoR2.py:8-53 of the reference; consumed by train.py:323-477) and the same names
+``MyConv1d / MyLinear / MyATT / Model`` -- backed by the MI355X HIP kernels.
+
+    python train.py --cf config.CoR2        # train.py does importlib.import_module(args.cf)
+"""
+import os
+
+from vqa_playground_pytorch_amd.cor2 import Model  # noqa: F401
+from vqa_playground_pytorch_amd.layers import (MutanFusion, MyATT, MyConv1d, MyLinear,  # noqa: F401
+                                               bmatmul, bmul)
+
+# The data directory (override with VQA_DATA_DIR; the reference hard-codes its authors' path)
+YOUR_DATA_DIR = os.environ.get("VQA_DATA_DIR", "/mnt/cephfs/lab/liujinlai.licio")
+data_dir = os.path.join(YOUR_DATA_DIR, "data/VQA/download")
+process_dir = os.path.join(YOUR_DATA_DIR, "data/VQA/preprocess")
+log_dir = os.path.join(YOUR_DATA_DIR, "data/VQA/logs")
+analyze_dir = os.path.join(YOUR_DATA_DIR, "data/VQA/analyze")
+
+version = 2
+samplingans = False
+loss_metric = "KLD"
+vgenome = False
+version1_multiple_choices = False
+# Process_img
+arch = "rcnn"
+size = 224
+
+# Process_qa
+nans = 2000
+splitnum = 2
+mwc = 0
+mql = 26
+
+# Train
+target_list = ["v", "q_id", "q_idxes"]
+epochs = 70
+restart_epoch = None
+keeping_epoch = 40
+
+resume = True
+print_freq = 10
+lr = 0.0001
+load_mem = None
+batch_size = 100
+clip_grad = True
+test_dev_range = None
+test_range = None
+debug = False
+
+method_name = os.path.splitext(os.path.basename(__file__))[0]
+if splitnum == 2:
+    method_name += "_VAL"
+log_dir = os.path.join(log_dir, method_name)
+analyze_dir = os.path.join(analyze_dir, method_name)

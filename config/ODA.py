@@ -1,0 +1,54 @@
+"""Drop-in for the reference's ``config/ODA.py``: the same module-level hyper-parameters
+(config/ODA.py:8-70 of the reference) and the names ``MyConv1d / MyLinear / MyATT / Model`` --
+backed by the MI355X HIP kernels.
+
+    python train.py --cf config.ODA
+"""
+import os
+
+from vqa_playground_pytorch_amd.layers import (MutanFusion, MyATT, MyConv1d, MyLinear,  # noqa: F401
+                                               bmatmul, bmul)
+from vqa_playground_pytorch_amd.oda import Model  # noqa: F401
+
+# Preprocess (relative paths by default, like the reference's fall-through branch; override with VQA_DATA_DIR)
+YOUR_DATA_DIR = os.environ.get("VQA_DATA_DIR", "")
+data_dir = os.path.join(YOUR_DATA_DIR, "data/VQA/download")
+process_dir = os.path.join(YOUR_DATA_DIR, "data/VQA/preprocess")
+log_dir = os.path.join(YOUR_DATA_DIR, "data/VQA/logs")
+analyze_dir = os.path.join(YOUR_DATA_DIR, "data/VQA/analyze")
+
+version = 2
+samplingans = False
+loss_metric = "KLD"
+vgenome = False
+version1_multiple_choices = False
+# Process_img
+arch = "rcnn"
+size = 224
+
+# Process_qa
+nans = 3000
+splitnum = 2
+mwc = 0
+mql = 26
+
+# Train
+target_list = ["v", "q_id", "q_idxes"]
+epochs = 100
+
+resume = True
+print_freq = 10
+lr = 0.0001
+load_mem = "DB"
+batch_size = 256
+clip_grad = True
+# if test_dev is None, skip
+test_dev_range = range(epochs, epochs + 5, 5)
+test_range = None
+debug = False
+
+method_name = os.path.splitext(os.path.basename(__file__))[0]
+if splitnum == 2:
+    method_name += "_VAL"
+log_dir = os.path.join(log_dir, method_name)
+analyze_dir = os.path.join(analyze_dir, method_name)

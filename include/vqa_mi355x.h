@@ -1,0 +1,153 @@
+/*
+ * vqa_mi355x.h -- C ABI of libvqa_mi355x.so: the MI355X (gfx950) kernels behind the CoR2 / ODA
+ * hot path of bupt-cist/vqa-playground-pytorch.
+ *
+ * The reference has no FFI: its boundary is the Python nn.Module surface of config/CoR2.py /
+ * config/ODA.py.  Each entry point below replaces one *sequence of ATen ops* in the
+ * reference, cited per function as file:line under /root/reference.  The Python host
+ * (vqa_playground_pytorch_amd/ops.py) binds these through ctypes from torch.autograd.Function
+ * forward/backward; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer to fp32 unless stated;
+ *     all tensors are row-major and dense unless a stride argument says otherwise;
+ *   - the CALLER allocates every buffer, including workspaces (sizes from the *_workspace_bytes
+ *     queries); the library never allocates, frees or synchronises, so every launcher can be
+ *     captured into a hipGraph;
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*);
+ *   - return value 0 = success, negative = error (VQA_E_*); the text of the last error of the
+ *     calling thread is available from vqa_last_error(); no C++ exception crosses the ABI;
+ *   - no global mutable state: re-entrant, safe to call from one host thread per device.
+ *
+ * Symbols: B samples, N regions per sample, D region feature width, G glimpses, L low dim,
+ * H hidden dim, R rank, M = B*N rows.
+ */
+#ifndef VQA_MI355X_H
+#define VQA_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQA_ABI_VERSION 1
+
+#define VQA_OK 0
+#define VQA_E_BADARG (-1)      /* null pointer, non-positive size, size over a documented limit */
+#define VQA_E_UNSUPPORTED (-2) /* alignment / shape the kernels do not cover */
+#define VQA_E_LAUNCH (-3)      /* HIP reported an error at launch */
+
+typedef void* vqa_stream_t; /* hipStream_t */
+
+int vqa_version(void);
+const char* vqa_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  pairwise relation build + alpha-weighted reduce.
+ * Replaces config/CoR2.py:191-199 (decare_cat: two .repeat() + two putils.bmul + add, a
+ * [B,N,N,D] tensor) and config/CoR2.py:216 ((alpha1[0].view(b,36,1,1) * v2_cat).sum(1)).
+ *
+ *   v2[b,j,:] = sum_i alpha[b,i] * ( v[b,i,:]*q1[b,:] + v[b,j,:]*q2[b,:] )
+ *
+ * v [B,N,D]; q1,q2 [B,D]; alpha: element (b,i) at alpha[(b*N+i)*alpha_stride] so glimpse 0 of a
+ * [B,N,G] attention tensor is passed without a copy (alpha_stride = G); v2 [B,N,D].
+ * mode 0 = pairwise: the N*N inner sum is evaluated term by term from the LDS-staged region tile
+ *          (the reference's summation structure);
+ * mode 1 = factored: q1*(sum_i alpha_i v_i) + (sum_i alpha_i)*q2*v_j -- the same value, one pass.
+ * Limits: D % 4 == 0, 16-byte aligned v/q1/q2/v2, N <= 160.
+ * ------------------------------------------------------------------------------------------- */
+int vqa_pairwise_relation_reduce_fwd(const float* v, const float* q1, const float* q2,
+                                     const float* alpha, int alpha_stride, float* v2,
+                                     int B, int N, int D, int mode, vqa_stream_t stream);
+
+/* Backward of K1.  g_v2 = dL/dv2 [B,N,D].  Outputs: d_alpha [B,N] dense, d_q1 [B,D], d_q2 [B,D],
+ * d_v [B,N,D] or NULL (v is a leaf in CoR2).  d_alpha is accumulated across the D-chunks of a
+ * sample with float atomics after being zeroed on `stream` by this call. */
+int vqa_pairwise_relation_reduce_bwd(const float* v, const float* q1, const float* q2,
+                                     const float* alpha, int alpha_stride, const float* g_v2,
+                                     float* d_alpha, float* d_q1, float* d_q2, float* d_v,
+                                     int B, int N, int D, vqa_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3  softmax over regions + attention-weighted region pooling.
+ * Replaces F.softmax(x, dim=1) inside MyConv1d (config/CoR2.py:83-87 as configured at :132) and
+ * putils.bmatmul(x_att.transpose(1,2), inputs) (config/CoR2.py:142; putils/__init__.py:89-95).
+ *
+ *   alpha[b,n,g] = softmax_n(logits[b,n,g]);   pooled[b,g,:] = sum_n alpha[b,n,g] * v[b,n,:]
+ *
+ * logits, alpha [B,N,G]; v [B,N,D]; pooled [B,G,D].  Limits: 1 <= G <= 8, N <= 1024, D % 4 == 0.
+ * ------------------------------------------------------------------------------------------- */
+int vqa_softmax_attention_pool_fwd(const float* logits, const float* v, float* alpha, float* pooled,
+                                   int B, int N, int D, int G, vqa_stream_t stream);
+
+/* Backward of K3.  d_pooled [B,G,D]; d_alpha_ext [B,N,G] or NULL = gradient that reaches alpha
+ * directly (CoR2 feeds alpha1[...,0] to K1); outputs d_logits [B,N,G], d_v [B,N,D] or NULL.
+ * Limit: G*D*4 + 4*N*G*4 bytes of LDS <= 160 KiB. */
+int vqa_softmax_attention_pool_bwd(const float* alpha, const float* v, const float* d_pooled,
+                                   const float* d_alpha_ext, float* d_logits, float* d_v,
+                                   int B, int N, int D, int G, vqa_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K4  low-rank bilinear (Mutan) fusion on the fp32 MFMA tile engine.
+ * Replaces putils.MutanFusion.forward (putils/__init__.py:232-238): R x { Linear(in1->H) on the
+ * region side, putils.bmul against the question-side factor, total += }.
+ *
+ *   h1[m,r,:] = x[m,:] W1_r^T + b1_r          (m = b*N + n)
+ *   out[m,:]  = sum_r h1[m,r,:] * h2[b,r,:]   (h2 = the question-side Linear2_r(x2), [B,R,H])
+ *
+ * x [M,L] with row stride ldx; w1[r] -> [H,L] dense (R host-side entries of device pointers, the
+ * reference keeps one nn.Linear per rank); b1[r] -> [H]; h2 [B,R,H]; out [M,H] dense;
+ * h1 [M,R,H] or NULL (saved for backward).  N = rows per sample (1 for 2-D inputs).
+ * Limits: R <= 8; L, H, ldx even; 8-byte aligned pointers.
+ * ------------------------------------------------------------------------------------------- */
+int vqa_lowrank_bilinear_fusion_fwd(const float* x, int ldx, const float* const* w1,
+                                    const float* const* b1, const float* h2, float* out, float* h1,
+                                    int B, int N, int L, int H, int R, vqa_stream_t stream);
+
+size_t vqa_lowrank_bilinear_fusion_bwd_workspace_bytes(int B, int N, int L, int H, int R);
+
+/* Backward of K4.  g = dL/dout [M,H]; h1 as saved by the forward.  Outputs: d_x [M,L] dense or
+ * NULL; d_w1[r] -> [H,L]; d_b1[r] -> [H]; d_h2 [B,R,H].  All outputs are overwritten (not
+ * accumulated).  workspace: vqa_lowrank_bilinear_fusion_bwd_workspace_bytes(...) bytes. */
+int vqa_lowrank_bilinear_fusion_bwd(const float* x, int ldx, const float* const* w1, const float* h2,
+                                    const float* h1, const float* g, float* d_x, float* const* d_w1,
+                                    float* const* d_b1, float* d_h2, void* workspace,
+                                    size_t workspace_bytes, int B, int N, int L, int H, int R,
+                                    vqa_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2  object-difference attention logits (ODA).
+ * Replaces the 36x36 python loop config/ODA.py:216-222 (vq[b,i,j*L+d] = (vl[b,i,d]-vl[b,j,d])*ql[b,d],
+ * a [B,N,N*L] tensor) and the dropout + 1x1 conv of MyConv1d on it (config/ODA.py:149, :89-105):
+ *
+ *   logits[b,i,g] = bias[g] + sum_{j,d} w[g,j*L+d] * keep(b,i,j*L+d) * (vl[b,i,d]-vl[b,j,d]) * ql[b,d]
+ *
+ * keep() = 1 when p_drop == 0, else 0 or 1/(1-p_drop) from a counter-based generator keyed by
+ * (seed, element index); vqa_object_difference_dropout_mask writes the same mask as fp32 [B,N,N*L]
+ * so a test can hand it to the oracle.  vl [B,N,L]; ql [B,L]; w [G,N*L]; bias [G]; logits [B,N,G].
+ * Limits: G <= 8, N <= 128, L <= 1024.
+ * ------------------------------------------------------------------------------------------- */
+int vqa_object_difference_attention_fwd(const float* vl, const float* ql, const float* w,
+                                        const float* bias, float* logits, float p_drop,
+                                        uint64_t seed, int B, int N, int L, int G,
+                                        vqa_stream_t stream);
+
+size_t vqa_object_difference_attention_bwd_workspace_bytes(int B, int N, int L, int G);
+
+/* Backward of K2: d_logits [B,N,G] -> d_vl [B,N,L], d_ql [B,L], d_w [G,N*L], d_bias [G]
+ * (all overwritten).  Same (p_drop, seed) as the forward regenerates the mask. */
+int vqa_object_difference_attention_bwd(const float* vl, const float* ql, const float* w,
+                                        const float* d_logits, float* d_vl, float* d_ql, float* d_w,
+                                        float* d_bias, void* workspace, size_t workspace_bytes,
+                                        float p_drop, uint64_t seed, int B, int N, int L, int G,
+                                        vqa_stream_t stream);
+
+int vqa_object_difference_dropout_mask(float* mask, float p_drop, uint64_t seed, int B, int N, int L,
+                                       vqa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQA_MI355X_H */

@@ -1,0 +1,277 @@
+"""GPU parity tests: every HIP kernel (through the C ABI, via ops.py) against the float64 numpy oracle
+(oracle/kernels_np.py) on the same seeded inputs.  Tolerance: 1e-3 relative fp32 is the north-star bar;
+these kernels are expected to sit near 1e-5, so the tests use RTOL below and print the achieved error.
+Run on the GPU box with:  python -m pytest tests -m gpu
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kernels_np as K
+from oracle import seeded
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-4  # well inside the 1e-3 north-star tolerance
+
+
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def g(a, requires_grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev())
+    return t.requires_grad_() if requires_grad else t
+
+
+def close(name, got, want, rtol=RTOL):
+    got = got.detach().cpu().numpy().astype(np.float64) if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    assert np.isfinite(got).all(), name + ": non-finite output"
+    scale = max(np.abs(want).max(), 1e-20)
+    err = np.abs(got - want).max() / scale
+    assert err <= rtol, "%s: rel err %.3e > %.1e" % (name, err, rtol)
+    return err
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from vqa_playground_pytorch_amd import ops as o
+    return o
+
+
+# ----------------------------------------------------------------------------------------------- K1
+@pytest.mark.parametrize("B,N,D,G,glimpse", [(3, 5, 12, 1, 0), (2, 36, 2048, 4, 0), (2, 7, 260, 3, 2),
+                                             (1, 1, 4, 1, 0), (2, 100, 512, 4, 0), (2, 37, 1024, 2, 1)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_pairwise_relation_fwd_bwd(ops, B, N, D, G, glimpse, mode):
+    v = seeded.seeded_array((B, N, D), 101)
+    q1 = 1 / (1 + np.exp(-seeded.seeded_array((B, D), 102)))
+    q2 = 1 / (1 + np.exp(-seeded.seeded_array((B, D), 103)))
+    al = np.abs(seeded.seeded_array((B, N, G), 104)) + 0.05          # deliberately not normalised
+    gout = seeded.seeded_array((B, N, D), 105)
+    vt, q1t, q2t, alt = g(v, True), g(q1, True), g(q2, True), g(al, True)
+    out = ops.pairwise_relation_reduce(vt, q1t, q2t, alt, glimpse=glimpse, mode=mode)
+    close("v2", out, K.pairwise_relation_reduce_fwd(v, q1, q2, al[:, :, glimpse]))
+    out.backward(g(gout))
+    da, dq1, dq2, dv = K.pairwise_relation_reduce_bwd(v, q1, q2, al[:, :, glimpse], gout)
+    da_full = np.zeros_like(al, dtype=np.float64)
+    da_full[:, :, glimpse] = da
+    close("d_alpha", alt.grad, da_full)
+    close("d_q1", q1t.grad, dq1)
+    close("d_q2", q2t.grad, dq2)
+    close("d_v", vt.grad, dv)
+
+
+def test_pairwise_relation_modes_agree_full_size(ops):
+    """BASELINE size (B=512, 36x2048): pairwise and factored evaluation agree, and the kernel is linear in alpha."""
+    B, N, D = 512, 36, 2048
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    v = torch.randn(B, N, D, generator=gen).to(dev())
+    q1 = torch.rand(B, D, generator=gen).to(dev())
+    q2 = torch.rand(B, D, generator=gen).to(dev())
+    al = torch.softmax(torch.randn(B, N, 4, generator=gen), dim=1).to(dev())
+    a = ops.pairwise_relation_reduce(v, q1, q2, al, 0, 0)
+    b = ops.pairwise_relation_reduce(v, q1, q2, al, 0, 1)
+    scale = a.abs().max().item()
+    assert (a - b).abs().max().item() <= 1e-5 * scale
+    c = ops.pairwise_relation_reduce(v, q1, q2, 2.0 * al, 0, 1)
+    assert (c - 2.0 * b).abs().max().item() <= 1e-5 * scale
+    # closed form with normalised alpha: q1 * pooled + q2 * v
+    pooled = torch.einsum("bn,bnd->bd", al[:, :, 0], v)
+    ref = q1[:, None, :] * pooled[:, None, :] + q2[:, None, :] * v
+    assert (b - ref).abs().max().item() <= 2e-5 * scale
+
+
+def test_pairwise_relation_rejects_bad_shapes(ops):
+    from vqa_playground_pytorch_amd import _lib
+    v = torch.zeros(2, 5, 10, device=dev())  # D % 4 != 0
+    with pytest.raises(_lib.VqaLibraryError):
+        ops.pairwise_relation_reduce(v, torch.zeros(2, 10, device=dev()), torch.zeros(2, 10, device=dev()),
+                                     torch.zeros(2, 5, 1, device=dev()))
+    with pytest.raises(ValueError):
+        ops.pairwise_relation_reduce(torch.zeros(2, 5, 8, device=dev()), torch.zeros(2, 8, device=dev()),
+                                     torch.zeros(2, 8, device=dev()), torch.zeros(2, 4, 1, device=dev()))
+
+
+# ----------------------------------------------------------------------------------------------- K3
+@pytest.mark.parametrize("B,N,D,G", [(3, 5, 12, 2), (4, 36, 2048, 4), (2, 100, 2048, 4), (2, 1, 8, 1),
+                                     (3, 70, 1028, 8), (2, 36, 4096, 3)])
+@pytest.mark.parametrize("with_ext,need_dv", [(True, True), (False, False)])
+def test_softmax_attention_pool(ops, B, N, D, G, with_ext, need_dv):
+    logits = 2.0 * seeded.seeded_array((B, N, G), 201)
+    v = seeded.seeded_array((B, N, D), 202)
+    gp = seeded.seeded_array((B, G, D), 203)
+    ga = seeded.seeded_array((B, N, G), 204)
+    lt, vt = g(logits, True), g(v, need_dv)
+    alpha, pooled = ops.softmax_attention_pool(lt, vt)
+    a_np, p_np = K.softmax_attention_pool_fwd(logits, v)
+    close("alpha", alpha, a_np)
+    close("pooled", pooled, p_np)
+    loss = (pooled * g(gp)).sum()
+    if with_ext:
+        loss = loss + (alpha * g(ga)).sum()
+    loss.backward()
+    dl, dv = K.softmax_attention_pool_bwd(a_np, v, gp, ga if with_ext else None)
+    close("d_logits", lt.grad, dl)
+    if need_dv:
+        close("d_v", vt.grad, dv)
+    else:
+        assert vt.grad is None
+
+
+def test_softmax_attention_pool_large_logits(ops):
+    """softmax must be max-shifted: logits around +/-80 would overflow a naive exp."""
+    B, N, D, G = 2, 36, 64, 4
+    logits = 80.0 * seeded.seeded_array((B, N, G), 211)
+    v = seeded.seeded_array((B, N, D), 212)
+    alpha, pooled = ops.softmax_attention_pool(g(logits), g(v))
+    a_np, p_np = K.softmax_attention_pool_fwd(logits, v)
+    close("alpha", alpha, a_np)
+    close("pooled", pooled, p_np)
+    assert abs(alpha.sum(dim=1).cpu().numpy() - 1.0).max() < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------- K4
+def _fusion_case(ops, B, N, L, H, R, seed, need_dx=True, two_d=False):
+    x = seeded.seeded_array((B, L) if two_d else (B, N, L), seed)
+    w1 = seeded.seeded_array((R, H, L), seed + 1, scale=1.0 / np.sqrt(L))
+    b1 = seeded.seeded_array((R, H), seed + 2, scale=0.1)
+    h2 = seeded.seeded_array((B, R, H), seed + 3)
+    go = seeded.seeded_array((B, H) if two_d else (B, N, H), seed + 4)
+    xt, h2t = g(x, need_dx), g(h2, True)
+    ws = [g(w1[r], True) for r in range(R)]
+    bs = [g(b1[r], True) for r in range(R)]
+    out = ops.lowrank_bilinear_fusion(xt, h2t, ws, bs)
+    x3 = x.reshape(B, N, L)
+    out_np, _ = K.lowrank_bilinear_fusion_fwd(x3, w1, b1, h2)
+    close("out", out.reshape(B, N, H), out_np)
+    out.backward(g(go))
+    dx, dw1, db1, dh2 = K.lowrank_bilinear_fusion_bwd(x3, w1, b1, h2, go.reshape(B, N, H))
+    if need_dx:
+        close("d_x", xt.grad.reshape(B, N, L), dx)
+    close("d_h2", h2t.grad, dh2)
+    for r in range(R):
+        close("d_w1[%d]" % r, ws[r].grad, dw1[r])
+        close("d_b1[%d]" % r, bs[r].grad, db1[r])
+
+
+@pytest.mark.parametrize("B,N,L,H,R", [(3, 5, 8, 16, 2), (4, 36, 310, 510, 2), (2, 100, 310, 510, 2),
+                                       (5, 7, 34, 66, 3), (1, 1, 2, 2, 1), (9, 36, 310, 510, 2)])
+def test_lowrank_bilinear_fusion(ops, B, N, L, H, R):
+    _fusion_case(ops, B, N, L, H, R, 300)
+
+
+@pytest.mark.parametrize("B,L,H,R", [(7, 1240, 510, 2), (5, 620, 510, 5), (64, 1240, 510, 2)])
+def test_lowrank_bilinear_fusion_2d(ops, B, L, H, R):
+    _fusion_case(ops, B, 1, L, H, R, 320, two_d=True)
+
+
+@pytest.mark.parametrize("tile", ["128x128", "64x128", "128x64", "64x64"])
+def test_lowrank_bilinear_fusion_every_tile_shape(ops, tile, monkeypatch):
+    monkeypatch.setenv("VQA_GEMM_TILE", tile)
+    _fusion_case(ops, 6, 36, 310, 510, 2, 340)
+    _fusion_case(ops, 3, 50, 70, 130, 2, 350, need_dx=False)
+
+
+def test_lowrank_bilinear_fusion_golden(ops, golden_dir):
+    """Against the reference's own MutanFusion output (tests/golden/blocks.npz, mutan3d)."""
+    blocks = np.load(os.path.join(golden_dir, "blocks.npz"))
+    from vqa_playground_pytorch_amd.layers import MutanFusion
+    mf = seeded.load_state(MutanFusion(8, 6, 16, 2), 21).to(dev())
+    y1, y2 = g(seeded.seeded_array((3, 5, 8), 22), True), g(seeded.seeded_array((3, 6), 23), True)
+    o = mf(y1, y2)
+    (o * g(seeded.seeded_array((3, 5, 16), 24))).sum().backward()
+    close("out", o, blocks["mutan3d.out"])
+    close("dx1", y1.grad, blocks["mutan3d.dx1"])
+    close("dx2", y2.grad, blocks["mutan3d.dx2"])
+    for name, p in mf.named_parameters():
+        close(name, p.grad, blocks["mutan3d.g." + name + ".full"])
+    mf2 = seeded.load_state(MutanFusion(8, 6, 16, 3), 25).to(dev())
+    z1, z2 = g(seeded.seeded_array((3, 8), 26), True), g(seeded.seeded_array((3, 6), 27), True)
+    o2 = mf2(z1, z2)
+    (o2 * g(seeded.seeded_array((3, 16), 28))).sum().backward()
+    close("out2d", o2, blocks["mutan2d.out"])
+    close("dx1_2d", z1.grad, blocks["mutan2d.dx1"])
+    close("dx2_2d", z2.grad, blocks["mutan2d.dx2"])
+    for name, p in mf2.named_parameters():
+        close(name, p.grad, blocks["mutan2d.g." + name + ".full"])
+
+
+def test_lowrank_bilinear_fusion_full_size_properties(ops):
+    """B=512 (M=18432): rank-sum linearity in h2 and agreement with a torch fp32 matmul restatement on GPU."""
+    B, N, L, H, R = 512, 36, 310, 510, 2
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.randn(B, N, L, generator=gen).to(dev())
+    h2 = torch.randn(B, R, H, generator=gen).to(dev())
+    ws = [(torch.randn(H, L, generator=gen) / L ** 0.5).to(dev()) for _ in range(R)]
+    bs = [(0.1 * torch.randn(H, generator=gen)).to(dev()) for _ in range(R)]
+    out = ops.lowrank_bilinear_fusion(x, h2, ws, bs)
+    ref = sum((x.double() @ ws[r].double().t() + bs[r].double()) * h2[:, r, None, :].double() for r in range(R))
+    scale = ref.abs().max().item()
+    assert (out.double() - ref).abs().max().item() <= 2e-5 * scale
+    out2 = ops.lowrank_bilinear_fusion(x, 3.0 * h2, ws, bs)
+    assert (out2 - 3.0 * out).abs().max().item() <= 1e-5 * scale * 3
+
+
+# ----------------------------------------------------------------------------------------------- K2
+@pytest.mark.parametrize("B,N,L,G", [(2, 4, 6, 3), (3, 36, 310, 4), (2, 13, 70, 2), (1, 1, 5, 1), (2, 37, 100, 8)])
+def test_object_difference_no_dropout(ops, B, N, L, G):
+    vl = np.abs(seeded.seeded_array((B, N, L), 401))
+    ql = np.abs(seeded.seeded_array((B, L), 402))
+    w = seeded.seeded_array((G, N * L), 403, scale=1.0 / np.sqrt(N * L))
+    bias = seeded.seeded_array((G,), 404, scale=0.1)
+    gl = seeded.seeded_array((B, N, G), 405)
+    vt, qt, wt, bt = g(vl, True), g(ql, True), g(w, True), g(bias, True)
+    logits = ops.object_difference_attention(vt, qt, wt, bt, 0.0, 0)
+    close("logits", logits, K.object_difference_logits_fwd(vl, ql, w, bias))
+    logits.backward(g(gl))
+    dvl, dql, dw, db = K.object_difference_logits_bwd(vl, ql, w, gl)
+    close("d_vl", vt.grad, dvl)
+    close("d_ql", qt.grad, dql)
+    close("d_w", wt.grad, dw)
+    close("d_bias", bt.grad, db)
+
+
+@pytest.mark.parametrize("B,N,L,G,p", [(3, 36, 310, 4, 0.5), (2, 13, 70, 2, 0.25), (130, 5, 64, 4, 0.5)])
+def test_object_difference_with_dropout(ops, B, N, L, G, p):
+    """The fused kernels regenerate the mask from (seed, index); export it and hand it to the oracle."""
+    seed = 1234567
+    vl = np.abs(seeded.seeded_array((B, N, L), 411))
+    ql = np.abs(seeded.seeded_array((B, L), 412))
+    w = seeded.seeded_array((G, N * L), 413, scale=1.0 / np.sqrt(N * L))
+    bias = seeded.seeded_array((G,), 414, scale=0.1)
+    gl = seeded.seeded_array((B, N, G), 415)
+    mask = ops.object_difference_dropout_mask(B, N, L, p, seed, dev()).cpu().numpy()
+    keep = (mask > 0).mean()
+    assert set(np.unique(mask)).issubset({0.0, np.float32(1.0 / (1.0 - p))})
+    assert abs(keep - (1.0 - p)) < 0.01, keep
+    vt, qt, wt, bt = g(vl, True), g(ql, True), g(w, True), g(bias, True)
+    logits = ops.object_difference_attention(vt, qt, wt, bt, p, seed)
+    close("logits", logits, K.object_difference_logits_fwd(vl, ql, w, bias, mask))
+    logits.backward(g(gl))
+    dvl, dql, dw, db = K.object_difference_logits_bwd(vl, ql, w, gl, mask)
+    close("d_vl", vt.grad, dvl)
+    close("d_ql", qt.grad, dql)
+    close("d_w", wt.grad, dw)
+    close("d_bias", bt.grad, db)
+    other = ops.object_difference_dropout_mask(B, N, L, p, seed + 1, dev()).cpu().numpy()
+    assert 0.4 < (other == mask).mean() < 0.6 + abs(0.5 - p), "a different seed must give a different mask"
+
+
+def test_object_difference_mask_is_unbiased(ops):
+    """Statistics of the counter-hash mask at the ODA shape: per-region, per-feature and per-pair keep rates."""
+    B, N, L, p = 8, 36, 310, 0.5
+    m = (ops.object_difference_dropout_mask(B, N, L, p, 99, dev()) > 0).float().view(B, N, N, L)
+    assert abs(m.mean().item() - 0.5) < 2e-3
+    for dims in [(0, 2, 3), (0, 1, 3), (0, 1, 2), (1, 2, 3)]:
+        r = m.mean(dim=dims)
+        assert (r - 0.5).abs().max().item() < 0.02, dims
+    # neighbouring regions share a hash word (one byte each): they must still be uncorrelated
+    a, b2 = m[:, 0::4].flatten(), m[:, 1::4].flatten()
+    corr = ((a - a.mean()) * (b2 - b2.mean())).mean() / (a.std() * b2.std())
+    assert abs(corr.item()) < 5e-3

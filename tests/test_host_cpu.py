@@ -1,0 +1,110 @@
+"""CPU-side checks of the product package: the C-ABI library loads and exports every symbol the
+header declares, the nn.Module surface matches the reference's (names, shapes, errors), and the
+product path refuses to run without a GPU instead of falling back."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import vqa_playground_pytorch_amd as pkg
+from vqa_playground_pytorch_amd import _lib, layers, ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_header_symbols():
+    handle = _lib.lib()
+    assert handle.vqa_version() == _lib.ABI_VERSION
+    header = open(os.path.join(ROOT, "include", "vqa_mi355x.h")).read()
+    declared = set(re.findall(r"\b(vqa_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(handle, name), name
+
+
+def test_workspace_queries_need_no_gpu():
+    handle = _lib.lib()
+    n = handle.vqa_lowrank_bilinear_fusion_bwd_workspace_bytes(512, 36, 310, 510, 2)
+    assert n >= 512 * 510 * 4 + 2 * 510 * 310 * 4
+    assert handle.vqa_lowrank_bilinear_fusion_bwd_workspace_bytes(0, 36, 310, 510, 2) == 0
+    assert handle.vqa_object_difference_attention_bwd_workspace_bytes(512, 36, 310, 4) == 128 * 4 * 36 * 310 * 4
+
+
+def test_bad_arguments_return_error_codes_without_gpu():
+    handle = _lib.lib()
+    rc = handle.vqa_pairwise_relation_reduce_fwd(None, None, None, None, 1, None, 1, 1, 4, 1, None)
+    assert rc == -1 and b"null pointer" in handle.vqa_last_error()
+    rc = handle.vqa_softmax_attention_pool_fwd(None, None, None, None, 1, 1, 4, 1, None)
+    assert rc == -1
+
+
+def _names(golden_dir, fname):
+    gold = np.load(os.path.join(golden_dir, fname))
+    return sorted(k[2:-5] for k in gold.files if k.startswith("g.") and k.endswith(".norm"))
+
+
+@pytest.mark.parametrize("cls,fname,nans,count", [(pkg.CoR2Model, "cor2_b4.npz", 2000, 11940244),
+                                                  (pkg.ODAModel, "oda_b4.npz", 3000, 7348434)])
+def test_state_dict_abi_matches_reference(cls, fname, nans, count, golden_dir):
+    model = cls(["PAD", "UNK"], nans)
+    assert sorted(n for n, _ in model.named_parameters()) == _names(golden_dir, fname)
+    assert sum(p.numel() for p in model.parameters()) == count
+    sd = model.state_dict()
+    assert sd["compress_v.conv.weight"].shape == (310, 2048, 1)
+    if cls is pkg.ODAModel:
+        assert sd["att.conv_att.conv.weight"].shape == (4, 11160, 1)
+    else:
+        assert sd["att1.conv_att.conv.weight"].shape == (4, 510, 1)
+        assert sd["fusion_final.list_linear1.1.linear.weight"].shape == (510, 1240)
+
+
+def test_reference_error_conventions():
+    with pytest.raises(ValueError):
+        layers.Linear(16, 7)(torch.zeros(2, 15))
+    with pytest.raises(ValueError):
+        layers.MyLinear(16, 7)(torch.zeros(2, 15))
+    with pytest.raises(ValueError):
+        layers.MyConv1d(16, 7, 1, 1)(torch.zeros(2, 16))
+    with pytest.raises(AssertionError):
+        layers.MyATT(16, 3, 12, 8)
+    with pytest.raises(ValueError):
+        layers.MutanFusion(8, 6, 16, 2)(torch.zeros(3, 5, 7), torch.zeros(3, 6))
+    with pytest.raises(ValueError):
+        layers.QuestionVectorInput(2400)(torch.zeros(2, 26, dtype=torch.long))
+
+
+def test_bmul_bmatmul_match_reference_golden(golden_dir):
+    from oracle import seeded
+    blocks = np.load(os.path.join(golden_dir, "blocks.npz"))
+    t = torch.from_numpy
+    np.testing.assert_allclose(layers.bmul(t(seeded.seeded_array((3, 5, 8), 11)), t(seeded.seeded_array((3, 8), 12))).numpy(),
+                               blocks["bmul.out"], rtol=1e-6)
+    np.testing.assert_allclose(layers.bmul(t(seeded.seeded_array((3, 5, 5, 8), 13)), t(seeded.seeded_array((3, 8), 12))).numpy(),
+                               blocks["bmul4.out"], rtol=1e-6)
+    np.testing.assert_allclose(layers.bmatmul(t(seeded.seeded_array((3, 2, 5), 14)), t(seeded.seeded_array((3, 5, 12), 15))).numpy(),
+                               blocks["bmatmul.out"], rtol=1e-5, atol=1e-6)
+
+
+def test_no_cpu_fallback():
+    """The HIP path must fail loudly on CPU tensors (no eager fallback)."""
+    with pytest.raises(_lib.VqaLibraryError):
+        ops.softmax_attention_pool(torch.zeros(2, 5, 4), torch.zeros(2, 5, 8))
+    with pytest.raises(_lib.VqaLibraryError):
+        ops.pairwise_relation_reduce(torch.zeros(2, 5, 8), torch.zeros(2, 8), torch.zeros(2, 8), torch.zeros(2, 5, 4))
+    model = pkg.CoR2Model(["PAD"], 10)
+    with pytest.raises(_lib.VqaLibraryError):
+        model({"v": torch.zeros(2, 36, 2048), "q_idxes": torch.zeros(2, 2400)})
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "vqa_playground_pytorch_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), os.path.join(dirpath, f)
+    for f in ["config/CoR2.py", "config/ODA.py"]:
+        path = os.path.join(ROOT, f)
+        if os.path.exists(path):
+            assert not re.search(r"^\s*(from|import)\s+oracle", open(path).read(), re.M)

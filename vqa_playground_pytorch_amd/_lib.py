@@ -1,0 +1,84 @@
+"""ctypes binding of libvqa_mi355x.so (C ABI: include/vqa_mi355x.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent,
+``lib()`` raises.  Build it with ``python __graft_entry__.py build`` (hipcc, gfx950).
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvqa_mi355x.so")
+ABI_VERSION = 1
+
+_c_f = ctypes.c_void_p          # device pointer to fp32
+_c_pp = ctypes.c_void_p         # host array of device pointers
+_c_i = ctypes.c_int
+_c_sz = ctypes.c_size_t
+_c_u64 = ctypes.c_uint64
+_c_fl = ctypes.c_float
+_c_st = ctypes.c_void_p         # hipStream_t
+
+# name -> (restype, argtypes); every symbol include/vqa_mi355x.h declares
+SIGNATURES = {
+    "vqa_version": (_c_i, []),
+    "vqa_last_error": (ctypes.c_char_p, []),
+    "vqa_pairwise_relation_reduce_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_pairwise_relation_reduce_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f,
+                                                _c_i, _c_i, _c_i, _c_st]),
+    "vqa_softmax_attention_pool_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_softmax_attention_pool_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_lowrank_bilinear_fusion_fwd": (_c_i, [_c_f, _c_i, _c_pp, _c_pp, _c_f, _c_f, _c_f,
+                                               _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_lowrank_bilinear_fusion_bwd_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i, _c_i, _c_i]),
+    "vqa_lowrank_bilinear_fusion_bwd": (_c_i, [_c_f, _c_i, _c_pp, _c_f, _c_f, _c_f, _c_f, _c_pp, _c_pp, _c_f,
+                                               _c_f, _c_sz, _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_object_difference_attention_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_fl, _c_u64,
+                                                   _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_object_difference_attention_bwd_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i, _c_i]),
+    "vqa_object_difference_attention_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz,
+                                                   _c_fl, _c_u64, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_object_difference_dropout_mask": (_c_i, [_c_f, _c_fl, _c_u64, _c_i, _c_i, _c_i, _c_st]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class VqaLibraryError(RuntimeError):
+    """libvqa_mi355x.so is missing, stale, or returned an error code."""
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises VqaLibraryError -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise VqaLibraryError(
+                "HIP extension %s not found: build it with `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU or PyTorch fallback for this path." % LIB_PATH)
+        try:
+            handle = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover - depends on the host's ROCm install
+            raise VqaLibraryError("cannot load %s: %s" % (LIB_PATH, e)) from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise VqaLibraryError("%s does not export %s (stale build?)" % (LIB_PATH, name)) from e
+            fn.restype = res
+            fn.argtypes = args
+        if handle.vqa_version() != ABI_VERSION:
+            raise VqaLibraryError("ABI version mismatch: library %d, binding %d" % (handle.vqa_version(), ABI_VERSION))
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().vqa_last_error()
+        raise VqaLibraryError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))

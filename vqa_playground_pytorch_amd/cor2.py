@@ -1,0 +1,72 @@
+"""CoR2 ("Chain of Reasoning") head on the MI355X kernels -- drop-in for config/CoR2.py:160-237.
+
+Same constructor, ``forward(sample) -> logits [B,num_ans]``, ``alpha_dict`` side output and
+state_dict names as the reference ``Model``; the region count is read from the input instead of
+being the literal 36, and per-replica batch 1 works (the reference raises IndexError there).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .layers import MutanFusion, MyATT, MyConv1d, MyLinear, QuestionVectorInput
+
+
+class Model(nn.Module):
+    def __init__(self, vocab_words=None, num_ans=None, seq2vec=None, relation_mode=1):
+        super().__init__()
+        self.vocab_words = vocab_words
+        self.num_classes = num_ans
+        # 0 = pairwise (every (i,j) term summed from the LDS tile), 1 = factored (same value, one pass)
+        self.relation_mode = relation_mode
+
+        self.seq2vec = seq2vec if seq2vec is not None else QuestionVectorInput(2400)
+        self.compress_v = MyConv1d(2048, 310, 1, 1, p=0.5, af="relu")
+        self.compress_v2 = MyConv1d(2048, 310, 1, 1, p=0.5, af="relu")
+        self.compress_q = MyLinear(2400, 310, p=0.5, af="relu")
+
+        self.fusion_vq1 = MutanFusion(310, 310, 510, 2)
+        self.att1 = MyATT(fuse_dim=510, glimpses=4, inputs_dim=2048, att_dim=620, af="relu")
+
+        self.fusion_vq2 = MutanFusion(310, 310, 510, 2)
+        self.att2 = MyATT(fuse_dim=510, glimpses=4, inputs_dim=2048, att_dim=620, af="relu")
+
+        self.linear_q = MyLinear(2400, 310, p=0.5, af="relu")
+        self.fusion_final = MutanFusion(1240, 310, 510, 2)
+        self.linear_classif = MyLinear(510, self.num_classes, p=0.5)
+
+        self.compress_q_1 = MyLinear(2400, 310, p=0.5, af="relu")
+        self.expand_q_1 = MyLinear(310, 2048, p=0.5, af="sigmoid")
+        self.compress_q_2 = MyLinear(2400, 310, p=0.5, af="relu")
+        self.expand_q_2 = MyLinear(310, 2048, p=0.5, af="sigmoid")
+        self.alpha_dict = {}
+
+    def relation_reduce(self, v_feature, guidance, alpha):
+        """config/CoR2.py:191-199 (decare_cat) + :216 fused: v2[b,j] = sum_i alpha[b,i,0] *
+        (v[b,i]*q1[b] + v[b,j]*q2[b]); the [B,N,N,D] tensor is never built (HIP kernel K1)."""
+        q_feature_1 = self.expand_q_1(self.compress_q_1(guidance))
+        q_feature_2 = self.expand_q_2(self.compress_q_2(guidance))
+        return ops.pairwise_relation_reduce(v_feature, q_feature_1, q_feature_2, alpha, glimpse=0,
+                                            mode=self.relation_mode)
+
+    def forward(self, sample):
+        v = sample["v"]
+        b = v.size(0)
+        v_feature = v.contiguous().view(b, -1, 2048)
+        q_feature = self.seq2vec(sample["q_idxes"] if "q_idxes" in sample else sample["q"])
+
+        q_feature_low = self.compress_q(q_feature)
+        v_feature_low = self.compress_v(v_feature)
+        fuse1 = self.fusion_vq1(v_feature_low, q_feature_low)
+        v1_att, alpha1, alpha1_full = self.att1.attend(v_feature, self.att1.conv_att.pre_activation(fuse1))
+
+        v2_feature = self.relation_reduce(v_feature, q_feature, alpha1_full)          # only glimpse 0 weights it
+        v2_feature_low = self.compress_v2(v2_feature)
+        fuse2 = self.fusion_vq2(v2_feature_low, q_feature_low)
+        v2_att, alpha2, _ = self.att2.attend(v2_feature, self.att2.conv_att.pre_activation(fuse2))
+
+        self.alpha_dict = {"alpha1": alpha1, "alpha2": alpha2, "feature": v2_feature[:, [0, 1], :]}
+
+        v_f = torch.cat([v1_att, v2_att], dim=1)
+        q_final = self.linear_q(q_feature)
+        x = self.fusion_final(v_f, q_final)
+        return self.linear_classif(x)

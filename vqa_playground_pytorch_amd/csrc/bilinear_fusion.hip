@@ -1,0 +1,402 @@
+// K4 -- low-rank bilinear (Mutan) fusion on the fp32 MFMA tile engine.
+//
+// Replaces putils.MutanFusion.forward (putils/__init__.py:232-238): per rank r a Linear(in1->H) on the
+// region side, a Linear(in2->H) on the question side, putils.bmul (python loop over B + stack) and
+// `total +=`.  The region-side contraction is dense (M = B*N rows, K = L, N = R*H) and is the one
+// MFMA-bound kernel of the path; the question-side multiply and the sum over ranks are its epilogue,
+// so the [M,R,H] intermediate is written at most once (only when backward needs it) and never re-read
+// in forward.
+//
+//   forward : out[m,:] = sum_r (x[m,:] W1_r^T + b1_r) * h2[b(m),r,:]              2*M*L*H*R FLOP
+//   backward: dx  = sum_r (g * h2_r) W1_r                                          2*M*H*L*R FLOP
+//             dW1_r = (g * h2_r)^T x     (split over M, slabs reduced in fixed order) 2*M*H*L*R FLOP
+//             dh2[b,r,:] = sum_n g[b,n,:] * h1[b,n,r,:] ;  db1_r = sum_b h2[b,r,:] * sum_n g[b,n,:]
+// (g * h2_r) is never materialised: it is formed while the A tile is staged.
+#include <cstdlib>
+
+#include "gemm_f32_mfma.hpp"
+
+namespace vqa {
+
+constexpr int kMaxR = 8;
+
+struct RankPtrs {
+  const float* w[kMaxR];
+  const float* b[kMaxR];
+};
+struct RankOutPtrs {
+  float* w[kMaxR];
+  float* b[kMaxR];
+};
+
+// ------------------------------------------------------------------------------------------ forward
+template <int BM, int BN>
+__global__ __launch_bounds__(kGemmThreads) void bilinear_fwd_kernel(const float* __restrict__ x, int ldx, RankPtrs rp,
+                                                                    const float* __restrict__ h2,
+                                                                    float* __restrict__ out, float* __restrict__ h1,
+                                                                    int M, int N, int L, int H, int R, int tiles_n) {
+  using T = GemmTile<BM, BN, true, true>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* smem = reinterpret_cast<float*>(smem_raw);
+  int* rowb_s = reinterpret_cast<int*>(smem + 2 * T::kStageFloats);  // [BM] sample index of each tile row
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+  for (int t = threadIdx.x; t < BM; t += kGemmThreads) rowb_s[t] = min(m0 + t, M - 1) / N;
+  // (visible after the first barrier inside gemm_tile)
+  const AccCoord<BM, BN> cc(m0, n0);
+  f32x16 total[T::TM][T::TN];
+  zero_acc(total);
+  for (int r = 0; r < R; ++r) {
+    f32x16 acc[T::TM][T::TN];
+    zero_acc(acc);
+    const SrcKC sa{x, ldx, M, L};
+    const SrcKC sb{rp.w[r], L, H, L};
+    gemm_tile<BM, BN, true, true>(sa, sb, m0, n0, 0, L, smem, acc);
+    const float* __restrict__ bias = rp.b[r];
+#pragma unroll
+    for (int tn = 0; tn < T::TN; ++tn) {
+      const int col = cc.col(tn);
+      if (col < H) {
+        const float bv = bias[col];
+#pragma unroll
+        for (int tm = 0; tm < T::TM; ++tm) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = cc.row(tm, i);
+            if (row < M) {
+              const float hv = acc[tm][tn][i] + bv;
+              const int b = rowb_s[row - m0];
+              if (h1 != nullptr) h1[((size_t)row * R + r) * H + col] = hv;
+              total[tm][tn][i] = fmaf(hv, h2[((size_t)b * R + r) * H + col], total[tm][tn][i]);
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int tn = 0; tn < T::TN; ++tn) {
+    const int col = cc.col(tn);
+    if (col < H) {
+#pragma unroll
+      for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = cc.row(tm, i);
+          if (row < M) out[(size_t)row * H + col] = total[tm][tn][i];
+        }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------- backward sources
+// A[m][k=h] = g[m][h] * h2[b(m)][r][h]   (K-contiguous; the scale is applied while staging)
+struct SrcScaledKC {
+  const float* g;
+  const float* h2r;  // h2 + r*H
+  int M, H, N, RH;
+  __device__ __forceinline__ float2 operator()(int m, int h) const {
+    if (m < M && h < H) {
+      const float2 a = ld2(g + (size_t)m * H + h);
+      const float2 s = ld2(h2r + (size_t)(m / N) * RH + h);
+      return make_float2(a.x * s.x, a.y * s.y);
+    }
+    return make_float2(0.f, 0.f);
+  }
+};
+// A[k=m][mn=h] = g[m][h] * h2[b(m)][r][h]   (MN-contiguous view of the same matrix, rows m in [m_lo, m_hi))
+struct SrcScaledMC {
+  const float* g;
+  const float* h2r;
+  int m_hi, H, N, RH;
+  __device__ __forceinline__ float2 operator()(int h, int m) const {
+    if (m < m_hi && h < H) {
+      const float2 a = ld2(g + (size_t)m * H + h);
+      const float2 s = ld2(h2r + (size_t)(m / N) * RH + h);
+      return make_float2(a.x * s.x, a.y * s.y);
+    }
+    return make_float2(0.f, 0.f);
+  }
+};
+
+// dx[m][l] = sum_r sum_h (g*h2_r)[m][h] * W1_r[h][l]
+template <int BM, int BN>
+__global__ __launch_bounds__(kGemmThreads) void bilinear_dx_kernel(const float* __restrict__ g, RankPtrs rp,
+                                                                   const float* __restrict__ h2, float* __restrict__ dx,
+                                                                   int M, int N, int L, int H, int R, int tiles_n) {
+  using T = GemmTile<BM, BN, true, false>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* smem = reinterpret_cast<float*>(smem_raw);
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+  f32x16 acc[T::TM][T::TN];
+  zero_acc(acc);
+  for (int r = 0; r < R; ++r) {
+    const SrcScaledKC sa{g, h2 + (size_t)r * H, M, H, N, R * H};
+    const SrcMC sb{rp.w[r], L, L, H};
+    gemm_tile<BM, BN, true, false>(sa, sb, m0, n0, 0, H, smem, acc);
+  }
+  const AccCoord<BM, BN> cc(m0, n0);
+#pragma unroll
+  for (int tn = 0; tn < T::TN; ++tn) {
+    const int col = cc.col(tn);
+    if (col < L) {
+#pragma unroll
+      for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = cc.row(tm, i);
+          if (row < M) dx[(size_t)row * L + col] = acc[tm][tn][i];
+        }
+    }
+  }
+}
+
+// slab[s][r][h][l] = sum_{m in split s} (g*h2_r)[m][h] * x[m][l]
+template <int BM, int BN>
+__global__ __launch_bounds__(kGemmThreads) void bilinear_dw_kernel(const float* __restrict__ g,
+                                                                   const float* __restrict__ h2,
+                                                                   const float* __restrict__ x, int ldx,
+                                                                   float* __restrict__ slab, int M, int N, int L, int H,
+                                                                   int R, int tiles_n, int rows_per_split) {
+  using T = GemmTile<BM, BN, false, false>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* smem = reinterpret_cast<float*>(smem_raw);
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int h0 = (bid / tiles_n) * BM, l0 = (bid % tiles_n) * BN;
+  const int r = blockIdx.y, s = blockIdx.z;
+  const int m_lo = s * rows_per_split, m_hi = min(M, m_lo + rows_per_split);
+  f32x16 acc[T::TM][T::TN];
+  zero_acc(acc);
+  const SrcScaledMC sa{g, h2 + (size_t)r * H, m_hi, H, N, R * H};
+  const SrcMC sb{x, ldx, L, m_hi};
+  gemm_tile<BM, BN, false, false>(sa, sb, h0, l0, m_lo, m_hi, smem, acc);
+  float* __restrict__ dst = slab + ((size_t)s * R + r) * H * L;
+  const AccCoord<BM, BN> cc(h0, l0);
+#pragma unroll
+  for (int tn = 0; tn < T::TN; ++tn) {
+    const int col = cc.col(tn);
+    if (col < L) {
+#pragma unroll
+      for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = cc.row(tm, i);
+          if (row < H) dst[(size_t)row * L + col] = acc[tm][tn][i];
+        }
+    }
+  }
+}
+
+// d_w1[r][h][l] = sum_s slab[s][r][h][l]   (fixed order: bitwise reproducible)
+__global__ __launch_bounds__(256) void bilinear_dw_reduce_kernel(const float* __restrict__ slab, RankOutPtrs out, int HL,
+                                                                 int R, int S) {
+  const int r = blockIdx.y;
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (e >= HL) return;
+  float2 a = make_float2(0.f, 0.f);
+  for (int s = 0; s < S; ++s) {
+    const float2 t = ld2(slab + ((size_t)s * R + r) * HL + e);
+    a.x += t.x;
+    a.y += t.y;
+  }
+  st2(out.w[r] + e, a);
+}
+
+// dh2[b][r][h] = sum_n g[b,n,h] * h1[b,n,r,h];  gs[b][h] = sum_n g[b,n,h]
+__global__ __launch_bounds__(128) void bilinear_dh2_kernel(const float* __restrict__ g, const float* __restrict__ h1,
+                                                           float* __restrict__ dh2, float* __restrict__ gs, int N, int H,
+                                                           int R) {
+  const int b = blockIdx.y;
+  const int h = (blockIdx.x * 128 + threadIdx.x) * 2;
+  if (h >= H) return;
+  float2 acc[kMaxR];
+#pragma unroll
+  for (int r = 0; r < kMaxR; ++r) acc[r] = make_float2(0.f, 0.f);
+  float2 gsum = make_float2(0.f, 0.f);
+  const float* gb = g + (size_t)b * N * H + h;
+  const float* hb = h1 + (size_t)b * N * R * H + h;
+#pragma unroll 4
+  for (int n = 0; n < N; ++n) {
+    const float2 gv = ld2(gb + (size_t)n * H);
+    gsum.x += gv.x;
+    gsum.y += gv.y;
+#pragma unroll
+    for (int r = 0; r < kMaxR; ++r) {
+      if (r < R) {
+        const float2 hv = ld2(hb + ((size_t)n * R + r) * H);
+        acc[r].x = fmaf(gv.x, hv.x, acc[r].x);
+        acc[r].y = fmaf(gv.y, hv.y, acc[r].y);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kMaxR; ++r)
+    if (r < R) st2(dh2 + ((size_t)b * R + r) * H + h, acc[r]);
+  st2(gs + (size_t)b * H + h, gsum);
+}
+
+// db1[r][h] = sum_b h2[b][r][h] * gs[b][h]
+__global__ __launch_bounds__(128) void bilinear_db_kernel(const float* __restrict__ h2, const float* __restrict__ gs,
+                                                          RankOutPtrs out, int B, int H, int R) {
+  const int r = blockIdx.y;
+  const int h = (blockIdx.x * 128 + threadIdx.x) * 2;
+  if (h >= H) return;
+  float2 a = make_float2(0.f, 0.f);
+#pragma unroll 4
+  for (int b = 0; b < B; ++b) {
+    const float2 s = ld2(h2 + ((size_t)b * R + r) * H + h);
+    const float2 t = ld2(gs + (size_t)b * H + h);
+    a.x = fmaf(s.x, t.x, a.x);
+    a.y = fmaf(s.y, t.y, a.y);
+  }
+  st2(out.b[r] + h, a);
+}
+
+static TileChoice tile_override_or(TileChoice c) {
+  const char* e = std::getenv("VQA_GEMM_TILE");  // experiment knob, e.g. "128x64"
+  if (e != nullptr) {
+    int bm = 0, bn = 0;
+    if (std::sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) return {bm, bn};
+  }
+  return c;
+}
+
+static int splits_for_dw(int M, int H, int L, int R, TileChoice t) {
+  const long tiles = (long)((H + t.bm - 1) / t.bm) * ((L + t.bn - 1) / t.bn) * R;
+  long s = (768 + tiles - 1) / tiles;
+  const long max_by_rows = (M + 255) / 256;  // keep >= 256 rows (16 stages) per split
+  if (s > max_by_rows) s = max_by_rows;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+static TileChoice dw_tile() { return tile_override_or({128, 64}); }
+
+}  // namespace vqa
+
+using namespace vqa;
+
+#define VQA_TILE_SWITCH(t, LAUNCH)                 \
+  do {                                             \
+    if ((t).bm == 128 && (t).bn == 128) {          \
+      LAUNCH(128, 128)                             \
+    } else if ((t).bm == 64 && (t).bn == 128) {    \
+      LAUNCH(64, 128)                              \
+    } else if ((t).bm == 128 && (t).bn == 64) {    \
+      LAUNCH(128, 64)                              \
+    } else {                                       \
+      LAUNCH(64, 64)                               \
+    }                                              \
+  } while (0)
+
+static int check_common(const char* who, const void* x, int ldx, int B, int N, int L, int H, int R) {
+  VQA_REQUIRE(B > 0 && N > 0 && L > 0 && H > 0 && R > 0, VQA_E_BADARG, "%s: bad sizes B=%d N=%d L=%d H=%d R=%d", who, B, N,
+              L, H, R);
+  VQA_REQUIRE(R <= kMaxR, VQA_E_UNSUPPORTED, "%s: R=%d exceeds %d", who, R, kMaxR);
+  VQA_REQUIRE(L % 2 == 0 && H % 2 == 0 && ldx % 2 == 0 && ldx >= L, VQA_E_UNSUPPORTED,
+              "%s: needs even L, H, ldx and ldx >= L (L=%d H=%d ldx=%d)", who, L, H, ldx);
+  VQA_REQUIRE(aligned(x, 8), VQA_E_UNSUPPORTED, "%s: x must be 8-byte aligned", who);
+  VQA_REQUIRE((long)B * N < (1L << 30), VQA_E_UNSUPPORTED, "%s: B*N too large", who);
+  return VQA_OK;
+}
+
+extern "C" int vqa_lowrank_bilinear_fusion_fwd(const float* x, int ldx, const float* const* w1, const float* const* b1,
+                                               const float* h2, float* out, float* h1, int B, int N, int L, int H, int R,
+                                               vqa_stream_t stream) {
+  VQA_REQUIRE(x && w1 && b1 && h2 && out, VQA_E_BADARG, "lowrank_bilinear_fusion_fwd: null pointer");
+  int rc = check_common("lowrank_bilinear_fusion_fwd", x, ldx, B, N, L, H, R);
+  if (rc != VQA_OK) return rc;
+  RankPtrs rp{};
+  for (int r = 0; r < R; ++r) {
+    VQA_REQUIRE(w1[r] && b1[r] && aligned(w1[r], 8), VQA_E_BADARG, "lowrank_bilinear_fusion_fwd: w1[%d]/b1[%d] null or unaligned", r, r);
+    rp.w[r] = w1[r];
+    rp.b[r] = b1[r];
+  }
+  VQA_REQUIRE(aligned(h2, 8) && aligned(out, 8), VQA_E_UNSUPPORTED, "lowrank_bilinear_fusion_fwd: h2/out must be 8-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int M = B * N;
+  const TileChoice t = tile_override_or(choose_tile(M, H, 1));
+  const int tiles_m = (M + t.bm - 1) / t.bm, tiles_n = (H + t.bn - 1) / t.bn;
+#define LAUNCH(BM_, BN_)                                                                                              \
+  {                                                                                                                   \
+    const size_t lds = GemmTile<BM_, BN_, true, true>::kSmemBytes + BM_ * sizeof(int);                                \
+    hipLaunchKernelGGL((bilinear_fwd_kernel<BM_, BN_>), dim3(tiles_m * tiles_n), dim3(kGemmThreads), lds, s, x, ldx,   \
+                       rp, h2, out, h1, M, N, L, H, R, tiles_n);                                                      \
+  }
+  VQA_TILE_SWITCH(t, LAUNCH);
+#undef LAUNCH
+  return check_launch("lowrank_bilinear_fusion_fwd");
+}
+
+extern "C" size_t vqa_lowrank_bilinear_fusion_bwd_workspace_bytes(int B, int N, int L, int H, int R) {
+  if (B <= 0 || N <= 0 || L <= 0 || H <= 0 || R <= 0 || R > kMaxR) return 0;
+  const int S = splits_for_dw(B * N, H, L, R, dw_tile());
+  return ((size_t)S * R * H * L + (size_t)B * H) * sizeof(float);
+}
+
+extern "C" int vqa_lowrank_bilinear_fusion_bwd(const float* x, int ldx, const float* const* w1, const float* h2,
+                                               const float* h1, const float* g, float* d_x, float* const* d_w1,
+                                               float* const* d_b1, float* d_h2, void* workspace, size_t workspace_bytes,
+                                               int B, int N, int L, int H, int R, vqa_stream_t stream) {
+  VQA_REQUIRE(x && w1 && h2 && h1 && g && d_w1 && d_b1 && d_h2 && workspace, VQA_E_BADARG,
+              "lowrank_bilinear_fusion_bwd: null pointer");
+  int rc = check_common("lowrank_bilinear_fusion_bwd", x, ldx, B, N, L, H, R);
+  if (rc != VQA_OK) return rc;
+  VQA_REQUIRE(workspace_bytes >= vqa_lowrank_bilinear_fusion_bwd_workspace_bytes(B, N, L, H, R), VQA_E_BADARG,
+              "lowrank_bilinear_fusion_bwd: workspace of %zu B is too small", workspace_bytes);
+  RankPtrs rp{};
+  RankOutPtrs ro{};
+  for (int r = 0; r < R; ++r) {
+    VQA_REQUIRE(w1[r] && d_w1[r] && d_b1[r] && aligned(w1[r], 8) && aligned(d_w1[r], 8) && aligned(d_b1[r], 8), VQA_E_BADARG,
+                "lowrank_bilinear_fusion_bwd: rank %d pointer null or unaligned", r);
+    rp.w[r] = w1[r];
+    ro.w[r] = d_w1[r];
+    ro.b[r] = d_b1[r];
+  }
+  VQA_REQUIRE(aligned(h2, 8) && aligned(h1, 8) && aligned(g, 8) && aligned(d_h2, 8) && aligned(workspace, 16) &&
+                  (d_x == nullptr || aligned(d_x, 8)),
+              VQA_E_UNSUPPORTED, "lowrank_bilinear_fusion_bwd: tensors must be 8-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int M = B * N;
+  const TileChoice tw = dw_tile();
+  const int S = splits_for_dw(M, H, L, R, tw);
+  float* slab = static_cast<float*>(workspace);
+  float* gs = slab + (size_t)S * R * H * L;
+
+  // (1) dh2 and the per-sample column sums of g
+  hipLaunchKernelGGL(bilinear_dh2_kernel, dim3((H / 2 + 127) / 128, B), dim3(128), 0, s, g, h1, d_h2, gs, N, H, R);
+  // (2) db1
+  hipLaunchKernelGGL(bilinear_db_kernel, dim3((H / 2 + 127) / 128, R), dim3(128), 0, s, h2, gs, ro, B, H, R);
+  // (3) dx
+  if (d_x != nullptr) {
+    const TileChoice t = tile_override_or(choose_tile(M, L, 1));
+    const int tiles_m = (M + t.bm - 1) / t.bm, tiles_n = (L + t.bn - 1) / t.bn;
+#define LAUNCH(BM_, BN_)                                                                                             \
+  {                                                                                                                  \
+    const size_t lds = GemmTile<BM_, BN_, true, false>::kSmemBytes;                                                  \
+    hipLaunchKernelGGL((bilinear_dx_kernel<BM_, BN_>), dim3(tiles_m * tiles_n), dim3(kGemmThreads), lds, s, g, rp, h2, \
+                       d_x, M, N, L, H, R, tiles_n);                                                                 \
+  }
+    VQA_TILE_SWITCH(t, LAUNCH);
+#undef LAUNCH
+  }
+  // (4) dW1: split over rows into slabs, (5) reduce the slabs in fixed order
+  {
+    const int tiles_m = (H + tw.bm - 1) / tw.bm, tiles_n = (L + tw.bn - 1) / tw.bn;
+    int rows_per_split = (M + S - 1) / S;
+    rows_per_split = (rows_per_split + kBK - 1) / kBK * kBK;
+#define LAUNCH(BM_, BN_)                                                                                            \
+  {                                                                                                                 \
+    const size_t lds = GemmTile<BM_, BN_, false, false>::kSmemBytes;                                                \
+    hipLaunchKernelGGL((bilinear_dw_kernel<BM_, BN_>), dim3(tiles_m * tiles_n, R, S), dim3(kGemmThreads), lds, s, g,  \
+                       h2, x, ldx, slab, M, N, L, H, R, tiles_n, rows_per_split);                                   \
+  }
+    VQA_TILE_SWITCH(tw, LAUNCH);
+#undef LAUNCH
+    const int HL = H * L;
+    hipLaunchKernelGGL(bilinear_dw_reduce_kernel, dim3((HL / 2 + 255) / 256, R), dim3(256), 0, s, slab, ro, HL, R, S);
+  }
+  return check_launch("lowrank_bilinear_fusion_bwd");
+}

@@ -1,0 +1,89 @@
+// Shared host/device helpers for libvqa_mi355x.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/vqa_mi355x.h"
+
+namespace vqa {
+
+// ---- per-thread error text (host) -----------------------------------------------------------
+char* error_buffer();  // defined in api.hip, thread_local storage of 512 bytes
+
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(error_buffer(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(VQA_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return VQA_OK;
+}
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// Raise a kernel's dynamic-LDS cap (default 64 KiB) once per device and size; one static per call site.
+#define VQA_ENSURE_LDS(kernel, bytes)                                                                   \
+  do {                                                                                                  \
+    static std::atomic<size_t> cap_[16];                                                                \
+    int dev_ = 0;                                                                                       \
+    (void)hipGetDevice(&dev_);                                                                          \
+    dev_ &= 15;                                                                                         \
+    if ((size_t)(bytes) > 65536 && (size_t)(bytes) > cap_[dev_].load(std::memory_order_relaxed)) {      \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),                        \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes));    \
+      if (e_ != hipSuccess) return ::vqa::fail(VQA_E_LAUNCH, "hipFuncSetAttribute(%s, %zu): %s", #kernel, \
+                                               (size_t)(bytes), hipGetErrorString(e_));                 \
+      cap_[dev_].store((size_t)(bytes), std::memory_order_relaxed);                                     \
+    }                                                                                                   \
+  } while (0)
+
+#define VQA_REQUIRE(cond, code, ...) \
+  do {                               \
+    if (!(cond)) return ::vqa::fail(code, __VA_ARGS__); \
+  } while (0)
+
+// ---- device helpers --------------------------------------------------------------------------
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
+  return x;
+}
+
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, kWave));
+  return x;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ void st2(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+
+__device__ __forceinline__ float4 fma4(float s, float4 a, float4 c) {
+  return make_float4(fmaf(s, a.x, c.x), fmaf(s, a.y, c.y), fmaf(s, a.z, c.z), fmaf(s, a.w, c.w));
+}
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 scale4(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
+
+// Bijective XCD-aware remap of a linear workgroup id: workgroups b and b+8 share an XCD (round-robin
+// dispatch, speed only -- never correctness), so give every XCD a contiguous chunk of the grid.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7, k = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+}  // namespace vqa

@@ -1,0 +1,402 @@
+// K2 -- object-difference attention logits (ODA).
+//
+// Replaces config/ODA.py:216-222 (a 36x36 python loop of (vi - vj) * q_low, torch.stack of 1296 [B,L]
+// tensors, transpose, view -> vq [B,N,N*L], 1.6 MB per sample) and the dropout(0.5) + 1x1 conv over
+// the 11160 channels of vq (config/ODA.py:149 with MyConv1d :89-105):
+//
+//   logits[b,i,g] = bias[g] + sum_{j,d} w[g,j*L+d] * keep(b,i,j,d) * (T[b,i,d] - T[b,j,d]),   T = vl * ql
+//
+// Neither vq nor its Bernoulli mask is ever written: every lane owns one feature d, builds the
+// differences in registers, draws the mask from a counter-based hash of (seed, element index) -- one
+// 32-bit word serves the four regions i = 4*iq .. 4*iq+3, one byte each, so p_drop is realised as
+// round(p*256)/256 -- and contracts against the four filter rows immediately.  Backward regenerates
+// the same mask from the same (seed, index).
+//
+// VALU-bound (~14 lane-ops per mask element, N*N*L = 401 760 elements per sample); compulsory HBM
+// traffic is only vl, ql, logits per sample plus the 178 KB filter, which stays in L2.
+#include "common.hpp"
+
+namespace vqa {
+
+constexpr int kOdaMaxG = 8;
+constexpr int kIC = 12;  // regions i (forward, dT) or j (dW) kept in registers per workgroup pass
+
+__device__ __forceinline__ uint32_t mask_word(uint64_t counter, uint64_t seed) {
+  uint32_t x = (uint32_t)counter ^ (uint32_t)seed;
+  const uint32_t y = (uint32_t)(counter >> 32) ^ (uint32_t)(seed >> 32);
+  x ^= y * 0x9E3779B1u + 0x7F4A7C15u;
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  x *= 0x27D4EB2Fu;
+  x ^= x >> 15;
+  return x;
+}
+// element (b, i, j, d): word index ((b*NQ + i/4)*N + j)*L + d, byte i%4
+__device__ __forceinline__ uint64_t mask_counter(int b, int iq, int j, int d, int NQ, int N, int L) {
+  return (((uint64_t)b * NQ + iq) * N + j) * L + d;
+}
+__device__ __forceinline__ float keep_scale(uint32_t word, int k, uint32_t p8, float scale) {
+  return ((word >> (8 * k)) & 255u) >= p8 ? scale : 0.f;
+}
+
+struct DropCfg {
+  uint32_t p8;   // drop when byte < p8
+  float scale;   // 256 / (256 - p8)
+  uint64_t seed;
+};
+
+static DropCfg make_drop(float p, uint64_t seed) {
+  int p8 = (int)(p * 256.f + 0.5f);
+  if (p8 < 0) p8 = 0;
+  if (p8 > 255) p8 = 255;
+  return DropCfg{(uint32_t)p8, 256.f / (256.f - (float)p8), seed};
+}
+
+// ------------------------------------------------------------------------------------------ forward
+// grid (ceil(N/kIC), B); block = round_up(min(L,1024), 64) threads, lane <-> feature d.
+template <int G, bool DROP>
+__global__ void oda_fwd_kernel(const float* __restrict__ vl, const float* __restrict__ ql, const float* __restrict__ w,
+                               const float* __restrict__ bias, float* __restrict__ logits, DropCfg dc, int N, int L) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red_s = reinterpret_cast<float*>(smem);  // [nwaves][kIC*G]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int b = blockIdx.y, i0 = blockIdx.x * kIC;
+  const int NQ = (N + 3) >> 2;
+  const float* vlb = vl + (size_t)b * N * L;
+  float acc[kIC][G];
+#pragma unroll
+  for (int ic = 0; ic < kIC; ++ic)
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[ic][g] = 0.f;
+
+  for (int d = tid; d < L; d += blockDim.x) {
+    const float qd = ql[(size_t)b * L + d];
+    float Ti[kIC];
+#pragma unroll
+    for (int ic = 0; ic < kIC; ++ic) Ti[ic] = (i0 + ic < N) ? vlb[(size_t)(i0 + ic) * L + d] * qd : 0.f;
+#pragma unroll 2
+    for (int j = 0; j < N; ++j) {
+      const float Tj = vlb[(size_t)j * L + d] * qd;
+      float wv[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) wv[g] = w[((size_t)g * N + j) * L + d];
+#pragma unroll
+      for (int q = 0; q < kIC / 4; ++q) {
+        uint32_t word = 0;
+        if (DROP) word = mask_word(mask_counter(b, (i0 >> 2) + q, j, d, NQ, N, L), dc.seed);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int ic = q * 4 + k;
+          float val = Ti[ic] - Tj;
+          if (DROP) val *= keep_scale(word, k, dc.p8, dc.scale);
+#pragma unroll
+          for (int g = 0; g < G; ++g) acc[ic][g] = fmaf(wv[g], val, acc[ic][g]);
+        }
+      }
+    }
+  }
+  // reduce over d: wave64 shuffles, then across waves through LDS
+#pragma unroll
+  for (int ic = 0; ic < kIC; ++ic)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float r = wave_sum(acc[ic][g]);
+      if (lane == 0) red_s[wave * (kIC * G) + ic * G + g] = r;
+    }
+  __syncthreads();
+  for (int t = tid; t < kIC * G; t += blockDim.x) {
+    const int ic = t / G, g = t % G;
+    if (i0 + ic < N) {
+      float s = bias[g];
+      for (int wv = 0; wv < nwaves; ++wv) s += red_s[wv * (kIC * G) + t];
+      logits[((size_t)b * N + i0 + ic) * G + g] = s;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------- backward: d_vl, d_ql
+// One workgroup per sample, lane <-> feature d.  dT[n][d] is accumulated in an LDS column private to
+// the lane:  dT[i] += sum_j m*U[i,j],  dT[j] -= sum_i m*U[i,j],  U[i,j,d] = sum_g dS[i,g] w[g,j,d].
+template <int G, bool DROP>
+__global__ void oda_bwd_data_kernel(const float* __restrict__ vl, const float* __restrict__ ql,
+                                    const float* __restrict__ w, const float* __restrict__ dS, float* __restrict__ d_vl,
+                                    float* __restrict__ d_ql, DropCfg dc, int N, int L) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* dT_s = reinterpret_cast<float*>(smem);        // [N][blockDim]
+  float* dS_s = dT_s + (size_t)N * blockDim.x;          // [N][G]
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int b = blockIdx.x;
+  const int NQ = (N + 3) >> 2;
+  const float* vlb = vl + (size_t)b * N * L;
+  for (int t = tid; t < N * G; t += nt) dS_s[t] = dS[(size_t)b * N * G + t];
+  __syncthreads();
+  for (int d = tid; d < L; d += nt) {
+    for (int n = 0; n < N; ++n) dT_s[n * nt + tid] = 0.f;
+    for (int i0 = 0; i0 < N; i0 += kIC) {
+      float ds[kIC][G], dTi[kIC];
+#pragma unroll
+      for (int ic = 0; ic < kIC; ++ic) {
+        dTi[ic] = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) ds[ic][g] = (i0 + ic < N) ? dS_s[(i0 + ic) * G + g] : 0.f;
+      }
+#pragma unroll 2
+      for (int j = 0; j < N; ++j) {
+        float wv[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) wv[g] = w[((size_t)g * N + j) * L + d];
+        float pj = 0.f;
+#pragma unroll
+        for (int q = 0; q < kIC / 4; ++q) {
+          uint32_t word = 0;
+          if (DROP) word = mask_word(mask_counter(b, (i0 >> 2) + q, j, d, NQ, N, L), dc.seed);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int ic = q * 4 + k;
+            float u = 0.f;
+#pragma unroll
+            for (int g = 0; g < G; ++g) u = fmaf(ds[ic][g], wv[g], u);
+            if (DROP) u *= keep_scale(word, k, dc.p8, dc.scale);
+            dTi[ic] += u;
+            pj += u;
+          }
+        }
+        dT_s[j * nt + tid] -= pj;
+      }
+#pragma unroll
+      for (int ic = 0; ic < kIC; ++ic)
+        if (i0 + ic < N) dT_s[(i0 + ic) * nt + tid] += dTi[ic];
+    }
+    const float qd = ql[(size_t)b * L + d];
+    float dq = 0.f;
+    for (int n = 0; n < N; ++n) {
+      const float t = dT_s[n * nt + tid];
+      d_vl[((size_t)b * N + n) * L + d] = t * qd;
+      dq = fmaf(t, vlb[(size_t)n * L + d], dq);
+    }
+    d_ql[(size_t)b * L + d] = dq;
+  }
+}
+
+// --------------------------------------------------------------------------------- backward: d_w slabs
+// grid (ceil(N/kIC) j-chunks, SG sample groups); lane <-> d; dw[jc][g] for the chunk lives in registers
+// across the group's samples:  dw[g,j,d] += sum_i dS[b,i,g] * m(b,i,j,d) * (T[b,i,d] - T[b,j,d]).
+template <int G, bool DROP>
+__global__ void oda_bwd_weight_kernel(const float* __restrict__ vl, const float* __restrict__ ql,
+                                      const float* __restrict__ dS, float* __restrict__ slab, DropCfg dc, int B, int N,
+                                      int L, int samples_per_group) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* dS_s = reinterpret_cast<float*>(smem);  // [N + 3][G] (zero padded to a multiple of 4 rows)
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int j0 = blockIdx.x * kIC, sg = blockIdx.y;
+  const int NQ = (N + 3) >> 2;
+  const int b_lo = sg * samples_per_group, b_hi = min(B, b_lo + samples_per_group);
+  const int d = tid;  // the launcher guarantees blockDim >= L, so one feature per lane
+  const bool active = d < L;
+  float dw[kIC][G];
+#pragma unroll
+  for (int jc = 0; jc < kIC; ++jc)
+#pragma unroll
+    for (int g = 0; g < G; ++g) dw[jc][g] = 0.f;
+  for (int b = b_lo; b < b_hi; ++b) {
+    __syncthreads();
+    for (int t = tid; t < NQ * 4 * G; t += nt) dS_s[t] = (t < N * G) ? dS[(size_t)b * N * G + t] : 0.f;
+    __syncthreads();
+    if (!active) continue;
+    const float* vlb = vl + (size_t)b * N * L;
+    const float qd = ql[(size_t)b * L + d];
+    float Tj[kIC];
+#pragma unroll
+    for (int jc = 0; jc < kIC; ++jc) Tj[jc] = (j0 + jc < N) ? vlb[(size_t)(j0 + jc) * L + d] * qd : 0.f;
+    for (int iq = 0; iq < NQ; ++iq) {
+      float Ti[4], ds[4][G];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = iq * 4 + k;
+        Ti[k] = (i < N) ? vlb[(size_t)i * L + d] * qd : 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) ds[k][g] = dS_s[i * G + g];  // zero rows beyond N
+      }
+#pragma unroll
+      for (int jc = 0; jc < kIC; ++jc) {
+        uint32_t word = 0;
+        if (DROP) word = mask_word(mask_counter(b, iq, j0 + jc, d, NQ, N, L), dc.seed);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float val = Ti[k] - Tj[jc];
+          if (DROP) val *= keep_scale(word, k, dc.p8, dc.scale);
+#pragma unroll
+          for (int g = 0; g < G; ++g) dw[jc][g] = fmaf(ds[k][g], val, dw[jc][g]);
+        }
+      }
+    }
+  }
+  if (!active) return;
+#pragma unroll
+  for (int jc = 0; jc < kIC; ++jc)
+    if (j0 + jc < N)
+#pragma unroll
+      for (int g = 0; g < G; ++g) slab[(((size_t)sg * G + g) * N + j0 + jc) * L + d] = dw[jc][g];
+}
+
+// d_w[e] = sum_sg slab[sg][e]  (fixed order), e over G*N*L
+__global__ __launch_bounds__(256) void oda_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                                         size_t n, int S) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  float a = 0.f;
+  for (int s = 0; s < S; ++s) a += slab[(size_t)s * n + e];
+  out[e] = a;
+}
+
+// d_bias[g] = sum_{b,i} dS[b,i,g]; one workgroup, deterministic tree
+__global__ __launch_bounds__(256) void oda_dbias_kernel(const float* __restrict__ dS, float* __restrict__ d_bias, int rows,
+                                                        int G) {
+  __shared__ float part[4 * kOdaMaxG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int g = 0; g < G; ++g) {
+    float a = 0.f;
+    for (int r = tid; r < rows; r += 256) a += dS[(size_t)r * G + g];
+    a = wave_sum(a);
+    if (lane == 0) part[wave * kOdaMaxG + g] = a;
+  }
+  __syncthreads();
+  if (tid < G) d_bias[tid] = part[tid] + part[kOdaMaxG + tid] + part[2 * kOdaMaxG + tid] + part[3 * kOdaMaxG + tid];
+}
+
+// mask[b][i][j*L+d] = keep/(1-p) exactly as the fused kernels draw it (test / debugging aid)
+__global__ __launch_bounds__(256) void oda_mask_kernel(float* __restrict__ mask, DropCfg dc, int N, int L) {
+  const int b = blockIdx.z, i = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;  // j*L + d
+  if (e >= N * L) return;
+  const int j = e / L, d = e % L;
+  const int NQ = (N + 3) >> 2;
+  float m = 1.f;
+  if (dc.p8 > 0) m = keep_scale(mask_word(mask_counter(b, i >> 2, j, d, NQ, N, L), dc.seed), i & 3, dc.p8, dc.scale);
+  mask[((size_t)b * N + i) * N * L + e] = m;
+}
+
+static int oda_threads(int L) {
+  int t = (L < 1024 ? L : 1024);
+  return (t + 63) / 64 * 64;
+}
+static int oda_groups(int B) { return B < 128 ? B : 128; }
+
+template <int G>
+static int launch_fwd(const float* vl, const float* ql, const float* w, const float* bias, float* logits, DropCfg dc,
+                      int B, int N, int L, hipStream_t s) {
+  const int nt = oda_threads(L);
+  const size_t lds = (size_t)(nt / 64) * kIC * G * sizeof(float);
+  dim3 grid((N + kIC - 1) / kIC, B);
+  if (dc.p8 > 0)
+    hipLaunchKernelGGL((oda_fwd_kernel<G, true>), grid, dim3(nt), lds, s, vl, ql, w, bias, logits, dc, N, L);
+  else
+    hipLaunchKernelGGL((oda_fwd_kernel<G, false>), grid, dim3(nt), lds, s, vl, ql, w, bias, logits, dc, N, L);
+  return check_launch("object_difference_attention_fwd");
+}
+
+template <int G>
+static int launch_bwd(const float* vl, const float* ql, const float* w, const float* dS, float* d_vl, float* d_ql,
+                      float* d_w, float* d_bias, float* slab, DropCfg dc, int B, int N, int L, hipStream_t s) {
+  const int nt = oda_threads(L);
+  {
+    const size_t lds = ((size_t)N * nt + (size_t)N * G) * sizeof(float);
+    VQA_REQUIRE(lds <= 160 * 1024, VQA_E_UNSUPPORTED, "object_difference_attention_bwd: N=%d L=%d need %zu B of LDS", N, L, lds);
+    if (dc.p8 > 0) {
+      VQA_ENSURE_LDS((oda_bwd_data_kernel<G, true>), lds);
+      hipLaunchKernelGGL((oda_bwd_data_kernel<G, true>), dim3(B), dim3(nt), lds, s, vl, ql, w, dS, d_vl, d_ql, dc, N, L);
+    } else {
+      VQA_ENSURE_LDS((oda_bwd_data_kernel<G, false>), lds);
+      hipLaunchKernelGGL((oda_bwd_data_kernel<G, false>), dim3(B), dim3(nt), lds, s, vl, ql, w, dS, d_vl, d_ql, dc, N, L);
+    }
+  }
+  {
+    const int SG = oda_groups(B);
+    const int spg = (B + SG - 1) / SG;
+    const size_t lds = (size_t)(N + 3) * G * sizeof(float);
+    dim3 grid((N + kIC - 1) / kIC, SG);
+    if (dc.p8 > 0)
+      hipLaunchKernelGGL((oda_bwd_weight_kernel<G, true>), grid, dim3(nt), lds, s, vl, ql, dS, slab, dc, B, N, L, spg);
+    else
+      hipLaunchKernelGGL((oda_bwd_weight_kernel<G, false>), grid, dim3(nt), lds, s, vl, ql, dS, slab, dc, B, N, L, spg);
+    const size_t n = (size_t)G * N * L;
+    hipLaunchKernelGGL(oda_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slab, d_w, n, SG);
+  }
+  hipLaunchKernelGGL(oda_dbias_kernel, dim3(1), dim3(256), 0, s, dS, d_bias, B * N, G);
+  return check_launch("object_difference_attention_bwd");
+}
+
+}  // namespace vqa
+
+using namespace vqa;
+
+static int oda_check(const char* who, int B, int N, int L, int G, float p) {
+  VQA_REQUIRE(B > 0 && N > 0 && L > 0 && G > 0, VQA_E_BADARG, "%s: bad sizes B=%d N=%d L=%d G=%d", who, B, N, L, G);
+  VQA_REQUIRE(G <= kOdaMaxG && N <= 128 && L <= 1024, VQA_E_UNSUPPORTED, "%s: needs G <= 8, N <= 128, L <= 1024 (G=%d N=%d L=%d)",
+              who, G, N, L);
+  VQA_REQUIRE(p >= 0.f && p < 1.f, VQA_E_BADARG, "%s: p_drop=%f outside [0,1)", who, (double)p);
+  VQA_REQUIRE(B <= 65535, VQA_E_UNSUPPORTED, "%s: B=%d exceeds 65535", who, B);
+  return VQA_OK;
+}
+
+#define VQA_G_SWITCH(G, CALL) \
+  switch (G) {                \
+    case 1: return CALL(1);   \
+    case 2: return CALL(2);   \
+    case 3: return CALL(3);   \
+    case 4: return CALL(4);   \
+    case 5: return CALL(5);   \
+    case 6: return CALL(6);   \
+    case 7: return CALL(7);   \
+    default: return CALL(8);  \
+  }
+
+extern "C" int vqa_object_difference_attention_fwd(const float* vl, const float* ql, const float* w, const float* bias,
+                                                   float* logits, float p_drop, uint64_t seed, int B, int N, int L,
+                                                   int G, vqa_stream_t stream) {
+  VQA_REQUIRE(vl && ql && w && bias && logits, VQA_E_BADARG, "object_difference_attention_fwd: null pointer");
+  int rc = oda_check("object_difference_attention_fwd", B, N, L, G, p_drop);
+  if (rc != VQA_OK) return rc;
+  const DropCfg dc = make_drop(p_drop, seed);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define CALL(G_) launch_fwd<G_>(vl, ql, w, bias, logits, dc, B, N, L, s)
+  VQA_G_SWITCH(G, CALL)
+#undef CALL
+}
+
+extern "C" size_t vqa_object_difference_attention_bwd_workspace_bytes(int B, int N, int L, int G) {
+  if (B <= 0 || N <= 0 || L <= 0 || G <= 0) return 0;
+  return (size_t)oda_groups(B) * G * N * L * sizeof(float);
+}
+
+extern "C" int vqa_object_difference_attention_bwd(const float* vl, const float* ql, const float* w,
+                                                   const float* d_logits, float* d_vl, float* d_ql, float* d_w,
+                                                   float* d_bias, void* workspace, size_t workspace_bytes, float p_drop,
+                                                   uint64_t seed, int B, int N, int L, int G, vqa_stream_t stream) {
+  VQA_REQUIRE(vl && ql && w && d_logits && d_vl && d_ql && d_w && d_bias && workspace, VQA_E_BADARG,
+              "object_difference_attention_bwd: null pointer");
+  int rc = oda_check("object_difference_attention_bwd", B, N, L, G, p_drop);
+  if (rc != VQA_OK) return rc;
+  VQA_REQUIRE(workspace_bytes >= vqa_object_difference_attention_bwd_workspace_bytes(B, N, L, G), VQA_E_BADARG,
+              "object_difference_attention_bwd: workspace of %zu B is too small", workspace_bytes);
+  const DropCfg dc = make_drop(p_drop, seed);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* slab = static_cast<float*>(workspace);
+#define CALL(G_) launch_bwd<G_>(vl, ql, w, d_logits, d_vl, d_ql, d_w, d_bias, slab, dc, B, N, L, s)
+  VQA_G_SWITCH(G, CALL)
+#undef CALL
+}
+
+extern "C" int vqa_object_difference_dropout_mask(float* mask, float p_drop, uint64_t seed, int B, int N, int L,
+                                                  vqa_stream_t stream) {
+  VQA_REQUIRE(mask, VQA_E_BADARG, "object_difference_dropout_mask: null pointer");
+  int rc = oda_check("object_difference_dropout_mask", B, N, L, 1, p_drop);
+  if (rc != VQA_OK) return rc;
+  const DropCfg dc = make_drop(p_drop, seed);
+  hipLaunchKernelGGL(oda_mask_kernel, dim3((N * L + 255) / 256, N, B), dim3(256), 0, static_cast<hipStream_t>(stream), mask,
+                     dc, N, L);
+  return check_launch("object_difference_dropout_mask");
+}

@@ -1,0 +1,191 @@
+"""Host-side mirror of the reference's layer library for the CoR2 / ODA hot path.
+
+Same class names, constructor arguments, parameter names/shapes and error
+behaviour as the reference, so its checkpoints load and its call sites read the same:
+
+  Linear, MutanFusion, bmul, bmatmul   <- putils/__init__.py:16-33, :205-241, :98-104, :89-95
+  MyConv1d, MyLinear, MyATT            <- config/CoR2.py:56-157 (identical copies in config/ODA.py:73-174)
+
+What differs is underneath: the python per-sample loops are gone; MutanFusion's region side, the
+attention softmax+pooling and (in the models) the pairwise relation / object-difference tensors run
+in hand-written HIP kernels through libvqa_mi355x.so (ops.py).  Plain dense GEMMs that the north
+star does not name (MyLinear / MyConv1d projections) go to rocBLAS/hipBLASLt through F.linear.
+There is no CPU path: GPU tensors only.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+def bmul(inputs1, inputs2):
+    """putils/__init__.py:98-104: out[b] = inputs1[b] * inputs2[b] (inputs2 broadcasts over the
+    middle axes of inputs1) -- one fused broadcast multiply instead of B launches + stack."""
+    b = inputs1.size(0)
+    shape = [b] + [1] * (inputs1.dim() - inputs2.dim()) + list(inputs2.shape[1:])
+    return inputs1 * inputs2.reshape(shape)
+
+
+def bmatmul(inputs1, inputs2):
+    """putils/__init__.py:89-95: out[b] = inputs1[b] @ inputs2[b]."""
+    return torch.matmul(inputs1, inputs2)
+
+
+def _activation(x, af, dim):
+    if not af:
+        return x
+    if af == "softmax":
+        return F.softmax(x, dim=dim)
+    if af == "sigmoid":
+        return torch.sigmoid(x)
+    if af == "tanh":
+        return torch.tanh(x)
+    return getattr(F, af)(x)
+
+
+class Linear(nn.Module):
+    """putils/__init__.py:16-33."""
+
+    def __init__(self, in_features, out_features, bias=True, seed=None):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        if seed:
+            torch.manual_seed(seed)
+        self.linear = nn.Linear(in_features, out_features, bias=bias)
+
+    def forward(self, x):
+        if x.size()[-1] != self.in_features:
+            raise ValueError(
+                "[error] putils.Linear(%s, %s): last dimension of input(%s) should equal to in_features(%s)"
+                % (self.in_features, self.out_features, x.size(-1), self.in_features))
+        return self.linear(x)
+
+
+class MyLinear(nn.Module):
+    """config/CoR2.py:94-122: af(linear(dropout_p(x)))."""
+
+    def __init__(self, in_features, out_features, seed=None, p=None, af=None, dim=None):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.p = p
+        self.af = af
+        self.dim = dim
+        if seed:
+            torch.manual_seed(seed)
+        self.linear = nn.Linear(in_features, out_features, bias=True)
+
+    def forward(self, x):
+        if x.size()[-1] != self.in_features:
+            raise ValueError(
+                "[error] putils.Linear(%s, %s): last dimension of input(%s) should equal to in_features(%s)"
+                % (self.in_features, self.out_features, x.size(-1), self.in_features))
+        if self.p:
+            x = F.dropout(x, p=self.p, training=self.training)
+        return _activation(self.linear(x), self.af, self.dim)
+
+
+class MyConv1d(nn.Module):
+    """config/CoR2.py:56-91 with kernel_size 1 (the only use): af(conv1d(dropout_p(x)^T)^T) on
+    [B,N,Cin].  The parameter keeps nn.Conv1d's (Cout,Cin,1) shape under the name ``conv``; the
+    contraction itself is a row-major GEMM on the [B*N,Cin] view (no transposes)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=1, stride=1, padding=0, seed=None, p=None, af=None,
+                 dim=None):
+        super().__init__()
+        if kernel_size != 1 or stride != 1 or padding != 0:
+            raise ValueError("MyConv1d: only kernel_size=1, stride=1, padding=0 is on the CoR2/ODA path")
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = kernel_size
+        self.stride = stride
+        self.p = p
+        self.af = af
+        self.dim = dim
+        if seed:
+            torch.manual_seed(seed)
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size, stride, padding=padding, dilation=1, groups=1,
+                              bias=True)
+
+    def pre_activation(self, x):
+        if x.dim() != 3:
+            raise ValueError("[error] putils.Conv1d(%s, %s, %s, %s): input_dim (%s) should equal to 3"
+                             % (self.in_channels, self.out_channels, self.kernel_size, self.stride, x.dim()))
+        if self.p:
+            x = F.dropout(x, p=self.p, training=self.training)
+        return F.linear(x, self.conv.weight.squeeze(-1), self.conv.bias)
+
+    def forward(self, x):
+        return _activation(self.pre_activation(x), self.af, self.dim)
+
+
+class MutanFusion(nn.Module):
+    """putils/__init__.py:205-241: sum_r Linear1_r(x1) * Linear2_r(x2) (x2 [B,in2] broadcasts over the
+    region axis of x1 [B,N,in1]).  Region side + product + rank sum = HIP kernel K4 (fp32 MFMA)."""
+
+    def __init__(self, input_dim1, input_dim2, hidden_dim, R, seed=None):
+        super().__init__()
+        self.input_dim1 = input_dim1
+        self.input_dim2 = input_dim2
+        self.hidden_dim = hidden_dim
+        self.R = R
+        self.list_linear1 = nn.ModuleList([Linear(input_dim1, hidden_dim) for _ in range(R)])
+        self.list_linear2 = nn.ModuleList([Linear(input_dim2, hidden_dim) for _ in range(R)])
+
+    def forward(self, inputs1, inputs2):
+        if inputs1.size(-1) != self.input_dim1:
+            raise ValueError(
+                "[error] putils.Linear(%s, %s): last dimension of input(%s) should equal to in_features(%s)"
+                % (self.input_dim1, self.hidden_dim, inputs1.size(-1), self.input_dim1))
+        if inputs2.dim() != 2 or inputs2.size(0) != inputs1.size(0):
+            raise ValueError("MutanFusion: inputs2 must be [B, input_dim2] with the batch of inputs1")
+        # question side: R small [B,in2]x[in2,H] GEMMs (Linear's own check raises ValueError on a bad last dim)
+        h2 = torch.stack([lin(inputs2) for lin in self.list_linear2], dim=1)           # [B,R,H]
+        weights = [lin.linear.weight for lin in self.list_linear1]
+        biases = [lin.linear.bias for lin in self.list_linear1]
+        return ops.lowrank_bilinear_fusion(inputs1, h2, weights, biases)
+
+
+class MyATT(nn.Module):
+    """config/CoR2.py:125-157: alpha = softmax over regions of conv_att(fuse); pooled = alpha^T @ inputs;
+    one MyLinear per glimpse; concat.  Returns (x_v [B,att_dim], tuple of G tensors [B,N,1]) like the
+    reference.  Softmax + pooling = HIP kernel K3."""
+
+    def __init__(self, fuse_dim, glimpses, inputs_dim, att_dim, seed=None, af="tanh"):
+        super().__init__()
+        assert att_dim % glimpses == 0
+        self.glimpses = glimpses
+        self.inputs_dim = inputs_dim
+        self.att_dim = att_dim
+        self.conv_att = MyConv1d(fuse_dim, glimpses, 1, 1, seed=seed, p=0.5, af="softmax", dim=1)
+        self.list_linear_v_fusion = nn.ModuleList(
+            [MyLinear(inputs_dim, int(att_dim / glimpses), p=0.5, af=af) for _ in range(glimpses)])
+        self.af = af
+
+    def attend(self, inputs, logits):
+        """logits [B,N,G] (pre-softmax) -> (x_v, list_att, alpha [B,N,G])."""
+        alpha, pooled = ops.softmax_attention_pool(logits, inputs)                     # [B,N,G], [B,G,D]
+        parts = [self.list_linear_v_fusion[g](pooled[:, g, :]) for g in range(self.glimpses)]
+        return torch.cat(parts, 1), torch.split(alpha, 1, dim=2), alpha
+
+    def forward(self, inputs, fuse):
+        x_v, list_att, _ = self.attend(inputs, self.conv_att.pre_activation(fuse))
+        return x_v, list_att
+
+
+class QuestionVectorInput(nn.Module):
+    """Stand-in for the question encoder slot ``seq2vec`` (putils.SkipThoughts, putils/__init__.py:878-985,
+    is upstream of the hot path and needs weight files that are not available offline): the sample's
+    'q_idxes' entry already holds the 2400-d question vector and is passed through."""
+
+    def __init__(self, dim=2400):
+        super().__init__()
+        self.dim = dim
+
+    def forward(self, q):
+        if not torch.is_floating_point(q) or q.size(-1) != self.dim:
+            raise ValueError("seq2vec slot holds no encoder: pass the %d-d question vector as sample['q_idxes'] "
+                             "(or construct the Model with seq2vec=<your encoder>)" % self.dim)
+        return q

@@ -1,0 +1,59 @@
+"""ODA ("Object-Difference Attention") head on the MI355X kernels -- drop-in for config/ODA.py:177-240.
+
+Same constructor / forward / ``alpha_dict`` / state_dict names as the reference ``Model``
+(``att.conv_att.conv.weight`` keeps its (4, N*310, 1) shape).  The [B,N,N*310] difference tensor and
+its dropout mask are never built: HIP kernel K2 contracts them against the attention filter on the fly.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .layers import MutanFusion, MyATT, MyConv1d, MyLinear, QuestionVectorInput
+
+
+class Model(nn.Module):
+    def __init__(self, vocab_words=None, num_ans=None, seq2vec=None, regions=36):
+        super().__init__()
+        self.vocab_words = vocab_words
+        self.num_classes = num_ans
+        self.regions = regions
+
+        self.seq2vec = seq2vec if seq2vec is not None else QuestionVectorInput(2400)
+        self.compress_v = MyConv1d(2048, 310, 1, 1, p=0.5, af="relu")
+        self.compress_q = MyLinear(2400, 310, p=0.5, af="relu")
+        self.att = MyATT(fuse_dim=regions * 310, glimpses=4, inputs_dim=2048, att_dim=620, af="relu")
+        self.linear_q = MyLinear(2400, 310, p=0.5, af="relu")
+        self.fusion_final = MutanFusion(620, 310, 510, 5)
+        self.linear_classif = MyLinear(510, self.num_classes, p=0.5)
+        self.alpha_dict = {}
+        self._mask_step = 0
+
+    def difference_logits(self, v_feature_low, q_feature_low):
+        """config/ODA.py:216-222 + the dropout/1x1-conv of conv_att (config/ODA.py:149), fused (K2)."""
+        conv = self.att.conv_att
+        p = conv.p if (self.training and conv.p) else 0.0
+        seed = 0
+        if p:
+            # fresh mask every call, drawn from torch's generator so torch.manual_seed governs it
+            seed = int(torch.randint(0, 2 ** 62, (1,), device="cpu").item())
+        w = conv.conv.weight.view(conv.out_channels, -1)
+        return ops.object_difference_attention(v_feature_low, q_feature_low, w, conv.conv.bias, p, seed)
+
+    def forward(self, sample):
+        v = sample["v"]
+        b = v.size(0)
+        v_feature = v.contiguous().view(b, -1, 2048)
+        if v_feature.size(1) != self.regions:
+            raise ValueError("ODA.Model was built for %d regions, input has %d" % (self.regions, v_feature.size(1)))
+        q_feature = self.seq2vec(sample["q_idxes"] if "q_idxes" in sample else sample["q"])
+
+        v_feature_low = self.compress_v(v_feature)
+        q_feature_low = self.compress_q(q_feature)
+        logits = self.difference_logits(v_feature_low, q_feature_low)
+        v_final, alphas, _ = self.att.attend(v_feature, logits)
+
+        self.alpha_dict = {"alphas": alphas[0]}
+
+        q_final = self.linear_q(q_feature)
+        x = self.fusion_final(v_final, q_final)
+        return self.linear_classif(x)

@@ -1,0 +1,263 @@
+"""torch.autograd.Function wrappers around the C ABI (include/vqa_mi355x.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every forward/backward
+below is one call into libvqa_mi355x.so on ``torch.cuda.current_stream()``.  Tensors must be
+fp32 CUDA(=HIP) tensors; anything else raises -- there is no eager/CPU fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class KernelTimer:
+    """Optional per-launch timing with HIP events recorded on the stream the kernels are launched on
+    (torch's current stream).  bench.py installs one around its timed region; None = no overhead."""
+
+    def __init__(self, names=None):
+        self.names = set(names) if names else None
+        self.events = {}
+
+    def wants(self, name):
+        return self.names is None or name in self.names
+
+    def summary(self):
+        """{(name, shape): (launches, mean_ms)} -- call after torch.cuda.synchronize()."""
+        out = {}
+        for key, evs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[key] = (len(ms), sum(ms) / max(len(ms), 1))
+        return out
+
+
+_timer = None
+
+
+def set_kernel_timer(timer):
+    global _timer
+    _timer = timer
+
+
+def _launch(name, shape, fn, *args):
+    """Call one C-ABI launcher on the current stream, check its return code, optionally time it."""
+    t = _timer
+    if t is not None and t.wants(name):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn(*args, _stream())
+        b.record()
+        t.events.setdefault((name, shape), []).append((a, b))
+    else:
+        rc = fn(*args, _stream())
+    _lib.check(rc, name)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _prep(name, t):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.VqaLibraryError(
+            "%s must be a GPU tensor: the MI355X HIP path has no CPU fallback (got %s)"
+            % (name, t.device if isinstance(t, torch.Tensor) else type(t)))
+    if t.dtype != torch.float32:
+        raise _lib.VqaLibraryError("%s must be float32, got %s" % (name, t.dtype))
+    return t.contiguous()
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class PairwiseRelationReduce(torch.autograd.Function):
+    """K1.  v2[b,j,:] = sum_i alpha[b,i,glimpse] * (v[b,i,:]*q1[b,:] + v[b,j,:]*q2[b,:]).
+    Replaces config/CoR2.py:191-199 + :216."""
+
+    @staticmethod
+    def forward(ctx, v, q1, q2, alpha, glimpse, mode):
+        v, q1, q2, alpha = _prep("v", v), _prep("q1", q1), _prep("q2", q2), _prep("alpha", alpha)
+        B, N, D = v.shape
+        if alpha.dim() != 3 or alpha.shape[0] != B or alpha.shape[1] != N or not 0 <= glimpse < alpha.shape[2]:
+            raise ValueError("alpha must be [B,N,G] with glimpse < G, got %s" % (tuple(alpha.shape),))
+        if q1.shape != (B, D) or q2.shape != (B, D):
+            raise ValueError("q1/q2 must be [B,D]")
+        G = alpha.shape[2]
+        v2 = torch.empty_like(v)
+        a_ptr = ctypes.c_void_p(alpha.data_ptr() + 4 * glimpse)
+        _launch("pairwise_relation_reduce_fwd", (B, N, D, int(mode)), _lib.lib().vqa_pairwise_relation_reduce_fwd,
+                _p(v), _p(q1), _p(q2), a_ptr, G, _p(v2), B, N, D, int(mode))
+        ctx.save_for_backward(v, q1, q2, alpha)
+        ctx.glimpse = glimpse
+        return v2
+
+    @staticmethod
+    def backward(ctx, g):
+        v, q1, q2, alpha = ctx.saved_tensors
+        g = _prep("grad_v2", g)
+        B, N, D = v.shape
+        G = alpha.shape[2]
+        d_alpha = torch.empty(B, N, device=v.device, dtype=torch.float32)
+        d_q1 = torch.empty_like(q1)
+        d_q2 = torch.empty_like(q2)
+        d_v = torch.empty_like(v) if ctx.needs_input_grad[0] else None
+        a_ptr = ctypes.c_void_p(alpha.data_ptr() + 4 * ctx.glimpse)
+        _launch("pairwise_relation_reduce_bwd", (B, N, D, d_v is not None), _lib.lib().vqa_pairwise_relation_reduce_bwd,
+                _p(v), _p(q1), _p(q2), a_ptr, G, _p(g), _p(d_alpha), _p(d_q1), _p(d_q2), _p(d_v), B, N, D)
+        d_alpha_full = torch.zeros_like(alpha)
+        d_alpha_full[:, :, ctx.glimpse] = d_alpha
+        return d_v, d_q1, d_q2, d_alpha_full, None, None
+
+
+class SoftmaxAttentionPool(torch.autograd.Function):
+    """K3.  alpha = softmax over regions of logits [B,N,G]; pooled[b,g,:] = sum_n alpha[b,n,g] v[b,n,:].
+    Replaces F.softmax(dim=1) (config/CoR2.py:83-87,:132) + putils.bmatmul (config/CoR2.py:142)."""
+
+    @staticmethod
+    def forward(ctx, logits, v):
+        logits, v = _prep("logits", logits), _prep("v", v)
+        B, N, G = logits.shape
+        if v.dim() != 3 or v.shape[0] != B or v.shape[1] != N:
+            raise ValueError("v must be [B,N,D] matching logits [B,N,G]")
+        D = v.shape[2]
+        alpha = torch.empty_like(logits)
+        pooled = torch.empty(B, G, D, device=v.device, dtype=torch.float32)
+        _launch("softmax_attention_pool_fwd", (B, N, D, G), _lib.lib().vqa_softmax_attention_pool_fwd,
+                _p(logits), _p(v), _p(alpha), _p(pooled), B, N, D, G)
+        ctx.save_for_backward(alpha, v)
+        ctx.set_materialize_grads(False)
+        return alpha, pooled
+
+    @staticmethod
+    def backward(ctx, d_alpha, d_pooled):
+        alpha, v = ctx.saved_tensors
+        B, N, G = alpha.shape
+        D = v.shape[2]
+        if d_pooled is None:
+            d_pooled = torch.zeros(B, G, D, device=v.device, dtype=torch.float32)
+        d_pooled = _prep("grad_pooled", d_pooled)
+        d_alpha = _prep("grad_alpha", d_alpha) if d_alpha is not None else None
+        d_logits = torch.empty_like(alpha)
+        d_v = torch.empty_like(v) if ctx.needs_input_grad[1] else None
+        _launch("softmax_attention_pool_bwd", (B, N, D, G, d_v is not None), _lib.lib().vqa_softmax_attention_pool_bwd,
+                _p(alpha), _p(v), _p(d_pooled), _p(d_alpha), _p(d_logits), _p(d_v), B, N, D, G)
+        return d_logits, d_v
+
+
+class LowRankBilinearFusion(torch.autograd.Function):
+    """K4.  out[b,n,:] = sum_r (x[b,n,:] W1_r^T + b1_r) * h2[b,r,:]   (x may also be [B,L]).
+    Replaces the region side of putils.MutanFusion.forward (putils/__init__.py:232-238)."""
+
+    @staticmethod
+    def forward(ctx, x, h2, *params):
+        R = len(params) // 2
+        w1 = [_prep("w1[%d]" % r, params[r]) for r in range(R)]
+        b1 = [_prep("b1[%d]" % r, params[R + r]) for r in range(R)]
+        x, h2 = _prep("x", x), _prep("h2", h2)
+        lead = x.shape[:-1]
+        B = x.shape[0]
+        L = x.shape[-1]
+        N = 1
+        for s in lead[1:]:
+            N *= s
+        H = w1[0].shape[0]
+        if h2.shape != (B, R, H):
+            raise ValueError("h2 must be [B,R,H] = %s, got %s" % ((B, R, H), tuple(h2.shape)))
+        for r in range(R):
+            if w1[r].shape != (H, L) or b1[r].shape != (H,):
+                raise ValueError("rank %d: weight %s / bias %s do not match (H=%d, L=%d)"
+                                 % (r, tuple(w1[r].shape), tuple(b1[r].shape), H, L))
+        need_bwd = any(ctx.needs_input_grad)
+        out = torch.empty(*lead, H, device=x.device, dtype=torch.float32)
+        h1 = torch.empty(B * N, R, H, device=x.device, dtype=torch.float32) if need_bwd else None
+        _launch("lowrank_bilinear_fusion_fwd", (B, N, L, H, R, need_bwd), _lib.lib().vqa_lowrank_bilinear_fusion_fwd,
+                _p(x), L, _ptr_array(w1), _ptr_array(b1), _p(h2), _p(out), _p(h1), B, N, L, H, R)
+        if need_bwd:
+            ctx.save_for_backward(x, h2, h1, *w1)
+        ctx.dims = (B, N, L, H, R)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, L, H, R = ctx.dims
+        x, h2, h1 = ctx.saved_tensors[:3]
+        w1 = list(ctx.saved_tensors[3:])
+        g = _prep("grad_out", g)
+        dev = x.device
+        d_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        d_h2 = torch.empty_like(h2)
+        d_w1 = [torch.empty_like(w) for w in w1]
+        d_b1 = [torch.empty(H, device=dev, dtype=torch.float32) for _ in range(R)]
+        L_ = _lib.lib()
+        ws_bytes = L_.vqa_lowrank_bilinear_fusion_bwd_workspace_bytes(B, N, L, H, R)
+        ws = torch.empty((ws_bytes + 3) // 4, device=dev, dtype=torch.float32)
+        _launch("lowrank_bilinear_fusion_bwd", (B, N, L, H, R, d_x is not None), L_.vqa_lowrank_bilinear_fusion_bwd,
+                _p(x), L, _ptr_array(w1), _p(h2), _p(h1), _p(g), _p(d_x), _ptr_array(d_w1), _ptr_array(d_b1), _p(d_h2),
+                _p(ws), ws_bytes, B, N, L, H, R)
+        return (d_x, d_h2, *d_w1, *d_b1)
+
+
+class ObjectDifferenceAttention(torch.autograd.Function):
+    """K2.  logits[b,i,g] = bias[g] + sum_{j,d} w[g,j*L+d] * keep * (vl[b,i,d]-vl[b,j,d]) * ql[b,d].
+    Replaces config/ODA.py:216-222 + the dropout and 1x1 conv of config/ODA.py:149."""
+
+    @staticmethod
+    def forward(ctx, vl, ql, w, bias, p_drop, seed):
+        vl, ql, w, bias = _prep("vl", vl), _prep("ql", ql), _prep("w", w), _prep("bias", bias)
+        B, N, L = vl.shape
+        G = bias.shape[0]
+        if ql.shape != (B, L) or w.numel() != G * N * L:
+            raise ValueError("object_difference_attention: ql must be [B,L], w must hold G*N*L = %d values (got %d)"
+                             % (G * N * L, w.numel()))
+        logits = torch.empty(B, N, G, device=vl.device, dtype=torch.float32)
+        _launch("object_difference_attention_fwd", (B, N, L, G, float(p_drop) > 0),
+                _lib.lib().vqa_object_difference_attention_fwd, _p(vl), _p(ql), _p(w), _p(bias), _p(logits),
+                float(p_drop), int(seed), B, N, L, G)
+        ctx.save_for_backward(vl, ql, w)
+        ctx.cfg = (float(p_drop), int(seed), G)
+        return logits
+
+    @staticmethod
+    def backward(ctx, d_logits):
+        vl, ql, w = ctx.saved_tensors
+        p_drop, seed, G = ctx.cfg
+        B, N, L = vl.shape
+        d_logits = _prep("grad_logits", d_logits)
+        d_vl, d_ql, d_w = torch.empty_like(vl), torch.empty_like(ql), torch.empty_like(w)
+        d_bias = torch.empty(G, device=vl.device, dtype=torch.float32)
+        L_ = _lib.lib()
+        ws_bytes = L_.vqa_object_difference_attention_bwd_workspace_bytes(B, N, L, G)
+        ws = torch.empty((ws_bytes + 3) // 4, device=vl.device, dtype=torch.float32)
+        _launch("object_difference_attention_bwd", (B, N, L, G, p_drop > 0), L_.vqa_object_difference_attention_bwd,
+                _p(vl), _p(ql), _p(w), _p(d_logits), _p(d_vl), _p(d_ql), _p(d_w), _p(d_bias), _p(ws), ws_bytes,
+                p_drop, seed, B, N, L, G)
+        return d_vl, d_ql, d_w, d_bias, None, None
+
+
+def object_difference_dropout_mask(B, N, L, p_drop, seed, device):
+    """The keep/(1-p) mask [B,N,N*L] exactly as K2 draws it (tests hand it to the oracle)."""
+    mask = torch.empty(B, N, N * L, device=device, dtype=torch.float32)
+    _launch("object_difference_dropout_mask", (B, N, L), _lib.lib().vqa_object_difference_dropout_mask,
+            _p(mask), float(p_drop), int(seed), B, N, L)
+    return mask
+
+
+def pairwise_relation_reduce(v, q1, q2, alpha, glimpse=0, mode=1):
+    return PairwiseRelationReduce.apply(v, q1, q2, alpha, glimpse, mode)
+
+
+def softmax_attention_pool(logits, v):
+    return SoftmaxAttentionPool.apply(logits, v)
+
+
+def lowrank_bilinear_fusion(x, h2, weights, biases):
+    return LowRankBilinearFusion.apply(x, h2, *weights, *biases)
+
+
+def object_difference_attention(vl, ql, w, bias, p_drop=0.0, seed=0):
+    return ObjectDifferenceAttention.apply(vl, ql, w, bias, p_drop, seed)

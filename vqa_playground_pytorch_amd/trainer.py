@@ -1,0 +1,104 @@
+"""Train step of the reference (train.py:41-107, :286-299, :535-548) for one process per GPU.
+
+The reference wraps the model in single-process ``nn.DataParallel`` (train.py:517): per step it scatters
+the batch, re-broadcasts every parameter, gathers logits and reduce-adds all gradients to GPU 0.  Here
+every rank owns a replica and a contiguous batch shard; the only data-path collective is ONE
+sum-all-reduce (RCCL over xGMI; ``gloo`` in the CPU tests) of a flat fp32 gradient buffer per step:
+
+  * parameter ``.grad`` tensors are views into the flat buffer, so autograd accumulates in place and no
+    gather/scatter copy is needed around the collective;
+  * SUM, not mean: the reference loss is a sum over the global batch (KLDivLoss(size_average=False),
+    train.py:541) and DataParallel adds replica gradients, so clip_grad_norm_(0.25) (train.py:82) sees
+    the same global-batch gradient on every rank;
+  * step order as train.py:63-86: forward, loss, scheduler.step(), zero_grad, backward, [all-reduce],
+    clip, optimizer.step().  lr follows ExponentialLR(gamma = 0.5 ** (1/50000)) stepped every iteration.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+
+def kld_sum_loss(logits, target):
+    """train.py:536-544: KLDivLoss(size_average=False)(F.log_softmax(logits), target)."""
+    return F.kl_div(F.log_softmax(logits, dim=1), target, reduction="sum")
+
+
+class FlatGradients:
+    """One contiguous fp32 buffer holding every parameter's gradient (views installed as p.grad)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.buffer = torch.zeros(total, device=dev, dtype=torch.float32)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.buffer[off:off + n].view_as(p)
+            off += n
+
+    def zero(self):
+        self.buffer.zero_()
+
+    def all_reduce_sum(self, group=None):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.buffer, op=dist.ReduceOp.SUM, group=group)
+
+    def clip_(self, max_norm):
+        """torch.nn.utils.clip_grad_norm_ semantics (L2, eps 1e-6) on the flat buffer; returns the norm."""
+        # accumulate in fp64: one long fp32 sum over ~12M elements is visibly (1e-3) off on some backends
+        norm = torch.linalg.vector_norm(self.buffer, dtype=torch.float64).to(torch.float32)
+        coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+        self.buffer.mul_(coef)
+        return norm
+
+
+class DataParallelTrainer:
+    """Replicated model + flat-gradient sum-all-reduce + the reference's clip/Adam/ExponentialLR."""
+
+    def __init__(self, model, lr=1e-4, clip=0.25, gamma=0.5 ** (1 / 50000), broadcast=True, group=None,
+                 fused_adam=None):
+        self.model = model
+        self.group = group
+        self.clip = clip
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        if broadcast and self.world > 1:
+            # identical initial weights on every rank, once (replaces DataParallel's per-step broadcast)
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t.data, src=0, group=group)
+        self.grads = FlatGradients(model.parameters())
+        params = self.grads.params
+        if fused_adam is None:
+            fused_adam = params[0].is_cuda
+        self.optimizer = torch.optim.Adam(params, lr=lr, fused=fused_adam) if fused_adam else torch.optim.Adam(params, lr=lr)
+        self.gamma = gamma
+        self.iteration = 0
+        self.base_lr = lr
+
+    def shard(self, tensor):
+        """This rank's contiguous slice of a global-batch tensor (rank r gets [r*B/P, (r+1)*B/P))."""
+        if self.world == 1:
+            return tensor
+        rank = dist.get_rank(self.group)
+        per = tensor.size(0) // self.world
+        return tensor[rank * per:(rank + 1) * per]
+
+    def step(self, sample, target):
+        """One training step on this rank's shard; returns (local loss tensor, global grad norm tensor)."""
+        logits = self.model(sample)
+        loss = kld_sum_loss(logits, target)
+        # scheduler.step() precedes optimizer.step() in the reference (train.py:75-86): step t uses lr0*gamma^t
+        self.iteration += 1
+        lr = self.base_lr * self.gamma ** self.iteration
+        for gp in self.optimizer.param_groups:
+            gp["lr"] = lr
+        self.grads.zero()
+        loss.backward()
+        self.grads.all_reduce_sum(self.group)
+        norm = self.grads.clip_(self.clip) if self.clip else None
+        self.optimizer.step()
+        return loss.detach(), norm
+
+    @property
+    def lr(self):
+        return self.optimizer.param_groups[0]["lr"]
