@@ -61,13 +61,11 @@ def roofline_entry(name, shape, launches, mean_ms, B):
             "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4), "traffic": None}
 
 
-def cpu_baseline(batch=32, steps=3):
-    """The reference cannot travel to the GPU box; time its op-for-op torch-CPU port (validated against the
-    reference's golden vectors in tests/) on all host cores: CoR2 fwd+bwd, dropout active."""
+def cpu_baseline_worker(batch, threads, budget_s):
+    """Runs in a child process (no GPU): CoR2 fwd+bwd of the oracle's reference-faithful torch-CPU port."""
     from oracle import reference_faithful as RF
     from oracle import seeded
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    torch.set_num_threads(threads)
     model = RF.CoR2Oracle(ANSWERS).train()
     v, q, a = (torch.from_numpy(x) for x in seeded.seeded_inputs(batch, answers=ANSWERS, seed=3))
 
@@ -75,17 +73,42 @@ def cpu_baseline(batch=32, steps=3):
         model.zero_grad(set_to_none=True)
         RF.kld_sum_loss(model({"v": v, "q": q}), a).backward()
 
-    one()
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    one()  # warm-up
+    steps, t0 = 0, time.perf_counter()
+    while steps < 2 or (time.perf_counter() - t0 < budget_s and steps < 50):
         one()
+        steps += 1
     dt = (time.perf_counter() - t0) / steps
-    return {"value": round(batch / dt, 2), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "CoR2 fwd+bwd (KLD-sum loss, dropout on), batch %d x %d steps after 1 warm-up, torch-CPU "
-                      "reference-faithful port (per-sample python loops, materialised [B,36,36,2048])" % (batch, steps)}
+    print(json.dumps({"value": round(batch / dt, 2), "unit": "samples/s", "cores": threads, "kind": "port",
+                      "sample": "CoR2 fwd+bwd (KLD-sum loss, dropout on), batch %d x %d steps after 1 warm-up; torch-CPU "
+                                "reference-faithful port (per-sample python loops, materialised [B,36,36,2048]); "
+                                "%d of the host's %d cores (more threads slow the reference's many tiny ops down)"
+                                % (batch, steps, threads, os.cpu_count() or 1)}))
+
+
+def cpu_baseline(batch=16, budget_s=12.0, hard_timeout_s=90.0):
+    """The reference cannot travel to the GPU box; time its op-for-op torch-CPU port (validated against the
+    reference's golden vectors in tests/) on the host cores.  Bounded: a child process with a hard timeout, so a
+    slow host can never stall the benchmark."""
+    import subprocess
+    threads = min(os.cpu_count() or 1, 16)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(batch), str(threads), str(budget_s)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=hard_timeout_s, env=env, cwd=ROOT)
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        if out.returncode == 0 and line:
+            return json.loads(line[-1])
+        return {"value": None, "unit": "samples/s", "cores": threads, "kind": "port",
+                "sample": "failed: rc=%d %s" % (out.returncode, out.stderr[-200:])}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "samples/s", "cores": threads, "kind": "port",
+                "sample": "did not finish 3 steps of batch %d within %.0f s" % (batch, hard_timeout_s)}
 
 
 def main():
+    if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-baseline-worker":
+        return cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -127,8 +150,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def log(msg):
+        if rank == 0 and os.environ.get("VQA_BENCH_VERBOSE"):
+            print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
+    t_start = time.perf_counter()
+    for i in range(args.warmup):
         trainer.step(sample, a)
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
+    log("warmup done")
     timer = ops.KernelTimer()
     barrier()
     ops.set_kernel_timer(timer)
@@ -138,6 +170,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ops.set_kernel_timer(None)
+    log("timed region done: %.3f s" % elapsed)
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -28,20 +28,33 @@ def rel(got, want):
     return np.abs(got - want).max() / max(np.abs(want).max(), 1e-20)
 
 
+ATOL = 1e-7  # gradients that are mathematically zero (the region-side Mutan biases and the attention-conv bias sit
+#              in front of a softmax over regions: a per-glimpse constant shift) come out as ~1e-9..1e-8 rounding
+#              noise on both sides; every other gradient here is O(1e-4..1), so 1e-7 absolute is fp32 noise
+
+
+def grad_err(got, want):
+    """max |got-want| measured against RTOL*scale + ATOL; <= 1 passes."""
+    got = got.detach().cpu().numpy().astype(np.float64) if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape and np.isfinite(got).all()
+    return np.abs(got - want).max() / (RTOL * np.abs(want).max() + ATOL)
+
+
 def check_grads(model, gold):
     worst = 0.0
     for name, p in model.named_parameters():
         gq = p.grad.detach().cpu().numpy().astype(np.float64)
         n = np.sqrt((gq ** 2).sum())
-        assert abs(n - gold["g." + name + ".norm"]) <= RTOL * max(gold["g." + name + ".norm"], 1e-12), name
-        e = rel(gq.reshape(gq.shape[0], -1)[:8, :8], gold["g." + name + ".corner"]) if np.abs(gold["g." + name + ".corner"]).max() > 0 else 0.0
-        # corners of large weight grads can be tiny relative to the tensor's scale: compare on the tensor's scale
-        scale = np.abs(gq).max()
-        e = np.abs(gq.reshape(gq.shape[0], -1)[:8, :8] - gold["g." + name + ".corner"]).max() / max(scale, 1e-20)
-        assert e <= RTOL, (name, e)
+        gn = float(gold["g." + name + ".norm"])
+        assert abs(n - gn) <= RTOL * gn + ATOL * np.sqrt(gq.size), (name, n, gn)
+        # compare elements on the tensor's own scale (a corner of a big weight grad can be tiny)
+        tol = RTOL * np.abs(gq).max() + ATOL
+        e = np.abs(gq.reshape(gq.shape[0], -1)[:8, :8] - gold["g." + name + ".corner"]).max() / tol
+        assert e <= 1.0, (name, e)
         if "g." + name + ".full" in gold.files:
-            e = rel(gq, gold["g." + name + ".full"])
-            assert e <= RTOL, (name, e)
+            e = np.abs(gq - gold["g." + name + ".full"]).max() / tol
+            assert e <= 1.0, (name, e)
         worst = max(worst, e)
     return worst
 
@@ -129,7 +142,7 @@ def test_cor2_100_regions_against_oracle():
     RF.kld_sum_loss(got, torch.from_numpy(a).to(dev())).backward()
     RF.kld_sum_loss(want, torch.from_numpy(a)).backward()
     for (n, p), (_, po) in zip(model.named_parameters(), oracle.named_parameters()):
-        assert rel(p.grad, po.grad.numpy()) <= RTOL, n
+        assert grad_err(p.grad, po.grad.numpy()) <= 1.0, n
 
 
 def test_train_mode_dropout_statistics():
