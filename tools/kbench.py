@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark of libvqa_mi355x.so at the BASELINE shapes (B=512, N=36, D=2048, L=310, H=510, G=4, R=2).
+Interleaved rounds in ONE process (guide rule 24); prints median / min per variant and the roofline fraction.
+
+    python tools/kbench.py [--only k4fwd,k1,...] [--tiles 128x128,64x64] [--rounds 20]
+"""
+import argparse
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from vqa_playground_pytorch_amd import ops  # noqa: E402
+
+B, N, D, L, H, G, R = 512, 36, 2048, 310, 510, 4, 2
+dev = torch.device("cuda:0")
+
+
+def timeit(fns, rounds, inner=5):
+    """fns: {label: callable}; returns {label: [ms per call for each round]}"""
+    out = {k: [] for k in fns}
+    for k, f in fns.items():
+        f()
+    torch.cuda.synchronize()
+    for _ in range(rounds):
+        for k, f in fns.items():
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(inner):
+                f()
+            b.record()
+            torch.cuda.synchronize()
+            out[k].append(a.elapsed_time(b) / inner)
+    return out
+
+
+def report(title, res, work, unit):
+    print("== " + title)
+    for k, ms in res.items():
+        med, mn = statistics.median(ms), min(ms)
+        if unit == "TF":
+            print("  %-28s median %8.1f us  min %8.1f us   %6.1f TF/s (%.1f%% of 157.3)" % (k, med * 1e3, mn * 1e3, work / med / 1e9, 100 * work / med / 1e9 / 157.3))
+        else:
+            print("  %-28s median %8.1f us  min %8.1f us   %6.0f GB/s (%.1f%% of 8000)" % (k, med * 1e3, mn * 1e3, work / med / 1e6, 100 * work / med / 1e6 / 8000))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--tiles", default="128x128,64x128,128x64,64x64")
+    ap.add_argument("--rounds", type=int, default=15)
+    args = ap.parse_args()
+    only = set(filter(None, args.only.split(",")))
+    want = lambda k: not only or k in only  # noqa: E731
+    tiles = args.tiles.split(",")
+    torch.manual_seed(0)
+    v = torch.randn(B, N, D, device=dev)
+    g_v = torch.randn(B, N, D, device=dev)
+    q1, q2 = torch.rand(B, D, device=dev), torch.rand(B, D, device=dev)
+    logits = torch.randn(B, N, G, device=dev)
+    alpha = torch.softmax(logits, 1)
+    x = torch.randn(B, N, L, device=dev)
+    h2 = torch.randn(B, R, H, device=dev)
+    ws = [torch.randn(H, L, device=dev) / L ** 0.5 for _ in range(R)]
+    bs = [torch.randn(H, device=dev) * 0.1 for _ in range(R)]
+    gout = torch.randn(B, N, H, device=dev)
+    gp = torch.randn(B, G, D, device=dev)
+
+    def set_tile(t):
+        if t:
+            os.environ["VQA_GEMM_TILE"] = t
+        else:
+            os.environ.pop("VQA_GEMM_TILE", None)
+
+    if want("k4fwd"):
+        fns = {}
+        for t in tiles + [""]:
+            def f(t=t):
+                set_tile(t)
+                ops.LowRankBilinearFusion.apply(x, h2, *ws, *bs)
+            fns["fwd(no h1) tile=%s" % (t or "auto")] = f
+        xr = x.clone().requires_grad_()
+        for t in tiles:
+            def f(t=t):
+                set_tile(t)
+                ops.LowRankBilinearFusion.apply(xr, h2, *ws, *bs)
+            fns["fwd(+h1)  tile=%s" % t] = f
+        report("K4 forward  (M=18432, K=310, N=2x510)", timeit(fns, args.rounds), B * (2 * R * N * L * H + 2 * R * N * H), "TF")
+        set_tile("")
+    if want("k4bwd"):
+        fns = {}
+        xr = x.clone().requires_grad_()
+        wr = [w.clone().requires_grad_() for w in ws]
+        br = [b.clone().requires_grad_() for b in bs]
+        for t in tiles + [""]:
+            set_tile(t)
+            out = ops.LowRankBilinearFusion.apply(xr, h2, *wr, *br)
+
+            def f(t=t, out=out):
+                set_tile(t)
+                torch.autograd.grad(out, [xr] + wr + br, gout, retain_graph=True)
+            fns["bwd tile=%s" % (t or "auto")] = f
+        report("K4 backward (dx + dW + dh2 + db)", timeit(fns, args.rounds), B * 4 * R * N * L * H, "TF")
+        set_tile("")
+    if want("k1"):
+        fns = {"fwd factored": lambda: ops.pairwise_relation_reduce(v, q1, q2, alpha, 0, 1),
+               "fwd pairwise": lambda: ops.pairwise_relation_reduce(v, q1, q2, alpha, 0, 0)}
+        report("K1 forward", timeit(fns, args.rounds), B * (2 * N * D + 2 * D + N) * 4, "GB")
+        q1r, q2r, ar = q1.clone().requires_grad_(), q2.clone().requires_grad_(), alpha.clone().requires_grad_()
+        out = ops.pairwise_relation_reduce(v, q1r, q2r, ar, 0, 1)
+        fns = {"bwd (no dv)": lambda: torch.autograd.grad(out, [q1r, q2r, ar], g_v, retain_graph=True)}
+        report("K1 backward", timeit(fns, args.rounds), B * (2 * N * D + 4 * D + 2 * N) * 4, "GB")
+    if want("k3"):
+        fns = {"fwd": lambda: ops.softmax_attention_pool(logits, v)}
+        report("K3 forward", timeit(fns, args.rounds), B * (N * D + 2 * N * G + G * D) * 4, "GB")
+        lr, vr = logits.clone().requires_grad_(), v.clone().requires_grad_()
+        a1, p1 = ops.softmax_attention_pool(lr, v)
+        a2, p2 = ops.softmax_attention_pool(lr, vr)
+        fns = {"bwd (no dv)": lambda: torch.autograd.grad(p1, [lr], gp, retain_graph=True),
+               "bwd (+dv)": lambda: torch.autograd.grad(p2, [lr, vr], gp, retain_graph=True)}
+        res = timeit(fns, args.rounds)
+        report("K3 backward (no dv)", {"bwd (no dv)": res["bwd (no dv)"]}, B * (N * D + G * D + 3 * N * G) * 4, "GB")
+        report("K3 backward (+dv)", {"bwd (+dv)": res["bwd (+dv)"]}, B * (2 * N * D + G * D + 3 * N * G) * 4, "GB")
+    if want("copy"):
+        y = torch.empty_like(v)
+        fns = {"torch copy 151MB": lambda: y.copy_(v)}
+        report("reference: device copy (read+write)", timeit(fns, args.rounds), 2 * v.numel() * 4, "GB")
+    if want("gemm"):
+        w = torch.randn(L, D, device=dev)
+        bias = torch.randn(L, device=dev)
+        fns = {"F.linear 18432x2048x310": lambda: torch.nn.functional.linear(v, w, bias)}
+        report("reference: hipBLASLt compress_v", timeit(fns, args.rounds), 2 * B * N * D * L, "TF")
+        w2 = torch.randn(2 * H, L, device=dev)
+        fns = {"F.linear 18432x310x1020": lambda: torch.nn.functional.linear(x, w2)}
+        report("reference: hipBLASLt K4-shaped GEMM", timeit(fns, args.rounds), 2 * B * N * L * 2 * H, "TF")
+
+
+if __name__ == "__main__":
+    main()

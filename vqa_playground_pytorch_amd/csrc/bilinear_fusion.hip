@@ -53,23 +53,25 @@ __global__ __launch_bounds__(kGemmThreads) void bilinear_fwd_kernel(const float*
     const SrcKC sb{rp.w[r], L, H, L};
     gemm_tile<BM, BN, true, true>(sa, sb, m0, n0, 0, L, smem, acc);
     const float* __restrict__ bias = rp.b[r];
+    // epilogue of rank r: total += (acc + b1_r) * h2[b(row), r, :].  The h2 / bias loads are unconditional
+    // (clamped) and issued as one batch per 32x32 tile, so they overlap instead of serialising behind branches.
 #pragma unroll
     for (int tn = 0; tn < T::TN; ++tn) {
       const int col = cc.col(tn);
-      if (col < H) {
-        const float bv = bias[col];
+      const int colc = min(col, H - 1);
+      const float bv = bias[colc];
+      const float* __restrict__ h2c = h2 + (size_t)r * H + colc;
 #pragma unroll
-        for (int tm = 0; tm < T::TM; ++tm) {
+      for (int tm = 0; tm < T::TM; ++tm) {
+        float qv[16];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int row = cc.row(tm, i);
-            if (row < M) {
-              const float hv = acc[tm][tn][i] + bv;
-              const int b = rowb_s[row - m0];
-              if (h1 != nullptr) h1[((size_t)row * R + r) * H + col] = hv;
-              total[tm][tn][i] = fmaf(hv, h2[((size_t)b * R + r) * H + col], total[tm][tn][i]);
-            }
-          }
+        for (int i = 0; i < 16; ++i) qv[i] = h2c[(size_t)rowb_s[min(cc.row(tm, i), M - 1) - m0] * (R * H)];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = cc.row(tm, i);
+          const float hv = acc[tm][tn][i] + bv;
+          if (h1 != nullptr && row < M && col < H) h1[((size_t)row * R + r) * H + col] = hv;
+          total[tm][tn][i] = fmaf(hv, qv[i], total[tm][tn][i]);
         }
       }
     }
@@ -90,32 +92,35 @@ __global__ __launch_bounds__(kGemmThreads) void bilinear_fwd_kernel(const float*
 }
 
 // --------------------------------------------------------------------------------- backward sources
+struct ScaledRaw {
+  float2 a, s;
+};
 // A[m][k=h] = g[m][h] * h2[b(m)][r][h]   (K-contiguous; the scale is applied while staging)
 struct SrcScaledKC {
+  using Raw = ScaledRaw;
   const float* g;
   const float* h2r;  // h2 + r*H
   int M, H, N, RH;
-  __device__ __forceinline__ float2 operator()(int m, int h) const {
-    if (m < M && h < H) {
-      const float2 a = ld2(g + (size_t)m * H + h);
-      const float2 s = ld2(h2r + (size_t)(m / N) * RH + h);
-      return make_float2(a.x * s.x, a.y * s.y);
-    }
-    return make_float2(0.f, 0.f);
+  __device__ __forceinline__ Raw fetch(int m, int h) const {
+    const int mc = min(m, M - 1), hc = min(h, H - 2);
+    return Raw{ld2(g + (size_t)mc * H + hc), ld2(h2r + (size_t)(mc / N) * RH + hc)};
+  }
+  __device__ __forceinline__ float2 finish(Raw v, int m, int h) const {
+    return keep_if(m < M && h < H, make_float2(v.a.x * v.s.x, v.a.y * v.s.y));
   }
 };
-// A[k=m][mn=h] = g[m][h] * h2[b(m)][r][h]   (MN-contiguous view of the same matrix, rows m in [m_lo, m_hi))
+// A[k=m][mn=h] = g[m][h] * h2[b(m)][r][h]   (MN-contiguous view of the same matrix, rows m < m_hi)
 struct SrcScaledMC {
+  using Raw = ScaledRaw;
   const float* g;
   const float* h2r;
   int m_hi, H, N, RH;
-  __device__ __forceinline__ float2 operator()(int h, int m) const {
-    if (m < m_hi && h < H) {
-      const float2 a = ld2(g + (size_t)m * H + h);
-      const float2 s = ld2(h2r + (size_t)(m / N) * RH + h);
-      return make_float2(a.x * s.x, a.y * s.y);
-    }
-    return make_float2(0.f, 0.f);
+  __device__ __forceinline__ Raw fetch(int h, int m) const {
+    const int mc = min(m, m_hi - 1), hc = min(h, H - 2);
+    return Raw{ld2(g + (size_t)mc * H + hc), ld2(h2r + (size_t)(mc / N) * RH + hc)};
+  }
+  __device__ __forceinline__ float2 finish(Raw v, int h, int m) const {
+    return keep_if(m < m_hi && h < H, make_float2(v.a.x * v.s.x, v.a.y * v.s.y));
   }
 };
 

@@ -11,7 +11,7 @@
 // its row stride is odd (BMN+1) which keeps that transposing ds_write_b32 at <= 2-way (free).  An
 // MN-contiguous source (W[k][n], g[m][h] read as [k=m][mn=h]) is written with ds_write_b64.
 //
-// Sources are functors:  float2 src(int mn, int k)  returning the two elements the calling lane stages --
+// Sources are functors (see Stager) that stage two elements per slot --
 //   K-contiguous : (mn, k) and (mn, k+1)       MN-contiguous: (k, mn) and (k, mn+1)
 // zero outside the matrix, with any prologue (e.g. the question-side scale of the bilinear backward)
 // applied on the fly.  k and mn passed to a source are always even, so even extents never straddle.
@@ -37,35 +37,38 @@ struct GemmTile {
   static constexpr int RA = BM / 32, RB = BN / 32;  // float2 registers per thread per stage
 };
 
+// A source functor provides
+//   using Raw = ...;                          what one staging slot keeps in registers while in flight
+//   Raw   fetch(int mn, int k) const;         UNCONDITIONAL loads from clamped (always valid) addresses
+//   float2 finish(Raw, int mn, int k) const;  zero outside the matrix + any prologue, applied at LDS-store time
+// Splitting fetch from finish matters: a load inside `if (in_range)` makes hipcc branch around every load and wait
+// vmcnt(0) behind each one, and a select right after the load drags the wait in front of the MFMAs -- either way
+// the stage serialises on memory latency (measured 1.3-4x on the K loop).
 template <int BMN, bool KC>
 struct Stager {
   static constexpr int NREG = BMN / 32;
   static constexpr int VPR = BMN / 2;                  // float2 per k-row of an MN-contiguous tile
   static constexpr int RPP = kGemmThreads / VPR;       // k-rows covered by one pass
+  __device__ __forceinline__ static int mn_of(int p, int tid) { return KC ? p * 32 + (tid >> 3) : 2 * (tid % VPR); }
+  __device__ __forceinline__ static int k_of(int p, int tid) { return KC ? 2 * (tid & 7) : p * RPP + tid / VPR; }
   template <class Src>
-  __device__ __forceinline__ static void load(float2 (&reg)[NREG], const Src& src, int mn0, int k0, int tid) {
-    if constexpr (KC) {
-      const int kq = tid & 7, rr = tid >> 3;
+  __device__ __forceinline__ static void load(typename Src::Raw (&reg)[NREG], const Src& src, int mn0, int k0, int tid) {
 #pragma unroll
-      for (int p = 0; p < NREG; ++p) reg[p] = src(mn0 + p * 32 + rr, k0 + 2 * kq);
-    } else {
-      const int c = tid % VPR, kr = tid / VPR;
-#pragma unroll
-      for (int p = 0; p < NREG; ++p) reg[p] = src(mn0 + 2 * c, k0 + p * RPP + kr);
-    }
+    for (int p = 0; p < NREG; ++p) reg[p] = src.fetch(mn0 + mn_of(p, tid), k0 + k_of(p, tid));
   }
-  __device__ __forceinline__ static void store(const float2 (&reg)[NREG], float* Xs, int S, int tid) {
-    if constexpr (KC) {
-      const int kq = tid & 7, rr = tid >> 3;
+  template <class Src>
+  __device__ __forceinline__ static void store(const typename Src::Raw (&reg)[NREG], const Src& src, int mn0, int k0,
+                                               float* Xs, int S, int tid) {
 #pragma unroll
-      for (int p = 0; p < NREG; ++p) {
-        Xs[(2 * kq) * S + p * 32 + rr] = reg[p].x;
-        Xs[(2 * kq + 1) * S + p * 32 + rr] = reg[p].y;
+    for (int p = 0; p < NREG; ++p) {
+      const int mn = mn_of(p, tid), k = k_of(p, tid);
+      const float2 v = src.finish(reg[p], mn0 + mn, k0 + k);
+      if constexpr (KC) {
+        Xs[k * S + mn] = v.x;
+        Xs[(k + 1) * S + mn] = v.y;
+      } else {
+        st2(&Xs[k * S + mn], v);
       }
-    } else {
-      const int c = tid % VPR, kr = tid / VPR;
-#pragma unroll
-      for (int p = 0; p < NREG; ++p) st2(&Xs[(p * RPP + kr) * S + 2 * c], reg[p]);
     }
   }
 };
@@ -83,22 +86,25 @@ __device__ __forceinline__ void gemm_tile(const SrcA& srcA, const SrcB& srcB, in
   const int a_off = (lane >> 5) * T::SA + wm * (T::TM * 32) + (lane & 31);
   const int b_off = (lane >> 5) * T::SB + wn * (T::TN * 32) + (lane & 31);
   const int nsteps = (k_end - k_begin + kBK - 1) / kBK;
-  float2 ra[T::RA], rb[T::RB];
+  typename SrcA::Raw ra[T::RA];
+  typename SrcB::Raw rb[T::RB];
   if (nsteps > 0) {
     StA::load(ra, srcA, m0, k_begin, tid);
     StB::load(rb, srcB, n0, k_begin, tid);
-    StA::store(ra, smem, T::SA, tid);
-    StB::store(rb, smem + kBK * T::SA, T::SB, tid);
+    StA::store(ra, srcA, m0, k_begin, smem, T::SA, tid);
+    StB::store(rb, srcB, n0, k_begin, smem + kBK * T::SA, T::SB, tid);
   }
   __syncthreads();
   for (int s = 0; s < nsteps; ++s) {
     const float* As = smem + (s & 1) * T::kStageFloats;
     const float* Bs = As + kBK * T::SA;
     const bool more = s + 1 < nsteps;
+    const int k_next = k_begin + (s + 1) * kBK;
     if (more) {
-      StA::load(ra, srcA, m0, k_begin + (s + 1) * kBK, tid);
-      StB::load(rb, srcB, n0, k_begin + (s + 1) * kBK, tid);
+      StA::load(ra, srcA, m0, k_next, tid);
+      StB::load(rb, srcB, n0, k_next, tid);
     }
+    __builtin_amdgcn_sched_barrier(0);  // next stage's loads are in flight; nothing below may move above them
 #pragma unroll
     for (int kp = 0; kp < kBK / 2; ++kp) {
       float a[T::TM], b[T::TN];
@@ -111,10 +117,11 @@ __device__ __forceinline__ void gemm_tile(const SrcA& srcA, const SrcB& srcB, in
 #pragma unroll
         for (int j = 0; j < T::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);  // the first use of the loaded registers (and its vmcnt wait) stays down here
     if (more) {
       float* An = smem + ((s + 1) & 1) * T::kStageFloats;
-      StA::store(ra, An, T::SA, tid);
-      StB::store(rb, An + kBK * T::SA, T::SB, tid);
+      StA::store(ra, srcA, m0, k_next, An, T::SA, tid);
+      StB::store(rb, srcB, n0, k_next, An + kBK * T::SA, T::SB, tid);
     }
     __syncthreads();
   }
@@ -145,21 +152,21 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
 }
 
 // ---- plain sources ---------------------------------------------------------------------------
-struct SrcKC {  // X[mn][k], K-contiguous rows of stride ld
+__device__ __forceinline__ float2 keep_if(bool ok, float2 v) { return make_float2(ok ? v.x : 0.f, ok ? v.y : 0.f); }
+
+struct SrcKC {  // X[mn][k], K-contiguous rows of stride ld.  Needs MN >= 1, K >= 2 (even).
+  using Raw = float2;
   const float* p;
   int ld, MN, K;
-  __device__ __forceinline__ float2 operator()(int mn, int k) const {
-    if (mn < MN && k < K) return ld2(p + (size_t)mn * ld + k);
-    return make_float2(0.f, 0.f);
-  }
+  __device__ __forceinline__ Raw fetch(int mn, int k) const { return ld2(p + (size_t)min(mn, MN - 1) * ld + min(k, K - 2)); }
+  __device__ __forceinline__ float2 finish(Raw v, int mn, int k) const { return keep_if(mn < MN && k < K, v); }
 };
-struct SrcMC {  // X[k][mn], MN-contiguous rows of stride ld
+struct SrcMC {  // X[k][mn], MN-contiguous rows of stride ld.  Needs K >= 1, MN >= 2 (even).
+  using Raw = float2;
   const float* p;
   int ld, MN, K;
-  __device__ __forceinline__ float2 operator()(int mn, int k) const {
-    if (mn < MN && k < K) return ld2(p + (size_t)k * ld + mn);
-    return make_float2(0.f, 0.f);
-  }
+  __device__ __forceinline__ Raw fetch(int mn, int k) const { return ld2(p + (size_t)min(k, K - 1) * ld + min(mn, MN - 2)); }
+  __device__ __forceinline__ float2 finish(Raw v, int mn, int k) const { return keep_if(mn < MN && k < K, v); }
 };
 
 // Host-side tile choice: fewest CU-rounds of (padded) work, mild preference for the larger tile.
