@@ -50,7 +50,7 @@ def report(title, res, work, unit):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
-    ap.add_argument("--tiles", default="128x128,64x128,128x64,64x64")
+    ap.add_argument("--tiles", default="128x128x1,128x128x2,64x128x2,64x128x3,128x64x2,128x64x3,64x64x1,64x64x2,64x64x3")
     ap.add_argument("--rounds", type=int, default=15)
     args = ap.parse_args()
     only = set(filter(None, args.only.split(",")))

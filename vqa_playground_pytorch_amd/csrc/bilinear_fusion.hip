@@ -30,12 +30,12 @@ struct RankOutPtrs {
 };
 
 // ------------------------------------------------------------------------------------------ forward
-template <int BM, int BN>
+template <int BM, int BN, int PF>
 __global__ __launch_bounds__(kGemmThreads) void bilinear_fwd_kernel(const float* __restrict__ x, int ldx, RankPtrs rp,
                                                                     const float* __restrict__ h2,
                                                                     float* __restrict__ out, float* __restrict__ h1,
                                                                     int M, int N, int L, int H, int R, int tiles_n) {
-  using T = GemmTile<BM, BN, true, true>;
+  using T = GemmTile<BM, BN, 16, true, true>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* smem = reinterpret_cast<float*>(smem_raw);
   int* rowb_s = reinterpret_cast<int*>(smem + 2 * T::kStageFloats);  // [BM] sample index of each tile row
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kGemmThreads) void bilinear_fwd_kernel(const float*
     zero_acc(acc);
     const SrcKC sa{x, ldx, M, L};
     const SrcKC sb{rp.w[r], L, H, L};
-    gemm_tile<BM, BN, true, true>(sa, sb, m0, n0, 0, L, smem, acc);
+    gemm_tile<BM, BN, 16, PF, true, true>(sa, sb, m0, n0, 0, L, smem, acc);
     const float* __restrict__ bias = rp.b[r];
     // epilogue of rank r: total += (acc + b1_r) * h2[b(row), r, :].  The h2 / bias loads are unconditional
     // (clamped) and issued as one batch per 32x32 tile, so they overlap instead of serialising behind branches.
@@ -125,11 +125,11 @@ struct SrcScaledMC {
 };
 
 // dx[m][l] = sum_r sum_h (g*h2_r)[m][h] * W1_r[h][l]
-template <int BM, int BN>
+template <int BM, int BN, int PF>
 __global__ __launch_bounds__(kGemmThreads) void bilinear_dx_kernel(const float* __restrict__ g, RankPtrs rp,
                                                                    const float* __restrict__ h2, float* __restrict__ dx,
                                                                    int M, int N, int L, int H, int R, int tiles_n) {
-  using T = GemmTile<BM, BN, true, false>;
+  using T = GemmTile<BM, BN, 16, true, false>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kGemmThreads) void bilinear_dx_kernel(const float* 
   for (int r = 0; r < R; ++r) {
     const SrcScaledKC sa{g, h2 + (size_t)r * H, M, H, N, R * H};
     const SrcMC sb{rp.w[r], L, L, H};
-    gemm_tile<BM, BN, true, false>(sa, sb, m0, n0, 0, H, smem, acc);
+    gemm_tile<BM, BN, 16, PF, true, false>(sa, sb, m0, n0, 0, H, smem, acc);
   }
   const AccCoord<BM, BN> cc(m0, n0);
 #pragma unroll
@@ -158,13 +158,14 @@ __global__ __launch_bounds__(kGemmThreads) void bilinear_dx_kernel(const float* 
 }
 
 // slab[s][r][h][l] = sum_{m in split s} (g*h2_r)[m][h] * x[m][l]
-template <int BM, int BN>
+template <int BM, int BN, int PF>
 __global__ __launch_bounds__(kGemmThreads) void bilinear_dw_kernel(const float* __restrict__ g,
                                                                    const float* __restrict__ h2,
                                                                    const float* __restrict__ x, int ldx,
-                                                                   float* __restrict__ slab, int M, int N, int L, int H,
-                                                                   int R, int tiles_n, int rows_per_split) {
-  using T = GemmTile<BM, BN, false, false>;
+                                                                   float* __restrict__ slab, float* __restrict__ dbslab,
+                                                                   int M, int N, int L, int H, int R, int tiles_n,
+                                                                   int rows_per_split) {
+  using T = GemmTile<BM, BN, 16, false, false>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -175,7 +176,21 @@ __global__ __launch_bounds__(kGemmThreads) void bilinear_dw_kernel(const float* 
   zero_acc(acc);
   const SrcScaledMC sa{g, h2 + (size_t)r * H, m_hi, H, N, R * H};
   const SrcMC sb{x, ldx, L, m_hi};
-  gemm_tile<BM, BN, false, false>(sa, sb, h0, l0, m_lo, m_hi, smem, acc);
+  float colsum[T::TM];
+#pragma unroll
+  for (int i = 0; i < T::TM; ++i) colsum[i] = 0.f;
+  gemm_tile<BM, BN, 16, PF, false, false>(sa, sb, h0, l0, m_lo, m_hi, smem, acc, colsum);
+  // db1 partial of this split: column sums of the (g*h2_r) tile; written once per tile row (first tile column,
+  // waves of the first wave column)
+  if (l0 == 0 && (threadIdx.x >> 6 & 1) == 0) {
+    const int lane = threadIdx.x & 63, wm = threadIdx.x >> 7;
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i) {
+      const float t = colsum[i] + __shfl_xor(colsum[i], 32, 64);
+      const int h = h0 + wm * (T::TM * 32) + i * 32 + (lane & 31);
+      if (lane < 32 && h < H) dbslab[((size_t)s * R + r) * H + h] = t;
+    }
+  }
   float* __restrict__ dst = slab + ((size_t)s * R + r) * H * L;
   const AccCoord<BM, BN> cc(h0, l0);
 #pragma unroll
@@ -194,10 +209,20 @@ __global__ __launch_bounds__(kGemmThreads) void bilinear_dw_kernel(const float* 
 }
 
 // d_w1[r][h][l] = sum_s slab[s][r][h][l]   (fixed order: bitwise reproducible)
-__global__ __launch_bounds__(256) void bilinear_dw_reduce_kernel(const float* __restrict__ slab, RankOutPtrs out, int HL,
-                                                                 int R, int S) {
+__global__ __launch_bounds__(256) void bilinear_dw_reduce_kernel(const float* __restrict__ slab,
+                                                                 const float* __restrict__ dbslab, RankOutPtrs out,
+                                                                 int HL, int H, int R, int S) {
   const int r = blockIdx.y;
   const int e = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (e < H) {  // bias gradient: the first H/2 lanes also fold the db partials (same fixed order)
+    float2 a = make_float2(0.f, 0.f);
+    for (int s = 0; s < S; ++s) {
+      const float2 t = ld2(dbslab + ((size_t)s * R + r) * H + e);
+      a.x += t.x;
+      a.y += t.y;
+    }
+    st2(out.b[r] + e, a);
+  }
   if (e >= HL) return;
   float2 a = make_float2(0.f, 0.f);
   for (int s = 0; s < S; ++s) {
@@ -208,24 +233,24 @@ __global__ __launch_bounds__(256) void bilinear_dw_reduce_kernel(const float* __
   st2(out.w[r] + e, a);
 }
 
-// dh2[b][r][h] = sum_n g[b,n,h] * h1[b,n,r,h];  gs[b][h] = sum_n g[b,n,h]
-__global__ __launch_bounds__(128) void bilinear_dh2_kernel(const float* __restrict__ g, const float* __restrict__ h1,
-                                                           float* __restrict__ dh2, float* __restrict__ gs, int N, int H,
-                                                           int R) {
+// dh2[b][r][h] = sum_n g[b,n,h] * h1[b,n,r,h].  grid (ceil(H/128), B); 256 lanes = 64 feature pairs x 4 region
+// slices (more loads in flight than one lane per feature pair); the slices meet in LDS.
+__global__ __launch_bounds__(256) void bilinear_dh2_kernel(const float* __restrict__ g, const float* __restrict__ h1,
+                                                           float* __restrict__ dh2, int N, int H, int R) {
+  __shared__ float2 part[3][kMaxR][64];
   const int b = blockIdx.y;
-  const int h = (blockIdx.x * 128 + threadIdx.x) * 2;
-  if (h >= H) return;
+  const int c = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int h = (blockIdx.x * 64 + c) * 2;
+  const bool active = h < H;
+  const int hc = active ? h : 0;
   float2 acc[kMaxR];
 #pragma unroll
   for (int r = 0; r < kMaxR; ++r) acc[r] = make_float2(0.f, 0.f);
-  float2 gsum = make_float2(0.f, 0.f);
-  const float* gb = g + (size_t)b * N * H + h;
-  const float* hb = h1 + (size_t)b * N * R * H + h;
-#pragma unroll 4
-  for (int n = 0; n < N; ++n) {
+  const float* gb = g + (size_t)b * N * H + hc;
+  const float* hb = h1 + (size_t)b * N * R * H + hc;
+#pragma unroll 3
+  for (int n = slice; n < N; n += 4) {
     const float2 gv = ld2(gb + (size_t)n * H);
-    gsum.x += gv.x;
-    gsum.y += gv.y;
 #pragma unroll
     for (int r = 0; r < kMaxR; ++r) {
       if (r < R) {
@@ -235,34 +260,39 @@ __global__ __launch_bounds__(128) void bilinear_dh2_kernel(const float* __restri
       }
     }
   }
+  if (slice > 0) {
 #pragma unroll
-  for (int r = 0; r < kMaxR; ++r)
-    if (r < R) st2(dh2 + ((size_t)b * R + r) * H + h, acc[r]);
-  st2(gs + (size_t)b * H + h, gsum);
-}
-
-// db1[r][h] = sum_b h2[b][r][h] * gs[b][h]
-__global__ __launch_bounds__(128) void bilinear_db_kernel(const float* __restrict__ h2, const float* __restrict__ gs,
-                                                          RankOutPtrs out, int B, int H, int R) {
-  const int r = blockIdx.y;
-  const int h = (blockIdx.x * 128 + threadIdx.x) * 2;
-  if (h >= H) return;
-  float2 a = make_float2(0.f, 0.f);
-#pragma unroll 4
-  for (int b = 0; b < B; ++b) {
-    const float2 s = ld2(h2 + ((size_t)b * R + r) * H + h);
-    const float2 t = ld2(gs + (size_t)b * H + h);
-    a.x = fmaf(s.x, t.x, a.x);
-    a.y = fmaf(s.y, t.y, a.y);
+    for (int r = 0; r < kMaxR; ++r)
+      if (r < R) part[slice - 1][r][c] = acc[r];
   }
-  st2(out.b[r] + h, a);
+  __syncthreads();
+  if (slice == 0 && active) {
+#pragma unroll
+    for (int r = 0; r < kMaxR; ++r) {
+      if (r < R) {
+        float2 t = acc[r];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          t.x += part[q][r][c].x;
+          t.y += part[q][r][c].y;
+        }
+        st2(dh2 + ((size_t)b * R + r) * H + h, t);
+      }
+    }
+  }
 }
 
 static TileChoice tile_override_or(TileChoice c) {
-  const char* e = std::getenv("VQA_GEMM_TILE");  // experiment knob, e.g. "128x64"
+  const char* e = std::getenv("VQA_GEMM_TILE");  // experiment knob, e.g. "128x64" or "64x64x3" (BM x BN [x PF])
   if (e != nullptr) {
-    int bm = 0, bn = 0;
-    if (std::sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) return {bm, bn};
+    int bm = 0, bn = 0, pf = 0;
+    const int n = std::sscanf(e, "%dx%dx%d", &bm, &bn, &pf);
+    if (n >= 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) {
+      c.bm = bm;
+      c.bn = bn;
+      c.pf = 2;
+      if (n == 3 && pf >= 1 && pf <= 3) c.pf = pf;
+    }
   }
   return c;
 }
@@ -277,23 +307,33 @@ static int splits_for_dw(int M, int H, int L, int R, TileChoice t) {
   return (int)s;
 }
 
-static TileChoice dw_tile() { return tile_override_or({128, 64}); }
+static TileChoice dw_tile() { return tile_override_or({128, 64, 2}); }
 
 }  // namespace vqa
 
 using namespace vqa;
 
-#define VQA_TILE_SWITCH(t, LAUNCH)                 \
+#define VQA_TILE_SWITCH_BK(t, LAUNCH, BK_)          \
   do {                                             \
     if ((t).bm == 128 && (t).bn == 128) {          \
-      LAUNCH(128, 128)                             \
+      LAUNCH(128, 128, BK_)                        \
     } else if ((t).bm == 64 && (t).bn == 128) {    \
-      LAUNCH(64, 128)                              \
+      LAUNCH(64, 128, BK_)                         \
     } else if ((t).bm == 128 && (t).bn == 64) {    \
-      LAUNCH(128, 64)                              \
+      LAUNCH(128, 64, BK_)                         \
     } else {                                       \
-      LAUNCH(64, 64)                               \
+      LAUNCH(64, 64, BK_)                          \
     }                                              \
+  } while (0)
+#define VQA_TILE_SWITCH(t, LAUNCH)         \
+  do {                                     \
+    if ((t).pf == 1) {                     \
+      VQA_TILE_SWITCH_BK(t, LAUNCH, 1);    \
+    } else if ((t).pf == 2) {              \
+      VQA_TILE_SWITCH_BK(t, LAUNCH, 2);    \
+    } else {                               \
+      VQA_TILE_SWITCH_BK(t, LAUNCH, 3);    \
+    }                                      \
   } while (0)
 
 static int check_common(const char* who, const void* x, int ldx, int B, int N, int L, int H, int R) {
@@ -324,10 +364,11 @@ extern "C" int vqa_lowrank_bilinear_fusion_fwd(const float* x, int ldx, const fl
   const int M = B * N;
   const TileChoice t = tile_override_or(choose_tile(M, H, 1));
   const int tiles_m = (M + t.bm - 1) / t.bm, tiles_n = (H + t.bn - 1) / t.bn;
-#define LAUNCH(BM_, BN_)                                                                                              \
+#define LAUNCH(BM_, BN_, BK_)                                                                                              \
   {                                                                                                                   \
-    const size_t lds = GemmTile<BM_, BN_, true, true>::kSmemBytes + BM_ * sizeof(int);                                \
-    hipLaunchKernelGGL((bilinear_fwd_kernel<BM_, BN_>), dim3(tiles_m * tiles_n), dim3(kGemmThreads), lds, s, x, ldx,   \
+    const size_t lds = GemmTile<BM_, BN_, 16, true, true>::kSmemBytes + BM_ * sizeof(int);                                \
+    VQA_ENSURE_LDS((bilinear_fwd_kernel<BM_, BN_, BK_>), lds);                                                        \
+    hipLaunchKernelGGL((bilinear_fwd_kernel<BM_, BN_, BK_>), dim3(tiles_m * tiles_n), dim3(kGemmThreads), lds, s, x, ldx,   \
                        rp, h2, out, h1, M, N, L, H, R, tiles_n);                                                      \
   }
   VQA_TILE_SWITCH(t, LAUNCH);
@@ -338,7 +379,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_fwd(const float* x, int ldx, const fl
 extern "C" size_t vqa_lowrank_bilinear_fusion_bwd_workspace_bytes(int B, int N, int L, int H, int R) {
   if (B <= 0 || N <= 0 || L <= 0 || H <= 0 || R <= 0 || R > kMaxR) return 0;
   const int S = splits_for_dw(B * N, H, L, R, dw_tile());
-  return ((size_t)S * R * H * L + (size_t)B * H) * sizeof(float);
+  return ((size_t)S * R * H * L + (size_t)S * R * H) * sizeof(float);
 }
 
 extern "C" int vqa_lowrank_bilinear_fusion_bwd(const float* x, int ldx, const float* const* w1, const float* h2,
@@ -368,40 +409,40 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd(const float* x, int ldx, const fl
   const TileChoice tw = dw_tile();
   const int S = splits_for_dw(M, H, L, R, tw);
   float* slab = static_cast<float*>(workspace);
-  float* gs = slab + (size_t)S * R * H * L;
+  float* dbslab = slab + (size_t)S * R * H * L;
 
-  // (1) dh2 and the per-sample column sums of g
-  hipLaunchKernelGGL(bilinear_dh2_kernel, dim3((H / 2 + 127) / 128, B), dim3(128), 0, s, g, h1, d_h2, gs, N, H, R);
-  // (2) db1
-  hipLaunchKernelGGL(bilinear_db_kernel, dim3((H / 2 + 127) / 128, R), dim3(128), 0, s, h2, gs, ro, B, H, R);
-  // (3) dx
+  // (1) dh2
+  hipLaunchKernelGGL(bilinear_dh2_kernel, dim3((H / 2 + 63) / 64, B), dim3(256), 0, s, g, h1, d_h2, N, H, R);
+  // (2) dx
   if (d_x != nullptr) {
     const TileChoice t = tile_override_or(choose_tile(M, L, 1));
     const int tiles_m = (M + t.bm - 1) / t.bm, tiles_n = (L + t.bn - 1) / t.bn;
-#define LAUNCH(BM_, BN_)                                                                                             \
+#define LAUNCH(BM_, BN_, BK_)                                                                                             \
   {                                                                                                                  \
-    const size_t lds = GemmTile<BM_, BN_, true, false>::kSmemBytes;                                                  \
-    hipLaunchKernelGGL((bilinear_dx_kernel<BM_, BN_>), dim3(tiles_m * tiles_n), dim3(kGemmThreads), lds, s, g, rp, h2, \
+    const size_t lds = GemmTile<BM_, BN_, 16, true, false>::kSmemBytes;                                                  \
+    VQA_ENSURE_LDS((bilinear_dx_kernel<BM_, BN_, BK_>), lds);                                                        \
+    hipLaunchKernelGGL((bilinear_dx_kernel<BM_, BN_, BK_>), dim3(tiles_m * tiles_n), dim3(kGemmThreads), lds, s, g, rp, h2, \
                        d_x, M, N, L, H, R, tiles_n);                                                                 \
   }
     VQA_TILE_SWITCH(t, LAUNCH);
 #undef LAUNCH
   }
-  // (4) dW1: split over rows into slabs, (5) reduce the slabs in fixed order
+  // (3) dW1 (+ db1 partials): split over rows into slabs, (4) reduce the slabs in fixed order
   {
     const int tiles_m = (H + tw.bm - 1) / tw.bm, tiles_n = (L + tw.bn - 1) / tw.bn;
     int rows_per_split = (M + S - 1) / S;
-    rows_per_split = (rows_per_split + kBK - 1) / kBK * kBK;
-#define LAUNCH(BM_, BN_)                                                                                            \
+    rows_per_split = (rows_per_split + 31) / 32 * 32;
+#define LAUNCH(BM_, BN_, BK_)                                                                                            \
   {                                                                                                                 \
-    const size_t lds = GemmTile<BM_, BN_, false, false>::kSmemBytes;                                                \
-    hipLaunchKernelGGL((bilinear_dw_kernel<BM_, BN_>), dim3(tiles_m * tiles_n, R, S), dim3(kGemmThreads), lds, s, g,  \
-                       h2, x, ldx, slab, M, N, L, H, R, tiles_n, rows_per_split);                                   \
+    const size_t lds = GemmTile<BM_, BN_, 16, false, false>::kSmemBytes;                                                \
+    VQA_ENSURE_LDS((bilinear_dw_kernel<BM_, BN_, BK_>), lds);                                                       \
+    hipLaunchKernelGGL((bilinear_dw_kernel<BM_, BN_, BK_>), dim3(tiles_m * tiles_n, R, S), dim3(kGemmThreads), lds, s, g,  \
+                       h2, x, ldx, slab, dbslab, M, N, L, H, R, tiles_n, rows_per_split);                                   \
   }
     VQA_TILE_SWITCH(tw, LAUNCH);
 #undef LAUNCH
     const int HL = H * L;
-    hipLaunchKernelGGL(bilinear_dw_reduce_kernel, dim3((HL / 2 + 255) / 256, R), dim3(256), 0, s, slab, ro, HL, R, S);
+    hipLaunchKernelGGL(bilinear_dw_reduce_kernel, dim3((HL / 2 + 255) / 256, R), dim3(256), 0, s, slab, dbslab, ro, HL, H, R, S);
   }
   return check_launch("lowrank_bilinear_fusion_bwd");
 }

@@ -2,8 +2,9 @@
 //
 // One workgroup = 256 threads = 4 waves arranged 2 x 2 over a BM x BN output tile; every wave owns
 // TM x TN = (BM/64) x (BN/64) accumulators of 32 x 32 (16 VGPRs each).  The K loop advances 16 at a
-// time through a two-stage LDS ring: global -> registers (8-byte loads, issued one stage ahead, so HBM/L2
-// latency hides under the previous stage's MFMAs) -> LDS -> MFMA operands.
+// time through a two-stage LDS ring: global -> registers (8-byte loads, issued TWO stages ahead, so HBM/L2
+// latency hides under a full stage of MFMAs) -> LDS -> MFMA operands; the staging instructions are interleaved
+// into the gaps between MFMAs with sched_group_barrier.
 //
 // LDS image (both operands): k-major, Xs[k][mn], so the 32 lanes that feed one MFMA operand row read
 // 32 consecutive dwords (ds_read_b32, conflict-free for any stride) -- lane l supplies A[i = l&31][k = l>>5]
@@ -22,19 +23,19 @@ namespace vqa {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int kBK = 16;
 constexpr int kGemmThreads = 256;
 
-template <int BM, int BN, bool A_KC, bool B_KC>
+template <int BM, int BN, int BK, bool A_KC, bool B_KC>
 struct GemmTile {
+  static_assert(BK == 16 || BK == 32, "BK must be 16 or 32");
   static_assert(BM == 64 || BM == 128, "BM must be 64 or 128");
   static_assert(BN == 64 || BN == 128, "BN must be 64 or 128");
   static constexpr int TM = BM / 64, TN = BN / 64;
   static constexpr int SA = BM + (A_KC ? 1 : 0);
   static constexpr int SB = BN + (B_KC ? 1 : 0);
-  static constexpr int kStageFloats = kBK * (SA + SB);
+  static constexpr int kStageFloats = BK * (SA + SB);
   static constexpr int kSmemBytes = 2 * kStageFloats * (int)sizeof(float);
-  static constexpr int RA = BM / 32, RB = BN / 32;  // float2 registers per thread per stage
+  static constexpr int RA = BM * BK / 512, RB = BN * BK / 512;  // float2 slots per thread per stage
 };
 
 // A source functor provides
@@ -44,13 +45,15 @@ struct GemmTile {
 // Splitting fetch from finish matters: a load inside `if (in_range)` makes hipcc branch around every load and wait
 // vmcnt(0) behind each one, and a select right after the load drags the wait in front of the MFMAs -- either way
 // the stage serialises on memory latency (measured 1.3-4x on the K loop).
-template <int BMN, bool KC>
+template <int BMN, int BK, bool KC>
 struct Stager {
-  static constexpr int NREG = BMN / 32;
+  static constexpr int NREG = BMN * BK / 512;          // float2 slots per thread per stage (256 threads)
+  static constexpr int KPR = BK / 2;                   // float2 per mn-row of a K-contiguous tile
+  static constexpr int MPP = kGemmThreads / KPR;       // mn-rows covered by one pass (K-contiguous)
   static constexpr int VPR = BMN / 2;                  // float2 per k-row of an MN-contiguous tile
-  static constexpr int RPP = kGemmThreads / VPR;       // k-rows covered by one pass
-  __device__ __forceinline__ static int mn_of(int p, int tid) { return KC ? p * 32 + (tid >> 3) : 2 * (tid % VPR); }
-  __device__ __forceinline__ static int k_of(int p, int tid) { return KC ? 2 * (tid & 7) : p * RPP + tid / VPR; }
+  static constexpr int RPP = kGemmThreads / VPR;       // k-rows covered by one pass (MN-contiguous)
+  __device__ __forceinline__ static int mn_of(int p, int tid) { return KC ? p * MPP + tid / KPR : 2 * (tid % VPR); }
+  __device__ __forceinline__ static int k_of(int p, int tid) { return KC ? 2 * (tid % KPR) : p * RPP + tid / VPR; }
   template <class Src>
   __device__ __forceinline__ static void load(typename Src::Raw (&reg)[NREG], const Src& src, int mn0, int k0, int tid) {
 #pragma unroll
@@ -75,55 +78,104 @@ struct Stager {
 
 // acc += A[m0 : m0+BM, k_begin : k_end) * B[k_begin : k_end), n0 : n0+BN].  All 256 threads call it; it
 // ends on a barrier, so the LDS ring may be reused immediately by the next call.
-template <int BM, int BN, bool A_KC, bool B_KC, class SrcA, class SrcB>
+template <int N>
+struct IntC {
+  static constexpr int value = N;
+};
+
+// a_colsum (optional): per-lane partial sums over k of the A fragments this lane fed to the MFMAs, i.e. for
+// fragment row i: sum over the k's with (k & 1) == lane >> 5 of A[k][wave_row0 + i*32 + (lane & 31)].  Adding the
+// two lane halves (shfl_xor 32) gives the column sums of the A tile -- the bias gradient of a weight-gradient GEMM
+// for one extra VALU add per fragment.
+template <int BM, int BN, int BK, int PF, bool A_KC, bool B_KC, class SrcA, class SrcB>
 __device__ __forceinline__ void gemm_tile(const SrcA& srcA, const SrcB& srcB, int m0, int n0, int k_begin, int k_end,
-                                          float* smem, f32x16 (&acc)[BM / 64][BN / 64]) {
-  using T = GemmTile<BM, BN, A_KC, B_KC>;
-  using StA = Stager<BM, A_KC>;
-  using StB = Stager<BN, B_KC>;
+                                          float* smem, f32x16 (&acc)[BM / 64][BN / 64],
+                                          float* a_colsum = nullptr) {
+  using T = GemmTile<BM, BN, BK, A_KC, B_KC>;
+  using StA = Stager<BM, BK, A_KC>;
+  using StB = Stager<BN, BK, B_KC>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int a_off = (lane >> 5) * T::SA + wm * (T::TM * 32) + (lane & 31);
   const int b_off = (lane >> 5) * T::SB + wn * (T::TN * 32) + (lane & 31);
-  const int nsteps = (k_end - k_begin + kBK - 1) / kBK;
-  typename SrcA::Raw ra[T::RA];
-  typename SrcB::Raw rb[T::RB];
+  const int nsteps = (k_end - k_begin + BK - 1) / BK;
+  // Pipeline (PF register sets in flight, two LDS stages, one barrier per stage):
+  //   stage s:  read all fragments of LDS[s&1]  ->  MFMA chain of stage s, with, in the shadow of the MFMAs,
+  //             { finish + ds_write of the register set holding stage s+1 into LDS[(s+1)&1] ; global loads of
+  //               stage s+1+PF into that same set }  ->  barrier.
+  // Every global load therefore has PF full stages of MFMAs to land (measured load-to-use latency under load is
+  // ~1.5 us, i.e. more than one 64x64 stage), and the staging instructions issue in the 64-cycle gaps between
+  // v_mfma_f32_32x32x2_f32 instead of in a serial phase of their own.  Set indices are compile-time (the stage
+  // loop is unrolled by PF) so the sets stay in registers.
+  typename SrcA::Raw ra[PF][T::RA];
+  typename SrcB::Raw rb[PF][T::RB];
   if (nsteps > 0) {
-    StA::load(ra, srcA, m0, k_begin, tid);
-    StB::load(rb, srcB, n0, k_begin, tid);
-    StA::store(ra, srcA, m0, k_begin, smem, T::SA, tid);
-    StB::store(rb, srcB, n0, k_begin, smem + kBK * T::SA, T::SB, tid);
+    StA::load(ra[0], srcA, m0, k_begin, tid);
+    StB::load(rb[0], srcB, n0, k_begin, tid);
+    StA::store(ra[0], srcA, m0, k_begin, smem, T::SA, tid);
+    StB::store(rb[0], srcB, n0, k_begin, smem + BK * T::SA, T::SB, tid);
+#pragma unroll
+    for (int t = 1; t <= PF; ++t) {  // stage t -> set t % PF  (clamped loads: harmless past the end)
+      StA::load(ra[t % PF], srcA, m0, k_begin + t * BK, tid);
+      StB::load(rb[t % PF], srcB, n0, k_begin + t * BK, tid);
+    }
   }
   __syncthreads();
-  for (int s = 0; s < nsteps; ++s) {
+  auto stage = [&](int s, auto set_c) {
+    constexpr int q = decltype(set_c)::value;  // set holding stage s+1
     const float* As = smem + (s & 1) * T::kStageFloats;
-    const float* Bs = As + kBK * T::SA;
-    const bool more = s + 1 < nsteps;
-    const int k_next = k_begin + (s + 1) * kBK;
-    if (more) {
-      StA::load(ra, srcA, m0, k_next, tid);
-      StB::load(rb, srcB, n0, k_next, tid);
+    const float* Bs = As + BK * T::SA;
+    float a[BK / 2][T::TM], b[BK / 2][T::TN];
+#pragma unroll
+    for (int kp = 0; kp < BK / 2; ++kp) {
+#pragma unroll
+      for (int i = 0; i < T::TM; ++i) a[kp][i] = As[kp * 2 * T::SA + a_off + i * 32];
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j) b[kp][j] = Bs[kp * 2 * T::SB + b_off + j * 32];
     }
-    __builtin_amdgcn_sched_barrier(0);  // next stage's loads are in flight; nothing below may move above them
+    __builtin_amdgcn_sched_barrier(0);  // fragment reads stay above; everything below is interleaved by the groups
 #pragma unroll
-    for (int kp = 0; kp < kBK / 2; ++kp) {
-      float a[T::TM], b[T::TN];
-#pragma unroll
-      for (int i = 0; i < T::TM; ++i) a[i] = As[kp * 2 * T::SA + a_off + i * 32];
-#pragma unroll
-      for (int j = 0; j < T::TN; ++j) b[j] = Bs[kp * 2 * T::SB + b_off + j * 32];
+    for (int kp = 0; kp < BK / 2; ++kp)
 #pragma unroll
       for (int i = 0; i < T::TM; ++i)
 #pragma unroll
-        for (int j = 0; j < T::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < T::TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp][i], b[kp][j], acc[i][j], 0, 0, 0);
+    if (a_colsum != nullptr) {
+#pragma unroll
+      for (int kp = 0; kp < BK / 2; ++kp)
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i) a_colsum[i] += a[kp][i];
     }
-    __builtin_amdgcn_sched_barrier(0);  // the first use of the loaded registers (and its vmcnt wait) stays down here
-    if (more) {
+    {
+      // Unconditional on purpose: a branch here would split the basic block and nothing could be interleaved with
+      // the MFMAs.  Past the last stage the loads hit clamped (valid) addresses, `finish` zero-fills, and the
+      // LDS stage written is not read again before the next call's prologue overwrites it.
       float* An = smem + ((s + 1) & 1) * T::kStageFloats;
-      StA::store(ra, srcA, m0, k_next, An, T::SA, tid);
-      StB::store(rb, srcB, n0, k_next, An + kBK * T::SA, T::SB, tid);
+      const int k_next = k_begin + (s + 1) * BK;
+      StA::store(ra[q], srcA, m0, k_next, An, T::SA, tid);
+      StB::store(rb[q], srcB, n0, k_next, An + BK * T::SA, T::SB, tid);
+      StA::load(ra[q], srcA, m0, k_next + PF * BK, tid);
+      StB::load(rb[q], srcB, n0, k_next + PF * BK, tid);
+    }
+    // one MFMA, then a few of the staging instructions, repeated: DS writes, VALU (selects, addresses), VMEM reads
+#pragma unroll
+    for (int g = 0; g < (BK / 2) * T::TM * T::TN; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);  // DS write
+      __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // VALU
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);  // VMEM read
     }
     __syncthreads();
+  };
+  for (int s = 0; s < nsteps; s += PF) {
+    stage(s, IntC<1 % PF>{});
+    if constexpr (PF > 1) {
+      if (s + 1 < nsteps) stage(s + 1, IntC<2 % PF>{});
+    }
+    if constexpr (PF > 2) {
+      if (s + 2 < nsteps) stage(s + 2, IntC<3 % PF>{});
+    }
   }
 }
 
@@ -171,13 +223,13 @@ struct SrcMC {  // X[k][mn], MN-contiguous rows of stride ld.  Needs K >= 1, MN 
 
 // Host-side tile choice: fewest CU-rounds of (padded) work, mild preference for the larger tile.
 struct TileChoice {
-  int bm, bn;
+  int bm, bn, pf;  // tile rows, tile cols, prefetch distance in stages (register sets in flight)
 };
 inline TileChoice choose_tile(long M, long N, long splits) {
   const int cand[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
-  const double pref[4] = {1.00, 1.04, 1.04, 1.10};
+  const double pref[4] = {1.35, 1.15, 1.25, 1.00};  // measured: the 64x64 tile (4 workgroups per CU) wins at these K
   double best = 1e300;
-  TileChoice out{128, 128};
+  TileChoice out{128, 128, 2};
   for (int c = 0; c < 4; ++c) {
     const long tm = (M + cand[c][0] - 1) / cand[c][0], tn = (N + cand[c][1] - 1) / cand[c][1];
     const long tiles = tm * tn * splits;
@@ -185,7 +237,7 @@ inline TileChoice choose_tile(long M, long N, long splits) {
     const double cost = (double)rounds * cand[c][0] * cand[c][1] * pref[c];
     if (cost < best) {
       best = cost;
-      out = {cand[c][0], cand[c][1]};
+      out = {cand[c][0], cand[c][1], 2};
     }
   }
   return out;
