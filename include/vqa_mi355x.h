@@ -56,7 +56,7 @@ const char* vqa_last_error(void);
  * mode 0 = pairwise: the N*N inner sum is evaluated term by term from the LDS-staged region tile
  *          (the reference's summation structure);
  * mode 1 = factored: q1*(sum_i alpha_i v_i) + (sum_i alpha_i)*q2*v_j -- the same value, one pass.
- * Limits: D % 4 == 0, 16-byte aligned v/q1/q2/v2, N <= 160.
+ * Limits: D % 4 == 0, 16-byte aligned v/q1/q2/v2, N <= 144.
  * ------------------------------------------------------------------------------------------- */
 int vqa_pairwise_relation_reduce_fwd(const float* v, const float* q1, const float* q2,
                                      const float* alpha, int alpha_stride, float* v2,
@@ -146,6 +146,31 @@ int vqa_object_difference_attention_bwd(const float* vl, const float* ql, const 
 
 int vqa_object_difference_dropout_mask(float* mask, float p_drop, uint64_t seed, int B, int N, int L,
                                        vqa_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K5  fused dropout + linear + bias + activation on the fp32 MFMA tile engine.
+ * Replaces MyConv1d.forward with kernel_size 1 (config/CoR2.py:72-88: F.dropout, transpose, nn.Conv1d,
+ * transpose, F.relu) as used by compress_v / compress_v2 (config/CoR2.py:168-169,213,218) -- and, being a
+ * plain  act(drop(x) W^T + b), MyLinear.forward (config/CoR2.py:106-121) as well.
+ *
+ *   y[m,:] = act( (x[m,:] * keep(m,:)) W^T + bias )        x [M,K] row stride ldx; w [N,K]; y [M,N] dense
+ *
+ * act: 0 = none, 1 = relu.  keep() as in K2: 1 when p_drop == 0, else 0 or 1/(1-p) from the counter hash of
+ * (seed, m*K+k); vqa_linear_dropout_mask writes it as fp32 [M,K] for tests.  bias may be NULL.
+ * Limits: K, N, ldx even; 8-byte aligned pointers.
+ * ------------------------------------------------------------------------------------------- */
+int vqa_linear_act_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int M, int K,
+                       int N, int act, float p_drop, uint64_t seed, vqa_stream_t stream);
+
+size_t vqa_linear_act_bwd_workspace_bytes(int M, int K, int N);
+
+/* Backward of K5.  y = the forward output (its sign is the relu mask); gy = dL/dy [M,N].  Outputs (overwritten):
+ * d_x [M,K] dense or NULL, d_w [N,K], d_b [N] or NULL.  Same (p_drop, seed) as the forward. */
+int vqa_linear_act_bwd(const float* x, int ldx, const float* w, const float* y, const float* gy, float* d_x,
+                       float* d_w, float* d_b, void* workspace, size_t workspace_bytes, int M, int K, int N,
+                       int act, float p_drop, uint64_t seed, vqa_stream_t stream);
+
+int vqa_linear_dropout_mask(float* mask, float p_drop, uint64_t seed, int M, int K, vqa_stream_t stream);
 
 #ifdef __cplusplus
 }

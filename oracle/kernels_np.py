@@ -122,3 +122,27 @@ def object_difference_logits_bwd(vl, ql, w, dlogits, mask=None):
     dd = dvq * ql[:, None, None, :]                                            # dL/ddiff [B,i,j,L]
     dvl = dd.sum(axis=2) - dd.sum(axis=1)
     return dvl, dql, dw, dbias
+
+
+# --------------------------------------------------------------------------------------
+# K5  dropout + linear + bias + activation   (config/CoR2.py:72-88 MyConv1d k=1; :106-121 MyLinear)
+# --------------------------------------------------------------------------------------
+def linear_act_fwd(x, w, bias, act=None, mask=None):
+    """x [M,K], w [N,K], bias [N] or None, mask [M,K] (keep/(1-p)) or None -> y [M,N] = act((x*mask) w^T + b)."""
+    x, w = np.asarray(x, F64), np.asarray(w, F64)
+    xd = x if mask is None else x * np.asarray(mask, F64)
+    z = xd @ w.T
+    if bias is not None:
+        z = z + np.asarray(bias, F64)
+    return np.maximum(z, 0.0) if act == "relu" else z
+
+
+def linear_act_bwd(x, w, y, gy, act=None, mask=None):
+    """-> (dx [M,K], dw [N,K], db [N]); y is the forward output (its sign is the relu mask)."""
+    x, w, y, gy = (np.asarray(a, F64) for a in (x, w, y, gy))
+    m = 1.0 if mask is None else np.asarray(mask, F64)
+    gz = gy * (y > 0) if act == "relu" else gy
+    dx = (gz @ w) * m
+    dw = gz.T @ (x * m)
+    db = gz.sum(axis=0)
+    return dx, dw, db

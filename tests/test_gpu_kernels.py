@@ -275,3 +275,54 @@ def test_object_difference_mask_is_unbiased(ops):
     a, b2 = m[:, 0::4].flatten(), m[:, 1::4].flatten()
     corr = ((a - a.mean()) * (b2 - b2.mean())).mean() / (a.std() * b2.std())
     assert abs(corr.item()) < 5e-3
+
+
+# ----------------------------------------------------------------------------------------------- K5
+@pytest.mark.parametrize("M,Kd,N,act", [(15, 8, 6, "relu"), (144, 2048, 310, "relu"), (180, 70, 130, None),
+                                        (1, 2, 2, "relu"), (700, 510, 4, None), (333, 310, 2048, "relu")])
+@pytest.mark.parametrize("p", [0.0, 0.5])
+def test_linear_act(ops, M, Kd, N, act, p):
+    seed = 4242
+    x = seeded.seeded_array((M, Kd), 501)
+    w = seeded.seeded_array((N, Kd), 502, scale=1.0 / np.sqrt(Kd))
+    b = seeded.seeded_array((N,), 503, scale=0.1)
+    gy = seeded.seeded_array((M, N), 504)
+    mask = None
+    if p > 0:
+        mask = ops.linear_dropout_mask(M, Kd, p, seed, dev()).cpu().numpy()
+        assert set(np.unique(mask)).issubset({0.0, np.float32(2.0)})
+        if M * Kd > 5000:
+            assert abs((mask > 0).mean() - 0.5) < 0.02
+    xt, wt, bt = g(x, True), g(w, True), g(b, True)
+    y = ops.linear_act(xt, wt, bt, act, p, seed)
+    y_np = K.linear_act_fwd(x, w, b, act, mask)
+    close("y", y, y_np)
+    y.backward(g(gy))
+    # use the GPU's own y for the relu mask: elements within rounding of 0 could flip between fp32 and fp64
+    dx, dw, db = K.linear_act_bwd(x, w, y.detach().cpu().numpy(), gy, act, mask)
+    close("d_x", xt.grad, dx)
+    close("d_w", wt.grad, dw)
+    close("d_b", bt.grad, db)
+
+
+def test_linear_act_3d_no_bias_no_dx(ops):
+    x = seeded.seeded_array((3, 36, 64), 511)
+    w = seeded.seeded_array((10, 64), 512, scale=0.125)
+    xt, wt = g(x), g(w, True)
+    y = ops.linear_act(xt, wt, None, "relu")
+    assert y.shape == (3, 36, 10)
+    close("y", y.reshape(108, 10), K.linear_act_fwd(x.reshape(108, 64), w, None, "relu"))
+    y.sum().backward()
+    _, dw, _ = K.linear_act_bwd(x.reshape(108, 64), w, y.detach().cpu().numpy().reshape(108, 10), np.ones((108, 10)), "relu")
+    close("d_w", wt.grad, dw)
+
+
+def test_linear_act_full_size_vs_fp64(ops):
+    """compress_v at B=512: [18432,2048] x [2048,310] against an fp64 matmul on the GPU."""
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(512 * 36, 2048, generator=gen).to(dev())
+    w = (torch.randn(310, 2048, generator=gen) / 2048 ** 0.5).to(dev())
+    b = (0.1 * torch.randn(310, generator=gen)).to(dev())
+    y = ops.linear_act(x, w, b, "relu")
+    ref = torch.relu(x.double() @ w.double().t() + b.double())
+    assert (y.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()

@@ -124,6 +124,34 @@ def main():
         res = timeit(fns, args.rounds)
         report("K3 backward (no dv)", {"bwd (no dv)": res["bwd (no dv)"]}, B * (N * D + G * D + 3 * N * G) * 4, "GB")
         report("K3 backward (+dv)", {"bwd (+dv)": res["bwd (+dv)"]}, B * (2 * N * D + G * D + 3 * N * G) * 4, "GB")
+    if want("k5"):
+        w = torch.randn(L, D, device=dev) / D ** 0.5
+        bias = torch.randn(L, device=dev) * 0.1
+        fns = {}
+        for t in tiles + [""]:
+            def f(t=t):
+                set_tile(t)
+                ops.LinearAct.apply(v, w, bias, 1, 0.0, 0)
+            fns["fwd p=0 tile=%s" % (t or "auto")] = f
+        def fd():
+            set_tile("")
+            ops.LinearAct.apply(v, w, bias, 1, 0.5, 77)
+        fns["fwd p=0.5 tile=auto"] = fd
+        fns["torch: dropout+F.linear+relu"] = lambda: torch.relu(torch.nn.functional.linear(torch.nn.functional.dropout(v, 0.5, True), w, bias))
+        report("K5 forward (compress_v: M=18432, K=2048, N=310)", timeit(fns, args.rounds), 2 * B * N * D * L, "TF")
+        set_tile("")
+        vr = v.clone().requires_grad_()
+        wr, br = w.clone().requires_grad_(), bias.clone().requires_grad_()
+        gy = torch.randn(B, N, L, device=dev)
+        y1 = ops.LinearAct.apply(v, wr, br, 1, 0.5, 77)
+        y2 = ops.LinearAct.apply(vr, wr, br, 1, 0.5, 77)
+        yt = torch.relu(torch.nn.functional.linear(torch.nn.functional.dropout(vr, 0.5, True), wr, br))
+        fns = {"bwd dW+db (no dx)": lambda: torch.autograd.grad(y1, [wr, br], gy, retain_graph=True),
+               "bwd dW+db+dx": lambda: torch.autograd.grad(y2, [vr, wr, br], gy, retain_graph=True),
+               "torch bwd dW+db+dx": lambda: torch.autograd.grad(yt, [vr, wr, br], gy, retain_graph=True)}
+        res = timeit(fns, args.rounds)
+        report("K5 backward, dW only", {"bwd dW+db (no dx)": res["bwd dW+db (no dx)"]}, 2 * B * N * D * L, "TF")
+        report("K5 backward, dW + dx", {k: res[k] for k in ("bwd dW+db+dx", "torch bwd dW+db+dx")}, 4 * B * N * D * L, "TF")
     if want("copy"):
         y = torch.empty_like(v)
         fns = {"torch copy 151MB": lambda: y.copy_(v)}

@@ -39,6 +39,11 @@ SIGNATURES = {
     "vqa_object_difference_attention_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz,
                                                    _c_fl, _c_u64, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_object_difference_dropout_mask": (_c_i, [_c_f, _c_fl, _c_u64, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_linear_act_fwd": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_fl, _c_u64, _c_st]),
+    "vqa_linear_act_bwd_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i]),
+    "vqa_linear_act_bwd": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz,
+                                  _c_i, _c_i, _c_i, _c_i, _c_fl, _c_u64, _c_st]),
+    "vqa_linear_dropout_mask": (_c_i, [_c_f, _c_fl, _c_u64, _c_i, _c_i, _c_st]),
 }
 
 _lock = threading.Lock()

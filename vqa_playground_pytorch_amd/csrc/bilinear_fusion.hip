@@ -12,8 +12,6 @@
 //             dW1_r = (g * h2_r)^T x     (split over M, slabs reduced in fixed order) 2*M*H*L*R FLOP
 //             dh2[b,r,:] = sum_n g[b,n,:] * h1[b,n,r,:] ;  db1_r = sum_b h2[b,r,:] * sum_n g[b,n,:]
 // (g * h2_r) is never materialised: it is formed while the A tile is staged.
-#include <cstdlib>
-
 #include "gemm_f32_mfma.hpp"
 
 namespace vqa {
@@ -282,21 +280,6 @@ __global__ __launch_bounds__(256) void bilinear_dh2_kernel(const float* __restri
   }
 }
 
-static TileChoice tile_override_or(TileChoice c) {
-  const char* e = std::getenv("VQA_GEMM_TILE");  // experiment knob, e.g. "128x64" or "64x64x3" (BM x BN [x PF])
-  if (e != nullptr) {
-    int bm = 0, bn = 0, pf = 0;
-    const int n = std::sscanf(e, "%dx%dx%d", &bm, &bn, &pf);
-    if (n >= 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) {
-      c.bm = bm;
-      c.bn = bn;
-      c.pf = 2;
-      if (n == 3 && pf >= 1 && pf <= 3) c.pf = pf;
-    }
-  }
-  return c;
-}
-
 static int splits_for_dw(int M, int H, int L, int R, TileChoice t) {
   const long tiles = (long)((H + t.bm - 1) / t.bm) * ((L + t.bn - 1) / t.bn) * R;
   long s = (768 + tiles - 1) / tiles;
@@ -312,29 +295,6 @@ static TileChoice dw_tile() { return tile_override_or({128, 64, 2}); }
 }  // namespace vqa
 
 using namespace vqa;
-
-#define VQA_TILE_SWITCH_BK(t, LAUNCH, BK_)          \
-  do {                                             \
-    if ((t).bm == 128 && (t).bn == 128) {          \
-      LAUNCH(128, 128, BK_)                        \
-    } else if ((t).bm == 64 && (t).bn == 128) {    \
-      LAUNCH(64, 128, BK_)                         \
-    } else if ((t).bm == 128 && (t).bn == 64) {    \
-      LAUNCH(128, 64, BK_)                         \
-    } else {                                       \
-      LAUNCH(64, 64, BK_)                          \
-    }                                              \
-  } while (0)
-#define VQA_TILE_SWITCH(t, LAUNCH)         \
-  do {                                     \
-    if ((t).pf == 1) {                     \
-      VQA_TILE_SWITCH_BK(t, LAUNCH, 1);    \
-    } else if ((t).pf == 2) {              \
-      VQA_TILE_SWITCH_BK(t, LAUNCH, 2);    \
-    } else {                               \
-      VQA_TILE_SWITCH_BK(t, LAUNCH, 3);    \
-    }                                      \
-  } while (0)
 
 static int check_common(const char* who, const void* x, int ldx, int B, int N, int L, int H, int R) {
   VQA_REQUIRE(B > 0 && N > 0 && L > 0 && H > 0 && R > 0, VQA_E_BADARG, "%s: bad sizes B=%d N=%d L=%d H=%d R=%d", who, B, N,

@@ -86,4 +86,52 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
 
+// ---- counter-based dropout (shared by K2 and the fused linear) ---------------------------------
+// One 32-bit hash word serves four mask elements, one byte each: keep iff byte >= p8, so the drop
+// probability is realised as round(p*256)/256 (p = 0.5 is exact) and kept values are scaled by
+// 256/(256-p8).  Forward and backward regenerate identical masks from (seed, element index).
+// lowbias32 finaliser (two 32-bit multiplies -- v_mul_lo_u32 is quarter rate, so multiplies are what a hash costs
+// here).  A bijection of the 32-bit counter xor-ed with a per-call key, so distinct elements never share a word.
+__device__ __forceinline__ uint32_t mask_word32(uint32_t counter, uint32_t key) {
+  uint32_t x = counter ^ key;
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
+}
+// 64-bit counters (K2 at very large batches): the high half perturbs the key
+__device__ __forceinline__ uint32_t mask_word(uint64_t counter, uint64_t seed) {
+  const uint32_t hi = (uint32_t)(counter >> 32);
+  const uint32_t key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u) ^ (hi * 0x85EBCA6Bu);
+  return mask_word32((uint32_t)counter, key);
+}
+struct DropCfg {
+  uint32_t p8;   // drop when byte < p8
+  float scale;   // 256 / (256 - p8)
+  uint64_t seed;
+};
+
+inline DropCfg make_drop(float p, uint64_t seed) {
+  int p8 = (int)(p * 256.f + 0.5f);
+  if (p8 < 0) p8 = 0;
+  if (p8 > 255) p8 = 255;
+  return DropCfg{(uint32_t)p8, 256.f / (256.f - (float)p8), seed};
+}
+
+
+// multipliers for the two consecutive elements e (even) and e+1 of a row-major tensor with < 2^32 elements
+__device__ __forceinline__ uint32_t drop_key(const DropCfg& dc) {
+  return (uint32_t)dc.seed ^ ((uint32_t)(dc.seed >> 32) * 0x9E3779B9u);
+}
+__device__ __forceinline__ float drop_one(uint32_t e, const DropCfg& dc) {
+  const uint32_t w = mask_word32(e >> 2, drop_key(dc)) >> (8 * (e & 3));
+  return (w & 255u) >= dc.p8 ? dc.scale : 0.f;
+}
+__device__ __forceinline__ float2 drop_pair(uint32_t e, const DropCfg& dc) {
+  const uint32_t w = mask_word32(e >> 2, drop_key(dc)) >> (8 * (e & 3));
+  return make_float2((w & 255u) >= dc.p8 ? dc.scale : 0.f, ((w >> 8) & 255u) >= dc.p8 ? dc.scale : 0.f);
+}
+
 }  // namespace vqa

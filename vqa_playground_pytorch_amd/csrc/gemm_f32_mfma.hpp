@@ -17,6 +17,8 @@
 // zero outside the matrix, with any prologue (e.g. the question-side scale of the bilinear backward)
 // applied on the fly.  k and mn passed to a source are always even, so even extents never straddle.
 #pragma once
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace vqa {
@@ -163,7 +165,7 @@ __device__ __forceinline__ void gemm_tile(const SrcA& srcA, const SrcB& srcB, in
     for (int g = 0; g < (BK / 2) * T::TM * T::TN; ++g) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
       __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);  // DS write
-      __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // VALU
+      __builtin_amdgcn_sched_group_barrier(0x002, 12, 0); // VALU
       __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);  // VMEM read
     }
     __syncthreads();
@@ -243,4 +245,44 @@ inline TileChoice choose_tile(long M, long N, long splits) {
   return out;
 }
 
+inline TileChoice tile_override_or(TileChoice c) {
+  const char* e = std::getenv("VQA_GEMM_TILE");  // experiment knob, e.g. "128x64" or "64x64x3" (BM x BN [x PF])
+  if (e != nullptr) {
+    int bm = 0, bn = 0, pf = 0;
+    const int n = std::sscanf(e, "%dx%dx%d", &bm, &bn, &pf);
+    if (n >= 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) {
+      c.bm = bm;
+      c.bn = bn;
+      c.pf = 2;
+      if (n == 3 && pf >= 1 && pf <= 3) c.pf = pf;
+    }
+  }
+  return c;
+}
+
+
 }  // namespace vqa
+
+#define VQA_TILE_SWITCH_BK(t, LAUNCH, BK_)          \
+  do {                                             \
+    if ((t).bm == 128 && (t).bn == 128) {          \
+      LAUNCH(128, 128, BK_)                        \
+    } else if ((t).bm == 64 && (t).bn == 128) {    \
+      LAUNCH(64, 128, BK_)                         \
+    } else if ((t).bm == 128 && (t).bn == 64) {    \
+      LAUNCH(128, 64, BK_)                         \
+    } else {                                       \
+      LAUNCH(64, 64, BK_)                          \
+    }                                              \
+  } while (0)
+#define VQA_TILE_SWITCH(t, LAUNCH)         \
+  do {                                     \
+    if ((t).pf == 1) {                     \
+      VQA_TILE_SWITCH_BK(t, LAUNCH, 1);    \
+    } else if ((t).pf == 2) {              \
+      VQA_TILE_SWITCH_BK(t, LAUNCH, 2);    \
+    } else {                               \
+      VQA_TILE_SWITCH_BK(t, LAUNCH, 3);    \
+    }                                      \
+  } while (0)
+

@@ -21,38 +21,12 @@ namespace vqa {
 constexpr int kOdaMaxG = 8;
 constexpr int kIC = 12;  // regions i (forward, dT) or j (dW) kept in registers per workgroup pass
 
-__device__ __forceinline__ uint32_t mask_word(uint64_t counter, uint64_t seed) {
-  uint32_t x = (uint32_t)counter ^ (uint32_t)seed;
-  const uint32_t y = (uint32_t)(counter >> 32) ^ (uint32_t)(seed >> 32);
-  x ^= y * 0x9E3779B1u + 0x7F4A7C15u;
-  x ^= x >> 16;
-  x *= 0x85EBCA6Bu;
-  x ^= x >> 13;
-  x *= 0xC2B2AE35u;
-  x ^= x >> 16;
-  x *= 0x27D4EB2Fu;
-  x ^= x >> 15;
-  return x;
-}
 // element (b, i, j, d): word index ((b*NQ + i/4)*N + j)*L + d, byte i%4
 __device__ __forceinline__ uint64_t mask_counter(int b, int iq, int j, int d, int NQ, int N, int L) {
   return (((uint64_t)b * NQ + iq) * N + j) * L + d;
 }
 __device__ __forceinline__ float keep_scale(uint32_t word, int k, uint32_t p8, float scale) {
   return ((word >> (8 * k)) & 255u) >= p8 ? scale : 0.f;
-}
-
-struct DropCfg {
-  uint32_t p8;   // drop when byte < p8
-  float scale;   // 256 / (256 - p8)
-  uint64_t seed;
-};
-
-static DropCfg make_drop(float p, uint64_t seed) {
-  int p8 = (int)(p * 256.f + 0.5f);
-  if (p8 < 0) p8 = 0;
-  if (p8 > 255) p8 = 255;
-  return DropCfg{(uint32_t)p8, 256.f / (256.f - (float)p8), seed};
 }
 
 // ------------------------------------------------------------------------------------------ forward

@@ -12,6 +12,8 @@ in hand-written HIP kernels through libvqa_mi355x.so (ops.py).  Plain dense GEMM
 star does not name (MyLinear / MyConv1d projections) go to rocBLAS/hipBLASLt through F.linear.
 There is no CPU path: GPU tensors only.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -117,7 +119,19 @@ class MyConv1d(nn.Module):
             x = F.dropout(x, p=self.p, training=self.training)
         return F.linear(x, self.conv.weight.squeeze(-1), self.conv.bias)
 
+    # K5 (fused dropout+GEMM+bias+relu on the hand-written fp32 MFMA engine) vs the library GEMM: set per process
+    # with VQA_FUSED_LINEAR=0/1; the default is whichever measured faster in situ (see profiles/README.md)
+    fused = os.environ.get("VQA_FUSED_LINEAR", "0") == "1"
+
     def forward(self, x):
+        if self.fused and self.af in (None, "relu") and x.dim() == 3 and x.is_cuda and self.out_channels >= 32 \
+                and x.size(0) * x.size(1) >= 1024:
+            # large region-side projection (compress_v / compress_v2): dropout + GEMM + bias + relu in ONE kernel
+            # on the fp32 MFMA tile engine (K5); the dropout mask is a counter hash keyed by a seed drawn from
+            # torch's CPU generator, so torch.manual_seed governs it and no mask tensor exists
+            p = self.p if (self.training and self.p) else 0.0
+            seed = int(torch.randint(0, 2 ** 62, (1,), device="cpu").item()) if p else 0
+            return ops.linear_act(x, self.conv.weight.squeeze(-1), self.conv.bias, self.af, p, seed)
         return _activation(self.pre_activation(x), self.af, self.dim)
 
 

@@ -239,6 +239,56 @@ class ObjectDifferenceAttention(torch.autograd.Function):
         return d_vl, d_ql, d_w, d_bias, None, None
 
 
+class LinearAct(torch.autograd.Function):
+    """K5.  y = act(dropout_p(x) W^T + b) on the fp32 MFMA tile engine; act in {None, 'relu'}.
+    Replaces MyConv1d(k=1).forward (config/CoR2.py:72-88) / MyLinear.forward (config/CoR2.py:106-121)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, act, p_drop, seed):
+        x, w = _prep("x", x), _prep("w", w)
+        bias = _prep("bias", bias) if bias is not None else None
+        K = x.shape[-1]
+        M = x.numel() // K
+        N = w.shape[0]
+        if w.shape != (N, K) or (bias is not None and bias.shape != (N,)):
+            raise ValueError("linear_act: weight must be [N,K] = [%d,%d], bias [N]" % (N, K))
+        y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+        _launch("linear_act_fwd", (M, K, N, float(p_drop) > 0), _lib.lib().vqa_linear_act_fwd,
+                _p(x), K, _p(w), _p(bias), _p(y), M, K, N, int(act), float(p_drop), int(seed))
+        ctx.save_for_backward(x, w, y)
+        ctx.cfg = (M, K, N, int(act), float(p_drop), int(seed), bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        M, K, N, act, p_drop, seed, has_bias = ctx.cfg
+        gy = _prep("grad_y", gy)
+        d_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        d_w = torch.empty_like(w)
+        d_b = torch.empty(N, device=x.device, dtype=torch.float32) if has_bias else None
+        L_ = _lib.lib()
+        ws_bytes = L_.vqa_linear_act_bwd_workspace_bytes(M, K, N)
+        ws = torch.empty((ws_bytes + 3) // 4, device=x.device, dtype=torch.float32)
+        _launch("linear_act_bwd", (M, K, N, p_drop > 0, d_x is not None), L_.vqa_linear_act_bwd,
+                _p(x), K, _p(w), _p(y), _p(gy), _p(d_x), _p(d_w), _p(d_b), _p(ws), ws_bytes, M, K, N, act, p_drop, seed)
+        return d_x, d_w, d_b, None, None, None
+
+
+def linear_act(x, w, bias=None, act=None, p_drop=0.0, seed=0):
+    code = {None: 0, "": 0, "relu": 1}.get(act)
+    if code is None:
+        raise ValueError("linear_act: act must be None or 'relu', got %r" % (act,))
+    return LinearAct.apply(x, w, bias, code, p_drop, seed)
+
+
+def linear_dropout_mask(M, K, p_drop, seed, device):
+    """The keep/(1-p) mask [M,K] exactly as K5 draws it (tests hand it to the oracle)."""
+    mask = torch.empty(M, K, device=device, dtype=torch.float32)
+    _launch("linear_dropout_mask", (M, K), _lib.lib().vqa_linear_dropout_mask, _p(mask), float(p_drop), int(seed), M, K)
+    return mask
+
+
 def object_difference_dropout_mask(B, N, L, p_drop, seed, device):
     """The keep/(1-p) mask [B,N,N*L] exactly as K2 draws it (tests hand it to the oracle)."""
     mask = torch.empty(B, N, N * L, device=device, dtype=torch.float32)
