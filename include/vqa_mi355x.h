@@ -172,6 +172,22 @@ int vqa_linear_act_bwd(const float* x, int ldx, const float* w, const float* y, 
 
 int vqa_linear_dropout_mask(float* mask, float p_drop, uint64_t seed, int M, int K, vqa_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Train-step tail over flat fp32 buffers.
+ * Replaces nn.utils.clip_grad_norm_(model.parameters(), 0.25) + optimizer.step() of torch.optim.Adam
+ * (train.py:81-86, :286-292): two HBM-bound launches instead of ~70 per-tensor walks, no host round trip.
+ *
+ * vqa_grad_norm_clip_coef: norm_and_coef[0] = ||g||_2 (fp64 accumulation), norm_and_coef[1] =
+ *   min(1, max_norm / (norm + 1e-6))  (max_norm <= 0: coef = 1).  workspace: vqa_grad_norm_workspace_bytes().
+ * vqa_adam_step: Adam (betas, eps, no weight decay / amsgrad) with bias correction for `step` (1-based) on the
+ *   gradients scaled by norm_and_coef[1] (NULL = unscaled); p, m, v updated in place.
+ * ------------------------------------------------------------------------------------------- */
+size_t vqa_grad_norm_workspace_bytes(void);
+int vqa_grad_norm_clip_coef(const float* g, size_t n, float max_norm, float* norm_and_coef, void* workspace,
+                            size_t workspace_bytes, vqa_stream_t stream);
+int vqa_adam_step(float* p, const float* g, float* m, float* v, size_t n, const float* norm_and_coef, float lr,
+                  float beta1, float beta2, float eps, int step, vqa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

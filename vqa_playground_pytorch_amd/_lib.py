@@ -44,6 +44,9 @@ SIGNATURES = {
     "vqa_linear_act_bwd": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz,
                                   _c_i, _c_i, _c_i, _c_i, _c_fl, _c_u64, _c_st]),
     "vqa_linear_dropout_mask": (_c_i, [_c_f, _c_fl, _c_u64, _c_i, _c_i, _c_st]),
+    "vqa_grad_norm_workspace_bytes": (_c_sz, []),
+    "vqa_grad_norm_clip_coef": (_c_i, [_c_f, _c_sz, _c_fl, _c_f, _c_f, _c_sz, _c_st]),
+    "vqa_adam_step": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_sz, _c_f, _c_fl, _c_fl, _c_fl, _c_fl, _c_i, _c_st]),
 }
 
 _lock = threading.Lock()

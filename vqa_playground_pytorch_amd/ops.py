@@ -282,6 +282,22 @@ def linear_act(x, w, bias=None, act=None, p_drop=0.0, seed=0):
     return LinearAct.apply(x, w, bias, code, p_drop, seed)
 
 
+def grad_norm_clip_coef(g_flat, max_norm, out, workspace):
+    """out[0] = ||g_flat||_2, out[1] = min(1, max_norm/(norm+1e-6)) -- clip_grad_norm_ semantics (train.py:82)."""
+    g_flat = _prep("g_flat", g_flat)
+    _launch("grad_norm_clip_coef", (g_flat.numel(),), _lib.lib().vqa_grad_norm_clip_coef, _p(g_flat), g_flat.numel(),
+            float(max_norm), _p(out), _p(workspace), workspace.numel() * workspace.element_size())
+
+
+def adam_step(p_flat, g_flat, m_flat, v_flat, norm_and_coef, lr, beta1, beta2, eps, step):
+    """One fused Adam update of the flat parameter buffer on gradients scaled by norm_and_coef[1] (train.py:86)."""
+    for name, t in (("p", p_flat), ("g", g_flat), ("m", m_flat), ("v", v_flat)):
+        if _prep(name, t) is not t:
+            raise ValueError("adam_step: %s must be contiguous" % name)
+    _launch("adam_step", (p_flat.numel(),), _lib.lib().vqa_adam_step, _p(p_flat), _p(g_flat), _p(m_flat), _p(v_flat),
+            p_flat.numel(), _p(norm_and_coef), float(lr), float(beta1), float(beta2), float(eps), int(step))
+
+
 def linear_dropout_mask(M, K, p_drop, seed, device):
     """The keep/(1-p) mask [M,K] exactly as K5 draws it (tests hand it to the oracle)."""
     mask = torch.empty(M, K, device=device, dtype=torch.float32)
