@@ -46,6 +46,32 @@ def kernel_models(B, N=REGIONS, D=FEAT, G=GLIMPSES, L=LOW, H=HID, R=RANK):
     }
 
 
+# HBM-side traffic per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+# separate runs, KiB units; profiles/r01_b_pmc_traffic.json).  FETCH_SIZE under-reports 16-byte-per-lane streaming
+# reads by exactly 2x on gfx950 (MI355X_MICROARCH.md, HBM section) and is taken as-is for the 8-byte-per-lane GEMM
+# staging loads (calibrated here against the algorithmic bytes of the K4 forward: 26.5 MB counted vs 26.1 MB expected).
+PMC_KERNELS = {  # C-ABI entry -> [(kernel-name prefix, grid, fetch multiplier)]
+    "lowrank_bilinear_fusion_fwd": [("vqa::bilinear_fwd_kernel", "589824", 1.0)],
+    "pairwise_relation_reduce_fwd": [("vqa::pairwise_fwd_reg_kernel", "262144", 2.0)],
+    "pairwise_relation_reduce_bwd": [("vqa::pairwise_bwd_stream_kernel", "262144", 2.0)],
+    "softmax_attention_pool_fwd": [("vqa::attention_pool_fwd_kernel", "262144", 2.0)],
+}
+
+
+def pmc_traffic(name, B):
+    path = os.path.join(ROOT, "profiles", "r01_b_pmc_traffic.json")
+    if B != BATCH or name not in PMC_KERNELS or not os.path.exists(path):
+        return None
+    table = json.load(open(path))
+    total = 0.0
+    for prefix, grid, mult in PMC_KERNELS[name]:
+        hit = [v for k, v in table.items() if k.startswith(prefix) and k.endswith("grid=" + grid)]
+        if not hit:
+            return None
+        total += (hit[0]["FETCH_SIZE_KiB"] * mult + hit[0]["WRITE_SIZE_KiB"]) * 1024.0
+    return int(total)
+
+
 def roofline_entry(name, shape, launches, mean_ms, B):
     bound, work = kernel_models(B)[name]
     if name == "softmax_attention_pool_bwd" and shape[-1]:
@@ -58,7 +84,8 @@ def roofline_entry(name, shape, launches, mean_ms, B):
     else:
         achieved, peak, unit = work / sec / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
     return {"kernel": name, "shape": list(shape), "launches": launches, "mean_ms": round(mean_ms, 5), "bound": bound,
-            "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4), "traffic": None}
+            "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
+            "traffic": pmc_traffic(name, B)}
 
 
 def cpu_baseline_worker(batch, threads, budget_s):

@@ -7,9 +7,10 @@
 //   forward : a workgroup owns (sample, 4*NT-wide feature chunk); every lane keeps G float4
 //             accumulators and streams the N region rows with coalesced 16-byte loads; the N*G
 //             softmax is recomputed per workgroup from the N*G logits (wave64 shuffles).
-//   backward: a workgroup owns a sample; d_pooled [G,D] sits in LDS; each wave takes region rows
-//             round-robin, forms the G dot products <d_pooled_g, v_n> with a wave64 reduction and
-//             (optionally) writes d_v_n in the same sweep; softmax backward closes in LDS.
+//   backward: same (sample, feature chunk) ownership as forward; every lane keeps its float4 column of the G rows
+//             of d_pooled in registers, streams the N region rows once, writes d_v_n in the same sweep and
+//             reduces the G dot products <d_pooled_g, v_n> with wave64 shuffles; a second tiny kernel closes the
+//             softmax backward on [B,N,G].
 //
 // HBM-bound.  Algorithmic bytes per sample (fp32): forward (N*D + 2*N*G + G*D)*4 = 328 832 B at
 // N=36, D=2048, G=4;  backward (N*D + G*D + 3*N*G)*4 (+ N*D*4 when d_v is written).
@@ -93,67 +94,90 @@ __global__ __launch_bounds__(NT) void attention_pool_fwd_kernel(const float* __r
   for (int g = 0; g < G; ++g) st4(pooled + ((size_t)b * G + g) * D + d, acc[g]);
 }
 
-// Backward: one workgroup per sample.
+// Backward, streaming form.  Kernel A: grid (D/1024, B), lane = one float4 column with the G rows of d_pooled in
+// registers; it streams the N region rows once, writes d_v in the same sweep and reduces the G dot products
+// <d_pooled_g, v_n> per row with wave64 shuffles -> LDS -> one float atomic per (workgroup, n, g) into a zeroed
+// accumulator.  Kernel B closes the softmax backward on the tiny [B,N,G] tensors.
 template <int NT, int G>
-__global__ __launch_bounds__(NT) void attention_pool_bwd_kernel(const float* __restrict__ alpha,
-                                                                const float* __restrict__ v,
-                                                                const float* __restrict__ d_pooled,
-                                                                const float* __restrict__ d_alpha_ext,
-                                                                float* __restrict__ d_logits, float* __restrict__ d_v,
-                                                                int N, int D) {
+__global__ __launch_bounds__(NT) void attention_pool_bwd_stream_kernel(const float* __restrict__ alpha,
+                                                                       const float* __restrict__ v,
+                                                                       const float* __restrict__ d_pooled,
+                                                                       float* __restrict__ dal_acc, float* __restrict__ d_v,
+                                                                       int N, int D) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* dp_s = reinterpret_cast<float*>(smem);  // [G][D]
-  float* alpha_s = dp_s + (size_t)G * D;         // [N][G]
-  float* dal_s = alpha_s + N * G;                // [N][G]  dL/dalpha
-  float* inner_s = dal_s + N * G;                // [kMaxG]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int b = blockIdx.x;
+  float* alpha_s = reinterpret_cast<float*>(smem);  // [N][G]
+  float* red_s = alpha_s + N * G;                   // [N][G]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int b = blockIdx.y;
+  const int d = (blockIdx.x * NT + tid) * 4;
+  const bool active = d < D;
+  const int dc = active ? d : 0;
   const int NG = N * G;
-  const float* dpb = d_pooled + (size_t)b * G * D;
-  for (int t = tid * 4; t < G * D; t += NT * 4) *reinterpret_cast<float4*>(dp_s + t) = ld4(dpb + t);
-  for (int t = tid; t < NG; t += NT) alpha_s[t] = alpha[(size_t)b * NG + t];
+  for (int t = tid; t < NG; t += NT) {
+    alpha_s[t] = alpha[(size_t)b * NG + t];
+    red_s[t] = 0.f;
+  }
+  float4 p[G];
+#pragma unroll
+  for (int gI = 0; gI < G; ++gI) {
+    const float4 t = ld4(d_pooled + ((size_t)b * G + gI) * D + dc);
+    p[gI] = active ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   __syncthreads();
-
-  const float* vb = v + (size_t)b * N * D;
-  float* dvb = d_v ? d_v + (size_t)b * N * D : nullptr;
-  for (int n = wave; n < N; n += NT / 64) {
-    float dot[G];
-    float a[G];
+  const float* vb = v + (size_t)b * N * D + dc;
+  float* dvb = d_v ? d_v + (size_t)b * N * D + dc : nullptr;
+  constexpr int RB = 4;  // rows per batch: RB independent 16-byte loads in flight per lane, then RB*G wave reductions
+  for (int n0 = 0; n0 < N; n0 += RB) {
+    float4 x[RB];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      dot[g] = 0.f;
-      a[g] = alpha_s[n * G + g];
-    }
-#pragma unroll 4
-    for (int d = lane * 4; d < D; d += 256) {
-      const float4 x = ld4(vb + (size_t)n * D + d);
-      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < RB; ++k) x[k] = ld4(vb + (size_t)min(n0 + k, N - 1) * D);
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const float4 p = *reinterpret_cast<const float4*>(dp_s + (size_t)g * D + d);
-        dot[g] += dot4(x, p);
-        o = fma4(a[g], p, o);
+    for (int k = 0; k < RB; ++k) {
+      const int n = n0 + k;
+      if (n < N) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        float dots[G];
+#pragma unroll
+        for (int gI = 0; gI < G; ++gI) {
+          dots[gI] = dot4(x[k], p[gI]);
+          o = fma4(alpha_s[n * G + gI], p[gI], o);
+        }
+        if (dvb && active) st4(dvb + (size_t)n * D, o);
+#pragma unroll
+        for (int gI = 0; gI < G; ++gI) {
+          const float r = wave_sum(dots[gI]);
+          if (lane == 0) atomicAdd(&red_s[n * G + gI], r);
+        }
       }
-      if (dvb) st4(dvb + (size_t)n * D + d, o);
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const float r = wave_sum(dot[g]);
-      if (lane == 0) dal_s[n * G + g] = r;
     }
   }
   __syncthreads();
-  if (d_alpha_ext != nullptr)
-    for (int t = tid; t < NG; t += NT) dal_s[t] += d_alpha_ext[(size_t)b * NG + t];
+  for (int t = tid; t < NG; t += NT) atomicAdd(&dal_acc[(size_t)b * NG + t], red_s[t]);
+}
+
+// d_logits = alpha * (dal - sum_n alpha*dal),  dal = accumulated <d_pooled, v> (+ the gradient arriving on alpha)
+__global__ __launch_bounds__(256) void attention_softmax_bwd_kernel(const float* __restrict__ alpha,
+                                                                    const float* __restrict__ dal_acc,
+                                                                    const float* __restrict__ d_alpha_ext,
+                                                                    float* __restrict__ d_logits, int N, int G) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* alpha_s = reinterpret_cast<float*>(smem);
+  float* dal_s = alpha_s + N * G;
+  float* inner_s = dal_s + N * G;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b = blockIdx.x, NG = N * G;
+  for (int t = tid; t < NG; t += 256) {
+    alpha_s[t] = alpha[(size_t)b * NG + t];
+    dal_s[t] = dal_acc[(size_t)b * NG + t] + (d_alpha_ext ? d_alpha_ext[(size_t)b * NG + t] : 0.f);
+  }
   __syncthreads();
-  for (int g = wave; g < G; g += NT / 64) {
+  for (int gI = wave; gI < G; gI += 4) {
     float s = 0.f;
-    for (int n = lane; n < N; n += 64) s += alpha_s[n * G + g] * dal_s[n * G + g];
+    for (int n = lane; n < N; n += 64) s += alpha_s[n * G + gI] * dal_s[n * G + gI];
     s = wave_sum(s);
-    if (lane == 0) inner_s[g] = s;
+    if (lane == 0) inner_s[gI] = s;
   }
   __syncthreads();
-  for (int t = tid; t < NG; t += NT) d_logits[(size_t)b * NG + t] = alpha_s[t] * (dal_s[t] - inner_s[t % G]);
+  for (int t = tid; t < NG; t += 256) d_logits[(size_t)b * NG + t] = alpha_s[t] * (dal_s[t] - inner_s[t % G]);
 }
 
 template <int G>
@@ -169,13 +193,16 @@ static int launch_fwd(const float* logits, const float* v, float* alpha, float* 
 template <int G>
 static int launch_bwd(const float* alpha, const float* v, const float* d_pooled, const float* d_alpha_ext,
                       float* d_logits, float* d_v, int B, int N, int D, hipStream_t s) {
-  constexpr int NT = 512;
-  const size_t lds = ((size_t)G * D + 2 * (size_t)N * G + kMaxG) * sizeof(float);
-  VQA_REQUIRE(lds <= 160 * 1024, VQA_E_UNSUPPORTED, "softmax_attention_pool_bwd: G*D=%d needs %zu B of LDS (> 160 KiB)",
-              G * D, lds);
-  VQA_ENSURE_LDS((attention_pool_bwd_kernel<NT, G>), lds);
-  hipLaunchKernelGGL((attention_pool_bwd_kernel<NT, G>), dim3(B), dim3(NT), lds, s, alpha, v, d_pooled, d_alpha_ext,
-                     d_logits, d_v, N, D);
+  constexpr int NT = 256;
+  // d_logits doubles as the zeroed accumulator of the first kernel (same [B,N,G] shape; kernel B reads each of its
+  // elements before overwriting it)
+  hipError_t e = hipMemsetAsync(d_logits, 0, (size_t)B * N * G * sizeof(float), s);
+  if (e != hipSuccess) return fail(VQA_E_LAUNCH, "softmax_attention_pool_bwd: memset: %s", hipGetErrorString(e));
+  const size_t lds = 2 * (size_t)N * G * sizeof(float);
+  hipLaunchKernelGGL((attention_pool_bwd_stream_kernel<NT, G>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), lds, s, alpha, v,
+                     d_pooled, d_logits, d_v, N, D);
+  hipLaunchKernelGGL(attention_softmax_bwd_kernel, dim3(B), dim3(256), lds + kMaxG * sizeof(float), s, alpha, d_logits,
+                     d_alpha_ext, d_logits, N, G);
   return check_launch("softmax_attention_pool_bwd");
 }
 

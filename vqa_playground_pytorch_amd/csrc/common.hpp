@@ -54,16 +54,32 @@ inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_
 // ---- device helpers --------------------------------------------------------------------------
 constexpr int kWave = 64;
 
+// wave64 reductions at VALU speed: four DPP steps (quad_perm, quad_perm, row_half_mirror, row_mirror) leave every lane
+// with the sum of its 16-lane row, four v_readlane combine the rows.  (__shfl_xor lowers to ds_bpermute: an LDS
+// round trip per step, ~600 cycles of dependent latency per reduction -- it made the streaming backward kernels
+// latency-bound.)  The result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum(float x) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
-  return x;
+  x += dpp_mov<0xB1>(x);   // quad_perm [1,0,3,2]
+  x += dpp_mov<0x4E>(x);   // quad_perm [2,3,0,1]
+  x += dpp_mov<0x141>(x);  // row_half_mirror
+  x += dpp_mov<0x140>(x);  // row_mirror
+  const int xi = __float_as_int(x);
+  return __int_as_float(__builtin_amdgcn_readlane(xi, 0)) + __int_as_float(__builtin_amdgcn_readlane(xi, 16)) +
+         __int_as_float(__builtin_amdgcn_readlane(xi, 32)) + __int_as_float(__builtin_amdgcn_readlane(xi, 48));
 }
 
 __device__ __forceinline__ float wave_max(float x) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, kWave));
-  return x;
+  x = fmaxf(x, dpp_mov<0xB1>(x));
+  x = fmaxf(x, dpp_mov<0x4E>(x));
+  x = fmaxf(x, dpp_mov<0x141>(x));
+  x = fmaxf(x, dpp_mov<0x140>(x));
+  const int xi = __float_as_int(x);
+  return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(xi, 0)), __int_as_float(__builtin_amdgcn_readlane(xi, 16))),
+               fmaxf(__int_as_float(__builtin_amdgcn_readlane(xi, 32)), __int_as_float(__builtin_amdgcn_readlane(xi, 48))));
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

@@ -136,6 +136,110 @@ __global__ __launch_bounds__(NT) void pairwise_bwd_kernel(const float* __restric
   for (int i = tid; i < N; i += NT) atomicAdd(&d_alpha[(size_t)b * N + i], red_s[i]);
 }
 
+// ---- register-tile variants (N <= kRegN, the reference's 36 regions) ------------------------------------------
+// One wave per workgroup, lane = one float4 column, the N region rows of that column held in VGPRs (144 for N=36):
+// no LDS, so occupancy is set by registers (3 waves per SIMD, 12 per CU, against 4 per CU for the 73 KB LDS tile)
+// and every lane has N independent 16-byte loads in flight.  Loads are unconditional from clamped rows (a load
+// under a branch would serialise on vmcnt(0), see gemm_f32_mfma.hpp); rows >= N are zeroed by a select.
+constexpr int kRegN = 36;
+
+__global__ __launch_bounds__(64) void pairwise_fwd_reg_kernel(const float* __restrict__ v, const float* __restrict__ q1,
+                                                              const float* __restrict__ q2, const float* __restrict__ alpha,
+                                                              int astride, float* __restrict__ v2, int N, int D) {
+  const int b = blockIdx.y;
+  const int d = (blockIdx.x * 64 + threadIdx.x) * 4;
+  if (d >= D) return;
+  const size_t base = (size_t)b * N * D + d;
+  float4 r[kRegN];
+#pragma unroll
+  for (int i = 0; i < kRegN; ++i) r[i] = ld4(v + base + (size_t)min(i, N - 1) * D);
+  const float4 q1v = ld4(q1 + (size_t)b * D + d), q2v = ld4(q2 + (size_t)b * D + d);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  float asum = 0.f;
+#pragma unroll
+  for (int i = 0; i < kRegN; ++i) {
+    const float a = i < N ? alpha[((size_t)b * N + i) * astride] : 0.f;  // wave-uniform address: scalar load
+    s = fma4(a, r[i], s);
+    asum += a;
+  }
+  const float4 s1 = mul4(q1v, s);
+  const float4 c2 = scale4(asum, q2v);
+#pragma unroll
+  for (int j = 0; j < kRegN; ++j) {
+    if (j < N)
+      st4(v2 + base + (size_t)j * D, make_float4(fmaf(c2.x, r[j].x, s1.x), fmaf(c2.y, r[j].y, s1.y),
+                                                 fmaf(c2.z, r[j].z, s1.z), fmaf(c2.w, r[j].w, s1.w)));
+  }
+}
+
+// Backward, two-pass streaming form (any N): pass 1 streams (v_j, g_j) once and keeps only the three column
+// accumulators (sum g, sum g*v, sum alpha*v), so the kernel runs at full occupancy; pass 2 re-reads the v rows this
+// workgroup has just streamed (36 KB per wave, served by L2 / Infinity Cache, not HBM) for dalpha_i = <v_i, q1*sum g>.
+// dalpha partials: wave64 shuffles -> LDS -> one float atomic per (workgroup, region).
+template <int NT>
+__global__ __launch_bounds__(NT) void pairwise_bwd_stream_kernel(const float* __restrict__ v, const float* __restrict__ q1,
+                                                                 const float* __restrict__ q2,
+                                                                 const float* __restrict__ alpha, int astride,
+                                                                 const float* __restrict__ g, float* __restrict__ d_alpha,
+                                                                 float* __restrict__ d_q1, float* __restrict__ d_q2,
+                                                                 float* __restrict__ d_v, int N, int D) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* alpha_s = reinterpret_cast<float*>(smem);  // [N]
+  float* red_s = alpha_s + N;                       // [N]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int b = blockIdx.y;
+  const int d = (blockIdx.x * NT + tid) * 4;
+  const bool active = d < D;
+  const int dc = active ? d : 0;
+  for (int i = tid; i < N; i += NT) {
+    alpha_s[i] = alpha[((size_t)b * N + i) * astride];
+    red_s[i] = 0.f;
+  }
+  __syncthreads();
+  const size_t base = (size_t)b * N * D + dc;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 gsum = z, gv = z, pooled = z;
+  float asum = 0.f;
+#pragma unroll 6
+  for (int j = 0; j < N; ++j) {
+    const float4 vj = ld4(v + base + (size_t)j * D);
+    const float4 gj = ld4(g + base + (size_t)j * D);
+    const float a = alpha_s[j];
+    gsum = add4(gsum, gj);
+    gv = add4(gv, mul4(gj, vj));
+    pooled = fma4(a, vj, pooled);
+    asum += a;
+  }
+  const float4 q1v = ld4(q1 + (size_t)b * D + dc), q2v = ld4(q2 + (size_t)b * D + dc);
+  const float4 u = active ? mul4(q1v, gsum) : z;
+  if (active) {
+    st4(d_q1 + (size_t)b * D + d, mul4(pooled, gsum));
+    st4(d_q2 + (size_t)b * D + d, scale4(asum, gv));
+  }
+  const float cpart = active ? dot4(gv, q2v) : 0.f;
+  const float4 c2 = scale4(asum, q2v);
+  constexpr int RB = 6;  // rows per batch: RB independent 16-byte loads in flight per lane, then RB wave reductions
+  for (int i0 = 0; i0 < N; i0 += RB) {
+    float4 vi[RB];
+#pragma unroll
+    for (int k = 0; k < RB; ++k) vi[k] = ld4(v + base + (size_t)min(i0 + k, N - 1) * D);
+#pragma unroll
+    for (int k = 0; k < RB; ++k) {
+      const int i = i0 + k;
+      if (i < N) {
+        if (d_v != nullptr && active) {
+          const float4 gi = ld4(g + base + (size_t)i * D);
+          st4(d_v + base + (size_t)i * D, add4(scale4(alpha_s[i], u), mul4(c2, gi)));
+        }
+        const float p = wave_sum(dot4(vi[k], u) + cpart);
+        if (lane == 0) atomicAdd(&red_s[i], p);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < N; i += NT) atomicAdd(&d_alpha[(size_t)b * N + i], red_s[i]);
+}
+
 static int pick_threads(int N) { return N <= 36 ? 128 : 64; }
 
 }  // namespace vqa
@@ -154,6 +258,11 @@ extern "C" int vqa_pairwise_relation_reduce_fwd(const float* v, const float* q1,
   VQA_REQUIRE(N <= 144, VQA_E_UNSUPPORTED, "pairwise_relation_reduce_fwd: N=%d exceeds the LDS tile limit 144", N);
   VQA_REQUIRE(B <= 65535, VQA_E_UNSUPPORTED, "pairwise_relation_reduce_fwd: B=%d exceeds 65535", B);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (mode == 1 && N <= kRegN) {
+    hipLaunchKernelGGL(pairwise_fwd_reg_kernel, dim3((D / 4 + 63) / 64, B), dim3(64), 0, s, v, q1, q2, alpha, alpha_stride,
+                       v2, N, D);
+    return check_launch("pairwise_relation_reduce_fwd");
+  }
   const int nt = pick_threads(N);
   const size_t lds = (size_t)N * nt * 16 + (size_t)N * 4;
   dim3 grid((D / 4 + nt - 1) / nt, B);
@@ -177,11 +286,17 @@ extern "C" int vqa_pairwise_relation_reduce_bwd(const float* v, const float* q1,
   VQA_REQUIRE(D % 4 == 0 && aligned(v, 16) && aligned(q1, 16) && aligned(q2, 16) && aligned(g_v2, 16) &&
                   aligned(d_q1, 16) && aligned(d_q2, 16) && (d_v == nullptr || aligned(d_v, 16)),
               VQA_E_UNSUPPORTED, "pairwise_relation_reduce_bwd: needs D %% 4 == 0 and 16-byte aligned tensors (D=%d)", D);
-  VQA_REQUIRE(N <= 144, VQA_E_UNSUPPORTED, "pairwise_relation_reduce_bwd: N=%d exceeds the LDS tile limit 144", N);
+  VQA_REQUIRE(N <= 4096, VQA_E_UNSUPPORTED, "pairwise_relation_reduce_bwd: N=%d exceeds 4096", N);
   VQA_REQUIRE(B <= 65535, VQA_E_UNSUPPORTED, "pairwise_relation_reduce_bwd: B=%d exceeds 65535", B);
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e = hipMemsetAsync(d_alpha, 0, (size_t)B * N * sizeof(float), s);
   if (e != hipSuccess) return fail(VQA_E_LAUNCH, "pairwise_relation_reduce_bwd: memset: %s", hipGetErrorString(e));
+  {
+    constexpr int NT = 256;
+    hipLaunchKernelGGL(pairwise_bwd_stream_kernel<NT>, dim3((D / 4 + NT - 1) / NT, B), dim3(NT), (size_t)N * 8, s, v, q1, q2,
+                       alpha, alpha_stride, g_v2, d_alpha, d_q1, d_q2, d_v, N, D);
+    if (true) return check_launch("pairwise_relation_reduce_bwd");
+  }
   const int nt = pick_threads(N);
   const size_t lds = (size_t)N * nt * 16 + (size_t)N * 8;
   dim3 grid((D / 4 + nt - 1) / nt, B);
