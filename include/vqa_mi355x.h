@@ -187,6 +187,10 @@ int vqa_grad_norm_clip_coef(const float* g, size_t n, float max_norm, float* nor
                             size_t workspace_bytes, vqa_stream_t stream);
 int vqa_adam_step(float* p, const float* g, float* m, float* v, size_t n, const float* norm_and_coef, float lr,
                   float beta1, float beta2, float eps, int step, vqa_stream_t stream);
+/* Same update with the two per-step scalars read from DEVICE memory: step_scalars[0] = lr / (1 - beta1^t),
+ * step_scalars[1] = 1 / sqrt(1 - beta2^t) -- so a captured hipGraph of the step can be replayed as lr and t move. */
+int vqa_adam_step_dyn(float* p, const float* g, float* m, float* v, size_t n, const float* norm_and_coef,
+                      const float* step_scalars, float beta1, float beta2, float eps, vqa_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -182,6 +182,10 @@ def test_train_step_matches_reference_trajectory(cls, fname, nans, golden_dir):
     np.testing.assert_allclose(norms, gold["train3.gnorm"], rtol=RTOL)
     assert abs(tr.lr - float(gold["train3.lr"])) <= 1e-12 * tr.lr
     for name, p in model.named_parameters():
+        if float(gold["g." + name + ".norm"]) < 1e-6:
+            # mathematically-zero gradient (a bias in front of the softmax over regions): Adam turns the ~1e-9
+            # rounding noise into +-lr steps whose signs differ between any two fp32 implementations
+            continue
         w = p.detach().cpu().numpy().astype(np.float64)
         gn = float(gold["train3.w." + name + ".norm"])
         assert abs(np.sqrt((w ** 2).sum()) - gn) <= 1e-5 * gn, name
@@ -211,3 +215,35 @@ def test_fused_adam_matches_torch_adam():
         opt.step()
         ops.adam_step(p, gi, m, v, nc, 1e-3, 0.9, 0.999, 1e-8, step)
         assert (p - ref_p.detach()).abs().max().item() <= 2e-6
+
+
+def test_graph_replay_equals_eager_steps():
+    """The hipGraph-replayed train step (two captured graphs, per-step scalars in device memory) follows exactly the
+    same trajectory as the kernel-by-kernel step (eval mode: no dropout, so both are deterministic)."""
+    from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
+    out = {}
+    for mode in (False, True):
+        model = build("cor2", 300)
+        tr = DataParallelTrainer(model, lr=2e-5, clip=0.25, graph=mode)
+        v, q, a = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(6, answers=300, seed=21))
+        losses = []
+        for step in range(7):
+            loss, norm = tr.step({"v": v, "q_idxes": q}, a)
+            losses.append((loss.item(), norm.item()))
+        if mode:
+            assert tr._graph is not None, "step was not captured"
+            v2, q2, a2 = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(6, answers=300, seed=22))
+            loss, _ = tr.step({"v": v2, "q_idxes": q2}, a2)      # new tensors: copied into the captured placeholders
+            losses.append((loss.item(), 0.0))
+        else:
+            v2, q2, a2 = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(6, answers=300, seed=22))
+            loss, _ = tr.step({"v": v2, "q_idxes": q2}, a2)
+            losses.append((loss.item(), 0.0))
+        out[mode] = (losses, [p.detach().clone() for p in model.parameters()], tr.lr)
+    # not bitwise: the d_alpha reductions of K1/K3 use float atomics and Adam renormalises every gradient, so the last
+    # bits of near-zero gradients become +-lr steps; a small lr keeps that below the comparison threshold
+    for (l0, n0), (l1, n1) in zip(out[False][0], out[True][0]):
+        assert abs(l0 - l1) <= 1e-4 * abs(l0) and abs(n0 - n1) <= 1e-4 * max(abs(n0), 1e-6)
+    assert out[False][2] == out[True][2]
+    for p0, p1 in zip(out[False][1], out[True][1]):
+        assert (p0 - p1).abs().max().item() <= 2e-3 * max(p0.abs().max().item(), 1e-3)

@@ -47,6 +47,7 @@ SIGNATURES = {
     "vqa_grad_norm_workspace_bytes": (_c_sz, []),
     "vqa_grad_norm_clip_coef": (_c_i, [_c_f, _c_sz, _c_fl, _c_f, _c_f, _c_sz, _c_st]),
     "vqa_adam_step": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_sz, _c_f, _c_fl, _c_fl, _c_fl, _c_fl, _c_i, _c_st]),
+    "vqa_adam_step_dyn": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_sz, _c_f, _c_f, _c_fl, _c_fl, _c_fl, _c_st]),
 }
 
 _lock = threading.Lock()

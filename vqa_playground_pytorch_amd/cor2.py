@@ -64,7 +64,10 @@ class Model(nn.Module):
         fuse2 = self.fusion_vq2(v2_feature_low, q_feature_low)
         v2_att, alpha2, _ = self.att2.attend(v2_feature, self.att2.conv_att.pre_activation(fuse2))
 
-        self.alpha_dict = {"alpha1": alpha1, "alpha2": alpha2, "feature": v2_feature[:, [0, 1], :]}
+        # side output read by visu.py:198-207; detached so it does not pin the autograd graph of the step
+        # (feature = the reference's v2_feature[:, [0, 1], :])
+        self.alpha_dict = {"alpha1": tuple(t.detach() for t in alpha1), "alpha2": tuple(t.detach() for t in alpha2),
+                           "feature": v2_feature[:, 0:2, :].detach()}
 
         v_f = torch.cat([v1_att, v2_att], dim=1)
         q_final = self.linear_q(q_feature)

@@ -58,10 +58,17 @@ __global__ __launch_bounds__(256) void norm_finish_kernel(const double* __restri
 
 // torch.optim.Adam (no amsgrad, no weight decay) on clipped gradients g*coef:
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+// `dyn` (optional, device): {lr / (1 - b1^t), 1 / sqrt(1 - b2^t)} -- the per-step scalars live in device memory so a
+// captured hipGraph of the step can be replayed while the learning rate and the bias corrections move on.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, size_t n, const float* __restrict__ coef_ptr,
-                                                   float b1, float b2, float eps, float step_size, float inv_sqrt_bc2) {
+                                                   const float* __restrict__ dyn, float b1, float b2, float eps,
+                                                   float step_size, float inv_sqrt_bc2) {
   const float coef = coef_ptr != nullptr ? coef_ptr[1] : 1.f;
+  if (dyn != nullptr) {
+    step_size = dyn[0];
+    inv_sqrt_bc2 = dyn[1];
+  }
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i + 3 < n) {
     const float4 gg = ld4(g + i);
@@ -120,6 +127,17 @@ extern "C" int vqa_adam_step(float* p, const float* g, float* m, float* v, size_
   const float step_size = (float)(lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   const size_t blocks = (n / 4 + 256) / 256;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n,
-                     norm_and_coef, beta1, beta2, eps, step_size, inv_sqrt_bc2);
+                     norm_and_coef, static_cast<const float*>(nullptr), beta1, beta2, eps, step_size, inv_sqrt_bc2);
   return check_launch("adam_step");
+}
+
+extern "C" int vqa_adam_step_dyn(float* p, const float* g, float* m, float* v, size_t n, const float* norm_and_coef,
+                                 const float* step_scalars, float beta1, float beta2, float eps, vqa_stream_t stream) {
+  VQA_REQUIRE(p && g && m && v && step_scalars && n > 0, VQA_E_BADARG, "adam_step_dyn: null pointer or n == 0");
+  VQA_REQUIRE(aligned(p, 16) && aligned(g, 16) && aligned(m, 16) && aligned(v, 16), VQA_E_UNSUPPORTED,
+              "adam_step_dyn: buffers must be 16-byte aligned");
+  const size_t blocks = (n / 4 + 256) / 256;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n,
+                     norm_and_coef, step_scalars, beta1, beta2, eps, 0.f, 1.f);
+  return check_launch("adam_step_dyn");
 }

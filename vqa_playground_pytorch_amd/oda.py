@@ -35,7 +35,7 @@ class Model(nn.Module):
         seed = 0
         if p:
             # fresh mask every call, drawn from torch's generator so torch.manual_seed governs it
-            seed = int(torch.randint(0, 2 ** 62, (1,), device="cpu").item())
+            seed = ops.draw_host_seed()
         w = conv.conv.weight.view(conv.out_channels, -1)
         return ops.object_difference_attention(v_feature_low, q_feature_low, w, conv.conv.bias, p, seed)
 
@@ -52,7 +52,7 @@ class Model(nn.Module):
         logits = self.difference_logits(v_feature_low, q_feature_low)
         v_final, alphas, _ = self.att.attend(v_feature, logits)
 
-        self.alpha_dict = {"alphas": alphas[0]}
+        self.alpha_dict = {"alphas": alphas[0].detach()}
 
         q_final = self.linear_q(q_feature)
         x = self.fusion_final(v_final, q_final)

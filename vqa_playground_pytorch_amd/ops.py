@@ -298,6 +298,22 @@ def adam_step(p_flat, g_flat, m_flat, v_flat, norm_and_coef, lr, beta1, beta2, e
             p_flat.numel(), _p(norm_and_coef), float(lr), float(beta1), float(beta2), float(eps), int(step))
 
 
+def adam_step_dyn(p_flat, g_flat, m_flat, v_flat, norm_and_coef, step_scalars, beta1, beta2, eps):
+    """adam_step with {lr/(1-b1^t), 1/sqrt(1-b2^t)} read from the device tensor ``step_scalars`` (graph replays)."""
+    _launch("adam_step_dyn", (p_flat.numel(),), _lib.lib().vqa_adam_step_dyn, _p(p_flat), _p(g_flat), _p(m_flat),
+            _p(v_flat), p_flat.numel(), _p(norm_and_coef), _p(step_scalars), float(beta1), float(beta2), float(eps))
+
+
+host_seed_draws = 0  # bumped whenever a kernel's dropout seed is drawn on the host (such a step cannot be graph-replayed)
+
+
+def draw_host_seed():
+    """A fresh 62-bit dropout seed from torch's CPU generator (so torch.manual_seed governs the fused masks)."""
+    global host_seed_draws
+    host_seed_draws += 1
+    return int(torch.randint(0, 2 ** 62, (1,), device="cpu").item())
+
+
 def linear_dropout_mask(M, K, p_drop, seed, device):
     """The keep/(1-p) mask [M,K] exactly as K5 draws it (tests hand it to the oracle)."""
     mask = torch.empty(M, K, device=device, dtype=torch.float32)

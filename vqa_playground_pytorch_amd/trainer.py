@@ -104,7 +104,7 @@ class DataParallelTrainer:
     """Replicated model + flat-gradient sum-all-reduce + the reference's clip/Adam/ExponentialLR."""
 
     def __init__(self, model, lr=1e-4, clip=0.25, gamma=0.5 ** (1 / 50000), broadcast=True, group=None,
-                 fused_adam=None):
+                 fused_adam=None, graph=False):
         self.model = model
         self.group = group
         self.clip = clip
@@ -120,8 +120,16 @@ class DataParallelTrainer:
         self.betas, self.eps = (0.9, 0.999), 1e-8           # torch.optim.Adam defaults (train.py:290)
         first = next(p for p in model.parameters() if p.requires_grad)
         self.hip = first.is_cuda                              # GPU: fused HIP tail; CPU (gloo tests): torch ops
+        # graph=True: after a few eager steps the step is captured into two hipGraphs (forward+loss+backward+gather,
+        # and clip+Adam) with the all-reduce launched eagerly between them; replays cost ~3 host launches instead of
+        # ~600.  Falls back to eager if a forward draws a host-side dropout seed (fused K2/K5 masks).
+        self.want_graph = bool(graph)
+        self._graph = None
+        self._eager_steps = 0
         if self.hip:
             self.flat = FlatState(model.parameters())
+            self.step_scalars = torch.zeros(2, device=first.device, dtype=torch.float32)
+            self._step_scalars_host = torch.zeros(2, dtype=torch.float32).pin_memory()
             self.grads = None
             self.optimizer = None
         else:
@@ -138,6 +146,12 @@ class DataParallelTrainer:
 
     def step(self, sample, target):
         """One training step on this rank's shard; returns (local loss tensor, global grad norm tensor)."""
+        if self.hip and self.want_graph:
+            return self._graph_step(sample, target)
+        return self.step_eager(sample, target)
+
+    def step_eager(self, sample, target):
+        """The same step launched kernel by kernel (no graph replay)."""
         logits = self.model(sample)
         loss = kld_sum_loss(logits, target)
         # scheduler.step() precedes optimizer.step() in the reference (train.py:75-86): step t uses lr0*gamma^t
@@ -162,6 +176,79 @@ class DataParallelTrainer:
         norm = self.grads.clip_(self.clip) if self.clip else None
         self.optimizer.step()
         return loss.detach(), norm
+
+    # ---- hipGraph replay of the step ---------------------------------------------------------------------------
+    def _front(self, sample, target):
+        """forward + loss + backward + gradient gather (graph 1)."""
+        f = self.flat
+        loss = kld_sum_loss(self.model(sample), target)
+        f.drop_grads()
+        loss.backward()
+        f.gather_grads()
+        return loss.detach()
+
+    def _tail(self):
+        """clip + Adam with the per-step scalars read from device memory (graph 2)."""
+        from . import ops
+        f = self.flat
+        ops.grad_norm_clip_coef(f.g, self.clip if self.clip else 0.0, f.norm_and_coef, f.workspace)
+        ops.adam_step_dyn(f.p, f.g, f.m, f.v, f.norm_and_coef, self.step_scalars, self.betas[0], self.betas[1], self.eps)
+
+    def _set_step_scalars(self):
+        self.iteration += 1
+        self._lr = lr = self.base_lr * self.gamma ** self.iteration
+        self._step_scalars_host[0] = lr / (1.0 - self.betas[0] ** self.iteration)
+        self._step_scalars_host[1] = 1.0 / (1.0 - self.betas[1] ** self.iteration) ** 0.5
+        self.step_scalars.copy_(self._step_scalars_host, non_blocking=True)
+
+    def _graph_step(self, sample, target):
+        from . import ops
+        f = self.flat
+        if self._graph is None:
+            seeds_before = ops.host_seed_draws
+            self._set_step_scalars()
+            loss = self._front(sample, target)
+            if self.world > 1:
+                dist.all_reduce(f.g, op=dist.ReduceOp.SUM, group=self.group)
+            self._tail()
+            self._eager_steps += 1
+            if ops.host_seed_draws != seeds_before:
+                self.want_graph = False       # host-seeded dropout mask in the forward: replay would freeze it
+            elif self._eager_steps >= 3:      # warmed up (allocator, LDS attributes, autotuned GEMMs): capture
+                self._capture(sample, target)
+            return loss, f.norm_and_coef[0]
+        g = self._graph
+        for k, t in g["sample"].items():
+            if sample[k].data_ptr() != t.data_ptr():
+                t.copy_(sample[k], non_blocking=True)
+        if target.data_ptr() != g["target"].data_ptr():
+            g["target"].copy_(target, non_blocking=True)
+        self._set_step_scalars()
+        g["front"].replay()
+        if self.world > 1:
+            dist.all_reduce(f.g, op=dist.ReduceOp.SUM, group=self.group)
+        g["tail"].replay()
+        return g["loss"], f.norm_and_coef[0]
+
+    def _capture(self, sample, target):
+        static_sample = {k: v for k, v in sample.items() if isinstance(v, torch.Tensor)}
+        # torch's capture recipe: one forward+backward on a side stream first, so the parameters' AccumulateGrad
+        # nodes belong to a capturable stream (nodes created on the default stream would run there and abort the
+        # capture).  It only refills the gradient buffer; no parameter is updated.
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._front(static_sample, target)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        front, tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(front, pool=pool):
+            loss = self._front(static_sample, target)
+        with torch.cuda.graph(tail, pool=pool):
+            self._tail()
+        torch.cuda.synchronize()
+        self._graph = {"front": front, "tail": tail, "loss": loss, "sample": static_sample, "target": target}
 
     @property
     def lr(self):
