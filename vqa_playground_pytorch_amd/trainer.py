@@ -241,11 +241,20 @@ class DataParallelTrainer:
             self._front(static_sample, target)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        mode = "global"
+        if self.world > 1:
+            # the collective library's watchdog thread polls events of outstanding work; let every rank drain its
+            # work list first and capture in thread-local mode so another thread's query cannot invalidate the capture
+            import time
+            dist.barrier(group=self.group)
+            torch.cuda.synchronize()
+            time.sleep(1.0)
+            mode = "thread_local"
         front, tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         pool = torch.cuda.graph_pool_handle()
-        with torch.cuda.graph(front, pool=pool):
+        with torch.cuda.graph(front, pool=pool, capture_error_mode=mode):
             loss = self._front(static_sample, target)
-        with torch.cuda.graph(tail, pool=pool):
+        with torch.cuda.graph(tail, pool=pool, capture_error_mode=mode):
             self._tail()
         torch.cuda.synchronize()
         self._graph = {"front": front, "tail": tail, "loss": loss, "sample": static_sample, "target": target}
