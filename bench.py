@@ -37,6 +37,8 @@ def kernel_models(B, N=REGIONS, D=FEAT, G=GLIMPSES, L=LOW, H=HID, R=RANK):
     """Algorithmic bytes / FLOPs per launch (SURVEY.md 8d per-sample figures x samples per launch)."""
     f = 4
     return {
+        "object_difference_attention_fwd": ("valu", B * 2 * G * N * N * L),                 # 2 flop per (mask element, glimpse)
+        "object_difference_attention_bwd": ("valu", B * 4 * G * N * N * L),                 # data pass + weight pass
         "lowrank_bilinear_fusion_fwd": ("mfma", B * (2 * R * N * L * H + 2 * R * N * H)),
         "lowrank_bilinear_fusion_bwd": ("mfma", B * (2 * 2 * R * N * L * H)),              # dx + dW1 contractions
         "pairwise_relation_reduce_fwd": ("hbm", B * (2 * N * D + 2 * D + N) * f),          # 606 352 B/sample
@@ -81,7 +83,7 @@ def roofline_entry(name, shape, launches, mean_ms, B):
     sec = mean_ms * 1e-3
     if bound == "hbm":
         achieved, peak, unit = work / sec / 1e9, HBM_PEAK_GBS, "GB/s"
-    else:
+    else:  # "mfma" and "valu" share the fp32 peak on gfx950 (157.3 TFLOP/s for both pipes)
         achieved, peak, unit = work / sec / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
     return {"kernel": name, "shape": list(shape), "launches": launches, "mean_ms": round(mean_ms, 5), "bound": bound,
             "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
@@ -143,6 +145,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (BASELINE config: 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--relation-mode", type=int, default=1, help="K1: 0 = pairwise, 1 = factored")
+    ap.add_argument("--model", default="cor2", choices=["cor2", "oda"], help="cor2 = the headline config; oda = "
+                    "BASELINE configs[2] (object-difference attention head, 3000 answers), reported the same way")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying "
                     "the captured hipGraphs of the step")
     args = ap.parse_args()
@@ -161,17 +165,21 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    from vqa_playground_pytorch_amd import CoR2Model, ops
+    from vqa_playground_pytorch_amd import CoR2Model, ODAModel, ops
     from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
 
     torch.manual_seed(1234)
-    model = CoR2Model(["PAD", "UNK"], ANSWERS, relation_mode=args.relation_mode).to(dev).train()
+    answers = ANSWERS if args.model == "cor2" else 3000
+    if args.model == "cor2":
+        model = CoR2Model(["PAD", "UNK"], answers, relation_mode=args.relation_mode).to(dev).train()
+    else:
+        model = ODAModel(["PAD", "UNK"], answers).to(dev).train()
     trainer = DataParallelTrainer(model, lr=1e-4, clip=0.25, graph=not args.no_graph)
     torch.manual_seed(100 + rank)  # per-rank dropout streams and data shards differ
     B = args.batch
     v = torch.randn(B, REGIONS, FEAT, device=dev)
     q = torch.randn(B, QDIM, device=dev)
-    a = torch.softmax(2.0 * torch.randn(B, ANSWERS, device=dev), dim=1)
+    a = torch.softmax(2.0 * torch.randn(B, answers, device=dev), dim=1)
     sample = {"v": v, "q_idxes": q}
 
     def barrier():
@@ -194,7 +202,7 @@ def main():
     log("warmup done (graph replay: %s)" % graphed)
     timer = ops.KernelTimer()
     barrier()
-    if not graphed:
+    if not graphed and args.no_graph:
         ops.set_kernel_timer(timer)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -203,11 +211,15 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.set_kernel_timer(None)
     log("timed region done: %.3f s" % elapsed)
-    if graphed:
+    if graphed or not args.no_graph:
         # HIP events cannot be recorded inside hipGraph replays, so the per-kernel durations for `roofline` are taken
         # live from an identical run of the same steps launched kernel by kernel, right after the timed region.
+        # Each of these steps is queued behind a ~10 ms device-side sleep, so the host has enqueued the whole step before
+        # the GPU starts it: the event pairs then bracket back-to-back kernels (pure kernel time, which is what
+        # rocprofv3's per-kernel average reports) instead of the host's launch gaps.
         ops.set_kernel_timer(timer)
         for _ in range(min(args.steps, 10)):
+            torch.cuda._sleep(24_000_000)
             trainer.step_eager(sample, a)
         barrier()
         ops.set_kernel_timer(None)
@@ -220,11 +232,12 @@ def main():
     if rank == 0:
         summary = timer.summary()
         entries = [roofline_entry(name, shape, n, ms, B) for (name, shape), (n, ms) in summary.items()
-                   if shape[0] == B and (len(shape) < 2 or shape[1] == REGIONS)]
+                   if name in kernel_models(B) and shape[0] == B and (len(shape) < 2 or shape[1] == REGIONS)]
         entries.sort(key=lambda e: -e["mean_ms"] * e["launches"])
-        dominant = next((e for e in entries if e["kernel"] == "lowrank_bilinear_fusion_fwd"), entries[0])
+        head = "lowrank_bilinear_fusion_fwd" if args.model == "cor2" else "object_difference_attention_fwd"
+        dominant = next((e for e in entries if e["kernel"] == head), entries[0])
         result = {
-            "metric": "VQA samples/sec (fwd+bwd), CoR2 batch 512, 36x2048 regions",
+            "metric": "VQA samples/sec (fwd+bwd), %s batch 512, 36x2048 regions" % ("CoR2" if args.model == "cor2" else "ODA"),
             "value": round(world * B * args.steps / elapsed, 1),
             "unit": "samples/s",
             "n_gpus": world,
@@ -236,8 +249,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "CoR2 fwd+bwd fp32, batch %d per GPU, 36x2048 regions + 2400-d question, 2-step "
-                                   "reasoning chain, 2000 answers (BASELINE configs[1]; configs[3] at 8 GPUs)" % B,
+            "config": {"workload": ("CoR2 fwd+bwd fp32, batch %d per GPU, 36x2048 regions + 2400-d question, 2-step "
+                                    "reasoning chain, 2000 answers (BASELINE configs[1]; configs[3] at 8 GPUs)" % B)
+                       if args.model == "cor2" else
+                       ("ODA fwd+bwd fp32, batch %d per GPU, 36x2048 regions + 2400-d question, 36x36 object-difference "
+                        "attention, 3000 answers (BASELINE configs[2])" % B),
                        "global_batch": world * B, "step": "forward + KLD-sum loss + backward + grad sum-all-reduce "
                        "+ clip 0.25 + Adam (dropout active)", "parallelism": "dp%d" % world,
                        "launch": "hipGraph replay (2 graphs + eager all-reduce)" if graphed else "eager",
@@ -246,7 +262,7 @@ def main():
                                                   "mean_ms", "launches")},
             "roofline_all": entries,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "cor2":
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result))
     if world > 1:

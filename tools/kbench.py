@@ -152,6 +152,26 @@ def main():
         res = timeit(fns, args.rounds)
         report("K5 backward, dW only", {"bwd dW+db (no dx)": res["bwd dW+db (no dx)"]}, 2 * B * N * D * L, "TF")
         report("K5 backward, dW + dx", {k: res[k] for k in ("bwd dW+db+dx", "torch bwd dW+db+dx")}, 4 * B * N * D * L, "TF")
+    if want("k2"):
+        vl = torch.rand(B, N, L, device=dev)
+        ql = torch.rand(B, L, device=dev)
+        wk = torch.randn(G, N * L, device=dev) / (N * L) ** 0.5
+        bk = torch.randn(G, device=dev) * 0.1
+        fns = {"fwd p=0": lambda: ops.object_difference_attention(vl, ql, wk, bk, 0.0, 0),
+               "fwd p=0.5": lambda: ops.object_difference_attention(vl, ql, wk, bk, 0.5, 7)}
+        # VALU-bound: N*N*L mask elements per sample, 2 flop per (element, glimpse) + the difference
+        report("K2 forward (ODA difference attention; 'TF' = 2*G*N*N*L*B flop)", timeit(fns, args.rounds), 2 * G * N * N * L * B, "TF")
+        vr, qr, wr, br = (t.clone().requires_grad_() for t in (vl, ql, wk, bk))
+        gl = torch.randn(B, N, G, device=dev)
+        o0 = ops.object_difference_attention(vr, qr, wr, br, 0.0, 0)
+        o5 = ops.object_difference_attention(vr, qr, wr, br, 0.5, 7)
+        fns = {"bwd p=0": lambda: torch.autograd.grad(o0, [vr, qr, wr, br], gl, retain_graph=True),
+               "bwd p=0.5": lambda: torch.autograd.grad(o5, [vr, qr, wr, br], gl, retain_graph=True)}
+        report("K2 backward (data + weight passes)", timeit(fns, args.rounds), 2 * 2 * G * N * N * L * B, "TF")
+        def torch_ref():
+            vq = ((vl[:, :, None, :] - vl[:, None, :, :]) * ql[:, None, None, :]).reshape(B, N, N * L)
+            return torch.nn.functional.linear(torch.nn.functional.dropout(vq, 0.5, True), wk, bk)
+        report("reference: torch broadcast difference + dropout + linear (materialises [B,36,11160])", timeit({"torch fwd p=0.5": torch_ref}, args.rounds), 2 * G * N * N * L * B, "TF")
     if want("copy"):
         y = torch.empty_like(v)
         fns = {"torch copy 151MB": lambda: y.copy_(v)}

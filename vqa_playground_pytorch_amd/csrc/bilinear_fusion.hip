@@ -93,15 +93,23 @@ __global__ __launch_bounds__(kGemmThreads) void bilinear_fwd_kernel(const float*
 struct ScaledRaw {
   float2 a, s;
 };
+// sample index of row m: m / N by multiply-high with inv = floor(2^32 / N) + 1 (exact for m < 2^32 / N, checked on
+// the host; an integer division costs ~25 VALU instructions, and the dW source needs one per staged slot per stage)
+struct RowToSample {
+  uint32_t inv;  // 0 when N == 1
+  __device__ __forceinline__ int operator()(int m) const { return inv ? (int)__umulhi((uint32_t)m, inv) : m; }
+};
+static RowToSample make_row_to_sample(int N) { return RowToSample{N == 1 ? 0u : (uint32_t)((1ull << 32) / (uint32_t)N) + 1u}; }
 // A[m][k=h] = g[m][h] * h2[b(m)][r][h]   (K-contiguous; the scale is applied while staging)
 struct SrcScaledKC {
   using Raw = ScaledRaw;
   const float* g;
   const float* h2r;  // h2 + r*H
-  int M, H, N, RH;
+  int M, H, RH;
+  RowToSample samp;
   __device__ __forceinline__ Raw fetch(int m, int h) const {
     const int mc = min(m, M - 1), hc = min(h, H - 2);
-    return Raw{ld2(g + (size_t)mc * H + hc), ld2(h2r + (size_t)(mc / N) * RH + hc)};
+    return Raw{ld2(g + (size_t)mc * H + hc), ld2(h2r + (size_t)samp(mc) * RH + hc)};
   }
   __device__ __forceinline__ float2 finish(Raw v, int m, int h) const {
     return keep_if(m < M && h < H, make_float2(v.a.x * v.s.x, v.a.y * v.s.y));
@@ -112,10 +120,11 @@ struct SrcScaledMC {
   using Raw = ScaledRaw;
   const float* g;
   const float* h2r;
-  int m_hi, H, N, RH;
+  int m_hi, H, RH;
+  RowToSample samp;
   __device__ __forceinline__ Raw fetch(int h, int m) const {
     const int mc = min(m, m_hi - 1), hc = min(h, H - 2);
-    return Raw{ld2(g + (size_t)mc * H + hc), ld2(h2r + (size_t)(mc / N) * RH + hc)};
+    return Raw{ld2(g + (size_t)mc * H + hc), ld2(h2r + (size_t)samp(mc) * RH + hc)};
   }
   __device__ __forceinline__ float2 finish(Raw v, int h, int m) const {
     return keep_if(m < m_hi && h < H, make_float2(v.a.x * v.s.x, v.a.y * v.s.y));
@@ -126,7 +135,8 @@ struct SrcScaledMC {
 template <int BM, int BN, int PF>
 __global__ __launch_bounds__(kGemmThreads) void bilinear_dx_kernel(const float* __restrict__ g, RankPtrs rp,
                                                                    const float* __restrict__ h2, float* __restrict__ dx,
-                                                                   int M, int N, int L, int H, int R, int tiles_n) {
+                                                                   int M, int N, int L, int H, int R, int tiles_n,
+                                                                   RowToSample samp) {
   using T = GemmTile<BM, BN, 16, true, false>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* smem = reinterpret_cast<float*>(smem_raw);
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(kGemmThreads) void bilinear_dx_kernel(const float* 
   f32x16 acc[T::TM][T::TN];
   zero_acc(acc);
   for (int r = 0; r < R; ++r) {
-    const SrcScaledKC sa{g, h2 + (size_t)r * H, M, H, N, R * H};
+    const SrcScaledKC sa{g, h2 + (size_t)r * H, M, H, R * H, samp};
     const SrcMC sb{rp.w[r], L, L, H};
     gemm_tile<BM, BN, 16, PF, true, false>(sa, sb, m0, n0, 0, H, smem, acc);
   }
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(kGemmThreads) void bilinear_dw_kernel(const float* 
                                                                    const float* __restrict__ x, int ldx,
                                                                    float* __restrict__ slab, float* __restrict__ dbslab,
                                                                    int M, int N, int L, int H, int R, int tiles_n,
-                                                                   int rows_per_split) {
+                                                                   int rows_per_split, RowToSample samp) {
   using T = GemmTile<BM, BN, 16, false, false>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* smem = reinterpret_cast<float*>(smem_raw);
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(kGemmThreads) void bilinear_dw_kernel(const float* 
   const int m_lo = s * rows_per_split, m_hi = min(M, m_lo + rows_per_split);
   f32x16 acc[T::TM][T::TN];
   zero_acc(acc);
-  const SrcScaledMC sa{g, h2 + (size_t)r * H, m_hi, H, N, R * H};
+  const SrcScaledMC sa{g, h2 + (size_t)r * H, m_hi, H, R * H, samp};
   const SrcMC sb{x, ldx, L, m_hi};
   float colsum[T::TM];
 #pragma unroll
@@ -303,7 +313,7 @@ static int check_common(const char* who, const void* x, int ldx, int B, int N, i
   VQA_REQUIRE(L % 2 == 0 && H % 2 == 0 && ldx % 2 == 0 && ldx >= L, VQA_E_UNSUPPORTED,
               "%s: needs even L, H, ldx and ldx >= L (L=%d H=%d ldx=%d)", who, L, H, ldx);
   VQA_REQUIRE(aligned(x, 8), VQA_E_UNSUPPORTED, "%s: x must be 8-byte aligned", who);
-  VQA_REQUIRE((long)B * N < (1L << 30), VQA_E_UNSUPPORTED, "%s: B*N too large", who);
+  VQA_REQUIRE((long)B * N < (1L << 30) && (long)B * N * N < (1L << 32), VQA_E_UNSUPPORTED, "%s: B*N too large", who);
   return VQA_OK;
 }
 
@@ -382,7 +392,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd(const float* x, int ldx, const fl
     const size_t lds = GemmTile<BM_, BN_, 16, true, false>::kSmemBytes;                                                  \
     VQA_ENSURE_LDS((bilinear_dx_kernel<BM_, BN_, BK_>), lds);                                                        \
     hipLaunchKernelGGL((bilinear_dx_kernel<BM_, BN_, BK_>), dim3(tiles_m * tiles_n), dim3(kGemmThreads), lds, s, g, rp, h2, \
-                       d_x, M, N, L, H, R, tiles_n);                                                                 \
+                       d_x, M, N, L, H, R, tiles_n, make_row_to_sample(N));                                                                 \
   }
     VQA_TILE_SWITCH(t, LAUNCH);
 #undef LAUNCH
@@ -397,7 +407,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd(const float* x, int ldx, const fl
     const size_t lds = GemmTile<BM_, BN_, 16, false, false>::kSmemBytes;                                                \
     VQA_ENSURE_LDS((bilinear_dw_kernel<BM_, BN_, BK_>), lds);                                                       \
     hipLaunchKernelGGL((bilinear_dw_kernel<BM_, BN_, BK_>), dim3(tiles_m * tiles_n, R, S), dim3(kGemmThreads), lds, s, g,  \
-                       h2, x, ldx, slab, dbslab, M, N, L, H, R, tiles_n, rows_per_split);                                   \
+                       h2, x, ldx, slab, dbslab, M, N, L, H, R, tiles_n, rows_per_split, make_row_to_sample(N));                                   \
   }
     VQA_TILE_SWITCH(tw, LAUNCH);
 #undef LAUNCH
