@@ -223,6 +223,10 @@ struct SrcMC {  // X[k][mn], MN-contiguous rows of stride ld.  Needs K >= 1, MN 
   __device__ __forceinline__ float2 finish(Raw v, int mn, int k) const { return keep_if(mn < MN && k < K, v); }
 };
 
+// Tried and rejected (round 1, measured with tools/kbench.py): BK = 32 (no gain at K = 310, fewer workgroups per CU);
+// PF = 3 register sets (occupancy loss outweighs the extra latency cover); a 3-stage LDS ring with double-buffered
+// operand fragments read one stage ahead (+63 VGPRs -> 2 waves per SIMD instead of 4: 83 vs 90 TF/s on the K4 forward).
+
 // Host-side tile choice: fewest CU-rounds of (padded) work, mild preference for the larger tile.
 struct TileChoice {
   int bm, bn, pf;  // tile rows, tile cols, prefetch distance in stages (register sets in flight)
