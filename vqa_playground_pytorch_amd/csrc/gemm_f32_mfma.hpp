@@ -225,7 +225,10 @@ struct SrcMC {  // X[k][mn], MN-contiguous rows of stride ld.  Needs K >= 1, MN 
 
 // Tried and rejected (round 1, measured with tools/kbench.py): BK = 32 (no gain at K = 310, fewer workgroups per CU);
 // PF = 3 register sets (occupancy loss outweighs the extra latency cover); a 3-stage LDS ring with double-buffered
-// operand fragments read one stage ahead (+63 VGPRs -> 2 waves per SIMD instead of 4: 83 vs 90 TF/s on the K4 forward).
+// operand fragments read one stage ahead (+63 VGPRs -> 2 waves per SIMD instead of 4: 83 vs 90 TF/s on the K4 forward);
+// a persistent workgroup streaming ONE pipeline across all its (tile, rank) segments so that the next tile's loads
+// overlap the current epilogue (per-stage descriptor/address recomputation cost more than the hidden pipeline fill:
+// 60 vs 90 TF/s) -- to be retried with incrementally updated per-slot addresses.
 
 // Host-side tile choice: fewest CU-rounds of (padded) work, mild preference for the larger tile.
 struct TileChoice {
