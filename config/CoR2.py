@@ -7,6 +7,7 @@
 import os
 
 from vqa_playground_pytorch_amd.cor2 import Model  # noqa: F401
+from vqa_playground_pytorch_amd.encoder import BayesianGRU, SkipThoughts  # noqa: F401
 from vqa_playground_pytorch_amd.layers import (MutanFusion, MyATT, MyConv1d, MyLinear,  # noqa: F401
                                                bmatmul, bmul)
 

@@ -6,6 +6,7 @@ backed by the MI355X HIP kernels.
 """
 import os
 
+from vqa_playground_pytorch_amd.encoder import BayesianGRU, SkipThoughts  # noqa: F401
 from vqa_playground_pytorch_amd.layers import (MutanFusion, MyATT, MyConv1d, MyLinear,  # noqa: F401
                                                bmatmul, bmul)
 from vqa_playground_pytorch_amd.oda import Model  # noqa: F401

@@ -226,11 +226,37 @@ def full_model(mod, name, nans, seed_w, seed_in, feature_key):
     print(name + "_b4.npz:", len(out), "arrays,", size // 1024, "KiB, loss", out["loss"])
 
 
+def encoder(putils):
+    """BayesianGRU(620, 2400, af='relu') + padded embedding, the pieces SkipThoughts assembles (its constructor
+    downloads weight files, so the pieces are built directly): eval-mode outputs + one gradient digest."""
+    out = {}
+    vocab, T, B = 9, 6, 4
+    emb = torch.nn.Embedding(vocab, 620, padding_idx=0)
+    gru = putils.BayesianGRU(input_size=620, hidden_size=2400, dropout=0.25, return_last=True, af="relu")
+    holder = torch.nn.Module()
+    holder.embedding, holder.gru = emb, gru
+    seeded.load_state(holder, 91)
+    holder.eval()
+    idx = torch.tensor([[3, 1, 4, 1, 5, 2], [2, 7, 0, 0, 0, 0], [8, 0, 0, 0, 0, 0], [1, 2, 3, 4, 0, 0]])
+    x = emb(idx)
+    lengths = (idx.size(1) - idx.eq(0).sum(1)).long()
+    y = gru(x, lengths)
+    (y * t(seeded.seeded_array((B, 2400), 92))).sum().backward()
+    out["q"] = y.detach().numpy()
+    out["all_hiddens_norm"] = np.float64(gru.all_hiddens.double().norm().item())
+    out["g.embedding"] = emb.weight.grad.numpy()
+    out["g.weight_hn.norm"] = np.float64(gru.gru_cell.weight_hn.weight.grad.double().norm().item())
+    out["g.weight_ir.bias"] = gru.gru_cell.weight_ir.bias.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "encoder.npz"), **out)
+    print("encoder.npz:", len(out), "arrays")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     cor, oda, putils = import_reference()
     blocks(cor, oda, putils)
+    encoder(putils)
     full_model(cor, "cor2", 2000, seed_w=0, seed_in=1, feature_key="feature")
     full_model(oda, "oda", 3000, seed_w=0, seed_in=1, feature_key=None)
 

@@ -1,0 +1,75 @@
+"""Question encoder (seq2vec slot): SkipThoughts = padded embedding + BayesianGRU, against outputs of the reference's
+own BayesianGRU (tests/golden/encoder.npz, built by make_golden.py).  Pure torch ops, so the parity check runs on CPU;
+the GPU test checks the GPU run against it and the encoder -> CoR2 head plumbing with int64 token ids."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import seeded
+from vqa_playground_pytorch_amd.encoder import BayesianGRU, SkipThoughts
+
+IDX = [[3, 1, 4, 1, 5, 2], [2, 7, 0, 0, 0, 0], [8, 0, 0, 0, 0, 0], [1, 2, 3, 4, 0, 0]]
+
+
+def build(device="cpu"):
+    enc = SkipThoughts(["w%d" % i for i in range(9)], af="relu")
+    # the golden generator seeded a holder with children {embedding, gru}: same names, same order
+    seeded.load_state(enc, 91)
+    return enc.eval().to(device)
+
+
+def test_state_dict_names_match_reference():
+    names = sorted(build().state_dict())
+    assert names == sorted(["embedding.weight"] +
+                           ["gru.gru_cell.weight_%s.%s" % (g, p) for g in ("ir", "ii", "in") for p in ("weight", "bias")] +
+                           ["gru.gru_cell.weight_%s.weight" % g for g in ("hr", "hi", "hn")])
+    assert sum(v.numel() for v in build().state_dict().values()) == 9 * 620 + 3 * (620 * 2400 + 2400) + 3 * 2400 * 2400
+
+
+def test_encoder_matches_reference_golden(golden_dir):
+    gold = np.load(os.path.join(golden_dir, "encoder.npz"))
+    enc = build()
+    q = enc(torch.tensor(IDX))
+    (q * torch.from_numpy(seeded.seeded_array((4, 2400), 92))).sum().backward()
+    scale = np.abs(gold["q"]).max()
+    assert np.abs(q.detach().numpy() - gold["q"]).max() <= 1e-5 * scale
+    assert abs(enc.gru.all_hiddens.double().norm().item() - gold["all_hiddens_norm"]) <= 1e-5 * gold["all_hiddens_norm"]
+    g = enc.embedding.weight.grad.numpy()
+    assert np.abs(g - gold["g.embedding"]).max() <= 1e-4 * np.abs(gold["g.embedding"]).max()
+    assert np.all(g[0] == 0)                                   # padding row gets no gradient
+    gn = enc.gru.gru_cell.weight_hn.weight.grad.double().norm().item()
+    assert abs(gn - gold["g.weight_hn.norm"]) <= 1e-4 * gold["g.weight_hn.norm"]
+    gb = enc.gru.gru_cell.weight_ir.bias.grad.numpy()
+    assert np.abs(gb - gold["g.weight_ir.bias"]).max() <= 1e-4 * np.abs(gold["g.weight_ir.bias"]).max()
+
+
+def test_sequence_shared_dropout_and_errors():
+    gru = BayesianGRU(8, 16, dropout=0.5, af="relu").train()
+    x = torch.randn(3, 5, 8)
+    a, b = gru(x, torch.tensor([5, 2, 1])), gru(x, torch.tensor([5, 2, 1]))
+    assert a.shape == (3, 16) and not torch.equal(a, b)       # fresh masks per sequence
+    gru.eval()
+    assert torch.equal(gru(x, torch.tensor([5, 2, 1])), gru(x, torch.tensor([5, 2, 1])))
+    with pytest.raises(ValueError):
+        build()(torch.zeros(2, 6))                            # float input: token ids expected
+    with pytest.raises(ValueError):
+        SkipThoughts(["a"], gru="GRU")
+
+
+@pytest.mark.gpu
+def test_encoder_feeds_the_hip_head(golden_dir):
+    from vqa_playground_pytorch_amd import CoR2Model
+    dev = torch.device("cuda:0")
+    gold = np.load(os.path.join(golden_dir, "encoder.npz"))
+    enc = build(dev)
+    q = enc(torch.tensor(IDX, device=dev))
+    assert np.abs(q.detach().cpu().numpy() - gold["q"]).max() <= 1e-3 * np.abs(gold["q"]).max()
+    model = CoR2Model(["w%d" % i for i in range(9)], 50, seq2vec=SkipThoughts(["w%d" % i for i in range(9)], af="relu")).to(dev)
+    assert any(k.startswith("seq2vec.gru.gru_cell.weight_hn") for k in model.state_dict())
+    v = torch.randn(4, 36, 2048, device=dev)
+    logits = model({"v": v, "q_idxes": torch.tensor(IDX, device=dev)})
+    logits.sum().backward()
+    assert logits.shape == (4, 50) and torch.isfinite(logits).all()
+    assert model.seq2vec.gru.gru_cell.weight_hn.weight.grad is not None

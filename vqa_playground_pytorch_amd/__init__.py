@@ -6,6 +6,7 @@ kernels in ``libvqa_mi355x.so`` (C ABI: include/vqa_mi355x.h).  ``config/CoR2.py
 """
 from . import _lib, layers, ops  # noqa: F401
 from .cor2 import Model as CoR2Model  # noqa: F401
+from .encoder import BayesianGRU, SkipThoughts  # noqa: F401
 from .oda import Model as ODAModel  # noqa: F401
 
-__all__ = ["CoR2Model", "ODAModel", "layers", "ops"]
+__all__ = ["CoR2Model", "ODAModel", "SkipThoughts", "BayesianGRU", "layers", "ops"]

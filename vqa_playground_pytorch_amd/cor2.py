@@ -19,6 +19,9 @@ class Model(nn.Module):
         # 0 = pairwise (every (i,j) term summed from the LDS tile), 1 = factored (same value, one pass)
         self.relation_mode = relation_mode
 
+        if seq2vec == "skipthoughts":      # the reference's encoder (config/CoR2.py:166), randomly initialised here
+            from .encoder import SkipThoughts
+            seq2vec = SkipThoughts(vocab_list=vocab_words, gru="BayesianGRU", return_last=True, af="relu")
         self.seq2vec = seq2vec if seq2vec is not None else QuestionVectorInput(2400)
         self.compress_v = MyConv1d(2048, 310, 1, 1, p=0.5, af="relu")
         self.compress_v2 = MyConv1d(2048, 310, 1, 1, p=0.5, af="relu")

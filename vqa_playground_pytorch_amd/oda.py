@@ -18,6 +18,9 @@ class Model(nn.Module):
         self.num_classes = num_ans
         self.regions = regions
 
+        if seq2vec == "skipthoughts":      # the reference's encoder (config/CoR2.py:166), randomly initialised here
+            from .encoder import SkipThoughts
+            seq2vec = SkipThoughts(vocab_list=vocab_words, gru="BayesianGRU", return_last=True, af="relu")
         self.seq2vec = seq2vec if seq2vec is not None else QuestionVectorInput(2400)
         self.compress_v = MyConv1d(2048, 310, 1, 1, p=0.5, af="relu")
         self.compress_q = MyLinear(2400, 310, p=0.5, af="relu")
