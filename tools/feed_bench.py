@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the CoR2 training step: batches start in (pinned) host memory and are streamed through
+feed.DevicePrefetcher while the hipGraph-replayed step runs.  NOT the headline number (bench.py times inputs resident
+in HBM); it sizes the feed path of SURVEY 8f row 4.   python tools/feed_bench.py [--steps 30]"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from vqa_playground_pytorch_amd import CoR2Model, feed  # noqa: E402
+from vqa_playground_pytorch_amd.trainer import DataParallelTrainer  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--batch", type=int, default=512)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    B = args.batch
+    torch.manual_seed(0)
+    host = [{"v": torch.randn(B, 36, 2048).pin_memory(), "q_idxes": torch.randn(B, 2400).pin_memory(),
+             "a": torch.softmax(torch.randn(B, 2000), 1).pin_memory()} for _ in range(3)]
+    model = CoR2Model(["PAD"], 2000).to(dev).train()
+    tr = DataParallelTrainer(model, graph=True)
+
+    def stream(n):
+        for i in range(n):
+            yield host[i % len(host)]
+
+    for b in feed.DevicePrefetcher(stream(6), dev):       # warm-up + graph capture
+        tr.step({"v": b["v"], "q_idxes": b["q_idxes"]}, b["a"])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in feed.DevicePrefetcher(stream(args.steps), dev):
+        tr.step({"v": b["v"], "q_idxes": b["q_idxes"]}, b["a"])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # raw H2D rate of one batch for reference
+    d = torch.empty_like(host[0]["v"], device=dev)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(10):
+        d.copy_(host[0]["v"], non_blocking=True)
+    torch.cuda.synchronize()
+    h2d = 10 * host[0]["v"].numel() * 4 / (time.perf_counter() - t1) / 1e9
+    print("host-fed: %.1f samples/s (%.3f ms/step, graph=%s); pinned H2D of v alone: %.1f GB/s"
+          % (B * args.steps / dt, 1e3 * dt / args.steps, tr._graph is not None, h2d))
+
+
+if __name__ == "__main__":
+    main()
