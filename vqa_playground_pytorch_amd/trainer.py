@@ -215,7 +215,15 @@ class DataParallelTrainer:
             if ops.host_seed_draws != seeds_before:
                 self.want_graph = False       # host-seeded dropout mask in the forward: replay would freeze it
             elif self._eager_steps >= 3:      # warmed up (allocator, LDS attributes, autotuned GEMMs): capture
-                self._capture(sample, target)
+                try:
+                    self._capture(sample, target)
+                except Exception as e:        # noqa: BLE001 -- any capture failure: keep training, kernel by kernel
+                    import sys
+                    print("[vqa trainer] hipGraph capture failed (%s: %s); continuing with eager launches"
+                          % (type(e).__name__, str(e).splitlines()[0] if str(e) else ""), file=sys.stderr)
+                    self._graph = None
+                    self.want_graph = False
+                    torch.cuda.synchronize()
             return loss, f.norm_and_coef[0]
         g = self._graph
         for k, t in g["sample"].items():
