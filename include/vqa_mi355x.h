@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VQA_ABI_VERSION 1
+#define VQA_ABI_VERSION 2
 
 #define VQA_OK 0
 #define VQA_E_BADARG (-1)      /* null pointer, non-positive size, size over a documented limit */
@@ -125,13 +125,14 @@ int vqa_lowrank_bilinear_fusion_bwd(const float* x, int ldx, const float* const*
  *   logits[b,i,g] = bias[g] + sum_{j,d} w[g,j*L+d] * keep(b,i,j*L+d) * (vl[b,i,d]-vl[b,j,d]) * ql[b,d]
  *
  * keep() = 1 when p_drop == 0, else 0 or 1/(1-p_drop) from a counter-based generator keyed by
- * (seed, element index); vqa_object_difference_dropout_mask writes the same mask as fp32 [B,N,N*L]
+ * (seed, element index).  seed_ptr (optional, DEVICE memory): when not NULL the effective seed is *seed_ptr + seed,
+ * read at run time -- a captured hipGraph can then be replayed with a fresh mask per step by updating that word; vqa_object_difference_dropout_mask writes the same mask as fp32 [B,N,N*L]
  * so a test can hand it to the oracle.  vl [B,N,L]; ql [B,L]; w [G,N*L]; bias [G]; logits [B,N,G].
  * Limits: G <= 8, N <= 128, L <= 1024.
  * ------------------------------------------------------------------------------------------- */
 int vqa_object_difference_attention_fwd(const float* vl, const float* ql, const float* w,
                                         const float* bias, float* logits, float p_drop,
-                                        uint64_t seed, int B, int N, int L, int G,
+                                        uint64_t seed, const uint64_t* seed_ptr, int B, int N, int L, int G,
                                         vqa_stream_t stream);
 
 size_t vqa_object_difference_attention_bwd_workspace_bytes(int B, int N, int L, int G);
@@ -141,11 +142,11 @@ size_t vqa_object_difference_attention_bwd_workspace_bytes(int B, int N, int L, 
 int vqa_object_difference_attention_bwd(const float* vl, const float* ql, const float* w,
                                         const float* d_logits, float* d_vl, float* d_ql, float* d_w,
                                         float* d_bias, void* workspace, size_t workspace_bytes,
-                                        float p_drop, uint64_t seed, int B, int N, int L, int G,
-                                        vqa_stream_t stream);
+                                        float p_drop, uint64_t seed, const uint64_t* seed_ptr, int B, int N,
+                                        int L, int G, vqa_stream_t stream);
 
-int vqa_object_difference_dropout_mask(float* mask, float p_drop, uint64_t seed, int B, int N, int L,
-                                       vqa_stream_t stream);
+int vqa_object_difference_dropout_mask(float* mask, float p_drop, uint64_t seed, const uint64_t* seed_ptr, int B,
+                                       int N, int L, vqa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K5  fused dropout + linear + bias + activation on the fp32 MFMA tile engine.
@@ -156,11 +157,11 @@ int vqa_object_difference_dropout_mask(float* mask, float p_drop, uint64_t seed,
  *   y[m,:] = act( (x[m,:] * keep(m,:)) W^T + bias )        x [M,K] row stride ldx; w [N,K]; y [M,N] dense
  *
  * act: 0 = none, 1 = relu.  keep() as in K2: 1 when p_drop == 0, else 0 or 1/(1-p) from the counter hash of
- * (seed, m*K+k); vqa_linear_dropout_mask writes it as fp32 [M,K] for tests.  bias may be NULL.
+ * (seed, m*K+k) -- seed / seed_ptr as in K2; vqa_linear_dropout_mask writes it as fp32 [M,K] for tests.  bias may be NULL.
  * Limits: K, N, ldx even; 8-byte aligned pointers.
  * ------------------------------------------------------------------------------------------- */
 int vqa_linear_act_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int M, int K,
-                       int N, int act, float p_drop, uint64_t seed, vqa_stream_t stream);
+                       int N, int act, float p_drop, uint64_t seed, const uint64_t* seed_ptr, vqa_stream_t stream);
 
 size_t vqa_linear_act_bwd_workspace_bytes(int M, int K, int N);
 
@@ -168,9 +169,10 @@ size_t vqa_linear_act_bwd_workspace_bytes(int M, int K, int N);
  * d_x [M,K] dense or NULL, d_w [N,K], d_b [N] or NULL.  Same (p_drop, seed) as the forward. */
 int vqa_linear_act_bwd(const float* x, int ldx, const float* w, const float* y, const float* gy, float* d_x,
                        float* d_w, float* d_b, void* workspace, size_t workspace_bytes, int M, int K, int N,
-                       int act, float p_drop, uint64_t seed, vqa_stream_t stream);
+                       int act, float p_drop, uint64_t seed, const uint64_t* seed_ptr, vqa_stream_t stream);
 
-int vqa_linear_dropout_mask(float* mask, float p_drop, uint64_t seed, int M, int K, vqa_stream_t stream);
+int vqa_linear_dropout_mask(float* mask, float p_drop, uint64_t seed, const uint64_t* seed_ptr, int M, int K,
+                            vqa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Train-step tail over flat fp32 buffers.

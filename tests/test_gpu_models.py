@@ -247,3 +247,23 @@ def test_graph_replay_equals_eager_steps():
     assert out[False][2] == out[True][2]
     for p0, p1 in zip(out[False][1], out[True][1]):
         assert (p0 - p1).abs().max().item() <= 2e-3 * max(p0.abs().max().item(), 1e-3)
+
+
+def test_oda_graph_replay_draws_fresh_masks():
+    """ODA in train mode: K2's dropout seed lives in device memory, so the step is graph-captured and every replay
+    still draws a new mask (losses differ from step to step on identical data; same torch seed -> same sequence)."""
+    from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
+
+    def run():
+        torch.manual_seed(7)
+        model = build("oda", 300).train()
+        tr = DataParallelTrainer(model, lr=1e-6, clip=0.25, graph=True)
+        v, q, a = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(8, answers=300, seed=31))
+        losses = [tr.step({"v": v, "q_idxes": q}, a)[0].item() for _ in range(8)]
+        return losses, tr._graph is not None
+
+    l1, graphed = run()
+    l2, _ = run()
+    assert graphed, "ODA train step should be graph-captured now that the mask seed is a device word"
+    assert len(set(round(x, 4) for x in l1[3:])) > 2, l1          # replays do not repeat one frozen mask
+    assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(l1, l2)), (l1, l2)

@@ -9,7 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VQA_LIB_PATH", os.path.join(_HERE, "libvqa_mi355x.so"))  # env override: profiling builds
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_f = ctypes.c_void_p          # device pointer to fp32
 _c_pp = ctypes.c_void_p         # host array of device pointers
@@ -33,17 +33,17 @@ SIGNATURES = {
     "vqa_lowrank_bilinear_fusion_bwd_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i, _c_i, _c_i]),
     "vqa_lowrank_bilinear_fusion_bwd": (_c_i, [_c_f, _c_i, _c_pp, _c_f, _c_f, _c_f, _c_f, _c_pp, _c_pp, _c_f,
                                                _c_f, _c_sz, _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
-    "vqa_object_difference_attention_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_fl, _c_u64,
+    "vqa_object_difference_attention_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_fl, _c_u64, _c_f,
                                                    _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_object_difference_attention_bwd_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i, _c_i]),
     "vqa_object_difference_attention_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz,
-                                                   _c_fl, _c_u64, _c_i, _c_i, _c_i, _c_i, _c_st]),
-    "vqa_object_difference_dropout_mask": (_c_i, [_c_f, _c_fl, _c_u64, _c_i, _c_i, _c_i, _c_st]),
-    "vqa_linear_act_fwd": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_fl, _c_u64, _c_st]),
+                                                   _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_object_difference_dropout_mask": (_c_i, [_c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_linear_act_fwd": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_fl, _c_u64, _c_f, _c_st]),
     "vqa_linear_act_bwd_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i]),
     "vqa_linear_act_bwd": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz,
-                                  _c_i, _c_i, _c_i, _c_i, _c_fl, _c_u64, _c_st]),
-    "vqa_linear_dropout_mask": (_c_i, [_c_f, _c_fl, _c_u64, _c_i, _c_i, _c_st]),
+                                  _c_i, _c_i, _c_i, _c_i, _c_fl, _c_u64, _c_f, _c_st]),
+    "vqa_linear_dropout_mask": (_c_i, [_c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_st]),
     "vqa_grad_norm_workspace_bytes": (_c_sz, []),
     "vqa_grad_norm_clip_coef": (_c_i, [_c_f, _c_sz, _c_fl, _c_f, _c_f, _c_sz, _c_st]),
     "vqa_adam_step": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_sz, _c_f, _c_fl, _c_fl, _c_fl, _c_fl, _c_i, _c_st]),

@@ -126,20 +126,24 @@ __device__ __forceinline__ uint32_t mask_word(uint64_t counter, uint64_t seed) {
 struct DropCfg {
   uint32_t p8;   // drop when byte < p8
   float scale;   // 256 / (256 - p8)
-  uint64_t seed;
+  uint64_t seed;              // host seed, or the salt added to *seed_ptr
+  const uint64_t* seed_ptr;   // optional DEVICE word holding the step's seed (graph replays: the host value is frozen at
+                              // capture, the device word moves on); the effective seed is *seed_ptr + seed
+  __device__ __forceinline__ uint64_t effective() const { return seed_ptr != nullptr ? seed_ptr[0] + seed : seed; }
 };
 
-inline DropCfg make_drop(float p, uint64_t seed) {
+inline DropCfg make_drop(float p, uint64_t seed, const uint64_t* seed_ptr = nullptr) {
   int p8 = (int)(p * 256.f + 0.5f);
   if (p8 < 0) p8 = 0;
   if (p8 > 255) p8 = 255;
-  return DropCfg{(uint32_t)p8, 256.f / (256.f - (float)p8), seed};
+  return DropCfg{(uint32_t)p8, 256.f / (256.f - (float)p8), seed, seed_ptr};
 }
 
 
 // multipliers for the two consecutive elements e (even) and e+1 of a row-major tensor with < 2^32 elements
 __device__ __forceinline__ uint32_t drop_key(const DropCfg& dc) {
-  return (uint32_t)dc.seed ^ ((uint32_t)(dc.seed >> 32) * 0x9E3779B9u);
+  const uint64_t s = dc.effective();
+  return (uint32_t)s ^ ((uint32_t)(s >> 32) * 0x9E3779B9u);
 }
 __device__ __forceinline__ float drop_one(uint32_t e, const DropCfg& dc) {
   const uint32_t w = mask_word32(e >> 2, drop_key(dc)) >> (8 * (e & 3));

@@ -249,13 +249,14 @@ static int linear_check(const char* who, const void* x, int ldx, int M, int K, i
 }
 
 extern "C" int vqa_linear_act_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int M, int K,
-                                  int N, int act, float p_drop, uint64_t seed, vqa_stream_t stream) {
+                                  int N, int act, float p_drop, uint64_t seed, const uint64_t* seed_ptr,
+                                  vqa_stream_t stream) {
   VQA_REQUIRE(x && w && y, VQA_E_BADARG, "linear_act_fwd: null pointer");
   int rc = linear_check("linear_act_fwd", x, ldx, M, K, N, act, p_drop);
   if (rc != VQA_OK) return rc;
   VQA_REQUIRE(aligned(w, 8) && aligned(y, 8), VQA_E_UNSUPPORTED, "linear_act_fwd: w/y must be 8-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const DropCfg dc = make_drop(p_drop, seed);
+  const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
   const TileChoice t = tile_override_or(choose_tile(M, N, 1));
   const int tiles_m = (M + t.bm - 1) / t.bm, tiles_n = (N + t.bn - 1) / t.bn;
 #define LAUNCH(BM_, BN_, PF_)                                                                                           \
@@ -284,7 +285,7 @@ extern "C" size_t vqa_linear_act_bwd_workspace_bytes(int M, int K, int N) {
 
 extern "C" int vqa_linear_act_bwd(const float* x, int ldx, const float* w, const float* y, const float* gy, float* d_x,
                                   float* d_w, float* d_b, void* workspace, size_t workspace_bytes, int M, int K, int N,
-                                  int act, float p_drop, uint64_t seed, vqa_stream_t stream) {
+                                  int act, float p_drop, uint64_t seed, const uint64_t* seed_ptr, vqa_stream_t stream) {
   VQA_REQUIRE(x && w && y && gy && d_w && workspace, VQA_E_BADARG, "linear_act_bwd: null pointer");
   int rc = linear_check("linear_act_bwd", x, ldx, M, K, N, act, p_drop);
   if (rc != VQA_OK) return rc;
@@ -294,7 +295,7 @@ extern "C" int vqa_linear_act_bwd(const float* x, int ldx, const float* w, const
                   (d_x == nullptr || aligned(d_x, 8)) && (d_b == nullptr || aligned(d_b, 8)),
               VQA_E_UNSUPPORTED, "linear_act_bwd: tensors must be 8-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const DropCfg dc = make_drop(p_drop, seed);
+  const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
   if (d_x != nullptr) {
     const TileChoice t = tile_override_or(choose_tile(M, K, 1));
     const int tiles_m = (M + t.bm - 1) / t.bm, tiles_n = (K + t.bn - 1) / t.bn;
@@ -352,11 +353,12 @@ __global__ __launch_bounds__(256) void linear_mask_kernel(float* __restrict__ ma
   if (e + 1 < n) mask[e + 1] = m.y;
 }
 
-extern "C" int vqa_linear_dropout_mask(float* mask, float p_drop, uint64_t seed, int M, int K, vqa_stream_t stream) {
+extern "C" int vqa_linear_dropout_mask(float* mask, float p_drop, uint64_t seed, const uint64_t* seed_ptr, int M, int K,
+                                       vqa_stream_t stream) {
   VQA_REQUIRE(mask && M > 0 && K > 0 && K % 2 == 0, VQA_E_BADARG, "linear_dropout_mask: bad arguments");
   VQA_REQUIRE(p_drop >= 0.f && p_drop < 1.f, VQA_E_BADARG, "linear_dropout_mask: p_drop=%f outside [0,1)", (double)p_drop);
   const size_t n = (size_t)M * K;
   hipLaunchKernelGGL(linear_mask_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     mask, n, make_drop(p_drop, seed));
+                     mask, n, make_drop(p_drop, seed, seed_ptr));
   return check_launch("linear_dropout_mask");
 }

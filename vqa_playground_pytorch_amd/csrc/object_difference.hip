@@ -39,6 +39,7 @@ __global__ void oda_fwd_kernel(const float* __restrict__ vl, const float* __rest
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int b = blockIdx.y, i0 = blockIdx.x * kIC;
   const int NQ = (N + 3) >> 2;
+  const uint64_t seed_eff = dc.effective();
   const float* vlb = vl + (size_t)b * N * L;
   float acc[kIC][G];
 #pragma unroll
@@ -60,7 +61,7 @@ __global__ void oda_fwd_kernel(const float* __restrict__ vl, const float* __rest
 #pragma unroll
       for (int q = 0; q < kIC / 4; ++q) {
         uint32_t word = 0;
-        if (DROP) word = mask_word(mask_counter(b, (i0 >> 2) + q, j, d, NQ, N, L), dc.seed);
+        if (DROP) word = mask_word(mask_counter(b, (i0 >> 2) + q, j, d, NQ, N, L), seed_eff);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int ic = q * 4 + k;
@@ -104,6 +105,7 @@ __global__ void oda_bwd_data_kernel(const float* __restrict__ vl, const float* _
   const int tid = threadIdx.x, nt = blockDim.x;
   const int b = blockIdx.x;
   const int NQ = (N + 3) >> 2;
+  const uint64_t seed_eff = dc.effective();
   const float* vlb = vl + (size_t)b * N * L;
   for (int t = tid; t < N * G; t += nt) dS_s[t] = dS[(size_t)b * N * G + t];
   __syncthreads();
@@ -126,7 +128,7 @@ __global__ void oda_bwd_data_kernel(const float* __restrict__ vl, const float* _
 #pragma unroll
         for (int q = 0; q < kIC / 4; ++q) {
           uint32_t word = 0;
-          if (DROP) word = mask_word(mask_counter(b, (i0 >> 2) + q, j, d, NQ, N, L), dc.seed);
+          if (DROP) word = mask_word(mask_counter(b, (i0 >> 2) + q, j, d, NQ, N, L), seed_eff);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int ic = q * 4 + k;
@@ -167,6 +169,7 @@ __global__ void oda_bwd_weight_kernel(const float* __restrict__ vl, const float*
   const int tid = threadIdx.x, nt = blockDim.x;
   const int j0 = blockIdx.x * kIC, sg = blockIdx.y;
   const int NQ = (N + 3) >> 2;
+  const uint64_t seed_eff = dc.effective();
   const int b_lo = sg * samples_per_group, b_hi = min(B, b_lo + samples_per_group);
   const int d = tid;  // the launcher guarantees blockDim >= L, so one feature per lane
   const bool active = d < L;
@@ -197,7 +200,7 @@ __global__ void oda_bwd_weight_kernel(const float* __restrict__ vl, const float*
 #pragma unroll
       for (int jc = 0; jc < kIC; ++jc) {
         uint32_t word = 0;
-        if (DROP) word = mask_word(mask_counter(b, iq, j0 + jc, d, NQ, N, L), dc.seed);
+        if (DROP) word = mask_word(mask_counter(b, iq, j0 + jc, d, NQ, N, L), seed_eff);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float val = Ti[k] - Tj[jc];
@@ -248,8 +251,9 @@ __global__ __launch_bounds__(256) void oda_mask_kernel(float* __restrict__ mask,
   if (e >= N * L) return;
   const int j = e / L, d = e % L;
   const int NQ = (N + 3) >> 2;
+  const uint64_t seed_eff = dc.effective();
   float m = 1.f;
-  if (dc.p8 > 0) m = keep_scale(mask_word(mask_counter(b, i >> 2, j, d, NQ, N, L), dc.seed), i & 3, dc.p8, dc.scale);
+  if (dc.p8 > 0) m = keep_scale(mask_word(mask_counter(b, i >> 2, j, d, NQ, N, L), seed_eff), i & 3, dc.p8, dc.scale);
   mask[((size_t)b * N + i) * N * L + e] = m;
 }
 
@@ -329,12 +333,12 @@ static int oda_check(const char* who, int B, int N, int L, int G, float p) {
   }
 
 extern "C" int vqa_object_difference_attention_fwd(const float* vl, const float* ql, const float* w, const float* bias,
-                                                   float* logits, float p_drop, uint64_t seed, int B, int N, int L,
-                                                   int G, vqa_stream_t stream) {
+                                                   float* logits, float p_drop, uint64_t seed, const uint64_t* seed_ptr, int B,
+                                                   int N, int L, int G, vqa_stream_t stream) {
   VQA_REQUIRE(vl && ql && w && bias && logits, VQA_E_BADARG, "object_difference_attention_fwd: null pointer");
   int rc = oda_check("object_difference_attention_fwd", B, N, L, G, p_drop);
   if (rc != VQA_OK) return rc;
-  const DropCfg dc = make_drop(p_drop, seed);
+  const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define CALL(G_) launch_fwd<G_>(vl, ql, w, bias, logits, dc, B, N, L, s)
   VQA_G_SWITCH(G, CALL)
@@ -349,14 +353,15 @@ extern "C" size_t vqa_object_difference_attention_bwd_workspace_bytes(int B, int
 extern "C" int vqa_object_difference_attention_bwd(const float* vl, const float* ql, const float* w,
                                                    const float* d_logits, float* d_vl, float* d_ql, float* d_w,
                                                    float* d_bias, void* workspace, size_t workspace_bytes, float p_drop,
-                                                   uint64_t seed, int B, int N, int L, int G, vqa_stream_t stream) {
+                                                   uint64_t seed, const uint64_t* seed_ptr, int B, int N, int L, int G,
+                                                   vqa_stream_t stream) {
   VQA_REQUIRE(vl && ql && w && d_logits && d_vl && d_ql && d_w && d_bias && workspace, VQA_E_BADARG,
               "object_difference_attention_bwd: null pointer");
   int rc = oda_check("object_difference_attention_bwd", B, N, L, G, p_drop);
   if (rc != VQA_OK) return rc;
   VQA_REQUIRE(workspace_bytes >= vqa_object_difference_attention_bwd_workspace_bytes(B, N, L, G), VQA_E_BADARG,
               "object_difference_attention_bwd: workspace of %zu B is too small", workspace_bytes);
-  const DropCfg dc = make_drop(p_drop, seed);
+  const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* slab = static_cast<float*>(workspace);
 #define CALL(G_) launch_bwd<G_>(vl, ql, w, d_logits, d_vl, d_ql, d_w, d_bias, slab, dc, B, N, L, s)
@@ -364,12 +369,13 @@ extern "C" int vqa_object_difference_attention_bwd(const float* vl, const float*
 #undef CALL
 }
 
-extern "C" int vqa_object_difference_dropout_mask(float* mask, float p_drop, uint64_t seed, int B, int N, int L,
+extern "C" int vqa_object_difference_dropout_mask(float* mask, float p_drop, uint64_t seed, const uint64_t* seed_ptr,
+                                                  int B, int N, int L,
                                                   vqa_stream_t stream) {
   VQA_REQUIRE(mask, VQA_E_BADARG, "object_difference_dropout_mask: null pointer");
   int rc = oda_check("object_difference_dropout_mask", B, N, L, 1, p_drop);
   if (rc != VQA_OK) return rc;
-  const DropCfg dc = make_drop(p_drop, seed);
+  const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
   hipLaunchKernelGGL(oda_mask_kernel, dim3((N * L + 255) / 256, N, B), dim3(256), 0, static_cast<hipStream_t>(stream), mask,
                      dc, N, L);
   return check_launch("object_difference_dropout_mask");

@@ -130,7 +130,7 @@ class MyConv1d(nn.Module):
             # on the fp32 MFMA tile engine (K5); the dropout mask is a counter hash keyed by a seed drawn from
             # torch's CPU generator, so torch.manual_seed governs it and no mask tensor exists
             p = self.p if (self.training and self.p) else 0.0
-            seed = ops.draw_host_seed() if p else 0
+            seed = ops.next_dropout_seed() if p else 0
             return ops.linear_act(x, self.conv.weight.squeeze(-1), self.conv.bias, self.af, p, seed)
         return _activation(self.pre_activation(x), self.af, self.dim)
 

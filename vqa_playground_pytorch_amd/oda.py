@@ -38,7 +38,7 @@ class Model(nn.Module):
         seed = 0
         if p:
             # fresh mask every call, drawn from torch's generator so torch.manual_seed governs it
-            seed = ops.draw_host_seed()
+            seed = ops.next_dropout_seed()
         w = conv.conv.weight.view(conv.out_channels, -1)
         return ops.object_difference_attention(v_feature_low, q_feature_low, w, conv.conv.bias, p, seed)
 

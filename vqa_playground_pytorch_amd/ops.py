@@ -71,6 +71,18 @@ def _prep(name, t):
     return t.contiguous()
 
 
+def _seed_args(seed):
+    """seed: an int (host seed), or (device int64 tensor [1], int salt) -> (c_uint64 value, device pointer or None).
+    With a device tensor the kernels read the step's seed at run time (*tensor + salt), which is what lets a captured
+    hipGraph draw a fresh mask on every replay."""
+    if isinstance(seed, tuple):
+        tensor, salt = seed
+        if not (isinstance(tensor, torch.Tensor) and tensor.is_cuda and tensor.dtype == torch.int64 and tensor.numel() >= 1):
+            raise ValueError("device seed must be a CUDA int64 tensor")
+        return int(salt) & 0x7FFFFFFFFFFFFFFF, ctypes.c_void_p(tensor.data_ptr())
+    return int(seed) & 0xFFFFFFFFFFFFFFFF, None
+
+
 def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
@@ -215,11 +227,12 @@ class ObjectDifferenceAttention(torch.autograd.Function):
             raise ValueError("object_difference_attention: ql must be [B,L], w must hold G*N*L = %d values (got %d)"
                              % (G * N * L, w.numel()))
         logits = torch.empty(B, N, G, device=vl.device, dtype=torch.float32)
+        sv, sp = _seed_args(seed)
         _launch("object_difference_attention_fwd", (B, N, L, G, float(p_drop) > 0),
                 _lib.lib().vqa_object_difference_attention_fwd, _p(vl), _p(ql), _p(w), _p(bias), _p(logits),
-                float(p_drop), int(seed), B, N, L, G)
+                float(p_drop), sv, sp, B, N, L, G)
         ctx.save_for_backward(vl, ql, w)
-        ctx.cfg = (float(p_drop), int(seed), G)
+        ctx.cfg = (float(p_drop), seed, G)
         return logits
 
     @staticmethod
@@ -233,9 +246,10 @@ class ObjectDifferenceAttention(torch.autograd.Function):
         L_ = _lib.lib()
         ws_bytes = L_.vqa_object_difference_attention_bwd_workspace_bytes(B, N, L, G)
         ws = torch.empty((ws_bytes + 3) // 4, device=vl.device, dtype=torch.float32)
+        sv, sp = _seed_args(seed)
         _launch("object_difference_attention_bwd", (B, N, L, G, p_drop > 0), L_.vqa_object_difference_attention_bwd,
                 _p(vl), _p(ql), _p(w), _p(d_logits), _p(d_vl), _p(d_ql), _p(d_w), _p(d_bias), _p(ws), ws_bytes,
-                p_drop, seed, B, N, L, G)
+                p_drop, sv, sp, B, N, L, G)
         return d_vl, d_ql, d_w, d_bias, None, None
 
 
@@ -253,10 +267,11 @@ class LinearAct(torch.autograd.Function):
         if w.shape != (N, K) or (bias is not None and bias.shape != (N,)):
             raise ValueError("linear_act: weight must be [N,K] = [%d,%d], bias [N]" % (N, K))
         y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+        sv, sp = _seed_args(seed)
         _launch("linear_act_fwd", (M, K, N, float(p_drop) > 0), _lib.lib().vqa_linear_act_fwd,
-                _p(x), K, _p(w), _p(bias), _p(y), M, K, N, int(act), float(p_drop), int(seed))
+                _p(x), K, _p(w), _p(bias), _p(y), M, K, N, int(act), float(p_drop), sv, sp)
         ctx.save_for_backward(x, w, y)
-        ctx.cfg = (M, K, N, int(act), float(p_drop), int(seed), bias is not None)
+        ctx.cfg = (M, K, N, int(act), float(p_drop), seed, bias is not None)
         return y
 
     @staticmethod
@@ -270,8 +285,9 @@ class LinearAct(torch.autograd.Function):
         L_ = _lib.lib()
         ws_bytes = L_.vqa_linear_act_bwd_workspace_bytes(M, K, N)
         ws = torch.empty((ws_bytes + 3) // 4, device=x.device, dtype=torch.float32)
+        sv, sp = _seed_args(seed)
         _launch("linear_act_bwd", (M, K, N, p_drop > 0, d_x is not None), L_.vqa_linear_act_bwd,
-                _p(x), K, _p(w), _p(y), _p(gy), _p(d_x), _p(d_w), _p(d_b), _p(ws), ws_bytes, M, K, N, act, p_drop, seed)
+                _p(x), K, _p(w), _p(y), _p(gy), _p(d_x), _p(d_w), _p(d_b), _p(ws), ws_bytes, M, K, N, act, p_drop, sv, sp)
         return d_x, d_w, d_b, None, None, None
 
 
@@ -305,6 +321,8 @@ def adam_step_dyn(p_flat, g_flat, m_flat, v_flat, norm_and_coef, step_scalars, b
 
 
 host_seed_draws = 0  # bumped whenever a kernel's dropout seed is drawn on the host (such a step cannot be graph-replayed)
+_device_seed = None   # (int64 CUDA tensor [1], next salt) installed by the trainer for graph-replayed steps
+_SALT_STRIDE = 0x9E3779B97F4A7C15 & 0x3FFFFFFFFFFFFFFF
 
 
 def draw_host_seed():
@@ -314,18 +332,41 @@ def draw_host_seed():
     return int(torch.randint(0, 2 ** 62, (1,), device="cpu").item())
 
 
+def set_device_seed(tensor):
+    """Install (or with None remove) the device word the fused dropout kernels read their per-step seed from."""
+    global _device_seed
+    _device_seed = [tensor, 0] if tensor is not None else None
+
+
+def next_dropout_seed():
+    """Seed for one fused-dropout call: (device tensor, salt) when the trainer installed a device seed word -- every
+    call site of a step gets its own salt, the word itself moves once per step -- else a fresh host seed."""
+    if _device_seed is None:
+        return draw_host_seed()
+    _device_seed[1] += 1
+    return (_device_seed[0], (_device_seed[1] * _SALT_STRIDE) & 0x3FFFFFFFFFFFFFFF)
+
+
+def begin_step_salts():
+    """Restart the per-call salt sequence (call at the start of every forward so eager and replayed steps agree)."""
+    if _device_seed is not None:
+        _device_seed[1] = 0
+
+
 def linear_dropout_mask(M, K, p_drop, seed, device):
     """The keep/(1-p) mask [M,K] exactly as K5 draws it (tests hand it to the oracle)."""
     mask = torch.empty(M, K, device=device, dtype=torch.float32)
-    _launch("linear_dropout_mask", (M, K), _lib.lib().vqa_linear_dropout_mask, _p(mask), float(p_drop), int(seed), M, K)
+    sv, sp = _seed_args(seed)
+    _launch("linear_dropout_mask", (M, K), _lib.lib().vqa_linear_dropout_mask, _p(mask), float(p_drop), sv, sp, M, K)
     return mask
 
 
 def object_difference_dropout_mask(B, N, L, p_drop, seed, device):
     """The keep/(1-p) mask [B,N,N*L] exactly as K2 draws it (tests hand it to the oracle)."""
     mask = torch.empty(B, N, N * L, device=device, dtype=torch.float32)
+    sv, sp = _seed_args(seed)
     _launch("object_difference_dropout_mask", (B, N, L), _lib.lib().vqa_object_difference_dropout_mask,
-            _p(mask), float(p_drop), int(seed), B, N, L)
+            _p(mask), float(p_drop), sv, sp, B, N, L)
     return mask
 
 

@@ -129,7 +129,13 @@ class DataParallelTrainer:
         if self.hip:
             self.flat = FlatState(model.parameters())
             self.step_scalars = torch.zeros(2, device=first.device, dtype=torch.float32)
-            self._step_scalars_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+            # pinned staging for the tiny per-step H2D copies: a ring, so a slot is not rewritten while an earlier
+            # (asynchronous) copy from it may still be pending on the stream
+            self._ring = 8
+            self._step_scalars_host = torch.zeros(self._ring, 2, dtype=torch.float32).pin_memory()
+            # per-step dropout seed of the fused kernels (K2, K5) in device memory: replays read the current value
+            self.seed_word = torch.zeros(1, device=first.device, dtype=torch.int64)
+            self._seed_host = torch.zeros(self._ring, 1, dtype=torch.int64).pin_memory()
             self.grads = None
             self.optimizer = None
         else:
@@ -180,8 +186,14 @@ class DataParallelTrainer:
     # ---- hipGraph replay of the step ---------------------------------------------------------------------------
     def _front(self, sample, target):
         """forward + loss + backward + gradient gather (graph 1)."""
+        from . import ops
         f = self.flat
-        loss = kld_sum_loss(self.model(sample), target)
+        ops.set_device_seed(self.seed_word)
+        ops.begin_step_salts()
+        try:
+            loss = kld_sum_loss(self.model(sample), target)
+        finally:
+            ops.set_device_seed(None)
         f.drop_grads()
         loss.backward()
         f.gather_grads()
@@ -197,9 +209,12 @@ class DataParallelTrainer:
     def _set_step_scalars(self):
         self.iteration += 1
         self._lr = lr = self.base_lr * self.gamma ** self.iteration
-        self._step_scalars_host[0] = lr / (1.0 - self.betas[0] ** self.iteration)
-        self._step_scalars_host[1] = 1.0 / (1.0 - self.betas[1] ** self.iteration) ** 0.5
-        self.step_scalars.copy_(self._step_scalars_host, non_blocking=True)
+        slot = self.iteration % self._ring
+        self._step_scalars_host[slot, 0] = lr / (1.0 - self.betas[0] ** self.iteration)
+        self._step_scalars_host[slot, 1] = 1.0 / (1.0 - self.betas[1] ** self.iteration) ** 0.5
+        self.step_scalars.copy_(self._step_scalars_host[slot], non_blocking=True)
+        self._seed_host[slot, 0] = int(torch.randint(0, 2 ** 62, (1,), device="cpu").item())   # torch.manual_seed governs it
+        self.seed_word.copy_(self._seed_host[slot], non_blocking=True)
 
     def _graph_step(self, sample, target):
         from . import ops
