@@ -154,6 +154,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("VQA_ONE_GPU_REHEARSAL") == "1":
+        local = 0                                               # all ranks share GPU 0 (gloo rehearsal only)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -163,7 +165,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("VQA_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; "gloo" only to rehearse the
+        if backend == "nccl":                                   # multi-rank flow on a single-GPU box
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from vqa_playground_pytorch_amd import CoR2Model, ODAModel, ops
     from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
