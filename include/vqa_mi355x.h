@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VQA_ABI_VERSION 2
+#define VQA_ABI_VERSION 3
 
 #define VQA_OK 0
 #define VQA_E_BADARG (-1)      /* null pointer, non-positive size, size over a documented limit */
@@ -40,6 +40,7 @@ extern "C" {
 #define VQA_E_LAUNCH (-3)      /* HIP reported an error at launch */
 
 typedef void* vqa_stream_t; /* hipStream_t */
+typedef uint16_t vqa_bf16_t; /* storage of one bfloat16 (upper half of an IEEE fp32) */
 
 int vqa_version(void);
 const char* vqa_last_error(void);
@@ -56,7 +57,7 @@ const char* vqa_last_error(void);
  * mode 0 = pairwise: the N*N inner sum is evaluated term by term from the LDS-staged region tile
  *          (the reference's summation structure);
  * mode 1 = factored: q1*(sum_i alpha_i v_i) + (sum_i alpha_i)*q2*v_j -- the same value, one pass.
- * Limits: D % 4 == 0, 16-byte aligned v/q1/q2/v2, N <= 144.
+ * Limits: D % 4 == 0, 16-byte aligned v/q1/q2/v2; N <= 144 in mode 0, N <= 4096 in mode 1.
  * ------------------------------------------------------------------------------------------- */
 int vqa_pairwise_relation_reduce_fwd(const float* v, const float* q1, const float* q2,
                                      const float* alpha, int alpha_stride, float* v2,
@@ -69,6 +70,17 @@ int vqa_pairwise_relation_reduce_bwd(const float* v, const float* q1, const floa
                                      const float* alpha, int alpha_stride, const float* g_v2,
                                      float* d_alpha, float* d_q1, float* d_q2, float* d_v,
                                      int B, int N, int D, vqa_stream_t stream);
+
+/* K1 with the region tensors (v, v2, g_v2, d_v) stored as bf16 -- the mixed-precision path of BASELINE
+ * configs[4] (bf16 storage, fp32 arithmetic and accumulation; q1, q2, alpha and their gradients stay
+ * fp32).  Same semantics and limits, with 8-byte instead of 16-byte alignment of the bf16 tensors. */
+int vqa_pairwise_relation_reduce_fwd_bf16(const vqa_bf16_t* v, const float* q1, const float* q2,
+                                          const float* alpha, int alpha_stride, vqa_bf16_t* v2,
+                                          int B, int N, int D, int mode, vqa_stream_t stream);
+int vqa_pairwise_relation_reduce_bwd_bf16(const vqa_bf16_t* v, const float* q1, const float* q2,
+                                          const float* alpha, int alpha_stride, const vqa_bf16_t* g_v2,
+                                          float* d_alpha, float* d_q1, float* d_q2, vqa_bf16_t* d_v,
+                                          int B, int N, int D, vqa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3  softmax over regions + attention-weighted region pooling.
@@ -88,6 +100,13 @@ int vqa_softmax_attention_pool_fwd(const float* logits, const float* v, float* a
 int vqa_softmax_attention_pool_bwd(const float* alpha, const float* v, const float* d_pooled,
                                    const float* d_alpha_ext, float* d_logits, float* d_v,
                                    int B, int N, int D, int G, vqa_stream_t stream);
+
+/* K3 with v / d_v stored as bf16 (logits, alpha, pooled and their gradients stay fp32). */
+int vqa_softmax_attention_pool_fwd_bf16(const float* logits, const vqa_bf16_t* v, float* alpha,
+                                        float* pooled, int B, int N, int D, int G, vqa_stream_t stream);
+int vqa_softmax_attention_pool_bwd_bf16(const float* alpha, const vqa_bf16_t* v, const float* d_pooled,
+                                        const float* d_alpha_ext, float* d_logits, vqa_bf16_t* d_v,
+                                        int B, int N, int D, int G, vqa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4  low-rank bilinear (Mutan) fusion on the fp32 MFMA tile engine.
@@ -116,6 +135,53 @@ int vqa_lowrank_bilinear_fusion_bwd(const float* x, int ldx, const float* const*
                                     float* const* d_b1, float* d_h2, void* workspace,
                                     size_t workspace_bytes, int B, int N, int L, int H, int R,
                                     vqa_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Mixed-precision (bf16) side -- BASELINE configs[4] "CoR2 bf16, 100x2048 dense regions": bf16 storage and
+ * bf16 MFMA operands (v_mfma_f32_32x32x16_bf16), fp32 accumulation, fp32 master weights.
+ * Operand contract: feature dims are zero-padded to a multiple of 64 by the caller (H of K4 to a multiple
+ * of 256), so the kernels carry no tail handling; row counts (M = B*N) are free.
+ * ------------------------------------------------------------------------------------------- */
+
+/* fp32 [batch, rows, cols] dense -> bf16 scattered to dst[b*dst_batch_stride + r*dst_row_stride +
+ * c*dst_col_stride]; with zero_fill != 0 the destination (dst_elems elements) is zeroed first, which writes
+ * the pads (pass 0 when several calls interleave into one destination that was zeroed by the first).  Used
+ * for the padded / transposed bf16 shadow copies of the fp32 master weights (nn.Linear weights of
+ * putils/__init__.py:16-33) and to narrow activations. */
+int vqa_pack_bf16(const float* src, int batch, int rows, int cols, vqa_bf16_t* dst,
+                  long dst_batch_stride, long dst_row_stride, long dst_col_stride, size_t dst_elems,
+                  int zero_fill, vqa_stream_t stream);
+
+/* c[M,N] (bf16, row stride ldc) = act(a[M,K] * b[N,K]^T + bias[N]); bias fp32 or NULL; act 0 none, 1 relu.
+ * The nn.Linear / 1x1 nn.Conv1d contraction of MyLinear / MyConv1d (config/CoR2.py:56-122) in bf16.
+ * Limits: K % 64 == 0; lda, ldb % 8 == 0; 16-byte aligned a, b. */
+int vqa_gemm_bf16_nt(const vqa_bf16_t* a, int lda, const vqa_bf16_t* b, int ldb, const float* bias,
+                     vqa_bf16_t* c, int ldc, int M, int N, int K, int act, vqa_stream_t stream);
+
+/* c[N1,N2] (fp32, dense) = a[K,N1]^T * b[K,N2] -- the weight-gradient contraction over the batch rows, split
+ * over K into fp32 slabs that are reduced in a fixed order (bitwise reproducible).
+ * Limits: N1, N2, lda, ldb % 8 == 0; 16-byte aligned pointers. */
+size_t vqa_gemm_bf16_tn_workspace_bytes(int K, int N1, int N2);
+int vqa_gemm_bf16_tn(const vqa_bf16_t* a, int lda, const vqa_bf16_t* b, int ldb, float* c, void* workspace,
+                     size_t workspace_bytes, int K, int N1, int N2, vqa_stream_t stream);
+
+/* K4 in bf16 (putils/__init__.py:232-238).  x [M,L] bf16 dense; w1 [R,H,L] bf16 (the R region-side weights,
+ * padded and stacked); b1 [R,H] fp32; h2 [B,R,H] fp32; out [M,H] bf16; h1 [M,R,H] bf16 or NULL.
+ * Limits: L % 64 == 0, H % 256 == 0, R <= 8. */
+int vqa_lowrank_bilinear_fusion_fwd_bf16(const vqa_bf16_t* x, const vqa_bf16_t* w1, const float* b1,
+                                         const float* h2, vqa_bf16_t* out, vqa_bf16_t* h1,
+                                         int B, int N, int L, int H, int R, vqa_stream_t stream);
+
+size_t vqa_lowrank_bilinear_fusion_bwd_bf16_workspace_bytes(int B, int N, int L, int H, int R);
+
+/* Backward of the bf16 K4.  w1t [L, R*H] bf16 = the weights transposed with the rank axis concatenated
+ * (w1t[l, r*H+h] = w1[r,h,l]; only read when d_x != NULL); g = dL/dout [M,H] bf16.  Outputs: d_x [M,L] bf16
+ * or NULL; d_w1 [R,H,L] fp32; d_b1 [R,H] fp32; d_h2 [B,R,H] fp32 (all overwritten). */
+int vqa_lowrank_bilinear_fusion_bwd_bf16(const vqa_bf16_t* x, const vqa_bf16_t* w1t, const float* h2,
+                                         const vqa_bf16_t* h1, const vqa_bf16_t* g, vqa_bf16_t* d_x,
+                                         float* d_w1, float* d_b1, float* d_h2, void* workspace,
+                                         size_t workspace_bytes, int B, int N, int L, int H, int R,
+                                         vqa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K2  object-difference attention logits (ODA).

@@ -1,0 +1,201 @@
+"""GPU parity tests of the mixed-precision (bf16 storage / bf16 MFMA / fp32 accumulate) side -- BASELINE configs[4]
+"CoR2 bf16, 100x2048 dense regions" -- against the float64 numpy oracle (oracle/kernels_np.py).
+
+Every bf16 kernel is fed inputs that are exactly representable in bf16, so the oracle sees the same numbers and the
+only differences are (i) fp32 accumulation order and (ii) the rounding of bf16 OUTPUTS / saved bf16 intermediates.
+Tolerances are therefore stated in units of the bf16 epsilon 2^-8:
+  - fp32 outputs computed from bf16 inputs            : RTOL_F32 = 2e-4 of the output scale
+  - bf16 outputs (one rounding)                       : elementwise |err| <= 2^-8 |ref| + RTOL_F32 * scale
+  - results that pass through a bf16 intermediate     : RTOL_MID = 2e-2 of the output scale (h1 / g*h2 are rounded to
+    (K4 backward)                                       bf16 before the second contraction)
+Run on the GPU box with:  python -m pytest tests -m gpu
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kernels_np as K
+from oracle import seeded
+
+pytestmark = pytest.mark.gpu
+
+EPS_BF16 = 2.0 ** -8
+RTOL_F32 = 2e-4
+RTOL_MID = 2e-2
+
+
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def bf_round(a):
+    """numpy fp32 -> nearest bf16 value (as fp32)."""
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def gbf(a, requires_grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev()).to(torch.bfloat16)
+    return t.requires_grad_() if requires_grad else t
+
+
+def g32(a, requires_grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev())
+    return t.requires_grad_() if requires_grad else t
+
+
+def npy(t):
+    return t.detach().float().cpu().numpy().astype(np.float64)
+
+
+def close_f32(name, got, want, rtol=RTOL_F32):
+    got, want = npy(got) if isinstance(got, torch.Tensor) else np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    assert np.isfinite(got).all(), name + ": non-finite output"
+    scale = max(np.abs(want).max(), 1e-20)
+    err = np.abs(got - want).max() / scale
+    assert err <= rtol, "%s: rel err %.3e > %.1e" % (name, err, rtol)
+
+
+def close_bf16(name, got, want, extra=RTOL_F32):
+    """bf16 output: one rounding of the exact value (plus fp32 accumulation noise)."""
+    assert got.dtype == torch.bfloat16, (name, got.dtype)
+    got, want = npy(got), np.asarray(want, np.float64)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    assert np.isfinite(got).all(), name + ": non-finite output"
+    scale = max(np.abs(want).max(), 1e-20)
+    bad = np.abs(got - want) > EPS_BF16 * np.abs(want) + extra * scale
+    assert not bad.any(), "%s: %d of %d elements outside one bf16 rounding (worst %.3e of scale)" % (
+        name, int(bad.sum()), bad.size, (np.abs(got - want).max() / scale))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from vqa_playground_pytorch_amd import ops as o
+    return o
+
+
+# ----------------------------------------------------------------------------------------------- K1 / K3 in bf16
+@pytest.mark.parametrize("B,N,D,G,glimpse", [(3, 5, 12, 1, 0), (2, 36, 2048, 4, 0), (2, 100, 2048, 4, 0), (2, 37, 1024, 2, 1)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_pairwise_relation_bf16(ops, B, N, D, G, glimpse, mode):
+    v = bf_round(seeded.seeded_array((B, N, D), 201))
+    q1 = 1 / (1 + np.exp(-seeded.seeded_array((B, D), 202)))
+    q2 = 1 / (1 + np.exp(-seeded.seeded_array((B, D), 203)))
+    al = np.abs(seeded.seeded_array((B, N, G), 204)) + 0.05
+    gout = bf_round(seeded.seeded_array((B, N, D), 205))
+    q1, q2, al = (np.asarray(a, np.float32) for a in (q1, q2, al))
+    vt, q1t, q2t, alt = gbf(v, True), g32(q1, True), g32(q2, True), g32(al, True)
+    out = ops.pairwise_relation_reduce(vt, q1t, q2t, alt, glimpse=glimpse, mode=mode)
+    close_bf16("v2", out, K.pairwise_relation_reduce_fwd(v, q1, q2, al[:, :, glimpse]))
+    out.backward(gbf(gout))
+    da, dq1, dq2, dv = K.pairwise_relation_reduce_bwd(v, q1, q2, al[:, :, glimpse], gout)
+    da_full = np.zeros_like(al, dtype=np.float64)
+    da_full[:, :, glimpse] = da
+    close_f32("d_alpha", alt.grad, da_full)
+    close_f32("d_q1", q1t.grad, dq1)
+    close_f32("d_q2", q2t.grad, dq2)
+    close_bf16("d_v", vt.grad, dv)
+
+
+@pytest.mark.parametrize("B,N,D,G", [(2, 36, 2048, 4), (2, 100, 2048, 4), (3, 7, 260, 3), (1, 1, 8, 1)])
+def test_softmax_attention_pool_bf16(ops, B, N, D, G):
+    logits = seeded.seeded_array((B, N, G), 211).astype(np.float32)
+    v = bf_round(seeded.seeded_array((B, N, D), 212))
+    dpool = seeded.seeded_array((B, G, D), 213).astype(np.float32)
+    dal = seeded.seeded_array((B, N, G), 214).astype(np.float32)
+    lt, vt = g32(logits, True), gbf(v, True)
+    alpha, pooled = ops.softmax_attention_pool(lt, vt)
+    a_ref, p_ref = K.softmax_attention_pool_fwd(logits, v)
+    close_f32("alpha", alpha, a_ref)
+    close_f32("pooled", pooled, p_ref)
+    (alpha * g32(dal)).sum().add((pooled * g32(dpool)).sum()).backward()
+    dl_ref, dv_ref = K.softmax_attention_pool_bwd(a_ref, v, dpool, dal)
+    close_f32("d_logits", lt.grad, dl_ref)
+    close_bf16("d_v", vt.grad, dv_ref)
+
+
+# ----------------------------------------------------------------------------------------------- bf16 GEMM engine
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (300, 320, 320), (128, 512, 1024), (1000, 64, 128), (257, 192, 64),
+                                   (12800, 512, 320)])
+@pytest.mark.parametrize("act", [None, "relu"])
+def test_gemm_bf16_nt(ops, M, N, K, act):
+    a = bf_round(seeded.seeded_array((M, K), 221))
+    b = bf_round(seeded.seeded_array((N, K), 222) / np.sqrt(K))   # deliberately asymmetric operands
+    bias = seeded.seeded_array((N,), 223).astype(np.float32)
+    c = ops.gemm_bf16_nt(gbf(a), gbf(b), g32(bias), act)
+    ref = a.astype(np.float64) @ b.astype(np.float64).T + bias
+    if act == "relu":
+        ref = np.maximum(ref, 0)
+    close_bf16("c", c, ref)
+
+
+@pytest.mark.parametrize("Kd,N1,N2", [(64, 64, 64), (1000, 1024, 320), (50, 128, 64), (3600, 320, 2048), (12800, 1024, 320),
+                                      (777, 8, 72)])
+def test_gemm_bf16_tn(ops, Kd, N1, N2):
+    a = bf_round(seeded.seeded_array((Kd, N1), 231))
+    b = bf_round(seeded.seeded_array((Kd, N2), 232))
+    c = ops.gemm_bf16_tn(gbf(a), gbf(b))
+    ref = a.astype(np.float64).T @ b.astype(np.float64)
+    close_f32("c", c, ref)
+    c2 = ops.gemm_bf16_tn(gbf(a), gbf(b))
+    assert torch.equal(c, c2), "split-K reduction must be bitwise reproducible"
+
+
+def test_pack_bf16(ops):
+    w = seeded.seeded_array((3, 10, 7), 241).astype(np.float32)
+    dst = torch.full((3, 16, 64), 7.0, device=dev(), dtype=torch.bfloat16)
+    ops.pack_bf16(g32(w), dst, 16 * 64, 64, 1)
+    want = np.zeros((3, 16, 64), np.float32)
+    want[:, :10, :7] = bf_round(w)
+    assert np.array_equal(npy(dst), want.astype(np.float64))
+    # transposed with the batch axis concatenated: dst[c, b*16 + r] = w[b, r, c]
+    dst_t = torch.full((8, 48), 7.0, device=dev(), dtype=torch.bfloat16)
+    ops.pack_bf16(g32(w), dst_t, 16, 1, 48)
+    want_t = np.zeros((8, 48), np.float32)
+    for b in range(3):
+        want_t[:7, b * 16:b * 16 + 10] = bf_round(w[b]).T
+    assert np.array_equal(npy(dst_t), want_t.astype(np.float64))
+
+
+# ----------------------------------------------------------------------------------------------- K4 in bf16
+@pytest.mark.parametrize("B,N,L,H,R", [(2, 5, 20, 30, 2), (3, 36, 310, 510, 2), (2, 100, 310, 510, 2), (4, 1, 130, 510, 3),
+                                       (130, 1, 64, 256, 1)])
+def test_lowrank_bilinear_fusion_bf16(ops, B, N, L, H, R):
+    Lp = ops.pad_to(L)
+    x = bf_round(seeded.seeded_array((B, N, L), 251))
+    w1 = bf_round(seeded.seeded_array((R, H, L), 252) / np.sqrt(L))
+    b1 = (0.1 * seeded.seeded_array((R, H), 253)).astype(np.float32)
+    h2 = seeded.seeded_array((B, R, H), 254).astype(np.float32)
+    gout = bf_round(seeded.seeded_array((B, N, H), 255))
+    xp = np.zeros((B, N, Lp), np.float32)
+    xp[..., :L] = x
+    xt, h2t = gbf(xp, True), g32(h2, True)
+    ws = [g32(w1[r], True) for r in range(R)]
+    bs = [g32(b1[r], True) for r in range(R)]
+    out = ops.lowrank_bilinear_fusion(xt, h2t, ws, bs)
+    Hp = ops.pad_to(H, 256)
+    assert out.shape == (B, N, Hp) and out.dtype == torch.bfloat16
+    ref, _ = K.lowrank_bilinear_fusion_fwd(x, w1, b1, h2)
+    close_bf16("out", out[..., :H], ref)
+    assert Hp == H or float(out[..., H:].detach().float().abs().max()) == 0.0, "pad columns must be exactly zero"
+    gp = np.zeros((B, N, Hp), np.float32)
+    gp[..., :H] = gout
+    out.backward(gbf(gp))
+    dx, dw1, db1, dh2 = K.lowrank_bilinear_fusion_bwd(x, w1, b1, h2, gout)
+    close_f32("d_x", xt.grad[..., :L], dx, RTOL_MID)
+    assert Lp == L or float(xt.grad[..., L:].float().abs().max()) == 0.0
+    close_f32("d_h2", h2t.grad, dh2, RTOL_MID)
+    for r in range(R):
+        close_f32("d_w1[%d]" % r, ws[r].grad, dw1[r], RTOL_MID)
+        close_f32("d_b1[%d]" % r, bs[r].grad, db1[r], RTOL_MID)
+
+
+def test_lowrank_bilinear_fusion_bf16_rejects_unpadded(ops):
+    from vqa_playground_pytorch_amd._lib import VqaLibraryError
+    x = torch.zeros(2, 3, 310, device=dev(), dtype=torch.bfloat16)
+    h2 = torch.zeros(2, 1, 510, device=dev())
+    w = torch.zeros(510, 310, device=dev())
+    b = torch.zeros(510, device=dev())
+    with pytest.raises((ValueError, VqaLibraryError)):
+        ops.lowrank_bilinear_fusion(x, h2, [w], [b])

@@ -9,13 +9,14 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VQA_LIB_PATH", os.path.join(_HERE, "libvqa_mi355x.so"))  # env override: profiling builds
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c_f = ctypes.c_void_p          # device pointer to fp32
 _c_pp = ctypes.c_void_p         # host array of device pointers
 _c_i = ctypes.c_int
 _c_sz = ctypes.c_size_t
 _c_u64 = ctypes.c_uint64
+_c_l = ctypes.c_long
 _c_fl = ctypes.c_float
 _c_st = ctypes.c_void_p         # hipStream_t
 
@@ -44,6 +45,21 @@ SIGNATURES = {
     "vqa_linear_act_bwd": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz,
                                   _c_i, _c_i, _c_i, _c_i, _c_fl, _c_u64, _c_f, _c_st]),
     "vqa_linear_dropout_mask": (_c_i, [_c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_st]),
+    # bf16 (mixed-precision) side
+    "vqa_pairwise_relation_reduce_fwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_pairwise_relation_reduce_bwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f,
+                                                     _c_i, _c_i, _c_i, _c_st]),
+    "vqa_softmax_attention_pool_fwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_softmax_attention_pool_bwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_pack_bf16": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_f, _c_l, _c_l, _c_l, _c_sz, _c_i, _c_st]),
+    "vqa_gemm_bf16_nt": (_c_i, [_c_f, _c_i, _c_f, _c_i, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_gemm_bf16_tn_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i]),
+    "vqa_gemm_bf16_tn": (_c_i, [_c_f, _c_i, _c_f, _c_i, _c_f, _c_f, _c_sz, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_lowrank_bilinear_fusion_fwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
+                                                    _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_lowrank_bilinear_fusion_bwd_bf16_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i, _c_i, _c_i]),
+    "vqa_lowrank_bilinear_fusion_bwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz,
+                                                    _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_grad_norm_workspace_bytes": (_c_sz, []),
     "vqa_grad_norm_clip_coef": (_c_i, [_c_f, _c_sz, _c_fl, _c_f, _c_f, _c_sz, _c_st]),
     "vqa_adam_step": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_sz, _c_f, _c_fl, _c_fl, _c_fl, _c_fl, _c_i, _c_st]),

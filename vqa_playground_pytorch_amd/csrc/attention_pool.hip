@@ -14,6 +14,9 @@
 //
 // HBM-bound.  Algorithmic bytes per sample (fp32): forward (N*D + 2*N*G + G*D)*4 = 328 832 B at
 // N=36, D=2048, G=4;  backward (N*D + G*D + 3*N*G)*4 (+ N*D*4 when d_v is written).
+//
+// The stream kernels are templates on the storage type T of the region tensors v / d_v (float, or bf16 for the
+// mixed-precision path: half the bytes of the dominant stream); logits, alpha, pooled and their gradients are fp32.
 #include "common.hpp"
 
 namespace vqa {
@@ -50,9 +53,9 @@ __device__ __forceinline__ void block_softmax_regions(const float* __restrict__ 
   __syncthreads();
 }
 
-template <int NT, int G>
+template <typename T, int NT, int G>
 __global__ __launch_bounds__(NT) void attention_pool_fwd_kernel(const float* __restrict__ logits,
-                                                                const float* __restrict__ v, float* __restrict__ alpha,
+                                                                const T* __restrict__ v, float* __restrict__ alpha,
                                                                 float* __restrict__ pooled, int N, int D) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* alpha_s = reinterpret_cast<float*>(smem);  // [N][G]
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(NT) void attention_pool_fwd_kernel(const float* __r
   const int b = blockIdx.y;
   const int d = (blockIdx.x * NT + tid) * 4;
   const bool active = d < D;
-  const float* vb = v + (size_t)b * N * D + d;
+  const T* vb = v + (size_t)b * N * D + d;
 
   // start the first rows of the stream before the softmax prologue so HBM latency overlaps it
   constexpr int PF = 4;
@@ -98,11 +101,11 @@ __global__ __launch_bounds__(NT) void attention_pool_fwd_kernel(const float* __r
 // registers; it streams the N region rows once, writes d_v in the same sweep and reduces the G dot products
 // <d_pooled_g, v_n> per row with wave64 shuffles -> LDS -> one float atomic per (workgroup, n, g) into a zeroed
 // accumulator.  Kernel B closes the softmax backward on the tiny [B,N,G] tensors.
-template <int NT, int G>
+template <typename T, int NT, int G>
 __global__ __launch_bounds__(NT) void attention_pool_bwd_stream_kernel(const float* __restrict__ alpha,
-                                                                       const float* __restrict__ v,
+                                                                       const T* __restrict__ v,
                                                                        const float* __restrict__ d_pooled,
-                                                                       float* __restrict__ dal_acc, float* __restrict__ d_v,
+                                                                       float* __restrict__ dal_acc, T* __restrict__ d_v,
                                                                        int N, int D) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* alpha_s = reinterpret_cast<float*>(smem);  // [N][G]
@@ -124,8 +127,8 @@ __global__ __launch_bounds__(NT) void attention_pool_bwd_stream_kernel(const flo
     p[gI] = active ? t : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
-  const float* vb = v + (size_t)b * N * D + dc;
-  float* dvb = d_v ? d_v + (size_t)b * N * D + dc : nullptr;
+  const T* vb = v + (size_t)b * N * D + dc;
+  T* dvb = d_v ? d_v + (size_t)b * N * D + dc : nullptr;
   constexpr int RB = 4;  // rows per batch: RB independent 16-byte loads in flight per lane, then RB*G wave reductions
   for (int n0 = 0; n0 < N; n0 += RB) {
     float4 x[RB];
@@ -180,48 +183,43 @@ __global__ __launch_bounds__(256) void attention_softmax_bwd_kernel(const float*
   for (int t = tid; t < NG; t += 256) d_logits[(size_t)b * NG + t] = alpha_s[t] * (dal_s[t] - inner_s[t % G]);
 }
 
-template <int G>
-static int launch_fwd(const float* logits, const float* v, float* alpha, float* pooled, int B, int N, int D,
-                      hipStream_t s) {
+template <typename T, int G>
+static int launch_fwd(const float* logits, const T* v, float* alpha, float* pooled, int B, int N, int D, hipStream_t s) {
   constexpr int NT = 256;
   const size_t lds = ((size_t)N * G + 2 * kMaxG) * sizeof(float);
   dim3 grid((D / 4 + NT - 1) / NT, B);
-  hipLaunchKernelGGL((attention_pool_fwd_kernel<NT, G>), grid, dim3(NT), lds, s, logits, v, alpha, pooled, N, D);
+  hipLaunchKernelGGL((attention_pool_fwd_kernel<T, NT, G>), grid, dim3(NT), lds, s, logits, v, alpha, pooled, N, D);
   return check_launch("softmax_attention_pool_fwd");
 }
 
-template <int G>
-static int launch_bwd(const float* alpha, const float* v, const float* d_pooled, const float* d_alpha_ext,
-                      float* d_logits, float* d_v, int B, int N, int D, hipStream_t s) {
+template <typename T, int G>
+static int launch_bwd(const float* alpha, const T* v, const float* d_pooled, const float* d_alpha_ext, float* d_logits,
+                      T* d_v, int B, int N, int D, hipStream_t s) {
   constexpr int NT = 256;
   // d_logits doubles as the zeroed accumulator of the first kernel (same [B,N,G] shape; kernel B reads each of its
   // elements before overwriting it)
   hipError_t e = hipMemsetAsync(d_logits, 0, (size_t)B * N * G * sizeof(float), s);
   if (e != hipSuccess) return fail(VQA_E_LAUNCH, "softmax_attention_pool_bwd: memset: %s", hipGetErrorString(e));
   const size_t lds = 2 * (size_t)N * G * sizeof(float);
-  hipLaunchKernelGGL((attention_pool_bwd_stream_kernel<NT, G>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), lds, s, alpha, v,
+  hipLaunchKernelGGL((attention_pool_bwd_stream_kernel<T, NT, G>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), lds, s, alpha, v,
                      d_pooled, d_logits, d_v, N, D);
   hipLaunchKernelGGL(attention_softmax_bwd_kernel, dim3(B), dim3(256), lds + kMaxG * sizeof(float), s, alpha, d_logits,
                      d_alpha_ext, d_logits, N, G);
   return check_launch("softmax_attention_pool_bwd");
 }
 
-}  // namespace vqa
-
-using namespace vqa;
-
-extern "C" int vqa_softmax_attention_pool_fwd(const float* logits, const float* v, float* alpha, float* pooled, int B,
-                                              int N, int D, int G, vqa_stream_t stream) {
-  VQA_REQUIRE(logits && v && alpha && pooled, VQA_E_BADARG, "softmax_attention_pool_fwd: null pointer");
-  VQA_REQUIRE(B > 0 && N > 0 && D > 0 && G > 0, VQA_E_BADARG, "softmax_attention_pool_fwd: bad sizes B=%d N=%d D=%d G=%d",
-              B, N, D, G);
-  VQA_REQUIRE(G <= kMaxG && N <= 1024, VQA_E_UNSUPPORTED, "softmax_attention_pool_fwd: needs G <= 8 and N <= 1024 (G=%d N=%d)",
-              G, N);
-  VQA_REQUIRE(D % 4 == 0 && aligned(v, 16) && aligned(pooled, 16), VQA_E_UNSUPPORTED,
-              "softmax_attention_pool_fwd: needs D %% 4 == 0 and 16-byte aligned v/pooled (D=%d)", D);
-  VQA_REQUIRE(B <= 65535, VQA_E_UNSUPPORTED, "softmax_attention_pool_fwd: B=%d exceeds 65535", B);
+template <typename T>
+static int pool_fwd_impl(const char* who, const float* logits, const T* v, float* alpha, float* pooled, int B, int N, int D,
+                         int G, vqa_stream_t stream) {
+  constexpr size_t kAlign = 4 * sizeof(T);
+  VQA_REQUIRE(logits && v && alpha && pooled, VQA_E_BADARG, "%s: null pointer", who);
+  VQA_REQUIRE(B > 0 && N > 0 && D > 0 && G > 0, VQA_E_BADARG, "%s: bad sizes B=%d N=%d D=%d G=%d", who, B, N, D, G);
+  VQA_REQUIRE(G <= kMaxG && N <= 1024, VQA_E_UNSUPPORTED, "%s: needs G <= 8 and N <= 1024 (G=%d N=%d)", who, G, N);
+  VQA_REQUIRE(D % 4 == 0 && aligned(v, kAlign) && aligned(pooled, 16), VQA_E_UNSUPPORTED,
+              "%s: needs D %% 4 == 0, %zu-byte aligned v and 16-byte aligned pooled (D=%d)", who, kAlign, D);
+  VQA_REQUIRE(B <= 65535, VQA_E_UNSUPPORTED, "%s: B=%d exceeds 65535", who, B);
   hipStream_t s = static_cast<hipStream_t>(stream);
-#define CALL_FWD(G_) launch_fwd<G_>(logits, v, alpha, pooled, B, N, D, s)
+#define CALL_FWD(G_) launch_fwd<T, G_>(logits, v, alpha, pooled, B, N, D, s)
   switch (G) {
     case 1: return CALL_FWD(1);
     case 2: return CALL_FWD(2);
@@ -235,18 +233,19 @@ extern "C" int vqa_softmax_attention_pool_fwd(const float* logits, const float* 
 #undef CALL_FWD
 }
 
-extern "C" int vqa_softmax_attention_pool_bwd(const float* alpha, const float* v, const float* d_pooled,
-                                              const float* d_alpha_ext, float* d_logits, float* d_v, int B, int N,
-                                              int D, int G, vqa_stream_t stream) {
-  VQA_REQUIRE(alpha && v && d_pooled && d_logits, VQA_E_BADARG, "softmax_attention_pool_bwd: null pointer");
-  VQA_REQUIRE(B > 0 && N > 0 && D > 0 && G > 0, VQA_E_BADARG, "softmax_attention_pool_bwd: bad sizes B=%d N=%d D=%d G=%d",
-              B, N, D, G);
-  VQA_REQUIRE(G <= kMaxG && N <= 1024, VQA_E_UNSUPPORTED, "softmax_attention_pool_bwd: needs G <= 8 and N <= 1024 (G=%d N=%d)",
-              G, N);
-  VQA_REQUIRE(D % 4 == 0 && aligned(v, 16) && aligned(d_pooled, 16) && (d_v == nullptr || aligned(d_v, 16)),
-              VQA_E_UNSUPPORTED, "softmax_attention_pool_bwd: needs D %% 4 == 0 and 16-byte aligned v/d_pooled/d_v (D=%d)", D);
+template <typename T>
+static int pool_bwd_impl(const char* who, const float* alpha, const T* v, const float* d_pooled, const float* d_alpha_ext,
+                         float* d_logits, T* d_v, int B, int N, int D, int G, vqa_stream_t stream) {
+  constexpr size_t kAlign = 4 * sizeof(T);
+  VQA_REQUIRE(alpha && v && d_pooled && d_logits, VQA_E_BADARG, "%s: null pointer", who);
+  VQA_REQUIRE(B > 0 && N > 0 && D > 0 && G > 0, VQA_E_BADARG, "%s: bad sizes B=%d N=%d D=%d G=%d", who, B, N, D, G);
+  VQA_REQUIRE(G <= kMaxG && N <= 1024, VQA_E_UNSUPPORTED, "%s: needs G <= 8 and N <= 1024 (G=%d N=%d)", who, G, N);
+  VQA_REQUIRE(D % 4 == 0 && aligned(v, kAlign) && aligned(d_pooled, 16) && (d_v == nullptr || aligned(d_v, kAlign)),
+              VQA_E_UNSUPPORTED, "%s: needs D %% 4 == 0, 16-byte aligned d_pooled and %zu-byte aligned v/d_v (D=%d)", who,
+              kAlign, D);
+  VQA_REQUIRE(B <= 65535, VQA_E_UNSUPPORTED, "%s: B=%d exceeds 65535", who, B);
   hipStream_t s = static_cast<hipStream_t>(stream);
-#define CALL_BWD(G_) launch_bwd<G_>(alpha, v, d_pooled, d_alpha_ext, d_logits, d_v, B, N, D, s)
+#define CALL_BWD(G_) launch_bwd<T, G_>(alpha, v, d_pooled, d_alpha_ext, d_logits, d_v, B, N, D, s)
   switch (G) {
     case 1: return CALL_BWD(1);
     case 2: return CALL_BWD(2);
@@ -258,4 +257,33 @@ extern "C" int vqa_softmax_attention_pool_bwd(const float* alpha, const float* v
     default: return CALL_BWD(8);
   }
 #undef CALL_BWD
+}
+
+}  // namespace vqa
+
+using namespace vqa;
+
+extern "C" int vqa_softmax_attention_pool_fwd(const float* logits, const float* v, float* alpha, float* pooled, int B,
+                                              int N, int D, int G, vqa_stream_t stream) {
+  return pool_fwd_impl<float>("softmax_attention_pool_fwd", logits, v, alpha, pooled, B, N, D, G, stream);
+}
+
+extern "C" int vqa_softmax_attention_pool_fwd_bf16(const float* logits, const vqa_bf16_t* v, float* alpha, float* pooled,
+                                                   int B, int N, int D, int G, vqa_stream_t stream) {
+  return pool_fwd_impl<bf16>("softmax_attention_pool_fwd_bf16", logits, reinterpret_cast<const bf16*>(v), alpha, pooled, B, N,
+                             D, G, stream);
+}
+
+extern "C" int vqa_softmax_attention_pool_bwd(const float* alpha, const float* v, const float* d_pooled,
+                                              const float* d_alpha_ext, float* d_logits, float* d_v, int B, int N,
+                                              int D, int G, vqa_stream_t stream) {
+  return pool_bwd_impl<float>("softmax_attention_pool_bwd", alpha, v, d_pooled, d_alpha_ext, d_logits, d_v, B, N, D, G,
+                              stream);
+}
+
+extern "C" int vqa_softmax_attention_pool_bwd_bf16(const float* alpha, const vqa_bf16_t* v, const float* d_pooled,
+                                                   const float* d_alpha_ext, float* d_logits, vqa_bf16_t* d_v, int B,
+                                                   int N, int D, int G, vqa_stream_t stream) {
+  return pool_bwd_impl<bf16>("softmax_attention_pool_bwd_bf16", alpha, reinterpret_cast<const bf16*>(v), d_pooled,
+                             d_alpha_ext, d_logits, reinterpret_cast<bf16*>(d_v), B, N, D, G, stream);
 }

@@ -1,0 +1,455 @@
+// Mixed-precision (bf16 storage / bf16 MFMA operands / fp32 accumulate) side of the library -- BASELINE configs[4]:
+// "CoR2 bf16, 100x2048 dense regions".  Holds the generic bf16 GEMMs on the tile engine of gemm_bf16_mfma.hpp and
+// K4 (low-rank bilinear fusion, putils/__init__.py:232-238) built on them.
+//
+// Operand contract: feature dims are padded to a multiple of 64 with zeros by the caller (the Python host keeps bf16
+// shadow copies of the fp32 master weights in this layout), so the kernels carry no tail handling; row counts
+// (M = B*N) are free.
+//
+//   K4 forward : out[m,:] = sum_r (x[m,:] W1_r^T + b1_r) * h2[b(m),r,:]       NT GEMM per rank, fused epilogue
+//   K4 backward: prep  gs[m,r,:] = g[m,:] * h2[b(m),r,:]  (bf16),  dh2[b,r,:] = sum_n g[b,n,:] * h1[b,n,r,:],
+//                      gsum[b,:] = sum_n g[b,n,:]          -- one streaming pass over g and h1
+//                db1[r,:] = sum_b h2[b,r,:] * gsum[b,:]
+//                dx  = gs[M, R*H] * W1t[L, R*H]^T           one NT GEMM over the concatenated rank axis
+//                dW1 = gs[M, R*H]^T * x[M, L]               one TN GEMM, split over M into fp32 slabs, fixed-order reduce
+#include "gemm_bf16_mfma.hpp"
+
+namespace vqa {
+
+constexpr int kBfMaxR = 8;
+
+struct BfTileChoice {
+  int bm, bn;
+};
+static BfTileChoice choose_bf_tile(long M, long N) {
+  const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+  const double pref[4] = {1.0, 1.1, 1.1, 1.25};
+  double best = 1e300;
+  BfTileChoice out{128, 128};
+  for (int c = 0; c < 4; ++c) {
+    const long tm = (M + cand[c][0] - 1) / cand[c][0], tn = (N + cand[c][1] - 1) / cand[c][1];
+    const double cost = (double)tm * tn * cand[c][0] * cand[c][1] * pref[c];
+    if (cost < best) {
+      best = cost;
+      out = {cand[c][0], cand[c][1]};
+    }
+  }
+  return out;
+}
+
+#define VQA_BF_TILE_SWITCH(t, LAUNCH)            \
+  do {                                           \
+    if ((t).bm == 128 && (t).bn == 128) {        \
+      LAUNCH(128, 128)                           \
+    } else if ((t).bm == 128 && (t).bn == 64) {  \
+      LAUNCH(128, 64)                            \
+    } else if ((t).bm == 64 && (t).bn == 128) {  \
+      LAUNCH(64, 128)                            \
+    } else {                                     \
+      LAUNCH(64, 64)                             \
+    }                                            \
+  } while (0)
+
+// ------------------------------------------------------------------------------------- generic NT
+// C[M,N] (bf16, row stride ldc) = act(A[M,K] * B[N,K]^T + bias[N]);  act: 0 none, 1 relu
+template <int BM, int BN>
+__global__ __launch_bounds__(kBfThreads) void gemm_bf16_nt_kernel(const bf16* __restrict__ A, int lda,
+                                                                  const bf16* __restrict__ B, int ldb,
+                                                                  const float* __restrict__ bias, bf16* __restrict__ C,
+                                                                  int ldc, int M, int N, int K, int act, int tiles_n) {
+  using T = BfTile<BM, BN>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+  f32x16 acc[T::TM][T::TN];
+  bf_zero_acc(acc);
+  gemm_bf16_nt_tile<BM, BN>(A, lda, M, B, ldb, N, m0, n0, K, smem, acc);
+  const BfAccCoord<BM, BN> cc(m0, n0);
+  const unsigned lo = cc.loff(ldc);
+#pragma unroll
+  for (int tn = 0; tn < T::TN; ++tn) {
+    const int col = cc.col(tn);
+    if (col < N) {
+      const float bv = bias != nullptr ? bias[col] : 0.f;
+#pragma unroll
+      for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float y = acc[tm][tn][i] + bv;
+          if (act == 1) y = fmaxf(y, 0.f);
+          if (cc.row(tm, i) < M) (C + cc.uoff(tm, tn, i, ldc))[lo] = (bf16)y;
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------- generic TN
+// slab[s][N1][N2] (fp32) = A[rows of split s, 0:N1)^T * B[rows of split s, 0:N2)
+template <int BM, int BN>
+__global__ __launch_bounds__(kBfThreads) void gemm_bf16_tn_kernel(const bf16* __restrict__ A, int lda,
+                                                                  const bf16* __restrict__ B, int ldb,
+                                                                  float* __restrict__ slab, int Kdim, int N1, int N2,
+                                                                  int rows_per_split, int tiles_n) {
+  using T = BfTile<BM, BN>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+  const int s = blockIdx.z;
+  const int k_lo = s * rows_per_split, k_hi = min(Kdim, k_lo + rows_per_split);
+  f32x16 acc[T::TM][T::TN];
+  bf_zero_acc(acc);
+  gemm_bf16_tn_tile<BM, BN>(A, lda, N1, B, ldb, N2, m0, n0, k_lo, k_hi, smem, acc);
+  float* __restrict__ dst = slab + (size_t)s * N1 * N2;
+  const BfAccCoord<BM, BN> cc(m0, n0);
+  const unsigned lo = cc.loff(N2);
+#pragma unroll
+  for (int tn = 0; tn < T::TN; ++tn) {
+    if (cc.col(tn) < N2) {
+#pragma unroll
+      for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (cc.row(tm, i) < N1) (dst + cc.uoff(tm, tn, i, N2))[lo] = acc[tm][tn][i];
+    }
+  }
+}
+
+// out[e] = sum_s slab[s][e]   (fixed order: bitwise reproducible); count % 4 == 0
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                                          size_t count, int S) {
+  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= count) return;
+  float4 a = ld4(slab + e);
+  for (int s = 1; s < S; ++s) a = add4(a, ld4(slab + (size_t)s * count + e));
+  st4(out + e, a);
+}
+
+static int tn_splits(int Kdim, int N1, int N2, BfTileChoice t) {
+  const long tiles = (long)((N1 + t.bm - 1) / t.bm) * ((N2 + t.bn - 1) / t.bn);
+  long s = (512 + tiles - 1) / tiles;
+  const long max_by_rows = (Kdim + 511) / 512;  // keep >= 512 rows (8 stages) per split
+  if (s > max_by_rows) s = max_by_rows;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+static BfTileChoice tn_tile(int N1, int N2) { return choose_bf_tile(N1, N2); }
+
+static int launch_nt(const char* who, const bf16* A, int lda, const bf16* B, int ldb, const float* bias, bf16* C, int ldc,
+                     int M, int N, int K, int act, hipStream_t s) {
+  const BfTileChoice t = choose_bf_tile(M, N);
+  const int tiles_m = (M + t.bm - 1) / t.bm, tiles_n = (N + t.bn - 1) / t.bn;
+#define LAUNCH(BM_, BN_)                                                                                                 \
+  {                                                                                                                      \
+    const size_t lds = BfTile<BM_, BN_>::kSmemBytes;                                                                     \
+    VQA_ENSURE_LDS((gemm_bf16_nt_kernel<BM_, BN_>), lds);                                                                \
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM_, BN_>), dim3(tiles_m * tiles_n), dim3(kBfThreads), lds, s, A, lda, B, ldb, \
+                       bias, C, ldc, M, N, K, act, tiles_n);                                                             \
+  }
+  VQA_BF_TILE_SWITCH(t, LAUNCH);
+#undef LAUNCH
+  return check_launch(who);
+}
+
+static size_t tn_workspace_bytes(int Kdim, int N1, int N2) {
+  const int S = tn_splits(Kdim, N1, N2, tn_tile(N1, N2));
+  return S > 1 ? (size_t)S * N1 * N2 * sizeof(float) : 0;
+}
+
+// C[N1,N2] fp32 dense.  workspace: tn_workspace_bytes (may be null when that is 0)
+static int launch_tn(const char* who, const bf16* A, int lda, const bf16* B, int ldb, float* C, float* workspace, int Kdim,
+                     int N1, int N2, hipStream_t s) {
+  const BfTileChoice t = tn_tile(N1, N2);
+  const int S = tn_splits(Kdim, N1, N2, t);
+  const int tiles_m = (N1 + t.bm - 1) / t.bm, tiles_n = (N2 + t.bn - 1) / t.bn;
+  int rows_per_split = (Kdim + S - 1) / S;
+  rows_per_split = (rows_per_split + kBfBK - 1) / kBfBK * kBfBK;
+  float* dst = S > 1 ? workspace : C;
+#define LAUNCH(BM_, BN_)                                                                                                    \
+  {                                                                                                                         \
+    const size_t lds = BfTile<BM_, BN_>::kSmemBytes;                                                                        \
+    VQA_ENSURE_LDS((gemm_bf16_tn_kernel<BM_, BN_>), lds);                                                                   \
+    hipLaunchKernelGGL((gemm_bf16_tn_kernel<BM_, BN_>), dim3(tiles_m * tiles_n, 1, S), dim3(kBfThreads), lds, s, A, lda, B, ldb, \
+                       dst, Kdim, N1, N2, rows_per_split, tiles_n);                                                         \
+  }
+  VQA_BF_TILE_SWITCH(t, LAUNCH);
+#undef LAUNCH
+  if (S > 1) {
+    const size_t count = (size_t)N1 * N2;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s, workspace, C, count, S);
+  }
+  return check_launch(who);
+}
+
+// ------------------------------------------------------------------------------------------ K4 forward
+// The question-side factor of the epilogue is staged through LDS: a BM-row tile touches only the samples
+// b0 .. b0 + ceil(BM/N), so their h2[b, r, n0 : n0+BN) rows are loaded once per (tile, rank), coalesced, into the
+// (idle) staging buffers, and every accumulator register finds its multiplier with one ds_read_b32.
+template <int BM, int BN>
+__global__ __launch_bounds__(kBfThreads) void bilinear_fwd_bf16_kernel(const bf16* __restrict__ x,
+                                                                       const bf16* __restrict__ w1,
+                                                                       const float* __restrict__ b1,
+                                                                       const float* __restrict__ h2, bf16* __restrict__ out,
+                                                                       bf16* __restrict__ h1, int M, int N, int L, int H,
+                                                                       int R, int tiles_n) {
+  using T = BfTile<BM, BN>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* h2_s = reinterpret_cast<float*>(smem);                  // [samples in tile][BN], overlays the staging ring
+  int* rowoff_s = reinterpret_cast<int*>(smem + T::kSmemBytes);  // [BM] (sample of the row - b0) * BN
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+  const int b0 = m0 / N;
+  const int ns = min(m0 + BM - 1, M - 1) / N - b0 + 1;  // samples touched by this tile (<= BM)
+  for (int t = threadIdx.x; t < BM; t += kBfThreads) rowoff_s[t] = (min(m0 + t, M - 1) / N - b0) * BN;
+  // (visible after the first barrier inside the tile loop)
+  const BfAccCoord<BM, BN> cc(m0, n0);
+  const unsigned lo_out = cc.loff(H), lo_h1 = cc.loff(R * H);
+  f32x16 total[T::TM][T::TN];
+  bf_zero_acc(total);
+  for (int r = 0; r < R; ++r) {
+    f32x16 acc[T::TM][T::TN];
+    bf_zero_acc(acc);
+    gemm_bf16_nt_tile<BM, BN>(x, L, M, w1 + (size_t)r * H * L, L, H, m0, n0, L, smem, acc);
+    for (int t = threadIdx.x; t < ns * BN; t += kBfThreads)
+      h2_s[t] = h2[((size_t)(b0 + t / BN) * R + r) * H + n0 + (t % BN)];
+    __syncthreads();
+    // epilogue of rank r: total += (acc + b1_r) * h2[b(row), r, :]
+#pragma unroll
+    for (int tn = 0; tn < T::TN; ++tn) {
+      const int col = cc.col(tn);  // < H: H % 256 == 0 and the grid covers exactly H columns
+      const float bv = b1[(size_t)r * H + col];
+      const float* h2c = h2_s + (col - n0);
+#pragma unroll
+      for (int tm = 0; tm < T::TM; ++tm) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = cc.row(tm, i);
+          const float hv = acc[tm][tn][i] + bv;
+          const float qv = h2c[rowoff_s[row - m0]];
+          if (h1 != nullptr && row < M) (h1 + (cc.uoff(tm, tn, i, R * H) + (size_t)r * H))[lo_h1] = (bf16)hv;
+          total[tm][tn][i] = fmaf(hv, qv, total[tm][tn][i]);
+        }
+      }
+    }
+    __syncthreads();  // h2_s is the next rank's staging buffer
+  }
+#pragma unroll
+  for (int tn = 0; tn < T::TN; ++tn) {
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (cc.row(tm, i) < M) (out + cc.uoff(tm, tn, i, H))[lo_out] = (bf16)total[tm][tn][i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ K4 backward prep
+// grid (H/256, B); 256 lanes = 64 columns-of-4 x 4 region slices; the slices meet in LDS.
+__global__ __launch_bounds__(256) void bilinear_bwd_prep_bf16_kernel(const bf16* __restrict__ g, const bf16* __restrict__ h1,
+                                                                     const float* __restrict__ h2, bf16* __restrict__ gs,
+                                                                     float* __restrict__ dh2, float* __restrict__ gsum,
+                                                                     int N, int H, int R) {
+  __shared__ float4 part[3][kBfMaxR + 1][64];
+  const int b = blockIdx.y;
+  const int c = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int h = (blockIdx.x * 64 + c) * 4;  // < H: H % 256 == 0
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc[kBfMaxR], q[kBfMaxR], gt = z;
+#pragma unroll
+  for (int r = 0; r < kBfMaxR; ++r) {
+    acc[r] = z;
+    q[r] = r < R ? ld4(h2 + ((size_t)b * R + r) * H + h) : z;
+  }
+#pragma unroll 2
+  for (int n = slice; n < N; n += 4) {
+    const size_t m = (size_t)b * N + n;
+    const float4 gv = ld4(g + m * H + h);
+    gt = add4(gt, gv);
+#pragma unroll
+    for (int r = 0; r < kBfMaxR; ++r) {
+      if (r < R) {
+        const float4 hv = ld4(h1 + (m * R + r) * H + h);
+        acc[r] = add4(acc[r], mul4(gv, hv));
+        st4(gs + (m * R + r) * H + h, mul4(gv, q[r]));
+      }
+    }
+  }
+  if (slice > 0) {
+#pragma unroll
+    for (int r = 0; r < kBfMaxR; ++r)
+      if (r < R) part[slice - 1][r][c] = acc[r];
+    part[slice - 1][kBfMaxR][c] = gt;
+  }
+  __syncthreads();
+  if (slice == 0) {
+#pragma unroll
+    for (int r = 0; r < kBfMaxR; ++r) {
+      if (r < R) {
+        float4 t = acc[r];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) t = add4(t, part[s][r][c]);
+        st4(dh2 + ((size_t)b * R + r) * H + h, t);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) gt = add4(gt, part[s][kBfMaxR][c]);
+    st4(gsum + (size_t)b * H + h, gt);
+  }
+}
+
+// db1[r][h] = sum_b h2[b,r,h] * gsum[b,h]   (fixed order over b)
+__global__ __launch_bounds__(256) void bilinear_db_bf16_kernel(const float* __restrict__ h2, const float* __restrict__ gsum,
+                                                               float* __restrict__ db1, int B, int H, int R) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= R * H) return;
+  const int h = e % H;
+  float a = 0.f;
+  for (int b = 0; b < B; ++b) a = fmaf(h2[(size_t)b * R * H + e], gsum[(size_t)b * H + h], a);
+  db1[e] = a;
+}
+
+// fp32 [batch, rows, cols] -> bf16 at dst[b*sb + r*sr + c*sc]  (dst zero-filled beforehand: the pads)
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int rows,
+                                                        int cols, long sb, long sr, long sc, size_t count) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= count) return;
+  const int c = (int)(e % cols);
+  const size_t t = e / cols;
+  const int r = (int)(t % rows);
+  const size_t b = t / rows;
+  dst[b * sb + (size_t)r * sr + (size_t)c * sc] = (bf16)src[e];
+}
+
+static int check_k4(const char* who, int B, int N, int L, int H, int R) {
+  VQA_REQUIRE(B > 0 && N > 0 && L > 0 && H > 0 && R > 0, VQA_E_BADARG, "%s: bad sizes B=%d N=%d L=%d H=%d R=%d", who, B, N, L,
+              H, R);
+  VQA_REQUIRE(R <= kBfMaxR, VQA_E_UNSUPPORTED, "%s: R=%d exceeds %d", who, R, kBfMaxR);
+  VQA_REQUIRE(L % 64 == 0 && H % 256 == 0, VQA_E_UNSUPPORTED,
+              "%s: the bf16 path needs zero-padded dims L %% 64 == 0 and H %% 256 == 0 (L=%d H=%d)", who, L, H);
+  VQA_REQUIRE((long)B * N < (1L << 30) && B <= 65535, VQA_E_UNSUPPORTED, "%s: B*N too large", who);
+  return VQA_OK;
+}
+
+}  // namespace vqa
+
+using namespace vqa;
+
+extern "C" int vqa_pack_bf16(const float* src, int batch, int rows, int cols, vqa_bf16_t* dst, long dst_batch_stride,
+                             long dst_row_stride, long dst_col_stride, size_t dst_elems, int zero_fill,
+                             vqa_stream_t stream) {
+  VQA_REQUIRE(src && dst, VQA_E_BADARG, "pack_bf16: null pointer");
+  VQA_REQUIRE(batch > 0 && rows > 0 && cols > 0 && dst_batch_stride >= 0 && dst_row_stride > 0 && dst_col_stride > 0,
+              VQA_E_BADARG, "pack_bf16: bad sizes batch=%d rows=%d cols=%d", batch, rows, cols);
+  const size_t last = (size_t)(batch - 1) * dst_batch_stride + (size_t)(rows - 1) * dst_row_stride +
+                      (size_t)(cols - 1) * dst_col_stride;
+  VQA_REQUIRE(last < dst_elems, VQA_E_BADARG, "pack_bf16: destination of %zu elements is too small (needs %zu)", dst_elems,
+              last + 1);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (zero_fill) {
+    hipError_t e = hipMemsetAsync(dst, 0, dst_elems * sizeof(vqa_bf16_t), s);
+    if (e != hipSuccess) return fail(VQA_E_LAUNCH, "pack_bf16: memset: %s", hipGetErrorString(e));
+  }
+  const size_t count = (size_t)batch * rows * cols;
+  hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, src,
+                     reinterpret_cast<bf16*>(dst), rows, cols, dst_batch_stride, dst_row_stride, dst_col_stride, count);
+  return check_launch("pack_bf16");
+}
+
+extern "C" int vqa_gemm_bf16_nt(const vqa_bf16_t* a, int lda, const vqa_bf16_t* b, int ldb, const float* bias,
+                                vqa_bf16_t* c, int ldc, int M, int N, int K, int act, vqa_stream_t stream) {
+  VQA_REQUIRE(a && b && c, VQA_E_BADARG, "gemm_bf16_nt: null pointer");
+  VQA_REQUIRE(M > 0 && N > 0 && K > 0, VQA_E_BADARG, "gemm_bf16_nt: bad sizes M=%d N=%d K=%d", M, N, K);
+  VQA_REQUIRE(act == 0 || act == 1, VQA_E_BADARG, "gemm_bf16_nt: act must be 0 (none) or 1 (relu), got %d", act);
+  VQA_REQUIRE(K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K && ldc >= N && aligned(a, 16) &&
+                  aligned(b, 16),
+              VQA_E_UNSUPPORTED, "gemm_bf16_nt: needs K %% 64 == 0, lda/ldb %% 8 == 0 and 16-byte aligned a/b (K=%d lda=%d ldb=%d)",
+              K, lda, ldb);
+  return launch_nt("gemm_bf16_nt", reinterpret_cast<const bf16*>(a), lda, reinterpret_cast<const bf16*>(b), ldb, bias,
+                   reinterpret_cast<bf16*>(c), ldc, M, N, K, act, static_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t vqa_gemm_bf16_tn_workspace_bytes(int K, int N1, int N2) {
+  if (K <= 0 || N1 <= 0 || N2 <= 0) return 0;
+  return tn_workspace_bytes(K, N1, N2);
+}
+
+extern "C" int vqa_gemm_bf16_tn(const vqa_bf16_t* a, int lda, const vqa_bf16_t* b, int ldb, float* c, void* workspace,
+                                size_t workspace_bytes, int K, int N1, int N2, vqa_stream_t stream) {
+  VQA_REQUIRE(a && b && c, VQA_E_BADARG, "gemm_bf16_tn: null pointer");
+  VQA_REQUIRE(K > 0 && N1 > 0 && N2 > 0, VQA_E_BADARG, "gemm_bf16_tn: bad sizes K=%d N1=%d N2=%d", K, N1, N2);
+  VQA_REQUIRE(N1 % 8 == 0 && N2 % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= N1 && ldb >= N2 && aligned(a, 16) &&
+                  aligned(b, 16) && aligned(c, 16),
+              VQA_E_UNSUPPORTED, "gemm_bf16_tn: needs N1, N2, lda, ldb %% 8 == 0 and 16-byte aligned pointers");
+  const size_t need = tn_workspace_bytes(K, N1, N2);
+  VQA_REQUIRE(workspace_bytes >= need && (need == 0 || (workspace && aligned(workspace, 16))), VQA_E_BADARG,
+              "gemm_bf16_tn: workspace of %zu B is too small (needs %zu)", workspace_bytes, need);
+  return launch_tn("gemm_bf16_tn", reinterpret_cast<const bf16*>(a), lda, reinterpret_cast<const bf16*>(b), ldb, c,
+                   static_cast<float*>(workspace), K, N1, N2, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int vqa_lowrank_bilinear_fusion_fwd_bf16(const vqa_bf16_t* x, const vqa_bf16_t* w1, const float* b1,
+                                                    const float* h2, vqa_bf16_t* out, vqa_bf16_t* h1, int B, int N, int L,
+                                                    int H, int R, vqa_stream_t stream) {
+  VQA_REQUIRE(x && w1 && b1 && h2 && out, VQA_E_BADARG, "lowrank_bilinear_fusion_fwd_bf16: null pointer");
+  int rc = check_k4("lowrank_bilinear_fusion_fwd_bf16", B, N, L, H, R);
+  if (rc != VQA_OK) return rc;
+  VQA_REQUIRE(aligned(x, 16) && aligned(w1, 16), VQA_E_UNSUPPORTED, "lowrank_bilinear_fusion_fwd_bf16: x/w1 must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int M = B * N;
+  BfTileChoice t = choose_bf_tile(M, H);
+  if (t.bm == 128 && t.bn == 128) t.bn = 64;  // total + per-rank accumulators: 128x128 would drop to one wave per SIMD
+  const int tiles_m = (M + t.bm - 1) / t.bm, tiles_n = H / t.bn;
+#define LAUNCH(BM_, BN_)                                                                                                  \
+  {                                                                                                                       \
+    const size_t lds = BfTile<BM_, BN_>::kSmemBytes + BM_ * sizeof(int);                                                  \
+    VQA_ENSURE_LDS((bilinear_fwd_bf16_kernel<BM_, BN_>), lds);                                                            \
+    hipLaunchKernelGGL((bilinear_fwd_bf16_kernel<BM_, BN_>), dim3(tiles_m * tiles_n), dim3(kBfThreads), lds, s,           \
+                       reinterpret_cast<const bf16*>(x), reinterpret_cast<const bf16*>(w1), b1, h2,                       \
+                       reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(h1), M, N, L, H, R, tiles_n);               \
+  }
+  VQA_BF_TILE_SWITCH(t, LAUNCH);
+#undef LAUNCH
+  return check_launch("lowrank_bilinear_fusion_fwd_bf16");
+}
+
+// workspace layout: gs bf16 [M, R*H] | gsum f32 [B, H] | TN slabs
+static size_t k4_gs_bytes(int B, int N, int H, int R) { return ((size_t)B * N * R * H * sizeof(vqa_bf16_t) + 255) / 256 * 256; }
+static size_t k4_gsum_bytes(int B, int H) { return ((size_t)B * H * sizeof(float) + 255) / 256 * 256; }
+
+extern "C" size_t vqa_lowrank_bilinear_fusion_bwd_bf16_workspace_bytes(int B, int N, int L, int H, int R) {
+  if (B <= 0 || N <= 0 || L <= 0 || H <= 0 || R <= 0 || R > kBfMaxR) return 0;
+  return k4_gs_bytes(B, N, H, R) + k4_gsum_bytes(B, H) + tn_workspace_bytes(B * N, R * H, L);
+}
+
+extern "C" int vqa_lowrank_bilinear_fusion_bwd_bf16(const vqa_bf16_t* x, const vqa_bf16_t* w1t, const float* h2,
+                                                    const vqa_bf16_t* h1, const vqa_bf16_t* g, vqa_bf16_t* d_x,
+                                                    float* d_w1, float* d_b1, float* d_h2, void* workspace,
+                                                    size_t workspace_bytes, int B, int N, int L, int H, int R,
+                                                    vqa_stream_t stream) {
+  VQA_REQUIRE(x && h2 && h1 && g && d_w1 && d_b1 && d_h2 && workspace, VQA_E_BADARG,
+              "lowrank_bilinear_fusion_bwd_bf16: null pointer");
+  VQA_REQUIRE(d_x == nullptr || w1t != nullptr, VQA_E_BADARG, "lowrank_bilinear_fusion_bwd_bf16: d_x needs w1t");
+  int rc = check_k4("lowrank_bilinear_fusion_bwd_bf16", B, N, L, H, R);
+  if (rc != VQA_OK) return rc;
+  VQA_REQUIRE(workspace_bytes >= vqa_lowrank_bilinear_fusion_bwd_bf16_workspace_bytes(B, N, L, H, R), VQA_E_BADARG,
+              "lowrank_bilinear_fusion_bwd_bf16: workspace of %zu B is too small", workspace_bytes);
+  VQA_REQUIRE(aligned(x, 16) && aligned(g, 16) && aligned(h1, 16) && aligned(h2, 16) && aligned(workspace, 256) &&
+                  aligned(d_w1, 16) && aligned(d_h2, 16) && (d_x == nullptr || (aligned(d_x, 16) && aligned(w1t, 16))),
+              VQA_E_UNSUPPORTED, "lowrank_bilinear_fusion_bwd_bf16: tensors must be 16-byte aligned (workspace 256)");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int M = B * N, RH = R * H;
+  char* ws = static_cast<char*>(workspace);
+  bf16* gs = reinterpret_cast<bf16*>(ws);
+  float* gsum = reinterpret_cast<float*>(ws + k4_gs_bytes(B, N, H, R));
+  float* slabs = reinterpret_cast<float*>(ws + k4_gs_bytes(B, N, H, R) + k4_gsum_bytes(B, H));
+  hipLaunchKernelGGL(bilinear_bwd_prep_bf16_kernel, dim3(H / 256, B), dim3(256), 0, s, reinterpret_cast<const bf16*>(g),
+                     reinterpret_cast<const bf16*>(h1), h2, gs, d_h2, gsum, N, H, R);
+  hipLaunchKernelGGL(bilinear_db_bf16_kernel, dim3((RH + 255) / 256), dim3(256), 0, s, h2, gsum, d_b1, B, H, R);
+  if (d_x != nullptr) {
+    rc = launch_nt("lowrank_bilinear_fusion_bwd_bf16(dx)", gs, RH, reinterpret_cast<const bf16*>(w1t), RH, nullptr,
+                   reinterpret_cast<bf16*>(d_x), L, M, L, RH, 0, s);
+    if (rc != VQA_OK) return rc;
+  }
+  return launch_tn("lowrank_bilinear_fusion_bwd_bf16(dw)", gs, RH, reinterpret_cast<const bf16*>(x), L, d_w1, slabs, M, RH, L,
+                   s);
+}

@@ -53,6 +53,7 @@ inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_
 
 // ---- device helpers --------------------------------------------------------------------------
 constexpr int kWave = 64;
+using f32x16 = __attribute__((ext_vector_type(16))) float;  // one 32x32 MFMA accumulator tile per wave
 
 // wave64 reductions at VALU speed: four DPP steps (quad_perm, quad_perm, row_half_mirror, row_mirror) leave every lane
 // with the sum of its 16-lane row, four v_readlane combine the rows.  (__shfl_xor lowers to ds_bpermute: an LDS
@@ -86,6 +87,25 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
 __device__ __forceinline__ void st2(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+
+// bf16 storage (the mixed-precision path: bf16 in HBM, fp32 in registers).  Four elements = one 8-byte access;
+// widening is a shift, narrowing is the hardware round-to-nearest-even convert (v_cvt_pk_bf16_f32, NaN stays NaN).
+using bf16 = __bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const bf16x2 t = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, t);
+}
+__device__ __forceinline__ float4 ld4(const bf16* p) {
+  const uint2 w = *reinterpret_cast<const uint2*>(p);
+  return make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
+}
+__device__ __forceinline__ void st4(bf16* p, float4 v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+}
 
 __device__ __forceinline__ float4 fma4(float s, float4 a, float4 c) {
   return make_float4(fmaf(s, a.x, c.x), fmaf(s, a.y, c.y), fmaf(s, a.z, c.z), fmaf(s, a.w, c.w));

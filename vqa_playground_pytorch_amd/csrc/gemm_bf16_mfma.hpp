@@ -1,0 +1,258 @@
+// bf16 MFMA tile engine for gfx950 (v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate, 8 passes).
+//
+// The mixed-precision path (BASELINE configs[4]) keeps every region-side matrix in bf16 with feature dims padded
+// to a multiple of 64 and zero-filled, so the engine has no K tail and no column masks; rows past a matrix end are
+// read from a clamped (valid) row and only ever reach accumulator rows / columns that are not stored.
+//
+// One workgroup = 256 threads = 4 waves arranged 2 x 2 over a BM x BN output tile; every wave owns
+// (BM/64) x (BN/64) accumulators of 32 x 32.  The K loop advances 64 at a time through a two-stage LDS ring.
+// LDS image of both operands: [mn][64 k] bf16 rows with a 144-byte pitch -- lane l of a wave feeds the MFMA with the
+// 8 consecutive k of row (l & 31) starting at 8 * (l >> 5), i.e. one ds_read_b128, and 9 * row mod 16 is a
+// bijection, so the 16 lanes of a read group land on 16 distinct 16-byte slots of the 256-byte bank row.
+//
+//   NT  C[M,N]  = A[M,K] * B[N,K]^T   both K-contiguous: 16-byte global loads, ds_write_b128 as loaded
+//   TN  C[N1,N2] = A[K,N1]^T * B[K,N2]  both K-strided (weight gradients: K = rows of the batch): each thread loads an
+//       8(k) x 8(mn) block as eight 16-byte rows, transposes it in registers (32 v_perm_b32) and writes eight
+//       ds_write_b128 -- the same LDS image, so the MFMA side is shared.
+//
+// Global loads run two stages ahead in two register sets (write-after-barrier pipeline, as in gemm_f32_mfma.hpp).
+#pragma once
+#include "common.hpp"
+
+namespace vqa {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // a 16-byte register quad (native vector: stays in VGPRs)
+
+constexpr int kBfThreads = 256;
+constexpr int kBfBK = 64;                  // k per LDS stage
+constexpr int kBfPitch = kBfBK * 2 + 16;   // bytes per LDS row
+
+template <int BM, int BN>
+struct BfTile {
+  static_assert(BM == 64 || BM == 128, "BM must be 64 or 128");
+  static_assert(BN == 64 || BN == 128, "BN must be 64 or 128");
+  static constexpr int TM = BM / 64, TN = BN / 64;
+  static constexpr int CA = BM * 8 / kBfThreads, CB = BN * 8 / kBfThreads;  // 16-byte chunks per thread per stage (NT)
+  static constexpr int kStageBytes = (BM + BN) * kBfPitch;
+  static constexpr int kSmemBytes = 2 * kStageBytes;
+};
+
+// MFMA side of one stage: all fragments of LDS stage `base`, then the TM x TN x 4 MFMAs.
+template <int BM, int BN>
+__device__ __forceinline__ void bf_stage_mfma(const char* base, f32x16 (&acc)[BM / 64][BN / 64]) {
+  using T = BfTile<BM, BN>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const char* ap = base + (wm * (BM / 2) + (lane & 31)) * kBfPitch + (lane >> 5) * 16;
+  const char* bp = base + BM * kBfPitch + (wn * (BN / 2) + (lane & 31)) * kBfPitch + (lane >> 5) * 16;
+  bf16x8 a[4][T::TM], b[4][T::TN];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i) a[kk][i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * kBfPitch + kk * 32);
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) b[kk][j] = *reinterpret_cast<const bf16x8*>(bp + j * 32 * kBfPitch + kk * 32);
+  }
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+}
+
+// Per-thread staging state of the NT form: chunk p of a thread is 16 bytes (8 k) of tile row tid/8 + 32 p.
+template <int BM, int BN>
+struct NtStager {
+  using T = BfTile<BM, BN>;
+  const bf16* a;
+  const bf16* b;
+  int oa[T::CA], ob[T::CB];  // element offsets of the (clamped) source rows
+  int lds_a, lds_b;          // byte offsets of chunk 0 in an LDS stage; chunk p is 32 rows further
+  int nsteps;
+  __device__ __forceinline__ NtStager(const bf16* A, int lda, int a_rows, const bf16* B, int ldb, int b_rows, int m0, int n0,
+                                      int K)
+      : a(A), b(B), nsteps(K / kBfBK) {
+    const int row = threadIdx.x >> 3, kc = threadIdx.x & 7;
+#pragma unroll
+    for (int p = 0; p < T::CA; ++p) oa[p] = min(m0 + row + 32 * p, a_rows - 1) * lda + kc * 8;
+#pragma unroll
+    for (int p = 0; p < T::CB; ++p) ob[p] = min(n0 + row + 32 * p, b_rows - 1) * ldb + kc * 8;
+    lds_a = row * kBfPitch + kc * 16;
+    lds_b = (BM + row) * kBfPitch + kc * 16;
+  }
+  __device__ __forceinline__ void load(u32x4 (&ra)[T::CA], u32x4 (&rb)[T::CB], int step) const {
+    const int k0 = min(step, nsteps - 1) * kBfBK;  // past the end: a valid (re-read) stage that is never consumed
+#pragma unroll
+    for (int p = 0; p < T::CA; ++p) ra[p] = *reinterpret_cast<const u32x4*>(a + oa[p] + k0);
+#pragma unroll
+    for (int p = 0; p < T::CB; ++p) rb[p] = *reinterpret_cast<const u32x4*>(b + ob[p] + k0);
+  }
+  __device__ __forceinline__ void store(const u32x4 (&ra)[T::CA], const u32x4 (&rb)[T::CB], char* base) const {
+#pragma unroll
+    for (int p = 0; p < T::CA; ++p) *reinterpret_cast<u32x4*>(base + lds_a + p * 32 * kBfPitch) = ra[p];
+#pragma unroll
+    for (int p = 0; p < T::CB; ++p) *reinterpret_cast<u32x4*>(base + lds_b + p * 32 * kBfPitch) = rb[p];
+  }
+};
+
+template <int MFMAS, int VALU>
+__device__ __forceinline__ void bf_interleave() {
+#pragma unroll
+  for (int g = 0; g < MFMAS; ++g) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // DS write
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
+    __builtin_amdgcn_sched_group_barrier(0x002, VALU, 0);  // VALU
+  }
+}
+
+// acc += A[m0 : m0+BM, 0 : K) * B[n0 : n0+BN, 0 : K)^T.  K % 64 == 0; element offsets must fit 31 bits.  Two register
+// sets run the global loads two stages ahead of the MFMAs.  Ends on a barrier (LDS reusable at once).
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_bf16_nt_tile(const bf16* __restrict__ A, int lda, int a_rows,
+                                                  const bf16* __restrict__ B, int ldb, int b_rows, int m0, int n0, int K,
+                                                  char* smem, f32x16 (&acc)[BM / 64][BN / 64]) {
+  using T = BfTile<BM, BN>;
+  const NtStager<BM, BN> st(A, lda, a_rows, B, ldb, b_rows, m0, n0, K);
+  u32x4 ra0[T::CA], rb0[T::CB], ra1[T::CA], rb1[T::CB];
+  st.load(ra0, rb0, 0);
+  st.store(ra0, rb0, smem);
+  st.load(ra1, rb1, 1);  // stage 1 -> set 1, stage 2 -> set 0, ...
+  st.load(ra0, rb0, 2);
+  __syncthreads();
+  for (int s = 0; s < st.nsteps; s += 2) {
+    bf_stage_mfma<BM, BN>(smem, acc);
+    st.store(ra1, rb1, smem + T::kStageBytes);
+    st.load(ra1, rb1, s + 3);
+    bf_interleave<4 * T::TM * T::TN, 4>();
+    __syncthreads();
+    if (s + 1 < st.nsteps) {
+      bf_stage_mfma<BM, BN>(smem + T::kStageBytes, acc);
+      st.store(ra0, rb0, smem);
+      st.load(ra0, rb0, s + 4);
+      bf_interleave<4 * T::TM * T::TN, 4>();
+      __syncthreads();
+    }
+  }
+}
+
+// 8 x 8 transpose of 16-bit elements held as eight 16-byte rows: out[mn] = the 8 k-values of column mn.
+__device__ __forceinline__ void transpose8x8_b16(const uint4 (&r)[8], uint4 (&t)[8]) {
+  const uint32_t* in = reinterpret_cast<const uint32_t*>(r);  // in[4*k + i]: row k, columns 2i, 2i+1
+  uint32_t* out = reinterpret_cast<uint32_t*>(t);             // out[4*mn + q]: column mn, rows 2q, 2q+1
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t hi = in[4 * (2 * q + 1) + i], lo = in[4 * (2 * q) + i];
+      out[4 * (2 * i) + q] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);      // low halves  -> column 2i
+      out[4 * (2 * i + 1) + q] = __builtin_amdgcn_perm(hi, lo, 0x07060302u);  // high halves -> column 2i+1
+    }
+}
+
+// Per-thread staging state of the TN form: one 8(k) x 8(mn) block per stage.
+template <int BM, int BN>
+struct TnStager {
+  const bf16* src;  // first element of this thread's column block, row 0
+  int ld, kb, lds_off, k_lo, k_hi;
+  __device__ __forceinline__ TnStager(const bf16* A, int lda, int a_cols, const bf16* B, int ldb, int b_cols, int m0, int n0,
+                                      int k_lo_, int k_hi_)
+      : k_lo(k_lo_), k_hi(k_hi_) {
+    const int tid = threadIdx.x;
+    // BM + BN blocks per stage (8 k-blocks x mn/8 column blocks per operand); spare threads redo the last ones
+    const int blk = tid < BM + BN ? tid : tid - (kBfThreads - (BM + BN));
+    const bool is_a = blk < BM;
+    const int ob = is_a ? blk : blk - BM;
+    kb = ob & 7;  // 16 consecutive lanes = 8 k-blocks x 2 column blocks: conflict-free ds_write_b128
+    const int mb = ob >> 3;
+    ld = is_a ? lda : ldb;
+    const int col = min((is_a ? m0 : n0) + mb * 8, (is_a ? a_cols : b_cols) - 8);
+    src = (is_a ? A : B) + col;
+    lds_off = ((is_a ? 0 : BM) + mb * 8) * kBfPitch + kb * 16;
+  }
+  __device__ __forceinline__ void load(uint4 (&r)[8], int step) const {
+    const int k0 = k_lo + step * kBfBK + kb * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = *reinterpret_cast<const uint4*>(src + (size_t)min(k0 + j, k_hi - 1) * ld);
+  }
+  __device__ __forceinline__ void store(const uint4 (&r)[8], int step, char* base) const {
+    const int k0 = k_lo + step * kBfBK + kb * 8;
+    uint4 m[8], t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = k0 + j < k_hi;
+      m[j] = make_uint4(ok ? r[j].x : 0u, ok ? r[j].y : 0u, ok ? r[j].z : 0u, ok ? r[j].w : 0u);
+    }
+    transpose8x8_b16(m, t);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4*>(base + lds_off + j * kBfPitch) = t[j];
+  }
+};
+
+// acc += A[k_lo : k_hi, m0 : m0+BM)^T * B[k_lo : k_hi, n0 : n0+BN).  a_cols / b_cols: widths of A / B (multiples of 8,
+// >= 8).  Rows >= k_hi contribute zero.  Ends on a barrier.
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_bf16_tn_tile(const bf16* __restrict__ A, int lda, int a_cols,
+                                                  const bf16* __restrict__ B, int ldb, int b_cols, int m0, int n0,
+                                                  int k_lo, int k_hi, char* smem, f32x16 (&acc)[BM / 64][BN / 64]) {
+  using T = BfTile<BM, BN>;
+  const TnStager<BM, BN> st(A, lda, a_cols, B, ldb, b_cols, m0, n0, k_lo, k_hi);
+  const int nsteps = (k_hi - k_lo + kBfBK - 1) / kBfBK;
+  uint4 r0[8], r1[8];
+  st.load(r0, 0);
+  st.store(r0, 0, smem);
+  st.load(r1, 1);
+  st.load(r0, 2);
+  __syncthreads();
+  for (int s = 0; s < nsteps; s += 2) {
+    bf_stage_mfma<BM, BN>(smem, acc);
+    st.store(r1, s + 1, smem + T::kStageBytes);
+    st.load(r1, s + 3);
+    bf_interleave<4 * T::TM * T::TN, 8>();
+    __syncthreads();
+    if (s + 1 < nsteps) {
+      bf_stage_mfma<BM, BN>(smem + T::kStageBytes, acc);
+      st.store(r0, s + 2, smem);
+      st.load(r0, s + 4);
+      bf_interleave<4 * T::TM * T::TN, 8>();
+      __syncthreads();
+    }
+  }
+}
+
+// Row / column of accumulator register i of tile (tm, tn) for the calling lane (C/D layout of the 32x32 MFMAs:
+// col = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)).  Split into a wave-uniform part (SGPRs: the
+// epilogue addresses become scalar base + one 32-bit lane offset instead of a 64-bit VGPR pair per element) and the
+// lane's own part.
+template <int BM, int BN>
+struct BfAccCoord {
+  int urow0, ucol0;  // wave-uniform: first row / column of the wave's sub-tile
+  int lrow, lcol;    // lane part
+  __device__ __forceinline__ BfAccCoord(int m0, int n0) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    urow0 = m0 + (wave >> 1) * (BM / 2);
+    ucol0 = n0 + (wave & 1) * (BN / 2);
+    lrow = 4 * (lane >> 5);
+    lcol = lane & 31;
+  }
+  __device__ __forceinline__ int urow(int tm, int i) const { return urow0 + tm * 32 + (i & 3) + 8 * (i >> 2); }
+  __device__ __forceinline__ int ucol(int tn) const { return ucol0 + tn * 32; }
+  __device__ __forceinline__ int row(int tm, int i) const { return urow(tm, i) + lrow; }
+  __device__ __forceinline__ int col(int tn) const { return ucol(tn) + lcol; }
+  // element (row, col) of a row-major matrix with leading dimension ld, as uniform offset + lane offset
+  __device__ __forceinline__ size_t uoff(int tm, int tn, int i, int ld) const { return (size_t)urow(tm, i) * ld + ucol(tn); }
+  __device__ __forceinline__ unsigned loff(int ld) const { return (unsigned)(lrow * ld + lcol); }
+};
+
+template <int TM, int TN>
+__device__ __forceinline__ void bf_zero_acc(f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+}
+
+}  // namespace vqa

@@ -23,8 +23,6 @@
 
 namespace vqa {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-
 constexpr int kGemmThreads = 256;
 
 template <int BM, int BN, int BK, bool A_KC, bool B_KC>

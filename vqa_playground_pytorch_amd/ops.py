@@ -2,7 +2,9 @@
 
 PyTorch is plumbing here: it owns device memory and the stream; every forward/backward
 below is one call into libvqa_mi355x.so on ``torch.cuda.current_stream()``.  Tensors must be
-fp32 CUDA(=HIP) tensors; anything else raises -- there is no eager/CPU fallback.
+fp32 CUDA(=HIP) tensors -- or, for the region-side tensors of the mixed-precision path (BASELINE
+configs[4]), bf16, which selects the ``*_bf16`` entry points; anything else raises -- there is no
+eager/CPU fallback.
 """
 import ctypes
 
@@ -61,14 +63,26 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _prep(name, t):
+def _prep(name, t, dtypes=(torch.float32,)):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise _lib.VqaLibraryError(
             "%s must be a GPU tensor: the MI355X HIP path has no CPU fallback (got %s)"
             % (name, t.device if isinstance(t, torch.Tensor) else type(t)))
-    if t.dtype != torch.float32:
-        raise _lib.VqaLibraryError("%s must be float32, got %s" % (name, t.dtype))
+    if t.dtype not in dtypes:
+        raise _lib.VqaLibraryError("%s must be %s, got %s" % (name, " or ".join(str(d) for d in dtypes), t.dtype))
     return t.contiguous()
+
+
+_REGION_DTYPES = (torch.float32, torch.bfloat16)   # storage types of the region-side tensors
+BF16_PAD = 64                                       # feature dims of the bf16 path are zero-padded to this multiple
+
+
+def _sfx(dtype):
+    return "_bf16" if dtype == torch.bfloat16 else ""
+
+
+def pad_to(n, multiple=BF16_PAD):
+    return (n + multiple - 1) // multiple * multiple
 
 
 def _seed_args(seed):
@@ -93,7 +107,7 @@ class PairwiseRelationReduce(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, v, q1, q2, alpha, glimpse, mode):
-        v, q1, q2, alpha = _prep("v", v), _prep("q1", q1), _prep("q2", q2), _prep("alpha", alpha)
+        v, q1, q2, alpha = _prep("v", v, _REGION_DTYPES), _prep("q1", q1), _prep("q2", q2), _prep("alpha", alpha)
         B, N, D = v.shape
         if alpha.dim() != 3 or alpha.shape[0] != B or alpha.shape[1] != N or not 0 <= glimpse < alpha.shape[2]:
             raise ValueError("alpha must be [B,N,G] with glimpse < G, got %s" % (tuple(alpha.shape),))
@@ -102,7 +116,8 @@ class PairwiseRelationReduce(torch.autograd.Function):
         G = alpha.shape[2]
         v2 = torch.empty_like(v)
         a_ptr = ctypes.c_void_p(alpha.data_ptr() + 4 * glimpse)
-        _launch("pairwise_relation_reduce_fwd", (B, N, D, int(mode)), _lib.lib().vqa_pairwise_relation_reduce_fwd,
+        name = "pairwise_relation_reduce_fwd" + _sfx(v.dtype)
+        _launch(name, (B, N, D, int(mode)), getattr(_lib.lib(), "vqa_" + name),
                 _p(v), _p(q1), _p(q2), a_ptr, G, _p(v2), B, N, D, int(mode))
         ctx.save_for_backward(v, q1, q2, alpha)
         ctx.glimpse = glimpse
@@ -111,7 +126,7 @@ class PairwiseRelationReduce(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         v, q1, q2, alpha = ctx.saved_tensors
-        g = _prep("grad_v2", g)
+        g = _prep("grad_v2", g.to(v.dtype), _REGION_DTYPES)
         B, N, D = v.shape
         G = alpha.shape[2]
         d_alpha = torch.empty(B, N, device=v.device, dtype=torch.float32)
@@ -119,7 +134,8 @@ class PairwiseRelationReduce(torch.autograd.Function):
         d_q2 = torch.empty_like(q2)
         d_v = torch.empty_like(v) if ctx.needs_input_grad[0] else None
         a_ptr = ctypes.c_void_p(alpha.data_ptr() + 4 * ctx.glimpse)
-        _launch("pairwise_relation_reduce_bwd", (B, N, D, d_v is not None), _lib.lib().vqa_pairwise_relation_reduce_bwd,
+        name = "pairwise_relation_reduce_bwd" + _sfx(v.dtype)
+        _launch(name, (B, N, D, d_v is not None), getattr(_lib.lib(), "vqa_" + name),
                 _p(v), _p(q1), _p(q2), a_ptr, G, _p(g), _p(d_alpha), _p(d_q1), _p(d_q2), _p(d_v), B, N, D)
         d_alpha_full = torch.zeros_like(alpha)
         d_alpha_full[:, :, ctx.glimpse] = d_alpha
@@ -132,15 +148,15 @@ class SoftmaxAttentionPool(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, v):
-        logits, v = _prep("logits", logits), _prep("v", v)
+        logits, v = _prep("logits", logits), _prep("v", v, _REGION_DTYPES)
         B, N, G = logits.shape
         if v.dim() != 3 or v.shape[0] != B or v.shape[1] != N:
             raise ValueError("v must be [B,N,D] matching logits [B,N,G]")
         D = v.shape[2]
         alpha = torch.empty_like(logits)
         pooled = torch.empty(B, G, D, device=v.device, dtype=torch.float32)
-        _launch("softmax_attention_pool_fwd", (B, N, D, G), _lib.lib().vqa_softmax_attention_pool_fwd,
-                _p(logits), _p(v), _p(alpha), _p(pooled), B, N, D, G)
+        name = "softmax_attention_pool_fwd" + _sfx(v.dtype)
+        _launch(name, (B, N, D, G), getattr(_lib.lib(), "vqa_" + name), _p(logits), _p(v), _p(alpha), _p(pooled), B, N, D, G)
         ctx.save_for_backward(alpha, v)
         ctx.set_materialize_grads(False)
         return alpha, pooled
@@ -156,7 +172,8 @@ class SoftmaxAttentionPool(torch.autograd.Function):
         d_alpha = _prep("grad_alpha", d_alpha) if d_alpha is not None else None
         d_logits = torch.empty_like(alpha)
         d_v = torch.empty_like(v) if ctx.needs_input_grad[1] else None
-        _launch("softmax_attention_pool_bwd", (B, N, D, G, d_v is not None), _lib.lib().vqa_softmax_attention_pool_bwd,
+        name = "softmax_attention_pool_bwd" + _sfx(v.dtype)
+        _launch(name, (B, N, D, G, d_v is not None), getattr(_lib.lib(), "vqa_" + name),
                 _p(alpha), _p(v), _p(d_pooled), _p(d_alpha), _p(d_logits), _p(d_v), B, N, D, G)
         return d_logits, d_v
 
@@ -212,6 +229,142 @@ class LowRankBilinearFusion(torch.autograd.Function):
                 _p(x), L, _ptr_array(w1), _p(h2), _p(h1), _p(g), _p(d_x), _ptr_array(d_w1), _ptr_array(d_b1), _p(d_h2),
                 _p(ws), ws_bytes, B, N, L, H, R)
         return (d_x, d_h2, *d_w1, *d_b1)
+
+
+def pack_bf16(src, dst, batch_stride, row_stride, col_stride, zero_fill=True, offset=0):
+    """fp32 [batch, rows, cols] (or [rows, cols]) -> bf16 scattered into ``dst`` (from element ``offset`` on) with the
+    given element strides; with zero_fill that part of ``dst`` is zeroed first (the pads of the padded / transposed
+    weight shadows)."""
+    src = _prep("src", src)
+    if src.dim() == 2:
+        src = src.unsqueeze(0)
+    if src.dim() != 3 or dst.dtype != torch.bfloat16 or not dst.is_cuda or not dst.is_contiguous():
+        raise ValueError("pack_bf16: src must be [batch,rows,cols] fp32, dst a contiguous CUDA bf16 tensor")
+    b, r, c = src.shape
+    _launch("pack_bf16", (b, r, c), _lib.lib().vqa_pack_bf16, _p(src), b, r, c,
+            ctypes.c_void_p(dst.data_ptr() + 2 * int(offset)), int(batch_stride), int(row_stride), int(col_stride),
+            dst.numel() - int(offset), int(bool(zero_fill)))
+    return dst
+
+
+class PackedWeightBf16(torch.autograd.Function):
+    """w fp32 [rows, cols] -> bf16 [rows_p, cols_p] zero-padded shadow (the operand layout of the bf16 GEMMs);
+    backward crops the gradient back to the master shape in fp32."""
+
+    @staticmethod
+    def forward(ctx, w, rows_p, cols_p):
+        w = _prep("w", w)
+        rows, cols = w.shape
+        if rows_p < rows or cols_p < cols:
+            raise ValueError("PackedWeightBf16: padded shape (%d,%d) smaller than %s" % (rows_p, cols_p, tuple(w.shape)))
+        ctx.shape = (rows, cols)
+        return pack_bf16(w, torch.empty(rows_p, cols_p, device=w.device, dtype=torch.bfloat16), 0, cols_p, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        rows, cols = ctx.shape
+        return g[:rows, :cols].float(), None, None
+
+
+def gemm_bf16_nt(a, b, bias=None, act=None, out=None):
+    """act(a[M,K] @ b[N,K]^T + bias) -> bf16 [M,N] on the bf16 MFMA tile engine (K % 64 == 0)."""
+    a, b = _prep("a", a, (torch.bfloat16,)), _prep("b", b, (torch.bfloat16,))
+    bias = _prep("bias", bias) if bias is not None else None
+    M, K = a.shape
+    N = b.shape[0]
+    if b.shape != (N, K) or (bias is not None and bias.shape != (N,)):
+        raise ValueError("gemm_bf16_nt: b must be [N,K] = [%d,%d], bias [N]" % (N, K))
+    code = {None: 0, "": 0, "relu": 1}.get(act)
+    if code is None:
+        raise ValueError("gemm_bf16_nt: act must be None or 'relu', got %r" % (act,))
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.bfloat16)
+    _launch("gemm_bf16_nt", (M, N, K, code), _lib.lib().vqa_gemm_bf16_nt, _p(a), K, _p(b), K, _p(bias), _p(out), N,
+            M, N, K, code)
+    return out
+
+
+def gemm_bf16_tn(a, b):
+    """a[K,N1]^T @ b[K,N2] -> fp32 [N1,N2] (weight-gradient contraction over the batch rows; fixed-order split-K)."""
+    a, b = _prep("a", a, (torch.bfloat16,)), _prep("b", b, (torch.bfloat16,))
+    K, N1 = a.shape
+    N2 = b.shape[1]
+    if b.shape[0] != K:
+        raise ValueError("gemm_bf16_tn: a [K,N1] and b [K,N2] must share K")
+    L_ = _lib.lib()
+    ws_bytes = L_.vqa_gemm_bf16_tn_workspace_bytes(K, N1, N2)
+    ws = torch.empty((ws_bytes + 3) // 4, device=a.device, dtype=torch.float32) if ws_bytes else None
+    c = torch.empty(N1, N2, device=a.device, dtype=torch.float32)
+    _launch("gemm_bf16_tn", (K, N1, N2), L_.vqa_gemm_bf16_tn, _p(a), N1, _p(b), N2, _p(c), _p(ws), ws_bytes, K, N1, N2)
+    return c
+
+
+class LowRankBilinearFusionBf16(torch.autograd.Function):
+    """K4 on the bf16 MFMA engine.  x bf16 [B,(N,)Lp] with Lp >= L zero-padded to a multiple of 64; h2 fp32 [B,R,H];
+    master weights / biases fp32 ([H,L] / [H] per rank).  Returns bf16 [B,(N,)Hp], Hp = H padded to 256 (pad = 0)."""
+
+    @staticmethod
+    def forward(ctx, x, h2, *params):
+        R = len(params) // 2
+        w1 = [_prep("w1[%d]" % r, params[r]) for r in range(R)]
+        b1 = [_prep("b1[%d]" % r, params[R + r]) for r in range(R)]
+        x, h2 = _prep("x", x, (torch.bfloat16,)), _prep("h2", h2)
+        lead = x.shape[:-1]
+        B, Lp = x.shape[0], x.shape[-1]
+        N = 1
+        for s in lead[1:]:
+            N *= s
+        H, L = w1[0].shape
+        Hp = pad_to(H, 256)
+        if Lp % BF16_PAD or Lp < L:
+            raise ValueError("bf16 fusion: x's last dim (%d) must be L=%d zero-padded to a multiple of %d" % (Lp, L, BF16_PAD))
+        if h2.shape != (B, R, H):
+            raise ValueError("h2 must be [B,R,H] = %s, got %s" % ((B, R, H), tuple(h2.shape)))
+        dev = x.device
+        w1p = torch.empty(R, Hp, Lp, device=dev, dtype=torch.bfloat16)
+        b1p = torch.zeros(R, Hp, device=dev, dtype=torch.float32)
+        for r in range(R):
+            if w1[r].shape != (H, L) or b1[r].shape != (H,):
+                raise ValueError("rank %d: weight %s / bias %s do not match (H=%d, L=%d)"
+                                 % (r, tuple(w1[r].shape), tuple(b1[r].shape), H, L))
+            pack_bf16(w1[r], w1p, 0, Lp, 1, zero_fill=(r == 0), offset=r * Hp * Lp)
+            b1p[r, :H] = b1[r]
+        h2p = torch.nn.functional.pad(h2, (0, Hp - H)) if Hp != H else h2
+        need_bwd = any(ctx.needs_input_grad)
+        out = torch.empty(*lead, Hp, device=dev, dtype=torch.bfloat16)
+        h1 = torch.empty(B * N, R, Hp, device=dev, dtype=torch.bfloat16) if need_bwd else None
+        _launch("lowrank_bilinear_fusion_fwd_bf16", (B, N, Lp, Hp, R, need_bwd),
+                _lib.lib().vqa_lowrank_bilinear_fusion_fwd_bf16, _p(x), _p(w1p), _p(b1p), _p(h2p), _p(out), _p(h1),
+                B, N, Lp, Hp, R)
+        if need_bwd:
+            ctx.save_for_backward(x, h2p, h1, *w1)
+        ctx.dims = (B, N, L, Lp, H, Hp, R)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, L, Lp, H, Hp, R = ctx.dims
+        x, h2p, h1 = ctx.saved_tensors[:3]
+        w1 = ctx.saved_tensors[3:]
+        g = _prep("grad_out", g.to(torch.bfloat16), (torch.bfloat16,))
+        dev = x.device
+        w1t = None
+        d_x = None
+        if ctx.needs_input_grad[0]:
+            w1t = torch.empty(Lp, R * Hp, device=dev, dtype=torch.bfloat16)   # w1t[l, r*Hp+h] = w1[r][h,l]
+            for r in range(R):   # rank r fills columns r*Hp .. r*Hp+H of every row; the first call zeroes the pads
+                pack_bf16(w1[r], w1t, 0, 1, R * Hp, zero_fill=(r == 0), offset=r * Hp)
+            d_x = torch.empty_like(x)
+        d_w1 = torch.empty(R, Hp, Lp, device=dev, dtype=torch.float32)
+        d_b1 = torch.empty(R, Hp, device=dev, dtype=torch.float32)
+        d_h2 = torch.empty(B, R, Hp, device=dev, dtype=torch.float32)
+        L_ = _lib.lib()
+        ws_bytes = L_.vqa_lowrank_bilinear_fusion_bwd_bf16_workspace_bytes(B, N, Lp, Hp, R)
+        ws = torch.empty((ws_bytes + 3) // 4, device=dev, dtype=torch.float32)
+        _launch("lowrank_bilinear_fusion_bwd_bf16", (B, N, Lp, Hp, R, d_x is not None),
+                L_.vqa_lowrank_bilinear_fusion_bwd_bf16, _p(x), _p(w1t), _p(h2p), _p(h1), _p(g), _p(d_x), _p(d_w1),
+                _p(d_b1), _p(d_h2), _p(ws), ws_bytes, B, N, Lp, Hp, R)
+        return (d_x, d_h2[:, :, :H], *[d_w1[r, :H, :L] for r in range(R)], *[d_b1[r, :H] for r in range(R)])
 
 
 class ObjectDifferenceAttention(torch.autograd.Function):
@@ -379,6 +532,8 @@ def softmax_attention_pool(logits, v):
 
 
 def lowrank_bilinear_fusion(x, h2, weights, biases):
+    if x.dtype == torch.bfloat16:
+        return LowRankBilinearFusionBf16.apply(x, h2, *weights, *biases)
     return LowRankBilinearFusion.apply(x, h2, *weights, *biases)
 
 
