@@ -28,13 +28,25 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TF = 157.3   # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
+MFMA_BF16_PEAK_TF = 2500.0 # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16), no sparsity
 
 BATCH, REGIONS, FEAT, QDIM, ANSWERS = 512, 36, 2048, 2400, 2000
 LOW, HID, GLIMPSES, RANK = 310, 510, 4, 2
 
 
-def kernel_models(B, N=REGIONS, D=FEAT, G=GLIMPSES, L=LOW, H=HID, R=RANK):
-    """Algorithmic bytes / FLOPs per launch (SURVEY.md 8d per-sample figures x samples per launch)."""
+def kernel_models(B, N=REGIONS, D=FEAT, G=GLIMPSES, L=LOW, H=HID, R=RANK, bf16=False):
+    """Algorithmic bytes / FLOPs per launch (SURVEY.md 8d per-sample figures x samples per launch).
+    bf16=True: the region tensors (v, v2, their gradients) are 2 bytes per element, everything else stays fp32."""
+    if bf16:
+        fv, f = 2, 4
+        return {
+            "lowrank_bilinear_fusion_fwd_bf16": ("mfma", B * (2 * R * N * L * H + 2 * R * N * H)),
+            "lowrank_bilinear_fusion_bwd_bf16": ("mfma", B * (2 * 2 * R * N * L * H)),
+            "pairwise_relation_reduce_fwd_bf16": ("hbm", B * (2 * N * D * fv + (2 * D + N) * f)),
+            "pairwise_relation_reduce_bwd_bf16": ("hbm", B * (2 * N * D * fv + (4 * D + 2 * N) * f)),
+            "softmax_attention_pool_fwd_bf16": ("hbm", B * (N * D * fv + (2 * N * G + G * D) * f)),
+            "softmax_attention_pool_bwd_bf16": ("hbm", B * (N * D * fv + (G * D + 3 * N * G) * f)),
+        }
     f = 4
     return {
         "object_difference_attention_fwd": ("valu", B * 2 * G * N * N * L),                 # 2 flop per (mask element, glimpse)
@@ -74,20 +86,22 @@ def pmc_traffic(name, B):
     return int(total)
 
 
-def roofline_entry(name, shape, launches, mean_ms, B):
-    bound, work = kernel_models(B)[name]
-    if name == "softmax_attention_pool_bwd" and shape[-1]:
-        work += B * REGIONS * FEAT * 4
-    if name == "lowrank_bilinear_fusion_bwd" and not shape[-1]:
+def roofline_entry(name, shape, launches, mean_ms, B, regions=REGIONS, bf16=False):
+    bound, work = kernel_models(B, N=regions, bf16=bf16)[name]
+    if name.startswith("softmax_attention_pool_bwd") and shape[-1]:
+        work += B * regions * FEAT * (2 if bf16 else 4)
+    if name.startswith("lowrank_bilinear_fusion_bwd") and not shape[-1]:
         work //= 2
     sec = mean_ms * 1e-3
     if bound == "hbm":
         achieved, peak, unit = work / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+    elif bf16:
+        achieved, peak, unit = work / sec / 1e12, MFMA_BF16_PEAK_TF, "TFLOP/s"
     else:  # "mfma" and "valu" share the fp32 peak on gfx950 (157.3 TFLOP/s for both pipes)
         achieved, peak, unit = work / sec / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
     return {"kernel": name, "shape": list(shape), "launches": launches, "mean_ms": round(mean_ms, 5), "bound": bound,
             "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
-            "traffic": pmc_traffic(name, B)}
+            "traffic": pmc_traffic(name, B) if regions == REGIONS and not bf16 else None}
 
 
 def cpu_baseline_worker(batch, threads, budget_s):
@@ -147,6 +161,10 @@ def main():
     ap.add_argument("--relation-mode", type=int, default=1, help="K1: 0 = pairwise, 1 = factored")
     ap.add_argument("--model", default="cor2", choices=["cor2", "oda"], help="cor2 = the headline config; oda = "
                     "BASELINE configs[2] (object-difference attention head, 3000 answers), reported the same way")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="f32 = the reference's arithmetic (headline); "
+                    "bf16 = BASELINE configs[4]: bf16 storage + bf16 MFMA on the region side, fp32 accumulate, fp32 "
+                    "master weights (use with --regions 100 --batch 128)")
+    ap.add_argument("--regions", type=int, default=REGIONS, help="regions per image (36; configs[4]: 100 dense regions)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying "
                     "the captured hipGraphs of the step")
     args = ap.parse_args()
@@ -176,14 +194,20 @@ def main():
 
     torch.manual_seed(1234)
     answers = ANSWERS if args.model == "cor2" else 3000
+    bf16 = args.dtype == "bf16"
+    if bf16 and args.model != "cor2":
+        raise SystemExit("--dtype bf16 is the CoR2 configuration (BASELINE configs[4])")
     if args.model == "cor2":
-        model = CoR2Model(["PAD", "UNK"], answers, relation_mode=args.relation_mode).to(dev).train()
+        model = CoR2Model(["PAD", "UNK"], answers, relation_mode=args.relation_mode,
+                          compute_dtype=torch.bfloat16 if bf16 else None).to(dev).train()
     else:
         model = ODAModel(["PAD", "UNK"], answers).to(dev).train()
     trainer = DataParallelTrainer(model, lr=1e-4, clip=0.25, graph=not args.no_graph)
     torch.manual_seed(100 + rank)  # per-rank dropout streams and data shards differ
     B = args.batch
-    v = torch.randn(B, REGIONS, FEAT, device=dev)
+    v = torch.randn(B, args.regions, FEAT, device=dev)
+    if bf16:
+        v = v.to(torch.bfloat16)   # the feature store hands over bf16 regions: half the bytes of the dominant stream
     q = torch.randn(B, QDIM, device=dev)
     a = torch.softmax(2.0 * torch.randn(B, answers, device=dev), dim=1)
     sample = {"v": v, "q_idxes": q}
@@ -212,7 +236,7 @@ def main():
         ops.set_kernel_timer(timer)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, _ = trainer.step(sample, a)
+        loss, gnorm = trainer.step(sample, a)
     barrier()
     elapsed = time.perf_counter() - t0
     ops.set_kernel_timer(None)
@@ -233,17 +257,24 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    assert torch.isfinite(loss).item(), "non-finite loss"
+    final_loss, final_gnorm = float(loss.item()), float(gnorm.item())
+    # sanity of the timed steps themselves (a replayed graph that computed garbage would still be fast): the loss of
+    # the last timed step is finite and positive (a KL divergence) and the gradient norm is of a trainable size
+    assert final_loss == final_loss and 0.0 < final_loss < 1e6, "implausible loss %r in the timed region" % final_loss
+    assert final_gnorm == final_gnorm and 0.0 < final_gnorm < 1e4, "implausible gradient norm %r" % final_gnorm
 
     if rank == 0:
         summary = timer.summary()
-        entries = [roofline_entry(name, shape, n, ms, B) for (name, shape), (n, ms) in summary.items()
-                   if name in kernel_models(B) and shape[0] == B and (len(shape) < 2 or shape[1] == REGIONS)]
+        models = kernel_models(B, N=args.regions, bf16=bf16)
+        entries = [roofline_entry(name, shape, n, ms, B, args.regions, bf16) for (name, shape), (n, ms) in summary.items()
+                   if name in models and shape[0] == B and (len(shape) < 2 or shape[1] == args.regions)]
         entries.sort(key=lambda e: -e["mean_ms"] * e["launches"])
-        head = "lowrank_bilinear_fusion_fwd" if args.model == "cor2" else "object_difference_attention_fwd"
+        head = ("lowrank_bilinear_fusion_fwd" + ("_bf16" if bf16 else "")) if args.model == "cor2" \
+            else "object_difference_attention_fwd"
         dominant = next((e for e in entries if e["kernel"] == head), entries[0])
         result = {
-            "metric": "VQA samples/sec (fwd+bwd), %s batch 512, 36x2048 regions" % ("CoR2" if args.model == "cor2" else "ODA"),
+            "metric": "VQA samples/sec (fwd+bwd), %s batch %d, %dx2048 regions"
+                      % ("CoR2" if args.model == "cor2" else "ODA", B, args.regions),
             "value": round(world * B * args.steps / elapsed, 1),
             "unit": "samples/s",
             "n_gpus": world,
@@ -253,10 +284,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": ("CoR2 fwd+bwd fp32, batch %d per GPU, 36x2048 regions + 2400-d question, 2-step "
-                                    "reasoning chain, 2000 answers (BASELINE configs[1]; configs[3] at 8 GPUs)" % B)
+            "config": {"workload": ("CoR2 fwd+bwd bf16 compute (bf16 region tensors + bf16 MFMA, fp32 accumulate, fp32 master "
+                                    "weights), batch %d per GPU, %dx2048 regions + 2400-d question, 2-step reasoning chain, "
+                                    "2000 answers (BASELINE configs[4])" % (B, args.regions)) if bf16 else
+                       ("CoR2 fwd+bwd fp32, batch %d per GPU, %dx2048 regions + 2400-d question, 2-step "
+                        "reasoning chain, 2000 answers (BASELINE configs[1]; configs[3] at 8 GPUs)" % (B, args.regions))
                        if args.model == "cor2" else
                        ("ODA fwd+bwd fp32, batch %d per GPU, 36x2048 regions + 2400-d question, 36x36 object-difference "
                         "attention, 3000 answers (BASELINE configs[2])" % B),
@@ -264,11 +298,12 @@ def main():
                        "+ clip 0.25 + Adam (dropout active)", "parallelism": "dp%d" % world,
                        "launch": "hipGraph replay (2 graphs + eager all-reduce)" if graphed else "eager",
                        "relation_mode": "factored" if args.relation_mode == 1 else "pairwise"},
+            "final_loss": round(final_loss, 3), "final_grad_norm": round(final_gnorm, 3),
             "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
                                                   "mean_ms", "launches")},
             "roofline_all": entries,
         }
-        if world == 1 and not args.no_cpu_baseline and args.model == "cor2":
+        if world == 1 and not args.no_cpu_baseline and args.model == "cor2" and not bf16 and args.regions == REGIONS:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result))
     if world > 1:

@@ -241,6 +241,20 @@ int vqa_linear_dropout_mask(float* mask, float p_drop, uint64_t seed, const uint
                             vqa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * KLD-sum loss on soft targets, with its gradient.
+ * Replaces MyLoss (train.py:536-544): KLDivLoss(size_average=False)(F.log_softmax(logits), target).
+ *
+ *   loss[0]       = sum_{b,c} target[b,c] * (log target[b,c] - log_softmax(logits)[b,c])     (0 log 0 = 0)
+ *   d_logits[b,c] = softmax(logits)[b,c] * sum_c target[b,c] - target[b,c]        (dloss/dlogits; may be NULL)
+ *
+ * logits, target, d_logits [B,C]; loss [1]; workspace: vqa_kld_sum_loss_workspace_bytes(B) bytes.
+ * Row losses are added in a fixed order (bitwise reproducible).  Limit: C <= 4096.
+ * ------------------------------------------------------------------------------------------- */
+size_t vqa_kld_sum_loss_workspace_bytes(int B);
+int vqa_kld_sum_loss(const float* logits, const float* target, float* loss, float* d_logits,
+                     void* workspace, size_t workspace_bytes, int B, int C, vqa_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Train-step tail over flat fp32 buffers.
  * Replaces nn.utils.clip_grad_norm_(model.parameters(), 0.25) + optimizer.step() of torch.optim.Adam
  * (train.py:81-86, :286-292): two HBM-bound launches instead of ~70 per-tensor walks, no host round trip.

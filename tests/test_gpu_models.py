@@ -225,18 +225,18 @@ def test_graph_replay_equals_eager_steps():
     for mode in (False, True):
         model = build("cor2", 300)
         tr = DataParallelTrainer(model, lr=2e-5, clip=0.25, graph=mode)
-        v, q, a = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(6, answers=300, seed=21))
+        v, q, a = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(64, answers=300, seed=21))
         losses = []
         for step in range(7):
             loss, norm = tr.step({"v": v, "q_idxes": q}, a)
             losses.append((loss.item(), norm.item()))
         if mode:
             assert tr._graph is not None, "step was not captured"
-            v2, q2, a2 = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(6, answers=300, seed=22))
+            v2, q2, a2 = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(64, answers=300, seed=22))
             loss, _ = tr.step({"v": v2, "q_idxes": q2}, a2)      # new tensors: copied into the captured placeholders
             losses.append((loss.item(), 0.0))
         else:
-            v2, q2, a2 = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(6, answers=300, seed=22))
+            v2, q2, a2 = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(64, answers=300, seed=22))
             loss, _ = tr.step({"v": v2, "q_idxes": q2}, a2)
             losses.append((loss.item(), 0.0))
         out[mode] = (losses, [p.detach().clone() for p in model.parameters()], tr.lr)
@@ -247,6 +247,31 @@ def test_graph_replay_equals_eager_steps():
     assert out[False][2] == out[True][2]
     for p0, p1 in zip(out[False][1], out[True][1]):
         assert (p0 - p1).abs().max().item() <= 2e-3 * max(p0.abs().max().item(), 1e-3)
+
+
+def test_graph_replays_queued_without_host_sync():
+    """bench.py's flow: replays queued back to back with no host read in between, at the headline batch.  The loss and
+    gradient norm read once at the end must equal those of the same steps launched kernel by kernel.  (Regression: a
+    memset node -- hipMemsetAsync in K1/K3 backward, and inside torch's multi-block sum of the loss -- replays wrongly
+    on ROCm 7.2; the step now contains none.)"""
+    from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
+    got = {}
+    for mode in (False, True):
+        model = build("cor2", 2000)
+        tr = DataParallelTrainer(model, lr=2e-5, clip=0.25, graph=mode)
+        gen = torch.Generator(device="cpu").manual_seed(11)
+        v = torch.randn(512, 36, 2048, generator=gen).to(dev())
+        q = torch.randn(512, 2400, generator=gen).to(dev())
+        a = torch.softmax(2.0 * torch.randn(512, 2000, generator=gen), dim=1).to(dev())
+        for _ in range(12):
+            loss, norm = tr.step({"v": v, "q_idxes": q}, a)
+        torch.cuda.synchronize()
+        got[mode] = (loss.item(), norm.item())
+        if mode:
+            assert tr._graph is not None, "step was not captured"
+    (l0, n0), (l1, n1) = got[False], got[True]
+    assert 100.0 < l0 < 2000.0, l0
+    assert abs(l0 - l1) <= 1e-4 * abs(l0) and abs(n0 - n1) <= 1e-3 * abs(n0), (got[False], got[True])
 
 
 def test_oda_graph_replay_draws_fresh_masks():

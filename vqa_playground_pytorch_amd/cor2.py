@@ -12,10 +12,18 @@ from .layers import MutanFusion, MyATT, MyConv1d, MyLinear, QuestionVectorInput
 
 
 class Model(nn.Module):
-    def __init__(self, vocab_words=None, num_ans=None, seq2vec=None, relation_mode=1):
+    def __init__(self, vocab_words=None, num_ans=None, seq2vec=None, relation_mode=1, compute_dtype=None):
         super().__init__()
         self.vocab_words = vocab_words
         self.num_classes = num_ans
+        # None / torch.float32: the reference's fp32 everywhere.  torch.bfloat16 (BASELINE configs[4]): the region-side
+        # tensors (v, v2, compressed regions, fusion outputs) are stored in bf16 and contracted on the bf16 MFMA engine
+        # with fp32 accumulation; parameters stay fp32 masters, the question side and everything [B,*]-sized stays fp32.
+        if compute_dtype in ("bf16", "bfloat16"):
+            compute_dtype = torch.bfloat16
+        if compute_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("compute_dtype must be None, torch.float32 or torch.bfloat16, got %r" % (compute_dtype,))
+        self.compute_dtype = compute_dtype or torch.float32
         # 0 = pairwise (every (i,j) term summed from the LDS tile), 1 = factored (same value, one pass)
         self.relation_mode = relation_mode
 
@@ -55,6 +63,8 @@ class Model(nn.Module):
         v = sample["v"]
         b = v.size(0)
         v_feature = v.contiguous().view(b, -1, 2048)
+        if v_feature.dtype != self.compute_dtype:
+            v_feature = v_feature.to(self.compute_dtype)
         q_feature = self.seq2vec(sample["q_idxes"] if "q_idxes" in sample else sample["q"])
 
         q_feature_low = self.compress_q(q_feature)
@@ -70,7 +80,7 @@ class Model(nn.Module):
         # side output read by visu.py:198-207; detached so it does not pin the autograd graph of the step
         # (feature = the reference's v2_feature[:, [0, 1], :])
         self.alpha_dict = {"alpha1": tuple(t.detach() for t in alpha1), "alpha2": tuple(t.detach() for t in alpha2),
-                           "feature": v2_feature[:, 0:2, :].detach()}
+                           "feature": v2_feature[:, 0:2, :].detach().float()}
 
         v_f = torch.cat([v1_att, v2_att], dim=1)
         q_final = self.linear_q(q_feature)

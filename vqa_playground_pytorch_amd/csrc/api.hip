@@ -6,6 +6,32 @@ char* error_buffer() {
   static thread_local char buf[512] = {0};
   return buf;
 }
+
+// Zero-fill as a plain kernel.  hipMemsetAsync must not be used in this library: captured into a hipGraph (memset
+// node) it is correct on the first replay only -- from the second replay on the K1 / K3 backward accumulators came
+// back wrong (ROCm 7.2, measured with tools/graph_memset_check.py), which silently corrupted every graph-replayed step.
+__global__ __launch_bounds__(256) void zero_fill_kernel(unsigned char* __restrict__ p, size_t head, size_t words,
+                                                        size_t tail) {
+  uint32_t* body = reinterpret_cast<uint32_t*>(p + head);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) body[i] = 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (size_t i = 0; i < head; ++i) p[i] = 0;
+    for (size_t i = 0; i < tail; ++i) p[head + words * 4 + i] = 0;
+  }
+}
+
+int zero_async(void* ptr, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return VQA_OK;
+  unsigned char* p = static_cast<unsigned char*>(ptr);
+  size_t head = (4 - (reinterpret_cast<uintptr_t>(p) & 3)) & 3;
+  if (head > bytes) head = bytes;
+  const size_t words = (bytes - head) / 4, tail = bytes - head - words * 4;
+  size_t blocks = (words + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, head, words, tail);
+  return check_launch("zero_fill");
+}
 }  // namespace vqa
 
 extern "C" int vqa_version(void) { return VQA_ABI_VERSION; }

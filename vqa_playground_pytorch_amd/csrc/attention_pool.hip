@@ -198,8 +198,8 @@ static int launch_bwd(const float* alpha, const T* v, const float* d_pooled, con
   constexpr int NT = 256;
   // d_logits doubles as the zeroed accumulator of the first kernel (same [B,N,G] shape; kernel B reads each of its
   // elements before overwriting it)
-  hipError_t e = hipMemsetAsync(d_logits, 0, (size_t)B * N * G * sizeof(float), s);
-  if (e != hipSuccess) return fail(VQA_E_LAUNCH, "softmax_attention_pool_bwd: memset: %s", hipGetErrorString(e));
+  int rc = zero_async(d_logits, (size_t)B * N * G * sizeof(float), s);
+  if (rc != VQA_OK) return rc;
   const size_t lds = 2 * (size_t)N * G * sizeof(float);
   hipLaunchKernelGGL((attention_pool_bwd_stream_kernel<T, NT, G>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), lds, s, alpha, v,
                      d_pooled, d_logits, d_v, N, D);

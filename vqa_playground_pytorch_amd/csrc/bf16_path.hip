@@ -346,8 +346,8 @@ extern "C" int vqa_pack_bf16(const float* src, int batch, int rows, int cols, vq
               last + 1);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (zero_fill) {
-    hipError_t e = hipMemsetAsync(dst, 0, dst_elems * sizeof(vqa_bf16_t), s);
-    if (e != hipSuccess) return fail(VQA_E_LAUNCH, "pack_bf16: memset: %s", hipGetErrorString(e));
+    int rc = zero_async(dst, dst_elems * sizeof(vqa_bf16_t), s);
+    if (rc != VQA_OK) return rc;
   }
   const size_t count = (size_t)batch * rows * cols;
   hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, src,

@@ -28,6 +28,8 @@ inline int check_launch(const char* what) {
   return VQA_OK;
 }
 
+int zero_async(void* ptr, size_t bytes, hipStream_t s);  // api.hip: zero-fill kernel (never hipMemsetAsync: see there)
+
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 // Raise a kernel's dynamic-LDS cap (default 64 KiB) once per device and size; one static per call site.

@@ -275,8 +275,8 @@ static int pairwise_bwd_impl(const char* who, const T* v, const float* q1, const
   VQA_REQUIRE(N <= 4096, VQA_E_UNSUPPORTED, "%s: N=%d exceeds 4096", who, N);
   VQA_REQUIRE(B <= 65535, VQA_E_UNSUPPORTED, "%s: B=%d exceeds 65535", who, B);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(d_alpha, 0, (size_t)B * N * sizeof(float), s);
-  if (e != hipSuccess) return fail(VQA_E_LAUNCH, "%s: memset: %s", who, hipGetErrorString(e));
+  int rc = zero_async(d_alpha, (size_t)B * N * sizeof(float), s);
+  if (rc != VQA_OK) return rc;
   constexpr int NT = 256;
   hipLaunchKernelGGL((pairwise_bwd_stream_kernel<T, NT>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), (size_t)N * 8, s, v, q1, q2,
                      alpha, alpha_stride, g_v2, d_alpha, d_q1, d_q2, d_v, N, D);

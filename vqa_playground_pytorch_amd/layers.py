@@ -111,12 +111,32 @@ class MyConv1d(nn.Module):
         self.conv = nn.Conv1d(in_channels, out_channels, kernel_size, stride, padding=padding, dilation=1, groups=1,
                               bias=True)
 
+    # bf16 path: "engine" = the hand-written bf16 MFMA GEMMs (ops.LinearBf16), "library" = hipBLASLt through F.linear
+    bf16_gemm = os.environ.get("VQA_BF16_GEMM", "engine")
+
+    def _linear_bf16(self, x, af):
+        """Mixed-precision form (x bf16, last dim possibly zero-padded past in_channels): bf16 operands, fp32
+        accumulate, fp32 master weights.  Wide layers return the output padded to a multiple of 64 (pad = 0) so the
+        next bf16 GEMM needs no tail; narrow ones (the G attention logits) come back as fp32."""
+        w = self.conv.weight.squeeze(-1)
+        if self.out_channels >= 32 and self.bf16_gemm == "engine":
+            return ops.linear_bf16(x, w, self.conv.bias, af)
+        n_p = ops.pad_to(self.out_channels) if self.out_channels >= 32 else self.out_channels
+        wp = ops.PackedWeightBf16.apply(w, n_p, x.size(-1))
+        bp = F.pad(self.conv.bias, (0, n_p - self.out_channels)).to(torch.bfloat16)
+        y = F.linear(x, wp, bp)
+        if self.out_channels < 32:
+            return _activation(y.float(), af, self.dim)
+        return _activation(y, af, self.dim)
+
     def pre_activation(self, x):
         if x.dim() != 3:
             raise ValueError("[error] putils.Conv1d(%s, %s, %s, %s): input_dim (%s) should equal to 3"
                              % (self.in_channels, self.out_channels, self.kernel_size, self.stride, x.dim()))
         if self.p:
             x = F.dropout(x, p=self.p, training=self.training)
+        if x.dtype == torch.bfloat16:
+            return self._linear_bf16(x, None)
         return F.linear(x, self.conv.weight.squeeze(-1), self.conv.bias)
 
     # K5 (fused dropout+GEMM+bias+relu on the hand-written fp32 MFMA engine) vs the library GEMM: set per process
@@ -124,6 +144,13 @@ class MyConv1d(nn.Module):
     fused = os.environ.get("VQA_FUSED_LINEAR", "0") == "1"
 
     def forward(self, x):
+        if x.dtype == torch.bfloat16 and self.af in (None, "relu"):
+            if x.dim() != 3:
+                raise ValueError("[error] putils.Conv1d(%s, %s, %s, %s): input_dim (%s) should equal to 3"
+                                 % (self.in_channels, self.out_channels, self.kernel_size, self.stride, x.dim()))
+            if self.p:
+                x = F.dropout(x, p=self.p, training=self.training)
+            return self._linear_bf16(x, self.af)
         if self.fused and self.af in (None, "relu") and x.dim() == 3 and x.is_cuda and self.out_channels >= 32 \
                 and x.size(0) * x.size(1) >= 1024:
             # large region-side projection (compress_v / compress_v2): dropout + GEMM + bias + relu in ONE kernel
@@ -149,7 +176,9 @@ class MutanFusion(nn.Module):
         self.list_linear2 = nn.ModuleList([Linear(input_dim2, hidden_dim) for _ in range(R)])
 
     def forward(self, inputs1, inputs2):
-        if inputs1.size(-1) != self.input_dim1:
+        # (bf16 region tensors carry the feature dim zero-padded to a multiple of 64: see ops.pad_to)
+        want = ops.pad_to(self.input_dim1) if inputs1.dtype == torch.bfloat16 else self.input_dim1
+        if inputs1.size(-1) != want:
             raise ValueError(
                 "[error] putils.Linear(%s, %s): last dimension of input(%s) should equal to in_features(%s)"
                 % (self.input_dim1, self.hidden_dim, inputs1.size(-1), self.input_dim1))

@@ -299,6 +299,57 @@ def gemm_bf16_tn(a, b):
     return c
 
 
+class LinearBf16(torch.autograd.Function):
+    """y = act(x W^T + b) on the bf16 MFMA engine: x bf16 [..., Kp] (Kp >= in_features, zero-padded), master W fp32
+    [out, in] / b fp32 [out]; returns bf16 [..., Np] with Np = out padded to 64 (pad columns exactly zero).
+    The nn.Linear / 1x1 nn.Conv1d contraction of MyLinear / MyConv1d (config/CoR2.py:56-122) in mixed precision."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, act):
+        x, w = _prep("x", x, (torch.bfloat16,)), _prep("w", w)
+        Kp = x.shape[-1]
+        out_f, in_f = w.shape
+        if Kp % BF16_PAD or Kp < in_f:
+            raise ValueError("linear_bf16: x's last dim (%d) must be in_features=%d zero-padded to a multiple of %d"
+                             % (Kp, in_f, BF16_PAD))
+        Np = pad_to(out_f)
+        dev = x.device
+        wp = pack_bf16(w, torch.empty(Np, Kp, device=dev, dtype=torch.bfloat16), 0, Kp, 1)
+        bp = None
+        if bias is not None:
+            bp = torch.zeros(Np, device=dev, dtype=torch.float32)
+            bp[:out_f] = _prep("bias", bias)
+        x2 = x.reshape(-1, Kp)
+        y = gemm_bf16_nt(x2, wp, bp, act)
+        ctx.save_for_backward(x2, w, y)
+        ctx.cfg = (act, bias is not None, Np)
+        return y.view(*x.shape[:-1], Np)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w, y = ctx.saved_tensors
+        act, has_bias, Np = ctx.cfg
+        out_f, in_f = w.shape
+        Kp = x2.shape[1]
+        gz = gy.reshape(-1, Np).to(torch.bfloat16)
+        if act == "relu":
+            gz = gz * (y > 0)
+        gz = gz.contiguous()
+        d_x = None
+        if ctx.needs_input_grad[0]:
+            wpt = pack_bf16(w, torch.empty(Kp, Np, device=x2.device, dtype=torch.bfloat16), 0, 1, Np)   # [Kp, Np] = W^T
+            d_x = gemm_bf16_nt(gz, wpt).view(*gy.shape[:-1], Kp)
+        d_w = gemm_bf16_tn(gz, x2)[:out_f, :in_f]
+        d_b = gz.float().sum(0)[:out_f] if has_bias else None
+        return d_x, d_w, d_b, None
+
+
+def linear_bf16(x, w, bias=None, act=None):
+    if act not in (None, "", "relu"):
+        raise ValueError("linear_bf16: act must be None or 'relu', got %r" % (act,))
+    return LinearBf16.apply(x, w, bias, act or None)
+
+
 class LowRankBilinearFusionBf16(torch.autograd.Function):
     """K4 on the bf16 MFMA engine.  x bf16 [B,(N,)Lp] with Lp >= L zero-padded to a multiple of 64; h2 fp32 [B,R,H];
     master weights / biases fp32 ([H,L] / [H] per rank).  Returns bf16 [B,(N,)Hp], Hp = H padded to 256 (pad = 0)."""
@@ -449,6 +500,37 @@ def linear_act(x, w, bias=None, act=None, p_drop=0.0, seed=0):
     if code is None:
         raise ValueError("linear_act: act must be None or 'relu', got %r" % (act,))
     return LinearAct.apply(x, w, bias, code, p_drop, seed)
+
+
+class KldSumLoss(torch.autograd.Function):
+    """KLDivLoss(size_average=False)(log_softmax(logits), target) (train.py:536-544) with its gradient from the same
+    pass over the logits; the B row losses are added in a fixed order (no atomics, no memset: replays cleanly)."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        logits, target = _prep("logits", logits), _prep("target", target)
+        if logits.dim() != 2 or target.shape != logits.shape:
+            raise ValueError("kld_sum_loss: logits and target must both be [B,C], got %s and %s"
+                             % (tuple(logits.shape), tuple(target.shape)))
+        B, C = logits.shape
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        need = ctx.needs_input_grad[0]
+        d_logits = torch.empty_like(logits) if need else None
+        ws = torch.empty(B, device=logits.device, dtype=torch.float32)
+        _launch("kld_sum_loss", (B, C, need), _lib.lib().vqa_kld_sum_loss, _p(logits), _p(target), _p(loss), _p(d_logits),
+                _p(ws), 4 * B, B, C)
+        if need:
+            ctx.save_for_backward(d_logits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_logits,) = ctx.saved_tensors
+        return d_logits * g, None
+
+
+def kld_sum_loss(logits, target):
+    return KldSumLoss.apply(logits, target)
 
 
 def grad_norm_clip_coef(g_flat, max_norm, out, workspace):

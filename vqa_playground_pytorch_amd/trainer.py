@@ -19,7 +19,11 @@ import torch.nn.functional as F
 
 
 def kld_sum_loss(logits, target):
-    """train.py:536-544: KLDivLoss(size_average=False)(F.log_softmax(logits), target)."""
+    """train.py:536-544: KLDivLoss(size_average=False)(F.log_softmax(logits), target).  GPU tensors go through the
+    fused HIP kernel (ops.KldSumLoss); CPU tensors (the gloo tests of the host logic) through the torch ops."""
+    if logits.is_cuda:
+        from . import ops
+        return ops.kld_sum_loss(logits, target)
     return F.kl_div(F.log_softmax(logits, dim=1), target, reduction="sum")
 
 
