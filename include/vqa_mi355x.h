@@ -241,6 +241,18 @@ int vqa_linear_dropout_mask(float* mask, float p_drop, uint64_t seed, const uint
                             vqa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Column sums: out[n] = sum_m x[m,n] -- the bias gradient grad_output.sum(0) of every nn.Linear / 1x1 nn.Conv1d
+ * on the path (putils/__init__.py:16-33; config/CoR2.py:56-122).  x [M,N] with row stride ld (fp32, or bf16 in
+ * the _bf16 form); out [N] fp32; workspace: vqa_column_sum_workspace_bytes(M, N) bytes (0 for short matrices).
+ * Row slabs are added in a fixed order (bitwise reproducible; no atomics, no memset -- safe to replay).
+ * ------------------------------------------------------------------------------------------- */
+size_t vqa_column_sum_workspace_bytes(int M, int N);
+int vqa_column_sum(const float* x, int ld, float* out, void* workspace, size_t workspace_bytes,
+                   int M, int N, vqa_stream_t stream);
+int vqa_column_sum_bf16(const vqa_bf16_t* x, int ld, float* out, void* workspace, size_t workspace_bytes,
+                        int M, int N, vqa_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * KLD-sum loss on soft targets, with its gradient.
  * Replaces MyLoss (train.py:536-544): KLDivLoss(size_average=False)(F.log_softmax(logits), target).
  *

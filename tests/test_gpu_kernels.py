@@ -328,6 +328,32 @@ def test_linear_act_full_size_vs_fp64(ops):
     assert (y.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
+# ----------------------------------------------------------------------------------------------- column sums
+@pytest.mark.parametrize("M,N", [(18432, 310), (512, 2048), (18432, 4), (7, 5), (1, 1), (3000, 155), (513, 2000)])
+def test_column_sum(ops, M, N):
+    x = seeded.seeded_array((M, N), 311)
+    out = ops.column_sum(g(x))
+    close("colsum", out, x.astype(np.float64).sum(0), 2e-5)
+    assert torch.equal(out, ops.column_sum(g(x))), "fixed-order reduction must be bitwise reproducible"
+    xb = g(x).to(torch.bfloat16)
+    close("colsum_bf16", ops.column_sum(xb), xb.float().cpu().numpy().astype(np.float64).sum(0), 2e-5)
+
+
+def test_linear_fn_matches_autograd(ops):
+    """ops.linear = F.linear with the bias gradient from column_sum (replay-safe)."""
+    x = g(seeded.seeded_array((6, 36, 310), 321), True)
+    w = g(seeded.seeded_array((40, 310), 322), True)
+    b = g(seeded.seeded_array((40,), 323), True)
+    gy = g(seeded.seeded_array((6, 36, 40), 324))
+    ops.linear(x, w, b).backward(gy)
+    got = [t.grad.clone() for t in (x, w, b)]
+    for t in (x, w, b):
+        t.grad = None
+    torch.nn.functional.linear(x, w, b).backward(gy)
+    for name, a, t in zip(("d_x", "d_w", "d_b"), got, (x, w, b)):
+        close(name, a, t.grad.cpu().numpy(), 1e-5)
+
+
 # ----------------------------------------------------------------------------------------------- loss
 @pytest.mark.parametrize("B,C", [(4, 2000), (512, 2000), (3, 3000), (1, 7), (5, 4096)])
 def test_kld_sum_loss(ops, B, C):

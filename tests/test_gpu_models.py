@@ -269,6 +269,9 @@ def test_graph_replays_queued_without_host_sync():
         got[mode] = (loss.item(), norm.item())
         if mode:
             assert tr._graph is not None, "step was not captured"
+            nodes = tr.graph_nodes
+            assert nodes["front"].get("kernel", 0) > 100 and nodes["tail"].get("kernel", 0) >= 3, nodes
+            assert all(c.get("memset", 0) == 0 for c in nodes.values()), nodes
     (l0, n0), (l1, n1) = got[False], got[True]
     assert 100.0 < l0 < 2000.0, l0
     assert abs(l0 - l1) <= 1e-4 * abs(l0) and abs(n0 - n1) <= 1e-3 * abs(n0), (got[False], got[True])

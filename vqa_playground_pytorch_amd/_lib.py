@@ -60,6 +60,9 @@ SIGNATURES = {
     "vqa_lowrank_bilinear_fusion_bwd_bf16_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i, _c_i, _c_i]),
     "vqa_lowrank_bilinear_fusion_bwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz,
                                                     _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_column_sum_workspace_bytes": (_c_sz, [_c_i, _c_i]),
+    "vqa_column_sum": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_sz, _c_i, _c_i, _c_st]),
+    "vqa_column_sum_bf16": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_sz, _c_i, _c_i, _c_st]),
     "vqa_kld_sum_loss_workspace_bytes": (_c_sz, [_c_i]),
     "vqa_kld_sum_loss": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_i, _c_i, _c_st]),
     "vqa_grad_norm_workspace_bytes": (_c_sz, []),

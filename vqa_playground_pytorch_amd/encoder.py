@@ -13,6 +13,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
+
 
 def _af(name):
     return {"tanh": torch.tanh, "relu": F.relu, "sigmoid": torch.sigmoid}[name]
@@ -54,7 +56,8 @@ class BayesianGRU(nn.Module):
         mx = [self._mask(x[:, :1, :]) for _ in range(3)]                       # [B,1,in], shared over time
         h = x.new_zeros(B, self.hidden_size)
         mh = [self._mask(h) for _ in range(3)]                                 # [B,hidden]
-        gi = [lin(x if m is None else x * m) for lin, m in zip((c.weight_ir, c.weight_ii, c.weight_in), mx)]
+        gi = [ops.linear(x if m is None else x * m, lin.weight, lin.bias)                # (replay-safe bias gradient)
+              for lin, m in zip((c.weight_ir, c.weight_ii, c.weight_in), mx)]
         outs = []
         for t in range(T):
             hr, hi, hn = (h if m is None else h * m for m in mh)

@@ -62,7 +62,7 @@ class Linear(nn.Module):
             raise ValueError(
                 "[error] putils.Linear(%s, %s): last dimension of input(%s) should equal to in_features(%s)"
                 % (self.in_features, self.out_features, x.size(-1), self.in_features))
-        return self.linear(x)
+        return ops.linear(x, self.linear.weight, self.linear.bias)
 
 
 class MyLinear(nn.Module):
@@ -86,7 +86,7 @@ class MyLinear(nn.Module):
                 % (self.in_features, self.out_features, x.size(-1), self.in_features))
         if self.p:
             x = F.dropout(x, p=self.p, training=self.training)
-        return _activation(self.linear(x), self.af, self.dim)
+        return _activation(ops.linear(x, self.linear.weight, self.linear.bias), self.af, self.dim)
 
 
 class MyConv1d(nn.Module):
@@ -124,7 +124,7 @@ class MyConv1d(nn.Module):
         n_p = ops.pad_to(self.out_channels) if self.out_channels >= 32 else self.out_channels
         wp = ops.PackedWeightBf16.apply(w, n_p, x.size(-1))
         bp = F.pad(self.conv.bias, (0, n_p - self.out_channels)).to(torch.bfloat16)
-        y = F.linear(x, wp, bp)
+        y = ops.linear(x, wp, bp)
         if self.out_channels < 32:
             return _activation(y.float(), af, self.dim)
         return _activation(y, af, self.dim)
@@ -137,7 +137,7 @@ class MyConv1d(nn.Module):
             x = F.dropout(x, p=self.p, training=self.training)
         if x.dtype == torch.bfloat16:
             return self._linear_bf16(x, None)
-        return F.linear(x, self.conv.weight.squeeze(-1), self.conv.bias)
+        return ops.linear(x, self.conv.weight.squeeze(-1), self.conv.bias)
 
     # K5 (fused dropout+GEMM+bias+relu on the hand-written fp32 MFMA engine) vs the library GEMM: set per process
     # with VQA_FUSED_LINEAR=0/1; the default is whichever measured faster in situ (see profiles/README.md)

@@ -340,7 +340,7 @@ class LinearBf16(torch.autograd.Function):
             wpt = pack_bf16(w, torch.empty(Kp, Np, device=x2.device, dtype=torch.bfloat16), 0, 1, Np)   # [Kp, Np] = W^T
             d_x = gemm_bf16_nt(gz, wpt).view(*gy.shape[:-1], Kp)
         d_w = gemm_bf16_tn(gz, x2)[:out_f, :in_f]
-        d_b = gz.float().sum(0)[:out_f] if has_bias else None
+        d_b = column_sum(gz)[:out_f] if has_bias else None
         return d_x, d_w, d_b, None
 
 
@@ -500,6 +500,49 @@ def linear_act(x, w, bias=None, act=None, p_drop=0.0, seed=0):
     if code is None:
         raise ValueError("linear_act: act must be None or 'relu', got %r" % (act,))
     return LinearAct.apply(x, w, bias, code, p_drop, seed)
+
+
+def column_sum(x):
+    """out[n] = sum_m x[m,n] for a 2-D fp32 / bf16 matrix -> fp32 [N]; fixed-order reduction, safe under graph replay."""
+    x = _prep("x", x, _REGION_DTYPES)
+    if x.dim() != 2:
+        raise ValueError("column_sum: x must be 2-D, got %s" % (tuple(x.shape),))
+    M, N = x.shape
+    L_ = _lib.lib()
+    ws_bytes = L_.vqa_column_sum_workspace_bytes(M, N)
+    ws = torch.empty((ws_bytes + 3) // 4, device=x.device, dtype=torch.float32) if ws_bytes else None
+    out = torch.empty(N, device=x.device, dtype=torch.float32)
+    name = "column_sum" + _sfx(x.dtype)
+    _launch(name, (M, N), getattr(L_, "vqa_" + name), _p(x), N, _p(out), _p(ws), ws_bytes, M, N)
+    return out
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b with the library GEMMs (rocBLAS / hipBLASLt through torch) and the bias gradient from
+    ``column_sum``: torch.autograd's own linear backward takes grad_output.sum(0) with a multi-workgroup reduction whose
+    semaphores are zeroed by a memset node, which replays wrongly inside a hipGraph on ROCm 7.2 (csrc/api.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy2 = gy.reshape(-1, gy.shape[-1])
+        d_x = (gy2 @ w).view(x.shape) if ctx.needs_input_grad[0] else None
+        d_w = gy2.t() @ x.reshape(-1, x.shape[-1]) if ctx.needs_input_grad[1] else None
+        d_b = column_sum(gy2).to(gy.dtype) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return d_x, d_w, d_b
+
+
+def linear(x, w, b=None):
+    """F.linear for GPU tensors with a replay-safe bias gradient (see LinearFn); CPU tensors take the torch op."""
+    if x.is_cuda:
+        return LinearFn.apply(x, w, b)
+    return torch.nn.functional.linear(x, w, b)
 
 
 class KldSumLoss(torch.autograd.Function):

@@ -27,6 +27,35 @@ def kld_sum_loss(logits, target):
     return F.kl_div(F.log_softmax(logits, dim=1), target, reduction="sum")
 
 
+_HIP_NODE_TYPES = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event",
+                   7: "event_record"}
+
+
+def graph_node_types(graph):
+    """{node type: count} of a captured (keep_graph=True, not yet re-captured) torch.cuda.CUDAGraph, read through
+    hipGraphGetNodes / hipGraphNodeGetType.  Returns {} when the runtime library cannot be queried."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        handle = ctypes.c_void_p(graph.raw_cuda_graph())
+        count = ctypes.c_size_t(0)
+        if hip.hipGraphGetNodes(handle, None, ctypes.byref(count)) != 0:
+            return {}
+        nodes = (ctypes.c_void_p * count.value)()
+        if hip.hipGraphGetNodes(handle, nodes, ctypes.byref(count)) != 0:
+            return {}
+        out = {}
+        for node in nodes:
+            kind = ctypes.c_int(-1)
+            if hip.hipGraphNodeGetType(ctypes.c_void_p(node), ctypes.byref(kind)) != 0:
+                return {}
+            name = _HIP_NODE_TYPES.get(kind.value, "type%d" % kind.value)
+            out[name] = out.get(name, 0) + 1
+        return out
+    except (OSError, AttributeError, RuntimeError):
+        return {}
+
+
 class FlatGradients:
     """One contiguous fp32 buffer holding every parameter's gradient (views installed as p.grad)."""
 
@@ -277,12 +306,22 @@ class DataParallelTrainer:
             torch.cuda.synchronize()
             time.sleep(1.0)
             mode = "thread_local"
-        front, tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        front, tail = torch.cuda.CUDAGraph(keep_graph=True), torch.cuda.CUDAGraph(keep_graph=True)
         pool = torch.cuda.graph_pool_handle()
         with torch.cuda.graph(front, pool=pool, capture_error_mode=mode):
             loss = self._front(static_sample, target)
         with torch.cuda.graph(tail, pool=pool, capture_error_mode=mode):
             self._tail()
+        # Audit before instantiating: a memset node (hipMemsetAsync under capture) is replayed correctly once and then
+        # writes garbage on ROCm 7.2 (tools/graph_memset_check.py).  The library and the model issue none -- zero fills
+        # are kernels, the loss and the bias gradients avoid torch's semaphore-based reductions -- and a step that
+        # contains one anyway (a user-supplied seq2vec, a new torch op) must not be replayed.
+        self.graph_nodes = {"front": graph_node_types(front), "tail": graph_node_types(tail)}
+        memsets = sum(c.get("memset", 0) for c in self.graph_nodes.values())
+        if memsets:
+            raise RuntimeError("captured step holds %d memset node(s), which do not replay reliably" % memsets)
+        front.instantiate()
+        tail.instantiate()
         torch.cuda.synchronize()
         self._graph = {"front": front, "tail": tail, "loss": loss, "sample": static_sample, "target": target}
 
