@@ -109,6 +109,36 @@ int vqa_softmax_attention_pool_bwd_bf16(const float* alpha, const vqa_bf16_t* v,
                                         int B, int N, int D, int G, vqa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K3a  attention logits: the dropout + 1x1 conv in front of the softmax of MyATT.
+ * Replaces MyConv1d(fuse_dim, glimpses, 1, 1, p=0.5).forward up to its activation (config/CoR2.py:72-82 as
+ * configured at :132): F.dropout, two transposes, nn.Conv1d with G output channels.
+ *
+ *   logits[m,g] = bias[g] + sum_k w[g,k] * keep(m,k) * x[m,k]            (m = b*N + n)
+ *
+ * keep() as in K2 / K5: 1 when p_drop == 0, else 0 or 1/(1-p_drop) from the counter-based generator keyed by
+ * (seed [+ *seed_ptr], m*K + k) -- vqa_linear_dropout_mask(M, K, ...) writes the same mask for a test.
+ * x [M,K] with row stride ldx (fp32, or bf16 in the _bf16 forms, where ldx may be K padded to 64 with zeros);
+ * w [G,K]; bias [G]; logits [M,G] fp32.  Limits: G <= 8, K even and <= 512.
+ * Backward: d_logits [M,G] -> d_x [M,ldx] (or NULL), d_w [G,K], d_bias [G]; workspace:
+ * vqa_attention_logits_bwd_workspace_bytes(M, K, G) bytes; workgroup partials are added in a fixed order.
+ * ------------------------------------------------------------------------------------------- */
+int vqa_attention_logits_fwd(const float* x, int ldx, const float* w, const float* bias, float* logits,
+                             float p_drop, uint64_t seed, const uint64_t* seed_ptr, int M, int K, int G,
+                             vqa_stream_t stream);
+int vqa_attention_logits_fwd_bf16(const vqa_bf16_t* x, int ldx, const float* w, const float* bias,
+                                  float* logits, float p_drop, uint64_t seed, const uint64_t* seed_ptr,
+                                  int M, int K, int G, vqa_stream_t stream);
+size_t vqa_attention_logits_bwd_workspace_bytes(int M, int K, int G);
+int vqa_attention_logits_bwd(const float* x, int ldx, const float* w, const float* d_logits, float* d_x,
+                             float* d_w, float* d_bias, void* workspace, size_t workspace_bytes,
+                             float p_drop, uint64_t seed, const uint64_t* seed_ptr, int M, int K, int G,
+                             vqa_stream_t stream);
+int vqa_attention_logits_bwd_bf16(const vqa_bf16_t* x, int ldx, const float* w, const float* d_logits,
+                                  vqa_bf16_t* d_x, float* d_w, float* d_bias, void* workspace,
+                                  size_t workspace_bytes, float p_drop, uint64_t seed,
+                                  const uint64_t* seed_ptr, int M, int K, int G, vqa_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K4  low-rank bilinear (Mutan) fusion on the fp32 MFMA tile engine.
  * Replaces putils.MutanFusion.forward (putils/__init__.py:232-238): R x { Linear(in1->H) on the
  * region side, putils.bmul against the question-side factor, total += }.

@@ -412,3 +412,44 @@ def test_backward_kernels_repeat_under_graph_replay(ops, B):
         torch.cuda.synchronize()
         err = ((got - want).abs().max() / want.abs().max()).item()
         assert err <= 1e-5, "replay %d: d_logits differs from the eager result by %.3e" % (i, err)
+
+
+# ----------------------------------------------------------------------------------------------- K3a attention logits
+@pytest.mark.parametrize("B,N,Kd,G", [(3, 36, 510, 4), (2, 100, 510, 4), (5, 7, 64, 1), (2, 3, 512, 8), (1, 1, 2, 2)])
+@pytest.mark.parametrize("p", [0.0, 0.5])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_attention_logits(ops, B, N, Kd, G, p, dtype):
+    """logits = bias + (x * keep) w^T and its backward against the oracle's linear closed form, with the kernel's own
+    dropout mask (exported through vqa_linear_dropout_mask) handed to the oracle."""
+    bf = dtype == "bf16"
+    ld = (Kd + 63) // 64 * 64 if bf else Kd
+    x = seeded.seeded_array((B, N, Kd), 331)
+    if bf:
+        x = torch.from_numpy(x).to(torch.bfloat16).float().numpy()
+    w = seeded.seeded_array((G, Kd), 332) / np.sqrt(Kd)
+    b = seeded.seeded_array((G,), 333)
+    gl = seeded.seeded_array((B, N, G), 334)
+    xp = np.zeros((B, N, ld), np.float32)
+    xp[..., :Kd] = x
+    xt = g(xp)
+    if bf:
+        xt = xt.to(torch.bfloat16)
+    xt.requires_grad_()
+    wt, bt = g(w, True), g(b, True)
+    seed = 777
+    out = ops.attention_logits(xt, wt, bt, p, seed)
+    assert out.dtype == torch.float32 and out.shape == (B, N, G)
+    M = B * N
+    mask = ops.linear_dropout_mask(M, Kd, p, seed, dev()).cpu().numpy() if p else None
+    x2 = x.reshape(M, Kd)
+    close("logits", out.reshape(M, G), K.linear_act_fwd(x2, w, b, None, mask))
+    out.backward(g(gl))
+    dx, dw, db = K.linear_act_bwd(x2, w, None, gl.reshape(M, G), None, mask)
+    if bf:
+        got = xt.grad.float().cpu().numpy().reshape(M, ld).astype(np.float64)
+        assert np.abs(got[:, :Kd] - dx).max() <= 2.0 ** -8 * np.abs(dx).max() + 1e-6
+        assert ld == Kd or np.abs(got[:, Kd:]).max() == 0.0
+    else:
+        close("d_x", xt.grad.reshape(M, Kd), dx)
+    close("d_w", wt.grad, dw)
+    close("d_b", bt.grad, db)

@@ -29,6 +29,13 @@ SIGNATURES = {
                                                 _c_i, _c_i, _c_i, _c_st]),
     "vqa_softmax_attention_pool_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_softmax_attention_pool_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_attention_logits_fwd": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_attention_logits_fwd_bf16": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_attention_logits_bwd_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i]),
+    "vqa_attention_logits_bwd": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_fl, _c_u64, _c_f,
+                                        _c_i, _c_i, _c_i, _c_st]),
+    "vqa_attention_logits_bwd_bf16": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_fl, _c_u64, _c_f,
+                                             _c_i, _c_i, _c_i, _c_st]),
     "vqa_lowrank_bilinear_fusion_fwd": (_c_i, [_c_f, _c_i, _c_pp, _c_pp, _c_f, _c_f, _c_f,
                                                _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_lowrank_bilinear_fusion_bwd_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i, _c_i, _c_i]),

@@ -297,15 +297,27 @@ __global__ __launch_bounds__(256) void bilinear_bwd_prep_bf16_kernel(const bf16*
   }
 }
 
-// db1[r][h] = sum_b h2[b,r,h] * gsum[b,h]   (fixed order over b)
+// db1[r][h] = sum_b h2[b,r,h] * gsum[b,h].  256 lanes = 64 columns x 4 sample slices (a serial loop over B per
+// column is a chain of B dependent L2 round trips: 36 us at B = 128); slices meet in LDS, fixed order.
 __global__ __launch_bounds__(256) void bilinear_db_bf16_kernel(const float* __restrict__ h2, const float* __restrict__ gsum,
                                                                float* __restrict__ db1, int B, int H, int R) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= R * H) return;
+  __shared__ float part[3][64];
+  const int c = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + c;  // < R*H: H % 256 == 0
   const int h = e % H;
-  float a = 0.f;
-  for (int b = 0; b < B; ++b) a = fmaf(h2[(size_t)b * R * H + e], gsum[(size_t)b * H + h], a);
-  db1[e] = a;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int b = slice;
+  for (; b + 12 < B; b += 16) {
+    a0 = fmaf(h2[(size_t)b * R * H + e], gsum[(size_t)b * H + h], a0);
+    a1 = fmaf(h2[(size_t)(b + 4) * R * H + e], gsum[(size_t)(b + 4) * H + h], a1);
+    a2 = fmaf(h2[(size_t)(b + 8) * R * H + e], gsum[(size_t)(b + 8) * H + h], a2);
+    a3 = fmaf(h2[(size_t)(b + 12) * R * H + e], gsum[(size_t)(b + 12) * H + h], a3);
+  }
+  for (; b < B; b += 4) a0 = fmaf(h2[(size_t)b * R * H + e], gsum[(size_t)b * H + h], a0);
+  const float a = (a0 + a1) + (a2 + a3);
+  if (slice > 0) part[slice - 1][c] = a;
+  __syncthreads();
+  if (slice == 0) db1[e] = a + part[0][c] + part[1][c] + part[2][c];
 }
 
 // fp32 [batch, rows, cols] -> bf16 at dst[b*sb + r*sr + c*sc]  (dst zero-filled beforehand: the pads)
@@ -444,7 +456,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd_bf16(const vqa_bf16_t* x, const v
   float* slabs = reinterpret_cast<float*>(ws + k4_gs_bytes(B, N, H, R) + k4_gsum_bytes(B, H));
   hipLaunchKernelGGL(bilinear_bwd_prep_bf16_kernel, dim3(H / 256, B), dim3(256), 0, s, reinterpret_cast<const bf16*>(g),
                      reinterpret_cast<const bf16*>(h1), h2, gs, d_h2, gsum, N, H, R);
-  hipLaunchKernelGGL(bilinear_db_bf16_kernel, dim3((RH + 255) / 256), dim3(256), 0, s, h2, gsum, d_b1, B, H, R);
+  hipLaunchKernelGGL(bilinear_db_bf16_kernel, dim3(RH / 64), dim3(256), 0, s, h2, gsum, d_b1, B, H, R);
   if (d_x != nullptr) {
     rc = launch_nt("lowrank_bilinear_fusion_bwd_bf16(dx)", gs, RH, reinterpret_cast<const bf16*>(w1t), RH, nullptr,
                    reinterpret_cast<bf16*>(d_x), L, M, L, RH, 0, s);

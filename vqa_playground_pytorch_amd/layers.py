@@ -133,6 +133,11 @@ class MyConv1d(nn.Module):
         if x.dim() != 3:
             raise ValueError("[error] putils.Conv1d(%s, %s, %s, %s): input_dim (%s) should equal to 3"
                              % (self.in_channels, self.out_channels, self.kernel_size, self.stride, x.dim()))
+        if ops.attention_logits_supported(x, self.in_channels, self.out_channels):
+            # the G attention logits of MyATT: dropout + 1x1 conv in one HIP kernel (K3a), fp32 out for either storage
+            p = self.p if (self.training and self.p) else 0.0
+            return ops.attention_logits(x, self.conv.weight.squeeze(-1), self.conv.bias, p,
+                                        ops.next_dropout_seed() if p else 0)
         if self.p:
             x = F.dropout(x, p=self.p, training=self.training)
         if x.dtype == torch.bfloat16:

@@ -178,6 +178,55 @@ class SoftmaxAttentionPool(torch.autograd.Function):
         return d_logits, d_v
 
 
+class AttentionLogits(torch.autograd.Function):
+    """K3a.  logits[..., g] = bias[g] + sum_k w[g,k] * keep * x[..., k] -- the dropout + 1x1 conv in front of MyATT's
+    softmax (config/CoR2.py:72-82 as configured at :132) in one pass over x; x fp32 [.., K] or bf16 [.., Kp >= K]."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, p_drop, seed):
+        x, w, bias = _prep("x", x, _REGION_DTYPES), _prep("w", w), _prep("bias", bias)
+        G, K = w.shape
+        ld = x.shape[-1]
+        M = x.numel() // ld
+        if bias.shape != (G,) or ld < K:
+            raise ValueError("attention_logits: w must be [G,K], bias [G], x's last dim >= K (got %s, %s, %s)"
+                             % (tuple(w.shape), tuple(bias.shape), tuple(x.shape)))
+        logits = torch.empty(*x.shape[:-1], G, device=x.device, dtype=torch.float32)
+        sv, sp = _seed_args(seed)
+        name = "attention_logits_fwd" + _sfx(x.dtype)
+        _launch(name, (M, K, G, float(p_drop) > 0), getattr(_lib.lib(), "vqa_" + name), _p(x), ld, _p(w), _p(bias),
+                _p(logits), float(p_drop), sv, sp, M, K, G)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (float(p_drop), seed, M, K, G, ld)
+        return logits
+
+    @staticmethod
+    def backward(ctx, d_logits):
+        x, w = ctx.saved_tensors
+        p_drop, seed, M, K, G, ld = ctx.cfg
+        d_logits = _prep("grad_logits", d_logits)
+        d_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        d_w = torch.empty_like(w)
+        d_b = torch.empty(G, device=x.device, dtype=torch.float32)
+        L_ = _lib.lib()
+        ws_bytes = L_.vqa_attention_logits_bwd_workspace_bytes(M, K, G)
+        ws = torch.empty((ws_bytes + 3) // 4, device=x.device, dtype=torch.float32)
+        sv, sp = _seed_args(seed)
+        name = "attention_logits_bwd" + _sfx(x.dtype)
+        _launch(name, (M, K, G, p_drop > 0, d_x is not None), getattr(L_, "vqa_" + name), _p(x), ld, _p(w), _p(d_logits),
+                _p(d_x), _p(d_w), _p(d_b), _p(ws), ws_bytes, p_drop, sv, sp, M, K, G)
+        return d_x, d_w, d_b, None, None
+
+
+def attention_logits(x, w, bias, p_drop=0.0, seed=0):
+    return AttentionLogits.apply(x, w, bias, p_drop, seed)
+
+
+def attention_logits_supported(x, in_features, out_features):
+    return x.is_cuda and out_features <= 8 and in_features <= 512 and in_features % 2 == 0 and \
+        x.shape[-1] % (4 if x.dtype == torch.bfloat16 else 2) == 0
+
+
 class LowRankBilinearFusion(torch.autograd.Function):
     """K4.  out[b,n,:] = sum_r (x[b,n,:] W1_r^T + b1_r) * h2[b,r,:]   (x may also be [B,L]).
     Replaces the region side of putils.MutanFusion.forward (putils/__init__.py:232-238)."""
