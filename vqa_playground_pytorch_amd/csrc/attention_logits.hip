@@ -213,22 +213,44 @@ __global__ __launch_bounds__(kAlThreads) void attention_logits_bwd_kernel(const 
   }
 }
 
-// d_w[g][k] = sum_blocks part[block][g][k] ; d_bias[g] = sum_blocks partb[block][g]   (fixed order)
+// d_w[g][k] = sum_blocks part[block][g][k] ; d_bias[g] = sum_blocks partb[block][g]   (fixed order).
+// 256 lanes = 64 outputs x 4 block slices, 4 partials in flight per lane (a serial loop over 256 partials per output
+// is a chain of dependent L2 round trips: 77 us); output G*K + g is d_bias[g].
 __global__ __launch_bounds__(256) void attention_logits_finish_kernel(const float* __restrict__ part,
                                                                       const float* __restrict__ partb,
                                                                       float* __restrict__ d_w, float* __restrict__ d_bias,
                                                                       int K, int G, int KPAD, int nblocks) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e < G * K) {
-    const int g = e / K, k = e % K;
-    float t = 0.f;
-    for (int b = 0; b < nblocks; ++b) t += part[((size_t)b * G + g) * KPAD + k];
-    d_w[e] = t;
+  __shared__ float red_s[3][64];
+  const int c = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + c;
+  const bool is_w = e < G * K, is_b = !is_w && e < G * K + G;
+  const float* src = partb;
+  size_t stride = (size_t)G, off = 0;
+  if (is_w) {
+    src = part;
+    stride = (size_t)G * KPAD;
+    off = (size_t)(e / K) * KPAD + (e % K);
+  } else if (is_b) {
+    off = (size_t)(e - G * K);
   }
-  if (e < G) {
-    float t = 0.f;
-    for (int b = 0; b < nblocks; ++b) t += partb[(size_t)b * G + e];
-    d_bias[e] = t;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (is_w || is_b) {
+    int b = slice;
+    for (; b + 12 < nblocks; b += 16) {
+      a0 += src[(size_t)b * stride + off];
+      a1 += src[(size_t)(b + 4) * stride + off];
+      a2 += src[(size_t)(b + 8) * stride + off];
+      a3 += src[(size_t)(b + 12) * stride + off];
+    }
+    for (; b < nblocks; b += 4) a0 += src[(size_t)b * stride + off];
+  }
+  const float a = (a0 + a1) + (a2 + a3);
+  if (slice > 0) red_s[slice - 1][c] = a;
+  __syncthreads();
+  if (slice == 0) {
+    const float t = a + red_s[0][c] + red_s[1][c] + red_s[2][c];
+    if (is_w) d_w[e] = t;
+    if (is_b) d_bias[e - G * K] = t;
   }
 }
 
@@ -307,7 +329,7 @@ static int al_bwd_impl(const char* who, const T* x, int ldx, const float* w, con
                      part, partb, M, K, dc)
   VQA_AL_SWITCH_G(G, CALL);
 #undef CALL
-  hipLaunchKernelGGL(attention_logits_finish_kernel, dim3((G * K + 255) / 256), dim3(256), 0, s, part, partb, d_w, d_bias, K,
+  hipLaunchKernelGGL(attention_logits_finish_kernel, dim3((G * K + G + 63) / 64), dim3(256), 0, s, part, partb, d_w, d_bias, K,
                      G, KPAD, blocks);
   return check_launch(who);
 }

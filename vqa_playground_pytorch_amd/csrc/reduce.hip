@@ -101,13 +101,58 @@ __global__ __launch_bounds__(kColThreads) void column_sum_kernel(const T* __rest
   }
 }
 
+// Short matrices (M <= kColShortM: the [B, .] question-side layers): ONE kernel, no workspace.  A workgroup = 16
+// adjacent columns x 16 row slices, 8 rows in flight per lane (the matrix was just written: L2 hits), slices meet in
+// LDS in a fixed order.
+constexpr int kColShortM = 1024;
+template <typename T>
+__global__ __launch_bounds__(256) void column_sum_short_kernel(const T* __restrict__ x, int ld, float* __restrict__ out, int M,
+                                                               int N) {
+  __shared__ float part[16][17];
+  const int c = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int n = blockIdx.x * 16 + c;
+  const int nc = min(n, N - 1);
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int m0 = slice; m0 < M; m0 += 128) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (float)x[(size_t)min(m0 + 16 * k, M - 1) * ld + nc];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (m0 + 16 * k < M) acc[k] += v[k];
+  }
+  part[slice][c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (slice == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += part[q][c];
+    out[n] = t;
+  }
+}
+
+// out[n] = sum_s slabs[s][n], fixed order; 256 lanes = 64 columns x 4 slab slices, 4 slabs in flight per lane
 __global__ __launch_bounds__(256) void column_sum_finish_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                                 int N, int S) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
-  float t = 0.f;
-  for (int s = 0; s < S; ++s) t += slabs[(size_t)s * N + n];
-  out[n] = t;
+  __shared__ float red_s[3][64];
+  const int c = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + c;
+  const int nc = min(n, N - 1);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int q = slice;
+  for (; q + 12 < S; q += 16) {
+    a0 += slabs[(size_t)q * N + nc];
+    a1 += slabs[(size_t)(q + 4) * N + nc];
+    a2 += slabs[(size_t)(q + 8) * N + nc];
+    a3 += slabs[(size_t)(q + 12) * N + nc];
+  }
+  for (; q < S; q += 4) a0 += slabs[(size_t)q * N + nc];
+  const float a = (a0 + a1) + (a2 + a3);
+  if (slice > 0) red_s[slice - 1][c] = a;
+  __syncthreads();
+  if (slice == 0 && n < N) out[n] = a + red_s[0][c] + red_s[1][c] + red_s[2][c];
 }
 
 static int column_slabs(int M, int N, int vec) {
@@ -130,6 +175,11 @@ static int column_sum_impl(const char* who, const T* x, int ld, float* out, void
                            int N, vqa_stream_t stream) {
   VQA_REQUIRE(x && out, VQA_E_BADARG, "%s: null pointer", who);
   VQA_REQUIRE(M > 0 && N > 0 && ld >= N, VQA_E_BADARG, "%s: bad sizes M=%d N=%d ld=%d", who, M, N, ld);
+  if (M <= kColShortM) {
+    hipLaunchKernelGGL(column_sum_short_kernel<T>, dim3((N + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), x, ld,
+                       out, M, N);
+    return check_launch(who);
+  }
   const int vec = column_vec(x, ld, N);
   const int S = column_slabs(M, N, vec);
   const size_t need = S > 1 ? (size_t)S * N * sizeof(float) : 0;
@@ -147,7 +197,7 @@ static int column_sum_impl(const char* who, const T* x, int ld, float* out, void
     hipLaunchKernelGGL((column_sum_kernel<T, 1>), grid, dim3(kColThreads), 0, s, x, ld, dst, M, N, rows_per_slab);
   }
   if (S > 1)
-    hipLaunchKernelGGL(column_sum_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, s, static_cast<const float*>(workspace),
+    hipLaunchKernelGGL(column_sum_finish_kernel, dim3((N + 63) / 64), dim3(256), 0, s, static_cast<const float*>(workspace),
                        out, N, S);
   return check_launch(who);
 }
@@ -157,7 +207,7 @@ static int column_sum_impl(const char* who, const T* x, int ld, float* out, void
 using namespace vqa;
 
 extern "C" size_t vqa_column_sum_workspace_bytes(int M, int N) {
-  if (M <= 0 || N <= 0) return 0;
+  if (M <= 0 || N <= 0 || M <= kColShortM) return 0;
   // the slab count depends on the vector width chosen at launch; size for the largest (vec = 1 gives the fewest column
   // blocks per row of workgroups, hence the most slabs -- bounded by the rows)
   int worst = 1;
