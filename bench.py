@@ -92,6 +92,8 @@ def roofline_entry(name, shape, launches, mean_ms, B, regions=REGIONS, bf16=Fals
         work += B * regions * FEAT * (2 if bf16 else 4)
     if name.startswith("lowrank_bilinear_fusion_bwd") and not shape[-1]:
         work //= 2
+    if name.startswith("pairwise_relation_reduce_bwd") and shape[-1]:      # second gradient tensor read as well
+        work += B * regions * FEAT * (2 if bf16 else 4)
     sec = mean_ms * 1e-3
     if bound == "hbm":
         achieved, peak, unit = work / sec / 1e9, HBM_PEAK_GBS, "GB/s"

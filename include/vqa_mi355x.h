@@ -63,13 +63,15 @@ int vqa_pairwise_relation_reduce_fwd(const float* v, const float* q1, const floa
                                      const float* alpha, int alpha_stride, float* v2,
                                      int B, int N, int D, int mode, vqa_stream_t stream);
 
-/* Backward of K1.  g_v2 = dL/dv2 [B,N,D].  Outputs: d_alpha [B,N] dense, d_q1 [B,D], d_q2 [B,D],
- * d_v [B,N,D] or NULL (v is a leaf in CoR2).  d_alpha is accumulated across the D-chunks of a
- * sample with float atomics after being zeroed on `stream` by this call. */
+/* Backward of K1.  g_v2 = dL/dv2 [B,N,D]; g_v2_b = a second gradient tensor of the same shape that is
+ * added to it on the fly, or NULL (CoR2's v2 has two consumers, config/CoR2.py:218-220; handing both
+ * gradients over saves the B*N*D-element add in front of this kernel).  Outputs: d_alpha [B,N] dense,
+ * d_q1 [B,D], d_q2 [B,D], d_v [B,N,D] or NULL (v is a leaf in CoR2).  d_alpha is accumulated across the
+ * D-chunks of a sample with float atomics after being zeroed on `stream` by this call. */
 int vqa_pairwise_relation_reduce_bwd(const float* v, const float* q1, const float* q2,
                                      const float* alpha, int alpha_stride, const float* g_v2,
-                                     float* d_alpha, float* d_q1, float* d_q2, float* d_v,
-                                     int B, int N, int D, vqa_stream_t stream);
+                                     const float* g_v2_b, float* d_alpha, float* d_q1, float* d_q2,
+                                     float* d_v, int B, int N, int D, vqa_stream_t stream);
 
 /* K1 with the region tensors (v, v2, g_v2, d_v) stored as bf16 -- the mixed-precision path of BASELINE
  * configs[4] (bf16 storage, fp32 arithmetic and accumulation; q1, q2, alpha and their gradients stay
@@ -79,8 +81,9 @@ int vqa_pairwise_relation_reduce_fwd_bf16(const vqa_bf16_t* v, const float* q1, 
                                           int B, int N, int D, int mode, vqa_stream_t stream);
 int vqa_pairwise_relation_reduce_bwd_bf16(const vqa_bf16_t* v, const float* q1, const float* q2,
                                           const float* alpha, int alpha_stride, const vqa_bf16_t* g_v2,
-                                          float* d_alpha, float* d_q1, float* d_q2, vqa_bf16_t* d_v,
-                                          int B, int N, int D, vqa_stream_t stream);
+                                          const vqa_bf16_t* g_v2_b, float* d_alpha, float* d_q1,
+                                          float* d_q2, vqa_bf16_t* d_v, int B, int N, int D,
+                                          vqa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3  softmax over regions + attention-weighted region pooling.

@@ -67,6 +67,36 @@ def test_pairwise_relation_fwd_bwd(ops, B, N, D, G, glimpse, mode):
     close("d_v", vt.grad, dv)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pairwise_relation_dual_outputs(ops, dtype):
+    """dual=True: two aliases of v2, one per consumer; their gradients are added inside the backward kernel."""
+    B, N, D, G = 3, 36, 512, 4
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    v = torch.randn(B, N, D, generator=gen).to(dev()).to(dtype)
+    q1, q2 = torch.rand(B, D, generator=gen).to(dev()), torch.rand(B, D, generator=gen).to(dev())
+    al = torch.softmax(torch.randn(B, N, G, generator=gen), 1).to(dev())
+    ga, gb = (torch.randn(B, N, D, generator=gen).to(dev()).to(dtype) for _ in range(2))
+    outs = {}
+    for dual in (False, True):
+        leaves = [t.clone().requires_grad_() for t in (v, q1, q2, al)]
+        if dual:
+            a, b = ops.pairwise_relation_reduce(*leaves, glimpse=1, mode=1, dual=True)
+            assert a.data_ptr() == b.data_ptr()
+            ((a.float() * ga.float()).sum() + (b.float() * gb.float()).sum()).backward()
+        else:
+            a = ops.pairwise_relation_reduce(*leaves, glimpse=1, mode=1)
+            (a.float() * (ga.float() + gb.float())).sum().backward()
+        outs[dual] = [t.grad.float() for t in leaves]
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-5     # bf16: the single-tensor path rounds ga+gb to bf16 first
+    for x, y in zip(outs[False], outs[True]):
+        assert ((x - y).abs().max() / x.abs().max()).item() <= tol
+    # one consumer only: the other gradient is None
+    leaves = [t.clone().requires_grad_() for t in (v, q1, q2, al)]
+    a, b = ops.pairwise_relation_reduce(*leaves, glimpse=1, mode=1, dual=True)
+    (b.float() * (ga.float() + gb.float())).sum().backward()
+    assert ((leaves[1].grad - outs[False][1]).abs().max() / outs[False][1].abs().max()).item() <= tol
+
+
 def test_pairwise_relation_modes_agree_full_size(ops):
     """BASELINE size (B=512, 36x2048): pairwise and factored evaluation agree, and the kernel is linear in alpha."""
     B, N, D = 512, 36, 2048

@@ -63,7 +63,7 @@ def k1_backward(B, N=36, D=2048, G=4):
     def call():
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         rc = L.vqa_pairwise_relation_reduce_bwd(v.data_ptr(), q1.data_ptr(), q2.data_ptr(), al.data_ptr(), G, g.data_ptr(),
-                                                d_alpha.data_ptr(), d_q1.data_ptr(), d_q2.data_ptr(), None, B, N, D, s)
+                                                None, d_alpha.data_ptr(), d_q1.data_ptr(), d_q2.data_ptr(), None, B, N, D, s)
         assert rc == 0
 
     call()

@@ -25,7 +25,7 @@ SIGNATURES = {
     "vqa_version": (_c_i, []),
     "vqa_last_error": (ctypes.c_char_p, []),
     "vqa_pairwise_relation_reduce_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
-    "vqa_pairwise_relation_reduce_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f,
+    "vqa_pairwise_relation_reduce_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
                                                 _c_i, _c_i, _c_i, _c_st]),
     "vqa_softmax_attention_pool_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_softmax_attention_pool_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
@@ -54,7 +54,7 @@ SIGNATURES = {
     "vqa_linear_dropout_mask": (_c_i, [_c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_st]),
     # bf16 (mixed-precision) side
     "vqa_pairwise_relation_reduce_fwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
-    "vqa_pairwise_relation_reduce_bwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f,
+    "vqa_pairwise_relation_reduce_bwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
                                                      _c_i, _c_i, _c_i, _c_st]),
     "vqa_softmax_attention_pool_fwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_softmax_attention_pool_bwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),

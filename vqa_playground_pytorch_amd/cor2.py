@@ -57,7 +57,7 @@ class Model(nn.Module):
         q_feature_1 = self.expand_q_1(self.compress_q_1(guidance))
         q_feature_2 = self.expand_q_2(self.compress_q_2(guidance))
         return ops.pairwise_relation_reduce(v_feature, q_feature_1, q_feature_2, alpha, glimpse=0,
-                                            mode=self.relation_mode)
+                                            mode=self.relation_mode, dual=True)
 
     def forward(self, sample):
         v = sample["v"]
@@ -72,10 +72,11 @@ class Model(nn.Module):
         fuse1 = self.fusion_vq1(v_feature_low, q_feature_low)
         v1_att, alpha1, alpha1_full = self.att1.attend(v_feature, self.att1.conv_att.pre_activation(fuse1))
 
-        v2_feature = self.relation_reduce(v_feature, q_feature, alpha1_full)          # only glimpse 0 weights it
+        # only glimpse 0 weights the relation; v2 has two consumers, each gets its own alias (see ops.pairwise_relation_reduce)
+        v2_feature, v2_for_pooling = self.relation_reduce(v_feature, q_feature, alpha1_full)
         v2_feature_low = self.compress_v2(v2_feature)
         fuse2 = self.fusion_vq2(v2_feature_low, q_feature_low)
-        v2_att, alpha2, _ = self.att2.attend(v2_feature, self.att2.conv_att.pre_activation(fuse2))
+        v2_att, alpha2, _ = self.att2.attend(v2_for_pooling, self.att2.conv_att.pre_activation(fuse2))
 
         # side output read by visu.py:198-207; detached so it does not pin the autograd graph of the step
         # (feature = the reference's v2_feature[:, [0, 1], :])

@@ -155,11 +155,15 @@ __global__ __launch_bounds__(NT) void pairwise_fwd_stream_kernel(const T* __rest
 // accumulators (sum g, sum g*v, sum alpha*v), so the kernel runs at full occupancy; pass 2 re-reads the v rows this
 // workgroup has just streamed (36 KB per wave, served by L2 / Infinity Cache, not HBM) for dalpha_i = <v_i, q1*sum g>.
 // dalpha partials: wave64 shuffles -> LDS -> one float atomic per (workgroup, region).
-template <typename T, int NT>
+// TWO: the gradient arrives in two tensors (v2 has two consumers -- the second-step compress and the second-step pooling
+// -- and is returned to autograd as two aliases, so the two gradients are added here in registers instead of by a
+// 3 x B*N*D-element add kernel in front of this one).
+template <typename T, int NT, bool TWO>
 __global__ __launch_bounds__(NT) void pairwise_bwd_stream_kernel(const T* __restrict__ v, const float* __restrict__ q1,
                                                                  const float* __restrict__ q2,
                                                                  const float* __restrict__ alpha, int astride,
-                                                                 const T* __restrict__ g, float* __restrict__ d_alpha,
+                                                                 const T* __restrict__ g, const T* __restrict__ g_b,
+                                                                 float* __restrict__ d_alpha,
                                                                  float* __restrict__ d_q1, float* __restrict__ d_q2,
                                                                  T* __restrict__ d_v, int N, int D) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -182,7 +186,8 @@ __global__ __launch_bounds__(NT) void pairwise_bwd_stream_kernel(const T* __rest
 #pragma unroll 6
   for (int j = 0; j < N; ++j) {
     const float4 vj = ld4(v + base + (size_t)j * D);
-    const float4 gj = ld4(g + base + (size_t)j * D);
+    float4 gj = ld4(g + base + (size_t)j * D);
+    if constexpr (TWO) gj = add4(gj, ld4(g_b + base + (size_t)j * D));
     const float a = alpha_s[j];
     gsum = add4(gsum, gj);
     gv = add4(gv, mul4(gj, vj));
@@ -207,7 +212,8 @@ __global__ __launch_bounds__(NT) void pairwise_bwd_stream_kernel(const T* __rest
       const int i = i0 + k;
       if (i < N) {
         if (d_v != nullptr && active) {
-          const float4 gi = ld4(g + base + (size_t)i * D);
+          float4 gi = ld4(g + base + (size_t)i * D);
+          if constexpr (TWO) gi = add4(gi, ld4(g_b + base + (size_t)i * D));
           st4(d_v + base + (size_t)i * D, add4(scale4(alpha_s[i], u), mul4(c2, gi)));
         }
         const float p = wave_sum(dot4(vi[k], u) + cpart);
@@ -262,14 +268,15 @@ static int pairwise_fwd_impl(const char* who, const T* v, const float* q1, const
 
 template <typename T>
 static int pairwise_bwd_impl(const char* who, const T* v, const float* q1, const float* q2, const float* alpha,
-                             int alpha_stride, const T* g_v2, float* d_alpha, float* d_q1, float* d_q2, T* d_v, int B, int N,
-                             int D, vqa_stream_t stream) {
+                             int alpha_stride, const T* g_v2, const T* g_v2_b, float* d_alpha, float* d_q1, float* d_q2,
+                             T* d_v, int B, int N, int D, vqa_stream_t stream) {
   constexpr size_t kAlign = 4 * sizeof(T);
   VQA_REQUIRE(v && q1 && q2 && alpha && g_v2 && d_alpha && d_q1 && d_q2, VQA_E_BADARG, "%s: null pointer", who);
   VQA_REQUIRE(B > 0 && N > 0 && D > 0 && alpha_stride > 0, VQA_E_BADARG, "%s: bad sizes B=%d N=%d D=%d alpha_stride=%d", who,
               B, N, D, alpha_stride);
   VQA_REQUIRE(D % 4 == 0 && aligned(v, kAlign) && aligned(q1, 16) && aligned(q2, 16) && aligned(g_v2, kAlign) &&
-                  aligned(d_q1, 16) && aligned(d_q2, 16) && (d_v == nullptr || aligned(d_v, kAlign)),
+                  aligned(d_q1, 16) && aligned(d_q2, 16) && (d_v == nullptr || aligned(d_v, kAlign)) &&
+                  (g_v2_b == nullptr || aligned(g_v2_b, kAlign)),
               VQA_E_UNSUPPORTED, "%s: needs D %% 4 == 0, 16-byte aligned fp32 and %zu-byte aligned region tensors (D=%d)", who,
               kAlign, D);
   VQA_REQUIRE(N <= 4096, VQA_E_UNSUPPORTED, "%s: N=%d exceeds 4096", who, N);
@@ -278,8 +285,13 @@ static int pairwise_bwd_impl(const char* who, const T* v, const float* q1, const
   int rc = zero_async(d_alpha, (size_t)B * N * sizeof(float), s);
   if (rc != VQA_OK) return rc;
   constexpr int NT = 256;
-  hipLaunchKernelGGL((pairwise_bwd_stream_kernel<T, NT>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), (size_t)N * 8, s, v, q1, q2,
-                     alpha, alpha_stride, g_v2, d_alpha, d_q1, d_q2, d_v, N, D);
+  if (g_v2_b != nullptr) {
+    hipLaunchKernelGGL((pairwise_bwd_stream_kernel<T, NT, true>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), (size_t)N * 8, s, v,
+                       q1, q2, alpha, alpha_stride, g_v2, g_v2_b, d_alpha, d_q1, d_q2, d_v, N, D);
+  } else {
+    hipLaunchKernelGGL((pairwise_bwd_stream_kernel<T, NT, false>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), (size_t)N * 8, s, v,
+                       q1, q2, alpha, alpha_stride, g_v2, g_v2_b, d_alpha, d_q1, d_q2, d_v, N, D);
+  }
   return check_launch(who);
 }
 
@@ -301,17 +313,18 @@ extern "C" int vqa_pairwise_relation_reduce_fwd_bf16(const vqa_bf16_t* v, const 
 }
 
 extern "C" int vqa_pairwise_relation_reduce_bwd(const float* v, const float* q1, const float* q2, const float* alpha,
-                                                int alpha_stride, const float* g_v2, float* d_alpha, float* d_q1,
-                                                float* d_q2, float* d_v, int B, int N, int D, vqa_stream_t stream) {
-  return pairwise_bwd_impl<float>("pairwise_relation_reduce_bwd", v, q1, q2, alpha, alpha_stride, g_v2, d_alpha, d_q1, d_q2,
-                                  d_v, B, N, D, stream);
+                                                int alpha_stride, const float* g_v2, const float* g_v2_b, float* d_alpha,
+                                                float* d_q1, float* d_q2, float* d_v, int B, int N, int D,
+                                                vqa_stream_t stream) {
+  return pairwise_bwd_impl<float>("pairwise_relation_reduce_bwd", v, q1, q2, alpha, alpha_stride, g_v2, g_v2_b, d_alpha, d_q1,
+                                  d_q2, d_v, B, N, D, stream);
 }
 
 extern "C" int vqa_pairwise_relation_reduce_bwd_bf16(const vqa_bf16_t* v, const float* q1, const float* q2,
                                                      const float* alpha, int alpha_stride, const vqa_bf16_t* g_v2,
-                                                     float* d_alpha, float* d_q1, float* d_q2, vqa_bf16_t* d_v, int B,
-                                                     int N, int D, vqa_stream_t stream) {
+                                                     const vqa_bf16_t* g_v2_b, float* d_alpha, float* d_q1, float* d_q2,
+                                                     vqa_bf16_t* d_v, int B, int N, int D, vqa_stream_t stream) {
   return pairwise_bwd_impl<bf16>("pairwise_relation_reduce_bwd_bf16", reinterpret_cast<const bf16*>(v), q1, q2, alpha,
-                                 alpha_stride, reinterpret_cast<const bf16*>(g_v2), d_alpha, d_q1, d_q2,
-                                 reinterpret_cast<bf16*>(d_v), B, N, D, stream);
+                                 alpha_stride, reinterpret_cast<const bf16*>(g_v2), reinterpret_cast<const bf16*>(g_v2_b),
+                                 d_alpha, d_q1, d_q2, reinterpret_cast<bf16*>(d_v), B, N, D, stream);
 }

@@ -106,7 +106,7 @@ class PairwiseRelationReduce(torch.autograd.Function):
     Replaces config/CoR2.py:191-199 + :216."""
 
     @staticmethod
-    def forward(ctx, v, q1, q2, alpha, glimpse, mode):
+    def forward(ctx, v, q1, q2, alpha, glimpse, mode, dual):
         v, q1, q2, alpha = _prep("v", v, _REGION_DTYPES), _prep("q1", q1), _prep("q2", q2), _prep("alpha", alpha)
         B, N, D = v.shape
         if alpha.dim() != 3 or alpha.shape[0] != B or alpha.shape[1] != N or not 0 <= glimpse < alpha.shape[2]:
@@ -121,12 +121,20 @@ class PairwiseRelationReduce(torch.autograd.Function):
                 _p(v), _p(q1), _p(q2), a_ptr, G, _p(v2), B, N, D, int(mode))
         ctx.save_for_backward(v, q1, q2, alpha)
         ctx.glimpse = glimpse
+        ctx.set_materialize_grads(False)
+        if dual:   # two aliases of the one result: autograd hands their gradients back separately (summed in the kernel)
+            return v2, v2.view_as(v2)
         return v2
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_b=None):
         v, q1, q2, alpha = ctx.saved_tensors
+        if g is None:
+            g, g_b = g_b, None
+        if g is None:
+            return None, None, None, None, None, None, None
         g = _prep("grad_v2", g.to(v.dtype), _REGION_DTYPES)
+        g_b = _prep("grad_v2_b", g_b.to(v.dtype), _REGION_DTYPES) if g_b is not None else None
         B, N, D = v.shape
         G = alpha.shape[2]
         d_alpha = torch.empty(B, N, device=v.device, dtype=torch.float32)
@@ -135,11 +143,11 @@ class PairwiseRelationReduce(torch.autograd.Function):
         d_v = torch.empty_like(v) if ctx.needs_input_grad[0] else None
         a_ptr = ctypes.c_void_p(alpha.data_ptr() + 4 * ctx.glimpse)
         name = "pairwise_relation_reduce_bwd" + _sfx(v.dtype)
-        _launch(name, (B, N, D, d_v is not None), getattr(_lib.lib(), "vqa_" + name),
-                _p(v), _p(q1), _p(q2), a_ptr, G, _p(g), _p(d_alpha), _p(d_q1), _p(d_q2), _p(d_v), B, N, D)
+        _launch(name, (B, N, D, d_v is not None, g_b is not None), getattr(_lib.lib(), "vqa_" + name),
+                _p(v), _p(q1), _p(q2), a_ptr, G, _p(g), _p(g_b), _p(d_alpha), _p(d_q1), _p(d_q2), _p(d_v), B, N, D)
         d_alpha_full = torch.zeros_like(alpha)
         d_alpha_full[:, :, ctx.glimpse] = d_alpha
-        return d_v, d_q1, d_q2, d_alpha_full, None, None
+        return d_v, d_q1, d_q2, d_alpha_full, None, None, None
 
 
 class SoftmaxAttentionPool(torch.autograd.Function):
@@ -697,8 +705,10 @@ def object_difference_dropout_mask(B, N, L, p_drop, seed, device):
     return mask
 
 
-def pairwise_relation_reduce(v, q1, q2, alpha, glimpse=0, mode=1):
-    return PairwiseRelationReduce.apply(v, q1, q2, alpha, glimpse, mode)
+def pairwise_relation_reduce(v, q1, q2, alpha, glimpse=0, mode=1, dual=False):
+    """dual=True returns (v2, alias of v2): give one to each of two consumers and their gradients are added inside the
+    backward kernel instead of by an extra full-size add."""
+    return PairwiseRelationReduce.apply(v, q1, q2, alpha, glimpse, mode, dual)
 
 
 def softmax_attention_pool(logits, v):
