@@ -212,11 +212,30 @@ class MyATT(nn.Module):
             [MyLinear(inputs_dim, int(att_dim / glimpses), p=0.5, af=af) for _ in range(glimpses)])
         self.af = af
 
+    def glimpse_projection(self, pooled):
+        """cat_g MyLinear_g(pooled[:, g, :]) (config/CoR2.py:143-147).  The G layers have one shape, so they run as ONE
+        batched GEMM over the [B,G,D] tensor (one dropout draw over all of it, one bias add, one activation) instead of
+        G x {slice, dropout, GEMM, activation} and, backward, G slice gradients that autograd zero-fills and adds."""
+        lins = self.list_linear_v_fusion
+        first = lins[0]
+        same = all((m.in_features, m.out_features, m.p, m.af) == (first.in_features, first.out_features, first.p, first.af)
+                   for m in lins)
+        if not (pooled.is_cuda and same and first.af in (None, "relu")):
+            return torch.cat([lins[g](pooled[:, g, :]) for g in range(self.glimpses)], 1)
+        if pooled.size(-1) != first.in_features:
+            raise ValueError(
+                "[error] putils.Linear(%s, %s): last dimension of input(%s) should equal to in_features(%s)"
+                % (first.in_features, first.out_features, pooled.size(-1), first.in_features))
+        x = F.dropout(pooled, p=first.p, training=self.training) if first.p else pooled
+        w = torch.stack([m.linear.weight for m in lins])                              # [G,A,D]
+        b = torch.stack([m.linear.bias for m in lins])                                # [G,A]
+        y = _activation(ops.batched_linear(x, w, b), first.af, None)                  # [B,G,A]
+        return y.reshape(y.size(0), -1)
+
     def attend(self, inputs, logits):
         """logits [B,N,G] (pre-softmax) -> (x_v, list_att, alpha [B,N,G])."""
         alpha, pooled = ops.softmax_attention_pool(logits, inputs)                     # [B,N,G], [B,G,D]
-        parts = [self.list_linear_v_fusion[g](pooled[:, g, :]) for g in range(self.glimpses)]
-        return torch.cat(parts, 1), torch.split(alpha, 1, dim=2), alpha
+        return self.glimpse_projection(pooled), torch.split(alpha, 1, dim=2), alpha
 
     def forward(self, inputs, fuse):
         x_v, list_att, _ = self.attend(inputs, self.conv_att.pre_activation(fuse))

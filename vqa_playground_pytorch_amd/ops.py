@@ -595,6 +595,35 @@ class LinearFn(torch.autograd.Function):
         return d_x, d_w, d_b
 
 
+class BatchedLinearFn(torch.autograd.Function):
+    """y[b,g,:] = x[b,g,:] W_g^T + bias_g for G same-shaped layers at once (MyATT's per-glimpse MyLinear list,
+    config/CoR2.py:133-134,143-147): one batched library GEMM forward, two backward, and the G bias gradients from one
+    column_sum -- instead of G times {GEMM, slice, add} plus the zero-fill / add chain autograd builds for the G slices
+    of the pooled tensor."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        # x [B,G,K], w [G,A,K], b [G,A] -> [B,G,A]
+        ctx.save_for_backward(x, w)
+        y = torch.bmm(x.transpose(0, 1), w.transpose(1, 2))          # [G,B,A]
+        return y.transpose(0, 1) + b                                  # contiguous [B,G,A]
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        B, G, A = gy.shape
+        gy = gy.contiguous()
+        gy_t = gy.transpose(0, 1)                                      # [G,B,A] view
+        d_x = torch.bmm(gy_t, w).transpose(0, 1) if ctx.needs_input_grad[0] else None
+        d_w = torch.bmm(gy_t.transpose(1, 2), x.transpose(0, 1)) if ctx.needs_input_grad[1] else None
+        d_b = column_sum(gy.view(B, G * A)).view(G, A) if ctx.needs_input_grad[2] else None
+        return d_x, d_w, d_b
+
+
+def batched_linear(x, w, b):
+    return BatchedLinearFn.apply(x, w, b)
+
+
 def linear(x, w, b=None):
     """F.linear for GPU tensors with a replay-safe bias gradient (see LinearFn); CPU tensors take the torch op."""
     if x.is_cuda:
