@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .layers import MutanFusion, MyATT, MyConv1d, MyLinear, QuestionVectorInput
+from .layers import MutanFusion, MyATT, MyConv1d, MyLinear, QuestionVectorInput, my_linears
 
 
 class Model(nn.Module):
@@ -51,12 +51,19 @@ class Model(nn.Module):
         self.expand_q_2 = MyLinear(310, 2048, p=0.5, af="sigmoid")
         self.alpha_dict = {}
 
-    def relation_reduce(self, v_feature, guidance, alpha):
+    def question_projections(self, q_feature):
+        """The four MyLinear(2400 -> 310) that read the question vector (config/CoR2.py:170,180,183,186, applied at
+        :205,:193-194,:230) as one batched GEMM, then the two sigmoid gates expand_q_{1,2}(.) as another.
+        -> (q_feature_low, q_final, q_gate_1 [B,2048], q_gate_2 [B,2048])."""
+        low = my_linears([self.compress_q, self.linear_q, self.compress_q_1, self.compress_q_2], q_feature,
+                         group_first=True)                                                          # [4,B,310]
+        gates = my_linears([self.expand_q_1, self.expand_q_2], low[2:4].transpose(0, 1), group_first=True)   # [2,B,2048]
+        return low[0], low[1], gates[0], gates[1]
+
+    def relation_reduce(self, v_feature, q_gate_1, q_gate_2, alpha):
         """config/CoR2.py:191-199 (decare_cat) + :216 fused: v2[b,j] = sum_i alpha[b,i,0] *
         (v[b,i]*q1[b] + v[b,j]*q2[b]); the [B,N,N,D] tensor is never built (HIP kernel K1)."""
-        q_feature_1 = self.expand_q_1(self.compress_q_1(guidance))
-        q_feature_2 = self.expand_q_2(self.compress_q_2(guidance))
-        return ops.pairwise_relation_reduce(v_feature, q_feature_1, q_feature_2, alpha, glimpse=0,
+        return ops.pairwise_relation_reduce(v_feature, q_gate_1, q_gate_2, alpha, glimpse=0,
                                             mode=self.relation_mode, dual=True)
 
     def forward(self, sample):
@@ -67,13 +74,13 @@ class Model(nn.Module):
             v_feature = v_feature.to(self.compute_dtype)
         q_feature = self.seq2vec(sample["q_idxes"] if "q_idxes" in sample else sample["q"])
 
-        q_feature_low = self.compress_q(q_feature)
+        q_feature_low, q_final, q_gate_1, q_gate_2 = self.question_projections(q_feature)
         v_feature_low = self.compress_v(v_feature)
         fuse1 = self.fusion_vq1(v_feature_low, q_feature_low)
         v1_att, alpha1, alpha1_full = self.att1.attend(v_feature, self.att1.conv_att.pre_activation(fuse1))
 
         # only glimpse 0 weights the relation; v2 has two consumers, each gets its own alias (see ops.pairwise_relation_reduce)
-        v2_feature, v2_for_pooling = self.relation_reduce(v_feature, q_feature, alpha1_full)
+        v2_feature, v2_for_pooling = self.relation_reduce(v_feature, q_gate_1, q_gate_2, alpha1_full)
         v2_feature_low = self.compress_v2(v2_feature)
         fuse2 = self.fusion_vq2(v2_feature_low, q_feature_low)
         v2_att, alpha2, _ = self.att2.attend(v2_for_pooling, self.att2.conv_att.pre_activation(fuse2))
@@ -84,6 +91,5 @@ class Model(nn.Module):
                            "feature": v2_feature[:, 0:2, :].detach().float()}
 
         v_f = torch.cat([v1_att, v2_att], dim=1)
-        q_final = self.linear_q(q_feature)
         x = self.fusion_final(v_f, q_final)
         return self.linear_classif(x)

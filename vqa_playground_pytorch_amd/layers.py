@@ -46,6 +46,41 @@ def _activation(x, af, dim):
     return getattr(F, af)(x)
 
 
+def _same_config(mods, keys):
+    first = mods[0]
+    return all(all(getattr(m, k) == getattr(first, k) for k in keys) for m in mods)
+
+
+def my_linears(mods, x, group_first=False):
+    """[m(x_g) for m in mods] for G same-shaped MyLinear / Linear modules as ONE batched GEMM: x is [B,K] (every module
+    reads the same input, each with its own dropout draw, as when the reference calls them one after the other) or
+    [B,G,K] (module g reads x[:, g, :]).  Returns [B,G,A], or [G,B,A] when group_first (each result contiguous).
+    The modules keep their own parameters (state_dict names unchanged); weights are stacked per call."""
+    first = mods[0]
+    lins = [m.linear for m in mods]
+    p = getattr(first, "p", None)
+    af = getattr(first, "af", None)
+    ok = x.is_cuda and _same_config(mods, ("in_features", "out_features")) and \
+        all(getattr(m, "p", None) == p and getattr(m, "af", None) == af for m in mods) and \
+        all((l.bias is None) == (lins[0].bias is None) for l in lins)
+    G = len(mods)
+    if not ok:
+        outs = [m(x if x.dim() == 2 else x[:, g, :]) for g, m in enumerate(mods)]
+        return torch.stack(outs, 0 if group_first else 1)
+    if x.size(-1) != first.in_features:
+        raise ValueError(
+            "[error] putils.Linear(%s, %s): last dimension of input(%s) should equal to in_features(%s)"
+            % (first.in_features, first.out_features, x.size(-1), first.in_features))
+    if x.dim() == 2:
+        x = x.unsqueeze(1).expand(x.size(0), G, x.size(1))          # stride-0 group axis: no copy
+    training = getattr(first, "training", False)
+    if p and training:
+        x = F.dropout(x, p=p, training=True)                         # one draw over [B,G,K]: G independent masks
+    w = torch.stack([l.weight for l in lins])                        # [G,A,K]
+    b = torch.stack([l.bias for l in lins]) if lins[0].bias is not None else None
+    return _activation(ops.batched_linear(x, w, b, group_first), af, None)
+
+
 class Linear(nn.Module):
     """putils/__init__.py:16-33."""
 
@@ -190,7 +225,11 @@ class MutanFusion(nn.Module):
         if inputs2.dim() != 2 or inputs2.size(0) != inputs1.size(0):
             raise ValueError("MutanFusion: inputs2 must be [B, input_dim2] with the batch of inputs1")
         # question side: R small [B,in2]x[in2,H] GEMMs (Linear's own check raises ValueError on a bad last dim)
-        h2 = torch.stack([lin(inputs2) for lin in self.list_linear2], dim=1)           # [B,R,H]
+        if inputs2.size(-1) != self.input_dim2:
+            raise ValueError(
+                "[error] putils.Linear(%s, %s): last dimension of input(%s) should equal to in_features(%s)"
+                % (self.input_dim2, self.hidden_dim, inputs2.size(-1), self.input_dim2))
+        h2 = my_linears(list(self.list_linear2), inputs2)                              # [B,R,H], one batched GEMM
         weights = [lin.linear.weight for lin in self.list_linear1]
         biases = [lin.linear.bias for lin in self.list_linear1]
         return ops.lowrank_bilinear_fusion(inputs1, h2, weights, biases)
@@ -216,20 +255,7 @@ class MyATT(nn.Module):
         """cat_g MyLinear_g(pooled[:, g, :]) (config/CoR2.py:143-147).  The G layers have one shape, so they run as ONE
         batched GEMM over the [B,G,D] tensor (one dropout draw over all of it, one bias add, one activation) instead of
         G x {slice, dropout, GEMM, activation} and, backward, G slice gradients that autograd zero-fills and adds."""
-        lins = self.list_linear_v_fusion
-        first = lins[0]
-        same = all((m.in_features, m.out_features, m.p, m.af) == (first.in_features, first.out_features, first.p, first.af)
-                   for m in lins)
-        if not (pooled.is_cuda and same and first.af in (None, "relu")):
-            return torch.cat([lins[g](pooled[:, g, :]) for g in range(self.glimpses)], 1)
-        if pooled.size(-1) != first.in_features:
-            raise ValueError(
-                "[error] putils.Linear(%s, %s): last dimension of input(%s) should equal to in_features(%s)"
-                % (first.in_features, first.out_features, pooled.size(-1), first.in_features))
-        x = F.dropout(pooled, p=first.p, training=self.training) if first.p else pooled
-        w = torch.stack([m.linear.weight for m in lins])                              # [G,A,D]
-        b = torch.stack([m.linear.bias for m in lins])                                # [G,A]
-        y = _activation(ops.batched_linear(x, w, b), first.af, None)                  # [B,G,A]
+        y = my_linears(list(self.list_linear_v_fusion), pooled)                       # [B,G,A]
         return y.reshape(y.size(0), -1)
 
     def attend(self, inputs, logits):

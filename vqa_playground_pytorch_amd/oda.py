@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .layers import MutanFusion, MyATT, MyConv1d, MyLinear, QuestionVectorInput
+from .layers import MutanFusion, MyATT, MyConv1d, MyLinear, QuestionVectorInput, my_linears
 
 
 class Model(nn.Module):
@@ -51,12 +51,13 @@ class Model(nn.Module):
         q_feature = self.seq2vec(sample["q_idxes"] if "q_idxes" in sample else sample["q"])
 
         v_feature_low = self.compress_v(v_feature)
-        q_feature_low = self.compress_q(q_feature)
+        # the two MyLinear(2400 -> 310) on the question vector (config/ODA.py:185,193 applied at :207,:233): one batched GEMM
+        q_both = my_linears([self.compress_q, self.linear_q], q_feature, group_first=True)   # [2,B,310]
+        q_feature_low, q_final = q_both[0], q_both[1]
         logits = self.difference_logits(v_feature_low, q_feature_low)
         v_final, alphas, _ = self.att.attend(v_feature, logits)
 
         self.alpha_dict = {"alphas": alphas[0].detach()}
 
-        q_final = self.linear_q(q_feature)
         x = self.fusion_final(v_final, q_final)
         return self.linear_classif(x)

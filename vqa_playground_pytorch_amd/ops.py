@@ -602,26 +602,35 @@ class BatchedLinearFn(torch.autograd.Function):
     of the pooled tensor."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
-        # x [B,G,K], w [G,A,K], b [G,A] -> [B,G,A]
+    def forward(ctx, x, w, b, group_first):
+        # x [B,G,K] (any batch / group strides, K contiguous), w [G,A,K], b [G,A] or None
+        #   -> [B,G,A] contiguous, or [G,B,A] contiguous when group_first
         ctx.save_for_backward(x, w)
+        ctx.group_first = group_first
         y = torch.bmm(x.transpose(0, 1), w.transpose(1, 2))          # [G,B,A]
-        return y.transpose(0, 1) + b                                  # contiguous [B,G,A]
+        if group_first:
+            return y if b is None else y + b.unsqueeze(1)
+        return y.transpose(0, 1).contiguous() if b is None else y.transpose(0, 1) + b
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        B, G, A = gy.shape
         gy = gy.contiguous()
-        gy_t = gy.transpose(0, 1)                                      # [G,B,A] view
+        if ctx.group_first:
+            G, B, A = gy.shape
+            gy_t = gy
+            d_b = torch.stack([column_sum(gy[g]) for g in range(G)]) if ctx.needs_input_grad[2] else None
+        else:
+            B, G, A = gy.shape
+            gy_t = gy.transpose(0, 1)                                  # [G,B,A] view
+            d_b = column_sum(gy.view(B, G * A)).view(G, A) if ctx.needs_input_grad[2] else None
         d_x = torch.bmm(gy_t, w).transpose(0, 1) if ctx.needs_input_grad[0] else None
         d_w = torch.bmm(gy_t.transpose(1, 2), x.transpose(0, 1)) if ctx.needs_input_grad[1] else None
-        d_b = column_sum(gy.view(B, G * A)).view(G, A) if ctx.needs_input_grad[2] else None
-        return d_x, d_w, d_b
+        return d_x, d_w, d_b, None
 
 
-def batched_linear(x, w, b):
-    return BatchedLinearFn.apply(x, w, b)
+def batched_linear(x, w, b=None, group_first=False):
+    return BatchedLinearFn.apply(x, w, b, group_first)
 
 
 def linear(x, w, b=None):
