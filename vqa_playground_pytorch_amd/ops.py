@@ -589,10 +589,28 @@ class LinearFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gy2 = gy.reshape(-1, gy.shape[-1])
+        x2 = x.reshape(-1, x.shape[-1])
         d_x = (gy2 @ w).view(x.shape) if ctx.needs_input_grad[0] else None
-        d_w = gy2.t() @ x.reshape(-1, x.shape[-1]) if ctx.needs_input_grad[1] else None
+        M, K = x2.shape
+        N = w.shape[0]
+        if (LinearFn.engine_dw and ctx.needs_input_grad[1] and M >= 4096 and x.dtype == torch.float32 and K % 2 == 0
+                and N % 2 == 0):
+            # tall weight gradient (the region projections, M = B*N rows): the fp32 tile engine's split-row form, which
+            # also returns the bias gradient as the column sums of its A fragments (no separate reduction)
+            gy2, x2 = gy2.contiguous(), x2.contiguous()
+            d_w = torch.empty_like(w)
+            d_b = torch.empty(N, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+            L_ = _lib.lib()
+            ws_bytes = L_.vqa_linear_act_bwd_workspace_bytes(M, K, N)
+            ws = torch.empty((ws_bytes + 3) // 4, device=x.device, dtype=torch.float32)
+            _launch("linear_act_bwd", (M, K, N, False, False), L_.vqa_linear_act_bwd, _p(x2), K, _p(w), _p(gy2), _p(gy2),
+                    None, _p(d_w), _p(d_b), _p(ws), ws_bytes, M, K, N, 0, 0.0, 0, None)
+            return d_x, d_w, d_b
+        d_w = gy2.t() @ x2 if ctx.needs_input_grad[1] else None
         d_b = column_sum(gy2).to(gy.dtype) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return d_x, d_w, d_b
+
+    engine_dw = __import__("os").environ.get("VQA_ENGINE_DW", "1") == "1"
 
 
 class BatchedLinearFn(torch.autograd.Function):
