@@ -249,6 +249,29 @@ def test_graph_replay_equals_eager_steps():
         assert (p0 - p1).abs().max().item() <= 2e-3 * max(p0.abs().max().item(), 1e-3)
 
 
+def test_stacked_parameters_are_views_of_the_flat_buffer():
+    """After the trainer lays the parameters out, the per-step stack of same-shaped layers (glimpse projections, question
+    projections, Mutan ranks) is a strided view of the flat buffer -- no copy -- and gradients still reach every member."""
+    from vqa_playground_pytorch_amd import ops
+    from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
+    model = build("cor2", 300)
+    lins = [m.linear for m in model.att1.list_linear_v_fusion]
+    before = ops.stack_params([l.weight for l in lins])
+    assert before.data_ptr() != lins[0].weight.data_ptr()            # separate allocations: a real stack
+    tr = DataParallelTrainer(model, lr=1e-4, clip=0.25)
+    for group in ([l.weight for l in lins], [l.bias for l in lins],
+                  [m.linear.weight for m in (model.compress_q, model.linear_q, model.compress_q_1, model.compress_q_2)],
+                  [m.linear.weight for m in model.fusion_vq1.list_linear2]):
+        st = ops.stack_params(group)
+        assert st.data_ptr() == group[0].data_ptr() and st.shape == (len(group),) + tuple(group[0].shape)
+        assert torch.equal(st, torch.stack([p.detach() for p in group]))
+    v, q, a = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(4, answers=300, seed=5))
+    tr.step({"v": v, "q_idxes": q}, a)
+    assert all(l.weight.grad is not None and torch.isfinite(l.weight.grad).all() for l in lins)
+    sd = model.state_dict()
+    assert sd["att1.list_linear_v_fusion.2.linear.weight"].shape == (155, 2048)
+
+
 def test_graph_replays_queued_without_host_sync():
     """bench.py's flow: replays queued back to back with no host read in between, at the headline batch.  The loss and
     gradient norm read once at the end must equal those of the same steps launched kernel by kernel.  (Regression: a

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .layers import MutanFusion, MyATT, MyConv1d, MyLinear, QuestionVectorInput, my_linears
+from .layers import MutanFusion, MyATT, MyConv1d, MyLinear, QuestionVectorInput, linear_stack_groups, my_linears
 
 
 class Model(nn.Module):
@@ -50,6 +50,10 @@ class Model(nn.Module):
         self.compress_q_2 = MyLinear(2400, 310, p=0.5, af="relu")
         self.expand_q_2 = MyLinear(310, 2048, p=0.5, af="sigmoid")
         self.alpha_dict = {}
+
+    def stack_groups(self):
+        return linear_stack_groups([self.compress_q, self.linear_q, self.compress_q_1, self.compress_q_2]) + \
+            linear_stack_groups([self.expand_q_1, self.expand_q_2])
 
     def question_projections(self, q_feature):
         """The four MyLinear(2400 -> 310) that read the question vector (config/CoR2.py:170,180,183,186, applied at

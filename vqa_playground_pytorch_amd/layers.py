@@ -76,9 +76,19 @@ def my_linears(mods, x, group_first=False):
     training = getattr(first, "training", False)
     if p and training:
         x = F.dropout(x, p=p, training=True)                         # one draw over [B,G,K]: G independent masks
-    w = torch.stack([l.weight for l in lins])                        # [G,A,K]
-    b = torch.stack([l.bias for l in lins]) if lins[0].bias is not None else None
+    w = ops.stack_params([l.weight for l in lins])                   # [G,A,K]: a view of the flat parameter buffer
+    b = ops.stack_params([l.bias for l in lins]) if lins[0].bias is not None else None   # when the trainer laid it out
     return _activation(ops.batched_linear(x, w, b, group_first), af, None)
+
+
+def linear_stack_groups(mods):
+    """[[weights...], [biases...]] of same-shaped Linear / MyLinear modules that ``my_linears`` runs as one batched GEMM:
+    the trainer places each list at equal spacing in its flat parameter buffer so that stacking them is a view."""
+    lins = [m.linear for m in mods]
+    groups = [[l.weight for l in lins]]
+    if lins[0].bias is not None:
+        groups.append([l.bias for l in lins])
+    return groups
 
 
 class Linear(nn.Module):
@@ -215,6 +225,9 @@ class MutanFusion(nn.Module):
         self.list_linear1 = nn.ModuleList([Linear(input_dim1, hidden_dim) for _ in range(R)])
         self.list_linear2 = nn.ModuleList([Linear(input_dim2, hidden_dim) for _ in range(R)])
 
+    def stack_groups(self):
+        return linear_stack_groups(list(self.list_linear2)) + linear_stack_groups(list(self.list_linear1))
+
     def forward(self, inputs1, inputs2):
         # (bf16 region tensors carry the feature dim zero-padded to a multiple of 64: see ops.pad_to)
         want = ops.pad_to(self.input_dim1) if inputs1.dtype == torch.bfloat16 else self.input_dim1
@@ -256,6 +269,9 @@ class MyATT(nn.Module):
         self.list_linear_v_fusion = nn.ModuleList(
             [MyLinear(inputs_dim, int(att_dim / glimpses), p=0.5, af=af) for _ in range(glimpses)])
         self.af = af
+
+    def stack_groups(self):
+        return linear_stack_groups(list(self.list_linear_v_fusion))
 
     def glimpse_projection(self, pooled):
         """cat_g MyLinear_g(pooled[:, g, :]) (config/CoR2.py:143-147).  The G layers have one shape, so they run as ONE

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .layers import MutanFusion, MyATT, MyConv1d, MyLinear, QuestionVectorInput, my_linears
+from .layers import MutanFusion, MyATT, MyConv1d, MyLinear, QuestionVectorInput, linear_stack_groups, my_linears
 
 
 class Model(nn.Module):
@@ -30,6 +30,9 @@ class Model(nn.Module):
         self.linear_classif = MyLinear(510, self.num_classes, p=0.5)
         self.alpha_dict = {}
         self._mask_step = 0
+
+    def stack_groups(self):
+        return linear_stack_groups([self.compress_q, self.linear_q])
 
     def difference_logits(self, v_feature_low, q_feature_low):
         """config/ODA.py:216-222 + the dropout/1x1-conv of conv_att (config/ODA.py:149), fused (K2)."""

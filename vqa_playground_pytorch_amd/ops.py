@@ -613,6 +613,36 @@ class LinearFn(torch.autograd.Function):
     engine_dw = __import__("os").environ.get("VQA_ENGINE_DW", "1") == "1"
 
 
+class StackParams(torch.autograd.Function):
+    """torch.stack(params) without the copy when the G same-shaped parameters sit at equal spacing in one buffer (the
+    trainer's FlatState lays the members of a stack group out that way): the result is then a strided view of that
+    buffer.  Backward hands each parameter its slice of the stacked gradient (views, no kernel either)."""
+
+    @staticmethod
+    def forward(ctx, *ps):
+        first = ps[0]
+        G = len(ps)
+        same = all(p.shape == first.shape and p.stride() == first.stride() and p.dtype == first.dtype for p in ps)
+        if same and G > 1 and first.is_contiguous():
+            esz = first.element_size()
+            step = (ps[1].data_ptr() - first.data_ptr()) // esz
+            base = first.untyped_storage().data_ptr()
+            ok = step >= first.numel() and all(ps[i].data_ptr() - first.data_ptr() == i * step * esz and
+                                               ps[i].untyped_storage().data_ptr() == base for i in range(G))
+            if ok:
+                return first.detach().as_strided((G,) + tuple(first.shape), (step,) + tuple(first.stride()),
+                                                 first.storage_offset())
+        return torch.stack([p.detach() for p in ps])
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g.unbind(0))
+
+
+def stack_params(params):
+    return StackParams.apply(*params)
+
+
 class BatchedLinearFn(torch.autograd.Function):
     """y[b,g,:] = x[b,g,:] W_g^T + bias_g for G same-shaped layers at once (MyATT's per-glimpse MyLinear list,
     config/CoR2.py:133-134,143-147): one batched library GEMM forward, two backward, and the G bias gradients from one

@@ -86,6 +86,16 @@ class FlatGradients:
         return norm
 
 
+def collect_stack_groups(model):
+    """Every module's ``stack_groups()`` (lists of same-shaped parameters that are stacked per step)."""
+    groups = []
+    for m in model.modules():
+        fn = getattr(m, "stack_groups", None)
+        if callable(fn):
+            groups.extend(fn())
+    return groups
+
+
 class FlatState:
     """GPU path: parameters, gradients and both Adam moments each live in ONE flat fp32 buffer (segments padded
     to 16 bytes).  ``p.data`` become views of the parameter buffer (state_dict / load_state_dict keep working);
@@ -93,8 +103,23 @@ class FlatState:
     multi-tensor copy (cheaper than zero + ~70 accumulate-adds), which is then the all-reduce payload and the
     input of the fused clip + Adam kernels (csrc/optimizer.hip)."""
 
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, params, stack_groups=()):
+        # members of a stack group (same-shaped parameters that layers.my_linears stacks for one batched GEMM) are laid
+        # out next to each other, in group order, so that the stack is a strided view of this buffer (ops.StackParams)
+        params = [p for p in params if p.requires_grad]
+        member = {}
+        for group in stack_groups:
+            group = [p for p in group if p.requires_grad]
+            if len(group) > 1 and not any(id(p) in member for p in group):
+                for p in group:
+                    member[id(p)] = group
+        ordered, placed = [], set()
+        for p in params:
+            for q in member.get(id(p), [p]):
+                if id(q) not in placed:
+                    placed.add(id(q))
+                    ordered.append(q)
+        self.params = ordered
         dev = self.params[0].device
         offs, off = [], 0
         for p in self.params:
@@ -160,7 +185,7 @@ class DataParallelTrainer:
         self._graph = None
         self._eager_steps = 0
         if self.hip:
-            self.flat = FlatState(model.parameters())
+            self.flat = FlatState(model.parameters(), collect_stack_groups(model))
             self.step_scalars = torch.zeros(2, device=first.device, dtype=torch.float32)
             # pinned staging for the tiny per-step H2D copies: a ring, so a slot is not rewritten while an earlier
             # (asynchronous) copy from it may still be pending on the stream
