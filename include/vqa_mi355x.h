@@ -286,6 +286,19 @@ int vqa_column_sum_bf16(const vqa_bf16_t* x, int ld, float* out, void* workspace
                         int M, int N, vqa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Epilogue / prologue of the batched [B,.] layers (G same-shaped MyLinear / putils.Linear run as one batched
+ * library GEMM: config/CoR2.py:94-122, putils/__init__.py:16-33).
+ *   vqa_bias_act:       out = act(y[g,b,:] + bias[g,:]);  y [G,B,A]; bias row g at bias + g*bias_stride or NULL;
+ *                       out [G,B,A] (group_first != 0) or [B,G,A].  act: 0 none, 1 relu, 2 sigmoid.
+ *   vqa_act_bwd_colsum: gz[g,b,:] = gy * act'(out) written [G,B,A]; d_bias[g,:] = sum_b gz[g,b,:] (fixed order) or
+ *                       NULL; gy and out in the layout vqa_bias_act wrote (group_first).
+ * ------------------------------------------------------------------------------------------- */
+int vqa_bias_act(const float* y, const float* bias, int bias_stride, float* out, int G, int B, int A,
+                 int act, int group_first, vqa_stream_t stream);
+int vqa_act_bwd_colsum(const float* gy, const float* out, float* gz, float* d_bias, int G, int B, int A,
+                       int act, int group_first, vqa_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * KLD-sum loss on soft targets, with its gradient.
  * Replaces MyLoss (train.py:536-544): KLDivLoss(size_average=False)(F.log_softmax(logits), target).
  *

@@ -483,3 +483,27 @@ def test_attention_logits(ops, B, N, Kd, G, p, dtype):
         close("d_x", xt.grad.reshape(M, Kd), dx)
     close("d_w", wt.grad, dw)
     close("d_b", bt.grad, db)
+
+
+# ----------------------------------------------------------------------------------------------- batched [B,.] layers
+@pytest.mark.parametrize("group_first", [False, True])
+@pytest.mark.parametrize("act", [None, "relu", "sigmoid"])
+def test_batched_linear(ops, group_first, act):
+    """G same-shaped layers as one batched GEMM with the fused bias/activation epilogue and activation-gradient/bias-
+    gradient prologue, against per-layer torch autograd."""
+    B, G, Kd, A = 37, 3, 50, 21
+    x = g(seeded.seeded_array((B, G, Kd), 341), True)
+    w = g(seeded.seeded_array((G, A, Kd), 342) / np.sqrt(Kd), True)
+    b = g(seeded.seeded_array((G, A), 343), True)
+    gy = g(seeded.seeded_array((G, B, A) if group_first else (B, G, A), 344))
+    out = ops.batched_linear(x, w, b, group_first, act)
+    out.backward(gy)
+    got = [t.grad.clone() for t in (x, w, b)]
+    for t in (x, w, b):
+        t.grad = None
+    f = {None: lambda z: z, "relu": torch.relu, "sigmoid": torch.sigmoid}[act]
+    ref = torch.stack([f(torch.nn.functional.linear(x[:, k], w[k], b[k])) for k in range(G)], 0 if group_first else 1)
+    close("out", out, ref.detach().cpu().numpy(), 1e-5)
+    ref.backward(gy)
+    for name, a_, t in zip(("d_x", "d_w", "d_b"), got, (x, w, b)):
+        close(name, a_, t.grad.cpu().numpy(), 1e-5)

@@ -67,6 +67,8 @@ SIGNATURES = {
     "vqa_lowrank_bilinear_fusion_bwd_bf16_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i, _c_i, _c_i]),
     "vqa_lowrank_bilinear_fusion_bwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz,
                                                     _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_bias_act": (_c_i, [_c_f, _c_f, _c_i, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_act_bwd_colsum": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_column_sum_workspace_bytes": (_c_sz, [_c_i, _c_i]),
     "vqa_column_sum": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_sz, _c_i, _c_i, _c_st]),
     "vqa_column_sum_bf16": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_sz, _c_i, _c_i, _c_st]),

@@ -1,0 +1,102 @@
+// Epilogue / prologue of the batched [B, .] layers (layers.my_linears: the question projections, the sigmoid gates,
+// Mutan's question-side ranks, the per-glimpse projections -- MyLinear of config/CoR2.py:94-122, putils.Linear of
+// putils/__init__.py:16-33): what surrounds their one batched library GEMM, as one kernel each way.
+//
+//   forward : out = act(y[g,b,:] + bias[g,:]), written [G,B,A] or [B,G,A]          (bias add + activation + layout)
+//   backward: gz[g,b,:] = gy * act'(out), always [G,B,A] (the layout the two backward GEMMs read);
+//             d_bias[g,:] = sum_b gz[g,b,:]   (16 columns x 16 row slices per workgroup, fixed order, no atomics)
+//
+// act: 0 none, 1 relu, 2 sigmoid.  Tiny tensors (B*G*A floats): these kernels exist to cut launches, not bytes.
+#include "common.hpp"
+
+namespace vqa {
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+  if (act == 1) return fmaxf(z, 0.f);
+  if (act == 2) return 1.f / (1.f + expf(-z));
+  return z;
+}
+__device__ __forceinline__ float act_bwd(float g, float out, int act) {
+  if (act == 1) return out > 0.f ? g : 0.f;
+  if (act == 2) return g * out * (1.f - out);
+  return g;
+}
+
+__global__ __launch_bounds__(256) void bias_act_kernel(const float* __restrict__ y, const float* __restrict__ bias,
+                                                       int bias_stride, float* __restrict__ out, int G, int B, int A, int act,
+                                                       int group_first) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (size_t)G * B * A) return;
+  const int a = (int)(e % A);
+  const size_t t = e / A;
+  const int b = (int)(t % B), g = (int)(t / B);
+  const float z = y[e] + (bias != nullptr ? bias[(size_t)g * bias_stride + a] : 0.f);
+  out[group_first ? e : ((size_t)b * G + g) * A + a] = act_fwd(z, act);
+}
+
+// grid (ceil(A/16), G); gy / out are [G,B,A] (group_first) or [B,G,A]
+__global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const float* __restrict__ gy, const float* __restrict__ out,
+                                                             float* __restrict__ gz, float* __restrict__ d_bias, int G, int B,
+                                                             int A, int act, int group_first) {
+  __shared__ float part[16][17];
+  const int c = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int g = blockIdx.y;
+  const int a = blockIdx.x * 16 + c;
+  const bool active = a < A;
+  const int ac = active ? a : A - 1;
+  const size_t row_stride = group_first ? (size_t)A : (size_t)G * A;
+  const size_t base = group_first ? (size_t)g * B * A + ac : (size_t)g * A + ac;
+  float acc = 0.f;
+  for (int b0 = slice; b0 < B; b0 += 64) {  // 16 slices x 4 rows in flight
+    float gv[4], ov[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const size_t off = base + (size_t)min(b0 + 16 * k, B - 1) * row_stride;
+      gv[k] = gy[off];
+      ov[k] = out[off];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int b = b0 + 16 * k;
+      if (b < B) {
+        const float z = act_bwd(gv[k], ov[k], act);
+        if (active) gz[((size_t)g * B + b) * A + a] = z;
+        acc += z;
+      }
+    }
+  }
+  part[slice][c] = acc;
+  __syncthreads();
+  if (slice == 0 && active && d_bias != nullptr) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += part[q][c];
+    d_bias[(size_t)g * A + a] = t;
+  }
+}
+
+}  // namespace vqa
+
+using namespace vqa;
+
+extern "C" int vqa_bias_act(const float* y, const float* bias, int bias_stride, float* out, int G, int B, int A, int act,
+                            int group_first, vqa_stream_t stream) {
+  VQA_REQUIRE(y && out, VQA_E_BADARG, "bias_act: null pointer");
+  VQA_REQUIRE(G > 0 && B > 0 && A > 0 && (bias == nullptr || bias_stride >= A), VQA_E_BADARG,
+              "bias_act: bad sizes G=%d B=%d A=%d bias_stride=%d", G, B, A, bias_stride);
+  VQA_REQUIRE(act >= 0 && act <= 2, VQA_E_BADARG, "bias_act: act must be 0 (none), 1 (relu) or 2 (sigmoid), got %d", act);
+  const size_t n = (size_t)G * B * A;
+  hipLaunchKernelGGL(bias_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), y, bias,
+                     bias_stride, out, G, B, A, act, group_first);
+  return check_launch("bias_act");
+}
+
+extern "C" int vqa_act_bwd_colsum(const float* gy, const float* out, float* gz, float* d_bias, int G, int B, int A, int act,
+                                  int group_first, vqa_stream_t stream) {
+  VQA_REQUIRE(gy && out && gz, VQA_E_BADARG, "act_bwd_colsum: null pointer");
+  VQA_REQUIRE(G > 0 && B > 0 && A > 0 && G <= 65535, VQA_E_BADARG, "act_bwd_colsum: bad sizes G=%d B=%d A=%d", G, B, A);
+  VQA_REQUIRE(act >= 0 && act <= 2, VQA_E_BADARG, "act_bwd_colsum: act must be 0, 1 or 2, got %d", act);
+  hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3((A + 15) / 16, G), dim3(256), 0, static_cast<hipStream_t>(stream), gy, out, gz,
+                     d_bias, G, B, A, act, group_first);
+  return check_launch("act_bwd_colsum");
+}

@@ -78,6 +78,8 @@ def my_linears(mods, x, group_first=False):
         x = F.dropout(x, p=p, training=True)                         # one draw over [B,G,K]: G independent masks
     w = ops.stack_params([l.weight for l in lins])                   # [G,A,K]: a view of the flat parameter buffer
     b = ops.stack_params([l.bias for l in lins]) if lins[0].bias is not None else None   # when the trainer laid it out
+    if af in (None, "", "relu", "sigmoid"):
+        return ops.batched_linear(x, w, b, group_first, af or None)      # bias + activation in the GEMM's epilogue kernel
     return _activation(ops.batched_linear(x, w, b, group_first), af, None)
 
 

@@ -643,42 +643,51 @@ def stack_params(params):
     return StackParams.apply(*params)
 
 
+_ACT_CODES = {None: 0, "": 0, "relu": 1, "sigmoid": 2}
+
+
 class BatchedLinearFn(torch.autograd.Function):
-    """y[b,g,:] = x[b,g,:] W_g^T + bias_g for G same-shaped layers at once (MyATT's per-glimpse MyLinear list,
-    config/CoR2.py:133-134,143-147): one batched library GEMM forward, two backward, and the G bias gradients from one
-    column_sum -- instead of G times {GEMM, slice, add} plus the zero-fill / add chain autograd builds for the G slices
-    of the pooled tensor."""
+    """out[b,g,:] = act(x[b,g,:] W_g^T + bias_g) for G same-shaped layers at once (MyATT's per-glimpse MyLinear list,
+    config/CoR2.py:133-134,143-147; the question projections; Mutan's question-side ranks): one batched library GEMM
+    forward and two backward, with everything around them in one HIP kernel each way (bias + activation + layout;
+    activation gradient + the G bias gradients) -- instead of G times {GEMM, bias, activation, slice} plus the zero-fill /
+    add chain autograd builds for G slices."""
 
     @staticmethod
-    def forward(ctx, x, w, b, group_first):
-        # x [B,G,K] (any batch / group strides, K contiguous), w [G,A,K], b [G,A] or None
+    def forward(ctx, x, w, b, group_first, act):
+        # x [B,G,K] (any batch / group strides, K contiguous), w [G,A,K], b [G,A] (rows at any stride) or None
         #   -> [B,G,A] contiguous, or [G,B,A] contiguous when group_first
-        ctx.save_for_backward(x, w)
-        ctx.group_first = group_first
         y = torch.bmm(x.transpose(0, 1), w.transpose(1, 2))          # [G,B,A]
-        if group_first:
-            return y if b is None else y + b.unsqueeze(1)
-        return y.transpose(0, 1).contiguous() if b is None else y.transpose(0, 1) + b
+        G, B, A = y.shape
+        code = _ACT_CODES[act]
+        out = torch.empty((G, B, A) if group_first else (B, G, A), device=y.device, dtype=torch.float32)
+        if b is not None and b.stride(-1) != 1:
+            b = b.contiguous()
+        _launch("bias_act", (G, B, A, code), _lib.lib().vqa_bias_act, _p(y), _p(b), b.stride(0) if b is not None else 0,
+                _p(out), G, B, A, code, int(bool(group_first)))
+        ctx.save_for_backward(x, w, out)
+        ctx.cfg = (bool(group_first), code, b is not None)
+        return out
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
-        gy = gy.contiguous()
-        if ctx.group_first:
-            G, B, A = gy.shape
-            gy_t = gy
-            d_b = torch.stack([column_sum(gy[g]) for g in range(G)]) if ctx.needs_input_grad[2] else None
-        else:
-            B, G, A = gy.shape
-            gy_t = gy.transpose(0, 1)                                  # [G,B,A] view
-            d_b = column_sum(gy.view(B, G * A)).view(G, A) if ctx.needs_input_grad[2] else None
-        d_x = torch.bmm(gy_t, w).transpose(0, 1) if ctx.needs_input_grad[0] else None
-        d_w = torch.bmm(gy_t.transpose(1, 2), x.transpose(0, 1)) if ctx.needs_input_grad[1] else None
-        return d_x, d_w, d_b, None
+        x, w, out = ctx.saved_tensors
+        group_first, code, has_bias = ctx.cfg
+        gy = _prep("grad_out", gy)
+        G, B, A = out.shape if group_first else (out.shape[1], out.shape[0], out.shape[2])
+        gz = torch.empty(G, B, A, device=gy.device, dtype=torch.float32)
+        d_b = torch.empty(G, A, device=gy.device, dtype=torch.float32) if (has_bias and ctx.needs_input_grad[2]) else None
+        _launch("act_bwd_colsum", (G, B, A, code), _lib.lib().vqa_act_bwd_colsum, _p(gy), _p(out), _p(gz), _p(d_b), G, B, A,
+                code, int(group_first))
+        d_x = torch.bmm(gz, w).transpose(0, 1) if ctx.needs_input_grad[0] else None
+        d_w = torch.bmm(gz.transpose(1, 2), x.transpose(0, 1)) if ctx.needs_input_grad[1] else None
+        return d_x, d_w, d_b, None, None
 
 
-def batched_linear(x, w, b=None, group_first=False):
-    return BatchedLinearFn.apply(x, w, b, group_first)
+def batched_linear(x, w, b=None, group_first=False, act=None):
+    if act not in _ACT_CODES:
+        raise ValueError("batched_linear: act must be None, 'relu' or 'sigmoid', got %r" % (act,))
+    return BatchedLinearFn.apply(x, w, b, group_first, act)
 
 
 def linear(x, w, b=None):
