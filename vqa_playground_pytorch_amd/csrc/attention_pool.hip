@@ -101,7 +101,10 @@ __global__ __launch_bounds__(NT) void attention_pool_fwd_kernel(const float* __r
 // registers; it streams the N region rows once, writes d_v in the same sweep and reduces the G dot products
 // <d_pooled_g, v_n> per row with wave64 shuffles -> LDS -> one float atomic per (workgroup, n, g) into a zeroed
 // accumulator.  Kernel B closes the softmax backward on the tiny [B,N,G] tensors.
-template <typename T, int NT, int G>
+// RS (row split): the NT/64 waves of a workgroup either sit side by side over NT*4 columns (RS = 1) or share NT*4/RS
+// columns and take every RS-th region row each (RS = NT/64).  A small batch (B*D/4 lanes, one 8..16-byte load per row
+// each) cannot keep enough bytes in flight to cover HBM latency; RS = 4 quadruples the lanes.
+template <typename T, int NT, int G, int RS>
 __global__ __launch_bounds__(NT) void attention_pool_bwd_stream_kernel(const float* __restrict__ alpha,
                                                                        const T* __restrict__ v,
                                                                        const float* __restrict__ d_pooled,
@@ -112,7 +115,9 @@ __global__ __launch_bounds__(NT) void attention_pool_bwd_stream_kernel(const flo
   float* red_s = alpha_s + N * G;                   // [N][G]
   const int tid = threadIdx.x, lane = tid & 63;
   const int b = blockIdx.y;
-  const int d = (blockIdx.x * NT + tid) * 4;
+  constexpr int COLS = NT / RS;  // float4 columns per workgroup
+  const int rs = tid / COLS;     // which rows: n = rs, rs + RS, ...
+  const int d = (blockIdx.x * COLS + tid % COLS) * 4;
   const bool active = d < D;
   const int dc = active ? d : 0;
   const int NG = N * G;
@@ -130,13 +135,13 @@ __global__ __launch_bounds__(NT) void attention_pool_bwd_stream_kernel(const flo
   const T* vb = v + (size_t)b * N * D + dc;
   T* dvb = d_v ? d_v + (size_t)b * N * D + dc : nullptr;
   constexpr int RB = 4;  // rows per batch: RB independent 16-byte loads in flight per lane, then RB*G wave reductions
-  for (int n0 = 0; n0 < N; n0 += RB) {
+  for (int n0 = rs; n0 < N; n0 += RB * RS) {
     float4 x[RB];
 #pragma unroll
-    for (int k = 0; k < RB; ++k) x[k] = ld4(vb + (size_t)min(n0 + k, N - 1) * D);
+    for (int k = 0; k < RB; ++k) x[k] = ld4(vb + (size_t)min(n0 + k * RS, N - 1) * D);
 #pragma unroll
     for (int k = 0; k < RB; ++k) {
-      const int n = n0 + k;
+      const int n = n0 + k * RS;
       if (n < N) {
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         float dots[G];
@@ -201,8 +206,14 @@ static int launch_bwd(const float* alpha, const T* v, const float* d_pooled, con
   int rc = zero_async(d_logits, (size_t)B * N * G * sizeof(float), s);
   if (rc != VQA_OK) return rc;
   const size_t lds = 2 * (size_t)N * G * sizeof(float);
-  hipLaunchKernelGGL((attention_pool_bwd_stream_kernel<T, NT, G>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), lds, s, alpha, v,
-                     d_pooled, d_logits, d_v, N, D);
+  if ((long)B * D / 4 < 4 * 65536) {  // fewer than 4 waves per CU worth of lanes: split the rows over the waves
+    constexpr int RS = NT / 64;
+    hipLaunchKernelGGL((attention_pool_bwd_stream_kernel<T, NT, G, RS>), dim3((D / 4 + 63) / 64, B), dim3(NT), lds, s, alpha,
+                       v, d_pooled, d_logits, d_v, N, D);
+  } else {
+    hipLaunchKernelGGL((attention_pool_bwd_stream_kernel<T, NT, G, 1>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), lds, s, alpha,
+                       v, d_pooled, d_logits, d_v, N, D);
+  }
   hipLaunchKernelGGL(attention_softmax_bwd_kernel, dim3(B), dim3(256), lds + kMaxG * sizeof(float), s, alpha, d_logits,
                      d_alpha_ext, d_logits, N, G);
   return check_launch("softmax_attention_pool_bwd");

@@ -158,7 +158,9 @@ __global__ __launch_bounds__(NT) void pairwise_fwd_stream_kernel(const T* __rest
 // TWO: the gradient arrives in two tensors (v2 has two consumers -- the second-step compress and the second-step pooling
 // -- and is returned to autograd as two aliases, so the two gradients are added here in registers instead of by a
 // 3 x B*N*D-element add kernel in front of this one).
-template <typename T, int NT, bool TWO>
+// RS (row split, as in attention_pool.hip): RS = NT/64 makes the waves of a workgroup share NT*4/RS columns and take
+// every RS-th row each -- four times the lanes for a small batch; the three column accumulators then meet in LDS.
+template <typename T, int NT, bool TWO, int RS>
 __global__ __launch_bounds__(NT) void pairwise_bwd_stream_kernel(const T* __restrict__ v, const float* __restrict__ q1,
                                                                  const float* __restrict__ q2,
                                                                  const float* __restrict__ alpha, int astride,
@@ -171,7 +173,9 @@ __global__ __launch_bounds__(NT) void pairwise_bwd_stream_kernel(const T* __rest
   float* red_s = alpha_s + N;                       // [N]
   const int tid = threadIdx.x, lane = tid & 63;
   const int b = blockIdx.y;
-  const int d = (blockIdx.x * NT + tid) * 4;
+  constexpr int COLS = NT / RS;  // float4 columns per workgroup
+  const int rs = tid / COLS, ct = tid % COLS;
+  const int d = (blockIdx.x * COLS + ct) * 4;
   const bool active = d < D;
   const int dc = active ? d : 0;
   for (int i = tid; i < N; i += NT) {
@@ -184,32 +188,45 @@ __global__ __launch_bounds__(NT) void pairwise_bwd_stream_kernel(const T* __rest
   float4 gsum = z, gv = z, pooled = z;
   float asum = 0.f;
 #pragma unroll 6
-  for (int j = 0; j < N; ++j) {
+  for (int j = rs; j < N; j += RS) {
     const float4 vj = ld4(v + base + (size_t)j * D);
     float4 gj = ld4(g + base + (size_t)j * D);
     if constexpr (TWO) gj = add4(gj, ld4(g_b + base + (size_t)j * D));
-    const float a = alpha_s[j];
     gsum = add4(gsum, gj);
     gv = add4(gv, mul4(gj, vj));
-    pooled = fma4(a, vj, pooled);
-    asum += a;
+    pooled = fma4(alpha_s[j], vj, pooled);
+  }
+  for (int j = 0; j < N; ++j) asum += alpha_s[j];
+  if constexpr (RS > 1) {  // column accumulators of the RS row slices meet in LDS (after alpha_s / red_s)
+    float4* comb = reinterpret_cast<float4*>(smem + (((size_t)N * 8 + 15) / 16) * 16);  // [RS][3][COLS]
+    comb[(rs * 3 + 0) * COLS + ct] = gsum;
+    comb[(rs * 3 + 1) * COLS + ct] = gv;
+    comb[(rs * 3 + 2) * COLS + ct] = pooled;
+    __syncthreads();
+    gsum = gv = pooled = z;
+#pragma unroll
+    for (int q = 0; q < RS; ++q) {
+      gsum = add4(gsum, comb[(q * 3 + 0) * COLS + ct]);
+      gv = add4(gv, comb[(q * 3 + 1) * COLS + ct]);
+      pooled = add4(pooled, comb[(q * 3 + 2) * COLS + ct]);
+    }
   }
   const float4 q1v = ld4(q1 + (size_t)b * D + dc), q2v = ld4(q2 + (size_t)b * D + dc);
   const float4 u = active ? mul4(q1v, gsum) : z;
-  if (active) {
+  if (active && rs == 0) {
     st4(d_q1 + (size_t)b * D + d, mul4(pooled, gsum));
     st4(d_q2 + (size_t)b * D + d, scale4(asum, gv));
   }
   const float cpart = active ? dot4(gv, q2v) : 0.f;
   const float4 c2 = scale4(asum, q2v);
   constexpr int RB = 6;  // rows per batch: RB independent 16-byte loads in flight per lane, then RB wave reductions
-  for (int i0 = 0; i0 < N; i0 += RB) {
+  for (int i0 = rs; i0 < N; i0 += RB * RS) {
     float4 vi[RB];
 #pragma unroll
-    for (int k = 0; k < RB; ++k) vi[k] = ld4(v + base + (size_t)min(i0 + k, N - 1) * D);
+    for (int k = 0; k < RB; ++k) vi[k] = ld4(v + base + (size_t)min(i0 + k * RS, N - 1) * D);
 #pragma unroll
     for (int k = 0; k < RB; ++k) {
-      const int i = i0 + k;
+      const int i = i0 + k * RS;
       if (i < N) {
         if (d_v != nullptr && active) {
           float4 gi = ld4(g + base + (size_t)i * D);
@@ -285,12 +302,25 @@ static int pairwise_bwd_impl(const char* who, const T* v, const float* q1, const
   int rc = zero_async(d_alpha, (size_t)B * N * sizeof(float), s);
   if (rc != VQA_OK) return rc;
   constexpr int NT = 256;
+  if ((long)B * D / 4 < 4 * 65536) {  // fewer than 4 waves per CU worth of lanes: split the rows over the waves
+    constexpr int RS = NT / 64;
+    const size_t lds = (((size_t)N * 8 + 15) / 16) * 16 + (size_t)RS * 3 * (NT / RS) * sizeof(float4);
+    const dim3 grid((D / 4 + 63) / 64, B);
+    if (g_v2_b != nullptr) {
+      hipLaunchKernelGGL((pairwise_bwd_stream_kernel<T, NT, true, RS>), grid, dim3(NT), lds, s, v, q1, q2, alpha, alpha_stride,
+                         g_v2, g_v2_b, d_alpha, d_q1, d_q2, d_v, N, D);
+    } else {
+      hipLaunchKernelGGL((pairwise_bwd_stream_kernel<T, NT, false, RS>), grid, dim3(NT), lds, s, v, q1, q2, alpha, alpha_stride,
+                         g_v2, g_v2_b, d_alpha, d_q1, d_q2, d_v, N, D);
+    }
+    return check_launch(who);
+  }
   if (g_v2_b != nullptr) {
-    hipLaunchKernelGGL((pairwise_bwd_stream_kernel<T, NT, true>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), (size_t)N * 8, s, v,
-                       q1, q2, alpha, alpha_stride, g_v2, g_v2_b, d_alpha, d_q1, d_q2, d_v, N, D);
+    hipLaunchKernelGGL((pairwise_bwd_stream_kernel<T, NT, true, 1>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), (size_t)N * 8, s,
+                       v, q1, q2, alpha, alpha_stride, g_v2, g_v2_b, d_alpha, d_q1, d_q2, d_v, N, D);
   } else {
-    hipLaunchKernelGGL((pairwise_bwd_stream_kernel<T, NT, false>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), (size_t)N * 8, s, v,
-                       q1, q2, alpha, alpha_stride, g_v2, g_v2_b, d_alpha, d_q1, d_q2, d_v, N, D);
+    hipLaunchKernelGGL((pairwise_bwd_stream_kernel<T, NT, false, 1>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), (size_t)N * 8, s,
+                       v, q1, q2, alpha, alpha_stride, g_v2, g_v2_b, d_alpha, d_q1, d_q2, d_v, N, D);
   }
   return check_launch(who);
 }
