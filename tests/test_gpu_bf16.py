@@ -186,7 +186,7 @@ def test_pack_bf16(ops):
 
 # ----------------------------------------------------------------------------------------------- K4 in bf16
 @pytest.mark.parametrize("B,N,L,H,R", [(2, 5, 20, 30, 2), (3, 36, 310, 510, 2), (2, 100, 310, 510, 2), (4, 1, 130, 510, 3),
-                                       (130, 1, 64, 256, 1)])
+                                       (130, 1, 64, 256, 1), (520, 3, 64, 510, 2)])   # the last: the large-batch prep form
 def test_lowrank_bilinear_fusion_bf16(ops, B, N, L, H, R):
     Lp = ops.pad_to(L)
     x = bf_round(seeded.seeded_array((B, N, L), 251))

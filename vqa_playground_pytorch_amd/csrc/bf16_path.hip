@@ -244,15 +244,18 @@ __global__ __launch_bounds__(kBfThreads) void bilinear_fwd_bf16_kernel(const bf1
 }
 
 // ------------------------------------------------------------------------------------------ K4 backward prep
-// grid (H/256, B); 256 lanes = 64 columns-of-4 x 4 region slices; the slices meet in LDS.
+// 256 lanes = (256/SL) columns-of-4 x SL region slices; the slices meet in LDS.  SL = 4 at large batches (grid
+// (H/256, B)); SL = 16 (grid (H/64, B)) when that grid would leave the chip short of loads in flight.
+template <int SL>
 __global__ __launch_bounds__(256) void bilinear_bwd_prep_bf16_kernel(const bf16* __restrict__ g, const bf16* __restrict__ h1,
                                                                      const float* __restrict__ h2, bf16* __restrict__ gs,
                                                                      float* __restrict__ dh2, float* __restrict__ gsum,
                                                                      int N, int H, int R) {
-  __shared__ float4 part[3][kBfMaxR + 1][64];
+  constexpr int COLS = 256 / SL;
+  __shared__ float4 part[SL - 1][kBfMaxR + 1][COLS];
   const int b = blockIdx.y;
-  const int c = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const int h = (blockIdx.x * 64 + c) * 4;  // < H: H % 256 == 0
+  const int c = threadIdx.x % COLS, slice = threadIdx.x / COLS;
+  const int h = (blockIdx.x * COLS + c) * 4;  // < H: H % 256 == 0
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 acc[kBfMaxR], q[kBfMaxR], gt = z;
 #pragma unroll
@@ -260,8 +263,8 @@ __global__ __launch_bounds__(256) void bilinear_bwd_prep_bf16_kernel(const bf16*
     acc[r] = z;
     q[r] = r < R ? ld4(h2 + ((size_t)b * R + r) * H + h) : z;
   }
-#pragma unroll 2
-  for (int n = slice; n < N; n += 4) {
+#pragma unroll 4
+  for (int n = slice; n < N; n += SL) {
     const size_t m = (size_t)b * N + n;
     const float4 gv = ld4(g + m * H + h);
     gt = add4(gt, gv);
@@ -286,13 +289,11 @@ __global__ __launch_bounds__(256) void bilinear_bwd_prep_bf16_kernel(const bf16*
     for (int r = 0; r < kBfMaxR; ++r) {
       if (r < R) {
         float4 t = acc[r];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) t = add4(t, part[s][r][c]);
+        for (int s = 0; s < SL - 1; ++s) t = add4(t, part[s][r][c]);
         st4(dh2 + ((size_t)b * R + r) * H + h, t);
       }
     }
-#pragma unroll
-    for (int s = 0; s < 3; ++s) gt = add4(gt, part[s][kBfMaxR][c]);
+    for (int s = 0; s < SL - 1; ++s) gt = add4(gt, part[s][kBfMaxR][c]);
     st4(gsum + (size_t)b * H + h, gt);
   }
 }
@@ -454,8 +455,13 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd_bf16(const vqa_bf16_t* x, const v
   bf16* gs = reinterpret_cast<bf16*>(ws);
   float* gsum = reinterpret_cast<float*>(ws + k4_gs_bytes(B, N, H, R));
   float* slabs = reinterpret_cast<float*>(ws + k4_gs_bytes(B, N, H, R) + k4_gsum_bytes(B, H));
-  hipLaunchKernelGGL(bilinear_bwd_prep_bf16_kernel, dim3(H / 256, B), dim3(256), 0, s, reinterpret_cast<const bf16*>(g),
-                     reinterpret_cast<const bf16*>(h1), h2, gs, d_h2, gsum, N, H, R);
+  if ((long)B * H < 4 * 65536) {
+    hipLaunchKernelGGL(bilinear_bwd_prep_bf16_kernel<16>, dim3(H / 64, B), dim3(256), 0, s, reinterpret_cast<const bf16*>(g),
+                       reinterpret_cast<const bf16*>(h1), h2, gs, d_h2, gsum, N, H, R);
+  } else {
+    hipLaunchKernelGGL(bilinear_bwd_prep_bf16_kernel<4>, dim3(H / 256, B), dim3(256), 0, s, reinterpret_cast<const bf16*>(g),
+                       reinterpret_cast<const bf16*>(h1), h2, gs, d_h2, gsum, N, H, R);
+  }
   hipLaunchKernelGGL(bilinear_db_bf16_kernel, dim3(RH / 64), dim3(256), 0, s, h2, gsum, d_b1, B, H, R);
   if (d_x != nullptr) {
     rc = launch_nt("lowrank_bilinear_fusion_bwd_bf16(dx)", gs, RH, reinterpret_cast<const bf16*>(w1t), RH, nullptr,
