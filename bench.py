@@ -151,6 +151,73 @@ def cpu_baseline(batch=16, budget_s=12.0, hard_timeout_s=90.0):
                 "sample": "did not finish 3 steps of batch %d within %.0f s" % (batch, hard_timeout_s)}
 
 
+def bench_oda_attention(args, world, rank, dev, ops):
+    """the ODA attention op alone.  Given the compressed regions v_low [B,N,310], the compressed
+    question q_low [B,310], the regions v [B,N,2048] and the attention filter (4, N*310): logits (K2, dropout 0.5 in the
+    kernel) -> softmax over regions + pooling (K3), forward + backward with a fixed upstream gradient.  No optimizer."""
+    torch.manual_seed(100 + rank)
+    B, N = args.batch, args.regions
+    vl = torch.relu(torch.randn(B, N, LOW, device=dev)).requires_grad_()
+    ql = torch.relu(torch.randn(B, LOW, device=dev)).requires_grad_()
+    v = torch.randn(B, N, FEAT, device=dev)
+    w = (torch.randn(GLIMPSES, N * LOW, device=dev) / (N * LOW) ** 0.5).requires_grad_()
+    bias = torch.zeros(GLIMPSES, device=dev, requires_grad=True)
+    g_pooled = torch.randn(B, GLIMPSES, FEAT, device=dev)
+
+    def step(seed):
+        for t in (vl, ql, w, bias):
+            t.grad = None
+        logits = ops.object_difference_attention(vl, ql, w, bias, 0.5, seed)
+        alpha, pooled = ops.softmax_attention_pool(logits, v)
+        torch.autograd.backward([pooled], [g_pooled])
+        return alpha
+
+    for i in range(args.warmup):
+        step(1000 + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer = ops.KernelTimer()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        alpha = step(2000 + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.set_kernel_timer(timer)
+    for i in range(min(args.steps, 10)):       # per-kernel durations from a second pass (event pairs around each launch)
+        torch.cuda._sleep(24_000_000)
+        step(3000 + i)
+    torch.cuda.synchronize()
+    ops.set_kernel_timer(None)
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    assert torch.isfinite(alpha).all() and torch.isfinite(vl.grad).all() and torch.isfinite(w.grad).all()
+    if rank == 0:
+        entries = [roofline_entry(name, shape, n, ms, B, N) for (name, shape), (n, ms) in timer.summary().items()
+                   if name in kernel_models(B, N=N)]
+        entries.sort(key=lambda e: -e["mean_ms"] * e["launches"])
+        dominant = next(e for e in entries if e["kernel"] == "object_difference_attention_bwd")
+        print(json.dumps({
+            "metric": "ODA object-difference attention op samples/sec (fwd+bwd), batch %d, %dx%d pairwise" % (B, N, N),
+            "value": round(world * B * args.steps / elapsed, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ODA attention op alone (BASELINE configs[2]; SURVEY 8d config 3): v_low [%d,%d,310], q_low, "
+                                   "v [%d,%d,2048], filter (4, %d) -> alpha, pooled; fwd+bwd, dropout 0.5 in K2"
+                                   % (B, N, B, N, N * LOW), "global_batch": world * B, "launch": "eager",
+                       "parallelism": "dp%d" % world},
+            "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "mean_ms",
+                                                  "launches")},
+            "roofline_all": entries}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-baseline-worker":
         return cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]))
@@ -161,8 +228,9 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (BASELINE config: 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--relation-mode", type=int, default=1, help="K1: 0 = pairwise, 1 = factored")
-    ap.add_argument("--model", default="cor2", choices=["cor2", "oda"], help="cor2 = the headline config; oda = "
-                    "BASELINE configs[2] (object-difference attention head, 3000 answers), reported the same way")
+    ap.add_argument("--model", default="cor2", choices=["cor2", "oda", "oda-attention"], help="cor2 = the headline config; "
+                    "oda = the ODA head (3000 answers), reported the same way; oda-attention = BASELINE configs[2] / SURVEY "
+                    "8d config 3: the object-difference attention op alone (K2 logits + K3 softmax-pool, fwd+bwd)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="f32 = the reference's arithmetic (headline); "
                     "bf16 = BASELINE configs[4]: bf16 storage + bf16 MFMA on the region side, fp32 accumulate, fp32 "
                     "master weights (use with --regions 100 --batch 128)")
@@ -193,6 +261,9 @@ def main():
 
     from vqa_playground_pytorch_amd import CoR2Model, ODAModel, ops
     from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
+
+    if args.model == "oda-attention":
+        return bench_oda_attention(args, world, rank, dev, ops)
 
     torch.manual_seed(1234)
     answers = ANSWERS if args.model == "cor2" else 3000
