@@ -47,6 +47,38 @@ def report(title, res, work, unit):
             print("  %-28s median %8.1f us  min %8.1f us   %6.0f GB/s (%.1f%% of 8000)" % (k, med * 1e3, mn * 1e3, work / med / 1e6, 100 * work / med / 1e6 / 8000))
 
 
+def bf16_section(rounds):
+    """bf16 engine at the configs[4] shapes (B=128, N=100: M=12800) against torch's bf16 matmul (hipBLASLt)."""
+    M = 12800
+    shapes_nt = [("compress fwd  [M,2048]x[320,2048]^T", M, 320, 2048), ("compress dx   [M,320]x[2048,320]^T", M, 2048, 320),
+                 ("K4 dx         [M,1024]x[320,1024]^T", M, 320, 1024)]
+    for title, m, n, k in shapes_nt:
+        a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        b = (torch.randn(n, k, device=dev) / k ** 0.5).to(torch.bfloat16)
+        fns = {"torch (hipBLASLt)": lambda: torch.nn.functional.linear(a, b)}
+        for t in ("128x128", "128x64", "64x128", "64x64"):
+            fns["engine NT " + t] = (lambda t=t: (os.environ.__setitem__("VQA_BF16_TILE", t), ops.gemm_bf16_nt(a, b))[1])
+        res = timeit(fns, rounds)
+        os.environ.pop("VQA_BF16_TILE", None)
+        print("== bf16 NT " + title)
+        for key, ms in res.items():
+            med = statistics.median(ms)
+            print("  %-22s median %7.1f us  %7.1f TF/s (%.1f%% of 2500)" % (key, med * 1e3, 2.0 * m * n * k / med / 1e9, 2.0 * m * n * k / med / 1e9 / 25))
+    shapes_tn = [("compress dW   [M,320]^T x [M,2048]", M, 320, 2048), ("K4 dW         [M,1024]^T x [M,320]", M, 1024, 320)]
+    for title, kd, n1, n2 in shapes_tn:
+        a = torch.randn(kd, n1, device=dev).to(torch.bfloat16)
+        b = torch.randn(kd, n2, device=dev).to(torch.bfloat16)
+        fns = {"torch (hipBLASLt)": lambda: a.t() @ b}
+        for t in ("128x128", "128x64", "64x128", "64x64"):
+            fns["engine TN " + t] = (lambda t=t: (os.environ.__setitem__("VQA_BF16_TILE", t), ops.gemm_bf16_tn(a, b))[1])
+        res = timeit(fns, rounds)
+        os.environ.pop("VQA_BF16_TILE", None)
+        print("== bf16 TN " + title)
+        for key, ms in res.items():
+            med = statistics.median(ms)
+            print("  %-22s median %7.1f us  %7.1f TF/s (%.1f%% of 2500)" % (key, med * 1e3, 2.0 * kd * n1 * n2 / med / 1e9, 2.0 * kd * n1 * n2 / med / 1e9 / 25))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -54,6 +86,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=15)
     args = ap.parse_args()
     only = set(filter(None, args.only.split(",")))
+    if only == {"bf16"}:
+        return bf16_section(args.rounds)
     want = lambda k: not only or k in only  # noqa: E731
     tiles = args.tiles.split(",")
     torch.manual_seed(0)

@@ -12,6 +12,8 @@
 //                db1[r,:] = sum_b h2[b,r,:] * gsum[b,:]
 //                dx  = gs[M, R*H] * W1t[L, R*H]^T           one NT GEMM over the concatenated rank axis
 //                dW1 = gs[M, R*H]^T * x[M, L]               one TN GEMM, split over M into fp32 slabs, fixed-order reduce
+#include <cstdlib>
+
 #include "gemm_bf16_mfma.hpp"
 
 namespace vqa {
@@ -21,20 +23,33 @@ constexpr int kBfMaxR = 8;
 struct BfTileChoice {
   int bm, bn;
 };
-static BfTileChoice choose_bf_tile(long M, long N) {
-  const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-  const double pref[4] = {1.0, 1.1, 1.1, 1.25};
-  double best = 1e300;
-  BfTileChoice out{128, 128};
-  for (int c = 0; c < 4; ++c) {
-    const long tm = (M + cand[c][0] - 1) / cand[c][0], tn = (N + cand[c][1] - 1) / cand[c][1];
-    const double cost = (double)tm * tn * cand[c][0] * cand[c][1] * pref[c];
-    if (cost < best) {
-      best = cost;
-      out = {cand[c][0], cand[c][1]};
+static bool bf_tile_override(BfTileChoice* t) {
+  if (const char* e = std::getenv("VQA_BF16_TILE")) {  // experiment knob, e.g. "128x64"
+    int bm = 0, bn = 0;
+    if (std::sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) {
+      *t = {bm, bn};
+      return true;
     }
   }
-  return out;
+  return false;
+}
+// Tile shapes from the sweeps of tools/kbench.py --only bf16 (M = 12800 rows):
+//   NT (forward / data-gradient form): 128x64 -- a 64-wide tile keeps N = 320 at 5 exact column tiles and 3 workgroups
+//      per CU; with a short K (<= 512: five stages) and a wide output the kernel is bound by its output stores and the
+//      smaller 64x64 tile (more workgroups in flight) wins.
+//   TN (weight-gradient form): 128x128 -- every staged 8x8 block costs 32 v_perm + 8 ds_write_b128, so the tile with
+//      the most MFMAs per staged element wins by 1.5-2x even where it pads N2 = 320 to 384.
+static BfTileChoice choose_bf_tile(long M, long N, long K = 1 << 20) {
+  BfTileChoice t{128, 64};
+  if (bf_tile_override(&t)) return t;
+  if (M <= 64) t.bm = 64;
+  if (K <= 512 && N >= 1024) t.bm = 64;
+  return t;
+}
+static BfTileChoice choose_bf_tile_tn(long N1, long N2) {
+  BfTileChoice t{N1 > 64 ? 128 : 64, N2 > 64 ? 128 : 64};
+  bf_tile_override(&t);
+  return t;
 }
 
 #define VQA_BF_TILE_SWITCH(t, LAUNCH)            \
@@ -133,11 +148,11 @@ static int tn_splits(int Kdim, int N1, int N2, BfTileChoice t) {
   if (s < 1) s = 1;
   return (int)s;
 }
-static BfTileChoice tn_tile(int N1, int N2) { return choose_bf_tile(N1, N2); }
+static BfTileChoice tn_tile(int N1, int N2) { return choose_bf_tile_tn(N1, N2); }
 
 static int launch_nt(const char* who, const bf16* A, int lda, const bf16* B, int ldb, const float* bias, bf16* C, int ldc,
                      int M, int N, int K, int act, hipStream_t s) {
-  const BfTileChoice t = choose_bf_tile(M, N);
+  const BfTileChoice t = choose_bf_tile(M, N, K);
   const int tiles_m = (M + t.bm - 1) / t.bm, tiles_n = (N + t.bn - 1) / t.bn;
 #define LAUNCH(BM_, BN_)                                                                                                 \
   {                                                                                                                      \
@@ -409,7 +424,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_fwd_bf16(const vqa_bf16_t* x, const v
   VQA_REQUIRE(aligned(x, 16) && aligned(w1, 16), VQA_E_UNSUPPORTED, "lowrank_bilinear_fusion_fwd_bf16: x/w1 must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int M = B * N;
-  BfTileChoice t = choose_bf_tile(M, H);
+  BfTileChoice t = choose_bf_tile(M, H, L);
   if (t.bm == 128 && t.bn == 128) t.bn = 64;  // total + per-rank accumulators: 128x128 would drop to one wave per SIMD
   const int tiles_m = (M + t.bm - 1) / t.bm, tiles_n = H / t.bn;
 #define LAUNCH(BM_, BN_)                                                                                                  \
