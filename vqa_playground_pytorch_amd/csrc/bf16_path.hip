@@ -80,6 +80,17 @@ __global__ __launch_bounds__(kBfThreads) void gemm_bf16_nt_kernel(const bf16* __
   bf_zero_acc(acc);
   gemm_bf16_nt_tile<BM, BN>(A, lda, M, B, ldb, N, m0, n0, K, smem, acc);
   const BfAccCoord<BM, BN> cc(m0, n0);
+  if (n0 + BN <= N && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
+    // whole column tile inside the matrix: coalesced 16-byte row stores through an LDS image (the staging ring is idle)
+    float bv[T::TN];
+#pragma unroll
+    for (int tn = 0; tn < T::TN; ++tn) bv[tn] = bias != nullptr ? bias[cc.col(tn)] : 0.f;
+    BfTileStore<BM, BN>::run(smem, C + (size_t)m0 * ldc + n0, ldc, M - m0, [&](int tm, int tn, int i) {
+      const float y = acc[tm][tn][i] + bv[tn];
+      return act == 1 ? fmaxf(y, 0.f) : y;
+    });
+    return;
+  }
   const unsigned lo = cc.loff(ldc);
 #pragma unroll
   for (int tn = 0; tn < T::TN; ++tn) {
@@ -211,6 +222,7 @@ __global__ __launch_bounds__(kBfThreads) void bilinear_fwd_bf16_kernel(const bf1
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* h2_s = reinterpret_cast<float*>(smem);                  // [samples in tile][BN], overlays the staging ring
   int* rowoff_s = reinterpret_cast<int*>(smem + T::kSmemBytes);  // [BM] (sample of the row - b0) * BN
+  char* tile_s = smem + T::kSmemBytes + BM * sizeof(int);        // bf16 output image for the coalesced row stores
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
   const int b0 = m0 / N;
@@ -218,7 +230,7 @@ __global__ __launch_bounds__(kBfThreads) void bilinear_fwd_bf16_kernel(const bf1
   for (int t = threadIdx.x; t < BM; t += kBfThreads) rowoff_s[t] = (min(m0 + t, M - 1) / N - b0) * BN;
   // (visible after the first barrier inside the tile loop)
   const BfAccCoord<BM, BN> cc(m0, n0);
-  const unsigned lo_out = cc.loff(H), lo_h1 = cc.loff(R * H);
+  const unsigned lo_h1 = cc.loff(R * H);
   f32x16 total[T::TM][T::TN];
   bf_zero_acc(total);
   for (int r = 0; r < R; ++r) {
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(kBfThreads) void bilinear_fwd_bf16_kernel(const bf1
     for (int t = threadIdx.x; t < ns * BN; t += kBfThreads)
       h2_s[t] = h2[((size_t)(b0 + t / BN) * R + r) * H + n0 + (t % BN)];
     __syncthreads();
-    // epilogue of rank r: total += (acc + b1_r) * h2[b(row), r, :]
+    // epilogue of rank r: h1_r = acc + b1_r (kept in acc), total += h1_r * h2[b(row), r, :]
 #pragma unroll
     for (int tn = 0; tn < T::TN; ++tn) {
       const int col = cc.col(tn);  // < H: H % 256 == 0 and the grid covers exactly H columns
@@ -240,22 +252,15 @@ __global__ __launch_bounds__(kBfThreads) void bilinear_fwd_bf16_kernel(const bf1
         for (int i = 0; i < 16; ++i) {
           const int row = cc.row(tm, i);
           const float hv = acc[tm][tn][i] + bv;
-          const float qv = h2c[rowoff_s[row - m0]];
           if (h1 != nullptr && row < M) (h1 + (cc.uoff(tm, tn, i, R * H) + (size_t)r * H))[lo_h1] = (bf16)hv;
-          total[tm][tn][i] = fmaf(hv, qv, total[tm][tn][i]);
+          total[tm][tn][i] = fmaf(hv, h2c[rowoff_s[row - m0]], total[tm][tn][i]);
         }
       }
     }
     __syncthreads();  // h2_s is the next rank's staging buffer
   }
-#pragma unroll
-  for (int tn = 0; tn < T::TN; ++tn) {
-#pragma unroll
-    for (int tm = 0; tm < T::TM; ++tm)
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        if (cc.row(tm, i) < M) (out + cc.uoff(tm, tn, i, H))[lo_out] = (bf16)total[tm][tn][i];
-  }
+  BfTileStore<BM, BN>::run(tile_s, out + (size_t)m0 * H + n0, (size_t)H, M - m0,
+                           [&](int tm, int tn, int i) { return total[tm][tn][i]; });
 }
 
 // ------------------------------------------------------------------------------------------ K4 backward prep
@@ -429,7 +434,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_fwd_bf16(const vqa_bf16_t* x, const v
   const int tiles_m = (M + t.bm - 1) / t.bm, tiles_n = H / t.bn;
 #define LAUNCH(BM_, BN_)                                                                                                  \
   {                                                                                                                       \
-    const size_t lds = BfTile<BM_, BN_>::kSmemBytes + BM_ * sizeof(int);                                                  \
+    const size_t lds = BfTile<BM_, BN_>::kSmemBytes + BM_ * sizeof(int) + BfTileStore<BM_, BN_>::kBytes;                  \
     VQA_ENSURE_LDS((bilinear_fwd_bf16_kernel<BM_, BN_>), lds);                                                            \
     hipLaunchKernelGGL((bilinear_fwd_bf16_kernel<BM_, BN_>), dim3(tiles_m * tiles_n), dim3(kBfThreads), lds, s,           \
                        reinterpret_cast<const bf16*>(x), reinterpret_cast<const bf16*>(w1), b1, h2,                       \

@@ -245,6 +245,42 @@ struct BfAccCoord {
   __device__ __forceinline__ unsigned loff(int ld) const { return (unsigned)(lrow * ld + lcol); }
 };
 
+// Coalesced bf16 store of a BM x BN tile of fp32 values held in the accumulator layout: the waves write their values
+// to an LDS image [BM][BN] bf16 (pitch BN*2 + 16 bytes: the two lane halves of a ds_write_b16 land 4 rows = 16 banks
+// apart), then every thread stores 16-byte chunks of whole rows -- BN*2 contiguous bytes per row instead of 2-byte
+// scattered stores, which are what bound the wide-output kernels.  `tile_s` needs BM * (BN*2 + 16) bytes and must not
+// alias anything live; both barriers are inside.  rows_valid = number of tile rows inside the matrix.
+template <int BM, int BN>
+struct BfTileStore {
+  static constexpr int kPitch = BN * 2 + 16;
+  static constexpr int kBytes = BM * kPitch;
+  template <class F>
+  __device__ __forceinline__ static void run(char* tile_s, bf16* __restrict__ dst, size_t ld, int rows_valid, F value) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r0 = (wave >> 1) * (BM / 2) + 4 * (lane >> 5), c0 = (wave & 1) * (BN / 2) + (lane & 31);
+#pragma unroll
+    for (int tm = 0; tm < BM / 64; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < BN / 64; ++tn)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = r0 + tm * 32 + (i & 3) + 8 * (i >> 2), col = c0 + tn * 32;
+          *reinterpret_cast<bf16*>(tile_s + row * kPitch + col * 2) = (bf16)value(tm, tn, i);
+        }
+    __syncthreads();
+    constexpr int CPR = BN / 8;                 // 16-byte chunks per row
+    constexpr int RPP = kBfThreads / CPR;       // rows per pass
+    const int cr = threadIdx.x / CPR, cc = threadIdx.x % CPR;
+#pragma unroll
+    for (int p = 0; p < BM / RPP; ++p) {
+      const int row = p * RPP + cr;
+      if (row < rows_valid)
+        *reinterpret_cast<u32x4*>(dst + (size_t)row * ld + cc * 8) = *reinterpret_cast<const u32x4*>(tile_s + row * kPitch + cc * 16);
+    }
+    __syncthreads();
+  }
+};
+
 template <int TM, int TN>
 __device__ __forceinline__ void bf_zero_acc(f32x16 (&acc)[TM][TN]) {
 #pragma unroll
