@@ -293,6 +293,7 @@ __global__ __launch_bounds__(256) void bilinear_dh2_kernel(const float* __restri
 static int splits_for_dw(int M, int H, int L, int R, TileChoice t) {
   const long tiles = (long)((H + t.bm - 1) / t.bm) * ((L + t.bn - 1) / t.bn) * R;
   long s = (768 + tiles - 1) / tiles;
+  if (const char* e = std::getenv("VQA_K4_DW_SPLITS")) s = std::atol(e);  // experiment knob
   const long max_by_rows = (M + 255) / 256;  // keep >= 256 rows (16 stages) per split
   if (s > max_by_rows) s = max_by_rows;
   if (s > 64) s = 64;

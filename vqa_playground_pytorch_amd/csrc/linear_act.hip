@@ -224,14 +224,22 @@ __global__ __launch_bounds__(256) void linear_dw_reduce_kernel(const float* __re
 
 static int splits_for_linear_dw(int M, int K, int N, TileChoice t) {
   const long tiles = (long)((N + t.bm - 1) / t.bm) * ((K + t.bn - 1) / t.bn);
-  long s = (1024 + tiles - 1) / tiles;
+  long s = (1280 + tiles - 1) / tiles;  // 5 workgroups per CU (sweep at N x K = 310 x 2048, M = 18432: 8 splits)
+  if (const char* e = std::getenv("VQA_LINEAR_DW_SPLITS")) s = std::atol(e);  // experiment knob
   const long max_by_rows = (M + 255) / 256;
   if (s > max_by_rows) s = max_by_rows;
   if (s > 64) s = 64;
   if (s < 1) s = 1;
   return (int)s;
 }
-static TileChoice linear_dw_tile() { return tile_override_or({64, 64, 2}); }
+static TileChoice linear_dw_tile() {
+  TileChoice t = tile_override_or({64, 64, 2});
+  if (const char* e = std::getenv("VQA_LINEAR_DW_TILE")) {  // experiment knob
+    int bm = 0, bn = 0;
+    if (std::sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) t = {bm, bn, 2};
+  }
+  return t;
+}
 
 }  // namespace vqa
 
