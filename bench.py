@@ -235,6 +235,9 @@ def main():
                     "bf16 = BASELINE configs[4]: bf16 storage + bf16 MFMA on the region side, fp32 accumulate, fp32 "
                     "master weights (use with --regions 100 --batch 128)")
     ap.add_argument("--regions", type=int, default=REGIONS, help="regions per image (36; configs[4]: 100 dense regions)")
+    ap.add_argument("--encoder", action="store_true", help="include the question encoder (SURVEY 8f row 3): SkipThoughts = "
+                    "embedding(620) + 26-step BayesianGRU(2400), randomly initialised, fed int64 token ids [B,26] instead of "
+                    "question vectors")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying "
                     "the captured hipGraphs of the step")
     args = ap.parse_args()
@@ -271,8 +274,10 @@ def main():
     if bf16 and args.model != "cor2":
         raise SystemExit("--dtype bf16 is the CoR2 configuration (BASELINE configs[4])")
     if args.model == "cor2":
-        model = CoR2Model(["PAD", "UNK"], answers, relation_mode=args.relation_mode,
-                          compute_dtype=torch.bfloat16 if bf16 else None).to(dev).train()
+        vocab = ["PAD", "UNK"] + ["w%d" % i for i in range(14998)] if args.encoder else ["PAD", "UNK"]
+        model = CoR2Model(vocab, answers, relation_mode=args.relation_mode,
+                          compute_dtype=torch.bfloat16 if bf16 else None,
+                          seq2vec="skipthoughts" if args.encoder else None).to(dev).train()
     else:
         model = ODAModel(["PAD", "UNK"], answers).to(dev).train()
     trainer = DataParallelTrainer(model, lr=1e-4, clip=0.25, graph=not args.no_graph)
@@ -282,6 +287,9 @@ def main():
     if bf16:
         v = v.to(torch.bfloat16)   # the feature store hands over bf16 regions: half the bytes of the dominant stream
     q = torch.randn(B, QDIM, device=dev)
+    if args.encoder:      # left-aligned token ids, 0 = PAD, lengths 5..26 (datasets.py:671-672)
+        lengths = torch.randint(5, 27, (B,), device=dev)
+        q = torch.randint(1, 15000, (B, 26), device=dev) * (torch.arange(26, device=dev)[None, :] < lengths[:, None])
     a = torch.softmax(2.0 * torch.randn(B, answers, device=dev), dim=1)
     sample = {"v": v, "q_idxes": q}
 
@@ -346,8 +354,9 @@ def main():
             else "object_difference_attention_fwd"
         dominant = next((e for e in entries if e["kernel"] == head), entries[0])
         result = {
-            "metric": "VQA samples/sec (fwd+bwd), %s batch %d, %dx2048 regions"
-                      % ("CoR2" if args.model == "cor2" else "ODA", B, args.regions),
+            "metric": "VQA samples/sec (fwd+bwd), %s batch %d, %dx2048 regions%s"
+                      % ("CoR2" if args.model == "cor2" else "ODA", B, args.regions,
+                         ", incl. SkipThoughts question encoder" if args.encoder else ""),
             "value": round(world * B * args.steps / elapsed, 1),
             "unit": "samples/s",
             "n_gpus": world,

@@ -299,6 +299,27 @@ int vqa_act_bwd_colsum(const float* gy, const float* out, float* gz, float* d_bi
                        int act, int group_first, vqa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Gate math of the BayesianGRU question encoder, one call per time step each way (putils/__init__.py:704-731
+ * with the cell of :604-646 and the sequence-shared dropout of :503-539); the three recurrent GEMMs of a
+ * step run as one batched library GEMM a[g] = hm[g] W_g^T in the host code (ops.GruSequence).
+ *   forward : r = sigmoid(gi_r[t] + a_r); i = sigmoid(gi_i[t] + a_i); n = af(gi_n[t] + r*a_n);
+ *             h_new = (1-i)*n + i*h_prev; hm_next[g] = h_new * masks[g] (the next step's GEMM inputs; NULL at
+ *             the last step); r, i, n, a_n saved for backward.
+ *   backward: dh = d_out_t + carry_in + sum_g dhm[g]*masks[g] (each may be NULL = 0); writes gz[g] = gradient
+ *             at a[g], d_gi[:, :, t, :] and carry_out = dh * i.
+ * gi, d_gi [3,B,T,H]; a, dhm, masks [3,B,H] (masks NULL = no dropout); h_prev, h_new, r, i, n, an, d_out_t,
+ * carry [B,H]; hm_next / gz: three [B,H] slabs hist_group_stride elements apart (slot t of a [3,T,B,H]
+ * history).  af: 1 relu, 3 tanh.  Limit: H % 4 == 0.
+ * ------------------------------------------------------------------------------------------- */
+int vqa_gru_gates_fwd(const float* gi, const float* a, const float* h_prev, const float* masks,
+                      float* h_new, float* hm_next, size_t hist_group_stride, float* r_s, float* i_s,
+                      float* n_s, float* an_s, int B, int T, int H, int t, int af, vqa_stream_t stream);
+int vqa_gru_gates_bwd(const float* d_out_t, const float* carry_in, const float* dhm, const float* masks,
+                      const float* r_s, const float* i_s, const float* n_s, const float* an_s,
+                      const float* h_prev, float* gz, size_t hist_group_stride, float* d_gi,
+                      float* carry_out, int B, int T, int H, int t, int af, vqa_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * KLD-sum loss on soft targets, with its gradient.
  * Replaces MyLoss (train.py:536-544): KLDivLoss(size_average=False)(F.log_softmax(logits), target).
  *

@@ -73,3 +73,55 @@ def test_encoder_feeds_the_hip_head(golden_dir):
     logits.sum().backward()
     assert logits.shape == (4, 50) and torch.isfinite(logits).all()
     assert model.seq2vec.gru.gru_cell.weight_hn.weight.grad is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("af", ["relu", "tanh"])
+@pytest.mark.parametrize("train", [False, True])
+def test_gpu_gru_sequence_matches_the_torch_path(af, train):
+    """The GPU form of BayesianGRU (batched input projections + ops.GruSequence: one batched recurrent GEMM and one HIP
+    gate kernel per step, each way) against the step-by-step torch form on CPU -- outputs, all hidden states and every
+    parameter gradient; in train mode both sides get the same sequence-shared dropout masks."""
+    dev = torch.device("cuda:0")
+    B, T, K, H = 5, 7, 12, 16
+    torch.manual_seed(3)
+    cpu = BayesianGRU(K, H, dropout=0.25, af=af)
+    gpu = BayesianGRU(K, H, dropout=0.25, af=af)
+    gpu.load_state_dict(cpu.state_dict())
+    gpu.to(dev)
+    cpu.train(train)
+    gpu.train(train)
+    gen = torch.Generator().manual_seed(11)
+    masks = [(torch.rand(B, 1, K, generator=gen) > 0.25).float() / 0.75 for _ in range(3)] + \
+            [(torch.rand(B, H, generator=gen) > 0.25).float() / 0.75 for _ in range(3)]
+    for m, device in ((cpu, "cpu"), (gpu, dev)):
+        queue = [t.to(device) for t in masks]
+        m._mask = (lambda like, q=queue: q.pop(0)) if train else (lambda like: None)
+    x = torch.randn(B, T, K, generator=gen)
+    lengths = torch.tensor([7, 3, 1, 5, 7])
+    gy = torch.randn(B, H, generator=gen)
+    xc, xg = x.clone().requires_grad_(), x.clone().to(dev).requires_grad_()
+    yc = cpu(xc, lengths)
+    yg = gpu(xg, lengths.to(dev))
+    assert np.abs(yg.detach().cpu().numpy() - yc.detach().numpy()).max() <= 1e-5
+    assert np.abs(gpu.all_hiddens.cpu().numpy() - cpu.all_hiddens.numpy()).max() <= 1e-5
+    yc.backward(gy)
+    yg.backward(gy.to(dev))
+    assert np.abs(xg.grad.cpu().numpy() - xc.grad.numpy()).max() <= 1e-5 * max(1.0, float(xc.grad.abs().max()))
+    for (n, pc), (_, pg) in zip(cpu.named_parameters(), gpu.named_parameters()):
+        scale = max(float(pc.grad.abs().max()), 1e-6)
+        assert np.abs(pg.grad.cpu().numpy() - pc.grad.numpy()).max() <= 2e-5 * scale, n
+
+
+@pytest.mark.gpu
+def test_gpu_embedding_backward():
+    from vqa_playground_pytorch_amd import ops
+    dev = torch.device("cuda:0")
+    w = torch.randn(9, 6, device=dev, requires_grad=True)
+    idx = torch.tensor(IDX, device=dev)
+    g = torch.randn(4, 6, 6, device=dev)
+    ops.embedding(w, idx, 0).backward(g)
+    got = w.grad.clone()
+    w.grad = None
+    torch.nn.functional.embedding(idx, w, padding_idx=0).backward(g)
+    assert torch.allclose(got, w.grad, atol=1e-6)

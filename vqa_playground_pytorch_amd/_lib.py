@@ -67,6 +67,10 @@ SIGNATURES = {
     "vqa_lowrank_bilinear_fusion_bwd_bf16_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i, _c_i, _c_i]),
     "vqa_lowrank_bilinear_fusion_bwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz,
                                                     _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_gru_gates_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_f, _c_f, _c_f, _c_f,
+                                 _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_gru_gates_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_f, _c_f,
+                                 _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_bias_act": (_c_i, [_c_f, _c_f, _c_i, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_act_bwd_colsum": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_column_sum_workspace_bytes": (_c_sz, [_c_i, _c_i]),

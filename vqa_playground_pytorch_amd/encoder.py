@@ -50,9 +50,42 @@ class BayesianGRU(nn.Module):
             return None
         return torch.bernoulli(torch.full_like(like, 1.0 - self.dropout)) / (1.0 - self.dropout)
 
+    def stack_groups(self):
+        c = self.gru_cell
+        inp, hid = (c.weight_ir, c.weight_ii, c.weight_in), (c.weight_hr, c.weight_hi, c.weight_hn)
+        groups = [[m.weight for m in inp], [m.weight for m in hid]]
+        if inp[0].bias is not None:
+            groups.append([m.bias for m in inp])
+        return groups
+
+    def _forward_hip(self, x, lengths):
+        """GPU form: the three input projections of all T steps as one batched GEMM, then ops.GruSequence (per step one
+        batched recurrent GEMM + one gate kernel; csrc/gru.hip)."""
+        c = self.gru_cell
+        B, T, K = x.shape
+        inp, hid = (c.weight_ir, c.weight_ii, c.weight_in), (c.weight_hr, c.weight_hi, c.weight_hn)
+        xg = x.reshape(B * T, 1, K).expand(B * T, 3, K)                        # stride-0 gate axis
+        if self.training and self.dropout > 0:
+            mx = torch.stack([self._mask(x[:, :1, :]) for _ in range(3)], 2)   # [B,1,3,K]: shared over time
+            xg = (x.unsqueeze(2) * mx).reshape(B * T, 3, K)
+            mh = torch.stack([self._mask(x.new_zeros(B, self.hidden_size)) for _ in range(3)])   # [3,B,H]
+        else:
+            mh = None
+        w_in = ops.stack_params([m.weight for m in inp])
+        b_in = ops.stack_params([m.bias for m in inp]) if inp[0].bias is not None else None
+        gi = ops.batched_linear(xg, w_in, b_in, group_first=True).view(3, B, T, self.hidden_size)
+        out = ops.gru_sequence(gi, ops.stack_params([m.weight for m in hid]), mh, self.af)      # [T,B,H]
+        if not self.return_last:
+            return out.transpose(0, 1)
+        self.all_hiddens = out.detach().transpose(0, 1)
+        idx = (lengths.long() - 1) % T
+        return out[idx, torch.arange(B, device=x.device)]
+
     def forward(self, x, lengths=None):
         c, af = self.gru_cell, _af(self.af)
         B, T, _ = x.shape
+        if x.is_cuda and self.af in ("relu", "tanh") and c.weight_hr.bias is None and self.hidden_size % 4 == 0:
+            return self._forward_hip(x, lengths)
         mx = [self._mask(x[:, :1, :]) for _ in range(3)]                       # [B,1,in], shared over time
         h = x.new_zeros(B, self.hidden_size)
         mh = [self._mask(h) for _ in range(3)]                                 # [B,hidden]
@@ -109,7 +142,7 @@ class SkipThoughts(nn.Module):
     def forward(self, x, return_hidden=False):
         if x.dtype != torch.long:
             raise ValueError("SkipThoughts expects int64 token ids [B,T] (0 = PAD)")
-        emb = self.embedding(x)
+        emb = ops.embedding(self.embedding.weight, x, self.embedding.padding_idx) if x.is_cuda else self.embedding(x)
         lengths = x.size(1) - x.eq(0).sum(1)
         out = self.gru(emb, lengths)
         return (out, self.gru.all_hiddens) if return_hidden else out

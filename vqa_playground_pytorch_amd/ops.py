@@ -697,6 +697,93 @@ def linear(x, w, b=None):
     return torch.nn.functional.linear(x, w, b)
 
 
+class GruSequence(torch.autograd.Function):
+    """The recurrent part of putils.BayesianGRU.forward (putils/__init__.py:704-731): T steps of
+    r,i = sigmoid(gi_{r,i}[t] + W_h{r,i}(h*m)), n = af(gi_n[t] + r * W_hn(h*m_n)), h = (1-i) n + i h.
+    gi [3,B,T,H] (the input-side projections of all steps), w [3,H,H] (W_hr, W_hi, W_hn stacked), masks [3,B,H] or
+    None (sequence-shared dropout) -> all hidden states [T,B,H].  Per step: ONE batched library GEMM + ONE gate kernel
+    (csrc/gru.hip) each way; the recurrent weight gradient is one batched GEMM over all T*B rows at the end."""
+
+    @staticmethod
+    def forward(ctx, gi, w, masks, af):
+        gi, w = _prep("gi", gi), _prep("w", w)
+        masks = _prep("masks", masks) if masks is not None else None
+        G, B, T, H = gi.shape
+        if G != 3 or w.shape != (3, H, H) or (masks is not None and masks.shape != (3, B, H)):
+            raise ValueError("gru_sequence: gi [3,B,T,H], w [3,H,H], masks [3,B,H] expected")
+        code = {"relu": 1, "tanh": 3}[af]
+        dev = gi.device
+        L_ = _lib.lib()
+        out = torch.empty(T, B, H, device=dev, dtype=torch.float32)
+        hist = torch.zeros(3, T, B, H, device=dev, dtype=torch.float32)        # hm_t = h_{t-1} * m_g; hm_0 = 0
+        saved = torch.empty(4, T, B, H, device=dev, dtype=torch.float32)       # r, i, n, a_n
+        h0 = torch.zeros(B, H, device=dev, dtype=torch.float32)
+        wt = w.transpose(1, 2)
+        gs = T * B * H
+        for t in range(T):
+            a = torch.bmm(hist[:, t], wt)                                       # [3,B,H]
+            nxt = ctypes.c_void_p(hist.data_ptr() + 4 * (t + 1) * B * H) if t + 1 < T else None
+            _launch("gru_gates_fwd", (B, T, H), L_.vqa_gru_gates_fwd, _p(gi), _p(a), _p(out[t - 1] if t else h0), _p(masks),
+                    _p(out[t]), nxt, gs, _p(saved[0, t]), _p(saved[1, t]), _p(saved[2, t]), _p(saved[3, t]), B, T, H, t, code)
+        ctx.save_for_backward(w, masks, out, hist, saved, h0)
+        ctx.cfg = (B, T, H, code)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        w, masks, out, hist, saved, h0 = ctx.saved_tensors
+        B, T, H, code = ctx.cfg
+        d_out = _prep("grad_out", d_out)
+        dev = d_out.device
+        L_ = _lib.lib()
+        gz = torch.empty(3, T, B, H, device=dev, dtype=torch.float32)
+        d_gi = torch.empty(3, B, T, H, device=dev, dtype=torch.float32)
+        carry = [torch.empty(B, H, device=dev, dtype=torch.float32) for _ in range(2)]
+        gs = T * B * H
+        dhm = None
+        for t in range(T - 1, -1, -1):
+            _launch("gru_gates_bwd", (B, T, H), L_.vqa_gru_gates_bwd, _p(d_out[t]), _p(carry[(t + 1) & 1]) if t + 1 < T else None,
+                    _p(dhm), _p(masks), _p(saved[0, t]), _p(saved[1, t]), _p(saved[2, t]), _p(saved[3, t]),
+                    _p(out[t - 1] if t else h0), ctypes.c_void_p(gz.data_ptr() + 4 * t * B * H), gs, _p(d_gi), _p(carry[t & 1]),
+                    B, T, H, t, code)
+            if t > 0:
+                dhm = torch.bmm(gz[:, t], w)                                    # gradient at hm_t: [3,B,H]
+        d_w = torch.bmm(gz.view(3, T * B, H).transpose(1, 2), hist.view(3, T * B, H)) if ctx.needs_input_grad[1] else None
+        return d_gi, d_w, None, None
+
+
+def gru_sequence(gi, w, masks, af):
+    if af not in ("relu", "tanh"):
+        raise ValueError("gru_sequence: af must be 'relu' or 'tanh', got %r" % (af,))
+    return GruSequence.apply(gi, w, masks, af)
+
+
+class EmbeddingFn(torch.autograd.Function):
+    """nn.Embedding lookup whose backward is a zero-filled table + index_add_ (atomic adds): torch's own
+    embedding_dense_backward issues a memset, which must not sit inside a replayed hipGraph (csrc/api.hip)."""
+
+    @staticmethod
+    def forward(ctx, weight, idx, padding_idx):
+        ctx.save_for_backward(idx)
+        ctx.cfg = (weight.shape, padding_idx)
+        return weight.index_select(0, idx.reshape(-1)).view(*idx.shape, weight.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        shape, padding_idx = ctx.cfg
+        flat = idx.reshape(-1)
+        g2 = g.reshape(flat.numel(), shape[1])
+        if padding_idx is not None:
+            g2 = g2 * (flat != padding_idx).unsqueeze(1)
+        d_w = torch.zeros(shape, device=g.device, dtype=g.dtype).index_add_(0, flat, g2)
+        return d_w, None, None
+
+
+def embedding(weight, idx, padding_idx=None):
+    return EmbeddingFn.apply(weight, idx, padding_idx)
+
+
 class KldSumLoss(torch.autograd.Function):
     """KLDivLoss(size_average=False)(log_softmax(logits), target) (train.py:536-544) with its gradient from the same
     pass over the logits; the B row losses are added in a fixed order (no atomics, no memset: replays cleanly)."""
