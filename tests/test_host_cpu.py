@@ -108,3 +108,38 @@ def test_product_never_imports_oracle():
         path = os.path.join(ROOT, f)
         if os.path.exists(path):
             assert not re.search(r"^\s*(from|import)\s+oracle", open(path).read(), re.M)
+
+
+def test_my_linears_cpu_path_and_stack_groups():
+    """Host logic of the batched [B,.] layers without a GPU: the per-module fallback of layers.my_linears (CPU tensors),
+    ops.StackParams on separately allocated parameters (a real stack whose gradient reaches every member), and the stack
+    groups a model hands to the trainer (same-shaped members, no parameter in two groups)."""
+    import torch
+
+    from vqa_playground_pytorch_amd import CoR2Model, ODAModel, layers, ops
+    from vqa_playground_pytorch_amd.trainer import collect_stack_groups
+
+    torch.manual_seed(0)
+    mods = [layers.MyLinear(6, 5, p=0.5, af="relu").eval() for _ in range(3)]
+    x = torch.randn(4, 6)
+    got = layers.my_linears(mods, x)
+    assert got.shape == (4, 3, 5)
+    for g, m in enumerate(mods):
+        assert torch.equal(got[:, g], m(x))
+    got_gf = layers.my_linears(mods, torch.stack([x, 2 * x, 3 * x], 1), group_first=True)
+    assert got_gf.shape == (3, 4, 5) and torch.equal(got_gf[2], mods[2](3 * x))
+
+    ps = [torch.randn(2, 3, requires_grad=True) for _ in range(4)]
+    st = ops.stack_params(ps)
+    assert st.shape == (4, 2, 3) and torch.equal(st, torch.stack([p.detach() for p in ps]))
+    (st * torch.arange(4.0).view(4, 1, 1)).sum().backward()
+    assert all(torch.equal(p.grad, torch.full((2, 3), float(i))) for i, p in enumerate(ps))
+
+    for model in (CoR2Model(["PAD", "UNK"], 50), ODAModel(["PAD", "UNK"], 50)):
+        groups = collect_stack_groups(model)
+        assert len(groups) >= 6
+        seen = set()
+        for group in groups:
+            assert len(group) >= 2 and all(p.shape == group[0].shape for p in group)
+            assert not (seen & {id(p) for p in group})
+            seen |= {id(p) for p in group}
