@@ -47,16 +47,16 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const float* __rest
   const size_t row_stride = group_first ? (size_t)A : (size_t)G * A;
   const size_t base = group_first ? (size_t)g * B * A + ac : (size_t)g * A + ac;
   float acc = 0.f;
-  for (int b0 = slice; b0 < B; b0 += 64) {  // 16 slices x 4 rows in flight
-    float gv[4], ov[4];
+  for (int b0 = slice; b0 < B; b0 += 128) {  // 16 slices x 8 rows in flight (the loop is a chain of L2 round trips)
+    float gv[8], ov[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 8; ++k) {
       const size_t off = base + (size_t)min(b0 + 16 * k, B - 1) * row_stride;
       gv[k] = gy[off];
       ov[k] = out[off];
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 8; ++k) {
       const int b = b0 + 16 * k;
       if (b < B) {
         const float z = act_bwd(gv[k], ov[k], act);
