@@ -226,7 +226,9 @@ struct SrcMC {  // X[k][mn], MN-contiguous rows of stride ld.  Needs K >= 1, MN 
 // operand fragments read one stage ahead (+63 VGPRs -> 2 waves per SIMD instead of 4: 83 vs 90 TF/s on the K4 forward);
 // a persistent workgroup streaming ONE pipeline across all its (tile, rank) segments so that the next tile's loads
 // overlap the current epilogue (per-stage descriptor/address recomputation cost more than the hidden pipeline fill:
-// 60 vs 90 TF/s) -- to be retried with incrementally updated per-slot addresses.
+// 60 vs 90 TF/s) -- to be retried with incrementally updated per-slot addresses; BK = 32 for the split-row weight
+// gradient of the region projections (2304 rows per split: step 3.66 ms against 3.61 with BK = 16); 128x64 / 64x128 tiles
+// for the same kernel (3.84 / 3.70 ms against 3.68).
 
 // Host-side tile choice: fewest CU-rounds of (padded) work, mild preference for the larger tile.
 struct TileChoice {
