@@ -12,6 +12,8 @@
 //             dW1_r = (g * h2_r)^T x     (split over M, slabs reduced in fixed order) 2*M*H*L*R FLOP
 //             dh2[b,r,:] = sum_n g[b,n,:] * h1[b,n,r,:] ;  db1_r = sum_b h2[b,r,:] * sum_n g[b,n,:]
 // (g * h2_r) is never materialised: it is formed while the A tile is staged.
+#include <cstdlib>
+
 #include "gemm_f32_mfma.hpp"
 
 namespace vqa {
@@ -220,6 +222,123 @@ __global__ __launch_bounds__(kGemmThreads) void bilinear_dw_kernel(const float* 
   }
 }
 
+// ---- weight gradient, per-sample form ------------------------------------------------------------------------
+// dW1_r[h,l] = sum_b h2[b,r,h] * P_b[h,l],  P_b = G_b^T X_b over the N rows of sample b: the rank scale is constant inside
+// a sample, so ONE MFMA accumulation P serves all R ranks (the (g*h2_r)-scaled form above repeats the whole contraction
+// per rank) and both operands are staged as they lie in memory (no scale, no second load per slot).  The K loop walks
+// the samples of a row slab inside one software pipeline: every sample is padded to whole 16-row stages (36 -> 48
+// virtual rows, the pad zero-filled at LDS-store time) and after its last stage a hook folds P into the R accumulators
+// (acc_r += h2[b,r,row] * P) and clears it.  MFMA work: (padded/N)/R of the scaled form = 0.67x at N = 36, R = 2.
+struct SampleRows {
+  int N, NP, b_lo, nb;
+  uint32_t inv;  // floor(2^32 / NP) + 1: exact quotient for the few thousand virtual rows of a slab
+  __device__ __forceinline__ void split(int kp, int& b, int& i) const {
+    b = (int)__umulhi((uint32_t)kp, inv);
+    i = kp - b * NP;
+  }
+};
+struct SrcSampleMC {  // X[virtual row][mn], MN-contiguous rows of stride ld
+  using Raw = float2;
+  const float* p;
+  int ld, MN;
+  SampleRows sr;
+  __device__ __forceinline__ Raw fetch(int mn, int kp) const {
+    int b, i;
+    sr.split(kp, b, i);
+    const int row = (sr.b_lo + min(b, sr.nb - 1)) * sr.N + min(i, sr.N - 1);
+    return ld2(p + (size_t)row * ld + min(mn, MN - 2));
+  }
+  __device__ __forceinline__ float2 finish(Raw v, int mn, int kp) const {
+    int b, i;
+    sr.split(kp, b, i);
+    return keep_if(mn < MN && i < sr.N && b < sr.nb, v);
+  }
+};
+
+template <int BM, int BN, int PF, int R>
+__global__ __launch_bounds__(kGemmThreads) void bilinear_dw_sample_kernel(
+    const float* __restrict__ g, const float* __restrict__ h2, const float* __restrict__ x, int ldx, float* __restrict__ slab,
+    float* __restrict__ dbslab, int B, int N, int L, int H, int tiles_m, int tiles_n, int samples_per_split, int SP,
+    uint32_t inv) {
+  using T = GemmTile<BM, BN, 16, false, false>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* smem = reinterpret_cast<float*>(smem_raw);
+  float* h2_s = smem + 2 * T::kStageFloats;  // [samples of the slab][R][BM]
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles = tiles_m * tiles_n;
+  const int s = bid / tiles, tile = bid % tiles;
+  const int h0 = (tile / tiles_n) * BM, l0 = (tile % tiles_n) * BN;
+  const int b_lo = s * samples_per_split;
+  const int nb = max(0, min(B - b_lo, samples_per_split));
+  for (int t = threadIdx.x; t < nb * R * BM; t += kGemmThreads) {
+    const int hh = t % BM, r = (t / BM) % R, bb = t / (BM * R);
+    h2_s[t] = h0 + hh < H ? h2[((size_t)(b_lo + bb) * R + r) * H + h0 + hh] : 0.f;
+  }
+  // (visible after the first barrier inside gemm_tile)
+  const int lane = threadIdx.x & 63, wm = threadIdx.x >> 7;
+  f32x16 P[T::TM][T::TN], acc[R][T::TM][T::TN];
+  zero_acc(P);
+  float colsum[T::TM], dbacc[R][T::TM];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    zero_acc(acc[r]);
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i) dbacc[r][i] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < T::TM; ++i) colsum[i] = 0.f;
+  const SampleRows sr{N, SP * 16, b_lo, max(nb, 1), inv};
+  const SrcSampleMC sa{g, H, H, sr};
+  const SrcSampleMC sb{x, ldx, L, sr};
+  const int row_base = wm * (BM / 2) + 4 * (lane >> 5);
+  auto fold = [&](int st) {
+    if ((st + 1) % SP != 0) return;
+    const float* __restrict__ hb = h2_s + (size_t)(st / SP) * R * BM;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int tm = 0; tm < T::TM; ++tm) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float sc = hb[r * BM + row_base + tm * 32 + (i & 3) + 8 * (i >> 2)];
+#pragma unroll
+          for (int tn = 0; tn < T::TN; ++tn) acc[r][tm][tn][i] = fmaf(sc, P[tm][tn][i], acc[r][tm][tn][i]);
+        }
+        dbacc[r][tm] = fmaf(hb[r * BM + wm * (BM / 2) + tm * 32 + (lane & 31)], colsum[tm], dbacc[r][tm]);
+      }
+    zero_acc(P);
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm) colsum[tm] = 0.f;
+  };
+  if (nb > 0) gemm_tile<BM, BN, 16, PF, false, false>(sa, sb, h0, l0, 0, nb * SP * 16, smem, P, colsum, fold);
+  const AccCoord<BM, BN> cc(h0, l0);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (l0 == 0 && (threadIdx.x >> 6 & 1) == 0) {
+#pragma unroll
+      for (int i = 0; i < T::TM; ++i) {
+        const float t = dbacc[r][i] + __shfl_xor(dbacc[r][i], 32, 64);
+        const int h = h0 + wm * (T::TM * 32) + i * 32 + (lane & 31);
+        if (lane < 32 && h < H) dbslab[((size_t)s * R + r) * H + h] = t;
+      }
+    }
+    float* __restrict__ dst = slab + ((size_t)s * R + r) * H * L;
+#pragma unroll
+    for (int tn = 0; tn < T::TN; ++tn) {
+      const int col = cc.col(tn);
+      if (col < L) {
+#pragma unroll
+        for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = cc.row(tm, i);
+            if (row < H) dst[(size_t)row * L + col] = acc[r][tm][tn][i];
+          }
+      }
+    }
+  }
+}
+
 // d_w1[r][h][l] = sum_s slab[s][r][h][l]   (fixed order: bitwise reproducible)
 __global__ __launch_bounds__(256) void bilinear_dw_reduce_kernel(const float* __restrict__ slab,
                                                                  const float* __restrict__ dbslab, RankOutPtrs out,
@@ -296,7 +415,7 @@ __global__ __launch_bounds__(256) void bilinear_dh2_kernel(const float* __restri
 
 static int splits_for_dw(int M, int H, int L, int R, TileChoice t) {
   const long tiles = (long)((H + t.bm - 1) / t.bm) * ((L + t.bn - 1) / t.bn) * R;
-  long s = (768 + tiles - 1) / tiles;
+  long s = (1280 + tiles - 1) / tiles;  // 5 workgroups per CU
   if (const char* e = std::getenv("VQA_K4_DW_SPLITS")) s = std::atol(e);  // experiment knob
   const long max_by_rows = (M + 255) / 256;  // keep >= 256 rows (16 stages) per split
   if (s > max_by_rows) s = max_by_rows;
@@ -305,7 +424,27 @@ static int splits_for_dw(int M, int H, int L, int R, TileChoice t) {
   return (int)s;
 }
 
-static TileChoice dw_tile() { return tile_override_or({128, 64, 2}); }
+// 64x64: measured fastest for both forms once the grid is dealt per XCD (step 3.59 ms against 3.66 with 128x64)
+static TileChoice dw_tile() { return tile_override_or({64, 64, 2}); }
+
+// per-sample form: worth it when a sample fills most of its padded stages and the ranks fit in registers
+static bool dw_per_sample(int N, int R) {
+  const int padded = (N + 15) / 16 * 16;
+  if (const char* e = std::getenv("VQA_K4_DW_FORM")) return std::atoi(e) != 0 && R <= 4;  // experiment knob
+  return R >= 2 && R <= 4 && N * 4 >= padded * 3;
+}
+static int dw_sample_splits(int B, int H, int L, TileChoice t) {
+  const long tiles = (long)((H + t.bm - 1) / t.bm) * ((L + t.bn - 1) / t.bn);
+  long s = (1280 + tiles - 1) / tiles;  // 5 workgroups per CU: 32 slabs of 16 samples at B = 512 (sweep: 20..64)
+  if (const char* e = std::getenv("VQA_K4_DW_SPLITS")) s = std::atol(e);  // experiment knob
+  if (s > B) s = B;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+static int dw_slabs(int B, int N, int L, int H, int R) {
+  return dw_per_sample(N, R) ? dw_sample_splits(B, H, L, dw_tile()) : splits_for_dw(B * N, H, L, R, dw_tile());
+}
 
 }  // namespace vqa
 
@@ -353,7 +492,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_fwd(const float* x, int ldx, const fl
 
 extern "C" size_t vqa_lowrank_bilinear_fusion_bwd_workspace_bytes(int B, int N, int L, int H, int R) {
   if (B <= 0 || N <= 0 || L <= 0 || H <= 0 || R <= 0 || R > kMaxR) return 0;
-  const int S = splits_for_dw(B * N, H, L, R, dw_tile());
+  const int S = dw_slabs(B, N, L, H, R);
   return ((size_t)S * R * H * L + (size_t)S * R * H) * sizeof(float);
 }
 
@@ -382,7 +521,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd(const float* x, int ldx, const fl
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int M = B * N;
   const TileChoice tw = dw_tile();
-  const int S = splits_for_dw(M, H, L, R, tw);
+  const int S = dw_slabs(B, N, L, H, R);
   float* slab = static_cast<float*>(workspace);
   float* dbslab = slab + (size_t)S * R * H * L;
 
@@ -405,6 +544,30 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd(const float* x, int ldx, const fl
   // (3) dW1 (+ db1 partials): split over rows into slabs, (4) reduce the slabs in fixed order
   {
     const int tiles_m = (H + tw.bm - 1) / tw.bm, tiles_n = (L + tw.bn - 1) / tw.bn;
+    if (dw_per_sample(N, R)) {
+      const int spl = (B + S - 1) / S, SP = (N + 15) / 16;
+      const uint32_t inv = (uint32_t)((1ull << 32) / (uint32_t)(SP * 16)) + 1u;
+#define LAUNCH_R(BM_, BN_, PF_, R_)                                                                                        \
+  {                                                                                                                        \
+    const size_t lds = GemmTile<BM_, BN_, 16, false, false>::kSmemBytes + (size_t)spl * R_ * BM_ * sizeof(float);         \
+    VQA_ENSURE_LDS((bilinear_dw_sample_kernel<BM_, BN_, PF_, R_>), lds);                                                   \
+    hipLaunchKernelGGL((bilinear_dw_sample_kernel<BM_, BN_, PF_, R_>), dim3(tiles_m * tiles_n * S), dim3(kGemmThreads), lds, \
+                       s, g, h2, x, ldx, slab, dbslab, B, N, L, H, tiles_m, tiles_n, spl, SP, inv);                        \
+  }
+#define LAUNCH(BM_, BN_, PF_)                 \
+  {                                           \
+    if (R == 2) {                             \
+      LAUNCH_R(BM_, BN_, PF_, 2)              \
+    } else if (R == 3) {                      \
+      LAUNCH_R(BM_, BN_, PF_, 3)              \
+    } else {                                  \
+      LAUNCH_R(BM_, BN_, PF_, 4)              \
+    }                                         \
+  }
+      VQA_TILE_SWITCH(tw, LAUNCH);
+#undef LAUNCH
+#undef LAUNCH_R
+    } else {
     int rows_per_split = (M + S - 1) / S;
     rows_per_split = (rows_per_split + 31) / 32 * 32;
 #define LAUNCH(BM_, BN_, BK_)                                                                                            \
@@ -416,6 +579,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd(const float* x, int ldx, const fl
   }
     VQA_TILE_SWITCH(tw, LAUNCH);
 #undef LAUNCH
+    }
     const int HL = H * L;
     hipLaunchKernelGGL(bilinear_dw_reduce_kernel, dim3((HL / 2 + 255) / 256, R), dim3(256), 0, s, slab, dbslab, ro, HL, H, R, S);
   }

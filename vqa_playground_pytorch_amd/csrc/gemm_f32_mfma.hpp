@@ -87,10 +87,18 @@ struct IntC {
 // fragment row i: sum over the k's with (k & 1) == lane >> 5 of A[k][wave_row0 + i*32 + (lane & 31)].  Adding the
 // two lane halves (shfl_xor 32) gives the column sums of the A tile -- the bias gradient of a weight-gradient GEMM
 // for one extra VALU add per fragment.
-template <int BM, int BN, int BK, int PF, bool A_KC, bool B_KC, class SrcA, class SrcB>
+struct NoStageHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+
+// hook (optional): called by every thread after stage s is complete (stage s covers k_begin + BK s .. + BK; the call sits
+// behind the stage's barrier, outside the MFMA / staging interleave, so it may branch) -- lets a caller fold the
+// accumulators away at segment boundaries inside ONE software pipeline (the per-sample rank scaling of the bilinear
+// weight gradient).
+template <int BM, int BN, int BK, int PF, bool A_KC, bool B_KC, class SrcA, class SrcB, class Hook = NoStageHook>
 __device__ __forceinline__ void gemm_tile(const SrcA& srcA, const SrcB& srcB, int m0, int n0, int k_begin, int k_end,
                                           float* smem, f32x16 (&acc)[BM / 64][BN / 64],
-                                          float* a_colsum = nullptr) {
+                                          float* a_colsum = nullptr, Hook hook = Hook()) {
   using T = GemmTile<BM, BN, BK, A_KC, B_KC>;
   using StA = Stager<BM, BK, A_KC>;
   using StB = Stager<BN, BK, B_KC>;
@@ -170,11 +178,18 @@ __device__ __forceinline__ void gemm_tile(const SrcA& srcA, const SrcB& srcB, in
   };
   for (int s = 0; s < nsteps; s += PF) {
     stage(s, IntC<1 % PF>{});
+    hook(s);
     if constexpr (PF > 1) {
-      if (s + 1 < nsteps) stage(s + 1, IntC<2 % PF>{});
+      if (s + 1 < nsteps) {
+        stage(s + 1, IntC<2 % PF>{});
+        hook(s + 1);
+      }
     }
     if constexpr (PF > 2) {
-      if (s + 2 < nsteps) stage(s + 2, IntC<3 % PF>{});
+      if (s + 2 < nsteps) {
+        stage(s + 2, IntC<3 % PF>{});
+        hook(s + 2);
+      }
     }
   }
 }
