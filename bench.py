@@ -280,7 +280,9 @@ def main():
                           seq2vec="skipthoughts" if args.encoder else None).to(dev).train()
     else:
         model = ODAModel(["PAD", "UNK"], answers).to(dev).train()
-    trainer = DataParallelTrainer(model, lr=1e-4, clip=0.25, graph=not args.no_graph)
+    # adopt_inputs: the synthetic batch is resident and the same tensors are handed over every step, so the replayed
+    # graphs read it in place (a real feeder goes through the trainer's private input buffers: tools/feed_bench.py)
+    trainer = DataParallelTrainer(model, lr=1e-4, clip=0.25, graph=not args.no_graph, adopt_inputs=True)
     torch.manual_seed(100 + rank)  # per-rank dropout streams and data shards differ
     B = args.batch
     v = torch.randn(B, args.regions, FEAT, device=dev)

@@ -239,6 +239,14 @@ def test_graph_replay_equals_eager_steps():
             v2, q2, a2 = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(64, answers=300, seed=22))
             loss, _ = tr.step({"v": v2, "q_idxes": q2}, a2)
             losses.append((loss.item(), 0.0))
+        # a batch of another shape (the short last batch of an epoch) is stepped kernel by kernel, and the captured
+        # graphs keep serving the regular batches after it
+        v3, q3, a3 = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(5, answers=300, seed=23))
+        loss, _ = tr.step({"v": v3, "q_idxes": q3}, a3)
+        losses.append((loss.item(), 0.0))
+        v4, q4, a4 = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(64, answers=300, seed=24))
+        loss, _ = tr.step({"v": v4, "q_idxes": q4}, a4)      # (the captured placeholders ARE the first batch's tensors)
+        losses.append((loss.item(), 0.0))
         out[mode] = (losses, [p.detach().clone() for p in model.parameters()], tr.lr)
     # not bitwise: the d_alpha reductions of K1/K3 use float atomics and Adam renormalises every gradient, so the last
     # bits of near-zero gradients become +-lr steps; a small lr keeps that below the comparison threshold
@@ -270,6 +278,33 @@ def test_stacked_parameters_are_views_of_the_flat_buffer():
     assert all(l.weight.grad is not None and torch.isfinite(l.weight.grad).all() for l in lins)
     sd = model.state_dict()
     assert sd["att1.list_linear_v_fusion.2.linear.weight"].shape == (155, 2048)
+
+
+def test_graph_trainer_fed_by_prefetcher_matches_eager():
+    """Distinct batches streamed from pinned host memory through feed.DevicePrefetcher (which recycles its two device
+    slots) into the graph-replayed trainer: the loss sequence equals the eager trainer's on the same batches, and the
+    caller's tensors are never written (the replayed graphs read private input buffers unless adopt_inputs=True)."""
+    from vqa_playground_pytorch_amd.feed import DevicePrefetcher
+    from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
+    batches = []
+    for i in range(9):
+        v, q, a = (torch.from_numpy(x).pin_memory() for x in seeded.seeded_inputs(32, answers=300, seed=60 + i))
+        batches.append({"v": v, "q_idxes": q, "a": a})
+    out = {}
+    for mode in (False, True):
+        tr = DataParallelTrainer(build("cor2", 300), lr=2e-5, clip=0.25, graph=mode)
+        losses = []
+        for b in DevicePrefetcher(batches, dev()):
+            loss, _ = tr.step({"v": b["v"], "q_idxes": b["q_idxes"]}, b["a"])
+            losses.append(loss.clone())              # device-side copy, no host read: the feeder keeps running ahead
+        torch.cuda.synchronize()
+        out[mode] = [x.item() for x in losses]
+        if mode:
+            assert tr._graph is not None, "step was not captured"
+            mine = [t.data_ptr() for t in tr._graph["sample"].values()] + [tr._graph["target"].data_ptr()]
+            assert not any(t.data_ptr() in mine for b in batches for t in b.values())
+    for l0, l1 in zip(out[False], out[True]):
+        assert abs(l0 - l1) <= 1e-4 * abs(l0), (out[False], out[True])
 
 
 def test_graph_replays_queued_without_host_sync():

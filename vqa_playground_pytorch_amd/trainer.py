@@ -162,7 +162,7 @@ class DataParallelTrainer:
     """Replicated model + flat-gradient sum-all-reduce + the reference's clip/Adam/ExponentialLR."""
 
     def __init__(self, model, lr=1e-4, clip=0.25, gamma=0.5 ** (1 / 50000), broadcast=True, group=None,
-                 fused_adam=None, graph=False):
+                 fused_adam=None, graph=False, adopt_inputs=False):
         self.model = model
         self.group = group
         self.clip = clip
@@ -182,6 +182,12 @@ class DataParallelTrainer:
         # and clip+Adam) with the all-reduce launched eagerly between them; replays cost ~3 host launches instead of
         # ~600.  Falls back to eager if a forward draws a host-side dropout seed (fused K2/K5 masks).
         self.want_graph = bool(graph)
+        # The replayed graphs read their batch from fixed buffers.  By default those are private copies and every batch is
+        # copied into them (one device-to-device pass over the batch per step).  adopt_inputs=True makes the tensors of
+        # the batch the step was captured on the graph's input buffers: no copy when the caller hands over the same
+        # tensors every step (resident synthetic data), but later batches OVERWRITE those tensors -- never combine it
+        # with a feeder that recycles its own buffers (feed.DevicePrefetcher).
+        self.adopt_inputs = bool(adopt_inputs)
         self._graph = None
         self._eager_steps = 0
         if self.hip:
@@ -299,6 +305,11 @@ class DataParallelTrainer:
                     torch.cuda.synchronize()
             return loss, f.norm_and_coef[0]
         g = self._graph
+        if target.shape != g["target"].shape or any(k not in sample or sample[k].shape != t.shape or sample[k].dtype != t.dtype
+                                                    for k, t in g["sample"].items()):
+            # a batch of another shape (the last one of an epoch): this step is launched kernel by kernel; the captured
+            # graphs stay valid for the regular batches that follow
+            return self.step_eager(sample, target)
         for k, t in g["sample"].items():
             if sample[k].data_ptr() != t.data_ptr():
                 t.copy_(sample[k], non_blocking=True)
@@ -312,7 +323,9 @@ class DataParallelTrainer:
         return g["loss"], f.norm_and_coef[0]
 
     def _capture(self, sample, target):
-        static_sample = {k: v for k, v in sample.items() if isinstance(v, torch.Tensor)}
+        static_sample = {k: (v if self.adopt_inputs else v.clone()) for k, v in sample.items() if isinstance(v, torch.Tensor)}
+        if not self.adopt_inputs:
+            target = target.clone()
         # torch's capture recipe: one forward+backward on a side stream first, so the parameters' AccumulateGrad
         # nodes belong to a capturable stream (nodes created on the default stream would run there and abort the
         # capture).  It only refills the gradient buffer; no parameter is updated.
