@@ -335,6 +335,26 @@ def test_graph_replays_queued_without_host_sync():
     assert abs(l0 - l1) <= 1e-4 * abs(l0) and abs(n0 - n1) <= 1e-3 * abs(n0), (got[False], got[True])
 
 
+def test_graph_trainer_respects_train_eval_switch():
+    """Dropout is baked into the captured graphs: after model.eval() the trainer must not replay the train-mode graph."""
+    from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
+    model = build("cor2", 300).train()
+    torch.manual_seed(0)
+    tr = DataParallelTrainer(model, lr=0.0, clip=0.25, graph=True)          # lr 0: the weights stay put
+    v, q, a = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(16, answers=300, seed=70))
+    for _ in range(5):
+        tr.step({"v": v, "q_idxes": q}, a)
+    assert tr._graph is not None
+    model.eval()
+    l1 = tr.step({"v": v, "q_idxes": q}, a)[0].item()      # (a replayed step returns the graph's loss buffer: read it
+    l2 = tr.step({"v": v, "q_idxes": q}, a)[0].item()      #  before the next step overwrites it)
+    assert l1 == l2, "eval-mode steps must be deterministic (no dropout)"
+    model.train()
+    l3 = tr.step({"v": v, "q_idxes": q}, a)[0].item()
+    l4 = tr.step({"v": v, "q_idxes": q}, a)[0].item()
+    assert l3 != l4, "train-mode steps draw fresh masks"
+
+
 def test_oda_graph_replay_draws_fresh_masks():
     """ODA in train mode: K2's dropout seed lives in device memory, so the step is graph-captured and every replay
     still draws a new mask (losses differ from step to step on identical data; same torch seed -> same sequence)."""

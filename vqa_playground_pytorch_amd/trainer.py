@@ -305,10 +305,11 @@ class DataParallelTrainer:
                     torch.cuda.synchronize()
             return loss, f.norm_and_coef[0]
         g = self._graph
-        if target.shape != g["target"].shape or any(k not in sample or sample[k].shape != t.shape or sample[k].dtype != t.dtype
+        if self.model.training != g["training"] or target.shape != g["target"].shape or any(k not in sample or sample[k].shape != t.shape or sample[k].dtype != t.dtype
                                                     for k, t in g["sample"].items()):
-            # a batch of another shape (the last one of an epoch): this step is launched kernel by kernel; the captured
-            # graphs stay valid for the regular batches that follow
+            # a batch of another shape (the last one of an epoch), or the model switched between train() and eval() since
+            # the capture (dropout is baked into the graph): this step is launched kernel by kernel; the captured graphs
+            # stay valid for the regular steps that follow
             return self.step_eager(sample, target)
         for k, t in g["sample"].items():
             if sample[k].data_ptr() != t.data_ptr():
@@ -361,7 +362,8 @@ class DataParallelTrainer:
         front.instantiate()
         tail.instantiate()
         torch.cuda.synchronize()
-        self._graph = {"front": front, "tail": tail, "loss": loss, "sample": static_sample, "target": target}
+        self._graph = {"front": front, "tail": tail, "loss": loss, "sample": static_sample, "target": target,
+                       "training": self.model.training}
 
     @property
     def lr(self):
