@@ -73,6 +73,31 @@ int vqa_pairwise_relation_reduce_bwd(const float* v, const float* q1, const floa
                                      const float* g_v2_b, float* d_alpha, float* d_q1, float* d_q2,
                                      float* d_v, int B, int N, int D, vqa_stream_t stream);
 
+/* K1, closed form with the pooled feature given.  s = sum_i alpha_i v_i is glimpse 0 of the first attention's
+ * pooled output and a softmax alpha sums to 1, so the relation step (config/CoR2.py:191-199 + :216) is the
+ * per-sample affine map v2[b,n,:] = t[b,:] + c2[b,:]*v[b,n,:] with t = q1*s, c2 = (sum_i alpha_i)*q2; its one
+ * consumer that needs it materialised is the second compress layer, which applies dropout first
+ * (config/CoR2.py:72-75 at :218):
+ *
+ *   out[b,n,:] = keep(b,n,:) * (t[b,:] + c2[b,:] * v[b,n,:])
+ *
+ * keep() = 1 when p_drop == 0, else 0 or 1/(1-p_drop) from the counter-based generator keyed by
+ * (seed [+ *seed_ptr], (b*N+n)*D + d) -- vqa_linear_dropout_mask(B*N, D, ...) writes the same mask.
+ * v, out [B,N,D]; t, c2 [B,D] fp32.  Backward: g = dL/dout -> d_t = sum_n keep*g, d_c2 = sum_n keep*g*v
+ * ([B,D] fp32, overwritten) and d_v = c2*keep*g [B,N,D] or NULL.  Limits: D % 4 == 0, B*N*D < 2^32. */
+int vqa_relation_apply_fwd(const float* v, const float* t, const float* c2, float* out, float p_drop,
+                           uint64_t seed, const uint64_t* seed_ptr, int B, int N, int D,
+                           vqa_stream_t stream);
+int vqa_relation_apply_bwd(const float* v, const float* c2, const float* g, float* d_t, float* d_c2,
+                           float* d_v, float p_drop, uint64_t seed, const uint64_t* seed_ptr,
+                           int B, int N, int D, vqa_stream_t stream);
+int vqa_relation_apply_fwd_bf16(const vqa_bf16_t* v, const float* t, const float* c2, vqa_bf16_t* out,
+                                float p_drop, uint64_t seed, const uint64_t* seed_ptr, int B, int N, int D,
+                                vqa_stream_t stream);
+int vqa_relation_apply_bwd_bf16(const vqa_bf16_t* v, const float* c2, const vqa_bf16_t* g, float* d_t,
+                                float* d_c2, vqa_bf16_t* d_v, float p_drop, uint64_t seed,
+                                const uint64_t* seed_ptr, int B, int N, int D, vqa_stream_t stream);
+
 /* K1 with the region tensors (v, v2, g_v2, d_v) stored as bf16 -- the mixed-precision path of BASELINE
  * configs[4] (bf16 storage, fp32 arithmetic and accumulation; q1, q2, alpha and their gradients stay
  * fp32).  Same semantics and limits, with 8-byte instead of 16-byte alignment of the bf16 tensors. */

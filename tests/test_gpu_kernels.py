@@ -507,3 +507,39 @@ def test_batched_linear(ops, group_first, act):
     ref.backward(gy)
     for name, a_, t in zip(("d_x", "d_w", "d_b"), got, (x, w, b)):
         close(name, a_, t.grad.cpu().numpy(), 1e-5)
+
+
+# ----------------------------------------------------------------------------------------------- K1 closed form
+@pytest.mark.parametrize("B,N,D", [(3, 36, 2048), (2, 100, 512), (5, 7, 260), (1, 1, 4), (300, 36, 1024)])
+@pytest.mark.parametrize("p", [0.0, 0.5])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_relation_apply(ops, B, N, D, p, dtype):
+    """out = keep * (t + c2 * v) with t = q1 * sum_i alpha_i v_i, c2 = (sum_i alpha_i) q2 equals the oracle's pairwise
+    relation reduce (every (i,j) term) times the kernel's own dropout mask; backward against the closed form."""
+    bf = dtype == "bf16"
+    v = seeded.seeded_array((B, N, D), 401)
+    if bf:
+        v = torch.from_numpy(v).to(torch.bfloat16).float().numpy()
+    q1 = 1 / (1 + np.exp(-seeded.seeded_array((B, D), 402)))
+    q2 = 1 / (1 + np.exp(-seeded.seeded_array((B, D), 403)))
+    al = np.abs(seeded.seeded_array((B, N), 404)) + 0.05
+    gout = seeded.seeded_array((B, N, D), 405)
+    if bf:
+        gout = torch.from_numpy(gout).to(torch.bfloat16).float().numpy()
+    t = (q1 * np.einsum("bn,bnd->bd", al, v)).astype(np.float32)
+    c2 = (al.sum(1, keepdims=True) * q2).astype(np.float32)
+    seed = 4242
+    mask = ops.linear_dropout_mask(B * N, D, p, seed, dev()).cpu().numpy().reshape(B, N, D).astype(np.float64) if p else 1.0
+    vt = g(v).to(torch.bfloat16) if bf else g(v)
+    vt.requires_grad_()
+    tt, ct = g(t, True), g(c2, True)
+    out = ops.relation_apply(vt, tt, ct, p, seed)
+    want = K.pairwise_relation_reduce_fwd(v, q1, q2, al) * mask if not bf else \
+        (t[:, None, :].astype(np.float64) + c2[:, None, :].astype(np.float64) * v) * mask
+    tol = 2.0 ** -7 if bf else RTOL
+    close("out", out.float(), want, tol)
+    out.backward(g(gout).to(out.dtype))
+    gm = gout.astype(np.float64) * mask
+    close("d_t", tt.grad, gm.sum(1))
+    close("d_c2", ct.grad, (gm * v).sum(1))
+    close("d_v", vt.grad.float(), c2[:, None, :].astype(np.float64) * gm, tol)

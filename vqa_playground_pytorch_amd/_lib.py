@@ -27,6 +27,10 @@ SIGNATURES = {
     "vqa_pairwise_relation_reduce_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_pairwise_relation_reduce_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
                                                 _c_i, _c_i, _c_i, _c_st]),
+    "vqa_relation_apply_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_relation_apply_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_relation_apply_fwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_relation_apply_bwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_i, _c_st]),
     "vqa_softmax_attention_pool_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_softmax_attention_pool_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_attention_logits_fwd": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_i, _c_st]),

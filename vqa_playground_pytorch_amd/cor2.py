@@ -81,18 +81,38 @@ class Model(nn.Module):
         q_feature_low, q_final, q_gate_1, q_gate_2 = self.question_projections(q_feature)
         v_feature_low = self.compress_v(v_feature)
         fuse1 = self.fusion_vq1(v_feature_low, q_feature_low)
-        v1_att, alpha1, alpha1_full = self.att1.attend(v_feature, self.att1.conv_att.pre_activation(fuse1))
+        v1_att, alpha1, alpha1_full, pooled1 = self.att1.attend(v_feature, self.att1.conv_att.pre_activation(fuse1),
+                                                                return_pooled=True)
 
-        # only glimpse 0 weights the relation; v2 has two consumers, each gets its own alias (see ops.pairwise_relation_reduce)
-        v2_feature, v2_for_pooling = self.relation_reduce(v_feature, q_gate_1, q_gate_2, alpha1_full)
-        v2_feature_low = self.compress_v2(v2_feature)
-        fuse2 = self.fusion_vq2(v2_feature_low, q_feature_low)
-        v2_att, alpha2, _ = self.att2.attend(v2_for_pooling, self.att2.conv_att.pre_activation(fuse2))
+        if self.relation_mode == 1:
+            # Closed form of the relation step (config/CoR2.py:191-199 + :216).  Only glimpse 0 of alpha1 weights it, and
+            # sum_i alpha1[i,0] v_i is exactly glimpse 0 of the pooled features att1 has just produced, while a softmax
+            # alpha sums to 1 -- so v2[b,n] = t[b] + q2[b] * v[b,n] with t = q1 * pooled1[:,0].  (The two unit sums only
+            # reach the attention maps as a per-glimpse constant, which the softmax backward cancels exactly.)  v2 is
+            # materialised once, already dropped out for compress_v2 (K1 apply kernel); the second attention pools v
+            # itself and maps the result: sum_n alpha2[n] v2[n] = t + q2 * sum_n alpha2[n] v[n].
+            t = q_gate_1 * pooled1[:, 0, :]
+            c2 = q_gate_2
+            p = self.compress_v2.p if (self.training and self.compress_v2.p) else 0.0
+            v2_dropped = ops.relation_apply(v_feature, t, c2, p, ops.next_dropout_seed() if p else 0)
+            v2_feature_low = self.compress_v2(v2_dropped, predropped=True)
+            fuse2 = self.fusion_vq2(v2_feature_low, q_feature_low)
+            v2_att, alpha2, _ = self.att2.attend(v_feature, self.att2.conv_att.pre_activation(fuse2),
+                                                 lambda pooled: torch.addcmul(t.unsqueeze(1), c2.unsqueeze(1), pooled))
+            feature = torch.addcmul(t.unsqueeze(1), c2.unsqueeze(1), v_feature[:, 0:2, :].float()).detach()
+        else:
+            # pairwise form: every (i, j) term of the relation tensor summed in the kernel, as the reference structures it;
+            # v2 has two consumers, each gets its own alias (see ops.pairwise_relation_reduce)
+            v2_feature, v2_for_pooling = self.relation_reduce(v_feature, q_gate_1, q_gate_2, alpha1_full)
+            v2_feature_low = self.compress_v2(v2_feature)
+            fuse2 = self.fusion_vq2(v2_feature_low, q_feature_low)
+            v2_att, alpha2, _ = self.att2.attend(v2_for_pooling, self.att2.conv_att.pre_activation(fuse2))
+            feature = v2_feature[:, 0:2, :].detach().float()
 
         # side output read by visu.py:198-207; detached so it does not pin the autograd graph of the step
         # (feature = the reference's v2_feature[:, [0, 1], :])
-        self.alpha_dict = {"alpha1": tuple(t.detach() for t in alpha1), "alpha2": tuple(t.detach() for t in alpha2),
-                           "feature": v2_feature[:, 0:2, :].detach().float()}
+        self.alpha_dict = {"alpha1": tuple(t_.detach() for t_ in alpha1), "alpha2": tuple(t_.detach() for t_ in alpha2),
+                           "feature": feature}
 
         v_f = torch.cat([v1_att, v2_att], dim=1)
         x = self.fusion_final(v_f, q_final)

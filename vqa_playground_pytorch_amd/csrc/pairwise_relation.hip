@@ -242,6 +242,84 @@ __global__ __launch_bounds__(NT) void pairwise_bwd_stream_kernel(const T* __rest
   for (int i = tid; i < N; i += NT) atomicAdd(&d_alpha[(size_t)b * N + i], red_s[i]);
 }
 
+// ---- closed form with the pooled feature given ("relation apply") ------------------------------------------------------
+// With s = sum_i alpha_i v_i already available -- it IS glimpse 0 of the first attention's pooled output, and a softmax
+// alpha sums to 1 -- the whole relation step is a per-sample affine map of the regions,
+//     v2[b,n,:] = t[b,:] + c2[b,:] * v[b,n,:],     t = q1 * s,  c2 = (sum_i alpha_i) * q2,
+// and the only consumer that needs it materialised is the second compress layer, which wants it dropped out
+// (config/CoR2.py:72-75 at :218): out = keep * v2 in ONE pass over v (keep = the counter-hash dropout of common.hpp keyed
+// by the element index (b*N+n)*D+d, i.e. the mask vqa_linear_dropout_mask(B*N, D, ...) exports).  The second attention
+// pools v itself (pooled2 = t + c2 * sum_n alpha2_n v_n), so v2 is never read back and its gradient arrives in one
+// tensor.  Backward: d_t = sum_n keep*g, d_c2 = sum_n keep*g*v, optional d_v = c2*keep*g -- one pass over (v, g), no
+// second pass, no atomics.
+__device__ __forceinline__ float4 keep4(uint32_t e, const DropCfg& dc) {
+  if (dc.p8 == 0) return make_float4(1.f, 1.f, 1.f, 1.f);
+  const float2 a = drop_pair(e, dc), b = drop_pair(e + 2, dc);
+  return make_float4(a.x, a.y, b.x, b.y);
+}
+
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void relation_apply_fwd_kernel(const T* __restrict__ v, const float* __restrict__ t,
+                                                                const float* __restrict__ c2, T* __restrict__ out, int N,
+                                                                int D, int rows_per_block, DropCfg dc) {
+  const int b = blockIdx.y;
+  const int d = (blockIdx.x * NT + threadIdx.x) * 4;
+  if (d >= D) return;
+  const float4 tv = ld4(t + (size_t)b * D + d), cv = ld4(c2 + (size_t)b * D + d);
+  const int n_lo = blockIdx.z * rows_per_block, n_hi = min(N, n_lo + rows_per_block);
+  const size_t base = (size_t)b * N * D + d;
+#pragma unroll 6
+  for (int n = n_lo; n < n_hi; ++n) {
+    const float4 x = ld4(v + base + (size_t)n * D);
+    const float4 k = keep4((uint32_t)(base + (size_t)n * D), dc);
+    st4(out + base + (size_t)n * D,
+        make_float4(k.x * fmaf(cv.x, x.x, tv.x), k.y * fmaf(cv.y, x.y, tv.y), k.z * fmaf(cv.z, x.z, tv.z),
+                    k.w * fmaf(cv.w, x.w, tv.w)));
+  }
+}
+
+template <typename T, int NT, int RS>
+__global__ __launch_bounds__(NT) void relation_apply_bwd_kernel(const T* __restrict__ v, const float* __restrict__ c2,
+                                                                const T* __restrict__ g, float* __restrict__ d_t,
+                                                                float* __restrict__ d_c2, T* __restrict__ d_v, int N, int D,
+                                                                DropCfg dc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  constexpr int COLS = NT / RS;
+  const int rs = tid / COLS, ct = tid % COLS;
+  const int d = (blockIdx.x * COLS + ct) * 4;
+  const bool active = d < D;
+  const int dc_ = active ? d : 0;
+  const size_t base = (size_t)b * N * D + dc_;
+  const float4 cv = ld4(c2 + (size_t)b * D + dc_);
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 st = z, sc = z;
+#pragma unroll 6
+  for (int n = rs; n < N; n += RS) {
+    const float4 x = ld4(v + base + (size_t)n * D);
+    const float4 gk = mul4(ld4(g + base + (size_t)n * D), keep4((uint32_t)(base + (size_t)n * D), dc));
+    st = add4(st, gk);
+    sc = add4(sc, mul4(gk, x));
+    if (d_v != nullptr && active) st4(d_v + base + (size_t)n * D, mul4(cv, gk));
+  }
+  if constexpr (RS > 1) {
+    float4* comb = reinterpret_cast<float4*>(smem);  // [RS][2][COLS]
+    comb[(rs * 2 + 0) * COLS + ct] = st;
+    comb[(rs * 2 + 1) * COLS + ct] = sc;
+    __syncthreads();
+    st = sc = z;
+#pragma unroll
+    for (int q = 0; q < RS; ++q) {
+      st = add4(st, comb[(q * 2 + 0) * COLS + ct]);
+      sc = add4(sc, comb[(q * 2 + 1) * COLS + ct]);
+    }
+  }
+  if (active && rs == 0) {
+    st4(d_t + (size_t)b * D + d, st);
+    st4(d_c2 + (size_t)b * D + d, sc);
+  }
+}
+
 static int pick_threads(int N) { return N <= 36 ? 128 : 64; }
 
 template <typename T>
@@ -325,6 +403,59 @@ static int pairwise_bwd_impl(const char* who, const T* v, const float* q1, const
   return check_launch(who);
 }
 
+template <typename T>
+static int relation_check(const char* who, const T* v, int B, int N, int D, float p) {
+  constexpr size_t kAlign = 4 * sizeof(T);
+  VQA_REQUIRE(B > 0 && N > 0 && D > 0, VQA_E_BADARG, "%s: bad sizes B=%d N=%d D=%d", who, B, N, D);
+  VQA_REQUIRE(p >= 0.f && p < 1.f, VQA_E_BADARG, "%s: p_drop=%f outside [0,1)", who, (double)p);
+  VQA_REQUIRE(D % 4 == 0 && aligned(v, kAlign), VQA_E_UNSUPPORTED, "%s: needs D %% 4 == 0 and %zu-byte aligned region tensors", who,
+              kAlign);
+  VQA_REQUIRE(B <= 65535 && (long)B * N * D < (1L << 32), VQA_E_UNSUPPORTED, "%s: B*N*D must stay below 2^32", who);
+  return VQA_OK;
+}
+
+template <typename T>
+static int relation_apply_fwd_impl(const char* who, const T* v, const float* t, const float* c2, T* out, float p_drop,
+                                   uint64_t seed, const uint64_t* seed_ptr, int B, int N, int D, vqa_stream_t stream) {
+  VQA_REQUIRE(v && t && c2 && out, VQA_E_BADARG, "%s: null pointer", who);
+  int rc = relation_check(who, v, B, N, D, p_drop);
+  if (rc != VQA_OK) return rc;
+  VQA_REQUIRE(aligned(t, 16) && aligned(c2, 16) && aligned(out, 4 * sizeof(T)), VQA_E_UNSUPPORTED, "%s: unaligned pointer", who);
+  constexpr int NT = 256;
+  const int col_blocks = (D / 4 + NT - 1) / NT;
+  int zsplit = (2048 + col_blocks * B - 1) / (col_blocks * B);  // >= 2048 workgroups when the batch alone gives fewer
+  if (zsplit > (N + 3) / 4) zsplit = (N + 3) / 4;
+  if (zsplit < 1) zsplit = 1;
+  const int rows_per_block = (N + zsplit - 1) / zsplit;
+  hipLaunchKernelGGL((relation_apply_fwd_kernel<T, NT>), dim3(col_blocks, B, (N + rows_per_block - 1) / rows_per_block), dim3(NT),
+                     0, static_cast<hipStream_t>(stream), v, t, c2, out, N, D, rows_per_block, make_drop(p_drop, seed, seed_ptr));
+  return check_launch(who);
+}
+
+template <typename T>
+static int relation_apply_bwd_impl(const char* who, const T* v, const float* c2, const T* g, float* d_t, float* d_c2, T* d_v,
+                                   float p_drop, uint64_t seed, const uint64_t* seed_ptr, int B, int N, int D,
+                                   vqa_stream_t stream) {
+  VQA_REQUIRE(v && c2 && g && d_t && d_c2, VQA_E_BADARG, "%s: null pointer", who);
+  int rc = relation_check(who, v, B, N, D, p_drop);
+  if (rc != VQA_OK) return rc;
+  VQA_REQUIRE(aligned(c2, 16) && aligned(d_t, 16) && aligned(d_c2, 16) && aligned(g, 4 * sizeof(T)) &&
+                  (d_v == nullptr || aligned(d_v, 4 * sizeof(T))),
+              VQA_E_UNSUPPORTED, "%s: unaligned pointer", who);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
+  constexpr int NT = 256;
+  if ((long)B * D / 4 < 4 * 65536) {  // small batch: the 4 waves of a workgroup share 256 columns and split the rows
+    constexpr int RS = NT / 64;
+    hipLaunchKernelGGL((relation_apply_bwd_kernel<T, NT, RS>), dim3((D / 4 + 63) / 64, B), dim3(NT),
+                       (size_t)RS * 2 * (NT / RS) * sizeof(float4), s, v, c2, g, d_t, d_c2, d_v, N, D, dc);
+  } else {
+    hipLaunchKernelGGL((relation_apply_bwd_kernel<T, NT, 1>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), 0, s, v, c2, g, d_t,
+                       d_c2, d_v, N, D, dc);
+  }
+  return check_launch(who);
+}
+
 }  // namespace vqa
 
 using namespace vqa;
@@ -357,4 +488,26 @@ extern "C" int vqa_pairwise_relation_reduce_bwd_bf16(const vqa_bf16_t* v, const 
   return pairwise_bwd_impl<bf16>("pairwise_relation_reduce_bwd_bf16", reinterpret_cast<const bf16*>(v), q1, q2, alpha,
                                  alpha_stride, reinterpret_cast<const bf16*>(g_v2), reinterpret_cast<const bf16*>(g_v2_b),
                                  d_alpha, d_q1, d_q2, reinterpret_cast<bf16*>(d_v), B, N, D, stream);
+}
+
+extern "C" int vqa_relation_apply_fwd(const float* v, const float* t, const float* c2, float* out, float p_drop, uint64_t seed,
+                                      const uint64_t* seed_ptr, int B, int N, int D, vqa_stream_t stream) {
+  return relation_apply_fwd_impl<float>("relation_apply_fwd", v, t, c2, out, p_drop, seed, seed_ptr, B, N, D, stream);
+}
+extern "C" int vqa_relation_apply_fwd_bf16(const vqa_bf16_t* v, const float* t, const float* c2, vqa_bf16_t* out, float p_drop,
+                                           uint64_t seed, const uint64_t* seed_ptr, int B, int N, int D, vqa_stream_t stream) {
+  return relation_apply_fwd_impl<bf16>("relation_apply_fwd_bf16", reinterpret_cast<const bf16*>(v), t, c2,
+                                       reinterpret_cast<bf16*>(out), p_drop, seed, seed_ptr, B, N, D, stream);
+}
+extern "C" int vqa_relation_apply_bwd(const float* v, const float* c2, const float* g, float* d_t, float* d_c2, float* d_v,
+                                      float p_drop, uint64_t seed, const uint64_t* seed_ptr, int B, int N, int D,
+                                      vqa_stream_t stream) {
+  return relation_apply_bwd_impl<float>("relation_apply_bwd", v, c2, g, d_t, d_c2, d_v, p_drop, seed, seed_ptr, B, N, D, stream);
+}
+extern "C" int vqa_relation_apply_bwd_bf16(const vqa_bf16_t* v, const float* c2, const vqa_bf16_t* g, float* d_t, float* d_c2,
+                                           vqa_bf16_t* d_v, float p_drop, uint64_t seed, const uint64_t* seed_ptr, int B, int N,
+                                           int D, vqa_stream_t stream) {
+  return relation_apply_bwd_impl<bf16>("relation_apply_bwd_bf16", reinterpret_cast<const bf16*>(v), c2,
+                                       reinterpret_cast<const bf16*>(g), d_t, d_c2, reinterpret_cast<bf16*>(d_v), p_drop, seed,
+                                       seed_ptr, B, N, D, stream);
 }

@@ -195,7 +195,15 @@ class MyConv1d(nn.Module):
     # with VQA_FUSED_LINEAR=0/1; the default is whichever measured faster in situ (see profiles/README.md)
     fused = os.environ.get("VQA_FUSED_LINEAR", "0") == "1"
 
-    def forward(self, x):
+    def forward(self, x, predropped=False):
+        """predropped=True: the producer of x has already applied this layer's input dropout (ops.relation_apply)."""
+        if predropped:
+            if x.dim() != 3:
+                raise ValueError("[error] putils.Conv1d(%s, %s, %s, %s): input_dim (%s) should equal to 3"
+                                 % (self.in_channels, self.out_channels, self.kernel_size, self.stride, x.dim()))
+            if x.dtype == torch.bfloat16:
+                return self._linear_bf16(x, self.af)
+            return _activation(ops.linear(x, self.conv.weight.squeeze(-1), self.conv.bias), self.af, self.dim)
         if x.dtype == torch.bfloat16 and self.af in (None, "relu"):
             if x.dim() != 3:
                 raise ValueError("[error] putils.Conv1d(%s, %s, %s, %s): input_dim (%s) should equal to 3"
@@ -282,10 +290,15 @@ class MyATT(nn.Module):
         y = my_linears(list(self.list_linear_v_fusion), pooled)                       # [B,G,A]
         return y.reshape(y.size(0), -1)
 
-    def attend(self, inputs, logits):
-        """logits [B,N,G] (pre-softmax) -> (x_v, list_att, alpha [B,N,G])."""
+    def attend(self, inputs, logits, pooled_map=None, return_pooled=False):
+        """logits [B,N,G] (pre-softmax) -> (x_v, list_att, alpha [B,N,G][, pooled [B,G,D]]).  pooled_map (optional)
+        transforms the pooled features before the glimpse projections.  (Nothing that carries an autograd graph is kept
+        on the module: a tensor stashed across steps would pin the previous step's graph.)"""
         alpha, pooled = ops.softmax_attention_pool(logits, inputs)                     # [B,N,G], [B,G,D]
-        return self.glimpse_projection(pooled), torch.split(alpha, 1, dim=2), alpha
+        x_v = self.glimpse_projection(pooled if pooled_map is None else pooled_map(pooled))
+        if return_pooled:
+            return x_v, torch.split(alpha, 1, dim=2), alpha, pooled
+        return x_v, torch.split(alpha, 1, dim=2), alpha
 
     def forward(self, inputs, fuse):
         x_v, list_att, _ = self.attend(inputs, self.conv_att.pre_activation(fuse))

@@ -150,6 +150,47 @@ class PairwiseRelationReduce(torch.autograd.Function):
         return d_v, d_q1, d_q2, d_alpha_full, None, None, None
 
 
+class RelationApply(torch.autograd.Function):
+    """K1, closed form with the pooled feature given: out[b,n,:] = keep * (t[b,:] + c2[b,:] * v[b,n,:]) -- the relation
+    step of config/CoR2.py:191-199,216 when s = sum_i alpha_i v_i comes from the first attention's pooled output
+    (t = q1 * s, c2 = q2 for a softmax alpha), with the dropout of the second compress layer (config/CoR2.py:72-75 at
+    :218) applied in the same pass.  v [B,N,D] fp32 or bf16; t, c2 [B,D] fp32."""
+
+    @staticmethod
+    def forward(ctx, v, t, c2, p_drop, seed):
+        v, t, c2 = _prep("v", v, _REGION_DTYPES), _prep("t", t), _prep("c2", c2)
+        B, N, D = v.shape
+        if t.shape != (B, D) or c2.shape != (B, D):
+            raise ValueError("relation_apply: t and c2 must be [B,D] = %s" % ((B, D),))
+        out = torch.empty_like(v)
+        sv, sp = _seed_args(seed)
+        name = "relation_apply_fwd" + _sfx(v.dtype)
+        _launch(name, (B, N, D, float(p_drop) > 0), getattr(_lib.lib(), "vqa_" + name), _p(v), _p(t), _p(c2), _p(out),
+                float(p_drop), sv, sp, B, N, D)
+        ctx.save_for_backward(v, c2)
+        ctx.cfg = (float(p_drop), seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        v, c2 = ctx.saved_tensors
+        p_drop, seed = ctx.cfg
+        B, N, D = v.shape
+        g = _prep("grad_out", g.to(v.dtype), _REGION_DTYPES)
+        d_t = torch.empty(B, D, device=v.device, dtype=torch.float32)
+        d_c2 = torch.empty(B, D, device=v.device, dtype=torch.float32)
+        d_v = torch.empty_like(v) if ctx.needs_input_grad[0] else None
+        sv, sp = _seed_args(seed)
+        name = "relation_apply_bwd" + _sfx(v.dtype)
+        _launch(name, (B, N, D, p_drop > 0, d_v is not None), getattr(_lib.lib(), "vqa_" + name), _p(v), _p(c2), _p(g),
+                _p(d_t), _p(d_c2), _p(d_v), p_drop, sv, sp, B, N, D)
+        return d_v, d_t, d_c2, None, None
+
+
+def relation_apply(v, t, c2, p_drop=0.0, seed=0):
+    return RelationApply.apply(v, t, c2, p_drop, seed)
+
+
 class SoftmaxAttentionPool(torch.autograd.Function):
     """K3.  alpha = softmax over regions of logits [B,N,G]; pooled[b,g,:] = sum_n alpha[b,n,g] v[b,n,:].
     Replaces F.softmax(dim=1) (config/CoR2.py:83-87,:132) + putils.bmatmul (config/CoR2.py:142)."""
