@@ -42,6 +42,8 @@ def kernel_models(B, N=REGIONS, D=FEAT, G=GLIMPSES, L=LOW, H=HID, R=RANK, bf16=F
         return {
             "lowrank_bilinear_fusion_fwd_bf16": ("mfma", B * (2 * R * N * L * H + 2 * R * N * H)),
             "lowrank_bilinear_fusion_bwd_bf16": ("mfma", B * (2 * 2 * R * N * L * H)),
+            "relation_apply_fwd_bf16": ("hbm", B * (2 * N * D * fv + 2 * D * f)),               # v in, dropped v2 out
+            "relation_apply_bwd_bf16": ("hbm", B * (2 * N * D * fv + 3 * D * f)),               # v, g in; d_t, d_c2 out
             "pairwise_relation_reduce_fwd_bf16": ("hbm", B * (2 * N * D * fv + (2 * D + N) * f)),
             "pairwise_relation_reduce_bwd_bf16": ("hbm", B * (2 * N * D * fv + (4 * D + 2 * N) * f)),
             "softmax_attention_pool_fwd_bf16": ("hbm", B * (N * D * fv + (2 * N * G + G * D) * f)),
@@ -53,6 +55,8 @@ def kernel_models(B, N=REGIONS, D=FEAT, G=GLIMPSES, L=LOW, H=HID, R=RANK, bf16=F
         "object_difference_attention_bwd": ("valu", B * 4 * G * N * N * L),                 # data pass + weight pass
         "lowrank_bilinear_fusion_fwd": ("mfma", B * (2 * R * N * L * H + 2 * R * N * H)),
         "lowrank_bilinear_fusion_bwd": ("mfma", B * (2 * 2 * R * N * L * H)),              # dx + dW1 contractions
+        "relation_apply_fwd": ("hbm", B * (2 * N * D + 2 * D) * f),                         # K1 closed form: v in, dropped v2 out
+        "relation_apply_bwd": ("hbm", B * (2 * N * D + 3 * D) * f),                         # v, g in; d_t, d_c2 out
         "pairwise_relation_reduce_fwd": ("hbm", B * (2 * N * D + 2 * D + N) * f),          # 606 352 B/sample
         "pairwise_relation_reduce_bwd": ("hbm", B * (2 * N * D + 4 * D + 2 * N) * f),      # v, g in; dq1,dq2,dalpha out
         "softmax_attention_pool_fwd": ("hbm", B * (N * D + 2 * N * G + G * D) * f),        # 328 832 B/sample
@@ -66,6 +70,8 @@ def kernel_models(B, N=REGIONS, D=FEAT, G=GLIMPSES, L=LOW, H=HID, R=RANK, bf16=F
 # staging loads (calibrated here against the algorithmic bytes of the K4 forward: 26.5 MB counted vs 26.1 MB expected).
 PMC_KERNELS = {  # C-ABI entry -> [(kernel-name prefix, grid, fetch multiplier)]
     "lowrank_bilinear_fusion_fwd": [("vqa::bilinear_fwd_kernel", "589824", 1.0)],
+    "relation_apply_fwd": [("vqa::relation_apply_fwd_kernel", None, 2.0)],
+    "relation_apply_bwd": [("vqa::relation_apply_bwd_kernel", None, 2.0)],
     "pairwise_relation_reduce_fwd": [("vqa::pairwise_fwd_reg_kernel", "262144", 2.0)],
     "pairwise_relation_reduce_bwd": [("vqa::pairwise_bwd_stream_kernel", "262144", 2.0)],
     "softmax_attention_pool_fwd": [("vqa::attention_pool_fwd_kernel", "262144", 2.0)],
@@ -79,7 +85,7 @@ def pmc_traffic(name, B):
     table = json.load(open(path))
     total = 0.0
     for prefix, grid, mult in PMC_KERNELS[name]:
-        hit = [v for k, v in table.items() if k.startswith(prefix) and k.endswith("grid=" + grid)]
+        hit = [v for k, v in table.items() if k.startswith(prefix) and (grid is None or k.endswith("grid=" + grid))]
         if not hit:
             return None
         total += (hit[0]["FETCH_SIZE_KiB"] * mult + hit[0]["WRITE_SIZE_KiB"]) * 1024.0
@@ -93,6 +99,8 @@ def roofline_entry(name, shape, launches, mean_ms, B, regions=REGIONS, bf16=Fals
     if name.startswith("lowrank_bilinear_fusion_bwd") and not shape[-1]:
         work //= 2
     if name.startswith("pairwise_relation_reduce_bwd") and shape[-1]:      # second gradient tensor read as well
+        work += B * regions * FEAT * (2 if bf16 else 4)
+    if name.startswith("relation_apply_bwd") and shape[-1]:                # d_v written as well
         work += B * regions * FEAT * (2 if bf16 else 4)
     sec = mean_ms * 1e-3
     if bound == "hbm":
