@@ -373,3 +373,85 @@ def test_oda_graph_replay_draws_fresh_masks():
     assert graphed, "ODA train step should be graph-captured now that the mask seed is a device word"
     assert len(set(round(x, 4) for x in l1[3:])) > 2, l1          # replays do not repeat one frozen mask
     assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(l1, l2)), (l1, l2)
+
+
+@pytest.mark.gpu
+def test_checkpoint_round_trip_and_torch_adam_interop(tmp_path):
+    """train.py:250-284 on the GPU path: the three checkpoint files carry the reference's names, the optimizer file
+    loads into a stock torch.optim.Adam over the same parameter list, and a replica that resumes from the files
+    takes the same next steps (hipGraph-replayed) as the trainer that wrote them."""
+    import os
+    from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
+    model = build("cor2", 300)
+    tr = DataParallelTrainer(model, lr=2e-5, clip=0.25, graph=True)
+    data = [tuple(torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(16, answers=300, seed=40 + i)) for i in range(9)]
+    for v, q, a in data[:5]:
+        tr.step({"v": v, "q_idxes": q}, a)
+    assert tr._graph is not None
+    path = tr.save_checkpoint({"epoch": 3, "exp_logger": None}, str(tmp_path))
+    assert sorted(os.listdir(path)) == ["ckpt_info.pth.tar", "ckpt_model.pth.tar", "ckpt_optim.pth.tar"]
+    saved = torch.load(os.path.join(path, "ckpt_model.pth.tar"))
+    assert list(saved) == list(model.state_dict())
+    assert all(not t.is_cuda for t in saved.values())
+
+    # stock Adam accepts the optimizer file; its moments are the trainer's flat buffers, parameter by parameter
+    optim_sd = torch.load(os.path.join(path, "ckpt_optim.pth.tar"))
+    params = [p for p in model.parameters() if p.requires_grad]
+    clones = [torch.nn.Parameter(p.detach().cpu().clone()) for p in params]
+    adam = torch.optim.Adam(clones, lr=1e-4)
+    adam.load_state_dict(optim_sd)
+    where = {id(p): o for p, o in zip(tr.flat.params, tr.flat.offsets)}
+    for p, c in zip(params, clones):
+        st = adam.state[c]
+        assert int(st["step"]) == 5
+        o = where[id(p)]
+        assert torch.equal(st["exp_avg"], tr.flat.m[o:o + p.numel()].view_as(p).cpu())
+        assert torch.equal(st["exp_avg_sq"], tr.flat.v[o:o + p.numel()].view_as(p).cpu())
+
+    # resume in a replica with other initial weights
+    from vqa_playground_pytorch_amd import CoR2Model
+    torch.manual_seed(7)
+    other = CoR2Model(["PAD", "UNK"], 300).eval().to(dev())
+    tr2 = DataParallelTrainer(other, lr=2e-5, clip=0.25, graph=True)
+    assert tr2.load_checkpoint(path) is None
+    for p, q in zip(model.parameters(), other.parameters()):
+        assert torch.equal(p, q)
+    assert tr2.adam_steps == 5 and tr2.iteration == 0
+    tr.iteration = 0                       # the reference's schedule restarts on resume; Adam's step count does not
+    for v, q, a in data[5:]:
+        l1, n1 = tr.step({"v": v, "q_idxes": q}, a)
+        l1, n1 = l1.item(), n1.item()
+        l2, n2 = tr2.step({"v": v, "q_idxes": q}, a)
+        assert abs(l1 - l2.item()) <= 1e-4 * abs(l1) and abs(n1 - n2.item()) <= 1e-4 * n1
+    assert tr.lr == tr2.lr and tr2.adam_steps == 9
+    for p, q in zip(model.parameters(), other.parameters()):
+        assert (p - q).abs().max().item() <= 2e-3 * max(p.abs().max().item(), 1e-3)
+
+
+@pytest.mark.gpu
+def test_reset_optimizer_under_graph_replay():
+    """learning_scheduler(cf) again (train.py:718-721) while the step is replayed from hipGraphs: the moments are zeroed
+    in place, so the captured graphs stay valid and the next step equals the first step of a new trainer."""
+    from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
+    import types
+    # the rule of config/CoR2.py (restart_epoch None, keeping_epoch 40) at a step size that keeps +-lr sign flips of
+    # near-zero gradients below the comparison threshold
+    cf = types.SimpleNamespace(lr=2e-5, restart_epoch=None, keeping_epoch=40)
+    model = build("cor2", 300)
+    tr = DataParallelTrainer(model, lr=cf.lr, clip=0.25, graph=True)
+    data = [tuple(torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(16, answers=300, seed=60 + i)) for i in range(6)]
+    for v, q, a in data[:5]:
+        tr.step({"v": v, "q_idxes": q}, a)
+    assert tr._graph is not None
+    assert tr.begin_epoch(1, cf) is True
+    assert tr.adam_steps == 0 and tr.iteration == 0 and float(tr.flat.m.abs().max()) == 0.0
+    twin = build("cor2", 300)
+    twin.load_state_dict(model.state_dict())
+    tr2 = DataParallelTrainer(twin, lr=cf.lr, clip=0.25, graph=False)
+    v, q, a = data[5]
+    l1, _ = tr.step({"v": v, "q_idxes": q}, a)          # replayed
+    l2, _ = tr2.step({"v": v, "q_idxes": q}, a)         # eager, step 1 of a new optimizer
+    assert abs(l1.item() - l2.item()) <= 1e-4 * abs(l2.item())
+    assert tr.lr == tr2.lr
+    for p, q_ in zip(model.parameters(), twin.parameters()):
+        assert (p - q_).abs().max().item() <= 2e-3 * max(p.abs().max().item(), 1e-3)

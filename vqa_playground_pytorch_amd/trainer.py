@@ -126,6 +126,7 @@ class FlatState:
             offs.append(off)
             off += (p.numel() + 3) // 4 * 4
         self.total = off
+        self.offsets = offs
         self.p = torch.zeros(off, device=dev, dtype=torch.float32)
         self.g = torch.zeros(off, device=dev, dtype=torch.float32)
         self.m = torch.zeros(off, device=dev, dtype=torch.float32)
@@ -172,7 +173,8 @@ class DataParallelTrainer:
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0, group=group)
         self.gamma = gamma
-        self.iteration = 0
+        self.iteration = 0          # scheduler.last_epoch: restarts with every (re-)created scheduler, also on resume
+        self.adam_steps = 0         # Adam's per-parameter `step`: travels with the optimizer state
         self.base_lr = lr
         self._lr = lr
         self.betas, self.eps = (0.9, 0.999), 1e-8           # torch.optim.Adam defaults (train.py:290)
@@ -226,6 +228,7 @@ class DataParallelTrainer:
         loss = kld_sum_loss(logits, target)
         # scheduler.step() precedes optimizer.step() in the reference (train.py:75-86): step t uses lr0*gamma^t
         self.iteration += 1
+        self.adam_steps += 1
         self._lr = lr = self.base_lr * self.gamma ** self.iteration
         if self.hip:
             from . import ops
@@ -236,7 +239,7 @@ class DataParallelTrainer:
             if self.world > 1:
                 dist.all_reduce(f.g, op=dist.ReduceOp.SUM, group=self.group)
             ops.grad_norm_clip_coef(f.g, self.clip if self.clip else 0.0, f.norm_and_coef, f.workspace)
-            ops.adam_step(f.p, f.g, f.m, f.v, f.norm_and_coef, lr, self.betas[0], self.betas[1], self.eps, self.iteration)
+            ops.adam_step(f.p, f.g, f.m, f.v, f.norm_and_coef, lr, self.betas[0], self.betas[1], self.eps, self.adam_steps)
             return loss.detach(), f.norm_and_coef[0]
         for gp in self.optimizer.param_groups:
             gp["lr"] = lr
@@ -272,10 +275,11 @@ class DataParallelTrainer:
 
     def _set_step_scalars(self):
         self.iteration += 1
+        self.adam_steps += 1
         self._lr = lr = self.base_lr * self.gamma ** self.iteration
-        slot = self.iteration % self._ring
-        self._step_scalars_host[slot, 0] = lr / (1.0 - self.betas[0] ** self.iteration)
-        self._step_scalars_host[slot, 1] = 1.0 / (1.0 - self.betas[1] ** self.iteration) ** 0.5
+        slot = self.adam_steps % self._ring
+        self._step_scalars_host[slot, 0] = lr / (1.0 - self.betas[0] ** self.adam_steps)
+        self._step_scalars_host[slot, 1] = 1.0 / (1.0 - self.betas[1] ** self.adam_steps) ** 0.5
         self.step_scalars.copy_(self._step_scalars_host[slot], non_blocking=True)
         self._seed_host[slot, 0] = int(torch.randint(0, 2 ** 62, (1,), device="cpu").item())   # torch.manual_seed governs it
         self.seed_word.copy_(self._seed_host[slot], non_blocking=True)
@@ -368,3 +372,124 @@ class DataParallelTrainer:
     @property
     def lr(self):
         return self._lr
+
+    # ---- optimizer (re-)creation and the reference's checkpoint files -----------------------------------------------
+    def _optimizer_params(self):
+        # train.py:288-292: filter(lambda p: p.requires_grad, model.parameters()) -- the order of the saved state
+        return [p for p in self.model.parameters() if p.requires_grad]
+
+    def reset_optimizer(self, lr=None):
+        """``optimizer, scheduler = learning_scheduler(cf)`` (train.py:286-299): fresh Adam moments and step count, the
+        learning rate back at ``cf.lr`` and a scheduler that starts over."""
+        if lr is not None:
+            self.base_lr = lr
+        self.iteration = 0
+        self.adam_steps = 0
+        self._lr = self.base_lr
+        if self.hip:
+            # fills are kernels and the moment buffers keep their addresses: a captured step stays valid
+            self.flat.m.zero_()
+            self.flat.v.zero_()
+        else:
+            self.optimizer = torch.optim.Adam(self.grads.params, lr=self.base_lr)
+
+    def begin_epoch(self, epoch, cf):
+        """The optimizer re-creation rule at the top of the reference's epoch loop (train.py:718-721): at
+        ``cf.restart_epoch``, and before every epoch below ``cf.keeping_epoch``.  Returns True if it was re-created."""
+        lr = getattr(cf, "lr", None)
+        if hasattr(cf, "restart_epoch") and epoch == cf.restart_epoch:
+            self.reset_optimizer(lr)
+            return True
+        if getattr(cf, "keeping_epoch", None) is not None and epoch < cf.keeping_epoch:
+            self.reset_optimizer(lr)
+            return True
+        return False
+
+    def optimizer_state_dict(self):
+        """``optimizer.state_dict()`` of the reference's torch.optim.Adam (train.py:290, saved at :729): per-parameter
+        ``step`` / ``exp_avg`` / ``exp_avg_sq`` keyed by the index of the parameter in the filtered
+        ``model.parameters()`` order, one param group.  Loadable by ``torch.optim.Adam.load_state_dict``."""
+        if not self.hip:
+            return self.optimizer.state_dict()
+        f = self.flat
+        where = {id(p): (o, p) for p, o in zip(f.params, f.offsets)}
+        params = self._optimizer_params()
+        state = {}
+        if self.adam_steps > 0:
+            for i, p in enumerate(params):
+                o, _ = where[id(p)]
+                n = p.numel()
+                state[i] = {"step": self.adam_steps,
+                            "exp_avg": f.m[o:o + n].view_as(p).clone(),
+                            "exp_avg_sq": f.v[o:o + n].view_as(p).clone()}
+        group = {"lr": self._lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "initial_lr": self.base_lr, "params": list(range(len(params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        """``optimizer.load_state_dict`` (train.py:283).  As in the reference, the scheduler is not part of the
+        checkpoint: it was created just before the load (train.py:519,:575) and starts over from ``cf.lr``, while
+        Adam's moments and step count continue."""
+        if not self.hip:
+            self.optimizer.load_state_dict(sd)
+            return
+        f = self.flat
+        where = {id(p): o for p, o in zip(f.params, f.offsets)}
+        params = self._optimizer_params()
+        group = sd["param_groups"][0]
+        if len(sd["param_groups"]) != 1 or len(group["params"]) != len(params):
+            raise ValueError("loaded state dict has a different number of parameter groups / parameters")
+        self.betas = tuple(group.get("betas", self.betas))
+        self.eps = group.get("eps", self.eps)
+        steps = set()
+        with torch.no_grad():
+            f.m.zero_()
+            f.v.zero_()
+            for key, p in zip(group["params"], params):
+                st = sd["state"].get(key)
+                if st is None:
+                    continue
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError("optimizer state of parameter %d has shape %s, expected %s"
+                                     % (key, tuple(st["exp_avg"].shape), tuple(p.shape)))
+                o, n = where[id(p)], p.numel()
+                f.m[o:o + n].view_as(p).copy_(st["exp_avg"])
+                f.v[o:o + n].view_as(p).copy_(st["exp_avg_sq"])
+                steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise ValueError("per-parameter Adam step counts differ (%s): one fused step count is kept" % sorted(steps))
+        self.adam_steps = steps.pop() if steps else 0
+        self.iteration = 0
+        self._lr = self.base_lr
+
+    def save_checkpoint(self, info, log_dir):
+        """train.py:250-267: ``log_dir/epoch_<n>/ckpt_{info,model,optim}.pth.tar`` holding ``info``, the model's
+        ``state_dict()`` (the reference's ``model.module.state_dict()`` names) and the optimizer state.
+        Replicas are identical, so only rank 0 writes."""
+        import os
+        if self.world > 1 and dist.get_rank(self.group) != 0:
+            return None
+        path = os.path.join(log_dir, "epoch_%d" % info["epoch"])
+        os.makedirs(path, exist_ok=True)
+        logger = info.get("exp_logger")
+        if logger is not None and hasattr(logger, "to_json"):
+            logger.to_json(os.path.join(path, "logger.json"))
+        torch.save(info, os.path.join(path, "ckpt_info.pth.tar"))
+        torch.save({k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
+                   os.path.join(path, "ckpt_model.pth.tar"))
+        optim = self.optimizer_state_dict()
+        for st in optim["state"].values():
+            for k, v in st.items():
+                if torch.is_tensor(v):
+                    st[k] = v.cpu()
+        torch.save(optim, os.path.join(path, "ckpt_optim.pth.tar"))
+        return path
+
+    def load_checkpoint(self, path_ckpt):
+        """train.py:270-284; returns ``info['exp_logger']`` like the reference (None if the file holds none)."""
+        import os
+        info = torch.load(os.path.join(path_ckpt, "ckpt_info.pth.tar"), weights_only=False)
+        model_state = torch.load(os.path.join(path_ckpt, "ckpt_model.pth.tar"), map_location="cpu")
+        self.model.load_state_dict(model_state)      # copies into the flat parameter buffer's views
+        self.load_optimizer_state_dict(torch.load(os.path.join(path_ckpt, "ckpt_optim.pth.tar"), map_location="cpu"))
+        return info.get("exp_logger") if isinstance(info, dict) else None
