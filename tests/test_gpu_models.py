@@ -408,6 +408,11 @@ def test_checkpoint_round_trip_and_torch_adam_interop(tmp_path):
         assert torch.equal(st["exp_avg"], tr.flat.m[o:o + p.numel()].view_as(p).cpu())
         assert torch.equal(st["exp_avg_sq"], tr.flat.v[o:o + p.numel()].view_as(p).cpu())
 
+    # ... and stock Adam's own state dict (tensor-valued `step`) loads back into the fused optimizer unchanged
+    m_before, v_before = tr.flat.m.clone(), tr.flat.v.clone()
+    tr.load_optimizer_state_dict(adam.state_dict())
+    assert tr.adam_steps == 5 and torch.equal(tr.flat.m, m_before) and torch.equal(tr.flat.v, v_before)
+
     # resume in a replica with other initial weights
     from vqa_playground_pytorch_amd import CoR2Model
     torch.manual_seed(7)
