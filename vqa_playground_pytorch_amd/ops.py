@@ -7,6 +7,7 @@ configs[4]), bf16, which selects the ``*_bf16`` entry points; anything else rais
 eager/CPU fallback.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -879,7 +880,9 @@ def adam_step_dyn(p_flat, g_flat, m_flat, v_flat, norm_and_coef, step_scalars, b
 
 
 host_seed_draws = 0  # bumped whenever a kernel's dropout seed is drawn on the host (such a step cannot be graph-replayed)
-_device_seed = None   # (int64 CUDA tensor [1], next salt) installed by the trainer for graph-replayed steps
+# [int64 CUDA tensor [1], next salt] installed by the trainer for graph-replayed steps.  Per thread: nn.DataParallel
+# drives one replica per thread, each on its own device, and a seed word belongs to one device
+_seed_state = threading.local()
 _SALT_STRIDE = 0x9E3779B97F4A7C15 & 0x3FFFFFFFFFFFFFFF
 
 
@@ -892,23 +895,24 @@ def draw_host_seed():
 
 def set_device_seed(tensor):
     """Install (or with None remove) the device word the fused dropout kernels read their per-step seed from."""
-    global _device_seed
-    _device_seed = [tensor, 0] if tensor is not None else None
+    _seed_state.word = [tensor, 0] if tensor is not None else None
 
 
 def next_dropout_seed():
     """Seed for one fused-dropout call: (device tensor, salt) when the trainer installed a device seed word -- every
     call site of a step gets its own salt, the word itself moves once per step -- else a fresh host seed."""
-    if _device_seed is None:
+    word = getattr(_seed_state, "word", None)
+    if word is None:
         return draw_host_seed()
-    _device_seed[1] += 1
-    return (_device_seed[0], (_device_seed[1] * _SALT_STRIDE) & 0x3FFFFFFFFFFFFFFF)
+    word[1] += 1
+    return (word[0], (word[1] * _SALT_STRIDE) & 0x3FFFFFFFFFFFFFFF)
 
 
 def begin_step_salts():
     """Restart the per-call salt sequence (call at the start of every forward so eager and replayed steps agree)."""
-    if _device_seed is not None:
-        _device_seed[1] = 0
+    word = getattr(_seed_state, "word", None)
+    if word is not None:
+        word[1] = 0
 
 
 def linear_dropout_mask(M, K, p_drop, seed, device):
