@@ -194,6 +194,29 @@ int vqa_lowrank_bilinear_fusion_bwd(const float* x, int ldx, const float* const*
                                     size_t workspace_bytes, int B, int N, int L, int H, int R,
                                     vqa_stream_t stream);
 
+/* K4, rank-folded form (csrc/bilinear_folded.hip).  The question-side factor is the same for every region of
+ * a sample, so the sum over ranks of putils.MutanFusion.forward (putils/__init__.py:232-238) commutes with the
+ * contraction:  out[b,n,:] = Weff_b x[b,n,:] + c_b,  Weff_b[j,k] = sum_r h2[b,r,j] W1_r[j,k],
+ * c_b[j] = sum_r h2[b,r,j] b1_r[j]  -- one contraction per sample against a weight built on the fly: 1/R of the
+ * matrix work and no [M,R,H] intermediate.  Same arguments as vqa_lowrank_bilinear_fusion_fwd without h1.
+ * Limits: N <= 112 regions per sample, R <= 4 (R <= 2 above 48 regions), L / H / ldx even; vqa_lowrank_bilinear_fusion_folded_supported()
+ * returns 1 when a shape qualifies (callers use the unfolded entry points otherwise). */
+int vqa_lowrank_bilinear_fusion_folded_supported(int B, int N, int L, int H, int R);
+int vqa_lowrank_bilinear_fusion_folded_fwd(const float* x, int ldx, const float* const* w1,
+                                           const float* const* b1, const float* h2, float* out, int B,
+                                           int N, int L, int H, int R, vqa_stream_t stream);
+
+/* Backward of the rank-folded form: nothing saved by the forward.  dx = Weff_b^T g on the folded kernel; the
+ * per-sample product P_b = g_b^T x_b yields dW1_r = sum_b h2[b,r,:] (.) P_b, db1_r, and
+ * dh2[b,r,h] = sum_l W1_r[h,l] P_b[h,l] + b1_r[h] sum_n g[b,n,h] in one pass (fixed-order slab reductions).
+ * Arguments as vqa_lowrank_bilinear_fusion_bwd with b1 in place of h1. */
+size_t vqa_lowrank_bilinear_fusion_folded_bwd_workspace_bytes(int B, int N, int L, int H, int R);
+int vqa_lowrank_bilinear_fusion_folded_bwd(const float* x, int ldx, const float* const* w1,
+                                           const float* const* b1, const float* h2, const float* g,
+                                           float* d_x, float* const* d_w1, float* const* d_b1, float* d_h2,
+                                           void* workspace, size_t workspace_bytes, int B, int N, int L,
+                                           int H, int R, vqa_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Mixed-precision (bf16) side -- BASELINE configs[4] "CoR2 bf16, 100x2048 dense regions": bf16 storage and
  * bf16 MFMA operands (v_mfma_f32_32x32x16_bf16), fp32 accumulation, fp32 master weights.

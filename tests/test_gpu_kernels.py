@@ -190,10 +190,39 @@ def _fusion_case(ops, B, N, L, H, R, seed, need_dx=True, two_d=False):
         close("d_b1[%d]" % r, bs[r].grad, db1[r])
 
 
+@pytest.mark.parametrize("form", ["folded", "engine"])
 @pytest.mark.parametrize("B,N,L,H,R", [(3, 5, 8, 16, 2), (4, 36, 310, 510, 2), (2, 100, 310, 510, 2),
                                        (5, 7, 34, 66, 3), (1, 1, 2, 2, 1), (9, 36, 310, 510, 2)])
-def test_lowrank_bilinear_fusion(ops, B, N, L, H, R):
+def test_lowrank_bilinear_fusion(ops, monkeypatch, form, B, N, L, H, R):
+    """Both forms of K4: the rank-folded one (one contraction per sample against sum_r h2_r (.) W1_r, nothing saved for
+    backward) and the R-GEMM tile-engine one."""
+    monkeypatch.setattr(ops, "_K4_FORM", form)
     _fusion_case(ops, B, N, L, H, R, 300)
+
+
+@pytest.mark.parametrize("B,N,L,H,R", [
+    (3, 16, 32, 48, 2),      # L a multiple of the chunk: the bias rides in an extra chunk; one region block
+    (13, 17, 30, 80, 4),     # two region blocks, rank 4, batch tail of the 8- and 4-sample groups
+    (6, 32, 18, 64, 3), (5, 33, 50, 130, 1), (4, 48, 310, 510, 4),
+    (3, 49, 70, 96, 2), (2, 80, 40, 62, 2), (3, 81, 36, 160, 1), (2, 112, 64, 100, 2),   # 5- and 7-block variants
+    (17, 36, 310, 330, 2),   # output features: 5 tiles of 64 forward, 80-wide tiles in the data gradient
+])
+def test_lowrank_bilinear_fusion_folded_shapes(ops, monkeypatch, B, N, L, H, R):
+    from vqa_playground_pytorch_amd import _lib
+    assert _lib.lib().vqa_lowrank_bilinear_fusion_folded_supported(B, N, L, H, R) == 1
+    monkeypatch.setattr(ops, "_K4_FORM", "folded")
+    _fusion_case(ops, B, N, L, H, R, 360)
+    _fusion_case(ops, B, N, L, H, R, 370, need_dx=False)
+
+
+def test_lowrank_bilinear_fusion_folded_limits(ops):
+    """Shapes outside the folded form are served by the tile-engine kernels (same results, checked above)."""
+    from vqa_playground_pytorch_amd import _lib
+    sup = _lib.lib().vqa_lowrank_bilinear_fusion_folded_supported
+    assert sup(4, 113, 310, 510, 2) == 0 and sup(4, 36, 310, 510, 5) == 0 and sup(4, 100, 310, 510, 3) == 0
+    assert sup(4, 36, 311, 510, 2) == 0 and sup(4, 100, 310, 510, 2) == 1
+    _fusion_case(ops, 2, 113, 20, 34, 2, 380)      # N too large: falls through to the engine form
+    _fusion_case(ops, 3, 36, 20, 34, 5, 381)       # R too large
 
 
 @pytest.mark.parametrize("B,L,H,R", [(7, 1240, 510, 2), (5, 620, 510, 5), (64, 1240, 510, 2)])
@@ -204,6 +233,7 @@ def test_lowrank_bilinear_fusion_2d(ops, B, L, H, R):
 @pytest.mark.parametrize("tile", ["128x128", "64x128", "128x64", "64x64"])
 def test_lowrank_bilinear_fusion_every_tile_shape(ops, tile, monkeypatch):
     monkeypatch.setenv("VQA_GEMM_TILE", tile)
+    monkeypatch.setattr(ops, "_K4_FORM", "engine")
     _fusion_case(ops, 6, 36, 310, 510, 2, 340)
     _fusion_case(ops, 3, 50, 70, 130, 2, 350, need_dx=False)
 
@@ -232,8 +262,10 @@ def test_lowrank_bilinear_fusion_golden(ops, golden_dir):
         close(name, p.grad, blocks["mutan2d.g." + name + ".full"])
 
 
-def test_lowrank_bilinear_fusion_full_size_properties(ops):
+@pytest.mark.parametrize("form", ["folded", "engine"])
+def test_lowrank_bilinear_fusion_full_size_properties(ops, monkeypatch, form):
     """B=512 (M=18432): rank-sum linearity in h2 and agreement with a torch fp32 matmul restatement on GPU."""
+    monkeypatch.setattr(ops, "_K4_FORM", form)
     B, N, L, H, R = 512, 36, 310, 510, 2
     gen = torch.Generator(device="cpu").manual_seed(3)
     x = torch.randn(B, N, L, generator=gen).to(dev())

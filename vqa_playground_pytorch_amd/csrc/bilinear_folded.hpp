@@ -1,0 +1,20 @@
+// Host-side interface between bilinear_folded.hip (rank-folded forward / data gradient on v_mfma_f32_16x16x4_f32) and
+// bilinear_fusion.hip (the per-sample weight-gradient kernel on the 32x32 tile engine).
+#pragma once
+#include "common.hpp"
+
+namespace vqa {
+
+constexpr int kFoldMaxR = 4;
+constexpr int kFoldMaxN = 112;
+
+bool folded_supported(int B, int N, int L, int H, int R);
+
+// dx[b,n,:] = Weff_b^T g[b,n,:]   (w1t: R dense [L,H] transposes of W1_r in device memory)
+int folded_data_gradient(const float* g, const float* const* w1t, const float* h2, float* d_x, int B, int N, int L, int H,
+                         int R, hipStream_t s);
+
+// wt[r] = w1[r]^T   ([H,L] -> [L,H]), all ranks in one launch
+int folded_transpose_weights(const float* const* w1, float* wt, int L, int H, int R, hipStream_t s);
+
+}  // namespace vqa

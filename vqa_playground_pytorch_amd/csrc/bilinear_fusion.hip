@@ -14,6 +14,7 @@
 // (g * h2_r) is never materialised: it is formed while the A tile is staged.
 #include <cstdlib>
 
+#include "bilinear_folded.hpp"
 #include "gemm_f32_mfma.hpp"
 
 namespace vqa {
@@ -339,6 +340,114 @@ __global__ __launch_bounds__(kGemmThreads) void bilinear_dw_sample_kernel(
   }
 }
 
+// Rank-folded backward, weight side.  The per-sample product P_b = g_b^T x_b that the kernel above accumulates into
+// the weight gradients also carries the question-side gradient:
+//     dh2[b,r,h] = sum_n g[b,n,h] (W1_r x[b,n,:] + b1_r)[h] = sum_l W1_r[h,l] P_b[h,l] + b1_r[h] sum_n g[b,n,h]
+// so no [M,R,H] intermediate has to be saved by the forward.  The MFMA operands are swapped (gemm_tile SWAP_AB): a lane
+// then holds ONE feature h and 16 region-side columns l of the 32x32 block, the rank scaling reads one h2 value per
+// lane, and the sum over l is an in-lane dot product with the lane's W1_r registers -- the two lane halves meet in one
+// cross-lane add and the 2 * tiles_n partial sums per (b, r, h) go to a slab that a fixed-order kernel reduces.
+template <int BM, int BN, int PF, int R>
+__global__ __launch_bounds__(kGemmThreads) void bilinear_dw_dh2_kernel(
+    const float* __restrict__ g, const float* __restrict__ h2, const float* __restrict__ x, int ldx, RankPtrs rp,
+    float* __restrict__ slab, float* __restrict__ dbslab, float* __restrict__ dh2part, int B, int N, int L, int H,
+    int tiles_m, int tiles_n, int samples_per_split, int SP, uint32_t inv) {
+  using T = GemmTile<BM, BN, 16, false, false>;
+  static_assert(T::TM == 1 && T::TN == 1, "one 32x32 block per wave");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* smem = reinterpret_cast<float*>(smem_raw);
+  float* h2_s = smem + 2 * T::kStageFloats;  // [samples of the slab][R][BM]
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles = tiles_m * tiles_n;
+  const int s = bid / tiles, tile = bid % tiles;
+  const int tile_n = tile % tiles_n;
+  const int h0 = (tile / tiles_n) * BM, l0 = tile_n * BN;
+  const int b_lo = s * samples_per_split;
+  const int nb = max(0, min(B - b_lo, samples_per_split));
+  for (int t = threadIdx.x; t < nb * R * BM; t += kGemmThreads) {
+    const int hh = t % BM, r = (t / BM) % R, bb = t / (BM * R);
+    h2_s[t] = h0 + hh < H ? h2[((size_t)(b_lo + bb) * R + r) * H + h0 + hh] : 0.f;
+  }
+  // (visible after the first barrier inside gemm_tile)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+  const int hloc = wm * 32 + (lane & 31), h = h0 + hloc;        // this lane's feature
+  const int lbase = l0 + wn * 32 + 4 * (lane >> 5);            // + (i & 3) + 8 * (i >> 2): its 16 region-side columns
+  float wreg[R][16], b1v[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    b1v[r] = (l0 == 0 && wn == 0 && h < H) ? rp.b[r][h] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int l = lbase + (i & 3) + 8 * (i >> 2);
+      wreg[r][i] = (h < H && l < L) ? rp.w[r][(size_t)h * L + l] : 0.f;
+    }
+  }
+  f32x16 P[1][1], acc[R];
+  zero_acc(P);
+  float colsum[1] = {0.f}, dbacc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+    dbacc[r] = 0.f;
+  }
+  const SampleRows sr{N, SP * 16, b_lo, max(nb, 1), inv};
+  const SrcSampleMC sa{g, H, H, sr};
+  const SrcSampleMC sb{x, ldx, L, sr};
+  float* __restrict__ part = dh2part + (size_t)(tile_n * 2 + wn) * B * R * H;
+  auto fold = [&](int st) {
+    if ((st + 1) % SP != 0) return;
+    const int bb = st / SP;
+    const float* __restrict__ hb = h2_s + (size_t)bb * R * BM;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float sc = hb[r * BM + hloc];
+      float d = b1v[r] * colsum[0];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        acc[r][i] = fmaf(sc, P[0][0][i], acc[r][i]);
+        d = fmaf(wreg[r][i], P[0][0][i], d);
+      }
+      dbacc[r] = fmaf(sc, colsum[0], dbacc[r]);
+      d += __shfl_xor(d, 32, 64);
+      if (lane < 32 && h < H) part[((size_t)(b_lo + bb) * R + r) * H + h] = d;
+    }
+    zero_acc(P);
+    colsum[0] = 0.f;
+  };
+  if (nb > 0) gemm_tile<BM, BN, 16, PF, false, false, true>(sa, sb, h0, l0, 0, nb * SP * 16, smem, P, colsum, fold);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (l0 == 0 && wn == 0) {
+      const float t = dbacc[r] + __shfl_xor(dbacc[r], 32, 64);
+      if (lane < 32 && h < H) dbslab[((size_t)s * R + r) * H + h] = t;
+    }
+    if (h < H) {
+      float* __restrict__ dst = slab + ((size_t)s * R + r) * H * L + (size_t)h * L;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {   // registers 4q .. 4q+3 are four consecutive columns
+        const int l = lbase + 8 * q;
+        if (l < L) st2(dst + l, make_float2(acc[r][4 * q], acc[r][4 * q + 1]));
+        if (l + 2 < L) st2(dst + l + 2, make_float2(acc[r][4 * q + 2], acc[r][4 * q + 3]));
+      }
+    }
+  }
+}
+
+// dh2[e] = sum_p part[p][e]   (e over B*R*H, float2 lanes; fixed order)
+__global__ __launch_bounds__(256) void bilinear_dh2_reduce_kernel(const float* __restrict__ part, float* __restrict__ dh2,
+                                                                  size_t n, int parts) {
+  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (e >= n) return;
+  float2 a = make_float2(0.f, 0.f);
+  for (int p = 0; p < parts; ++p) {
+    const float2 t = ld2(part + (size_t)p * n + e);
+    a.x += t.x;
+    a.y += t.y;
+  }
+  st2(dh2 + e, a);
+}
+
 // d_w1[r][h][l] = sum_s slab[s][r][h][l]   (fixed order: bitwise reproducible)
 __global__ __launch_bounds__(256) void bilinear_dw_reduce_kernel(const float* __restrict__ slab,
                                                                  const float* __restrict__ dbslab, RankOutPtrs out,
@@ -584,4 +693,104 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd(const float* x, int ldx, const fl
     hipLaunchKernelGGL(bilinear_dw_reduce_kernel, dim3((HL / 2 + 255) / 256, R), dim3(256), 0, s, slab, dbslab, ro, HL, H, R, S);
   }
   return check_launch("lowrank_bilinear_fusion_bwd");
+}
+
+// ---- rank-folded backward (forward: bilinear_folded.hip) -----------------------------------------------------------
+static size_t folded_bwd_floats(int B, int L, int H, int R, size_t* wt_off, size_t* slab_off, size_t* db_off,
+                                size_t* part_off) {
+  const TileChoice t{64, 64, 2};
+  const int S = dw_sample_splits(B, H, L, t), tiles_n = (L + t.bn - 1) / t.bn;
+  size_t off = 0;
+  *wt_off = off;
+  off += (size_t)R * L * H;
+  *slab_off = off;
+  off += (size_t)S * R * H * L;
+  *db_off = off;
+  off += (size_t)S * R * H;
+  off = (off + 3) / 4 * 4;
+  *part_off = off;
+  off += (size_t)2 * tiles_n * B * R * H;
+  return off;
+}
+
+extern "C" size_t vqa_lowrank_bilinear_fusion_folded_bwd_workspace_bytes(int B, int N, int L, int H, int R) {
+  if (!folded_supported(B, N, L, H, R)) return 0;
+  size_t a, b, c, d;
+  return folded_bwd_floats(B, L, H, R, &a, &b, &c, &d) * sizeof(float);
+}
+
+extern "C" int vqa_lowrank_bilinear_fusion_folded_bwd(const float* x, int ldx, const float* const* w1,
+                                                      const float* const* b1, const float* h2, const float* g, float* d_x,
+                                                      float* const* d_w1, float* const* d_b1, float* d_h2, void* workspace,
+                                                      size_t workspace_bytes, int B, int N, int L, int H, int R,
+                                                      vqa_stream_t stream) {
+  VQA_REQUIRE(x && w1 && b1 && h2 && g && d_w1 && d_b1 && d_h2 && workspace, VQA_E_BADARG,
+              "lowrank_bilinear_fusion_folded_bwd: null pointer");
+  VQA_REQUIRE(folded_supported(B, N, L, H, R), VQA_E_UNSUPPORTED,
+              "lowrank_bilinear_fusion_folded_bwd: shape outside the folded form (B=%d N=%d L=%d H=%d R=%d)", B, N, L, H, R);
+  int rc = check_common("lowrank_bilinear_fusion_folded_bwd", x, ldx, B, N, L, H, R);
+  if (rc != VQA_OK) return rc;
+  VQA_REQUIRE(workspace_bytes >= vqa_lowrank_bilinear_fusion_folded_bwd_workspace_bytes(B, N, L, H, R), VQA_E_BADARG,
+              "lowrank_bilinear_fusion_folded_bwd: workspace of %zu B is too small", workspace_bytes);
+  RankPtrs rp{};
+  RankOutPtrs ro{};
+  for (int r = 0; r < R; ++r) {
+    VQA_REQUIRE(w1[r] && b1[r] && d_w1[r] && d_b1[r] && aligned(w1[r], 8) && aligned(d_w1[r], 8) && aligned(d_b1[r], 8),
+                VQA_E_BADARG, "lowrank_bilinear_fusion_folded_bwd: rank %d pointer null or unaligned", r);
+    rp.w[r] = w1[r];
+    rp.b[r] = b1[r];
+    ro.w[r] = d_w1[r];
+    ro.b[r] = d_b1[r];
+  }
+  VQA_REQUIRE(aligned(h2, 8) && aligned(g, 8) && aligned(d_h2, 8) && aligned(workspace, 16) && (d_x == nullptr || aligned(d_x, 8)),
+              VQA_E_UNSUPPORTED, "lowrank_bilinear_fusion_folded_bwd: tensors must be 8-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  size_t wt_off, slab_off, db_off, part_off;
+  folded_bwd_floats(B, L, H, R, &wt_off, &slab_off, &db_off, &part_off);
+  float* ws = static_cast<float*>(workspace);
+  float *wt = ws + wt_off, *slab = ws + slab_off, *dbslab = ws + db_off, *part = ws + part_off;
+
+  // (1) dx = Weff^T g on the folded kernel (needs W1_r^T, contraction-contiguous)
+  if (d_x != nullptr) {
+    rc = folded_transpose_weights(w1, wt, L, H, R, s);
+    if (rc != VQA_OK) return rc;
+    const float* wtp[kFoldMaxR];
+    for (int r = 0; r < R; ++r) wtp[r] = wt + (size_t)r * L * H;
+    rc = folded_data_gradient(g, wtp, h2, d_x, B, N, L, H, R, s);
+    if (rc != VQA_OK) return rc;
+  }
+  // (2) P_b = g_b^T x_b once per sample: dW1_r, db1_r slabs and the dh2 partial sums
+  const TileChoice tw{64, 64, 2};
+  const int S = dw_sample_splits(B, H, L, tw);
+  const int tiles_m = (H + 63) / 64, tiles_n = (L + 63) / 64;
+  const int spl = (B + S - 1) / S, SP = (N + 15) / 16;
+  const uint32_t inv = (uint32_t)((1ull << 32) / (uint32_t)(SP * 16)) + 1u;
+  static const int pf = [] {   // register sets in flight (experiment knob; 1 keeps three waves per SIMD at R = 2)
+    const char* e = std::getenv("VQA_K4_FOLD_DW_PF");
+    return e != nullptr && std::atoi(e) == 2 ? 2 : 1;
+  }();
+#define LAUNCH_PF(R_, PF_)                                                                                                 \
+  {                                                                                                                        \
+    const size_t lds = GemmTile<64, 64, 16, false, false>::kSmemBytes + (size_t)spl * R_ * 64 * sizeof(float);             \
+    VQA_ENSURE_LDS((bilinear_dw_dh2_kernel<64, 64, PF_, R_>), lds);                                                        \
+    hipLaunchKernelGGL((bilinear_dw_dh2_kernel<64, 64, PF_, R_>), dim3(tiles_m * tiles_n * S), dim3(kGemmThreads), lds, s, \
+                       g, h2, x, ldx, rp, slab, dbslab, part, B, N, L, H, tiles_m, tiles_n, spl, SP, inv);                 \
+  }
+#define LAUNCH_R(R_) \
+  if (pf == 2) LAUNCH_PF(R_, 2) else LAUNCH_PF(R_, 1)
+  switch (R) {
+    case 1: LAUNCH_R(1) break;
+    case 2: LAUNCH_R(2) break;
+    case 3: LAUNCH_R(3) break;
+    default: LAUNCH_R(4) break;
+  }
+#undef LAUNCH_R
+#undef LAUNCH_PF
+  // (3) fixed-order reductions
+  const int HL = H * L;
+  hipLaunchKernelGGL(bilinear_dw_reduce_kernel, dim3((HL / 2 + 255) / 256, R), dim3(256), 0, s, slab, dbslab, ro, HL, H, R, S);
+  const size_t n = (size_t)B * R * H;
+  hipLaunchKernelGGL(bilinear_dh2_reduce_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, s, part, d_h2, n,
+                     2 * tiles_n);
+  return check_launch("lowrank_bilinear_fusion_folded_bwd");
 }

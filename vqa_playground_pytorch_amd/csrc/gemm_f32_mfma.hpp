@@ -95,7 +95,11 @@ struct NoStageHook {
 // behind the stage's barrier, outside the MFMA / staging interleave, so it may branch) -- lets a caller fold the
 // accumulators away at segment boundaries inside ONE software pipeline (the per-sample rank scaling of the bilinear
 // weight gradient).
-template <int BM, int BN, int BK, int PF, bool A_KC, bool B_KC, class SrcA, class SrcB, class Hook = NoStageHook>
+// SWAP_AB: feed the B fragment as the instruction's A operand and vice versa -- the accumulator block then holds the
+// TRANSPOSED 32x32 tile (lane: column = its A-tile row index, 16 rows = B-tile column indices), which turns a reduction
+// over the B-side index into an in-lane sum (dh2 of the rank-folded bilinear backward).
+template <int BM, int BN, int BK, int PF, bool A_KC, bool B_KC, bool SWAP_AB = false, class SrcA, class SrcB,
+          class Hook = NoStageHook>
 __device__ __forceinline__ void gemm_tile(const SrcA& srcA, const SrcB& srcB, int m0, int n0, int k_begin, int k_end,
                                           float* smem, f32x16 (&acc)[BM / 64][BN / 64],
                                           float* a_colsum = nullptr, Hook hook = Hook()) {
@@ -148,7 +152,8 @@ __device__ __forceinline__ void gemm_tile(const SrcA& srcA, const SrcB& srcB, in
       for (int i = 0; i < T::TM; ++i)
 #pragma unroll
         for (int j = 0; j < T::TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp][i], b[kp][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = SWAP_AB ? __builtin_amdgcn_mfma_f32_32x32x2f32(b[kp][j], a[kp][i], acc[i][j], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp][i], b[kp][j], acc[i][j], 0, 0, 0);
     if (a_colsum != nullptr) {
 #pragma unroll
       for (int kp = 0; kp < BK / 2; ++kp)

@@ -7,6 +7,7 @@ configs[4]), bf16, which selects the ``*_bf16`` entry points; anything else rais
 eager/CPU fallback.
 """
 import ctypes
+import os
 import threading
 
 import torch
@@ -277,6 +278,9 @@ def attention_logits_supported(x, in_features, out_features):
         x.shape[-1] % (4 if x.dtype == torch.bfloat16 else 2) == 0
 
 
+_K4_FORM = os.environ.get("VQA_K4_FORM", "folded")   # "engine": always the R-GEMM tile-engine kernels
+
+
 class LowRankBilinearFusion(torch.autograd.Function):
     """K4.  out[b,n,:] = sum_r (x[b,n,:] W1_r^T + b1_r) * h2[b,r,:]   (x may also be [B,L]).
     Replaces the region side of putils.MutanFusion.forward (putils/__init__.py:232-238)."""
@@ -302,26 +306,48 @@ class LowRankBilinearFusion(torch.autograd.Function):
                                  % (r, tuple(w1[r].shape), tuple(b1[r].shape), H, L))
         need_bwd = any(ctx.needs_input_grad)
         out = torch.empty(*lead, H, device=x.device, dtype=torch.float32)
-        h1 = torch.empty(B * N, R, H, device=x.device, dtype=torch.float32) if need_bwd else None
-        _launch("lowrank_bilinear_fusion_fwd", (B, N, L, H, R, need_bwd), _lib.lib().vqa_lowrank_bilinear_fusion_fwd,
-                _p(x), L, _ptr_array(w1), _ptr_array(b1), _p(h2), _p(out), _p(h1), B, N, L, H, R)
-        if need_bwd:
-            ctx.save_for_backward(x, h2, h1, *w1)
+        L_ = _lib.lib()
+        # rank-folded form (csrc/bilinear_folded.hip): one contraction per sample against sum_r h2_r (.) W1_r, nothing
+        # saved for backward but the inputs; the R-GEMM tile-engine form serves the shapes it does not cover
+        folded = N > 1 and _K4_FORM != "engine" and bool(L_.vqa_lowrank_bilinear_fusion_folded_supported(B, N, L, H, R))
+        ctx.folded = folded
+        if folded:
+            _launch("lowrank_bilinear_fusion_fwd", (B, N, L, H, R, need_bwd), L_.vqa_lowrank_bilinear_fusion_folded_fwd,
+                    _p(x), L, _ptr_array(w1), _ptr_array(b1), _p(h2), _p(out), B, N, L, H, R)
+            if need_bwd:
+                ctx.save_for_backward(x, h2, *w1, *b1)
+        else:
+            h1 = torch.empty(B * N, R, H, device=x.device, dtype=torch.float32) if need_bwd else None
+            _launch("lowrank_bilinear_fusion_fwd", (B, N, L, H, R, need_bwd), L_.vqa_lowrank_bilinear_fusion_fwd,
+                    _p(x), L, _ptr_array(w1), _ptr_array(b1), _p(h2), _p(out), _p(h1), B, N, L, H, R)
+            if need_bwd:
+                ctx.save_for_backward(x, h2, h1, *w1)
         ctx.dims = (B, N, L, H, R)
         return out
 
     @staticmethod
     def backward(ctx, g):
         B, N, L, H, R = ctx.dims
-        x, h2, h1 = ctx.saved_tensors[:3]
-        w1 = list(ctx.saved_tensors[3:])
         g = _prep("grad_out", g)
+        L_ = _lib.lib()
+        if ctx.folded:
+            x, h2 = ctx.saved_tensors[:2]
+            w1, b1 = list(ctx.saved_tensors[2:2 + R]), list(ctx.saved_tensors[2 + R:])
+        else:
+            x, h2, h1 = ctx.saved_tensors[:3]
+            w1 = list(ctx.saved_tensors[3:])
         dev = x.device
         d_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         d_h2 = torch.empty_like(h2)
         d_w1 = [torch.empty_like(w) for w in w1]
         d_b1 = [torch.empty(H, device=dev, dtype=torch.float32) for _ in range(R)]
-        L_ = _lib.lib()
+        if ctx.folded:
+            ws_bytes = L_.vqa_lowrank_bilinear_fusion_folded_bwd_workspace_bytes(B, N, L, H, R)
+            ws = torch.empty((ws_bytes + 3) // 4, device=dev, dtype=torch.float32)
+            _launch("lowrank_bilinear_fusion_bwd", (B, N, L, H, R, d_x is not None), L_.vqa_lowrank_bilinear_fusion_folded_bwd,
+                    _p(x), L, _ptr_array(w1), _ptr_array(b1), _p(h2), _p(g), _p(d_x), _ptr_array(d_w1), _ptr_array(d_b1),
+                    _p(d_h2), _p(ws), ws_bytes, B, N, L, H, R)
+            return (d_x, d_h2, *d_w1, *d_b1)
         ws_bytes = L_.vqa_lowrank_bilinear_fusion_bwd_workspace_bytes(B, N, L, H, R)
         ws = torch.empty((ws_bytes + 3) // 4, device=dev, dtype=torch.float32)
         _launch("lowrank_bilinear_fusion_bwd", (B, N, L, H, R, d_x is not None), L_.vqa_lowrank_bilinear_fusion_bwd,
