@@ -34,6 +34,9 @@ BATCH, REGIONS, FEAT, QDIM, ANSWERS = 512, 36, 2048, 2400, 2000
 LOW, HID, GLIMPSES, RANK = 310, 510, 4, 2
 
 
+K4_FOLDED = os.environ.get("VQA_K4_FORM", "folded") != "engine"
+
+
 def kernel_models(B, N=REGIONS, D=FEAT, G=GLIMPSES, L=LOW, H=HID, R=RANK, bf16=False):
     """Algorithmic bytes / FLOPs per launch (SURVEY.md 8d per-sample figures x samples per launch).
     bf16=True: the region tensors (v, v2, their gradients) are 2 bytes per element, everything else stays fp32."""
@@ -69,7 +72,7 @@ def kernel_models(B, N=REGIONS, D=FEAT, G=GLIMPSES, L=LOW, H=HID, R=RANK, bf16=F
 # reads by exactly 2x on gfx950 (MI355X_MICROARCH.md, HBM section) and is taken as-is for the 8-byte-per-lane GEMM
 # staging loads (calibrated here against the algorithmic bytes of the K4 forward: 26.5 MB counted vs 26.1 MB expected).
 PMC_KERNELS = {  # C-ABI entry -> [(kernel-name prefix, grid, fetch multiplier)]
-    "lowrank_bilinear_fusion_fwd": [("vqa::bilinear_fwd_kernel", "589824", 1.0)],
+    "lowrank_bilinear_fusion_fwd": [("vqa::bilinear_folded_kernel<3, 2, true", "262144", 1.0)],
     "relation_apply_fwd": [("vqa::relation_apply_fwd_kernel", None, 2.0)],
     "relation_apply_bwd": [("vqa::relation_apply_bwd_kernel", None, 2.0)],
     "pairwise_relation_reduce_fwd": [("vqa::pairwise_fwd_reg_kernel", "262144", 2.0)],
@@ -109,9 +112,19 @@ def roofline_entry(name, shape, launches, mean_ms, B, regions=REGIONS, bf16=Fals
         achieved, peak, unit = work / sec / 1e12, MFMA_BF16_PEAK_TF, "TFLOP/s"
     else:  # "mfma" and "valu" share the fp32 peak on gfx950 (157.3 TFLOP/s for both pipes)
         achieved, peak, unit = work / sec / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
-    return {"kernel": name, "shape": list(shape), "launches": launches, "mean_ms": round(mean_ms, 5), "bound": bound,
-            "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
-            "traffic": pmc_traffic(name, B) if regions == REGIONS and not bf16 else None}
+    entry = {"kernel": name, "shape": list(shape), "launches": launches, "mean_ms": round(mean_ms, 5), "bound": bound,
+             "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
+             "traffic": pmc_traffic(name, B) if regions == REGIONS and not bf16 else None}
+    if name == "lowrank_bilinear_fusion_fwd" and K4_FOLDED and regions <= 112:
+        # `achieved` prices the kernel at SURVEY 8d's algorithmic FLOPs (R GEMMs per fusion).  The rank-folded kernel
+        # executes 1/R of them on the matrix core, plus the padding of a sample to whole 16-region blocks and of L / H to
+        # the 16-wide chunk / 64-wide tile: state what the MFMA pipe really ran as well.
+        nb = {1: 1, 2: 2, 3: 3, 4: 5, 5: 5, 6: 7, 7: 7}[(regions + 15) // 16]
+        executed = 2.0 * B * (nb * 16) * ((LOW + 1 + 15) // 16 * 16) * ((HID + 63) // 64 * 64)
+        entry["form"] = "rank-folded (csrc/bilinear_folded.hip)"
+        entry["mfma_flops_executed"] = int(executed)
+        entry["mfma_executed_tflops"] = round(executed / sec / 1e12, 2)
+    return entry
 
 
 def cpu_baseline_worker(batch, threads, budget_s):

@@ -696,10 +696,21 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd(const float* x, int ldx, const fl
 }
 
 // ---- rank-folded backward (forward: bilinear_folded.hip) -----------------------------------------------------------
+// sample slabs of the folded weight-gradient kernel: ONE round of resident workgroups (3 per CU at ranks 1-2, 2 above:
+// its register budget), as many slabs as fit -- 19 at B = 512 (sweep 16..64: 137 us + 12 us reduce, against 141 + 19
+// with the 32 slabs that suit the unfolded kernel, whose two-workgroup occupancy spreads over 1.7 rounds)
+static int dw_fold_splits(int B, int H, int L, int R) {
+  const long tiles = (long)((H + 63) / 64) * ((L + 63) / 64);
+  long s = (256L * (R <= 2 ? 3 : 2)) / tiles;
+  if (const char* e = std::getenv("VQA_K4_DW_SPLITS")) s = std::atol(e);  // experiment knob
+  if (s > B) s = B;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  return (int)s;
+}
 static size_t folded_bwd_floats(int B, int L, int H, int R, size_t* wt_off, size_t* slab_off, size_t* db_off,
                                 size_t* part_off) {
-  const TileChoice t{64, 64, 2};
-  const int S = dw_sample_splits(B, H, L, t), tiles_n = (L + t.bn - 1) / t.bn;
+  const int S = dw_fold_splits(B, H, L, R), tiles_n = (L + 63) / 64;
   size_t off = 0;
   *wt_off = off;
   off += (size_t)R * L * H;
@@ -760,8 +771,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_folded_bwd(const float* x, int ldx, c
     if (rc != VQA_OK) return rc;
   }
   // (2) P_b = g_b^T x_b once per sample: dW1_r, db1_r slabs and the dh2 partial sums
-  const TileChoice tw{64, 64, 2};
-  const int S = dw_sample_splits(B, H, L, tw);
+  const int S = dw_fold_splits(B, H, L, R);
   const int tiles_m = (H + 63) / 64, tiles_n = (L + 63) / 64;
   const int spl = (B + S - 1) / S, SP = (N + 15) / 16;
   const uint32_t inv = (uint32_t)((1ull << 32) / (uint32_t)(SP * 16)) + 1u;

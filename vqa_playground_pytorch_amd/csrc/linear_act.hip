@@ -239,8 +239,9 @@ static int splits_for_linear_dw(int M, int K, int N, TileChoice t) {
 static TileChoice linear_dw_tile() {
   TileChoice t = tile_override_or({64, 64, 2});
   if (const char* e = std::getenv("VQA_LINEAR_DW_TILE")) {  // experiment knob
-    int bm = 0, bn = 0;
-    if (std::sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) t = {bm, bn, 2};
+    int bm = 0, bn = 0, pf = 2;
+    const int got = std::sscanf(e, "%dx%dx%d", &bm, &bn, &pf);
+    if (got >= 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128) && pf >= 1 && pf <= 3) t = {bm, bn, pf};
   }
   return t;
 }
