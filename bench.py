@@ -68,7 +68,7 @@ def kernel_models(B, N=REGIONS, D=FEAT, G=GLIMPSES, L=LOW, H=HID, R=RANK, bf16=F
 
 
 # HBM-side traffic per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-# separate runs, KiB units; profiles/r01_e_pmc_traffic.json, built by tools/pmc_table.py).  FETCH_SIZE under-reports 16-byte-per-lane streaming
+# separate runs, KiB units; profiles/r01_f_pmc_traffic.json, built by tools/pmc_table.py).  FETCH_SIZE under-reports 16-byte-per-lane streaming
 # reads by exactly 2x on gfx950 (MI355X_MICROARCH.md, HBM section) and is taken as-is for the 8-byte-per-lane GEMM
 # staging loads (calibrated here against the algorithmic bytes of the K4 forward: 26.5 MB counted vs 26.1 MB expected).
 PMC_KERNELS = {  # C-ABI entry -> [(kernel-name prefix, grid, fetch multiplier)]
@@ -82,7 +82,7 @@ PMC_KERNELS = {  # C-ABI entry -> [(kernel-name prefix, grid, fetch multiplier)]
 
 
 def pmc_traffic(name, B):
-    path = os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")
     if B != BATCH or name not in PMC_KERNELS or not os.path.exists(path):
         return None
     table = json.load(open(path))

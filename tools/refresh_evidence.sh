@@ -1,0 +1,42 @@
+#!/bin/bash
+# Regenerates the measured evidence of a round on the MI355X box (run through gpurun from the repo root):
+#   bash tools/refresh_evidence.sh r01_f
+# Writes everything under gpurun_out/<tag>/ ; copy what is to be judged into profiles/.
+set -u
+TAG=${1:-r01_x}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+
+# 1. HBM traffic counters: two separate --pmc passes (never combined with trace domains), kernel by kernel
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$c
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-graph > "$OUT/pmc_$c.log" 2>&1
+done
+python3 "$ROOT/tools/pmc_table.py" /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE "$ROOT/profiles/${TAG}_pmc_traffic.json" > "$OUT/pmc_table.log" 2>&1
+cp "$ROOT/profiles/${TAG}_pmc_traffic.json" "$OUT/" 2>/dev/null
+
+# 2. bench lines
+cd "$ROOT"
+run() { name=$1; shift; timeout 900 python3 bench.py "$@" > "$OUT/$name.log" 2>&1; tail -1 "$OUT/$name.log" > "$OUT/$name.json"; }
+run bench_b512 --steps 20 --warmup 5
+run bench_b512_eager --steps 20 --warmup 5 --no-graph --no-cpu-baseline
+run bench_b512_pairwise --steps 20 --warmup 5 --relation-mode 0 --no-cpu-baseline
+run bench_f32_n100_b128 --regions 100 --batch 128 --steps 20 --warmup 5 --no-cpu-baseline
+run bench_bf16_n100_b128 --dtype bf16 --regions 100 --batch 128 --steps 20 --warmup 5 --no-cpu-baseline
+run bench_b512_encoder --encoder --steps 10 --warmup 5 --no-cpu-baseline
+run bench_oda_b512 --model oda --steps 20 --warmup 5 --no-cpu-baseline
+VQA_K4_FORM=engine run bench_b512_k4_engine --steps 20 --warmup 5 --no-cpu-baseline
+
+# 3. rocprofv3 kernel traces of the same commands (graph replay and kernel by kernel)
+cd /tmp
+for mode in graph eager; do
+  extra=""; [ $mode = eager ] && extra="--no-graph"
+  rm -rf /tmp/kt_$mode
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$mode -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline $extra > "$OUT/kt_$mode.log" 2>&1
+  f=$(find /tmp/kt_$mode -name "*kernel_stats.csv" | sort | sed -n 1p)
+  [ -n "$f" ] && cp "$f" "$OUT/bench_b512_${mode}_kernel_stats.csv"
+  python3 "$ROOT/tools/by_grid.py" /tmp/kt_$mode 1 "hand-written kernels, per-dispatch durations by (kernel, grid work-items); rocprofv3 --kernel-trace of bench.py --steps 20 --warmup 5 --no-cpu-baseline $extra (the last column is the total over the run)" > "$OUT/vqa_kernels_by_grid_$mode.txt" 2>&1
+done
+ls -la "$OUT"

@@ -228,7 +228,8 @@ __global__ __launch_bounds__(256) void linear_dw_reduce_kernel(const float* __re
 
 static int splits_for_linear_dw(int M, int K, int N, TileChoice t) {
   const long tiles = (long)((N + t.bm - 1) / t.bm) * ((K + t.bn - 1) / t.bn);
-  long s = (1280 + tiles - 1) / tiles;  // 5 workgroups per CU (sweep at N x K = 310 x 2048, M = 18432: 8 splits)
+  long s = (2560 + tiles - 1) / tiles;  // 10 workgroups per CU (sweep 4..24 at N x K = 310 x 2048, M = 18432: 16 splits, 256 us
+                                        // with the slab reduction against 267 at 8; the curve is flat from 12 to 24)
   if (const char* e = std::getenv("VQA_LINEAR_DW_SPLITS")) s = std::atol(e);  // experiment knob
   const long max_by_rows = (M + 255) / 256;
   if (s > max_by_rows) s = max_by_rows;
