@@ -347,12 +347,15 @@ __global__ __launch_bounds__(kGemmThreads) void bilinear_dw_sample_kernel(
 // then holds ONE feature h and 16 region-side columns l of the 32x32 block, the rank scaling reads one h2 value per
 // lane, and the sum over l is an in-lane dot product with the lane's W1_r registers -- the two lane halves meet in one
 // cross-lane add and the 2 * tiles_n partial sums per (b, r, h) go to a slab that a fixed-order kernel reduces.
-template <int BM, int BN, int PF, int R>
+// BK: rows of a pipeline stage.  16 in general (a sample = SP stages of 16 rows); 40 when a whole sample fits one stage
+// (32 < N <= 40, the reference's 36 regions): one barrier and one fold per sample instead of three, 40 instead of 48
+// padded rows.
+template <int BM, int BN, int PF, int R, int BK>
 __global__ __launch_bounds__(kGemmThreads) void bilinear_dw_dh2_kernel(
     const float* __restrict__ g, const float* __restrict__ h2, const float* __restrict__ x, int ldx, RankPtrs rp,
     float* __restrict__ slab, float* __restrict__ dbslab, float* __restrict__ dh2part, int B, int N, int L, int H,
     int tiles_m, int tiles_n, int samples_per_split, int SP, uint32_t inv) {
-  using T = GemmTile<BM, BN, 16, false, false>;
+  using T = GemmTile<BM, BN, BK, false, false>;
   static_assert(T::TM == 1 && T::TN == 1, "one 32x32 block per wave");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* smem = reinterpret_cast<float*>(smem_raw);
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(kGemmThreads) void bilinear_dw_dh2_kernel(
     for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
     dbacc[r] = 0.f;
   }
-  const SampleRows sr{N, SP * 16, b_lo, max(nb, 1), inv};
+  const SampleRows sr{N, SP * BK, b_lo, max(nb, 1), inv};
   const SrcSampleMC sa{g, H, H, sr};
   const SrcSampleMC sb{x, ldx, L, sr};
   float* __restrict__ part = dh2part + (size_t)(tile_n * 2 + wn) * B * R * H;
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(kGemmThreads) void bilinear_dw_dh2_kernel(
     zero_acc(P);
     colsum[0] = 0.f;
   };
-  if (nb > 0) gemm_tile<BM, BN, 16, PF, false, false, true>(sa, sb, h0, l0, 0, nb * SP * 16, smem, P, colsum, fold);
+  if (nb > 0) gemm_tile<BM, BN, BK, PF, false, false, true>(sa, sb, h0, l0, 0, nb * SP * BK, smem, P, colsum, fold);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     if (l0 == 0 && wn == 0) {
@@ -696,21 +699,30 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd(const float* x, int ldx, const fl
 }
 
 // ---- rank-folded backward (forward: bilinear_folded.hip) -----------------------------------------------------------
-// sample slabs of the folded weight-gradient kernel: ONE round of resident workgroups (3 per CU at ranks 1-2, 2 above:
-// its register budget), as many slabs as fit -- 19 at B = 512 (sweep 16..64: 137 us + 12 us reduce, against 141 + 19
-// with the 32 slabs that suit the unfolded kernel, whose two-workgroup occupancy spreads over 1.7 rounds)
-static int dw_fold_splits(int B, int H, int L, int R) {
+// sample slabs of the folded weight-gradient kernel: ONE round of resident workgroups (register budget: 3 per CU at
+// ranks 1-2 with 16-row stages, 2 otherwise), as many slabs as fit -- at B = 512, N = 36: 12 slabs of the one-stage-per-
+// sample form, 133 us + 8 us reduce (sweeps: 19 slabs of the 16-row form 137 + 12; 32 slabs 141 + 19).  The kernel is
+// bound by the L2 -> LDS operand traffic of its 64x64 tiles (16 FLOP per byte), not by barriers or padding.
+static int dw_fold_bk(int N, int R) {
+  static const int knob = [] {   // experiment knob: 16 forces the three-stage form at 32 < N <= 40
+    const char* e = std::getenv("VQA_K4_FOLD_DW_BK");
+    return e != nullptr ? std::atoi(e) : 0;
+  }();
+  return (N > 32 && N <= 40 && R <= 2 && knob != 16) ? 40 : 16;
+}
+static int dw_fold_splits(int B, int N, int H, int L, int R) {
   const long tiles = (long)((H + 63) / 64) * ((L + 63) / 64);
-  long s = (256L * (R <= 2 ? 3 : 2)) / tiles;
+  const int resident = dw_fold_bk(N, R) == 40 ? 2 : (R <= 2 ? 3 : 2);   // workgroups per CU (register budget)
+  long s = (256L * resident) / tiles;
   if (const char* e = std::getenv("VQA_K4_DW_SPLITS")) s = std::atol(e);  // experiment knob
   if (s > B) s = B;
   if (s > 64) s = 64;
   if (s < 1) s = 1;
   return (int)s;
 }
-static size_t folded_bwd_floats(int B, int L, int H, int R, size_t* wt_off, size_t* slab_off, size_t* db_off,
+static size_t folded_bwd_floats(int B, int N, int L, int H, int R, size_t* wt_off, size_t* slab_off, size_t* db_off,
                                 size_t* part_off) {
-  const int S = dw_fold_splits(B, H, L, R), tiles_n = (L + 63) / 64;
+  const int S = dw_fold_splits(B, N, H, L, R), tiles_n = (L + 63) / 64;
   size_t off = 0;
   *wt_off = off;
   off += (size_t)R * L * H;
@@ -727,7 +739,7 @@ static size_t folded_bwd_floats(int B, int L, int H, int R, size_t* wt_off, size
 extern "C" size_t vqa_lowrank_bilinear_fusion_folded_bwd_workspace_bytes(int B, int N, int L, int H, int R) {
   if (!folded_supported(B, N, L, H, R)) return 0;
   size_t a, b, c, d;
-  return folded_bwd_floats(B, L, H, R, &a, &b, &c, &d) * sizeof(float);
+  return folded_bwd_floats(B, N, L, H, R, &a, &b, &c, &d) * sizeof(float);
 }
 
 extern "C" int vqa_lowrank_bilinear_fusion_folded_bwd(const float* x, int ldx, const float* const* w1,
@@ -757,7 +769,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_folded_bwd(const float* x, int ldx, c
               VQA_E_UNSUPPORTED, "lowrank_bilinear_fusion_folded_bwd: tensors must be 8-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   size_t wt_off, slab_off, db_off, part_off;
-  folded_bwd_floats(B, L, H, R, &wt_off, &slab_off, &db_off, &part_off);
+  folded_bwd_floats(B, N, L, H, R, &wt_off, &slab_off, &db_off, &part_off);
   float* ws = static_cast<float*>(workspace);
   float *wt = ws + wt_off, *slab = ws + slab_off, *dbslab = ws + db_off, *part = ws + part_off;
 
@@ -771,21 +783,24 @@ extern "C" int vqa_lowrank_bilinear_fusion_folded_bwd(const float* x, int ldx, c
     if (rc != VQA_OK) return rc;
   }
   // (2) P_b = g_b^T x_b once per sample: dW1_r, db1_r slabs and the dh2 partial sums
-  const int S = dw_fold_splits(B, H, L, R);
+  const int S = dw_fold_splits(B, N, H, L, R);
   const int tiles_m = (H + 63) / 64, tiles_n = (L + 63) / 64;
-  const int spl = (B + S - 1) / S, SP = (N + 15) / 16;
-  const uint32_t inv = (uint32_t)((1ull << 32) / (uint32_t)(SP * 16)) + 1u;
   static const int pf = [] {   // register sets in flight (experiment knob; 1 keeps three waves per SIMD at R = 2)
     const char* e = std::getenv("VQA_K4_FOLD_DW_PF");
     return e != nullptr && std::atoi(e) == 2 ? 2 : 1;
   }();
-#define LAUNCH_PF(R_, PF_)                                                                                                 \
-  {                                                                                                                        \
-    const size_t lds = GemmTile<64, 64, 16, false, false>::kSmemBytes + (size_t)spl * R_ * 64 * sizeof(float);             \
-    VQA_ENSURE_LDS((bilinear_dw_dh2_kernel<64, 64, PF_, R_>), lds);                                                        \
-    hipLaunchKernelGGL((bilinear_dw_dh2_kernel<64, 64, PF_, R_>), dim3(tiles_m * tiles_n * S), dim3(kGemmThreads), lds, s, \
-                       g, h2, x, ldx, rp, slab, dbslab, part, B, N, L, H, tiles_m, tiles_n, spl, SP, inv);                 \
+  const int bk = dw_fold_bk(N, R);
+  const int spl = (B + S - 1) / S, SP = (N + bk - 1) / bk;
+  const uint32_t inv = (uint32_t)((1ull << 32) / (uint32_t)(SP * bk)) + 1u;
+#define LAUNCH_K(R_, PF_, BK_)                                                                                                  \
+  {                                                                                                                             \
+    const size_t lds = GemmTile<64, 64, BK_, false, false>::kSmemBytes + (size_t)spl * R_ * 64 * sizeof(float);                 \
+    VQA_ENSURE_LDS((bilinear_dw_dh2_kernel<64, 64, PF_, R_, BK_>), lds);                                                        \
+    hipLaunchKernelGGL((bilinear_dw_dh2_kernel<64, 64, PF_, R_, BK_>), dim3(tiles_m * tiles_n * S), dim3(kGemmThreads), lds, s, \
+                       g, h2, x, ldx, rp, slab, dbslab, part, B, N, L, H, tiles_m, tiles_n, spl, SP, inv);                      \
   }
+#define LAUNCH_PF(R_, PF_) \
+  if (bk == 40) LAUNCH_K(R_, PF_, 40) else LAUNCH_K(R_, PF_, 16)
 #define LAUNCH_R(R_) \
   if (pf == 2) LAUNCH_PF(R_, 2) else LAUNCH_PF(R_, 1)
   switch (R) {
@@ -796,6 +811,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_folded_bwd(const float* x, int ldx, c
   }
 #undef LAUNCH_R
 #undef LAUNCH_PF
+#undef LAUNCH_K
   // (3) fixed-order reductions
   const int HL = H * L;
   hipLaunchKernelGGL(bilinear_dw_reduce_kernel, dim3((HL / 2 + 255) / 256, R), dim3(256), 0, s, slab, dbslab, ro, HL, H, R, S);

@@ -27,7 +27,7 @@ constexpr int kGemmThreads = 256;
 
 template <int BM, int BN, int BK, bool A_KC, bool B_KC>
 struct GemmTile {
-  static_assert(BK == 16 || BK == 32, "BK must be 16 or 32");
+  static_assert(BK % 8 == 0 && BK >= 16 && BK <= 48, "BK must be a multiple of 8 in 16..48");
   static_assert(BM == 64 || BM == 128, "BM must be 64 or 128");
   static_assert(BN == 64 || BN == 128, "BN must be 64 or 128");
   static constexpr int TM = BM / 64, TN = BN / 64;
