@@ -85,6 +85,8 @@ def pmc_traffic(name, B):
     path = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")
     if B != BATCH or name not in PMC_KERNELS or not os.path.exists(path):
         return None
+    if name == "lowrank_bilinear_fusion_fwd" and not K4_FOLDED:       # the table holds the folded kernel
+        return None
     table = json.load(open(path))
     total = 0.0
     for prefix, grid, mult in PMC_KERNELS[name]:
