@@ -34,7 +34,7 @@ BATCH, REGIONS, FEAT, QDIM, ANSWERS = 512, 36, 2048, 2400, 2000
 LOW, HID, GLIMPSES, RANK = 310, 510, 4, 2
 
 
-K4_FOLDED = os.environ.get("VQA_K4_FORM", "folded") != "engine"
+K4_FOLDED = os.environ.get("VQA_K4_FORM", "auto") != "engine"
 
 
 def kernel_models(B, N=REGIONS, D=FEAT, G=GLIMPSES, L=LOW, H=HID, R=RANK, bf16=False):

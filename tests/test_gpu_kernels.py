@@ -215,14 +215,18 @@ def test_lowrank_bilinear_fusion_folded_shapes(ops, monkeypatch, B, N, L, H, R):
     _fusion_case(ops, B, N, L, H, R, 370, need_dx=False)
 
 
-def test_lowrank_bilinear_fusion_folded_limits(ops):
+def test_lowrank_bilinear_fusion_folded_limits(ops, monkeypatch):
     """Shapes outside the folded form are served by the tile-engine kernels (same results, checked above)."""
+    monkeypatch.setattr(ops, "_K4_FORM", "folded")
     from vqa_playground_pytorch_amd import _lib
     sup = _lib.lib().vqa_lowrank_bilinear_fusion_folded_supported
     assert sup(4, 113, 310, 510, 2) == 0 and sup(4, 36, 310, 510, 5) == 0 and sup(4, 100, 310, 510, 3) == 0
     assert sup(4, 36, 311, 510, 2) == 0 and sup(4, 100, 310, 510, 2) == 1
     _fusion_case(ops, 2, 113, 20, 34, 2, 380)      # N too large: falls through to the engine form
     _fusion_case(ops, 3, 36, 20, 34, 5, 381)       # R too large
+    monkeypatch.setattr(ops, "_K4_FORM", "auto")   # the default: folded from 32 samples on, engine below
+    _fusion_case(ops, 33, 36, 40, 66, 2, 382)
+    _fusion_case(ops, 31, 36, 40, 66, 2, 383)
 
 
 @pytest.mark.parametrize("B,L,H,R", [(7, 1240, 510, 2), (5, 620, 510, 5), (64, 1240, 510, 2)])

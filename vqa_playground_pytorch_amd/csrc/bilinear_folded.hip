@@ -39,17 +39,20 @@ struct FoldPtrs {
 // w_r [O][ldw]       C-contiguous weights (forward: W1_r [H][L]; data gradient: W1_r^T [L][H])
 // h2  [B][R][h2_dim] indexed by the output feature (H2_ROWS, forward) or by the contraction index (data gradient)
 // out [B*N][ld_out]
+// (second launch bound: at least two waves per SIMD, i.e. at most 256 registers per lane)
 template <int NB, int R, bool H2_ROWS, int WAVES, int OB>
-__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void bilinear_folded_kernel(const float* __restrict__ in, int ld_in, FoldPtrs wp, int ldw,
-                                                                 const float* __restrict__ h2, int h2_dim,
-                                                                 float* __restrict__ out, int ld_out, int B, int N, int C,
-                                                                 int O, int tiles_o) {
+__global__ __launch_bounds__(64 * WAVES, 2) void bilinear_folded_kernel(const float* __restrict__ in, int ld_in, FoldPtrs wp,
+                                                                        int ldw, const float* __restrict__ h2, int h2_dim,
+                                                                        float* __restrict__ out, int ld_out, int B, int N,
+                                                                        int C, int O, int tiles_o) {
   constexpr int CK = kFoldCK, P = CK + 4;   // contraction chunk and LDS pitch in floats
   constexpr int CK2 = CK / 2;          // float2 per staged row
   constexpr int T = 64 * WAVES;        // threads = one wave per sample of the group
   constexpr int OBR = OB * 16;         // output features per workgroup (OB blocks of 16 per wave)
   constexpr int WPT = (OBR * CK2 + T - 1) / T;   // float2 of one rank's W tile per thread (upper bound)
   constexpr int IPT = (WAVES * NB * 16 * CK2 + T - 1) / T;  // upper bound of the `in` float2 per thread
+  static_assert(WPT <= 8 && IPT <= 24, "slot validity bits live in one 32-bit mask");
+  static_assert(T % CK2 == 0 && (CK == 16 || CK == 32), "chunk of 16 or 32 columns");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int w_floats = R * OBR * P, in_floats = WAVES * N * P, h2_floats = H2_ROWS ? 0 : WAVES * R * CK;
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void bilinear_folde
   // staging slots of this thread: 32-bit offsets from wave-uniform bases (saddr + voffset loads).  Loads are
   // unconditional on clamped addresses (a branch per guarded load serialises them); out-of-range slots are zeroed
   // on their way into LDS.
-  const int c2 = 2 * (tid % CK2);      // the same column pair for every slot (256 % CK2 == 0)
+  const int c2 = 2 * (tid % CK2);      // the same column pair for every slot (T % CK2 == 0)
   int woff[WPT], ioff[IPT];
   unsigned okmask = 0;                 // bit i: W slot i in range, bit 8+i: `in` slot i in range
 #pragma unroll
@@ -123,19 +126,20 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void bilinear_folde
     float* __restrict__ is = ws + w_floats;
     const bool cok = ch * CK + c2 < C;
     const bool bias_col = H2_ROWS && ch * CK + c2 == C;   // (C and c2 are even: the bias column is always an .x)
-    const float2 zero = make_float2(0.f, 0.f);
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int i = 0; i < WPT; ++i) {
-        float2 t = (cok && (okmask >> i & 1)) ? wreg[r][i] : zero;
+        const bool ok = cok && (okmask >> i & 1);   // (component-wise: a float2 select is lowered through scratch)
+        float2 t = make_float2(ok ? wreg[r][i].x : 0.f, ok ? wreg[r][i].y : 0.f);
         if (bias_col) t.x = breg[r][i];
         if (OBR * CK2 % T == 0 || (tid + i * T) / CK2 < OBR) st2(ws + r * OBR * P + lds_slot + i * (T / CK2) * P, t);
       }
 #pragma unroll
     for (int i = 0; i < IPT; ++i)
       if ((tid + i * T) / CK2 < WAVES * N) {
-        float2 t = (cok && (okmask >> (8 + i) & 1)) ? ireg[i] : zero;
+        const bool ok = cok && (okmask >> (8 + i) & 1);
+        float2 t = make_float2(ok ? ireg[i].x : 0.f, ok ? ireg[i].y : 0.f);
         if (bias_col) t.x = 1.f;
         st2(is + lds_slot + i * (T / CK2) * P, t);
       }
@@ -215,7 +219,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void bilinear_folde
 }
 
 static size_t folded_lds_bytes(int N, int R, bool h2_rows, int waves, int ob = 4) {
-  return 2 * sizeof(float) * ((size_t)R * ob * 16 * (kFoldCK + 4) + (size_t)waves * N * (kFoldCK + 4) + (h2_rows ? 0 : waves * R * kFoldCK));
+  return 2 * sizeof(float) *
+         ((size_t)R * ob * 16 * (kFoldCK + 4) + (size_t)waves * N * (kFoldCK + 4) + (h2_rows ? 0 : waves * R * kFoldCK));
 }
 
 // Workgroup shape: `waves` samples (one wave each) x `ob` blocks of 16 output features.  The kernel is MFMA-paced, so a

@@ -278,7 +278,10 @@ def attention_logits_supported(x, in_features, out_features):
         x.shape[-1] % (4 if x.dtype == torch.bfloat16 else 2) == 0
 
 
-_K4_FORM = os.environ.get("VQA_K4_FORM", "folded")   # "engine": always the R-GEMM tile-engine kernels
+# "auto": rank-folded K4 where it is supported and the batch gives its per-sample workgroups enough to do (a handful of
+# samples runs faster on the R-GEMM tile-engine kernels); "folded": wherever supported; "engine": never
+_K4_FORM = os.environ.get("VQA_K4_FORM", "auto")
+_K4_FOLD_MIN_BATCH = 32
 
 
 class LowRankBilinearFusion(torch.autograd.Function):
@@ -309,7 +312,8 @@ class LowRankBilinearFusion(torch.autograd.Function):
         L_ = _lib.lib()
         # rank-folded form (csrc/bilinear_folded.hip): one contraction per sample against sum_r h2_r (.) W1_r, nothing
         # saved for backward but the inputs; the R-GEMM tile-engine form serves the shapes it does not cover
-        folded = N > 1 and _K4_FORM != "engine" and bool(L_.vqa_lowrank_bilinear_fusion_folded_supported(B, N, L, H, R))
+        folded = (N > 1 and _K4_FORM != "engine" and (_K4_FORM == "folded" or B >= _K4_FOLD_MIN_BATCH)
+                  and bool(L_.vqa_lowrank_bilinear_fusion_folded_supported(B, N, L, H, R)))
         ctx.folded = folded
         if folded:
             _launch("lowrank_bilinear_fusion_fwd", (B, N, L, H, R, need_bwd), L_.vqa_lowrank_bilinear_fusion_folded_fwd,
