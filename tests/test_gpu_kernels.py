@@ -284,6 +284,29 @@ def test_lowrank_bilinear_fusion_full_size_properties(ops, monkeypatch, form):
     assert (out2 - 3.0 * out).abs().max().item() <= 1e-5 * scale * 3
 
 
+@pytest.mark.parametrize("B,N", [(1501, 36), (203, 100)])
+def test_lowrank_bilinear_fusion_large_batch_against_torch_fp64(ops, B, N):
+    """Folded K4, forward and every gradient, at batches that are no multiple of its 8- / 4-sample groups and give the
+    weight-gradient kernel uneven sample slabs; reference = torch autograd in fp64 on the GPU."""
+    L, H, R = 310, 510, 2
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.randn(B, N, L, generator=gen).to(dev()).requires_grad_()
+    h2 = torch.randn(B, R, H, generator=gen).to(dev()).requires_grad_()
+    ws = [(torch.randn(H, L, generator=gen) / L ** 0.5).to(dev()).requires_grad_() for _ in range(R)]
+    bs = [(0.1 * torch.randn(H, generator=gen)).to(dev()).requires_grad_() for _ in range(R)]
+    go = torch.randn(B, N, H, generator=gen).to(dev())
+    leaves = [x, h2, *ws, *bs]
+    out = ops.lowrank_bilinear_fusion(x, h2, ws, bs)
+    got = torch.autograd.grad(out, leaves, go)
+    ld = [t.detach().double().requires_grad_() for t in leaves]
+    ref_out = sum((ld[0] @ ld[2 + r].t() + ld[2 + R + r]) * ld[1][:, r, None, :] for r in range(R))
+    want = torch.autograd.grad(ref_out, ld, go.double())
+    assert (out.double() - ref_out).abs().max().item() <= 2e-5 * ref_out.abs().max().item()
+    for name, a, b in zip(["d_x", "d_h2"] + ["d_w1[%d]" % r for r in range(R)] + ["d_b1[%d]" % r for r in range(R)], got, want):
+        err = (a.double() - b).abs().max().item() / b.abs().max().item()
+        assert err <= 2e-5, "%s: %.2e" % (name, err)
+
+
 # ----------------------------------------------------------------------------------------------- K2
 @pytest.mark.parametrize("B,N,L,G", [(2, 4, 6, 3), (3, 36, 310, 4), (2, 13, 70, 2), (1, 1, 5, 1), (2, 37, 100, 8)])
 def test_object_difference_no_dropout(ops, B, N, L, G):
