@@ -18,6 +18,14 @@
 // The W1 tile [R][64][CK] is shared by the four waves, each stages its own x rows; both sit in LDS with a pitch of
 // CK+4 = 20 floats, so the 16-byte fragment reads (16 rows x 4 quads per wave) are bank-conflict free.  A lane's four
 // consecutive contraction indices feed four successive MFMAs (the k order inside a dot product is free).
+//
+// Where the time goes at B = 512, N = 36, R = 2 (forward, 88 us alone): ablation builds put ~60 us in the MFMA-paced
+// chunk loop (within 10 % of the matrix core's rate for the padded work), ~12 us in staging (global -> LDS, barrier) and
+// ~16 us in launch, prologue and the output stores of a grid that runs as ONE round of resident workgroups.  Tried and
+// dropped: 32-column chunks (half the barriers, one workgroup less per CU: 104 us), A fragments fetched a feature block
+// ahead in the source (30 more registers, one wave less per SIMD: 119 us), two register sets in flight (the x / g rows
+// do not wait on HBM: no gain, one wave less per SIMD), a float2 select on the way into LDS (hipcc lowers it through
+// scratch memory: +14 us on the data gradient -- the selects are component-wise for that reason).
 #include <cstdlib>
 
 #include "bilinear_folded.hpp"
