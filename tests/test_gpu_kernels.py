@@ -443,6 +443,42 @@ def test_linear_fn_matches_autograd(ops):
         close(name, a, t.grad.cpu().numpy(), 1e-5)
 
 
+@pytest.mark.parametrize("rows,need_dx", [(6 * 36, True), (6 * 36, False), (128 * 36, True), (128 * 36, False)])
+def test_linear_fn_relu_epilogue(ops, rows, need_dx):
+    """ops.linear(..., act="relu"): relu in the GEMM epilogue; backward applies the mask either as a tensor op (small M,
+    or when the data gradient needs the masked gradient) or inside the tile engine's weight-gradient kernel (tall M, no
+    data gradient: compress_v) -- all against torch autograd in fp64."""
+    x = g(seeded.seeded_array((rows, 70), 331), need_dx)
+    w = g(seeded.seeded_array((34, 70), 332), True)
+    b = g(seeded.seeded_array((34,), 333), True)
+    gy = g(seeded.seeded_array((rows, 34), 334))
+    y = ops.linear(x, w, b, act="relu")
+    y.backward(gy)
+    xd, wd, bd = (t.detach().double().requires_grad_() for t in (x, w, b))
+    yd = torch.relu(torch.nn.functional.linear(xd, wd, bd))
+    yd.backward(gy.double())
+    close("y", y, yd.detach().cpu().numpy(), 1e-5)
+    assert (y >= 0).all()
+    if need_dx:
+        close("d_x", x.grad, xd.grad.cpu().numpy(), 2e-5)
+    close("d_w", w.grad, wd.grad.cpu().numpy(), 2e-5)
+    close("d_b", b.grad, bd.grad.cpu().numpy(), 2e-5)
+
+
+def test_split_groups(ops):
+    """ops.split_groups: chunk views forward, one concatenation backward (an unused chunk counts as zeros)."""
+    t = g(seeded.seeded_array((4, 5, 6), 341), True)
+    a, b_, c = ops.split_groups(t, (1, 1, 2))
+    assert a.shape == (5, 6) and c.shape == (2, 5, 6) and a.data_ptr() == t.data_ptr()
+    (a.sum() * 2.0 + (c * c).sum()).backward()
+    want = torch.zeros_like(t)
+    want[0] = 2.0
+    want[2:4] = 2.0 * t.detach()[2:4]
+    assert torch.equal(t.grad, want)
+    with pytest.raises(ValueError):
+        ops.split_groups(t, (1, 2))
+
+
 # ----------------------------------------------------------------------------------------------- loss
 @pytest.mark.parametrize("B,C", [(4, 2000), (512, 2000), (3, 3000), (1, 7), (5, 4096)])
 def test_kld_sum_loss(ops, B, C):

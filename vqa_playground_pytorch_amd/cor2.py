@@ -61,8 +61,10 @@ class Model(nn.Module):
         -> (q_feature_low, q_final, q_gate_1 [B,2048], q_gate_2 [B,2048])."""
         low = my_linears([self.compress_q, self.linear_q, self.compress_q_1, self.compress_q_2], q_feature,
                          group_first=True)                                                          # [4,B,310]
-        gates = my_linears([self.expand_q_1, self.expand_q_2], low[2:4].transpose(0, 1), group_first=True)   # [2,B,2048]
-        return low[0], low[1], gates[0], gates[1]
+        q_feature_low, q_final, low_gates = ops.split_groups(low, (1, 1, 2))      # views; one cat kernel backward
+        gates = my_linears([self.expand_q_1, self.expand_q_2], low_gates.transpose(0, 1), group_first=True)   # [2,B,2048]
+        q_gate_1, q_gate_2 = ops.split_groups(gates, (1, 1))
+        return q_feature_low, q_final, q_gate_1, q_gate_2
 
     def relation_reduce(self, v_feature, q_gate_1, q_gate_2, alpha):
         """config/CoR2.py:191-199 (decare_cat) + :216 fused: v2[b,j] = sum_i alpha[b,i,0] *

@@ -203,7 +203,7 @@ class MyConv1d(nn.Module):
                                  % (self.in_channels, self.out_channels, self.kernel_size, self.stride, x.dim()))
             if x.dtype == torch.bfloat16:
                 return self._linear_bf16(x, self.af)
-            return _activation(ops.linear(x, self.conv.weight.squeeze(-1), self.conv.bias), self.af, self.dim)
+            return self._linear_f32(x)
         if x.dtype == torch.bfloat16 and self.af in (None, "relu"):
             if x.dim() != 3:
                 raise ValueError("[error] putils.Conv1d(%s, %s, %s, %s): input_dim (%s) should equal to 3"
@@ -219,7 +219,19 @@ class MyConv1d(nn.Module):
             p = self.p if (self.training and self.p) else 0.0
             seed = ops.next_dropout_seed() if p else 0
             return ops.linear_act(x, self.conv.weight.squeeze(-1), self.conv.bias, self.af, p, seed)
+        if self.af == "relu" and x.dim() == 3 and x.dtype == torch.float32 and x.is_cuda and \
+                not ops.attention_logits_supported(x, self.in_channels, self.out_channels):
+            if self.p:
+                x = F.dropout(x, p=self.p, training=self.training)
+            return self._linear_f32(x)
         return _activation(self.pre_activation(x), self.af, self.dim)
+
+    def _linear_f32(self, x):
+        """af(conv) with a relu riding in the library GEMM's epilogue (ops.LinearFn); other activations as torch ops."""
+        w, b = self.conv.weight.squeeze(-1), self.conv.bias
+        if self.af == "relu" and x.is_cuda:
+            return ops.linear(x, w, b, act="relu")
+        return _activation(ops.linear(x, w, b), self.af, self.dim)
 
 
 class MutanFusion(nn.Module):

@@ -56,7 +56,7 @@ class Model(nn.Module):
         v_feature_low = self.compress_v(v_feature)
         # the two MyLinear(2400 -> 310) on the question vector (config/ODA.py:185,193 applied at :207,:233): one batched GEMM
         q_both = my_linears([self.compress_q, self.linear_q], q_feature, group_first=True)   # [2,B,310]
-        q_feature_low, q_final = q_both[0], q_both[1]
+        q_feature_low, q_final = ops.split_groups(q_both, (1, 1))                              # views; one cat kernel backward
         logits = self.difference_logits(v_feature_low, q_feature_low)
         v_final, alphas, _ = self.att.attend(v_feature, logits)
 

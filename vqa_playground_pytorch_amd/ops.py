@@ -652,35 +652,54 @@ class LinearFn(torch.autograd.Function):
     semaphores are zeroed by a memset node, which replays wrongly inside a hipGraph on ROCm 7.2 (csrc/api.hip)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
-        ctx.save_for_backward(x, w)
+    def forward(ctx, x, w, b, act=None):
+        # act "relu": the activation rides in the library GEMM's epilogue (one kernel instead of GEMM + clamp), and its
+        # gradient mask is applied by whoever consumes grad_output first (see backward)
         ctx.has_bias = b is not None
+        ctx.relu = act == "relu"
+        if act not in (None, "relu"):
+            raise ValueError("linear: act must be None or 'relu', got %r" % (act,))
+        if ctx.relu:
+            if b is not None and x.dtype == torch.float32 and hasattr(torch, "_addmm_activation"):
+                y = torch._addmm_activation(b, x.reshape(-1, x.shape[-1]), w.t(), use_gelu=False).view(*x.shape[:-1], w.shape[0])
+            else:
+                y = torch.relu(torch.nn.functional.linear(x, w, b))
+            ctx.save_for_backward(x, w, y)
+            return y
+        ctx.save_for_backward(x, w)
         return torch.nn.functional.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
-        gy2 = gy.reshape(-1, gy.shape[-1])
+        x, w = ctx.saved_tensors[:2]
+        y = ctx.saved_tensors[2] if ctx.relu else None
         x2 = x.reshape(-1, x.shape[-1])
-        d_x = (gy2 @ w).view(x.shape) if ctx.needs_input_grad[0] else None
         M, K = x2.shape
         N = w.shape[0]
-        if (LinearFn.engine_dw and ctx.needs_input_grad[1] and M >= 4096 and x.dtype == torch.float32 and K % 2 == 0
-                and N % 2 == 0):
+        engine = (LinearFn.engine_dw and ctx.needs_input_grad[1] and M >= 4096 and x.dtype == torch.float32 and K % 2 == 0
+                  and N % 2 == 0)
+        mask_in_kernel = ctx.relu and engine and not ctx.needs_input_grad[0]
+        if ctx.relu and not mask_in_kernel:
+            gy = torch.ops.aten.threshold_backward(gy, y, 0)
+        gy2 = gy.reshape(-1, gy.shape[-1])
+        d_x = (gy2 @ w).view(x.shape) if ctx.needs_input_grad[0] else None
+        if engine:
             # tall weight gradient (the region projections, M = B*N rows): the fp32 tile engine's split-row form, which
-            # also returns the bias gradient as the column sums of its A fragments (no separate reduction)
+            # also returns the bias gradient as the column sums of its A fragments (no separate reduction) and, when no
+            # data gradient needs the masked grad_output as a tensor, applies the relu mask while it stages the operand
             gy2, x2 = gy2.contiguous(), x2.contiguous()
+            y2 = y.reshape(-1, N).contiguous() if mask_in_kernel else gy2
             d_w = torch.empty_like(w)
             d_b = torch.empty(N, device=x.device, dtype=torch.float32) if ctx.has_bias else None
             L_ = _lib.lib()
             ws_bytes = L_.vqa_linear_act_bwd_workspace_bytes(M, K, N)
             ws = torch.empty((ws_bytes + 3) // 4, device=x.device, dtype=torch.float32)
-            _launch("linear_act_bwd", (M, K, N, False, False), L_.vqa_linear_act_bwd, _p(x2), K, _p(w), _p(gy2), _p(gy2),
-                    None, _p(d_w), _p(d_b), _p(ws), ws_bytes, M, K, N, 0, 0.0, 0, None)
-            return d_x, d_w, d_b
+            _launch("linear_act_bwd", (M, K, N, False, False), L_.vqa_linear_act_bwd, _p(x2), K, _p(w), _p(y2), _p(gy2),
+                    None, _p(d_w), _p(d_b), _p(ws), ws_bytes, M, K, N, 1 if mask_in_kernel else 0, 0.0, 0, None)
+            return d_x, d_w, d_b, None
         d_w = gy2.t() @ x2 if ctx.needs_input_grad[1] else None
         d_b = column_sum(gy2).to(gy.dtype) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return d_x, d_w, d_b
+        return d_x, d_w, d_b, None
 
     engine_dw = __import__("os").environ.get("VQA_ENGINE_DW", "1") == "1"
 
@@ -762,11 +781,43 @@ def batched_linear(x, w, b=None, group_first=False, act=None):
     return BatchedLinearFn.apply(x, w, b, group_first, act)
 
 
-def linear(x, w, b=None):
-    """F.linear for GPU tensors with a replay-safe bias gradient (see LinearFn); CPU tensors take the torch op."""
+class SplitGroups(torch.autograd.Function):
+    """t [G, ...] -> its chunks along dim 0 (``sizes``; a chunk of one group loses the dim) as views.  Forward is free;
+    backward is ONE concatenation of the chunks' gradients -- the slices ``t[0], t[1], t[2:4]`` would instead make autograd
+    zero-fill a full-size tensor per slice, copy the slice gradient in and add the tensors up (7 kernels for the four
+    question projections of CoR2, 5 for its two gates)."""
+
+    @staticmethod
+    def forward(ctx, t, sizes):
+        if sum(sizes) != t.shape[0]:
+            raise ValueError("split_groups: sizes %s do not add up to %d groups" % (sizes, t.shape[0]))
+        ctx.sizes, ctx.tail = tuple(sizes), tuple(t.shape[1:])
+        outs, o = [], 0
+        for n in sizes:
+            outs.append(t[o] if n == 1 else t[o:o + n])
+            o += n
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        parts = []
+        for n, g in zip(ctx.sizes, grads):
+            if g is None:
+                g = torch.zeros((n,) + ctx.tail, device=next(x for x in grads if x is not None).device, dtype=torch.float32)
+            parts.append(g.reshape((n,) + ctx.tail))
+        return torch.cat(parts, 0), None
+
+
+def split_groups(t, sizes):
+    return SplitGroups.apply(t, tuple(sizes))
+
+
+def linear(x, w, b=None, act=None):
+    """act(F.linear) for GPU tensors with a replay-safe bias gradient (see LinearFn); CPU tensors take the torch ops."""
     if x.is_cuda:
-        return LinearFn.apply(x, w, b)
-    return torch.nn.functional.linear(x, w, b)
+        return LinearFn.apply(x, w, b, act)
+    y = torch.nn.functional.linear(x, w, b)
+    return torch.relu(y) if act == "relu" else y
 
 
 class GruSequence(torch.autograd.Function):
