@@ -83,7 +83,7 @@ class Model(nn.Module):
         q_feature_low, q_final, q_gate_1, q_gate_2 = self.question_projections(q_feature)
         v_feature_low = self.compress_v(v_feature)
         fuse1 = self.fusion_vq1(v_feature_low, q_feature_low)
-        v1_att, alpha1, alpha1_full, pooled1 = self.att1.attend(v_feature, self.att1.conv_att.pre_activation(fuse1),
+        v1_att, alpha1, alpha1_full, pooled1_first = self.att1.attend(v_feature, self.att1.conv_att.pre_activation(fuse1),
                                                                 return_pooled=True)
 
         if self.relation_mode == 1:
@@ -93,14 +93,14 @@ class Model(nn.Module):
             # reach the attention maps as a per-glimpse constant, which the softmax backward cancels exactly.)  v2 is
             # materialised once, already dropped out for compress_v2 (K1 apply kernel); the second attention pools v
             # itself and maps the result: sum_n alpha2[n] v2[n] = t + q2 * sum_n alpha2[n] v[n].
-            t = q_gate_1 * pooled1[:, 0, :]
+            t = q_gate_1 * pooled1_first
             c2 = q_gate_2
             p = self.compress_v2.p if (self.training and self.compress_v2.p) else 0.0
             v2_dropped = ops.relation_apply(v_feature, t, c2, p, ops.next_dropout_seed() if p else 0)
             v2_feature_low = self.compress_v2(v2_dropped, predropped=True)
             fuse2 = self.fusion_vq2(v2_feature_low, q_feature_low)
             v2_att, alpha2, _ = self.att2.attend(v_feature, self.att2.conv_att.pre_activation(fuse2),
-                                                 lambda pooled: torch.addcmul(t.unsqueeze(1), c2.unsqueeze(1), pooled))
+                                                 lambda pooled: ops.affine_map(pooled, t, c2))
             feature = torch.addcmul(t.unsqueeze(1), c2.unsqueeze(1), v_feature[:, 0:2, :].float()).detach()
         else:
             # pairwise form: every (i, j) term of the relation tensor summed in the kernel, as the reference structures it;

@@ -303,13 +303,16 @@ class MyATT(nn.Module):
         return y.reshape(y.size(0), -1)
 
     def attend(self, inputs, logits, pooled_map=None, return_pooled=False):
-        """logits [B,N,G] (pre-softmax) -> (x_v, list_att, alpha [B,N,G][, pooled [B,G,D]]).  pooled_map (optional)
+        """logits [B,N,G] (pre-softmax) -> (x_v, list_att, alpha [B,N,G][, pooled[:, 0] [B,D]]).  pooled_map (optional)
         transforms the pooled features before the glimpse projections.  (Nothing that carries an autograd graph is kept
         on the module: a tensor stashed across steps would pin the previous step's graph.)"""
         alpha, pooled = ops.softmax_attention_pool(logits, inputs)                     # [B,N,G], [B,G,D]
+        first = None
+        if return_pooled:       # glimpse 0 for the caller (CoR2's relation step), the whole tensor for the projections
+            pooled, first = ops.with_first_group(pooled)
         x_v = self.glimpse_projection(pooled if pooled_map is None else pooled_map(pooled))
         if return_pooled:
-            return x_v, torch.split(alpha, 1, dim=2), alpha, pooled
+            return x_v, torch.split(alpha, 1, dim=2), alpha, first
         return x_v, torch.split(alpha, 1, dim=2), alpha
 
     def forward(self, inputs, fuse):
