@@ -71,9 +71,20 @@ def my_linears(mods, x, group_first=False):
         raise ValueError(
             "[error] putils.Linear(%s, %s): last dimension of input(%s) should equal to in_features(%s)"
             % (first.in_features, first.out_features, x.size(-1), first.in_features))
+    training = getattr(first, "training", False)
+    if x.dim() == 2 and not group_first and not (p and training) and af in (None, "") and x.dtype == torch.float32:
+        # G layers on ONE input without dropout or activation (Mutan's rank factors, putils/__init__.py:232-238): a
+        # plain GEMM against the [G*A, K] stack -- the sum over the groups in the data gradient happens inside the GEMM
+        # (no expand / reduce pair around a batched one), the bias gradient is one column sum
+        w = ops.stack_params([l.weight for l in lins])
+        if w.is_contiguous():
+            b = None
+            if lins[0].bias is not None:       # (through ops.linear: its bias gradient is the replay-safe column sum)
+                b = ops.stack_params([l.bias for l in lins]).reshape(G * first.out_features)
+            y = ops.linear(x, w.view(G * first.out_features, first.in_features), b)
+            return y.view(x.size(0), G, first.out_features)
     if x.dim() == 2:
         x = x.unsqueeze(1).expand(x.size(0), G, x.size(1))          # stride-0 group axis: no copy
-    training = getattr(first, "training", False)
     if p and training:
         x = F.dropout(x, p=p, training=True)                         # one draw over [B,G,K]: G independent masks
     w = ops.stack_params([l.weight for l in lins])                   # [G,A,K]: a view of the flat parameter buffer
