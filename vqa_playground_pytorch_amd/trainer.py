@@ -97,8 +97,8 @@ def collect_stack_groups(model):
 
 
 class FlatState:
-    """GPU path: parameters, gradients and both Adam moments each live in ONE flat fp32 buffer (segments padded
-    to 16 bytes).  ``p.data`` become views of the parameter buffer (state_dict / load_state_dict keep working);
+    """GPU path: parameters, gradients and both Adam moments each live in ONE flat fp32 buffer (segments aligned
+    to 16 bytes, the members of a stack group packed back to back).  ``p.data`` become views of the parameter buffer (state_dict / load_state_dict keep working);
     after backward the per-parameter gradients autograd produced are gathered into the gradient buffer by one
     multi-tensor copy (cheaper than zero + ~70 accumulate-adds), which is then the all-reduce payload and the
     input of the fused clip + Adam kernels (csrc/optimizer.hip)."""
@@ -121,10 +121,18 @@ class FlatState:
                     ordered.append(q)
         self.params = ordered
         dev = self.params[0].device
+        # segments start 16-byte aligned; the members of a stack group follow each other without padding (8-byte
+        # aligned: even sizes), so the stack [G, ...] is a CONTIGUOUS view (ops.StackParams) -- e.g. the G biases of 510
         offs, off = [], 0
-        for p in self.params:
+        for i, p in enumerate(self.params):
+            group = member.get(id(p))
+            tight = group is not None and p.numel() % 2 == 0
+            inside = tight and i > 0 and member.get(id(self.params[i - 1])) is group
+            if not inside:
+                off = (off + 3) // 4 * 4
             offs.append(off)
-            off += (p.numel() + 3) // 4 * 4
+            off += p.numel()
+        off = (off + 3) // 4 * 4
         self.total = off
         self.offsets = offs
         self.p = torch.zeros(off, device=dev, dtype=torch.float32)
