@@ -346,15 +346,6 @@ int vqa_bias_act(const float* y, const float* bias, int bias_stride, float* out,
 int vqa_act_bwd_colsum(const float* gy, const float* out, float* gz, float* d_bias, int G, int B, int A,
                        int act, int group_first, vqa_stream_t stream);
 
-/* Affine map of pooled features: out[b,g,:] = t[b,:] + c[b,:] * pooled[b,g,:] -- the closed form of the relation step
- * (config/CoR2.py:191-199 + :216: v2 = q1 * sum_i alpha_i v_i + q2 * v) applied after the pooling of the second
- * attention (config/CoR2.py:142) instead of before it.  Backward, one pass: d_pooled = g * c (or NULL),
- * d_t = sum_g g, d_c = sum_g g * pooled.  pooled / out / g [B,G,D], t / c [B,D], D % 4 == 0, 16-byte aligned. */
-int vqa_affine_map_fwd(const float* pooled, const float* t, const float* c, float* out, int B, int G, int D,
-                       vqa_stream_t stream);
-int vqa_affine_map_bwd(const float* g, const float* pooled, const float* c, float* d_pooled, float* d_t,
-                       float* d_c, int B, int G, int D, vqa_stream_t stream);
-
 /* ---------------------------------------------------------------------------------------------
  * Gate math of the BayesianGRU question encoder, one call per time step each way (putils/__init__.py:704-731
  * with the cell of :604-646 and the sequence-shared dropout of :503-539); the three recurrent GEMMs of a

@@ -465,21 +465,6 @@ def test_linear_fn_relu_epilogue(ops, rows, need_dx):
     close("d_b", b.grad, bd.grad.cpu().numpy(), 2e-5)
 
 
-@pytest.mark.parametrize("B,G,D", [(5, 4, 2048), (3, 1, 8), (512, 4, 2048), (2, 7, 260)])
-def test_affine_map(ops, B, G, D):
-    """out = t + c * pooled (closed-form relation applied after pooling) and its one-pass backward vs autograd fp64."""
-    pooled, t, c = (g(seeded.seeded_array(s, 351 + i), True) for i, s in enumerate(((B, G, D), (B, D), (B, D))))
-    go = g(seeded.seeded_array((B, G, D), 355))
-    out = ops.affine_map(pooled, t, c)
-    out.backward(go)
-    ld = [x.detach().double().requires_grad_() for x in (pooled, t, c)]
-    ref = torch.addcmul(ld[1].unsqueeze(1), ld[2].unsqueeze(1), ld[0])
-    ref.backward(go.double())
-    close("out", out, ref.detach().cpu().numpy(), 1e-6)
-    for name, a, b_ in zip(("d_pooled", "d_t", "d_c"), (pooled, t, c), ld):
-        close(name, a.grad, b_.grad.cpu().numpy(), 2e-6)
-
-
 def test_with_first_group(ops):
     pooled = g(seeded.seeded_array((6, 4, 8), 361), True)
     full, first = ops.with_first_group(pooled)

@@ -100,7 +100,8 @@ class Model(nn.Module):
             v2_feature_low = self.compress_v2(v2_dropped, predropped=True)
             fuse2 = self.fusion_vq2(v2_feature_low, q_feature_low)
             v2_att, alpha2, _ = self.att2.attend(v_feature, self.att2.conv_att.pre_activation(fuse2),
-                                                 lambda pooled: ops.affine_map(pooled, t, c2))
+                                                 lambda pooled, pd: ops.relation_apply(
+                                                     pooled, t, c2, pd, ops.next_dropout_seed() if pd else 0))
             feature = torch.addcmul(t.unsqueeze(1), c2.unsqueeze(1), v_feature[:, 0:2, :].float()).detach()
         else:
             # pairwise form: every (i, j) term of the relation tensor summed in the kernel, as the reference structures it;

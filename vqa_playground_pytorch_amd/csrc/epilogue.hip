@@ -75,43 +75,6 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const float* __rest
   }
 }
 
-// Affine map of pooled features (the closed-form relation step applied after the second attention's pooling,
-// cor2.py: sum_n alpha2[n] v2[n] = t + c * sum_n alpha2[n] v[n]):  out[b,g,:] = t[b,:] + c[b,:] * pooled[b,g,:].
-// Backward in ONE pass over (g, pooled): d_pooled = g * c, d_t = sum_g g, d_c = sum_g g * pooled -- autograd's own chain
-// for the broadcast addcmul is a multiply, two reductions and another multiply.  Lane = one float4 column of a sample.
-__global__ __launch_bounds__(256) void affine_map_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ t,
-                                                             const float* __restrict__ c, float* __restrict__ out, int B,
-                                                             int G, int D) {
-  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (e >= (size_t)B * D) return;
-  const size_t b = e / D, d = e % D;
-  const float4 tv = ld4(t + e), cv = ld4(c + e);
-  for (int g = 0; g < G; ++g) {
-    const size_t o = (b * G + g) * D + d;
-    const float4 p = ld4(pooled + o);
-    st4(out + o, make_float4(fmaf(cv.x, p.x, tv.x), fmaf(cv.y, p.y, tv.y), fmaf(cv.z, p.z, tv.z), fmaf(cv.w, p.w, tv.w)));
-  }
-}
-__global__ __launch_bounds__(256) void affine_map_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ pooled,
-                                                             const float* __restrict__ c, float* __restrict__ d_pooled,
-                                                             float* __restrict__ d_t, float* __restrict__ d_c, int B, int G,
-                                                             int D) {
-  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (e >= (size_t)B * D) return;
-  const size_t b = e / D, d = e % D;
-  const float4 cv = ld4(c + e);
-  float4 st = make_float4(0.f, 0.f, 0.f, 0.f), sc = st;
-  for (int g = 0; g < G; ++g) {
-    const size_t o = (b * G + g) * D + d;
-    const float4 gv = ld4(gout + o), p = ld4(pooled + o);
-    st = add4(st, gv);
-    sc = add4(sc, mul4(gv, p));
-    if (d_pooled != nullptr) st4(d_pooled + o, mul4(gv, cv));
-  }
-  st4(d_t + e, st);
-  st4(d_c + e, sc);
-}
-
 }  // namespace vqa
 
 using namespace vqa;
@@ -136,29 +99,4 @@ extern "C" int vqa_act_bwd_colsum(const float* gy, const float* out, float* gz, 
   hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3((A + 15) / 16, G), dim3(256), 0, static_cast<hipStream_t>(stream), gy, out, gz,
                      d_bias, G, B, A, act, group_first);
   return check_launch("act_bwd_colsum");
-}
-
-extern "C" int vqa_affine_map_fwd(const float* pooled, const float* t, const float* c, float* out, int B, int G, int D,
-                                  vqa_stream_t stream) {
-  VQA_REQUIRE(pooled && t && c && out, VQA_E_BADARG, "affine_map_fwd: null pointer");
-  VQA_REQUIRE(B > 0 && G > 0 && D > 0 && D % 4 == 0, VQA_E_BADARG, "affine_map_fwd: bad sizes B=%d G=%d D=%d (D %% 4 == 0)", B, G, D);
-  VQA_REQUIRE(aligned(pooled, 16) && aligned(t, 16) && aligned(c, 16) && aligned(out, 16), VQA_E_UNSUPPORTED,
-              "affine_map_fwd: tensors must be 16-byte aligned");
-  const size_t n = (size_t)B * D / 4;
-  hipLaunchKernelGGL(affine_map_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     pooled, t, c, out, B, G, D);
-  return check_launch("affine_map_fwd");
-}
-
-extern "C" int vqa_affine_map_bwd(const float* g, const float* pooled, const float* c, float* d_pooled, float* d_t, float* d_c,
-                                  int B, int G, int D, vqa_stream_t stream) {
-  VQA_REQUIRE(g && pooled && c && d_t && d_c, VQA_E_BADARG, "affine_map_bwd: null pointer");
-  VQA_REQUIRE(B > 0 && G > 0 && D > 0 && D % 4 == 0, VQA_E_BADARG, "affine_map_bwd: bad sizes B=%d G=%d D=%d (D %% 4 == 0)", B, G, D);
-  VQA_REQUIRE(aligned(g, 16) && aligned(pooled, 16) && aligned(c, 16) && aligned(d_t, 16) && aligned(d_c, 16) &&
-                  (d_pooled == nullptr || aligned(d_pooled, 16)),
-              VQA_E_UNSUPPORTED, "affine_map_bwd: tensors must be 16-byte aligned");
-  const size_t n = (size_t)B * D / 4;
-  hipLaunchKernelGGL(affine_map_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), g,
-                     pooled, c, d_pooled, d_t, d_c, B, G, D);
-  return check_launch("affine_map_bwd");
 }

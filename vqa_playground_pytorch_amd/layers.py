@@ -51,15 +51,18 @@ def _same_config(mods, keys):
     return all(all(getattr(m, k) == getattr(first, k) for k in keys) for m in mods)
 
 
-def my_linears(mods, x, group_first=False):
+def my_linears(mods, x, group_first=False, predropped=False):
     """[m(x_g) for m in mods] for G same-shaped MyLinear / Linear modules as ONE batched GEMM: x is [B,K] (every module
     reads the same input, each with its own dropout draw, as when the reference calls them one after the other) or
     [B,G,K] (module g reads x[:, g, :]).  Returns [B,G,A], or [G,B,A] when group_first (each result contiguous).
-    The modules keep their own parameters (state_dict names unchanged); weights are stacked per call."""
+    The modules keep their own parameters (state_dict names unchanged); weights are stacked per call.
+    predropped: the producer of x ([B,G,K]) has already applied the modules' input dropout."""
     first = mods[0]
     lins = [m.linear for m in mods]
     p = getattr(first, "p", None)
     af = getattr(first, "af", None)
+    if predropped and x.dim() != 3:
+        raise ValueError("my_linears: predropped needs one input per module ([B,G,K])")
     ok = x.is_cuda and _same_config(mods, ("in_features", "out_features")) and \
         all(getattr(m, "p", None) == p and getattr(m, "af", None) == af for m in mods) and \
         all((l.bias is None) == (lins[0].bias is None) for l in lins)
@@ -85,7 +88,7 @@ def my_linears(mods, x, group_first=False):
             return y.view(x.size(0), G, first.out_features)
     if x.dim() == 2:
         x = x.unsqueeze(1).expand(x.size(0), G, x.size(1))          # stride-0 group axis: no copy
-    if p and training:
+    if p and training and not predropped:
         x = F.dropout(x, p=p, training=True)                         # one draw over [B,G,K]: G independent masks
     w = ops.stack_params([l.weight for l in lins])                   # [G,A,K]: a view of the flat parameter buffer
     b = ops.stack_params([l.bias for l in lins]) if lins[0].bias is not None else None   # when the trainer laid it out
@@ -306,22 +309,31 @@ class MyATT(nn.Module):
     def stack_groups(self):
         return linear_stack_groups(list(self.list_linear_v_fusion))
 
-    def glimpse_projection(self, pooled):
+    def glimpse_dropout(self):
+        """Input dropout rate of the per-glimpse MyLinear list in the current mode (0.0 in eval)."""
+        first = self.list_linear_v_fusion[0]
+        return float(first.p) if (self.training and getattr(first, "p", None)) else 0.0
+
+    def glimpse_projection(self, pooled, predropped=False):
         """cat_g MyLinear_g(pooled[:, g, :]) (config/CoR2.py:143-147).  The G layers have one shape, so they run as ONE
         batched GEMM over the [B,G,D] tensor (one dropout draw over all of it, one bias add, one activation) instead of
         G x {slice, dropout, GEMM, activation} and, backward, G slice gradients that autograd zero-fills and adds."""
-        y = my_linears(list(self.list_linear_v_fusion), pooled)                       # [B,G,A]
+        y = my_linears(list(self.list_linear_v_fusion), pooled, predropped=predropped)   # [B,G,A]
         return y.reshape(y.size(0), -1)
 
     def attend(self, inputs, logits, pooled_map=None, return_pooled=False):
-        """logits [B,N,G] (pre-softmax) -> (x_v, list_att, alpha [B,N,G][, pooled[:, 0] [B,D]]).  pooled_map (optional)
-        transforms the pooled features before the glimpse projections.  (Nothing that carries an autograd graph is kept
-        on the module: a tensor stashed across steps would pin the previous step's graph.)"""
+        """logits [B,N,G] (pre-softmax) -> (x_v, list_att, alpha [B,N,G][, pooled[:, 0] [B,D]]).  pooled_map (optional):
+        ``pooled_map(pooled, p) -> tensor`` transforms the pooled features before the glimpse projections AND applies
+        their input dropout at rate p (so the two share one pass).  (Nothing that carries an autograd graph is kept on
+        the module: a tensor stashed across steps would pin the previous step's graph.)"""
         alpha, pooled = ops.softmax_attention_pool(logits, inputs)                     # [B,N,G], [B,G,D]
         first = None
         if return_pooled:       # glimpse 0 for the caller (CoR2's relation step), the whole tensor for the projections
             pooled, first = ops.with_first_group(pooled)
-        x_v = self.glimpse_projection(pooled if pooled_map is None else pooled_map(pooled))
+        if pooled_map is None:
+            x_v = self.glimpse_projection(pooled)
+        else:
+            x_v = self.glimpse_projection(pooled_map(pooled, self.glimpse_dropout()), predropped=True)
         if return_pooled:
             return x_v, torch.split(alpha, 1, dim=2), alpha, first
         return x_v, torch.split(alpha, 1, dim=2), alpha

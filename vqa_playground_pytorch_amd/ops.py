@@ -781,39 +781,6 @@ def batched_linear(x, w, b=None, group_first=False, act=None):
     return BatchedLinearFn.apply(x, w, b, group_first, act)
 
 
-class AffineMap(torch.autograd.Function):
-    """out[b,g,:] = t[b,:] + c[b,:] * pooled[b,g,:] (csrc/epilogue.hip): the closed-form relation step of CoR2 applied to
-    the pooled features of the second attention; backward is one pass instead of autograd's multiply / reduce chain."""
-
-    @staticmethod
-    def forward(ctx, pooled, t, c):
-        pooled, t, c = _prep("pooled", pooled), _prep("t", t), _prep("c", c)
-        B, G, D = pooled.shape
-        if t.shape != (B, D) or c.shape != (B, D):
-            raise ValueError("affine_map: t / c must be [B,D] = %s, got %s / %s" % ((B, D), tuple(t.shape), tuple(c.shape)))
-        out = torch.empty_like(pooled)
-        _launch("affine_map_fwd", (B, G, D), _lib.lib().vqa_affine_map_fwd, _p(pooled), _p(t), _p(c), _p(out), B, G, D)
-        ctx.save_for_backward(pooled, c)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        pooled, c = ctx.saved_tensors
-        g = _prep("grad_out", g)
-        B, G, D = pooled.shape
-        d_pooled = torch.empty_like(pooled) if ctx.needs_input_grad[0] else None
-        d_t, d_c = torch.empty_like(c), torch.empty_like(c)
-        _launch("affine_map_bwd", (B, G, D), _lib.lib().vqa_affine_map_bwd, _p(g), _p(pooled), _p(c), _p(d_pooled), _p(d_t),
-                _p(d_c), B, G, D)
-        return d_pooled, d_t, d_c
-
-
-def affine_map(pooled, t, c):
-    if pooled.dtype != torch.float32 or pooled.shape[-1] % 4:
-        return torch.addcmul(t.unsqueeze(1), c.unsqueeze(1), pooled)
-    return AffineMap.apply(pooled, t, c)
-
-
 class WithFirstGroup(torch.autograd.Function):
     """pooled [B,G,D] -> (pooled, pooled[:,0]) for the two consumers of the first attention's pooled features (its own
     glimpse projections; the relation step, which reads glimpse 0).  Backward adds the slice gradient into a copy of
