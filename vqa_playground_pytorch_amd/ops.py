@@ -770,7 +770,12 @@ class BatchedLinearFn(torch.autograd.Function):
         d_b = torch.empty(G, A, device=gy.device, dtype=torch.float32) if (has_bias and ctx.needs_input_grad[2]) else None
         _launch("act_bwd_colsum", (G, B, A, code), _lib.lib().vqa_act_bwd_colsum, _p(gy), _p(out), _p(gz), _p(d_b), G, B, A,
                 code, int(group_first))
-        d_x = torch.bmm(gz, w).transpose(0, 1) if ctx.needs_input_grad[0] else None
+        d_x = None
+        if ctx.needs_input_grad[0]:
+            # written in the consumer's [B,G,K] layout (row stride G*K, batch stride K: a layout the strided-batched GEMM
+            # takes as it is), so the kernels behind it get a contiguous gradient without a copy
+            d_x = torch.empty(B, G, w.shape[2], device=gy.device, dtype=gz.dtype)
+            torch.bmm(gz, w, out=d_x.transpose(0, 1))
         d_w = torch.bmm(gz.transpose(1, 2), x.transpose(0, 1)) if ctx.needs_input_grad[1] else None
         return d_x, d_w, d_b, None, None
 
