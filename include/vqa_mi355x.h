@@ -346,6 +346,13 @@ int vqa_bias_act(const float* y, const float* bias, int bias_stride, float* out,
 int vqa_act_bwd_colsum(const float* gy, const float* out, float* gz, float* d_bias, int G, int B, int A,
                        int act, int group_first, vqa_stream_t stream);
 
+/* Rank sum of the vector-vector Mutan fusion (putils.MutanFusion.forward, putils/__init__.py:232-238, with 2-D inputs --
+ * fusion_final of config/CoR2.py:182 / config/ODA.py:197):  out[b,:] = sum_r h1[b,r,:] * h2[b,r,:]  (the reference's
+ * bmul + `total +=` over the ranks);  backward d_h1 = g * h2, d_h2 = g * h1.  h1 / h2 [B,R,H] dense, H even. */
+int vqa_rank_product_fwd(const float* h1, const float* h2, float* out, int B, int R, int H, vqa_stream_t stream);
+int vqa_rank_product_bwd(const float* g, const float* h1, const float* h2, float* d_h1, float* d_h2, int B,
+                         int R, int H, vqa_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Gate math of the BayesianGRU question encoder, one call per time step each way (putils/__init__.py:704-731
  * with the cell of :604-646 and the sequence-shared dropout of :503-539); the three recurrent GEMMs of a

@@ -465,6 +465,20 @@ def test_linear_fn_relu_epilogue(ops, rows, need_dx):
     close("d_b", b.grad, bd.grad.cpu().numpy(), 2e-5)
 
 
+@pytest.mark.parametrize("B,R,H", [(512, 2, 510), (512, 5, 510), (3, 1, 2), (7, 3, 66)])
+def test_rank_product(ops, B, R, H):
+    h1, h2 = g(seeded.seeded_array((B, R, H), 371), True), g(seeded.seeded_array((B, R, H), 372), True)
+    go = g(seeded.seeded_array((B, H), 373))
+    out = ops.rank_product(h1, h2)
+    out.backward(go)
+    a, b_ = h1.detach().double().requires_grad_(), h2.detach().double().requires_grad_()
+    ref = (a * b_).sum(1)
+    ref.backward(go.double())
+    close("out", out, ref.detach().cpu().numpy(), 2e-6)
+    close("d_h1", h1.grad, a.grad.cpu().numpy(), 2e-6)
+    close("d_h2", h2.grad, b_.grad.cpu().numpy(), 2e-6)
+
+
 def test_with_first_group(ops):
     pooled = g(seeded.seeded_array((6, 4, 8), 361), True)
     full, first = ops.with_first_group(pooled)

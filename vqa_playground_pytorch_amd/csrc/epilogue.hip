@@ -75,6 +75,38 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const float* __rest
   }
 }
 
+// Rank sum of the vector-vector Mutan fusion (putils/__init__.py:232-238 with 2-D inputs: fusion_final):
+//   out[b,:] = sum_r h1[b,r,:] * h2[b,r,:];   backward d_h1 = g * h2, d_h2 = g * h1 (g broadcast over r)
+// one kernel each way instead of multiply + reduce and two broadcast multiplies.  Lane = one float2 column of a sample.
+__global__ __launch_bounds__(256) void rank_product_fwd_kernel(const float* __restrict__ h1, const float* __restrict__ h2,
+                                                               float* __restrict__ out, int B, int R, int H) {
+  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (e >= (size_t)B * H) return;
+  const size_t b = e / H, h = e % H;
+  float2 acc = make_float2(0.f, 0.f);
+  for (int r = 0; r < R; ++r) {
+    const size_t o = (b * R + r) * H + h;
+    const float2 x = ld2(h1 + o), y = ld2(h2 + o);
+    acc.x = fmaf(x.x, y.x, acc.x);
+    acc.y = fmaf(x.y, y.y, acc.y);
+  }
+  st2(out + e, acc);
+}
+__global__ __launch_bounds__(256) void rank_product_bwd_kernel(const float* __restrict__ g, const float* __restrict__ h1,
+                                                               const float* __restrict__ h2, float* __restrict__ d_h1,
+                                                               float* __restrict__ d_h2, int B, int R, int H) {
+  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (e >= (size_t)B * H) return;
+  const size_t b = e / H, h = e % H;
+  const float2 gv = ld2(g + e);
+  for (int r = 0; r < R; ++r) {
+    const size_t o = (b * R + r) * H + h;
+    const float2 x = ld2(h1 + o), y = ld2(h2 + o);
+    st2(d_h1 + o, make_float2(gv.x * y.x, gv.y * y.y));
+    st2(d_h2 + o, make_float2(gv.x * x.x, gv.y * x.y));
+  }
+}
+
 }  // namespace vqa
 
 using namespace vqa;
@@ -99,4 +131,26 @@ extern "C" int vqa_act_bwd_colsum(const float* gy, const float* out, float* gz, 
   hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3((A + 15) / 16, G), dim3(256), 0, static_cast<hipStream_t>(stream), gy, out, gz,
                      d_bias, G, B, A, act, group_first);
   return check_launch("act_bwd_colsum");
+}
+
+extern "C" int vqa_rank_product_fwd(const float* h1, const float* h2, float* out, int B, int R, int H, vqa_stream_t stream) {
+  VQA_REQUIRE(h1 && h2 && out, VQA_E_BADARG, "rank_product_fwd: null pointer");
+  VQA_REQUIRE(B > 0 && R > 0 && H > 0 && H % 2 == 0, VQA_E_BADARG, "rank_product_fwd: bad sizes B=%d R=%d H=%d (H even)", B, R, H);
+  VQA_REQUIRE(aligned(h1, 8) && aligned(h2, 8) && aligned(out, 8), VQA_E_UNSUPPORTED, "rank_product_fwd: tensors must be 8-byte aligned");
+  const size_t n = (size_t)B * H / 2;
+  hipLaunchKernelGGL(rank_product_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     h1, h2, out, B, R, H);
+  return check_launch("rank_product_fwd");
+}
+
+extern "C" int vqa_rank_product_bwd(const float* g, const float* h1, const float* h2, float* d_h1, float* d_h2, int B, int R,
+                                    int H, vqa_stream_t stream) {
+  VQA_REQUIRE(g && h1 && h2 && d_h1 && d_h2, VQA_E_BADARG, "rank_product_bwd: null pointer");
+  VQA_REQUIRE(B > 0 && R > 0 && H > 0 && H % 2 == 0, VQA_E_BADARG, "rank_product_bwd: bad sizes B=%d R=%d H=%d (H even)", B, R, H);
+  VQA_REQUIRE(aligned(g, 8) && aligned(h1, 8) && aligned(h2, 8) && aligned(d_h1, 8) && aligned(d_h2, 8), VQA_E_UNSUPPORTED,
+              "rank_product_bwd: tensors must be 8-byte aligned");
+  const size_t n = (size_t)B * H / 2;
+  hipLaunchKernelGGL(rank_product_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     g, h1, h2, d_h1, d_h2, B, R, H);
+  return check_launch("rank_product_bwd");
 }

@@ -282,9 +282,9 @@ class MutanFusion(nn.Module):
         if inputs1.dim() == 2 and inputs1.is_cuda:
             # vector-vector fusion (fusion_final: B rows, not B*N): a few hundred MFLOP, far too little for the K4 tile
             # kernels (16-64 workgroups, each walking the whole K = 1240 twice: 85 us forward).  Both sides run as
-            # batched library GEMMs and the rank sum is one fused multiply-reduce.
+            # library GEMMs and the rank sum is one fused multiply-reduce kernel (ops.rank_product).
             h1 = my_linears(list(self.list_linear1), inputs1)                          # [B,R,H]
-            return (h1 * h2).sum(dim=1)
+            return ops.rank_product(h1, h2)
         weights = [lin.linear.weight for lin in self.list_linear1]
         biases = [lin.linear.bias for lin in self.list_linear1]
         return ops.lowrank_bilinear_fusion(inputs1, h2, weights, biases)

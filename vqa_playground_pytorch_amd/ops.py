@@ -786,6 +786,37 @@ def batched_linear(x, w, b=None, group_first=False, act=None):
     return BatchedLinearFn.apply(x, w, b, group_first, act)
 
 
+class RankProduct(torch.autograd.Function):
+    """out[b,:] = sum_r h1[b,r,:] * h2[b,r,:] -- the rank sum of the vector-vector Mutan fusion (fusion_final), one kernel
+    each way (csrc/epilogue.hip) instead of multiply + reduce forward and two broadcast multiplies backward."""
+
+    @staticmethod
+    def forward(ctx, h1, h2):
+        h1, h2 = _prep("h1", h1), _prep("h2", h2)
+        if h1.dim() != 3 or h1.shape != h2.shape:
+            raise ValueError("rank_product: h1 and h2 must both be [B,R,H], got %s / %s" % (tuple(h1.shape), tuple(h2.shape)))
+        B, R, H = h1.shape
+        out = torch.empty(B, H, device=h1.device, dtype=torch.float32)
+        _launch("rank_product_fwd", (B, R, H), _lib.lib().vqa_rank_product_fwd, _p(h1), _p(h2), _p(out), B, R, H)
+        ctx.save_for_backward(h1, h2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h1, h2 = ctx.saved_tensors
+        g = _prep("grad_out", g)
+        B, R, H = h1.shape
+        d_h1, d_h2 = torch.empty_like(h1), torch.empty_like(h2)
+        _launch("rank_product_bwd", (B, R, H), _lib.lib().vqa_rank_product_bwd, _p(g), _p(h1), _p(h2), _p(d_h1), _p(d_h2), B, R, H)
+        return d_h1, d_h2
+
+
+def rank_product(h1, h2):
+    if h1.dtype != torch.float32 or h1.shape[-1] % 2:
+        return (h1 * h2).sum(dim=1)
+    return RankProduct.apply(h1, h2)
+
+
 class WithFirstGroup(torch.autograd.Function):
     """pooled [B,G,D] -> (pooled, pooled[:,0]) for the two consumers of the first attention's pooled features (its own
     glimpse projections; the relation step, which reads glimpse 0).  Backward adds the slice gradient into a copy of
