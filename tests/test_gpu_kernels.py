@@ -284,10 +284,13 @@ def test_lowrank_bilinear_fusion_full_size_properties(ops, monkeypatch, form):
     assert (out2 - 3.0 * out).abs().max().item() <= 1e-5 * scale * 3
 
 
-@pytest.mark.parametrize("B,N", [(1501, 36), (203, 100)])
-def test_lowrank_bilinear_fusion_large_batch_against_torch_fp64(ops, B, N):
+@pytest.mark.parametrize("form", ["folded", "engine"])
+@pytest.mark.parametrize("B,N", [(1501, 36), (203, 100), (4099, 36)])
+def test_lowrank_bilinear_fusion_large_batch_against_torch_fp64(ops, monkeypatch, form, B, N):
     """Folded K4, forward and every gradient, at batches that are no multiple of its 8- / 4-sample groups and give the
-    weight-gradient kernel uneven sample slabs; reference = torch autograd in fp64 on the GPU."""
+    weight-gradient kernel uneven sample slabs -- 4099 samples also exceed what one slab can keep of the question-side
+    factors in LDS (regression: the slab count must grow with the batch); reference = torch autograd in fp64 on the GPU."""
+    monkeypatch.setattr(ops, "_K4_FORM", form)
     L, H, R = 310, 510, 2
     gen = torch.Generator(device="cpu").manual_seed(11)
     x = torch.randn(B, N, L, generator=gen).to(dev()).requires_grad_()

@@ -545,17 +545,22 @@ static bool dw_per_sample(int N, int R) {
   if (const char* e = std::getenv("VQA_K4_DW_FORM")) return std::atoi(e) != 0 && R <= 4;  // experiment knob
   return R >= 2 && R <= 4 && N * 4 >= padded * 3;
 }
-static int dw_sample_splits(int B, int H, int L, TileChoice t) {
+static long dw_max_samples_per_slab(int R) { return 65536 / ((long)R * 64 * (long)sizeof(float)); }
+static int dw_sample_splits(int B, int H, int L, TileChoice t, int R) {
   const long tiles = (long)((H + t.bm - 1) / t.bm) * ((L + t.bn - 1) / t.bn);
   long s = (1280 + tiles - 1) / tiles;  // 5 workgroups per CU: 32 slabs of 16 samples at B = 512 (sweep: 20..64)
   if (const char* e = std::getenv("VQA_K4_DW_SPLITS")) s = std::atol(e);  // experiment knob
-  if (s > B) s = B;
   if (s > 64) s = 64;
+  // the question-side factors of a slab's samples wait in LDS ([samples][R][BM] floats): at most 64 KB of them
+  const long per = dw_max_samples_per_slab(R) * 64 / t.bm;
+  const long by_lds = (B + per - 1) / per;
+  if (s < by_lds) s = by_lds;
+  if (s > B) s = B;
   if (s < 1) s = 1;
   return (int)s;
 }
 static int dw_slabs(int B, int N, int L, int H, int R) {
-  return dw_per_sample(N, R) ? dw_sample_splits(B, H, L, dw_tile()) : splits_for_dw(B * N, H, L, R, dw_tile());
+  return dw_per_sample(N, R) ? dw_sample_splits(B, H, L, dw_tile(), R) : splits_for_dw(B * N, H, L, R, dw_tile());
 }
 
 }  // namespace vqa
@@ -715,8 +720,11 @@ static int dw_fold_splits(int B, int N, int H, int L, int R) {
   const int resident = dw_fold_bk(N, R) == 40 ? 2 : (R <= 2 ? 3 : 2);   // workgroups per CU (register budget)
   long s = (256L * resident) / tiles;
   if (const char* e = std::getenv("VQA_K4_DW_SPLITS")) s = std::atol(e);  // experiment knob
-  if (s > B) s = B;
   if (s > 64) s = 64;
+  // the question-side factors of a slab's samples wait in LDS ([samples][R][64] floats): at most 64 KB of them
+  const long by_lds = (B + dw_max_samples_per_slab(R) - 1) / dw_max_samples_per_slab(R);
+  if (s < by_lds) s = by_lds;
+  if (s > B) s = B;
   if (s < 1) s = 1;
   return (int)s;
 }
