@@ -466,3 +466,25 @@ def test_reset_optimizer_under_graph_replay():
     assert tr.lr == tr2.lr
     for p, q_ in zip(model.parameters(), twin.parameters()):
         assert (p - q_).abs().max().item() <= 2e-3 * max(p.abs().max().item(), 1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,nans,kw", [("cor2", 2000, {}), ("cor2", 2000, {"relation_mode": 0}), ("oda", 3000, {}),
+                                          ("cor2", 2000, {"compute_dtype": torch.bfloat16})])
+def test_inference_without_grad(name, nans, kw):
+    """eval() + torch.no_grad() (the reference's test / visu loops, train.py:139,:210; visu.py:188): every custom
+    autograd Function of the path must also run when nothing requires a gradient, and give the same logits."""
+    from vqa_playground_pytorch_amd import CoR2Model, ODAModel
+    torch.manual_seed(0)
+    model = {"cor2": CoR2Model, "oda": ODAModel}[name](["PAD"], nans, **kw).to(dev()).eval()
+    for B in (1, 5, 64):
+        v, q = torch.randn(B, 36, 2048, device=dev()), torch.randn(B, 2400, device=dev())
+        with torch.no_grad():
+            y = model({"v": v, "q_idxes": q})
+            ad = model.alpha_dict
+        y2 = model({"v": v, "q_idxes": q})
+        assert y.shape == (B, nans) and torch.isfinite(y).all() and not y.requires_grad
+        assert torch.allclose(y, y2, rtol=1e-4, atol=1e-5)
+        for val in ad.values():
+            for t in (val if isinstance(val, tuple) else (val,)):
+                assert torch.isfinite(t).all() and not t.requires_grad
