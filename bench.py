@@ -261,6 +261,8 @@ def main():
     ap.add_argument("--encoder", action="store_true", help="include the question encoder (SURVEY 8f row 3): SkipThoughts = "
                     "embedding(620) + 26-step BayesianGRU(2400), randomly initialised, fed int64 token ids [B,26] instead of "
                     "question vectors")
+    ap.add_argument("--overlap", action="store_true", help="CoR2: backward in two halves, the second reasoning step's "
+                    "gradients all-reduced under the second half (trainer overlap; at one GPU it only splits the backward)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying "
                     "the captured hipGraphs of the step")
     args = ap.parse_args()
@@ -305,7 +307,8 @@ def main():
         model = ODAModel(["PAD", "UNK"], answers).to(dev).train()
     # adopt_inputs: the synthetic batch is resident and the same tensors are handed over every step, so the replayed
     # graphs read it in place (a real feeder goes through the trainer's private input buffers: tools/feed_bench.py)
-    trainer = DataParallelTrainer(model, lr=1e-4, clip=0.25, graph=not args.no_graph, adopt_inputs=True)
+    trainer = DataParallelTrainer(model, lr=1e-4, clip=0.25, graph=not args.no_graph, adopt_inputs=True,
+                                  overlap=("force" if world == 1 else True) if args.overlap else None)
     torch.manual_seed(100 + rank)  # per-rank dropout streams and data shards differ
     B = args.batch
     v = torch.randn(B, args.regions, FEAT, device=dev)
@@ -404,7 +407,8 @@ def main():
                         "attention, 3000 answers (BASELINE configs[2])" % B),
                        "global_batch": world * B, "step": "forward + KLD-sum loss + backward + grad sum-all-reduce "
                        "+ clip 0.25 + Adam (dropout active)", "parallelism": "dp%d" % world,
-                       "launch": "hipGraph replay (2 graphs + eager all-reduce)" if graphed else "eager",
+                       "launch": ("hipGraph replay (3 graphs: backward in two halves, the first all-reduce under the second)"
+                                  if trainer.overlap else "hipGraph replay (2 graphs + eager all-reduce)") if graphed else "eager",
                        "relation_mode": "factored" if args.relation_mode == 1 else "pairwise"},
             "final_loss": round(final_loss, 3), "final_grad_norm": round(final_gnorm, 3),
             "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",

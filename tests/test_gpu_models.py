@@ -488,3 +488,61 @@ def test_inference_without_grad(name, nans, kw):
         for val in ad.values():
             for t in (val if isinstance(val, tuple) else (val,)):
                 assert torch.isfinite(t).all() and not t.requires_grad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("mode", [1, 0])
+def test_two_half_backward_matches_single_pass(graph, mode):
+    """DataParallelTrainer(overlap=...): backward stops at the tensors the second reasoning step reads from the first
+    (CoR2Model.forward_with_cut), the late parameters' gradients are gathered (and, with more than one rank, all-reduced
+    under the second half), then backward resumes.  Same losses, gradient norms and weights as the single-pass step --
+    eager and hipGraph-replayed, closed-form and pairwise relation step."""
+    from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
+    data = [tuple(torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(48, answers=300, seed=80 + i)) for i in range(7)]
+    out = {}
+    for overlap in (False, "force"):
+        model = build("cor2", 300, relation_mode=mode)
+        tr = DataParallelTrainer(model, lr=2e-5, clip=0.25, graph=graph, overlap=overlap)
+        assert tr.overlap == bool(overlap)
+        traj = []
+        for v, q, a in data:
+            loss, norm = tr.step({"v": v, "q_idxes": q}, a)
+            traj.append((loss.item(), norm.item()))
+        if graph:
+            assert tr._graph is not None, "step was not captured"
+            if overlap:
+                assert set(tr.graph_nodes) == {"front_a", "front_b", "tail"}
+        out[overlap] = (traj, [p.detach().clone() for p in model.parameters()])
+    for (l0, n0), (l1, n1) in zip(out[False][0], out["force"][0]):
+        assert abs(l0 - l1) <= 1e-4 * abs(l0) and abs(n0 - n1) <= 1e-4 * max(abs(n0), 1e-6), (out[False][0], out["force"][0])
+    for p0, p1 in zip(out[False][1], out["force"][1]):
+        assert (p0 - p1).abs().max().item() <= 2e-3 * max(p0.abs().max().item(), 1e-3)
+
+
+@pytest.mark.gpu
+def test_late_parameters_cover_exactly_the_second_step():
+    """The late bucket holds the parameters whose gradients are complete at the cut, contiguous at the head of the flat
+    gradient buffer; every other parameter gets its gradient in the second half (none is missed, none is in both)."""
+    from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
+    model = build("cor2", 300)
+    tr = DataParallelTrainer(model, overlap="force")
+    assert tr.overlap
+    late, early = {id(p) for p in tr._late}, {id(p) for p in tr._early}
+    assert not (late & early) and late | early == {id(p) for p in model.parameters()}
+    names = {id(p): n for n, p in model.named_parameters()}
+    assert all(names[i].split(".")[0] in ("compress_v2", "fusion_vq2", "att2", "fusion_final", "linear_classif") for i in late)
+    assert max(tr.flat.offset_of(p) + p.numel() for p in tr._late) <= tr._split <= min(tr.flat.offset_of(p) for p in tr._early)
+    v, q, a = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(8, answers=300, seed=5))
+    used = torch.zeros_like(tr.flat.g, dtype=torch.bool)        # (alignment gaps between segments belong to no parameter)
+    for p in tr.flat.params:
+        o = tr.flat.offset_of(p)
+        used[o:o + p.numel()] = True
+    tr.flat.g.fill_(float("nan"))
+    tr._front_a({"v": v, "q_idxes": q}, a, device_seed=False)
+    head = used.clone()
+    head[tr._split:] = False
+    assert torch.isfinite(tr.flat.g[head]).all()                   # late gradients are in place after the first half
+    assert torch.isnan(tr.flat.g[used & ~head]).all()              # ... and nothing else has been touched yet
+    tr._front_b()
+    assert torch.isfinite(tr.flat.g[used]).all()

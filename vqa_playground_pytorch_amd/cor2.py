@@ -51,6 +51,20 @@ class Model(nn.Module):
         self.expand_q_2 = MyLinear(310, 2048, p=0.5, af="sigmoid")
         self.alpha_dict = {}
 
+    def late_parameters(self):
+        """Parameters of the second reasoning step.  Their gradients are complete once backward has walked from the loss
+        to the tensors ``forward_with_cut`` reports -- before the first step's layers are touched -- so a data-parallel
+        trainer can start reducing them while the rest of backward runs (trainer.DataParallelTrainer, overlap=True)."""
+        mods = [self.compress_v2, self.fusion_vq2, self.att2, self.fusion_final, self.linear_classif]
+        return [p for m in mods for p in m.parameters()]
+
+    def forward_with_cut(self, sample):
+        """-> (logits, outs, ins): ``outs`` are the first reasoning step's results that the second one reads, ``ins`` the
+        detached aliases it actually consumed.  d loss / d ins fed as grad_outputs of ``outs`` completes the backward."""
+        cut = []
+        logits = self(sample, cut)
+        return logits, cut[0], cut[1]
+
     def stack_groups(self):
         return linear_stack_groups([self.compress_q, self.linear_q, self.compress_q_1, self.compress_q_2]) + \
             linear_stack_groups([self.expand_q_1, self.expand_q_2])
@@ -72,7 +86,7 @@ class Model(nn.Module):
         return ops.pairwise_relation_reduce(v_feature, q_gate_1, q_gate_2, alpha, glimpse=0,
                                             mode=self.relation_mode, dual=True)
 
-    def forward(self, sample):
+    def forward(self, sample, _cut=None):
         v = sample["v"]
         b = v.size(0)
         v_feature = v.contiguous().view(b, -1, 2048)
@@ -85,6 +99,16 @@ class Model(nn.Module):
         fuse1 = self.fusion_vq1(v_feature_low, q_feature_low)
         v1_att, alpha1, alpha1_full, pooled1_first = self.att1.attend(v_feature, self.att1.conv_att.pre_activation(fuse1),
                                                                 return_pooled=True)
+        if _cut is not None:
+            # everything the second reasoning step (relation, compress_v2, fusion_vq2, att2, fusion_final, classifier)
+            # reads from the first.  The second step runs on detached aliases of these tensors, so a backward pass from the
+            # loss ends at the aliases (some of the originals are ancestors of others -- q_feature_low of v1_att -- and
+            # would otherwise drag the first step's layers into it); a second pass then carries the aliases' gradients
+            # from the originals to the inputs (see late_parameters / trainer.DataParallelTrainer overlap)
+            outs = [q_feature_low, q_final, q_gate_1, q_gate_2, pooled1_first, v1_att, alpha1_full]
+            ins = [t.detach().requires_grad_(t.requires_grad) for t in outs]
+            _cut.extend([outs, ins])
+            q_feature_low, q_final, q_gate_1, q_gate_2, pooled1_first, v1_att, alpha1_full = ins
 
         if self.relation_mode == 1:
             # Closed form of the relation step (config/CoR2.py:191-199 + :216).  Only glimpse 0 of alpha1 weights it, and

@@ -154,6 +154,25 @@ class FlatState:
         for p in self.params:
             p.grad = None
 
+    def store_grads(self, params, grads):
+        """Gradients computed by torch.autograd.grad for a subset of the parameters -> their slots of the flat buffer."""
+        if not hasattr(self, "_view_of"):
+            self._view_of = {id(p): v for p, v in zip(self.params, self.g_views)}
+        src, dst = [], []
+        for p, g in zip(params, grads):
+            view = self._view_of[id(p)]
+            if g is None:
+                view.zero_()
+            else:
+                src.append(g)
+                dst.append(view)
+            p.grad = view
+        if src:
+            torch._foreach_copy_(dst, src)
+
+    def offset_of(self, p):
+        return self.offsets[next(i for i, q in enumerate(self.params) if q is p)]
+
     def gather_grads(self):
         src, dst = [], []
         for p, view in zip(self.params, self.g_views):
@@ -171,7 +190,7 @@ class DataParallelTrainer:
     """Replicated model + flat-gradient sum-all-reduce + the reference's clip/Adam/ExponentialLR."""
 
     def __init__(self, model, lr=1e-4, clip=0.25, gamma=0.5 ** (1 / 50000), broadcast=True, group=None,
-                 fused_adam=None, graph=False, adopt_inputs=False):
+                 fused_adam=None, graph=False, adopt_inputs=False, overlap=None):
         self.model = model
         self.group = group
         self.clip = clip
@@ -200,8 +219,29 @@ class DataParallelTrainer:
         self.adopt_inputs = bool(adopt_inputs)
         self._graph = None
         self._eager_steps = 0
+        # overlap (GPU path, models that offer late_parameters() / forward_with_cut(): CoR2): backward runs in two halves;
+        # the gradients of the second reasoning step -- complete after the first half -- are all-reduced while the
+        # second half runs.  Off unless asked for (VQA_DP_OVERLAP=1 or overlap=True): correct by construction and covered
+        # by tests, but its gain over xGMI has not been measured yet.  "force" also splits at world size 1 (tests).
+        if overlap is None:
+            import os
+            overlap = os.environ.get("VQA_DP_OVERLAP", "0") == "1"
+        self.overlap = False
         if self.hip:
-            self.flat = FlatState(model.parameters(), collect_stack_groups(model))
+            params = list(model.parameters())
+            can_split = bool(overlap) and hasattr(model, "late_parameters") and hasattr(model, "forward_with_cut") and \
+                (self.world > 1 or overlap == "force")
+            if can_split:
+                late_ids = {id(p) for p in model.late_parameters()}
+                params = [p for p in params if id(p) in late_ids] + [p for p in params if id(p) not in late_ids]
+            self.flat = FlatState(params, collect_stack_groups(model))
+            if can_split:
+                late = [p for p in self.flat.params if id(p) in late_ids]
+                early = [p for p in self.flat.params if id(p) not in late_ids]
+                if late and early:
+                    split = min(self.flat.offset_of(p) for p in early)
+                    if all(self.flat.offset_of(p) + p.numel() <= split for p in late):
+                        self.overlap, self._late, self._early, self._split = True, late, early, split
             self.step_scalars = torch.zeros(2, device=first.device, dtype=torch.float32)
             # pinned staging for the tiny per-step H2D copies: a ring, so a slot is not rewritten while an earlier
             # (asynchronous) copy from it may still be pending on the stream
@@ -232,6 +272,8 @@ class DataParallelTrainer:
 
     def step_eager(self, sample, target):
         """The same step launched kernel by kernel (no graph replay)."""
+        if self.overlap:
+            return self._step_split_eager(sample, target)
         logits = self.model(sample)
         loss = kld_sum_loss(logits, target)
         # scheduler.step() precedes optimizer.step() in the reference (train.py:75-86): step t uses lr0*gamma^t
@@ -295,6 +337,8 @@ class DataParallelTrainer:
     def _graph_step(self, sample, target):
         from . import ops
         f = self.flat
+        if self.overlap:
+            return self._graph_step_split(sample, target)
         if self._graph is None:
             seeds_before = ops.host_seed_draws
             self._set_step_scalars()
@@ -376,6 +420,135 @@ class DataParallelTrainer:
         torch.cuda.synchronize()
         self._graph = {"front": front, "tail": tail, "loss": loss, "sample": static_sample, "target": target,
                        "training": self.model.training}
+
+    # ---- backward in two halves, the first all-reduce under the second (overlap=True) ---------------------------------
+    def _front_a(self, sample, target, device_seed=True):
+        """forward + loss + backward from the loss down to the cut + gather of the late parameters' gradients."""
+        from . import ops
+        if device_seed:
+            ops.set_device_seed(self.seed_word)
+            ops.begin_step_salts()
+        try:
+            logits, outs, ins = self.model.forward_with_cut(sample)
+            loss = kld_sum_loss(logits, target)
+        finally:
+            if device_seed:
+                ops.set_device_seed(None)
+        live = [(o, i) for o, i in zip(outs, ins) if i.requires_grad]
+        grads = torch.autograd.grad(loss, self._late + [i for _, i in live], allow_unused=True)
+        self.flat.store_grads(self._late, grads[:len(self._late)])
+        pairs = [(o, g) for (o, _), g in zip(live, grads[len(self._late):]) if g is not None]
+        self._cut = ([o for o, _ in pairs], [g for _, g in pairs])
+        return loss.detach()
+
+    def _front_b(self):
+        """backward from the cut to the inputs + gather of the early parameters' gradients."""
+        tensors, grads_in = self._cut
+        self._cut = None
+        grads = torch.autograd.grad(tensors, self._early, grad_outputs=grads_in, allow_unused=True)
+        self.flat.store_grads(self._early, grads)
+
+    def _reduce_late_async(self):
+        if self.world > 1:
+            return dist.all_reduce(self.flat.g[:self._split], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return None
+
+    def _reduce_early(self, pending):
+        if self.world > 1:
+            dist.all_reduce(self.flat.g[self._split:], op=dist.ReduceOp.SUM, group=self.group)
+        if pending is not None:
+            pending.wait()
+
+    def _step_split_eager(self, sample, target):
+        from . import ops
+        f = self.flat
+        loss = self._front_a(sample, target, device_seed=False)
+        pending = self._reduce_late_async()
+        self._front_b()
+        self._reduce_early(pending)
+        self.iteration += 1
+        self.adam_steps += 1
+        self._lr = lr = self.base_lr * self.gamma ** self.iteration
+        ops.grad_norm_clip_coef(f.g, self.clip if self.clip else 0.0, f.norm_and_coef, f.workspace)
+        ops.adam_step(f.p, f.g, f.m, f.v, f.norm_and_coef, lr, self.betas[0], self.betas[1], self.eps, self.adam_steps)
+        return loss, f.norm_and_coef[0]
+
+    def _graph_step_split(self, sample, target):
+        from . import ops
+        f = self.flat
+        if self._graph is None:
+            seeds_before = ops.host_seed_draws
+            self._set_step_scalars()
+            loss = self._front_a(sample, target)
+            pending = self._reduce_late_async()
+            self._front_b()
+            self._reduce_early(pending)
+            self._tail()
+            self._eager_steps += 1
+            if ops.host_seed_draws != seeds_before:
+                self.want_graph = False
+            elif self._eager_steps >= 3:
+                try:
+                    self._capture_split(sample, target)
+                except Exception as e:        # noqa: BLE001 -- any capture failure: keep training, kernel by kernel
+                    import sys
+                    print("[vqa trainer] hipGraph capture failed (%s: %s); continuing with eager launches"
+                          % (type(e).__name__, str(e).splitlines()[0] if str(e) else ""), file=sys.stderr)
+                    self._graph = None
+                    self.want_graph = False
+                    torch.cuda.synchronize()
+            return loss, f.norm_and_coef[0]
+        g = self._graph
+        if self.model.training != g["training"] or target.shape != g["target"].shape or any(
+                k not in sample or sample[k].shape != t.shape or sample[k].dtype != t.dtype for k, t in g["sample"].items()):
+            return self.step_eager(sample, target)
+        for k, t in g["sample"].items():
+            if sample[k].data_ptr() != t.data_ptr():
+                t.copy_(sample[k], non_blocking=True)
+        if target.data_ptr() != g["target"].data_ptr():
+            g["target"].copy_(target, non_blocking=True)
+        self._set_step_scalars()
+        g["front_a"].replay()
+        pending = self._reduce_late_async()
+        g["front_b"].replay()
+        self._reduce_early(pending)
+        g["tail"].replay()
+        return g["loss"], f.norm_and_coef[0]
+
+    def _capture_split(self, sample, target):
+        static_sample = {k: (v if self.adopt_inputs else v.clone()) for k, v in sample.items() if isinstance(v, torch.Tensor)}
+        if not self.adopt_inputs:
+            target = target.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._front_a(static_sample, target)
+            self._front_b()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        mode = "global"
+        if self.world > 1:
+            import time
+            dist.barrier(group=self.group)
+            torch.cuda.synchronize()
+            time.sleep(1.0)
+            mode = "thread_local"
+        graphs = {k: torch.cuda.CUDAGraph(keep_graph=True) for k in ("front_a", "front_b", "tail")}
+        pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(graphs["front_a"], pool=pool, capture_error_mode=mode):
+            loss = self._front_a(static_sample, target)
+        with torch.cuda.graph(graphs["front_b"], pool=pool, capture_error_mode=mode):
+            self._front_b()
+        with torch.cuda.graph(graphs["tail"], pool=pool, capture_error_mode=mode):
+            self._tail()
+        self.graph_nodes = {k: graph_node_types(v) for k, v in graphs.items()}
+        memsets = sum(c.get("memset", 0) for c in self.graph_nodes.values())
+        if memsets:
+            raise RuntimeError("captured step holds %d memset node(s), which do not replay reliably" % memsets)
+        for v in graphs.values():
+            v.instantiate()
+        torch.cuda.synchronize()
+        self._graph = dict(graphs, loss=loss, sample=static_sample, target=target, training=self.model.training)
 
     @property
     def lr(self):
