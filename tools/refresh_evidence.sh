@@ -39,4 +39,13 @@ for mode in graph eager; do
   [ -n "$f" ] && cp "$f" "$OUT/bench_b512_${mode}_kernel_stats.csv"
   python3 "$ROOT/tools/by_grid.py" /tmp/kt_$mode 1 "hand-written kernels, per-dispatch durations by (kernel, grid work-items); rocprofv3 --kernel-trace of bench.py --steps 20 --warmup 5 --no-cpu-baseline $extra (the last column is the total over the run)" > "$OUT/vqa_kernels_by_grid_$mode.txt" 2>&1
 done
+# 4. the other two configurations, kernel by kernel is not needed: the replayed run's stats and per-dispatch durations
+for cfg in "oda_b512|--model oda" "bf16_n100_b128|--dtype bf16 --regions 100 --batch 128"; do
+  name=${cfg%%|*}; args=${cfg#*|}
+  rm -rf /tmp/kt_$name
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$name -- python3 "$ROOT/bench.py" $args --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/kt_$name.log" 2>&1
+  f=$(find /tmp/kt_$name -name "*kernel_stats.csv" | sort | sed -n 1p)
+  [ -n "$f" ] && cp "$f" "$OUT/bench_${name}_kernel_stats.csv"
+  python3 "$ROOT/tools/by_grid.py" /tmp/kt_$name 1 "hand-written kernels, per-dispatch durations by (kernel, grid work-items); rocprofv3 --kernel-trace of bench.py $args --steps 20 --warmup 5 --no-cpu-baseline (the last column is the total over the run)" > "$OUT/vqa_kernels_by_grid_$name.txt" 2>&1
+done
 ls -la "$OUT"

@@ -229,19 +229,43 @@ __global__ __launch_bounds__(256) void oda_reduce_kernel(const float* __restrict
   out[e] = a;
 }
 
-// d_bias[g] = sum_{b,i} dS[b,i,g]; one workgroup, deterministic tree
-__global__ __launch_bounds__(256) void oda_dbias_kernel(const float* __restrict__ dS, float* __restrict__ d_bias, int rows,
-                                                        int G) {
-  __shared__ float part[4 * kOdaMaxG];
+// d_bias[g] = sum_{b,i} dS[b,i,g]; one workgroup of 1024 lanes, fixed order.  A lane takes every 1024th row and keeps
+// eight rows (8*G independent loads) in flight: the tensor is tiny (B*N*G floats), the kernel is a chain of load
+// latencies -- with one dependent load at a time it took 44 us at B*N = 18432, more than a third of the data pass.
+template <int G>
+__global__ __launch_bounds__(1024) void oda_dbias_kernel(const float* __restrict__ dS, float* __restrict__ d_bias, int rows) {
+  __shared__ float part[16][G];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float acc[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) acc[g] = 0.f;
+  for (int r0 = tid; r0 < rows; r0 += 8 * 1024) {
+    float v[8][G];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int r = min(r0 + 1024 * k, rows - 1);
+#pragma unroll
+      for (int g = 0; g < G; ++g) v[k][g] = dS[(size_t)r * G + g];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (r0 + 1024 * k < rows) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g] += v[k][g];
+      }
+  }
+#pragma unroll
   for (int g = 0; g < G; ++g) {
-    float a = 0.f;
-    for (int r = tid; r < rows; r += 256) a += dS[(size_t)r * G + g];
-    a = wave_sum(a);
-    if (lane == 0) part[wave * kOdaMaxG + g] = a;
+    const float a = wave_sum(acc[g]);
+    if (lane == 0) part[wave][g] = a;
   }
   __syncthreads();
-  if (tid < G) d_bias[tid] = part[tid] + part[kOdaMaxG + tid] + part[2 * kOdaMaxG + tid] + part[3 * kOdaMaxG + tid];
+  if (tid < G) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += part[w][tid];
+    d_bias[tid] = t;
+  }
 }
 
 // mask[b][i][j*L+d] = keep/(1-p) exactly as the fused kernels draw it (test / debugging aid)
@@ -303,7 +327,7 @@ static int launch_bwd(const float* vl, const float* ql, const float* w, const fl
     const size_t n = (size_t)G * N * L;
     hipLaunchKernelGGL(oda_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slab, d_w, n, SG);
   }
-  hipLaunchKernelGGL(oda_dbias_kernel, dim3(1), dim3(256), 0, s, dS, d_bias, B * N, G);
+  hipLaunchKernelGGL(oda_dbias_kernel<G>, dim3(1), dim3(1024), 0, s, dS, d_bias, B * N);
   return check_launch("object_difference_attention_bwd");
 }
 
