@@ -219,14 +219,28 @@ __global__ void oda_bwd_weight_kernel(const float* __restrict__ vl, const float*
       for (int g = 0; g < G; ++g) slab[(((size_t)sg * G + g) * N + j0 + jc) * L + d] = dw[jc][g];
 }
 
-// d_w[e] = sum_sg slab[sg][e]  (fixed order), e over G*N*L
+// d_w[e] = sum_sg slab[sg][e]  (fixed order), e over G*N*L.  256 lanes = 64 elements x 4 quarters of the slab list, eight
+// loads in flight per lane, the quarters added in order through LDS (one lane walking all 128 slabs with one load in
+// flight took 32 us for 23 MB).
 __global__ __launch_bounds__(256) void oda_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                          size_t n, int S) {
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n) return;
+  __shared__ float part[3][64];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const size_t e = (size_t)blockIdx.x * 64 + c;
+  const size_t ec = e < n ? e : n - 1;
+  const int per = (S + 3) / 4, s_lo = q * per, s_hi = min(S, s_lo + per);
   float a = 0.f;
-  for (int s = 0; s < S; ++s) a += slab[(size_t)s * n + e];
-  out[e] = a;
+  for (int s0 = s_lo; s0 < s_hi; s0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = slab[(size_t)min(s0 + k, S - 1) * n + ec];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (s0 + k < s_hi) a += v[k];
+  }
+  if (q > 0) part[q - 1][c] = a;
+  __syncthreads();
+  if (q == 0 && e < n) out[e] = ((a + part[0][c]) + part[1][c]) + part[2][c];
 }
 
 // d_bias[g] = sum_{b,i} dS[b,i,g]; one workgroup of 1024 lanes, fixed order.  A lane takes every 1024th row and keeps
@@ -325,7 +339,7 @@ static int launch_bwd(const float* vl, const float* ql, const float* w, const fl
     else
       hipLaunchKernelGGL((oda_bwd_weight_kernel<G, false>), grid, dim3(nt), lds, s, vl, ql, dS, slab, dc, B, N, L, spg);
     const size_t n = (size_t)G * N * L;
-    hipLaunchKernelGGL(oda_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slab, d_w, n, SG);
+    hipLaunchKernelGGL(oda_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, slab, d_w, n, SG);
   }
   hipLaunchKernelGGL(oda_dbias_kernel<G>, dim3(1), dim3(1024), 0, s, dS, d_bias, B * N);
   return check_launch("object_difference_attention_bwd");
