@@ -27,6 +27,7 @@ run bench_f32_n100_b128 --regions 100 --batch 128 --steps 20 --warmup 5 --no-cpu
 run bench_bf16_n100_b128 --dtype bf16 --regions 100 --batch 128 --steps 20 --warmup 5 --no-cpu-baseline
 run bench_b512_encoder --encoder --steps 10 --warmup 5 --no-cpu-baseline
 run bench_oda_b512 --model oda --steps 20 --warmup 5 --no-cpu-baseline
+run bench_oda_attention_b512 --model oda-attention --steps 20 --warmup 5
 VQA_K4_FORM=engine run bench_b512_k4_engine --steps 20 --warmup 5 --no-cpu-baseline
 
 # 3. rocprofv3 kernel traces of the same commands (graph replay and kernel by kernel)
