@@ -376,6 +376,23 @@ def pack_bf16(src, dst, batch_stride, row_stride, col_stride, zero_fill=True, of
     return dst
 
 
+_shadows = {}
+
+
+def _shadow(master, shape, tag):
+    """Persistent zero-initialised bf16 buffer for the padded (or transposed) shadow of an fp32 master weight.  The pads
+    never change, so they are zeroed ONCE; every step only repacks the interior (pack_bf16 with zero_fill=False) -- instead
+    of an allocation, a zero-fill kernel and a pack kernel per weight and step.  Keyed by the master's address: parameters
+    keep theirs (views of the trainer's flat buffer), and a stale entry only ever has its interior overwritten."""
+    key = (master.data_ptr(), tuple(shape), tag, master.device.index)
+    buf = _shadows.get(key)
+    if buf is None:
+        if len(_shadows) > 256:
+            _shadows.clear()
+        buf = _shadows[key] = torch.zeros(shape, device=master.device, dtype=torch.bfloat16)
+    return buf
+
+
 class PackedWeightBf16(torch.autograd.Function):
     """w fp32 [rows, cols] -> bf16 [rows_p, cols_p] zero-padded shadow (the operand layout of the bf16 GEMMs);
     backward crops the gradient back to the master shape in fp32."""
@@ -387,7 +404,7 @@ class PackedWeightBf16(torch.autograd.Function):
         if rows_p < rows or cols_p < cols:
             raise ValueError("PackedWeightBf16: padded shape (%d,%d) smaller than %s" % (rows_p, cols_p, tuple(w.shape)))
         ctx.shape = (rows, cols)
-        return pack_bf16(w, torch.empty(rows_p, cols_p, device=w.device, dtype=torch.bfloat16), 0, cols_p, 1)
+        return pack_bf16(w, _shadow(w, (rows_p, cols_p), "p"), 0, cols_p, 1, zero_fill=False)
 
     @staticmethod
     def backward(ctx, g):
@@ -443,7 +460,7 @@ class LinearBf16(torch.autograd.Function):
                              % (Kp, in_f, BF16_PAD))
         Np = pad_to(out_f)
         dev = x.device
-        wp = pack_bf16(w, torch.empty(Np, Kp, device=dev, dtype=torch.bfloat16), 0, Kp, 1)
+        wp = pack_bf16(w, _shadow(w, (Np, Kp), "nk"), 0, Kp, 1, zero_fill=False)
         bp = None
         if bias is not None:
             bp = torch.zeros(Np, device=dev, dtype=torch.float32)
@@ -466,7 +483,7 @@ class LinearBf16(torch.autograd.Function):
         gz = gz.contiguous()
         d_x = None
         if ctx.needs_input_grad[0]:
-            wpt = pack_bf16(w, torch.empty(Kp, Np, device=x2.device, dtype=torch.bfloat16), 0, 1, Np)   # [Kp, Np] = W^T
+            wpt = pack_bf16(w, _shadow(w, (Kp, Np), "kn"), 0, 1, Np, zero_fill=False)   # [Kp, Np] = W^T
             d_x = gemm_bf16_nt(gz, wpt).view(*gy.shape[:-1], Kp)
         d_w = gemm_bf16_tn(gz, x2)[:out_f, :in_f]
         d_b = column_sum(gz)[:out_f] if has_bias else None
@@ -501,13 +518,13 @@ class LowRankBilinearFusionBf16(torch.autograd.Function):
         if h2.shape != (B, R, H):
             raise ValueError("h2 must be [B,R,H] = %s, got %s" % ((B, R, H), tuple(h2.shape)))
         dev = x.device
-        w1p = torch.empty(R, Hp, Lp, device=dev, dtype=torch.bfloat16)
+        w1p = _shadow(w1[0], (R, Hp, Lp), "k4")
         b1p = torch.zeros(R, Hp, device=dev, dtype=torch.float32)
         for r in range(R):
             if w1[r].shape != (H, L) or b1[r].shape != (H,):
                 raise ValueError("rank %d: weight %s / bias %s do not match (H=%d, L=%d)"
                                  % (r, tuple(w1[r].shape), tuple(b1[r].shape), H, L))
-            pack_bf16(w1[r], w1p, 0, Lp, 1, zero_fill=(r == 0), offset=r * Hp * Lp)
+            pack_bf16(w1[r], w1p, 0, Lp, 1, zero_fill=False, offset=r * Hp * Lp)
             b1p[r, :H] = b1[r]
         h2p = torch.nn.functional.pad(h2, (0, Hp - H)) if Hp != H else h2
         need_bwd = any(ctx.needs_input_grad)
@@ -531,9 +548,9 @@ class LowRankBilinearFusionBf16(torch.autograd.Function):
         w1t = None
         d_x = None
         if ctx.needs_input_grad[0]:
-            w1t = torch.empty(Lp, R * Hp, device=dev, dtype=torch.bfloat16)   # w1t[l, r*Hp+h] = w1[r][h,l]
-            for r in range(R):   # rank r fills columns r*Hp .. r*Hp+H of every row; the first call zeroes the pads
-                pack_bf16(w1[r], w1t, 0, 1, R * Hp, zero_fill=(r == 0), offset=r * Hp)
+            w1t = _shadow(w1[0], (Lp, R * Hp), "k4t")   # w1t[l, r*Hp+h] = w1[r][h,l]; pads zeroed once
+            for r in range(R):   # rank r fills columns r*Hp .. r*Hp+H of every row
+                pack_bf16(w1[r], w1t, 0, 1, R * Hp, zero_fill=False, offset=r * Hp)
             d_x = torch.empty_like(x)
         d_w1 = torch.empty(R, Hp, Lp, device=dev, dtype=torch.float32)
         d_b1 = torch.empty(R, Hp, device=dev, dtype=torch.float32)
