@@ -546,3 +546,27 @@ def test_late_parameters_cover_exactly_the_second_step():
     assert torch.isnan(tr.flat.g[used & ~head]).all()              # ... and nothing else has been touched yet
     tr._front_b()
     assert torch.isfinite(tr.flat.g[used]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_half_backward_oda(graph):
+    """The same for ODA: the cut is behind the attention (fusion_final + classifier are the late bucket)."""
+    from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
+    data = [tuple(torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(40, answers=300, seed=90 + i)) for i in range(6)]
+    out = {}
+    for overlap in (False, "force"):
+        model = build("oda", 300)
+        tr = DataParallelTrainer(model, lr=2e-5, clip=0.25, graph=graph, overlap=overlap)
+        assert tr.overlap == bool(overlap)
+        traj = []
+        for v, q, a in data:
+            loss, norm = tr.step({"v": v, "q_idxes": q}, a)
+            traj.append((loss.item(), norm.item()))
+        if graph:
+            assert tr._graph is not None, "step was not captured"
+        out[overlap] = (traj, [p.detach().clone() for p in model.parameters()])
+    for (l0, n0), (l1, n1) in zip(out[False][0], out["force"][0]):
+        assert abs(l0 - l1) <= 1e-4 * abs(l0) and abs(n0 - n1) <= 1e-4 * max(abs(n0), 1e-6), (out[False][0], out["force"][0])
+    for p0, p1 in zip(out[False][1], out["force"][1]):
+        assert (p0 - p1).abs().max().item() <= 2e-3 * max(p0.abs().max().item(), 1e-3)

@@ -45,7 +45,18 @@ class Model(nn.Module):
         w = conv.conv.weight.view(conv.out_channels, -1)
         return ops.object_difference_attention(v_feature_low, q_feature_low, w, conv.conv.bias, p, seed)
 
-    def forward(self, sample):
+    def late_parameters(self):
+        """Parameters behind the attention (fusion_final, the classifier: 3.9 M of the 7.3 M): their gradients are complete
+        before backward enters the attention and the region projection (see cor2.CoR2Model.late_parameters)."""
+        return [p for m in (self.fusion_final, self.linear_classif) for p in m.parameters()]
+
+    def forward_with_cut(self, sample):
+        """-> (logits, outs, ins) as cor2.CoR2Model.forward_with_cut: the cut is (attended features, q_final)."""
+        cut = []
+        logits = self(sample, cut)
+        return logits, cut[0], cut[1]
+
+    def forward(self, sample, _cut=None):
         v = sample["v"]
         b = v.size(0)
         v_feature = v.contiguous().view(b, -1, 2048)
@@ -62,5 +73,10 @@ class Model(nn.Module):
 
         self.alpha_dict = {"alphas": alphas[0].detach()}
 
+        if _cut is not None:
+            outs = [v_final, q_final]
+            ins = [t.detach().requires_grad_(t.requires_grad) for t in outs]
+            _cut.extend([outs, ins])
+            v_final, q_final = ins
         x = self.fusion_final(v_final, q_final)
         return self.linear_classif(x)
