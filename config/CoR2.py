@@ -6,7 +6,7 @@
 """
 import os
 
-from vqa_playground_pytorch_amd.cor2 import Model  # noqa: F401
+from vqa_playground_pytorch_amd import cor2 as _impl
 from vqa_playground_pytorch_amd.encoder import BayesianGRU, SkipThoughts  # noqa: F401
 from vqa_playground_pytorch_amd.layers import (MutanFusion, MyATT, MyConv1d, MyLinear,  # noqa: F401
                                                bmatmul, bmul)
@@ -54,3 +54,16 @@ if splitnum == 2:
     method_name += "_VAL"
 log_dir = os.path.join(log_dir, method_name)
 analyze_dir = os.path.join(analyze_dir, method_name)
+
+# Question encoder of the two-argument constructor ``Model(vocab_words, num_ans)`` (train.py:515):
+#   "skipthoughts" -- what the reference builds (config/CoR2.py:166): embedding(620) + BayesianGRU(2400) over int64 token ids
+#                     [B,26]; randomly initialised here (the uni-skip weight files are downloaded by the reference and
+#                     are not available offline: load them with model.seq2vec.load_pretrained(...) or a checkpoint);
+#   "vector"       -- no encoder: sample['q_idxes'] already holds the 2400-d question vector (benchmarks, BASELINE.json).
+# Either way a floating [B,2400] 'q_idxes' is taken as the question vector itself.
+question_encoder = os.environ.get("VQA_SEQ2VEC", "skipthoughts")
+
+
+class Model(_impl.Model):
+    def __init__(self, vocab_words=None, num_ans=None, seq2vec=None, **kwargs):
+        super().__init__(vocab_words, num_ans, seq2vec=question_encoder if seq2vec is None else seq2vec, **kwargs)

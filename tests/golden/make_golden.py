@@ -9,6 +9,7 @@ from ``oracle.seeded`` and records OUTPUTS only (inputs/params are regenerated
 from seeds by the tests).  Nothing of the reference's source text is stored.
 
     python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+    python tests/golden/make_golden.py --out /tmp/g --only blocks,encoder   # elsewhere / a subset
 """
 import contextlib
 import importlib
@@ -28,8 +29,21 @@ from oracle import seeded  # noqa: E402
 REF = "/root/reference"
 
 
+def _load_by_path(name, path):
+    """Import one of the reference's files under a private module name.  The repo has its own ``config`` package (the
+    drop-in modules), so ``import config.CoR2`` would resolve to the REPO's model; the reference's files are therefore
+    loaded by path (their own ``from putils import *`` still resolves through sys.path to /root/reference/putils)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def import_reference():
-    sys.path.insert(0, REF)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
     sys.dont_write_bytecode = True
     for m in ["deepdish", "h5py", "nltk", "nltk.corpus", "nltk.parse", "nltk.parse.stanford", "yagmail",
               "munch", "configobj", "passlib", "passlib.hash", "tables", "torchvision",
@@ -39,9 +53,11 @@ def import_reference():
         except Exception:
             sys.modules[m] = mock.MagicMock(name=m)
     with contextlib.redirect_stdout(io.StringIO()):
-        cor = importlib.import_module("config.CoR2")
-        oda = importlib.import_module("config.ODA")
+        cor = _load_by_path("_reference_config_CoR2", os.path.join(REF, "config", "CoR2.py"))
+        oda = _load_by_path("_reference_config_ODA", os.path.join(REF, "config", "ODA.py"))
         putils = importlib.import_module("putils")
+    assert os.path.realpath(putils.__file__).startswith(REF), putils.__file__
+    assert os.path.realpath(cor.__file__).startswith(REF) and os.path.realpath(oda.__file__).startswith(REF)
 
     class Identity(torch.nn.Module):
         def __init__(self, *a, **k):
@@ -75,7 +91,7 @@ def kld_sum(logits, target):
     return torch.nn.KLDivLoss(reduction="sum")(torch.nn.functional.log_softmax(logits, dim=1), target)
 
 
-def blocks(cor, oda, putils):
+def blocks(cor, oda, putils, out_dir=HERE):
     out = {}
     x1 = t(seeded.seeded_array((3, 5, 8), 11))
     x2 = t(seeded.seeded_array((3, 8), 12))
@@ -151,11 +167,11 @@ def blocks(cor, oda, putils):
     out["decare.q1"] = h.expand_q_1(h.compress_q_1(qq)).detach().numpy()
     out["decare.q2"] = h.expand_q_2(h.compress_q_2(qq)).detach().numpy()
     out["decare.v2"] = (al.contiguous().view(3, 5, 1, 1) * cat).sum(1).detach().numpy()
-    np.savez_compressed(os.path.join(HERE, "blocks.npz"), **out)
+    np.savez_compressed(os.path.join(out_dir, "blocks.npz"), **out)
     print("blocks.npz:", len(out), "arrays")
 
 
-def full_model(mod, name, nans, seed_w, seed_in, feature_key):
+def full_model(mod, name, nans, seed_w, seed_in, feature_key, out_dir=HERE):
     model = seeded.load_state(mod.Model(["PAD", "UNK"], nans), seed_w).eval()  # eval: dropout off, grads on
     v, q, a = seeded.seeded_inputs(4, answers=nans, seed=seed_in)
     vt, qt, at = t(v), t(q).requires_grad_(), t(a)
@@ -221,12 +237,12 @@ def full_model(mod, name, nans, seed_w, seed_in, feature_key):
         w = p.detach().numpy().astype(np.float64)
         out["train3.w." + pname + ".sum"] = np.float64(w.sum())
         out["train3.w." + pname + ".norm"] = np.float64(np.sqrt((w ** 2).sum()))
-    np.savez_compressed(os.path.join(HERE, name + "_b4.npz"), **out)
-    size = os.path.getsize(os.path.join(HERE, name + "_b4.npz"))
+    np.savez_compressed(os.path.join(out_dir, name + "_b4.npz"), **out)
+    size = os.path.getsize(os.path.join(out_dir, name + "_b4.npz"))
     print(name + "_b4.npz:", len(out), "arrays,", size // 1024, "KiB, loss", out["loss"])
 
 
-def encoder(putils):
+def encoder(putils, out_dir=HERE):
     """BayesianGRU(620, 2400, af='relu') + padded embedding, the pieces SkipThoughts assembles (its constructor
     downloads weight files, so the pieces are built directly): eval-mode outputs + one gradient digest."""
     out = {}
@@ -247,18 +263,29 @@ def encoder(putils):
     out["g.embedding"] = emb.weight.grad.numpy()
     out["g.weight_hn.norm"] = np.float64(gru.gru_cell.weight_hn.weight.grad.double().norm().item())
     out["g.weight_ir.bias"] = gru.gru_cell.weight_ir.bias.grad.numpy()
-    np.savez_compressed(os.path.join(HERE, "encoder.npz"), **out)
+    np.savez_compressed(os.path.join(out_dir, "encoder.npz"), **out)
     print("encoder.npz:", len(out), "arrays")
 
 
-def main():
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=HERE, help="directory the .npz files are written to (default: this directory)")
+    ap.add_argument("--only", default="", help="comma list out of blocks,encoder,cor2,oda (default: all)")
+    args = ap.parse_args(argv)
+    only = set(filter(None, args.only.split(",")))
+    os.makedirs(args.out, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     cor, oda, putils = import_reference()
-    blocks(cor, oda, putils)
-    encoder(putils)
-    full_model(cor, "cor2", 2000, seed_w=0, seed_in=1, feature_key="feature")
-    full_model(oda, "oda", 3000, seed_w=0, seed_in=1, feature_key=None)
+    if not only or "blocks" in only:
+        blocks(cor, oda, putils, args.out)
+    if not only or "encoder" in only:
+        encoder(putils, args.out)
+    if not only or "cor2" in only:
+        full_model(cor, "cor2", 2000, seed_w=0, seed_in=1, feature_key="feature", out_dir=args.out)
+    if not only or "oda" in only:
+        full_model(oda, "oda", 3000, seed_w=0, seed_in=1, feature_key=None, out_dir=args.out)
 
 
 if __name__ == "__main__":

@@ -260,3 +260,22 @@ def test_b1_works():
     model = seeded.load_state(RF.CoR2Oracle(50, feat=32, qdim=24, low=10, hidden=12, glimpses=2, att_dim=8), 3).eval()
     v, q, _ = seeded.seeded_inputs(1, regions=5, feat=32, qdim=24, answers=50, seed=4)
     assert model({"v": t(v), "q": t(q)}).shape == (1, 50)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference only exists in the authoring container")
+def test_golden_recipe_regenerates_committed_fixtures(golden_dir, tmp_path):
+    """tests/golden/make_golden.py -- the committed recipe -- still runs next to the repo's own ``config`` package (it
+    loads the reference's config/CoR2.py / config/ODA.py BY PATH) and reproduces the committed building-block and
+    encoder fixtures bit for bit.  Runs in a child process: the recipe mocks third-party modules in sys.modules."""
+    import subprocess
+    import sys
+    out = str(tmp_path)
+    script = os.path.join(golden_dir, "make_golden.py")
+    r = subprocess.run([sys.executable, script, "--out", out, "--only", "blocks,encoder"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for name in ("blocks.npz", "encoder.npz"):
+        new, old = np.load(os.path.join(out, name)), np.load(os.path.join(golden_dir, name))
+        assert sorted(new.files) == sorted(old.files)
+        for k in new.files:
+            assert np.array_equal(new[k], old[k]), (name, k)

@@ -12,6 +12,7 @@
 //   backward: gz = gy * act'(y);  dW = gz^T drop(x)  (split over M, slabs reduced in fixed order; db = colsum gz)
 //             dx = (gz W) * dropmask                           2*M*K*N FLOP each
 #include "gemm_f32_mfma.hpp"
+#include "gemm_f32_rt.hpp"
 
 namespace vqa {
 
@@ -247,6 +248,43 @@ static TileChoice linear_dw_tile() {
   return t;
 }
 
+// ---- register-tile engine (gemm_f32_rt.hpp): the default for the tall region projections ----
+struct EpiBiasAct {
+  float* y;
+  const float* bias;
+  int ldy, act;
+  float scale;
+  __device__ __forceinline__ void operator()(int row, int col, float v) const {
+    v += bias != nullptr ? bias[col] : 0.f;
+    if (act == 1) v = fmaxf(v, 0.f);
+    y[(size_t)row * ldy + col] = v;
+  }
+};
+
+// "0" = never, "1" (default) = where it applies (tall matrices with 4-element-aligned rows; everything else stays on
+// the 64 x 64 LDS-tile engine above)
+static bool rt_enabled() {
+  const char* e = std::getenv("VQA_RT_ENGINE");
+  return e == nullptr || e[0] != '0';
+}
+static bool rt_fwd_ok(int M, int K, int N, int ldx) {
+  return rt_enabled() && M >= 1152 && K >= 64 && K % 4 == 0 && ldx % 4 == 0 && (size_t)M * ldx * 4 < (1ull << 32) &&
+         (size_t)N * K * 4 < (1ull << 32);
+}
+static int rt_dw_splits(int M) {
+  int s = 16;   // 4 n1 tiles x 16 n2 tiles x 16 row splits = 1024 waves for 310 x 2048 (one per SIMD)
+  if (const char* e = std::getenv("VQA_RT_DW_SPLITS")) s = std::atoi(e);
+  const int max_by_rows = M / 64 > 0 ? M / 64 : 1;
+  if (s > max_by_rows) s = max_by_rows;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  return s;
+}
+static bool rt_dw_ok(int M, int K, int N, int ldx) {
+  return rt_enabled() && M >= 4096 && K % 4 == 0 && ldx % 4 == 0 && (size_t)M * ldx * 4 < (1ull << 32) &&
+         (size_t)M * N * 4 < (1ull << 32);
+}
+
 }  // namespace vqa
 
 using namespace vqa;
@@ -271,6 +309,23 @@ extern "C" int vqa_linear_act_fwd(const float* x, int ldx, const float* w, const
   VQA_REQUIRE(aligned(w, 8) && aligned(y, 8), VQA_E_UNSUPPORTED, "linear_act_fwd: w/y must be 8-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
+  if (rt_fwd_ok(M, K, N, ldx)) {
+    // 144 x 160 workgroup tiles, each wave 9 x 5 accumulator blocks over half of K (M = 18432, N = 310: 256 workgroups)
+    using S = rt::NtShape<9, 5, 1, 2, 2>;
+    const int tiles_m = (M + S::BM - 1) / S::BM, tiles_n = (N + S::BN - 1) / S::BN;
+    const rt::NtArgs a{x, w, ldx, K, M, N, K, tiles_n, nullptr};
+    const EpiBiasAct epi{y, bias, N, act, 1.f};
+    if (dc.p8 > 0) {
+      VQA_ENSURE_LDS((rt::gemm_nt_kernel<9, 5, 1, 2, 2, true, EpiBiasAct>), S::kLdsBytes);
+      hipLaunchKernelGGL((rt::gemm_nt_kernel<9, 5, 1, 2, 2, true, EpiBiasAct>), dim3(tiles_m * tiles_n), dim3(rt::kThreads),
+                         S::kLdsBytes, s, a, dc, epi);
+    } else {
+      VQA_ENSURE_LDS((rt::gemm_nt_kernel<9, 5, 1, 2, 2, false, EpiBiasAct>), S::kLdsBytes);
+      hipLaunchKernelGGL((rt::gemm_nt_kernel<9, 5, 1, 2, 2, false, EpiBiasAct>), dim3(tiles_m * tiles_n), dim3(rt::kThreads),
+                         S::kLdsBytes, s, a, dc, epi);
+    }
+    return check_launch("linear_act_fwd");
+  }
   const TileChoice t = tile_override_or(choose_tile(M, N, 1));
   const int tiles_m = (M + t.bm - 1) / t.bm, tiles_n = (N + t.bn - 1) / t.bn;
 #define LAUNCH(BM_, BN_, PF_)                                                                                           \
@@ -293,7 +348,8 @@ extern "C" int vqa_linear_act_fwd(const float* x, int ldx, const float* w, const
 
 extern "C" size_t vqa_linear_act_bwd_workspace_bytes(int M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 0;
-  const int S = splits_for_linear_dw(M, K, N, linear_dw_tile());
+  int S = splits_for_linear_dw(M, K, N, linear_dw_tile());
+  if (rt_enabled() && M >= 4096 && rt_dw_splits(M) > S) S = rt_dw_splits(M);   // either engine fits
   return ((size_t)S * N * K + (size_t)S * N) * sizeof(float);
 }
 
@@ -329,7 +385,29 @@ extern "C" int vqa_linear_act_bwd(const float* x, int ldx, const float* w, const
     VQA_TILE_SWITCH(t, LAUNCH);
 #undef LAUNCH
   }
-  {
+  if (rt_dw_ok(M, K, N, ldx)) {
+    // register-tile TN form: workgroup = 4 waves x (80 rows of d_w) x 128 columns x one row split; the relu gate (y > 0)
+    // and the dropout mask of x are applied to the operands in registers
+    const int S = rt_dw_splits(M);
+    float* slab = static_cast<float*>(workspace);
+    float* dbslab = slab + (size_t)S * N * K;
+    int rows_per_split = (M + S - 1) / S;
+    rows_per_split = (rows_per_split + 15) / 16 * 16;
+    const rt::TnArgs a{gy, act == 1 ? y : nullptr, x, slab, dbslab, N, ldx, M, N, K, (N + 319) / 320, (K + 127) / 128,
+                       rows_per_split};
+    const dim3 grid(a.tiles1 * a.tiles2 * S);
+    const bool gate = act == 1, drop = dc.p8 > 0;
+    if (gate && drop)
+      hipLaunchKernelGGL((rt::gemm_tn_kernel<5, 2, true, true>), grid, dim3(rt::kThreads), 0, s, a, dc);
+    else if (gate)
+      hipLaunchKernelGGL((rt::gemm_tn_kernel<5, 2, true, false>), grid, dim3(rt::kThreads), 0, s, a, dc);
+    else if (drop)
+      hipLaunchKernelGGL((rt::gemm_tn_kernel<5, 2, false, true>), grid, dim3(rt::kThreads), 0, s, a, dc);
+    else
+      hipLaunchKernelGGL((rt::gemm_tn_kernel<5, 2, false, false>), grid, dim3(rt::kThreads), 0, s, a, dc);
+    const int NK = N * K;
+    hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3((NK / 2 + 255) / 256), dim3(256), 0, s, slab, dbslab, d_w, d_b, NK, N, S);
+  } else {
     const TileChoice t = linear_dw_tile();
     const int S = splits_for_linear_dw(M, K, N, t);
     float* slab = static_cast<float*>(workspace);

@@ -205,9 +205,15 @@ class MyConv1d(nn.Module):
             return self._linear_bf16(x, None)
         return ops.linear(x, self.conv.weight.squeeze(-1), self.conv.bias)
 
-    # K5 (fused dropout+GEMM+bias+relu on the hand-written fp32 MFMA engine) vs the library GEMM: set per process
-    # with VQA_FUSED_LINEAR=0/1; the default is whichever measured faster in situ (see profiles/README.md)
-    fused = os.environ.get("VQA_FUSED_LINEAR", "0") == "1"
+    # K5 (fused dropout+GEMM+bias+relu on the hand-written fp32 MFMA engines) vs the library GEMM + a separate dropout
+    # pass: set per process with VQA_FUSED_LINEAR=0/1.  Default: fused -- since the register-tile engine
+    # (csrc/gemm_f32_rt.hpp) the forward beats the library GEMM at these shapes and no dropout pass over
+    # [B,36,2048] exists any more (see profiles/README.md)
+    fused = os.environ.get("VQA_FUSED_LINEAR", "1") == "1"
+
+    def _fused_ok(self, x):
+        return self.fused and self.af in (None, "relu") and x.dim() == 3 and x.is_cuda and x.dtype == torch.float32 \
+            and self.out_channels >= 32 and x.size(0) * x.size(1) >= 1024
 
     def forward(self, x, predropped=False):
         """predropped=True: the producer of x has already applied this layer's input dropout (ops.relation_apply)."""
@@ -217,6 +223,8 @@ class MyConv1d(nn.Module):
                                  % (self.in_channels, self.out_channels, self.kernel_size, self.stride, x.dim()))
             if x.dtype == torch.bfloat16:
                 return self._linear_bf16(x, self.af)
+            if self._fused_ok(x):
+                return ops.linear_act(x, self.conv.weight.squeeze(-1), self.conv.bias, self.af, 0.0, 0)
             return self._linear_f32(x)
         if x.dtype == torch.bfloat16 and self.af in (None, "relu"):
             if x.dim() != 3:
@@ -225,8 +233,7 @@ class MyConv1d(nn.Module):
             if self.p:
                 x = F.dropout(x, p=self.p, training=self.training)
             return self._linear_bf16(x, self.af)
-        if self.fused and self.af in (None, "relu") and x.dim() == 3 and x.is_cuda and self.out_channels >= 32 \
-                and x.size(0) * x.size(1) >= 1024:
+        if self._fused_ok(x):
             # large region-side projection (compress_v / compress_v2): dropout + GEMM + bias + relu in ONE kernel
             # on the fp32 MFMA tile engine (K5); the dropout mask is a counter hash keyed by a seed drawn from
             # torch's CPU generator, so torch.manual_seed governs it and no mask tensor exists
@@ -357,3 +364,12 @@ class QuestionVectorInput(nn.Module):
             raise ValueError("seq2vec slot holds no encoder: pass the %d-d question vector as sample['q_idxes'] "
                              "(or construct the Model with seq2vec=<your encoder>)" % self.dim)
         return q
+
+
+def question_feature(seq2vec, q):
+    """What ``Model.forward`` feeds the head: ``seq2vec(q_idxes)`` for int64 token ids [B,T] as the reference does
+    (config/CoR2.py:205, fed by datasets.py:928-969), and -- north_star's "(region-feature, question-embedding)"
+    interface -- a floating [B,2400] tensor taken as the question vector itself, whatever the slot holds."""
+    if torch.is_floating_point(q) and q.dim() == 2 and q.size(-1) == 2400:
+        return q
+    return seq2vec(q)

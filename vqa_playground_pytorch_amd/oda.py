@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .layers import MutanFusion, MyATT, MyConv1d, MyLinear, QuestionVectorInput, linear_stack_groups, my_linears
+from .layers import MutanFusion, MyATT, MyConv1d, MyLinear, QuestionVectorInput, linear_stack_groups, my_linears, question_feature
 
 
 class Model(nn.Module):
@@ -21,6 +21,8 @@ class Model(nn.Module):
         if seq2vec == "skipthoughts":      # the reference's encoder (config/CoR2.py:166), randomly initialised here
             from .encoder import SkipThoughts
             seq2vec = SkipThoughts(vocab_list=vocab_words, gru="BayesianGRU", return_last=True, af="relu")
+        if seq2vec == "vector":             # explicit pass-through slot: sample['q_idxes'] holds the 2400-d question vector
+            seq2vec = None
         self.seq2vec = seq2vec if seq2vec is not None else QuestionVectorInput(2400)
         self.compress_v = MyConv1d(2048, 310, 1, 1, p=0.5, af="relu")
         self.compress_q = MyLinear(2400, 310, p=0.5, af="relu")
@@ -62,7 +64,7 @@ class Model(nn.Module):
         v_feature = v.contiguous().view(b, -1, 2048)
         if v_feature.size(1) != self.regions:
             raise ValueError("ODA.Model was built for %d regions, input has %d" % (self.regions, v_feature.size(1)))
-        q_feature = self.seq2vec(sample["q_idxes"] if "q_idxes" in sample else sample["q"])
+        q_feature = question_feature(self.seq2vec, sample["q_idxes"] if "q_idxes" in sample else sample["q"])
 
         v_feature_low = self.compress_v(v_feature)
         # the two MyLinear(2400 -> 310) on the question vector (config/ODA.py:185,193 applied at :207,:233): one batched GEMM

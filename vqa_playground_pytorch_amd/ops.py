@@ -629,16 +629,30 @@ class LinearAct(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         M, K, N, act, p_drop, seed, has_bias = ctx.cfg
         gy = _prep("grad_y", gy)
-        d_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        d_x = None
+        if ctx.needs_input_grad[0] and p_drop == 0 and M >= 4096 and LinearAct.library_dgrad:
+            # tall data gradient without a dropout mask (compress_v2 behind the relation kernel): the gated gradient is
+            # materialised once, the data gradient is a plain library GEMM on it (at [18432,310] x [310,2048] it and the
+            # register-tile engine tie: tools/rt_probe.hip), and the weight gradient below runs ungated on the same tensor
+            if act == 1:
+                gy = torch.ops.aten.threshold_backward(gy, y, 0)
+                act = 0
+            d_x = (gy.reshape(M, N) @ w).view(x.shape)
+        elif ctx.needs_input_grad[0]:
+            d_x = torch.empty_like(x)
+        in_kernel_dx = d_x is not None and not (p_drop == 0 and M >= 4096 and LinearAct.library_dgrad)
         d_w = torch.empty_like(w)
         d_b = torch.empty(N, device=x.device, dtype=torch.float32) if has_bias else None
         L_ = _lib.lib()
         ws_bytes = L_.vqa_linear_act_bwd_workspace_bytes(M, K, N)
         ws = torch.empty((ws_bytes + 3) // 4, device=x.device, dtype=torch.float32)
         sv, sp = _seed_args(seed)
-        _launch("linear_act_bwd", (M, K, N, p_drop > 0, d_x is not None), L_.vqa_linear_act_bwd,
-                _p(x), K, _p(w), _p(y), _p(gy), _p(d_x), _p(d_w), _p(d_b), _p(ws), ws_bytes, M, K, N, act, p_drop, sv, sp)
+        _launch("linear_act_bwd", (M, K, N, p_drop > 0, in_kernel_dx), L_.vqa_linear_act_bwd,
+                _p(x), K, _p(w), _p(y), _p(gy), _p(d_x) if in_kernel_dx else None, _p(d_w), _p(d_b), _p(ws), ws_bytes,
+                M, K, N, act, p_drop, sv, sp)
         return d_x, d_w, d_b, None, None, None
+
+    library_dgrad = os.environ.get("VQA_LIBRARY_DGRAD", "1") == "1"
 
 
 def linear_act(x, w, bias=None, act=None, p_drop=0.0, seed=0):
