@@ -8,10 +8,11 @@ fp32, dropout active -- BASELINE.json configs[1] (N=1) / configs[3] (N=8, global
         --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 5
 
 Rank 0 prints ONE JSON line.  Inputs are synthetic and resident in HBM before the timed region.  The
-`roofline` object is for the dominant hand-written kernel (K4 forward, the fp32-MFMA low-rank bilinear
-fusion at M = 512*36 rows), timed live with HIP events on the launch stream inside the timed steps;
-`roofline_all` lists every hand-written kernel the step launches.  `cpu_baseline` times the oracle's
-reference-faithful torch-CPU port (oracle/reference_faithful.py) on a bounded sample on the host cores.
+`roofline` object is for the hand-written kernel with the largest share of the step (mean duration x
+launches), timed live with HIP events on the launch stream; `roofline_all` lists EVERY timed op of the
+step -- all C-ABI launches and the library GEMMs -- with its model, and `step_coverage` says how much of
+ms_per_step they add up to.  `cpu_baseline` times the oracle's reference-faithful torch-CPU port
+(oracle/reference_faithful.py) on a bounded sample on the host cores.
 """
 import argparse
 import json
@@ -31,102 +32,186 @@ MFMA_F32_PEAK_TF = 157.3   # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
 MFMA_BF16_PEAK_TF = 2500.0 # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16), no sparsity
 
 BATCH, REGIONS, FEAT, QDIM, ANSWERS = 512, 36, 2048, 2400, 2000
+ROTATE = 4                 # resident batches of the `rotating_inputs` pass (4 x 151 MB > the 256 MB Infinity Cache)
 LOW, HID, GLIMPSES, RANK = 310, 510, 4, 2
 
 
 K4_FOLDED = os.environ.get("VQA_K4_FORM", "auto") != "engine"
+EVIDENCE_TAG = "r02"      # profiles/<tag>_pmc_traffic.json / <tag>_pmc_mfma.json: rocprofv3 --pmc passes of this command
 
 
-def kernel_models(B, N=REGIONS, D=FEAT, G=GLIMPSES, L=LOW, H=HID, R=RANK, bf16=False):
-    """Algorithmic bytes / FLOPs per launch (SURVEY.md 8d per-sample figures x samples per launch).
-    bf16=True: the region tensors (v, v2, their gradients) are 2 bytes per element, everything else stays fp32."""
-    if bf16:
-        fv, f = 2, 4
-        return {
-            "lowrank_bilinear_fusion_fwd_bf16": ("mfma", B * (2 * R * N * L * H + 2 * R * N * H)),
-            "lowrank_bilinear_fusion_bwd_bf16": ("mfma", B * (2 * 2 * R * N * L * H)),
-            "relation_apply_fwd_bf16": ("hbm", B * (2 * N * D * fv + 2 * D * f)),               # v in, dropped v2 out
-            "relation_apply_bwd_bf16": ("hbm", B * (2 * N * D * fv + 3 * D * f)),               # v, g in; d_t, d_c2 out
-            "pairwise_relation_reduce_fwd_bf16": ("hbm", B * (2 * N * D * fv + (2 * D + N) * f)),
-            "pairwise_relation_reduce_bwd_bf16": ("hbm", B * (2 * N * D * fv + (4 * D + 2 * N) * f)),
-            "softmax_attention_pool_fwd_bf16": ("hbm", B * (N * D * fv + (2 * N * G + G * D) * f)),
-            "softmax_attention_pool_bwd_bf16": ("hbm", B * (N * D * fv + (G * D + 3 * N * G) * f)),
-        }
-    f = 4
-    return {
-        "object_difference_attention_fwd": ("valu", B * 2 * G * N * N * L),                 # 2 flop per (mask element, glimpse)
-        "object_difference_attention_bwd": ("valu", B * 4 * G * N * N * L),                 # data pass + weight pass
-        "lowrank_bilinear_fusion_fwd": ("mfma", B * (2 * R * N * L * H + 2 * R * N * H)),
-        "lowrank_bilinear_fusion_bwd": ("mfma", B * (2 * 2 * R * N * L * H)),              # dx + dW1 contractions
-        "relation_apply_fwd": ("hbm", B * (2 * N * D + 2 * D) * f),                         # K1 closed form: v in, dropped v2 out
-        "relation_apply_bwd": ("hbm", B * (2 * N * D + 3 * D) * f),                         # v, g in; d_t, d_c2 out
-        "pairwise_relation_reduce_fwd": ("hbm", B * (2 * N * D + 2 * D + N) * f),          # 606 352 B/sample
-        "pairwise_relation_reduce_bwd": ("hbm", B * (2 * N * D + 4 * D + 2 * N) * f),      # v, g in; dq1,dq2,dalpha out
-        "softmax_attention_pool_fwd": ("hbm", B * (N * D + 2 * N * G + G * D) * f),        # 328 832 B/sample
-        "softmax_attention_pool_bwd": ("hbm", B * (N * D + G * D + 3 * N * G) * f),        # (+N*D when d_v is written)
-    }
+def work_of(name, shape):
+    """(bound, algorithmic work per launch) of one timed op -- bytes for "hbm", FLOPs for "mfma" / "valu" -- from the
+    shape its wrapper in ops.py reports (SURVEY.md 8d per-sample figures x the samples of the launch).
+    None: no model (the op is still listed with its time)."""
+    bf16 = name.endswith("_bf16")
+    base = name[:-5] if bf16 else name
+    fv, f = (2 if bf16 else 4), 4        # bytes per element of the region tensors / of everything else
+    s = shape
+    if base == "lowrank_bilinear_fusion_fwd":
+        B, N, L, H, R = s[:5]
+        return "mfma", B * (2 * R * N * L * H + 2 * R * N * H)
+    if base == "lowrank_bilinear_fusion_bwd":
+        B, N, L, H, R, dx = s[:6]
+        return "mfma", B * (2 * R * N * L * H) * (2 if dx else 1)                    # dW1 (+ dx) contractions
+    if base == "linear_act_fwd":
+        M, K, N = s[:3]
+        return "mfma", 2 * M * K * N
+    if base == "linear_act_bwd":
+        M, K, N, _drop, dx = s[:5]
+        return "mfma", 2 * M * K * N * (2 if dx else 1)                              # dW (+ dx)
+    if base == "library_gemm":
+        M, N, K = s[:3]
+        return "mfma", 2 * M * N * K
+    if base in ("gemm_bf16_nt", "gemm_bf16_tn"):
+        return "mfma", 2 * s[0] * s[1] * s[2]
+    if base == "object_difference_attention_fwd":
+        B, N, L, G = s[:4]
+        return "valu", B * 2 * G * N * N * L                                         # 2 flop per (mask element, glimpse)
+    if base == "object_difference_attention_bwd":
+        B, N, L, G = s[:4]
+        return "valu", B * 4 * G * N * N * L                                         # data pass + weight pass
+    if base == "relation_apply_fwd":
+        B, N, D = s[:3]
+        return "hbm", B * (2 * N * D * fv + 2 * D * f)                               # v in, dropped v2 out
+    if base == "relation_apply_bwd":
+        B, N, D, _drop, dv = s[:5]
+        return "hbm", B * ((2 + (1 if dv else 0)) * N * D * fv + 3 * D * f)          # v, g in; d_t, d_c2 (, d_v) out
+    if base == "pairwise_relation_reduce_fwd":
+        B, N, D = s[:3]
+        return "hbm", B * (2 * N * D * fv + (2 * D + N) * f)                         # 606 352 B/sample at fp32
+    if base == "pairwise_relation_reduce_bwd":
+        B, N, D, dv, gb = s[:5]
+        return "hbm", B * ((2 + (1 if dv else 0) + (1 if gb else 0)) * N * D * fv + (4 * D + 2 * N) * f)
+    if base == "softmax_attention_pool_fwd":
+        B, N, D, G = s[:4]
+        return "hbm", B * (N * D * fv + (2 * N * G + G * D) * f)                     # 328 832 B/sample at fp32
+    if base == "softmax_attention_pool_bwd":
+        B, N, D, G, dv = s[:5]
+        return "hbm", B * ((1 + (1 if dv else 0)) * N * D * fv + (G * D + 3 * N * G) * f)
+    if base == "attention_logits_fwd":
+        M, K, G = s[:3]
+        return "hbm", M * (K * fv + G * f)
+    if base == "attention_logits_bwd":
+        M, K, G, _drop, dx = s[:5]
+        return "hbm", M * ((1 + (1 if dx else 0)) * K * fv + G * f)
+    if base == "kld_sum_loss":
+        B, C, need = s[:3]
+        return "hbm", B * C * f * (3 if need else 2)
+    if base == "grad_norm_clip_coef":
+        return "hbm", s[0] * f
+    if base in ("adam_step", "adam_step_dyn"):
+        return "hbm", s[0] * 7 * f                                                   # p, g, m, v in; p, m, v out
+    if base == "column_sum":
+        return "hbm", s[0] * s[1] * fv
+    if base == "bias_act":
+        G, B, A = s[:3]
+        return "hbm", 2 * G * B * A * f
+    if base == "act_bwd_colsum":
+        G, B, A = s[:3]
+        return "hbm", 3 * G * B * A * f
+    if base == "rank_product_fwd":
+        B, R, H = s[:3]
+        return "hbm", (2 * R + 1) * B * H * f
+    if base == "rank_product_bwd":
+        B, R, H = s[:3]
+        return "hbm", (4 * R + 1) * B * H * f
+    return None
 
 
 # HBM-side traffic per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-# separate runs, KiB units; profiles/r01_f_pmc_traffic.json, built by tools/pmc_table.py).  FETCH_SIZE under-reports 16-byte-per-lane streaming
-# reads by exactly 2x on gfx950 (MI355X_MICROARCH.md, HBM section) and is taken as-is for the 8-byte-per-lane GEMM
-# staging loads (calibrated here against the algorithmic bytes of the K4 forward: 26.5 MB counted vs 26.1 MB expected).
-PMC_KERNELS = {  # C-ABI entry -> [(kernel-name prefix, grid, fetch multiplier)]
-    "lowrank_bilinear_fusion_fwd": [("vqa::bilinear_folded_kernel<3, 2, true", "262144", 1.0)],
-    "relation_apply_fwd": [("vqa::relation_apply_fwd_kernel", None, 2.0)],
-    "relation_apply_bwd": [("vqa::relation_apply_bwd_kernel", None, 2.0)],
-    "pairwise_relation_reduce_fwd": [("vqa::pairwise_fwd_reg_kernel", "262144", 2.0)],
-    "pairwise_relation_reduce_bwd": [("vqa::pairwise_bwd_stream_kernel", "262144", 2.0)],
-    "softmax_attention_pool_fwd": [("vqa::attention_pool_fwd_kernel", "262144", 2.0)],
+# separate runs, kernel by kernel, KiB units; profiles/<tag>_pmc_traffic.json, built by tools/pmc_table.py).  FETCH_SIZE
+# under-reports 16-byte-per-lane streaming reads by exactly 2x on gfx950 (MI355X_MICROARCH.md, HBM section); the multiplier
+# is stated per kernel.  Counters cannot be collected inside the driver's own run of this file (no profiler is attached
+# there): the table is the committed evidence of the same command, and `traffic_source` says so in the output line.
+PMC_KERNELS = {  # C-ABI entry -> [(kernel-name prefix, fetch multiplier)]
+    "lowrank_bilinear_fusion_fwd": [("vqa::bilinear_folded_kernel<3, 2, true", 1.0)],
+    "linear_act_fwd": [("vqa::rt::gemm_nt_kernel<9, 5, 1, 2, 2", 2.0)],
+    "linear_act_bwd": [("vqa::rt::gemm_tn_kernel<5, 2", 2.0)],
+    "relation_apply_fwd": [("vqa::relation_apply_fwd_kernel", 2.0)],
+    "relation_apply_bwd": [("vqa::relation_apply_bwd_kernel", 2.0)],
+    "pairwise_relation_reduce_fwd": [("vqa::pairwise_fwd", 2.0)],
+    "pairwise_relation_reduce_bwd": [("vqa::pairwise_bwd_stream_kernel", 2.0)],
+    "softmax_attention_pool_fwd": [("vqa::attention_pool_fwd_kernel", 2.0)],
+    "softmax_attention_pool_bwd": [("vqa::attention_pool_bwd_stream_kernel", 2.0)],
 }
+_tables = {}
+
+
+def _evidence(kind):
+    if kind not in _tables:
+        path = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (EVIDENCE_TAG, kind))
+        _tables[kind] = json.load(open(path)) if os.path.exists(path) else {}
+    return _tables[kind]
 
 
 def pmc_traffic(name, B):
-    path = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")
-    if B != BATCH or name not in PMC_KERNELS or not os.path.exists(path):
+    """HBM bytes per launch of the kernel(s) behind one C-ABI op at the headline batch, or None."""
+    table = _evidence("traffic")
+    if B != BATCH or name not in PMC_KERNELS or not table:
         return None
     if name == "lowrank_bilinear_fusion_fwd" and not K4_FOLDED:       # the table holds the folded kernel
         return None
-    table = json.load(open(path))
     total = 0.0
-    for prefix, grid, mult in PMC_KERNELS[name]:
-        hit = [v for k, v in table.items() if k.startswith(prefix) and (grid is None or k.endswith("grid=" + grid))]
+    for prefix, mult in PMC_KERNELS[name]:
+        hit = sorted((v for k, v in table.items() if k.startswith(prefix)), key=lambda v: -v.get("launches", 0))
         if not hit:
             return None
         total += (hit[0]["FETCH_SIZE_KiB"] * mult + hit[0]["WRITE_SIZE_KiB"]) * 1024.0
     return int(total)
 
 
+def pmc_mfma(name):
+    """Counter-backed matrix-pipe occupancy of the kernel behind an op: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES and the
+    MFMA instruction count (profiles/<tag>_pmc_mfma.json, tools/pmc_mfma.py), or None."""
+    table = _evidence("mfma")
+    if name not in PMC_KERNELS or not table:
+        return None
+    prefix = PMC_KERNELS[name][0][0]
+    hit = sorted((v for k, v in table.items() if k.startswith(prefix)), key=lambda v: -v.get("launches", 0))
+    return hit[0] if hit else None
+
+
 def roofline_entry(name, shape, launches, mean_ms, B, regions=REGIONS, bf16=False):
-    bound, work = kernel_models(B, N=regions, bf16=bf16)[name]
-    if name.startswith("softmax_attention_pool_bwd") and shape[-1]:
-        work += B * regions * FEAT * (2 if bf16 else 4)
-    if name.startswith("lowrank_bilinear_fusion_bwd") and not shape[-1]:
-        work //= 2
-    if name.startswith("pairwise_relation_reduce_bwd") and shape[-1]:      # second gradient tensor read as well
-        work += B * regions * FEAT * (2 if bf16 else 4)
-    if name.startswith("relation_apply_bwd") and shape[-1]:                # d_v written as well
-        work += B * regions * FEAT * (2 if bf16 else 4)
-    sec = mean_ms * 1e-3
+    model = work_of(name, shape)
+    entry = {"kernel": name, "shape": list(shape), "launches": launches, "mean_ms": round(mean_ms, 5)}
+    if model is None:
+        entry.update({"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None})
+        return entry
+    bound, work = model
+    sec = max(mean_ms, 1e-9) * 1e-3
     if bound == "hbm":
         achieved, peak, unit = work / sec / 1e9, HBM_PEAK_GBS, "GB/s"
-    elif bf16:
+    elif name.endswith("_bf16") or name.startswith("gemm_bf16"):
         achieved, peak, unit = work / sec / 1e12, MFMA_BF16_PEAK_TF, "TFLOP/s"
     else:  # "mfma" and "valu" share the fp32 peak on gfx950 (157.3 TFLOP/s for both pipes)
         achieved, peak, unit = work / sec / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
-    entry = {"kernel": name, "shape": list(shape), "launches": launches, "mean_ms": round(mean_ms, 5), "bound": bound,
-             "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
-             "traffic": pmc_traffic(name, B) if regions == REGIONS and not bf16 else None}
-    if name == "lowrank_bilinear_fusion_fwd" and K4_FOLDED and regions <= 112:
+    entry.update({"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+                  "frac": round(achieved / peak, 4),
+                  "traffic": pmc_traffic(name, shape[0]) if regions == REGIONS and not bf16 else None})
+    if name == "lowrank_bilinear_fusion_fwd" and K4_FOLDED and regions <= 112 and len(shape) >= 5 and shape[1] > 1:
         # `achieved` prices the kernel at SURVEY 8d's algorithmic FLOPs (R GEMMs per fusion).  The rank-folded kernel
         # executes 1/R of them on the matrix core, plus the padding of a sample to whole 16-region blocks and of L / H to
         # the 16-wide chunk / 64-wide tile: state what the MFMA pipe really ran as well.
         nb = {1: 1, 2: 2, 3: 3, 4: 5, 5: 5, 6: 7, 7: 7}[(regions + 15) // 16]
-        executed = 2.0 * B * (nb * 16) * ((LOW + 1 + 15) // 16 * 16) * ((HID + 63) // 64 * 64)
+        executed = 2.0 * shape[0] * (nb * 16) * ((LOW + 1 + 15) // 16 * 16) * ((HID + 63) // 64 * 64)
         entry["form"] = "rank-folded (csrc/bilinear_folded.hip)"
         entry["mfma_flops_executed"] = int(executed)
         entry["mfma_executed_tflops"] = round(executed / sec / 1e12, 2)
+    busy = pmc_mfma(name) if regions == REGIONS and not bf16 else None
+    if busy is not None:
+        entry["mfma_busy_pct"] = busy.get("mfma_busy_pct")
+        entry["mfma_counters"] = {k: busy[k] for k in busy if k.startswith("SQ_") or k == "launches"}
     return entry
+
+
+def step_table(summary, steps_timed, B, regions, bf16):
+    """Every timed op of the per-kernel pass as a roofline entry, sorted by its share of the step."""
+    entries = [roofline_entry(name, shape, n, ms, B, regions, bf16) for (name, shape), (n, ms) in summary.items()]
+    for e in entries:
+        e["ms_per_step"] = round(e["mean_ms"] * e["launches"] / max(steps_timed, 1), 5)
+    entries.sort(key=lambda e: -e["ms_per_step"])
+    return entries
 
 
 def cpu_baseline_worker(batch, threads, budget_s):
@@ -150,16 +235,11 @@ def cpu_baseline_worker(batch, threads, budget_s):
     print(json.dumps({"value": round(batch / dt, 2), "unit": "samples/s", "cores": threads, "kind": "port",
                       "sample": "CoR2 fwd+bwd (KLD-sum loss, dropout on), batch %d x %d steps after 1 warm-up; torch-CPU "
                                 "reference-faithful port (per-sample python loops, materialised [B,36,36,2048]); "
-                                "%d of the host's %d cores (more threads slow the reference's many tiny ops down)"
-                                % (batch, steps, threads, os.cpu_count() or 1)}))
+                                "%d threads on a host with %d cores" % (batch, steps, threads, os.cpu_count() or 1)}))
 
 
-def cpu_baseline(batch=16, budget_s=12.0, hard_timeout_s=90.0):
-    """The reference cannot travel to the GPU box; time its op-for-op torch-CPU port (validated against the
-    reference's golden vectors in tests/) on the host cores.  Bounded: a child process with a hard timeout, so a
-    slow host can never stall the benchmark."""
+def _cpu_baseline_run(batch, threads, budget_s, hard_timeout_s):
     import subprocess
-    threads = min(os.cpu_count() or 1, 16)
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(batch), str(threads), str(budget_s)]
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))
     try:
@@ -172,6 +252,24 @@ def cpu_baseline(batch=16, budget_s=12.0, hard_timeout_s=90.0):
     except subprocess.TimeoutExpired:
         return {"value": None, "unit": "samples/s", "cores": threads, "kind": "port",
                 "sample": "did not finish 3 steps of batch %d within %.0f s" % (batch, hard_timeout_s)}
+
+
+def cpu_baseline(batch=16, budget_s=10.0, hard_timeout_s=90.0):
+    """The reference cannot travel to the GPU box; time its op-for-op torch-CPU port (validated against the
+    reference's golden vectors in tests/) on the host cores.  Bounded: child processes with a hard timeout, so a
+    slow host can never stall the benchmark.  Two thread counts: 16 (the reference's thousands of tiny per-sample ops
+    get slower with more) and every core of the host (os.cpu_count() threads, batch 32); the better one is
+    `value`, the other is reported next to it."""
+    cores = os.cpu_count() or 1
+    runs = [_cpu_baseline_run(batch, min(cores, 16), budget_s, hard_timeout_s)]
+    if cores > 16:      # (on a 256-core host the all-core run is several times slower: bounded tightly, reported either way)
+        runs.append(_cpu_baseline_run(batch, cores, budget_s / 2, 45.0))
+    ok = [r for r in runs if r.get("value")]
+    best = max(ok, key=lambda r: r["value"]) if ok else runs[0]
+    best = dict(best)
+    best["host_cores"] = cores
+    best["all_runs"] = [{"cores": r["cores"], "value": r["value"], "sample": r["sample"]} for r in runs]
+    return best
 
 
 def bench_oda_attention(args, world, rank, dev, ops):
@@ -220,10 +318,8 @@ def bench_oda_attention(args, world, rank, dev, ops):
     elapsed = float(t.item())
     assert torch.isfinite(alpha).all() and torch.isfinite(vl.grad).all() and torch.isfinite(w.grad).all()
     if rank == 0:
-        entries = [roofline_entry(name, shape, n, ms, B, N) for (name, shape), (n, ms) in timer.summary().items()
-                   if name in kernel_models(B, N=N)]
-        entries.sort(key=lambda e: -e["mean_ms"] * e["launches"])
-        dominant = next(e for e in entries if e["kernel"] == "object_difference_attention_bwd")
+        entries = step_table(timer.summary(), min(args.steps, 10), B, N, False)
+        dominant = next(e for e in entries if e["bound"] is not None)
         print(json.dumps({
             "metric": "ODA object-difference attention op samples/sec (fwd+bwd), batch %d, %dx%d pairwise" % (B, N, N),
             "value": round(world * B * args.steps / elapsed, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
@@ -263,6 +359,7 @@ def main():
                     "question vectors")
     ap.add_argument("--overlap", action="store_true", help="CoR2: backward in two halves, the second reasoning step's "
                     "gradients all-reduced under the second half (trainer overlap; at one GPU it only splits the backward)")
+    ap.add_argument("--no-rotate", action="store_true", help="skip the rotating-inputs pass")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying "
                     "the captured hipGraphs of the step")
     args = ap.parse_args()
@@ -363,25 +460,62 @@ def main():
             trainer.step_eager(sample, a)
         barrier()
         ops.set_kernel_timer(None)
+    final_loss, final_gnorm = float(loss.item()), float(gnorm.item())
+    # The same steps over ROTATE different resident batches: every step's batch then comes from HBM, not from the Infinity
+    # Cache.  The replayed graphs read fixed input buffers, so each step starts with one device-to-device copy of the
+    # batch into them (151 MB read + written, inside the timed region) -- an upper bound on what cold inputs cost.
+    rotating = None
+    if graphed and world == 1 and not args.encoder and not args.no_rotate:
+        extra = [{"v": torch.randn_like(v.float()).to(v.dtype), "q_idxes": torch.randn_like(q)} for _ in range(ROTATE)]
+        targets = [torch.softmax(2.0 * torch.randn(B, answers, device=dev), dim=1) for _ in range(ROTATE)]
+        for i in range(ROTATE):
+            trainer.step(extra[i], targets[i])
+        barrier()
+        r0 = time.perf_counter()
+        for i in range(args.steps):
+            trainer.step(extra[i % ROTATE], targets[i % ROTATE])
+        barrier()
+        r_el = time.perf_counter() - r0
+        rotating = {"batches": ROTATE, "value": round(B * args.steps / r_el, 1), "unit": "samples/s",
+                    "ms_per_step": round(1e3 * r_el / args.steps, 3),
+                    "note": "each step = one device-to-device copy of the next batch into the graph's input buffers + the step"}
+    dist_info = None
+    if world > 1:
+        # what a reader needs to sanity-check a scaling record: ranks seen by the process group, the all-reduce payload and
+        # its duration measured on its own (back to back, nothing to overlap with), the per-rank rate
+        payload = trainer.flat.g
+        for _ in range(3):
+            dist.all_reduce(payload, op=dist.ReduceOp.SUM)
+        barrier()
+        a0 = time.perf_counter()
+        for _ in range(10):
+            dist.all_reduce(payload, op=dist.ReduceOp.SUM)
+        barrier()
+        ar_ms = 1e3 * (time.perf_counter() - a0) / 10
+        payload.zero_()
+        dist_info = {"nranks": dist.get_world_size(), "backend": dist.get_backend(), "allreduce_payload_bytes": payload.numel() * 4,
+                     "allreduce_ms_alone": round(ar_ms, 3),
+                     "allreduce_busbw_GBs": round(2 * (world - 1) / world * payload.numel() * 4 / (ar_ms * 1e-3) / 1e9, 1),
+                     "per_rank_samples_per_s": round(B * args.steps / elapsed, 1), "overlap": bool(trainer.overlap)}
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    final_loss, final_gnorm = float(loss.item()), float(gnorm.item())
     # sanity of the timed steps themselves (a replayed graph that computed garbage would still be fast): the loss of
     # the last timed step is finite and positive (a KL divergence) and the gradient norm is of a trainable size
     assert final_loss == final_loss and 0.0 < final_loss < 1e6, "implausible loss %r in the timed region" % final_loss
     assert final_gnorm == final_gnorm and 0.0 < final_gnorm < 1e4, "implausible gradient norm %r" % final_gnorm
 
     if rank == 0:
-        summary = timer.summary()
-        models = kernel_models(B, N=args.regions, bf16=bf16)
-        entries = [roofline_entry(name, shape, n, ms, B, args.regions, bf16) for (name, shape), (n, ms) in summary.items()
-                   if name in models and shape[0] == B and (len(shape) < 2 or shape[1] == args.regions)]
-        entries.sort(key=lambda e: -e["mean_ms"] * e["launches"])
-        head = ("lowrank_bilinear_fusion_fwd" + ("_bf16" if bf16 else "")) if args.model == "cor2" \
-            else "object_difference_attention_fwd"
-        dominant = next((e for e in entries if e["kernel"] == head), entries[0])
+        steps_timed = min(args.steps, 10) if (graphed or not args.no_graph) else args.steps
+        entries = step_table(timer.summary(), steps_timed, B, args.regions, bf16)
+        # `roofline` = the hand-written kernel that takes the largest share of the step (mean duration x launches), not a
+        # favourite; library GEMMs (hipBLASLt through torch) are listed in roofline_all with their time and rate as well
+        ours = [e for e in entries if e["bound"] is not None and e["kernel"] != "library_gemm"]
+        dominant = ours[0] if ours else entries[0]
+        kernel_ms = sum(e["ms_per_step"] for e in entries)
+        lib_ms = sum(e["ms_per_step"] for e in entries if e["kernel"] == "library_gemm")
+        ms_step = 1e3 * elapsed / args.steps
         result = {
             "metric": "VQA samples/sec (fwd+bwd), %s batch %d, %dx2048 regions%s"
                       % ("CoR2" if args.model == "cor2" else "ODA", B, args.regions,
@@ -391,7 +525,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "ms_per_step": round(ms_step, 3),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -409,12 +543,26 @@ def main():
                        "+ clip 0.25 + Adam (dropout active)", "parallelism": "dp%d" % world,
                        "launch": ("hipGraph replay (3 graphs: backward in two halves, the first all-reduce under the second)"
                                   if trainer.overlap else "hipGraph replay (2 graphs + eager all-reduce)") if graphed else "eager",
-                       "relation_mode": "factored" if args.relation_mode == 1 else "pairwise"},
+                       "relation_mode": "factored" if args.relation_mode == 1 else "pairwise",
+                       "inputs": "ONE resident batch (%.0f MB of regions) re-read every step: it fits the 256 MB Infinity "
+                                 "Cache, so the HBM-bound kernels' GB/s are upper bounds; `rotating_inputs` times the same "
+                                 "steps over %d different resident batches" % (v.numel() * v.element_size() / 1e6, ROTATE)},
             "final_loss": round(final_loss, 3), "final_grad_norm": round(final_gnorm, 3),
-            "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
-                                                  "mean_ms", "launches")},
+            "roofline": dict({k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
+                                                       "mean_ms", "launches", "ms_per_step")},
+                             **{k: dominant[k] for k in ("mfma_busy_pct",) if k in dominant}),
+            "traffic_source": "profiles/%s_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                              "(committed evidence; no profiler is attached in this run)" % EVIDENCE_TAG,
+            # how much of the step the per-kernel table accounts for (its durations come from the kernel-by-kernel pass,
+            # ms_per_step from the replayed graphs; the rest is framework glue: small element-wise kernels, copies, gaps)
+            "step_coverage": {"timed_ops_ms": round(kernel_ms, 3), "of_ms_per_step": round(kernel_ms / ms_step, 3),
+                              "library_gemm_ms": round(lib_ms, 3), "hand_written_ms": round(kernel_ms - lib_ms, 3)},
             "roofline_all": entries,
         }
+        if rotating is not None:
+            result["rotating_inputs"] = rotating
+        if world > 1:
+            result["distributed"] = dist_info
         if world == 1 and not args.no_cpu_baseline and args.model == "cor2" and not bf16 and args.regions == REGIONS:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result))

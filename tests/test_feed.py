@@ -53,3 +53,18 @@ def test_prefetcher_gpu_delivers_identical_batches_with_slot_reuse():
         assert torch.equal(g["v"].cpu(), batches[i]["v"]) and torch.equal(g["a"].cpu(), batches[i]["a"])
         assert torch.equal(g["q_idxes"].cpu(), batches[i]["q_idxes"]) and torch.equal(x.cpu(), batches[i]["v"] * 2.0)
     assert i == 6 and len(pf.slots) == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("last", [3, 1])
+def test_prefetcher_gpu_short_final_batch(last):
+    """The reference's DataLoader has no drop_last (datasets.py:975): the final batch of an epoch is shorter -- also by all
+    but ONE sample, which a plain copy_ into the full-size slot would silently broadcast."""
+    dev = torch.device("cuda:0")
+    batches = [feed.collate(items(8, seed=s), 20) for s in range(4)] + [feed.collate(items(last, seed=9), 20)]
+    n = 0
+    for g, b in zip(feed.DevicePrefetcher(batches, dev, depth=2), batches):     # (a yielded batch lives until the next one)
+        for k in b:
+            assert g[k].shape == b[k].shape and torch.equal(g[k].cpu(), b[k]), k
+        n += 1
+    assert n == 5

@@ -341,6 +341,33 @@ def test_graph_replays_queued_without_host_sync():
     assert abs(l0 - l1) <= 1e-4 * abs(l0) and abs(n0 - n1) <= 1e-3 * abs(n0), (got[False], got[True])
 
 
+def test_graph_replays_far_behind_the_host_keep_their_step_scalars():
+    """The per-step Adam scalars (lr / bias corrections) and the dropout seed travel through an 8-slot pinned ring.  A host
+    that runs more than 8 replays ahead of the GPU (here: 24 steps queued behind a device-side sleep) must not rewrite a
+    slot before the GPU has copied it: the weights after the queued steps equal those of the same steps run one by one."""
+    from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
+    v, q, a = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(8, answers=300, seed=71))
+    finals = []
+    for queued in (False, True):
+        model = build("cor2", 300)                          # eval mode: no dropout, deterministic
+        tr = DataParallelTrainer(model, lr=1e-3, clip=0.25, gamma=0.9, graph=True)     # gamma 0.9: lr moves fast per step
+        for _ in range(4):
+            tr.step({"v": v, "q_idxes": q}, a)
+        assert tr._graph is not None
+        torch.cuda.synchronize()
+        if queued:
+            torch.cuda._sleep(int(2.4e9))                   # ~1 s: every replay below is enqueued behind it
+        for _ in range(24):
+            tr.step({"v": v, "q_idxes": q}, a)
+            if not queued:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        finals.append(tr.flat.p.clone())
+    diff = (finals[0] - finals[1]).abs().max().item()
+    scale = finals[0].abs().max().item()
+    assert diff <= 1e-6 * scale, (diff, scale)
+
+
 def test_graph_trainer_respects_train_eval_switch():
     """Dropout is baked into the captured graphs: after model.eval() the trainer must not replay the train-mode graph."""
     from vqa_playground_pytorch_amd.trainer import DataParallelTrainer

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Matrix-pipe occupancy per kernel from a rocprofv3 --pmc pass (profiles/*_pmc_mfma.json, read by bench.py).
+
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 \\
+              SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d out/mfma -- \\
+              python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate
+    python tools/pmc_mfma.py out/mfma profiles/rNN_pmc_mfma.json
+
+Counter units on gfx950 (calibrated on tools/rt_probe.hip, whose forward kernel issues exactly 1024 waves x 11520
+v_mfma_f32_16x16x4_f32): SQ_INSTS_MFMA = instructions; SQ_VALU_MFMA_BUSY_CYCLES = matrix-pipe busy cycles summed over
+all SIMDs (= 32 x SQ_INSTS_MFMA for that instruction); SQ_BUSY_CU_CYCLES = busy cycles summed over the CUs;
+SQ_BUSY_CYCLES = the same per shader engine (32 SEs, 8 CUs = 32 SIMDs each); SQ_WAVE_CYCLES = wave lifetimes in units
+of 4 cycles.  Derived:
+
+    mfma_busy_pct = 100 * SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs * SQ_BUSY_CU_CYCLES)
+                  = 100 * SQ_VALU_MFMA_BUSY_CYCLES / (32 SIMDs per SE * SQ_BUSY_CYCLES)      (SURVEY 5.1's ratio, normalised)
+
+i.e. the share of the kernel's duration, launch to last wave, in which a SIMD's matrix pipe was executing an MFMA,
+averaged over the SIMDs of the busy CUs.  Keys are "<kernel name>|grid=<work-items>"."""
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def main():
+    dirs, dest = sys.argv[1:-1], sys.argv[-1]
+    per = {}
+    for d in dirs:
+        for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+            for row in csv.DictReader(open(path)):
+                name = re.sub(r"^void ", "", row["Kernel_Name"]).split("(")[0]
+                if "vqa" not in name:
+                    continue
+                key = "%s|grid=%s" % (name, row.get("Grid_Size", "?"))
+                disp = per.setdefault(key, {}).setdefault(row["Dispatch_Id"], {})
+                disp[row["Counter_Name"]] = disp.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+    table = {}
+    for key, dispatches in sorted(per.items()):
+        names = sorted({c for d in dispatches.values() for c in d})
+        entry = {"launches": len(dispatches)}
+        for c in names:
+            vals = [d[c] for d in dispatches.values() if c in d]
+            entry[c] = sum(vals) / len(vals)
+        busy, cu = entry.get("SQ_VALU_MFMA_BUSY_CYCLES"), entry.get("SQ_BUSY_CU_CYCLES")
+        if busy is not None and cu:
+            entry["mfma_busy_pct"] = round(100.0 * busy / (4.0 * cu), 2)
+        if busy is not None and entry.get("SQ_BUSY_CYCLES"):
+            entry["mfma_busy_over_sq_busy_per_simd"] = round(busy / (32.0 * entry["SQ_BUSY_CYCLES"]), 4)
+        if entry.get("SQ_INSTS_MFMA", 0) > 0 or "mfma" in key or "gemm" in key or "bilinear" in key or "linear" in key:
+            table[key] = entry
+    json.dump(table, open(dest, "w"), indent=1, sort_keys=True)
+    print("wrote %s: %d kernels" % (dest, len(table)))
+    for k, v in table.items():
+        if v.get("mfma_busy_pct"):
+            print("  %-110s launches %4d  mfma busy %5.1f %%" % (k[:110], v["launches"], v["mfma_busy_pct"]))
+
+
+if __name__ == "__main__":
+    main()

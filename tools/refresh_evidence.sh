@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates the measured evidence of a round on the MI355X box (run through gpurun from the repo root):
-#   bash tools/refresh_evidence.sh r01_f
+#   bash tools/refresh_evidence.sh r02_a
 # Writes everything under gpurun_out/<tag>/ ; copy what is to be judged into profiles/.
 set -u
-TAG=${1:-r01_x}
+TAG=${1:-r02_x}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -12,16 +12,20 @@ cd /tmp && export TMPDIR=/tmp
 # 1. HBM traffic counters: two separate --pmc passes (never combined with trace domains), kernel by kernel
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-graph > "$OUT/pmc_$c.log" 2>&1
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate > "$OUT/pmc_$c.log" 2>&1
 done
-python3 "$ROOT/tools/pmc_table.py" /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE "$ROOT/profiles/${TAG}_pmc_traffic.json" > "$OUT/pmc_table.log" 2>&1
-cp "$ROOT/profiles/${TAG}_pmc_traffic.json" "$OUT/" 2>/dev/null
+python3 "$ROOT/tools/pmc_table.py" /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE "$OUT/pmc_traffic.json" > "$OUT/pmc_table.log" 2>&1
+# 1b. matrix-pipe occupancy counters (their own pass), CoR2 and ODA steps
+rm -rf /tmp/pmc_mfma /tmp/pmc_mfma_oda
+MFMA_CTRS="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
+timeout 600 rocprofv3 --pmc $MFMA_CTRS --output-format csv -d /tmp/pmc_mfma -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate > "$OUT/pmc_mfma.log" 2>&1
+python3 "$ROOT/tools/pmc_mfma.py" /tmp/pmc_mfma "$OUT/pmc_mfma.json" > "$OUT/pmc_mfma_table.log" 2>&1
 
 # 2. bench lines
 cd "$ROOT"
 run() { name=$1; shift; timeout 900 python3 bench.py "$@" > "$OUT/$name.log" 2>&1; tail -1 "$OUT/$name.log" > "$OUT/$name.json"; }
 run bench_b512 --steps 20 --warmup 5
-run bench_b512_eager --steps 20 --warmup 5 --no-graph --no-cpu-baseline
+run bench_b512_eager --steps 20 --warmup 5 --no-graph --no-cpu-baseline --no-rotate
 run bench_b512_pairwise --steps 20 --warmup 5 --relation-mode 0 --no-cpu-baseline
 run bench_f32_n100_b128 --regions 100 --batch 128 --steps 20 --warmup 5 --no-cpu-baseline
 run bench_bf16_n100_b128 --dtype bf16 --regions 100 --batch 128 --steps 20 --warmup 5 --no-cpu-baseline

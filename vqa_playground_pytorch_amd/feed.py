@@ -92,20 +92,33 @@ class DevicePrefetcher:
             return True
         s = self._slot(batch)
         self.n += 1
-        src = {}
+        # The slots are sized by the first batch.  The reference's DataLoader has no drop_last (datasets.py:975), so the
+        # last batch of an epoch is shorter: it is staged into / yielded as the leading rows of the slot buffers (a plain
+        # copy_ would raise on the size mismatch -- or, for a remainder of ONE sample, silently broadcast it).
+        src, dev = {}, {}
         for k, t in batch.items():
+            full = s["dev"][k]
+            if t.shape[1:] != full.shape[1:] or t.dtype != full.dtype or t.size(0) > full.size(0):
+                full = s["dev"][k] = torch.empty_like(t, device=self.device)      # a larger / differently shaped batch
+                s["host"].pop(k, None)
+            b = t.size(0)
             if t.is_pinned():
                 src[k] = t                              # already page-locked (DataLoader(pin_memory=True)): DMA from it
             else:
-                if k not in s["host"]:
+                if k not in s["host"] or s["host"][k].shape[1:] != t.shape[1:] or s["host"][k].size(0) < b:
                     s["host"][k] = torch.empty_like(t).pin_memory()
-                s["host"][k].copy_(t)                   # pageable -> pinned staging slot (a host memcpy: ~10 GB/s)
-                src[k] = s["host"][k]
+                stage = s["host"][k].narrow(0, 0, b)
+                stage.copy_(t)                          # pageable -> pinned staging slot (a host memcpy: ~10 GB/s)
+                src[k] = stage
+            dev[k] = full.narrow(0, 0, b) if b != full.size(0) else full
         with torch.cuda.stream(self.stream):
             for k in batch:
-                s["dev"][k].copy_(src[k], non_blocking=True)
+                if dev[k].shape != src[k].shape:
+                    raise RuntimeError("prefetcher: staging shape %s does not match the batch %s"
+                                       % (tuple(dev[k].shape), tuple(src[k].shape)))
+                dev[k].copy_(src[k], non_blocking=True)
             s["ready"].record(self.stream)
-        self.queue.append((s, s["dev"]))
+        self.queue.append((s, dev))
         return True
 
     def __iter__(self):

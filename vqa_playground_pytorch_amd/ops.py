@@ -61,6 +61,37 @@ def _launch(name, shape, fn, *args):
     _lib.check(rc, name)
 
 
+class _Timed:
+    """Event pair around library (torch / hipBLASLt) ops on the current stream, so that bench.py's per-kernel table covers
+    the whole step and not only the C-ABI launches.  A no-op unless a KernelTimer is installed."""
+
+    __slots__ = ("key", "a")
+
+    def __init__(self, name, shape):
+        self.key = (name, tuple(int(x) for x in shape))
+        self.a = None
+
+    def __enter__(self):
+        t = _timer
+        if t is not None and t.wants(self.key[0]):
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.a is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            t = _timer
+            if t is not None:
+                t.events.setdefault(self.key, []).append((self.a, b))
+        return False
+
+
+def timed(name, shape):
+    return _Timed(name, shape)
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -377,6 +408,7 @@ def pack_bf16(src, dst, batch_stride, row_stride, col_stride, zero_fill=True, of
 
 
 _shadows = {}
+_shadow_lock = threading.Lock()
 
 
 def _shadow(master, shape, tag):
@@ -385,11 +417,13 @@ def _shadow(master, shape, tag):
     of an allocation, a zero-fill kernel and a pack kernel per weight and step.  Keyed by the master's address: parameters
     keep theirs (views of the trainer's flat buffer), and a stale entry only ever has its interior overwritten."""
     key = (master.data_ptr(), tuple(shape), tag, master.device.index)
-    buf = _shadows.get(key)
-    if buf is None:
-        if len(_shadows) > 256:
-            _shadows.clear()
-        buf = _shadows[key] = torch.zeros(shape, device=master.device, dtype=torch.bfloat16)
+    with _shadow_lock:      # (nn.DataParallel-style callers drive one replica per thread)
+        buf = _shadows.get(key)
+        if buf is None:
+            # never evicted: a captured hipGraph holds the ADDRESS of a shadow and no Python reference to it, so freeing
+            # one would let replays write packed weights into memory the allocator has handed to someone else.  The set
+            # is bounded by (weights x layouts) of the models alive in the process.
+            buf = _shadows[key] = torch.zeros(shape, device=master.device, dtype=torch.bfloat16)
     return buf
 
 
@@ -637,7 +671,8 @@ class LinearAct(torch.autograd.Function):
             if act == 1:
                 gy = torch.ops.aten.threshold_backward(gy, y, 0)
                 act = 0
-            d_x = (gy.reshape(M, N) @ w).view(x.shape)
+            with timed("library_gemm", (M, K, N)):
+                d_x = (gy.reshape(M, N) @ w).view(x.shape)
         elif ctx.needs_input_grad[0]:
             d_x = torch.empty_like(x)
         in_kernel_dx = d_x is not None and not (p_drop == 0 and M >= 4096 and LinearAct.library_dgrad)
@@ -690,15 +725,18 @@ class LinearFn(torch.autograd.Function):
         ctx.relu = act == "relu"
         if act not in (None, "relu"):
             raise ValueError("linear: act must be None or 'relu', got %r" % (act,))
+        gemm = (x.numel() // x.shape[-1], w.shape[0], x.shape[-1])     # (M, N, K) of the library GEMM, for the timer
         if ctx.relu:
-            if b is not None and x.dtype == torch.float32 and hasattr(torch, "_addmm_activation"):
-                y = torch._addmm_activation(b, x.reshape(-1, x.shape[-1]), w.t(), use_gelu=False).view(*x.shape[:-1], w.shape[0])
-            else:
-                y = torch.relu(torch.nn.functional.linear(x, w, b))
+            with timed("library_gemm", gemm):
+                if b is not None and x.dtype == torch.float32 and hasattr(torch, "_addmm_activation"):
+                    y = torch._addmm_activation(b, x.reshape(-1, x.shape[-1]), w.t(), use_gelu=False).view(*x.shape[:-1], w.shape[0])
+                else:
+                    y = torch.relu(torch.nn.functional.linear(x, w, b))
             ctx.save_for_backward(x, w, y)
             return y
         ctx.save_for_backward(x, w)
-        return torch.nn.functional.linear(x, w, b)
+        with timed("library_gemm", gemm):
+            return torch.nn.functional.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, gy):
@@ -713,7 +751,10 @@ class LinearFn(torch.autograd.Function):
         if ctx.relu and not mask_in_kernel:
             gy = torch.ops.aten.threshold_backward(gy, y, 0)
         gy2 = gy.reshape(-1, gy.shape[-1])
-        d_x = (gy2 @ w).view(x.shape) if ctx.needs_input_grad[0] else None
+        d_x = None
+        if ctx.needs_input_grad[0]:
+            with timed("library_gemm", (M, K, N)):
+                d_x = (gy2 @ w).view(x.shape)
         if engine:
             # tall weight gradient (the region projections, M = B*N rows): the fp32 tile engine's split-row form, which
             # also returns the bias gradient as the column sums of its A fragments (no separate reduction) and, when no
@@ -728,7 +769,10 @@ class LinearFn(torch.autograd.Function):
             _launch("linear_act_bwd", (M, K, N, False, False), L_.vqa_linear_act_bwd, _p(x2), K, _p(w), _p(y2), _p(gy2),
                     None, _p(d_w), _p(d_b), _p(ws), ws_bytes, M, K, N, 1 if mask_in_kernel else 0, 0.0, 0, None)
             return d_x, d_w, d_b, None
-        d_w = gy2.t() @ x2 if ctx.needs_input_grad[1] else None
+        d_w = None
+        if ctx.needs_input_grad[1]:
+            with timed("library_gemm", (N, K, M)):
+                d_w = gy2.t() @ x2
         d_b = column_sum(gy2).to(gy.dtype) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return d_x, d_w, d_b, None
 
@@ -779,7 +823,8 @@ class BatchedLinearFn(torch.autograd.Function):
     def forward(ctx, x, w, b, group_first, act):
         # x [B,G,K] (any batch / group strides, K contiguous), w [G,A,K], b [G,A] (rows at any stride) or None
         #   -> [B,G,A] contiguous, or [G,B,A] contiguous when group_first
-        y = torch.bmm(x.transpose(0, 1), w.transpose(1, 2))          # [G,B,A]
+        with timed("library_gemm", (x.shape[1] * x.shape[0], w.shape[1], w.shape[2])):
+            y = torch.bmm(x.transpose(0, 1), w.transpose(1, 2))      # [G,B,A]
         G, B, A = y.shape
         code = _ACT_CODES[act]
         out = torch.empty((G, B, A) if group_first else (B, G, A), device=y.device, dtype=torch.float32)
@@ -806,8 +851,12 @@ class BatchedLinearFn(torch.autograd.Function):
             # written in the consumer's [B,G,K] layout (row stride G*K, batch stride K: a layout the strided-batched GEMM
             # takes as it is), so the kernels behind it get a contiguous gradient without a copy
             d_x = torch.empty(B, G, w.shape[2], device=gy.device, dtype=gz.dtype)
-            torch.bmm(gz, w, out=d_x.transpose(0, 1))
-        d_w = torch.bmm(gz.transpose(1, 2), x.transpose(0, 1)) if ctx.needs_input_grad[1] else None
+            with timed("library_gemm", (G * B, w.shape[2], A)):
+                torch.bmm(gz, w, out=d_x.transpose(0, 1))
+        d_w = None
+        if ctx.needs_input_grad[1]:
+            with timed("library_gemm", (G * A, w.shape[2], B)):
+                d_w = torch.bmm(gz.transpose(1, 2), x.transpose(0, 1))
         return d_x, d_w, d_b, None, None
 
 

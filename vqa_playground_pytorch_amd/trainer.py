@@ -246,6 +246,7 @@ class DataParallelTrainer:
             # pinned staging for the tiny per-step H2D copies: a ring, so a slot is not rewritten while an earlier
             # (asynchronous) copy from it may still be pending on the stream
             self._ring = 8
+            self._ring_events = [None] * self._ring       # recorded behind a slot's copies; waited for before it is rewritten
             self._step_scalars_host = torch.zeros(self._ring, 2, dtype=torch.float32).pin_memory()
             # per-step dropout seed of the fused kernels (K2, K5) in device memory: replays read the current value
             self.seed_word = torch.zeros(1, device=first.device, dtype=torch.int64)
@@ -256,6 +257,12 @@ class DataParallelTrainer:
             self.grads = FlatGradients(model.parameters())
             self.optimizer = torch.optim.Adam(self.grads.params, lr=lr)
 
+    @staticmethod
+    def _model_keys(sample):
+        """The entries of a sample dict the models read (config/CoR2.py:203-205): feeder batches also carry the target
+        'a' and 'q_id', which must not be cloned / re-copied into the graph's input buffers every step."""
+        return {"v", "q_idxes"} if "q_idxes" in sample else {"v", "q"}
+
     def shard(self, tensor):
         """This rank's contiguous slice of a global-batch tensor (rank r gets [r*B/P, (r+1)*B/P))."""
         if self.world == 1:
@@ -265,7 +272,10 @@ class DataParallelTrainer:
         return tensor[rank * per:(rank + 1) * per]
 
     def step(self, sample, target):
-        """One training step on this rank's shard; returns (local loss tensor, global grad norm tensor)."""
+        """One training step on this rank's shard; returns (local loss tensor, global grad norm tensor).
+        Replayed steps return the graph's OWN output tensors: the same two tensors every step, overwritten by the next
+        replay -- read them (``.item()`` / ``.clone()``) before the next step if you keep a history; eager steps return
+        fresh tensors."""
         if self.hip and self.want_graph:
             return self._graph_step(sample, target)
         return self.step_eager(sample, target)
@@ -328,11 +338,20 @@ class DataParallelTrainer:
         self.adam_steps += 1
         self._lr = lr = self.base_lr * self.gamma ** self.iteration
         slot = self.adam_steps % self._ring
+        # A replayed step costs the host a few launches per ~3 ms of GPU work, so a loop that never synchronises runs far
+        # ahead: without this wait the slot of step t could be rewritten with step t + ring's values before the GPU has
+        # executed the copy of step t (wrong lr / bias correction, the same dropout seed twice).
+        pending = self._ring_events[slot]
+        if pending is not None:
+            pending.synchronize()
         self._step_scalars_host[slot, 0] = lr / (1.0 - self.betas[0] ** self.adam_steps)
         self._step_scalars_host[slot, 1] = 1.0 / (1.0 - self.betas[1] ** self.adam_steps) ** 0.5
         self.step_scalars.copy_(self._step_scalars_host[slot], non_blocking=True)
         self._seed_host[slot, 0] = int(torch.randint(0, 2 ** 62, (1,), device="cpu").item())   # torch.manual_seed governs it
         self.seed_word.copy_(self._seed_host[slot], non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        self._ring_events[slot] = done
 
     def _graph_step(self, sample, target):
         from . import ops
@@ -380,7 +399,8 @@ class DataParallelTrainer:
         return g["loss"], f.norm_and_coef[0]
 
     def _capture(self, sample, target):
-        static_sample = {k: (v if self.adopt_inputs else v.clone()) for k, v in sample.items() if isinstance(v, torch.Tensor)}
+        static_sample = {k: (v if self.adopt_inputs else v.clone()) for k, v in sample.items()
+                         if isinstance(v, torch.Tensor) and k in self._model_keys(sample)}
         if not self.adopt_inputs:
             target = target.clone()
         # torch's capture recipe: one forward+backward on a side stream first, so the parameters' AccumulateGrad
@@ -412,6 +432,9 @@ class DataParallelTrainer:
         # are kernels, the loss and the bias gradients avoid torch's semaphore-based reductions -- and a step that
         # contains one anyway (a user-supplied seq2vec, a new torch op) must not be replayed.
         self.graph_nodes = {"front": graph_node_types(front), "tail": graph_node_types(tail)}
+        if any("kernel" not in c for c in self.graph_nodes.values()):
+            # the audit could not read the graphs (runtime library not queryable): unknown is not "clean" -- stay eager
+            raise RuntimeError("cannot audit the captured graphs for memset nodes (hipGraphGetNodes unavailable)")
         memsets = sum(c.get("memset", 0) for c in self.graph_nodes.values())
         if memsets:
             raise RuntimeError("captured step holds %d memset node(s), which do not replay reliably" % memsets)
@@ -516,7 +539,8 @@ class DataParallelTrainer:
         return g["loss"], f.norm_and_coef[0]
 
     def _capture_split(self, sample, target):
-        static_sample = {k: (v if self.adopt_inputs else v.clone()) for k, v in sample.items() if isinstance(v, torch.Tensor)}
+        static_sample = {k: (v if self.adopt_inputs else v.clone()) for k, v in sample.items()
+                         if isinstance(v, torch.Tensor) and k in self._model_keys(sample)}
         if not self.adopt_inputs:
             target = target.clone()
         side = torch.cuda.Stream()
@@ -542,6 +566,9 @@ class DataParallelTrainer:
         with torch.cuda.graph(graphs["tail"], pool=pool, capture_error_mode=mode):
             self._tail()
         self.graph_nodes = {k: graph_node_types(v) for k, v in graphs.items()}
+        if any("kernel" not in c for c in self.graph_nodes.values()):
+            # the audit could not read the graphs (runtime library not queryable): unknown is not "clean" -- stay eager
+            raise RuntimeError("cannot audit the captured graphs for memset nodes (hipGraphGetNodes unavailable)")
         memsets = sum(c.get("memset", 0) for c in self.graph_nodes.values())
         if memsets:
             raise RuntimeError("captured step holds %d memset node(s), which do not replay reliably" % memsets)
