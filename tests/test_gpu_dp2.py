@@ -1,0 +1,52 @@
+"""The multi-rank step on hardware that has ONE GPU: two ranks (gloo, device tensors) share cuda:0 and must reproduce the
+single-process step on the whole batch -- kernel by kernel and replayed from hipGraphs, with the single flat all-reduce and
+with the two-half backward whose first all-reduce runs under the second half (trainer.DataParallelTrainer; train.py:517's
+DataParallel replaced by one process per GPU).  The RCCL path itself needs >= 2 GPUs and is the driver's scaling run."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "tools", "dp2_one_gpu.py")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(world, env):
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env)
+    if world == 1:
+        cmd = [sys.executable, TOOL]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), TOOL]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and lines, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("model", ["cor2", "oda"])
+def test_two_ranks_on_one_gpu_match_one_process(model):
+    want = _run(1, {"G": "0", "MODEL": model})
+    assert want["world"] == 1 and len(want["losses"]) == 7
+    for graph in ("0", "1"):
+        for overlap in ("0", "1"):
+            got = _run(2, {"G": graph, "VQA_DP_OVERLAP": overlap, "MODEL": model})
+            tag = (model, graph, overlap)
+            assert got["world"] == 2, tag
+            assert got["graph"] == (graph == "1"), tag           # the step really was captured / really was not
+            assert got["overlap"] == (overlap == "1"), tag
+            for a, b in zip(got["losses"], want["losses"]):
+                assert abs(a - b) <= 1e-4 * abs(b), (tag, got["losses"], want["losses"])
+            for a, b in zip(got["norms"], want["norms"]):
+                assert abs(a - b) <= 1e-3 * abs(b), (tag, got["norms"], want["norms"])
+            assert abs(got["weight_digest"] - want["weight_digest"]) <= 1e-5 * abs(want["weight_digest"]) + 1e-6, tag

@@ -266,6 +266,67 @@ def test_lowrank_bilinear_fusion_golden(ops, golden_dir):
         close(name, p.grad, blocks["mutan2d.g." + name + ".full"])
 
 
+def test_block_goldens_conv_linear(ops, golden_dir):
+    """HIP-backed MyConv1d (softmax over regions, relu) and MyLinear (sigmoid) against the reference's own outputs
+    (tests/golden/blocks.npz conv_softmax / conv_relu / linear_sigmoid; config/CoR2.py:56-122), eval mode."""
+    blocks = np.load(os.path.join(golden_dir, "blocks.npz"))
+    from vqa_playground_pytorch_amd.layers import MyConv1d, MyLinear
+    f = g(seeded.seeded_array((3, 5, 16), 32))
+    cv = seeded.load_state(MyConv1d(16, 2, 1, 1, p=0.5, af="softmax", dim=1), 31).eval().to(dev())
+    close("conv_softmax", cv(f), blocks["conv_softmax.out"])
+    cr = seeded.load_state(MyConv1d(16, 7, 1, 1, p=0.5, af="relu"), 33).eval().to(dev())
+    close("conv_relu", cr(f), blocks["conv_relu.out"])
+    ml = seeded.load_state(MyLinear(16, 7, p=0.5, af="sigmoid"), 34).eval().to(dev())
+    close("linear_sigmoid", ml(f), blocks["linear_sigmoid.out"])
+
+
+def test_block_goldens_attention(ops, golden_dir):
+    """HIP-backed MyATT (K3a logits + K3 softmax/pooling + the batched glimpse projections) against the reference's MyATT:
+    outputs, input gradients and every parameter gradient (blocks.npz att.*; config/CoR2.py:125-157)."""
+    blocks = np.load(os.path.join(golden_dir, "blocks.npz"))
+    from vqa_playground_pytorch_amd.layers import MyATT
+    att = seeded.load_state(MyATT(16, 2, 12, 8, af="relu"), 41).eval().to(dev())
+    inp, fu = g(seeded.seeded_array((3, 5, 12), 42), True), g(seeded.seeded_array((3, 5, 16), 43), True)
+    xv, latt = att(inp, fu)
+    assert isinstance(latt, (tuple, list)) and len(latt) == 2 and latt[0].shape == (3, 5, 1)
+    alpha = torch.cat(list(latt), dim=2)
+    ((xv * g(seeded.seeded_array((3, 8), 44))).sum() + (alpha * g(seeded.seeded_array((3, 5, 2), 45))).sum()).backward()
+    close("att.x_v", xv, blocks["att.x_v"])
+    close("att.alpha", alpha, blocks["att.alpha"])
+    close("att.dinputs", inp.grad, blocks["att.dinputs"])
+    close("att.dfuse", fu.grad, blocks["att.dfuse"])
+    for name, p in att.named_parameters():
+        want = blocks["att.g." + name + ".full"]
+        got = p.grad.detach().cpu().numpy().astype(np.float64)
+        # (the conv bias sits in front of a softmax over regions: its gradient is mathematically zero, rounding noise on
+        #  both sides -- compared absolutely)
+        assert np.abs(got - want).max() <= RTOL * np.abs(want).max() + 1e-7, name
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_block_goldens_relation(ops, golden_dir, mode):
+    """K1 (pairwise and factored form) against the reference's decare_cat + alpha-weighted reduce at small dims
+    (blocks.npz decare.*; config/CoR2.py:191-199, :216); the gates come from HIP-backed MyLinear stacks."""
+    blocks = np.load(os.path.join(golden_dir, "blocks.npz"))
+    from vqa_playground_pytorch_amd.layers import MyLinear
+    mods = [seeded.load_state(MyLinear(6, 4, p=0.5, af="relu"), 51), seeded.load_state(MyLinear(4, 12, p=0.5, af="sigmoid"), 52),
+            seeded.load_state(MyLinear(6, 4, p=0.5, af="relu"), 53), seeded.load_state(MyLinear(4, 12, p=0.5, af="sigmoid"), 54)]
+    c1, e1, c2, e2 = (m.eval().to(dev()) for m in mods)
+    vv, qq = g(seeded.seeded_array((3, 5, 12), 55)), g(seeded.seeded_array((3, 6), 56))
+    al = torch.softmax(g(seeded.seeded_array((3, 5, 1), 57)), dim=1)
+    q1, q2 = e1(c1(qq)), e2(c2(qq))
+    close("decare.q1", q1, blocks["decare.q1"])
+    close("decare.q2", q2, blocks["decare.q2"])
+    v2 = ops.pairwise_relation_reduce(vv, q1, q2, al.contiguous(), glimpse=0, mode=mode)
+    close("decare.v2", v2, blocks["decare.v2"])
+    # the materialised pairwise tensor itself, row by row through the kernel: a one-hot alpha picks out[b, i, :, :]
+    cat = blocks["decare.cat"]                                        # [3, 5, 5, 12]: [b, i, j, :] = v_i q1 + v_j q2
+    for i in range(5):
+        onehot = torch.zeros(3, 5, 1, device=dev())
+        onehot[:, i] = 1.0
+        close("decare.cat[:, %d]" % i, ops.pairwise_relation_reduce(vv, q1, q2, onehot, glimpse=0, mode=mode), cat[:, i])
+
+
 @pytest.mark.parametrize("form", ["folded", "engine"])
 def test_lowrank_bilinear_fusion_full_size_properties(ops, monkeypatch, form):
     """B=512 (M=18432): rank-sum linearity in h2 and agreement with a torch fp32 matmul restatement on GPU."""

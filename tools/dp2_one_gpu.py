@@ -1,24 +1,55 @@
-# two ranks on ONE GPU with gloo (CUDA tensors): exercises graph replay + the all-reduce(s) between the graphs.
-#   G=1|0 graph replay or eager;  VQA_DP_OVERLAP=1: backward in two halves, first all-reduce under the second half
-import os, sys, torch, torch.distributed as dist
-sys.path.insert(0, os.getcwd())
-from vqa_playground_pytorch_amd import CoR2Model
-from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
-dist.init_process_group("gloo")
-rank = dist.get_rank()
-dev = torch.device("cuda:0"); torch.cuda.set_device(0)
-torch.manual_seed(rank)
-model = CoR2Model(["PAD"], 300).to(dev).eval()
+#!/usr/bin/env python3
+"""Two data-parallel ranks on ONE GPU (gloo with device tensors): exercises the multi-rank step -- per-rank shards, the
+flat-gradient SUM all-reduce between the replayed hipGraphs, the two-half backward with the first all-reduce under the
+second half -- on a single-GPU box.  Rank 0 prints ONE JSON line with the global losses / gradient norms of 7 steps.
+
+    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/dp2_one_gpu.py
+    python tools/dp2_one_gpu.py            # the same steps in one process on the whole batch (the expected record)
+  env: G=1|0 graph replay or kernel by kernel;  VQA_DP_OVERLAP=1: backward in two halves;  MODEL=cor2|oda
+(tests/test_gpu_dp2.py runs all combinations and compares them with the single-process record.)"""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vqa_playground_pytorch_amd import CoR2Model, ODAModel  # noqa: E402
+from vqa_playground_pytorch_amd.trainer import DataParallelTrainer  # noqa: E402
+
+multi = "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1
+if multi:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+rank = dist.get_rank() if multi else 0
+dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+torch.manual_seed(100 + rank)              # different initial weights per rank: the trainer broadcasts rank 0's
+cls = {"cor2": CoR2Model, "oda": ODAModel}[os.environ.get("MODEL", "cor2")]
+if rank == 0:
+    torch.manual_seed(100)
+model = cls(["PAD"], 300).to(dev).eval()    # eval mode: no dropout, so N ranks on shards == 1 process on the batch
 tr = DataParallelTrainer(model, lr=1e-4, graph=os.environ.get("G", "1") == "1")
 torch.manual_seed(5)
-v = torch.randn(8, 36, 2048, device=dev); q = torch.randn(8, 2400, device=dev); a = torch.softmax(torch.randn(8, 300, device=dev), 1)
-out = []
-for i in range(7):
+v, q = torch.randn(8, 36, 2048, device=dev), torch.randn(8, 2400, device=dev)
+a = torch.softmax(torch.randn(8, 300, device=dev), 1)
+losses, norms = [], []
+for _ in range(7):
     loss, norm = tr.step({"v": tr.shard(v), "q_idxes": tr.shard(q)}, tr.shard(a))
-    t = loss.clone(); dist.all_reduce(t)
-    out.append((round(t.item(), 4), round(norm.item(), 3)))
-if rank == 0: print(("graph" if tr._graph is not None else "eager") + (" overlap" if tr.overlap else ""), out, flush=True)
+    t = loss.clone()
+    if multi:
+        dist.all_reduce(t)
+    losses.append(t.item())
+    norms.append(norm.item())
 w = torch.cat([p.detach().reshape(-1)[:100] for p in model.parameters()])
-w2 = w.clone(); dist.broadcast(w2, 0)
-assert torch.equal(w, w2), "replicas diverged"
-dist.barrier(); dist.destroy_process_group()
+if multi:
+    w0 = w.clone()
+    dist.broadcast(w0, 0)
+    assert torch.equal(w, w0), "replicas diverged"
+if rank == 0:
+    print(json.dumps({"world": dist.get_world_size() if multi else 1, "graph": tr._graph is not None, "overlap": bool(tr.overlap),
+                      "losses": losses, "norms": norms, "weight_digest": float(w.double().sum().item())}), flush=True)
+if multi:
+    dist.barrier()
+    dist.destroy_process_group()

@@ -13,6 +13,8 @@
 // Every kernel is a template on the storage type T of the region tensors (v, v2, g, d_v): float, or bf16 for the
 // mixed-precision path (BASELINE configs[4]; half the bytes, all arithmetic still fp32 in registers).  q1, q2,
 // alpha and their gradients are fp32 in both.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace vqa {
@@ -110,6 +112,55 @@ __global__ __launch_bounds__(64) void pairwise_fwd_reg_kernel(const T* __restric
     if (j < N)
       st4(v2 + base + (size_t)j * D, make_float4(fmaf(c2.x, r[j].x, s1.x), fmaf(c2.y, r[j].y, s1.y),
                                                  fmaf(c2.z, r[j].z, s1.z), fmaf(c2.w, r[j].w, s1.w)));
+  }
+}
+
+// Pairwise form from registers (mode 0, N <= kRegN): the kernel north_star describes -- every (i, j) term of the relation
+// tensor v_i*q1 + v_j*q2 is formed and weighted by alpha_i, as the reference sums it (config/CoR2.py:191-199, :216) -- with
+// the region rows of a lane's float4 column held in VGPRs instead of an LDS tile.  The LDS version issued N*N
+// ds_read_b128 per lane (24 TB/s of LDS reads chip-wide at B = 512: 225 us, 0.17 of the HBM roofline); from registers
+// the inner sum is 2*N*N packed FMAs per lane (v_pk_fma_f32: two components per instruction) -- ~20 us of VALU at the
+// chip's rate, under the ~50 us the 302 MB of v and v2 take at HBM speed.  alpha is wave-uniform (one sample per
+// workgroup row): scalar loads, broadcast operands.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T>
+__global__ __launch_bounds__(64, 3) void pairwise_fwd_pairs_reg_kernel(const T* __restrict__ v, const float* __restrict__ q1,
+                                                                    const float* __restrict__ q2,
+                                                                    const float* __restrict__ alpha, int astride,
+                                                                    T* __restrict__ v2, int N, int D) {
+  const int b = blockIdx.y;
+  const int d = (blockIdx.x * 64 + threadIdx.x) * 4;
+  if (d >= D) return;
+  const size_t base = (size_t)b * N * D + d;
+  f32x2 lo[kRegN], hi[kRegN];   // components (x, y) and (z, w) of the N rows of this lane's column
+#pragma unroll
+  for (int i = 0; i < kRegN; ++i) {
+    const float4 t = ld4(v + base + (size_t)min(i, N - 1) * D);
+    lo[i] = f32x2{t.x, t.y};
+    hi[i] = f32x2{t.z, t.w};
+  }
+  const float4 q1v = ld4(q1 + (size_t)b * D + d), q2v = ld4(q2 + (size_t)b * D + d);
+  const f32x2 q1l = {q1v.x, q1v.y}, q1h = {q1v.z, q1v.w}, q2l = {q2v.x, q2v.y}, q2h = {q2v.z, q2v.w};
+  float a[kRegN];
+#pragma unroll
+  for (int i = 0; i < kRegN; ++i) a[i] = i < N ? alpha[((size_t)b * N + i) * astride] : 0.f;   // rows >= N weigh nothing
+  // The j loop is not unrolled (36 x 36 x 4 FMAs of straight-line code would be 40 KB), so row j cannot be picked from
+  // the register file by a constant index: it is loaded again (an L1 / L2 hit -- this lane fetched it microseconds ago),
+  // one iteration ahead of its use.
+  float4 vnext = ld4(v + base);
+  for (int j = 0; j < N; ++j) {
+    const float4 vj = vnext;
+    vnext = ld4(v + base + (size_t)min(j + 1, N - 1) * D);
+    const f32x2 tl = f32x2{vj.x, vj.y} * q2l, th = f32x2{vj.z, vj.w} * q2h;
+    f32x2 accl = {0.f, 0.f}, acch = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < kRegN; ++i) {
+      const f32x2 ai = {a[i], a[i]};
+      accl = __builtin_elementwise_fma(ai, __builtin_elementwise_fma(lo[i], q1l, tl), accl);
+      acch = __builtin_elementwise_fma(ai, __builtin_elementwise_fma(hi[i], q1h, th), acch);
+    }
+    st4(v2 + base + (size_t)j * D, make_float4(accl.x, accl.y, acch.x, acch.y));
   }
 }
 
@@ -345,6 +396,11 @@ static int pairwise_fwd_impl(const char* who, const T* v, const float* q1, const
     constexpr int NT = 256;
     hipLaunchKernelGGL((pairwise_fwd_stream_kernel<T, NT>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), (size_t)N * 4, s, v, q1, q2,
                        alpha, alpha_stride, v2, N, D);
+    return check_launch(who);
+  }
+  if (N <= kRegN && std::getenv("VQA_K1_PAIRWISE_LDS") == nullptr) {   // (the env knob keeps the LDS-tile form reachable)
+    hipLaunchKernelGGL(pairwise_fwd_pairs_reg_kernel<T>, dim3((D / 4 + 63) / 64, B), dim3(64), 0, s, v, q1, q2, alpha,
+                       alpha_stride, v2, N, D);
     return check_launch(who);
   }
   VQA_REQUIRE(N <= 144, VQA_E_UNSUPPORTED, "%s: N=%d exceeds the LDS tile limit 144 of mode 0", who, N);
