@@ -49,4 +49,6 @@ def test_two_ranks_on_one_gpu_match_one_process(model):
                 assert abs(a - b) <= 1e-4 * abs(b), (tag, got["losses"], want["losses"])
             for a, b in zip(got["norms"], want["norms"]):
                 assert abs(a - b) <= 1e-3 * abs(b), (tag, got["norms"], want["norms"])
-            assert abs(got["weight_digest"] - want["weight_digest"]) <= 1e-5 * abs(want["weight_digest"]) + 1e-6, tag
+            # (a sum over a few thousand weights after 7 Adam steps: the two ranks add their gradient halves in another
+            #  order than one process does, and Adam's normalisation amplifies rounding where a gradient is near zero)
+            assert abs(got["weight_digest"] - want["weight_digest"]) <= 1e-4 * abs(want["weight_digest"]) + 1e-5, tag

@@ -298,9 +298,10 @@ def test_block_goldens_attention(ops, golden_dir):
     for name, p in att.named_parameters():
         want = blocks["att.g." + name + ".full"]
         got = p.grad.detach().cpu().numpy().astype(np.float64)
-        # (the conv bias sits in front of a softmax over regions: its gradient is mathematically zero, rounding noise on
-        #  both sides -- compared absolutely)
-        assert np.abs(got - want).max() <= RTOL * np.abs(want).max() + 1e-7, name
+        # (the conv bias sits in front of a softmax over regions: its gradient is mathematically zero -- the sum of O(1)
+        #  terms that cancel, i.e. ~1e-7 of rounding noise on both sides -- and is compared absolutely)
+        atol = 1e-6 if name == "conv_att.conv.bias" else 1e-7
+        assert np.abs(got - want).max() <= RTOL * np.abs(want).max() + atol, name
 
 
 @pytest.mark.parametrize("mode", [0, 1])

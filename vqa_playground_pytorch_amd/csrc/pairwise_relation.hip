@@ -146,12 +146,12 @@ __global__ __launch_bounds__(64, 3) void pairwise_fwd_pairs_reg_kernel(const T* 
 #pragma unroll
   for (int i = 0; i < kRegN; ++i) a[i] = i < N ? alpha[((size_t)b * N + i) * astride] : 0.f;   // rows >= N weigh nothing
   // The j loop is not unrolled (36 x 36 x 4 FMAs of straight-line code would be 40 KB), so row j cannot be picked from
-  // the register file by a constant index: it is loaded again (an L1 / L2 hit -- this lane fetched it microseconds ago),
-  // one iteration ahead of its use.
-  float4 vnext = ld4(v + base);
+  // the register file by a constant index: it is loaded again (an L1 / L2 hit -- this lane fetched it microseconds ago).
+  float4 n1 = ld4(v + base), n2 = ld4(v + base + (size_t)min(1, N - 1) * D);   // two ahead: see pairwise_fwd_pairs_reg2_kernel
   for (int j = 0; j < N; ++j) {
-    const float4 vj = vnext;
-    vnext = ld4(v + base + (size_t)min(j + 1, N - 1) * D);
+    const float4 vj = n1;
+    n1 = n2;
+    n2 = ld4(v + base + (size_t)min(j + 2, N - 1) * D);
     const f32x2 tl = f32x2{vj.x, vj.y} * q2l, th = f32x2{vj.z, vj.w} * q2h;
     f32x2 accl = {0.f, 0.f}, acch = {0.f, 0.f};
 #pragma unroll
@@ -161,6 +161,45 @@ __global__ __launch_bounds__(64, 3) void pairwise_fwd_pairs_reg_kernel(const T* 
       acch = __builtin_elementwise_fma(ai, __builtin_elementwise_fma(hi[i], q1h, th), acch);
     }
     st4(v2 + base + (size_t)j * D, make_float4(accl.x, accl.y, acch.x, acch.y));
+  }
+}
+
+// The same with a float2 column per lane (fp32 storage): 72 row registers instead of 144, so 5-6 waves share a SIMD instead
+// of 3 and twice as many, half-sized waves pass through it.  A wave loads its rows, runs its N x N sum, stores -- with few
+// large waves the whole chip is in the same phase at the same time and the 302 MB of traffic do not overlap with the
+// 2 N N packed FMAs per lane (99 us); with many small ones the phases interleave.
+__global__ __launch_bounds__(64, 5) void pairwise_fwd_pairs_reg2_kernel(const float* __restrict__ v, const float* __restrict__ q1,
+                                                                     const float* __restrict__ q2,
+                                                                     const float* __restrict__ alpha, int astride,
+                                                                     float* __restrict__ v2, int N, int D) {
+  const int b = blockIdx.y;
+  const int d = (blockIdx.x * 64 + threadIdx.x) * 2;
+  if (d >= D) return;
+  const size_t base = (size_t)b * N * D + d;
+  f32x2 r[kRegN];
+#pragma unroll
+  for (int i = 0; i < kRegN; ++i) r[i] = *reinterpret_cast<const f32x2*>(v + base + (size_t)min(i, N - 1) * D);
+  const f32x2 q1v = *reinterpret_cast<const f32x2*>(q1 + (size_t)b * D + d);
+  const f32x2 q2v = *reinterpret_cast<const f32x2*>(q2 + (size_t)b * D + d);
+  float a[kRegN];
+#pragma unroll
+  for (int i = 0; i < kRegN; ++i) a[i] = i < N ? alpha[((size_t)b * N + i) * astride] : 0.f;
+  // Row j again (an L1 / L2 hit), TWO iterations ahead of its use: vmcnt counts loads and stores in issue order, so a
+  // reload issued right behind the store of row j - 1 could only be waited for with vmcnt(0) -- i.e. together with that
+  // store's whole HBM round trip, once per row (88 us).  Two ahead, the wait leaves the younger store in flight.
+  f32x2 n1 = *reinterpret_cast<const f32x2*>(v + base);
+  f32x2 n2 = *reinterpret_cast<const f32x2*>(v + base + (size_t)min(1, N - 1) * D);
+  for (int j = 0; j < N; ++j) {
+    const f32x2 tj = n1 * q2v;
+    n1 = n2;
+    n2 = *reinterpret_cast<const f32x2*>(v + base + (size_t)min(j + 2, N - 1) * D);
+    f32x2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < kRegN; ++i) {
+      const f32x2 ai = {a[i], a[i]};
+      acc = __builtin_elementwise_fma(ai, __builtin_elementwise_fma(r[i], q1v, tj), acc);
+    }
+    *reinterpret_cast<f32x2*>(v2 + base + (size_t)j * D) = acc;
   }
 }
 
@@ -399,8 +438,16 @@ static int pairwise_fwd_impl(const char* who, const T* v, const float* q1, const
     return check_launch(who);
   }
   if (N <= kRegN && std::getenv("VQA_K1_PAIRWISE_LDS") == nullptr) {   // (the env knob keeps the LDS-tile form reachable)
-    hipLaunchKernelGGL(pairwise_fwd_pairs_reg_kernel<T>, dim3((D / 4 + 63) / 64, B), dim3(64), 0, s, v, q1, q2, alpha,
-                       alpha_stride, v2, N, D);
+    const int tiles_d = (D / 4 + 63) / 64;
+    if constexpr (sizeof(T) == 4) {
+      if ((long)B * D >= (1L << 19) && std::getenv("VQA_K1_PAIRWISE_REG4") == nullptr) {   // enough columns for half-sized waves
+        hipLaunchKernelGGL(pairwise_fwd_pairs_reg2_kernel, dim3((D / 2 + 63) / 64, B), dim3(64), 0, s, v, q1, q2, alpha,
+                           alpha_stride, v2, N, D);
+        return check_launch(who);
+      }
+    }
+    hipLaunchKernelGGL(pairwise_fwd_pairs_reg_kernel<T>, dim3(tiles_d, B), dim3(64), 0, s, v, q1, q2, alpha, alpha_stride, v2,
+                       N, D);
     return check_launch(who);
   }
   VQA_REQUIRE(N <= 144, VQA_E_UNSUPPORTED, "%s: N=%d exceeds the LDS tile limit 144 of mode 0", who, N);
