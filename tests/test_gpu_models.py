@@ -348,8 +348,8 @@ def test_graph_replays_far_behind_the_host_keep_their_step_scalars():
     from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
     v, q, a = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(8, answers=300, seed=71))
     finals = []
-    for queued in (False, True):
-        model = build("cor2", 300)                          # eval mode: no dropout, deterministic
+    for queued in (False, False, True):
+        model = build("cor2", 300)                          # eval mode: no dropout
         tr = DataParallelTrainer(model, lr=1e-3, clip=0.25, gamma=0.9, graph=True)     # gamma 0.9: lr moves fast per step
         for _ in range(4):
             tr.step({"v": v, "q_idxes": q}, a)
@@ -363,9 +363,13 @@ def test_graph_replays_far_behind_the_host_keep_their_step_scalars():
                 torch.cuda.synchronize()
         torch.cuda.synchronize()
         finals.append(tr.flat.p.clone())
-    diff = (finals[0] - finals[1]).abs().max().item()
-    scale = finals[0].abs().max().item()
-    assert diff <= 1e-6 * scale, (diff, scale)
+    # two synchronised runs differ by the float atomics of the backward kernels (amplified by Adam where a gradient is
+    # near zero): that is the noise floor.  A rewritten ring slot would apply lr * 0.9^8 = 0.43 lr in a step: the summed
+    # update of the 24 steps (~9e-3 per weight) would move by tens of per cent, far above it.
+    noise = (finals[0] - finals[1]).abs().max().item()
+    diff = (finals[0] - finals[2]).abs().max().item()
+    assert diff <= 3.0 * noise + 1e-6, (diff, noise)
+    assert diff <= 1e-3, (diff, noise)
 
 
 def test_graph_trainer_respects_train_eval_switch():

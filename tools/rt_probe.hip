@@ -33,8 +33,9 @@ struct EpiBiasRelu {
   float* y;
   const float* bias;
   int ldy, act;
+  float scale;
   __device__ __forceinline__ void operator()(int row, int col, float v) const {
-    v += bias != nullptr ? bias[col] : 0.f;
+    v = v * scale + (bias != nullptr ? bias[col] : 0.f);
     if (act == 1) v = fmaxf(v, 0.f);
     y[(size_t)row * ldy + col] = v;
   }
@@ -146,7 +147,7 @@ static void launch_nt(const float* A, int lda, const float* B, int ldb, const fl
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::kLdsBytes));
     once = true;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(rt::kThreads), S::kLdsBytes, 0, p, dc, EpiBiasRelu{y, bias, N, act});
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(rt::kThreads), S::kLdsBytes, 0, p, dc, EpiBiasRelu{y, bias, N, act, (DROP && dc.p8 > 0) ? dc.scale : 1.f});
 }
 
 int main(int argc, char** argv) {
@@ -208,6 +209,13 @@ int main(int argc, char** argv) {
     float ms = time_ms([&] { __VA_ARGS__; }, iters);                                                          \
     printf("  exp %-40s %.1f us  %.1f TF/s\n", label, ms * 1e3, flop / ms / 1e9);                              \
   }
+      {
+        const DropCfg dch = make_drop(0.5f, 777);
+        RT_TIME("dropout, VALU unpinned (TUNE 0)", (launch_nt<9, 5, 1, 2, 2, true, 0>(A, K, B, K, bias, y, M, N, K, 1, dch)));
+        RT_TIME("dropout, VALU 1 per MFMA (TUNE 32)", (launch_nt<9, 5, 1, 2, 2, true, 32>(A, K, B, K, bias, y, M, N, K, 1, dch)));
+        RT_TIME("no dropout (TUNE 0)", (launch_nt<9, 5, 1, 2, 2, false, 0>(A, K, B, K, bias, y, M, N, K, 1, dc0)));
+        RT_TIME("dropout, VALU unpinned (TUNE 0) again", (launch_nt<9, 5, 1, 2, 2, true, 0>(A, K, B, K, bias, y, M, N, K, 1, dch)));
+      }
       RT_TIME("stamped (TUNE 16)", (launch_nt<9, 5, 1, 2, 2, false, 16>(A, K, B, K, bias, y, M, N, K, 1, dc0, stamps)));
       clock_report("real kernel");
       RT_TIME("no loads in loop (TUNE 17)", (launch_nt<9, 5, 1, 2, 2, false, 17>(A, K, B, K, bias, y, M, N, K, 1, dc0, stamps)));
@@ -231,14 +239,14 @@ int main(int argc, char** argv) {
     }
     // ragged shape: M, N, K all off the tile grid
     {
-      const int M2 = 1000, K2 = 316, N2 = 170;
+      const int M2 = 1000, K2 = 352, N2 = 170;
       const DropCfg dc = make_drop(0.5f, 99);
       ref_nt_kernel<<<dim3((N2 + 63) / 64, M2), 64>>>(A, K2, B, K2, bias, yref, M2, N2, K2, 0, dc);
       CK(hipMemset(y, 0xff, (size_t)M2 * N2 * 4));
       launch_nt<9, 5, 1, 2, 2, true>(A, K2, B, K2, bias, y, M2, N2, K2, 0, dc);
       CK(hipDeviceSynchronize());
       CK(hipGetLastError());
-      compare("fwd ragged 1000x316x170 dropout", y, yref, (size_t)M2 * N2, N2);
+      compare("fwd ragged 1000x352x170 dropout", y, yref, (size_t)M2 * N2, N2);
     }
     // ------------------------------------------------------------ NT: data gradient  dx = gz [M,310] W^T[2048,312]
     {

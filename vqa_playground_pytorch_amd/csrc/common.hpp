@@ -124,10 +124,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
 
-// ---- counter-based dropout (shared by K2 and the fused linear) ---------------------------------
-// One 32-bit hash word serves four mask elements, one byte each: keep iff byte >= p8, so the drop
-// probability is realised as round(p*256)/256 (p = 0.5 is exact) and kept values are scaled by
-// 256/(256-p8).  Forward and backward regenerate identical masks from (seed, element index).
+// ---- counter-based dropout (the fused linear kernels, K1 apply, K3a; K2 keeps its own counter layout) -----------
+// The mask of element e of a row-major tensor is a pure function of (seed, e); forward and backward regenerate it.
+//   p = 0.5 (p8 == 128, the only rate the models use): ONE BIT per element -- keep iff bit (e & 31) of the hash word of
+//     counter e >> 5 is set, kept values scaled by 2.  32 elements per hash word: next to fp32 MFMAs VALU work is not
+//     hidden (the matrix pipe and the vector ALU share the FMA datapath), so the hashes per element are what the mask costs.
+//   any other rate: one BYTE per element (byte e & 3 of the word of counter e >> 2), keep iff byte >= p8, so the drop
+//     probability is realised as round(p*256)/256 and kept values are scaled by 256/(256-p8).
 // lowbias32 finaliser (two 32-bit multiplies -- v_mul_lo_u32 is quarter rate, so multiplies are what a hash costs
 // here).  A bijection of the 32-bit counter xor-ed with a per-call key, so distinct elements never share a word.
 __device__ __forceinline__ uint32_t mask_word32(uint32_t counter, uint32_t key) {
@@ -162,16 +165,23 @@ inline DropCfg make_drop(float p, uint64_t seed, const uint64_t* seed_ptr = null
 }
 
 
-// multipliers for the two consecutive elements e (even) and e+1 of a row-major tensor with < 2^32 elements
 __device__ __forceinline__ uint32_t drop_key(const DropCfg& dc) {
   const uint64_t s = dc.effective();
   return (uint32_t)s ^ ((uint32_t)(s >> 32) * 0x9E3779B9u);
 }
+constexpr uint32_t kDropHalf = 128u;   // p8 of p = 0.5: the one-bit-per-element form
+// factor (0 or 1/(1-p)) of element e of a row-major tensor with < 2^32 elements
 __device__ __forceinline__ float drop_one(uint32_t e, const DropCfg& dc) {
+  if (dc.p8 == kDropHalf) return ((mask_word32(e >> 5, drop_key(dc)) >> (e & 31u)) & 1u) != 0u ? 2.f : 0.f;
   const uint32_t w = mask_word32(e >> 2, drop_key(dc)) >> (8 * (e & 3));
   return (w & 255u) >= dc.p8 ? dc.scale : 0.f;
 }
+// the two consecutive elements e (even) and e + 1
 __device__ __forceinline__ float2 drop_pair(uint32_t e, const DropCfg& dc) {
+  if (dc.p8 == kDropHalf) {
+    const uint32_t w = mask_word32(e >> 5, drop_key(dc)) >> (e & 31u);
+    return make_float2((w & 1u) != 0u ? 2.f : 0.f, (w & 2u) != 0u ? 2.f : 0.f);
+  }
   const uint32_t w = mask_word32(e >> 2, drop_key(dc)) >> (8 * (e & 3));
   return make_float2((w & 255u) >= dc.p8 ? dc.scale : 0.f, ((w >> 8) & 255u) >= dc.p8 ? dc.scale : 0.f);
 }

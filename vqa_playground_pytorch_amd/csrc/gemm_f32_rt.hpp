@@ -19,6 +19,8 @@
 // 4 r .. 4 r + 3 of a 64-column span as one 16-byte load, component c feeds accumulator block c, and the four blocks of a
 // span come back together as 16-byte stores.
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace vqa {
@@ -44,15 +46,16 @@ __device__ __forceinline__ float ldg4(rsrc_t r, uint32_t off, uint32_t soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, (int)soff, 0));
 }
 
-// keep/(1-p) factors of the four elements 4 w .. 4 w + 3 of the counter-hash dropout (common.hpp: one word, one byte each)
-__device__ __forceinline__ f32x4 drop4(uint32_t word_index, uint32_t key, uint32_t p8, float scale) {
-  const uint32_t w = mask_word32(word_index, key);
-  f32x4 m;
-  m[0] = (w & 255u) >= p8 ? scale : 0.f;
-  m[1] = ((w >> 8) & 255u) >= p8 ? scale : 0.f;
-  m[2] = ((w >> 16) & 255u) >= p8 ? scale : 0.f;
-  m[3] = (w >> 24) >= p8 ? scale : 0.f;
-  return m;
+// p = 0.5 dropout in registers (common.hpp: ONE BIT per element, bit e & 31 of the hash word of counter e >> 5).  `bits`
+// holds the four mask bits of the float4 in its low nibble; the kept values are NOT scaled here -- the factor 2 is applied
+// once per output element in the epilogue.  Two VALU instructions per element (v_bfe_i32 + v_and_b32).
+__device__ __forceinline__ void keep4_bits(f32x4& x, uint32_t bits) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t m = 0u - ((bits >> e) & 1u);      // all ones / all zeros (v_bfe_i32)
+    const float xe = x[e];                           // (a bit_cast of the vector-element lvalue itself reads element 0)
+    x[e] = __uint_as_float(__float_as_uint(xe) & m);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -61,7 +64,9 @@ __device__ __forceinline__ f32x4 drop4(uint32_t word_index, uint32_t key, uint32
 // Workgroup tile (16 RB WM) x (16 CB WN); WK waves split the contraction range and are summed through LDS at the end
 // (WM WN WK = 4).  `epi(row, col, value)` is called once per valid output element by the lane that holds it: lanes r = 0..15
 // hold 16 consecutive columns of one row, register t the rows 4 g + t.
-// DROP: A is multiplied by the dropout mask of element (m, k) while it is in registers (needs K % 4 == 0).
+// DROP: A is masked by the p = 0.5 dropout of element (m, k) while it is in registers (needs K % 32 == 0: a row block's
+// hash word then serves two consecutive chunks); the kept values' factor 2 is the epilogue's (`epi` receives acc * 2... the
+// caller's functor applies dc.scale).
 // ------------------------------------------------------------------------------------------------------------------
 struct NtArgs {
   const float* A;
@@ -96,12 +101,14 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg 
 
   // per-lane byte offsets of the fragment rows (clamped: loads are unconditional, out-of-range rows are never stored)
   uint32_t offA[RB], offB[CB];
-  uint32_t wordA[RB];   // DROP: index of the hash word of (row, k = 4 g), to which 4 c is added per chunk
+  uint32_t wordA[RB];   // DROP: index of the hash word of (row, k = 0), to which c / 2 is added per pair of chunks
+  uint32_t hw[RB];      // DROP: the hash words of the current pair of chunks
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
     const int row = min(m0 + 16 * i + r, p.M - 1);
     offA[i] = ((uint32_t)row * (uint32_t)p.lda + 4u * g) * 4u;
-    wordA[i] = ((uint32_t)row * (uint32_t)p.K + 4u * g) >> 2;
+    wordA[i] = ((uint32_t)row * (uint32_t)p.K) >> 5;
+    hw[i] = 0u;
   }
 #pragma unroll
   for (int j = 0; j < CB; ++j) {
@@ -119,8 +126,8 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg 
     for (int j = 0; j < CB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nfull = p.K >> 4;                       // whole 16-deep chunks
-  const int per = (nfull + WK - 1) / WK;
-  const int c_lo = wk * per, c_hi = min(nfull, c_lo + per);
+  const int per = ((nfull + WK - 1) / WK + 1) & ~1; // per wave: even, so every wave starts on an even chunk (DROP pairs them)
+  const int c_lo = min(nfull, wk * per), c_hi = min(nfull, c_lo + per);
 
   auto load = [&](f32x4(&a)[RB], f32x4(&b)[CB], int c) {
     const uint32_t so = (uint32_t)c * 64u;
@@ -138,29 +145,39 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg 
       for (int j = 0; j < CB; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[kb], b[j][kb], acc[i][j], 0, 0, 0);
   };
-  auto mask_row = [&](f32x4& ai, int i, int c) { ai *= drop4(wordA[i] + 4u * (uint32_t)c, key, dc.p8, dc.scale); };
-  auto compute = [&](f32x4(&a)[RB], f32x4(&b)[CB], int c) {   // one chunk on its own (odd chunk, prologue)
+  // DROP: chunk c covers the elements k = 16 c + 4 g .. + 3 of the lane's row: bits 16 (c & 1) + 4 g .. + 3 of the hash word
+  // of counter (row K + 16 c) >> 5.  FRESH (c even): the word is computed; c odd: the one of c - 1 is reused.
+  auto mask_row = [&](f32x4& ai, int i, int c, bool fresh) {
+    if (fresh) hw[i] = mask_word32(wordA[i] + (uint32_t)(c >> 1), key);
+    keep4_bits(ai, hw[i] >> (4u * g + 16u * (uint32_t)(c & 1)));
+  };
+  auto compute = [&](f32x4(&a)[RB], f32x4(&b)[CB], int c) {   // one chunk on its own (c even)
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      if constexpr (DROP) mask_row(a[i], i, c);
+      if constexpr (DROP) mask_row(a[i], i, c, true);
       mfma_row(a[i], b, i);
     }
   };
   // One pipeline step: the loads of chunk cn go out in the shadow of the first MFMAs of chunk c (one load per PER MFMAs),
   // so they have the rest of this chunk -- thousands of cycles -- to land.  Left to itself hipcc clusters the loads right
   // in front of their first use (it prices a global load at tens of cycles), which exposes the whole L2 / HBM latency.
-  // DROP: the mask of row block i + 1 (a hash + 4 selects, ~25 VALU instructions) is applied in the shadow of row block
-  // i's 4 CB MFMAs, and the one of the NEXT chunk's block 0 under this chunk's last block: on entry a[0] is masked already.
-  // The VALU slots are pinned two per MFMA -- as a burst in front of each block they idle the matrix pipe for 10-13 %.
-  auto step = [&](f32x4(&an)[RB], f32x4(&bn)[CB], int cn, f32x4(&a)[RB], f32x4(&b)[CB], int c) {
+  // DROP: the mask of row block i + 1 is applied in the shadow of row block i's 4 CB MFMAs, and the one of the NEXT
+  // chunk's block 0 under this chunk's last block: on entry a[0] is masked already.  EVEN = parity of c (compile time):
+  // the hash words are computed at their first use, which for block 0 of a pair is the odd step in front of it.
+  // The VALU instructions are NOT pinned between the MFMAs: next to fp32 MFMAs they are not free (the matrix pipe and the
+  // vector ALU share the FMA datapath), and what they cost is mostly per interrupted MFMA-to-MFMA hand-over (~10 cycles,
+  // one VALU instruction or two) -- measured: spread one per MFMA, 118 instructions per chunk cost as much as 240 did;
+  // the compiler's own placement, a burst of ~13 in front of each row block, interrupts the MFMA stream 9 times per chunk.
+  auto step = [&](f32x4(&an)[RB], f32x4(&bn)[CB], int cn, f32x4(&a)[RB], f32x4(&b)[CB], int c, auto even) {
+    constexpr bool EVEN = decltype(even)::value;
     if constexpr ((TUNE & 1) == 0) load(an, bn, cn);
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       if constexpr (DROP) {
         if (i + 1 < RB)
-          mask_row(a[i + 1], i + 1, c);
+          mask_row(a[i + 1], i + 1, c, EVEN);
         else
-          mask_row(an[0], 0, cn);
+          mask_row(an[0], 0, cn, !EVEN);
       }
       mfma_row(a[i], b, i);
     }
@@ -169,35 +186,31 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg 
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // MFMA
-      if constexpr (DROP) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // VALU
+      if constexpr (DROP && (TUNE & 32) != 0) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);      // VALU (experiment)
       if (m % PER == PER - 1 && m / PER < NL) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
     }
     __builtin_amdgcn_sched_barrier(0);
   };
 
   {
-    // Two named register sets.  The loop body is branch-free over PAIRS of chunks: with a conditional second half hipcc
-    // sinks that half's loads into the conditional block.  An odd chunk goes first, on its own.
+    // Two named register sets.  The loop body is branch-free over PAIRS of chunks (even, odd): with a conditional second
+    // half hipcc sinks that half's loads into the conditional block.  A last odd-numbered chunk follows on its own.
     f32x4 a0[RB], b0[CB], a1[RB], b1[CB];
+    const int c_pairs = c_lo + ((c_hi - c_lo) & ~1);
     int c = c_lo;
-    if (((c_hi - c_lo) & 1) != 0 && c_lo < c_hi) {
-      load(a0, b0, c);
-      compute(a0, b0, c);
-      ++c;
-    }
-    if (c < c_hi) {
+    if (c < c_pairs) {
       load(a0, b0, c);
       if constexpr ((TUNE & 1) != 0) load(a1, b1, c + 1);
-      if constexpr (DROP) mask_row(a0[0], 0, c);
+      if constexpr (DROP) mask_row(a0[0], 0, c, true);
       __builtin_amdgcn_sched_barrier(0);
       unsigned long long t0 = 0, r0 = 0;
       if constexpr ((TUNE & 16) != 0) {
         t0 = __builtin_amdgcn_s_memtime();
         r0 = __builtin_amdgcn_s_memrealtime();
       }
-      for (; c < c_hi; c += 2) {
-        step(a1, b1, c + 1, a0, b0, c);
-        step(a0, b0, min(c + 2, c_hi - 1), a1, b1, c + 1);   // (last pair: a harmless reload of a valid chunk)
+      for (; c < c_pairs; c += 2) {
+        step(a1, b1, c + 1, a0, b0, c, std::true_type{});
+        step(a0, b0, min(c + 2, c_pairs - 1), a1, b1, c + 1, std::false_type{});   // (last pair: a harmless reload)
       }
       if constexpr ((TUNE & 16) != 0) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -206,6 +219,10 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg 
           p.stamps[(size_t)(blockIdx.x * 4 + wave) * 2 + 1] = r1 - r0;
         }
       }
+    }
+    if (c_pairs < c_hi) {          // (c_pairs is even: the lone chunk computes its own hash words)
+      load(a0, b0, c_pairs);
+      compute(a0, b0, c_pairs);
     }
   }
   if ((p.K & 15) != 0 && wk == WK - 1) {
@@ -228,10 +245,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg 
         const float v = ldg4(Bb, offB[j] - 16u * g + 4u * (uint32_t)min(k, p.K - 1), 0u);
         b[j][e] = k < p.K ? v : 0.f;
       }
-    if constexpr (DROP) {
-#pragma unroll
-      for (int i = 0; i < RB; ++i) a[i] *= drop4(wordA[i] + 4u * (uint32_t)nfull, key, dc.p8, dc.scale);
-    }
+    // (DROP requires K % 32 == 0: no tail)
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -319,7 +333,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_kernel(TnArgs p, DropCfg 
   for (int q = 0; q < SP; ++q) {
     const uint32_t col = (uint32_t)min(n2_0 + 64 * q + 4 * r, p.N2 - 4);
     offQ[q] = ((uint32_t)(4 * g) * (uint32_t)p.ldq + col) * 4u;
-    wordQ[q] = ((uint32_t)(4 * g) * (uint32_t)p.N2 + col) >> 2;
+    wordQ[q] = (uint32_t)(4 * g) * (uint32_t)p.N2 + col;      // element index of (row 4 g, col) -- a multiple of 4
   }
   const rsrc_t Pb = make_rsrc(p.P, ((size_t)(p.M - 1) * p.ldp + p.N1) * 4);
   const rsrc_t Yb = make_rsrc(MASK ? p.Y : p.P, ((size_t)(p.M - 1) * p.ldp + p.N1) * 4);
@@ -364,10 +378,13 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_kernel(TnArgs p, DropCfg 
 #pragma unroll
       for (int i = 0; i < RB; ++i) st.a[kb][i] = st.y[kb][i] > 0.f ? st.a[kb][i] : 0.f;
     }
-    if constexpr (DROP) {
-      const uint32_t wrow = ((uint32_t)(m_c + kb) * (uint32_t)p.N2) >> 2;
+    if constexpr (DROP) {     // p = 0.5 bit mask of the four columns (unscaled: the factor 2 is the epilogue's)
+      const uint32_t erow = (uint32_t)(m_c + kb) * (uint32_t)p.N2;
 #pragma unroll
-      for (int q = 0; q < SP; ++q) st.q[kb][q] *= drop4(wrow + wordQ[q], key, dc.p8, dc.scale);
+      for (int q = 0; q < SP; ++q) {
+        const uint32_t e = erow + wordQ[q];
+        keep4_bits(st.q[kb][q], mask_word32(e >> 5, key) >> (e & 31u));
+      }
     }
   };
   auto mfmas = [&](Set& st, int kb) {   // (the bias-gradient sums live here: a prepared-ahead step may belong to a dummy reload)
@@ -403,11 +420,9 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_kernel(TnArgs p, DropCfg 
     }
     constexpr int NL = 4 * (RB * (MASK ? 2 : 1) + SP), NM = 16 * RB * SP;
     constexpr int PER = (3 * NM) / (4 * NL) > 0 ? (3 * NM) / (4 * NL) : 1;
-    constexpr int NV = (MASK || DROP) ? 2 : 1;
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);     // VALU
       if (m % PER == PER - 1 && m / PER < NL) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -455,8 +470,8 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_kernel(TnArgs p, DropCfg 
         const uint32_t o = offQ[q] - (uint32_t)(4 * g) * (uint32_t)p.ldq * 4u;
         f32x4 v = ldg16(Qb, o + sq, 0u);
         if constexpr (DROP) {
-          const uint32_t w = (rc * (uint32_t)p.N2 + (o >> 2)) >> 2;
-          v *= drop4(w, key, dc.p8, dc.scale);
+          const uint32_t e = rc * (uint32_t)p.N2 + (o >> 2);
+          keep4_bits(v, mask_word32(e >> 5, key) >> (e & 31u));
         }
         st.q[kb][q] = v;
       }
@@ -475,6 +490,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_kernel(TnArgs p, DropCfg 
     }
   }
 
+  const float qscale = DROP ? dc.scale : 1.f;      // the kept values of Q were not scaled in the loop
   float* __restrict__ dst = p.slab + (size_t)s * p.N1 * p.N2;
 #pragma unroll
   for (int i = 0; i < RB; ++i)
@@ -487,7 +503,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_kernel(TnArgs p, DropCfg 
           const int row = n1_0 + 16 * i + 4 * g + t;
           if (row < p.N1)
             *reinterpret_cast<f32x4*>(dst + (size_t)row * p.N2 + col) =
-                f32x4{acc[i][q][0][t], acc[i][q][1][t], acc[i][q][2][t], acc[i][q][3][t]};
+                f32x4{acc[i][q][0][t], acc[i][q][1][t], acc[i][q][2][t], acc[i][q][3][t]} * qscale;
         }
       }
     }

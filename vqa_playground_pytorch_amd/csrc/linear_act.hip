@@ -255,7 +255,7 @@ struct EpiBiasAct {
   int ldy, act;
   float scale;
   __device__ __forceinline__ void operator()(int row, int col, float v) const {
-    v += bias != nullptr ? bias[col] : 0.f;
+    v = fmaf(v, scale, bias != nullptr ? bias[col] : 0.f);      // scale: 2 when the operand was masked unscaled (p = 0.5)
     if (act == 1) v = fmaxf(v, 0.f);
     y[(size_t)row * ldy + col] = v;
   }
@@ -267,9 +267,11 @@ static bool rt_enabled() {
   const char* e = std::getenv("VQA_RT_ENGINE");
   return e == nullptr || e[0] != '0';
 }
-static bool rt_fwd_ok(int M, int K, int N, int ldx) {
+// p8: 0 (no dropout) or 128 (p = 0.5, the one-bit mask; needs rows of whole 32-element hash words); other rates stay on
+// the LDS-tile engine
+static bool rt_fwd_ok(int M, int K, int N, int ldx, uint32_t p8) {
   return rt_enabled() && M >= 1152 && K >= 64 && K % 4 == 0 && ldx % 4 == 0 && (size_t)M * ldx * 4 < (1ull << 32) &&
-         (size_t)N * K * 4 < (1ull << 32);
+         (size_t)N * K * 4 < (1ull << 32) && (p8 == 0 || (p8 == kDropHalf && K % 32 == 0));
 }
 static int rt_dw_splits(int M) {
   int s = 16;   // 4 n1 tiles x 16 n2 tiles x 16 row splits = 1024 waves for 310 x 2048 (one per SIMD)
@@ -280,9 +282,9 @@ static int rt_dw_splits(int M) {
   if (s < 1) s = 1;
   return s;
 }
-static bool rt_dw_ok(int M, int K, int N, int ldx) {
+static bool rt_dw_ok(int M, int K, int N, int ldx, uint32_t p8) {
   return rt_enabled() && M >= 4096 && K % 4 == 0 && ldx % 4 == 0 && (size_t)M * ldx * 4 < (1ull << 32) &&
-         (size_t)M * N * 4 < (1ull << 32);
+         (size_t)M * N * 4 < (1ull << 32) && (size_t)M * K < (1ull << 32) && (p8 == 0 || p8 == kDropHalf);
 }
 
 }  // namespace vqa
@@ -309,12 +311,12 @@ extern "C" int vqa_linear_act_fwd(const float* x, int ldx, const float* w, const
   VQA_REQUIRE(aligned(w, 8) && aligned(y, 8), VQA_E_UNSUPPORTED, "linear_act_fwd: w/y must be 8-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
-  if (rt_fwd_ok(M, K, N, ldx)) {
+  if (rt_fwd_ok(M, K, N, ldx, dc.p8)) {
     // 144 x 160 workgroup tiles, each wave 9 x 5 accumulator blocks over half of K (M = 18432, N = 310: 256 workgroups)
     using S = rt::NtShape<9, 5, 1, 2, 2>;
     const int tiles_m = (M + S::BM - 1) / S::BM, tiles_n = (N + S::BN - 1) / S::BN;
     const rt::NtArgs a{x, w, ldx, K, M, N, K, tiles_n, nullptr};
-    const EpiBiasAct epi{y, bias, N, act, 1.f};
+    const EpiBiasAct epi{y, bias, N, act, dc.p8 > 0 ? dc.scale : 1.f};
     if (dc.p8 > 0) {
       VQA_ENSURE_LDS((rt::gemm_nt_kernel<9, 5, 1, 2, 2, true, EpiBiasAct>), S::kLdsBytes);
       hipLaunchKernelGGL((rt::gemm_nt_kernel<9, 5, 1, 2, 2, true, EpiBiasAct>), dim3(tiles_m * tiles_n), dim3(rt::kThreads),
@@ -385,7 +387,7 @@ extern "C" int vqa_linear_act_bwd(const float* x, int ldx, const float* w, const
     VQA_TILE_SWITCH(t, LAUNCH);
 #undef LAUNCH
   }
-  if (rt_dw_ok(M, K, N, ldx)) {
+  if (rt_dw_ok(M, K, N, ldx, dc.p8)) {
     // register-tile TN form: workgroup = 4 waves x (80 rows of d_w) x 128 columns x one row split; the relu gate (y > 0)
     // and the dropout mask of x are applied to the operands in registers
     const int S = rt_dw_splits(M);
