@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VQA_ABI_VERSION 3
+#define VQA_ABI_VERSION 4
 
 #define VQA_OK 0
 #define VQA_E_BADARG (-1)      /* null pointer, non-positive size, size over a documented limit */
@@ -216,6 +216,15 @@ int vqa_lowrank_bilinear_fusion_folded_bwd(const float* x, int ldx, const float*
                                            float* d_x, float* const* d_w1, float* const* d_b1, float* d_h2,
                                            void* workspace, size_t workspace_bytes, int B, int N, int L,
                                            int H, int R, vqa_stream_t stream);
+/* The same with gate_dx != 0: d_x[b,n,l] is zeroed where x[b,n,l] <= 0.  x is then the relu output of the layer in
+ * front of the fusion (compress_v / compress_v2, config/CoR2.py:213-214,:218-219: F.relu at :86 feeds MutanFusion
+ * directly), and relu's own backward -- grad * (y > 0) -- is applied here, in the store of d_x, instead of as a masked
+ * operand in that layer's weight- and data-gradient kernels.  Needs ldx == L. */
+int vqa_lowrank_bilinear_fusion_folded_bwd_gated(const float* x, int ldx, const float* const* w1,
+                                                 const float* const* b1, const float* h2, const float* g,
+                                                 float* d_x, float* const* d_w1, float* const* d_b1,
+                                                 float* d_h2, void* workspace, size_t workspace_bytes, int B,
+                                                 int N, int L, int H, int R, int gate_dx, vqa_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Mixed-precision (bf16) side -- BASELINE configs[4] "CoR2 bf16, 100x2048 dense regions": bf16 storage and

@@ -266,6 +266,29 @@ def test_lowrank_bilinear_fusion_golden(ops, golden_dir):
         close(name, p.grad, blocks["mutan2d.g." + name + ".full"])
 
 
+@pytest.mark.parametrize("B", [40, 5])
+def test_lowrank_bilinear_fusion_gated_dx(ops, B):
+    """gate_dx: the gradient of x comes back multiplied by (x > 0) -- the relu gate of the layer that produced x, applied in
+    the store of the folded data-gradient kernel (B >= 32) or as a torch op behind the R-GEMM form -- everything else unchanged."""
+    N, L, H, R = 36, 70, 130, 2
+    gen = torch.Generator(device="cpu").manual_seed(12)
+    x = torch.relu(torch.randn(B, N, L, generator=gen)).to(dev())          # about half the entries are exactly 0
+    h2 = torch.randn(B, R, H, generator=gen).to(dev())
+    ws = [(torch.randn(H, L, generator=gen) / L ** 0.5).to(dev()).requires_grad_() for _ in range(R)]
+    bs = [(torch.randn(H, generator=gen) * 0.1).to(dev()).requires_grad_() for _ in range(R)]
+    go = torch.randn(B, N, H, generator=gen).to(dev())
+    grads = []
+    for gate in (False, True):
+        xr, hr = x.clone().requires_grad_(), h2.clone().requires_grad_()
+        out = ops.lowrank_bilinear_fusion(xr, hr, ws, bs, gate_dx=gate)
+        grads.append(torch.autograd.grad(out, [xr, hr] + ws + bs, go))
+    plain, gated = grads
+    assert torch.equal(gated[0], plain[0] * (x > 0)), "d_x must be exactly the ungated gradient times (x > 0)"
+    assert (gated[0] != plain[0]).any()
+    for a, b in zip(gated[1:], plain[1:]):
+        assert torch.equal(a, b)
+
+
 def test_block_goldens_conv_linear(ops, golden_dir):
     """HIP-backed MyConv1d (softmax over regions, relu) and MyLinear (sigmoid) against the reference's own outputs
     (tests/golden/blocks.npz conv_softmax / conv_relu / linear_sigmoid; config/CoR2.py:56-122), eval mode."""

@@ -114,13 +114,13 @@ def main():
         for t in tiles + [""]:
             def f(t=t):
                 set_tile(t)
-                ops.LowRankBilinearFusion.apply(x, h2, *ws, *bs)
+                ops.LowRankBilinearFusion.apply(x, h2, False, *ws, *bs)
             fns["fwd(no h1) tile=%s" % (t or "auto")] = f
         xr = x.clone().requires_grad_()
         for t in tiles:
             def f(t=t):
                 set_tile(t)
-                ops.LowRankBilinearFusion.apply(xr, h2, *ws, *bs)
+                ops.LowRankBilinearFusion.apply(xr, h2, False, *ws, *bs)
             fns["fwd(+h1)  tile=%s" % t] = f
         report("K4 forward  (M=18432, K=310, N=2x510)", timeit(fns, args.rounds), B * (2 * R * N * L * H + 2 * R * N * H), "TF")
         set_tile("")
@@ -131,7 +131,7 @@ def main():
         br = [b.clone().requires_grad_() for b in bs]
         for t in tiles + [""]:
             set_tile(t)
-            out = ops.LowRankBilinearFusion.apply(xr, h2, *wr, *br)
+            out = ops.LowRankBilinearFusion.apply(xr, h2, False, *wr, *br)
 
             def f(t=t, out=out):
                 set_tile(t)

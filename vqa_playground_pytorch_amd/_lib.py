@@ -9,7 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VQA_LIB_PATH", os.path.join(_HERE, "libvqa_mi355x.so"))  # env override: profiling builds
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_f = ctypes.c_void_p          # device pointer to fp32
 _c_pp = ctypes.c_void_p         # host array of device pointers
@@ -51,6 +51,8 @@ SIGNATURES = {
     "vqa_lowrank_bilinear_fusion_folded_bwd_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i, _c_i, _c_i]),
     "vqa_lowrank_bilinear_fusion_folded_bwd": (_c_i, [_c_f, _c_i, _c_pp, _c_pp, _c_f, _c_f, _c_f, _c_pp, _c_pp, _c_f,
                                                       _c_f, _c_sz, _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_lowrank_bilinear_fusion_folded_bwd_gated": (_c_i, [_c_f, _c_i, _c_pp, _c_pp, _c_f, _c_f, _c_f, _c_pp, _c_pp, _c_f,
+                                                            _c_f, _c_sz, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_rank_product_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_st]),
     "vqa_rank_product_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_st]),
     "vqa_object_difference_attention_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_fl, _c_u64, _c_f,

@@ -4,6 +4,8 @@ Same constructor, ``forward(sample) -> logits [B,num_ans]``, ``alpha_dict`` side
 state_dict names as the reference ``Model``; the region count is read from the input instead of
 being the literal 36, and per-replica batch 1 works (the reference raises IndexError there).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -52,6 +54,11 @@ class Model(nn.Module):
         self.compress_q_2 = MyLinear(2400, 310, p=0.5, af="relu")
         self.expand_q_2 = MyLinear(310, 2048, p=0.5, af="sigmoid")
         self.alpha_dict = {}
+        # compress_v / compress_v2 feed their relu output to fusion_vq1 / fusion_vq2 and nothing else, so the fusion's data
+        # gradient can apply the relu gate in its store (ops.lowrank_bilinear_fusion, gate_dx) and the projections' backward
+        # kernels run ungated.  Measured at B = 512 (profiles/README.md): what the projections save (25 us) the fusion's
+        # epilogue pays back in dependent loads of the gate (2 x 13 us) -- off by default, VQA_FUSE_RELU_GATE=1 turns it on.
+        self.compress_v.grad_pregated = self.compress_v2.grad_pregated = os.environ.get("VQA_FUSE_RELU_GATE", "0") == "1"
 
     def late_parameters(self):
         """Parameters of the second reasoning step.  Their gradients are complete once backward has walked from the loss
@@ -98,7 +105,7 @@ class Model(nn.Module):
 
         q_feature_low, q_final, q_gate_1, q_gate_2 = self.question_projections(q_feature)
         v_feature_low = self.compress_v(v_feature)
-        fuse1 = self.fusion_vq1(v_feature_low, q_feature_low)
+        fuse1 = self.fusion_vq1(v_feature_low, q_feature_low, relu_input=self.compress_v.grad_pregated)
         v1_att, alpha1, alpha1_full, pooled1_first = self.att1.attend(v_feature, self.att1.conv_att.pre_activation(fuse1),
                                                                 return_pooled=True)
         if _cut is not None:
@@ -124,7 +131,7 @@ class Model(nn.Module):
             p = self.compress_v2.p if (self.training and self.compress_v2.p) else 0.0
             v2_dropped = ops.relation_apply(v_feature, t, c2, p, ops.next_dropout_seed() if p else 0)
             v2_feature_low = self.compress_v2(v2_dropped, predropped=True)
-            fuse2 = self.fusion_vq2(v2_feature_low, q_feature_low)
+            fuse2 = self.fusion_vq2(v2_feature_low, q_feature_low, relu_input=self.compress_v2.grad_pregated)
             v2_att, alpha2, _ = self.att2.attend(v_feature, self.att2.conv_att.pre_activation(fuse2),
                                                  lambda pooled, pd: ops.relation_apply(
                                                      pooled, t, c2, pd, ops.next_dropout_seed() if pd else 0))
@@ -134,7 +141,7 @@ class Model(nn.Module):
             # v2 has two consumers, each gets its own alias (see ops.pairwise_relation_reduce)
             v2_feature, v2_for_pooling = self.relation_reduce(v_feature, q_gate_1, q_gate_2, alpha1_full)
             v2_feature_low = self.compress_v2(v2_feature)
-            fuse2 = self.fusion_vq2(v2_feature_low, q_feature_low)
+            fuse2 = self.fusion_vq2(v2_feature_low, q_feature_low, relu_input=self.compress_v2.grad_pregated)
             v2_att, alpha2, _ = self.att2.attend(v2_for_pooling, self.att2.conv_att.pre_activation(fuse2))
             feature = v2_feature[:, 0:2, :].detach().float()
 

@@ -52,7 +52,8 @@ template <int NB, int R, bool H2_ROWS, int WAVES, int OB>
 __global__ __launch_bounds__(64 * WAVES, 2) void bilinear_folded_kernel(const float* __restrict__ in, int ld_in, FoldPtrs wp,
                                                                         int ldw, const float* __restrict__ h2, int h2_dim,
                                                                         float* __restrict__ out, int ld_out, int B, int N,
-                                                                        int C, int O, int tiles_o) {
+                                                                        int C, int O, int tiles_o,
+                                                                        const float* __restrict__ gate) {
   constexpr int CK = kFoldCK, P = CK + 4;   // contraction chunk and LDS pitch in floats
   constexpr int CK2 = CK / 2;          // float2 per staged row
   constexpr int T = 64 * WAVES;        // threads = one wave per sample of the group
@@ -217,8 +218,18 @@ __global__ __launch_bounds__(64 * WAVES, 2) void bilinear_folded_kernel(const fl
     for (int nb = 0; nb < NB; ++nb) {
       const int n = nb * 16 + l16;
       if (n < N) {
-        float* __restrict__ dst = out + ((size_t)(b0 + wave) * N + n) * ld_out + o;
-        const f32x4 t = acc[ob][nb];
+        const size_t at = ((size_t)(b0 + wave) * N + n) * ld_out + o;
+        float* __restrict__ dst = out + at;
+        f32x4 t = acc[ob][nb];
+        if (gate != nullptr) {
+          // data gradient towards a relu output: zero where the forward value (laid out like `out`) is not positive -- the
+          // gate of the layer that produced it, applied here so that layer's backward kernels need no masked operand
+          const float2 g0 = ld2(gate + at), g1 = o + 2 < O ? ld2(gate + at + 2) : make_float2(0.f, 0.f);
+          t[0] = g0.x > 0.f ? t[0] : 0.f;
+          t[1] = g0.y > 0.f ? t[1] : 0.f;
+          t[2] = g1.x > 0.f ? t[2] : 0.f;
+          t[3] = g1.y > 0.f ? t[3] : 0.f;
+        }
         st2(dst, make_float2(t[0], t[1]));
         if (o + 2 < O) st2(dst + 2, make_float2(t[2], t[3]));
       }
@@ -272,7 +283,7 @@ static FoldCfg folded_config(int B, int N, int O, int R, bool h2_rows) {
 
 template <bool H2_ROWS>
 static int launch_folded(const char* who, const float* in, int ld_in, const FoldPtrs& wp, int ldw, const float* h2, int h2_dim,
-                         float* out, int ld_out, int B, int N, int C, int O, int R, hipStream_t s) {
+                         float* out, int ld_out, int B, int N, int C, int O, int R, hipStream_t s, const float* gate = nullptr) {
   const FoldCfg cfg = folded_config(B, N, O, R, H2_ROWS);
   const int waves = cfg.waves, obr = cfg.ob * 16;
   const int tiles_o = (O + obr - 1) / obr, groups = (B + waves - 1) / waves;
@@ -281,7 +292,7 @@ static int launch_folded(const char* who, const float* in, int ld_in, const Fold
   {                                                                                                                          \
     VQA_ENSURE_LDS((bilinear_folded_kernel<NB_, R_, H2_ROWS, W_, OB_>), lds);                                                \
     hipLaunchKernelGGL((bilinear_folded_kernel<NB_, R_, H2_ROWS, W_, OB_>), dim3(tiles_o * groups), dim3(64 * W_), lds, s,   \
-                       in, ld_in, wp, ldw, h2, h2_dim, out, ld_out, B, N, C, O, tiles_o);                                    \
+                       in, ld_in, wp, ldw, h2, h2_dim, out, ld_out, B, N, C, O, tiles_o, gate);                              \
   }
 #define LAUNCH_W(NB_, R_, OB_) \
   if (waves == 8) LAUNCH_C(NB_, R_, 8, OB_) else LAUNCH_C(NB_, R_, 4, OB_)
@@ -353,10 +364,10 @@ int folded_transpose_weights(const float* const* w1, float* wt, int L, int H, in
 }
 
 int folded_data_gradient(const float* g, const float* const* w1t, const float* h2, float* d_x, int B, int N, int L, int H,
-                         int R, hipStream_t s) {
+                         int R, hipStream_t s, const float* gate) {
   FoldPtrs wp{};
   for (int r = 0; r < R; ++r) wp.w[r] = w1t[r];
-  return launch_folded<false>("lowrank_bilinear_fusion_folded_bwd (dx)", g, H, wp, H, h2, H, d_x, L, B, N, H, L, R, s);
+  return launch_folded<false>("lowrank_bilinear_fusion_folded_bwd (dx)", g, H, wp, H, h2, H, d_x, L, B, N, H, L, R, s, gate);
 }
 
 }  // namespace vqa

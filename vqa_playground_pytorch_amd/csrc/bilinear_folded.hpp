@@ -10,9 +10,10 @@ constexpr int kFoldMaxN = 112;
 
 bool folded_supported(int B, int N, int L, int H, int R);
 
-// dx[b,n,:] = Weff_b^T g[b,n,:]   (w1t: R dense [L,H] transposes of W1_r in device memory)
+// dx[b,n,:] = Weff_b^T g[b,n,:]   (w1t: R dense [L,H] transposes of W1_r in device memory); gate (optional, [B*N,L] like
+// d_x): d_x is zeroed where gate <= 0
 int folded_data_gradient(const float* g, const float* const* w1t, const float* h2, float* d_x, int B, int N, int L, int H,
-                         int R, hipStream_t s);
+                         int R, hipStream_t s, const float* gate = nullptr);
 
 // wt[r] = w1[r]^T   ([H,L] -> [L,H]), all ranks in one launch
 int folded_transpose_weights(const float* const* w1, float* wt, int L, int H, int R, hipStream_t s);

@@ -755,6 +755,15 @@ extern "C" int vqa_lowrank_bilinear_fusion_folded_bwd(const float* x, int ldx, c
                                                       float* const* d_w1, float* const* d_b1, float* d_h2, void* workspace,
                                                       size_t workspace_bytes, int B, int N, int L, int H, int R,
                                                       vqa_stream_t stream) {
+  return vqa_lowrank_bilinear_fusion_folded_bwd_gated(x, ldx, w1, b1, h2, g, d_x, d_w1, d_b1, d_h2, workspace, workspace_bytes, B,
+                                                      N, L, H, R, 0, stream);
+}
+
+extern "C" int vqa_lowrank_bilinear_fusion_folded_bwd_gated(const float* x, int ldx, const float* const* w1,
+                                                            const float* const* b1, const float* h2, const float* g,
+                                                            float* d_x, float* const* d_w1, float* const* d_b1, float* d_h2,
+                                                            void* workspace, size_t workspace_bytes, int B, int N, int L,
+                                                            int H, int R, int gate_dx, vqa_stream_t stream) {
   VQA_REQUIRE(x && w1 && b1 && h2 && g && d_w1 && d_b1 && d_h2 && workspace, VQA_E_BADARG,
               "lowrank_bilinear_fusion_folded_bwd: null pointer");
   VQA_REQUIRE(folded_supported(B, N, L, H, R), VQA_E_UNSUPPORTED,
@@ -787,7 +796,8 @@ extern "C" int vqa_lowrank_bilinear_fusion_folded_bwd(const float* x, int ldx, c
     if (rc != VQA_OK) return rc;
     const float* wtp[kFoldMaxR];
     for (int r = 0; r < R; ++r) wtp[r] = wt + (size_t)r * L * H;
-    rc = folded_data_gradient(g, wtp, h2, d_x, B, N, L, H, R, s);
+    VQA_REQUIRE(!gate_dx || ldx == L, VQA_E_UNSUPPORTED, "lowrank_bilinear_fusion_folded_bwd: gate_dx needs a dense x (ldx == L)");
+    rc = folded_data_gradient(g, wtp, h2, d_x, B, N, L, H, R, s, gate_dx ? x : nullptr);
     if (rc != VQA_OK) return rc;
   }
   // (2) P_b = g_b^T x_b once per sample: dW1_r, db1_r slabs and the dh2 partial sums

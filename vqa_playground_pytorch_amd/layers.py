@@ -210,6 +210,9 @@ class MyConv1d(nn.Module):
     # (csrc/gemm_f32_rt.hpp) the forward beats the library GEMM at these shapes and no dropout pass over
     # [B,36,2048] exists any more (see profiles/README.md)
     fused = os.environ.get("VQA_FUSED_LINEAR", "1") == "1"
+    # Set by a model whose ONLY consumer of this layer's relu output hands the gradient back already multiplied by
+    # relu'(output) (MutanFusion(..., relu_input=True)): the fused backward then skips its own gate.
+    grad_pregated = False
 
     def _fused_ok(self, x):
         return self.fused and self.af in (None, "relu") and x.dim() == 3 and x.is_cuda and x.dtype == torch.float32 \
@@ -224,7 +227,8 @@ class MyConv1d(nn.Module):
             if x.dtype == torch.bfloat16:
                 return self._linear_bf16(x, self.af)
             if self._fused_ok(x):
-                return ops.linear_act(x, self.conv.weight.squeeze(-1), self.conv.bias, self.af, 0.0, 0)
+                return ops.linear_act(x, self.conv.weight.squeeze(-1), self.conv.bias, self.af, 0.0, 0,
+                                      pregated=self.grad_pregated)
             return self._linear_f32(x)
         if x.dtype == torch.bfloat16 and self.af in (None, "relu"):
             if x.dim() != 3:
@@ -239,7 +243,8 @@ class MyConv1d(nn.Module):
             # torch's CPU generator, so torch.manual_seed governs it and no mask tensor exists
             p = self.p if (self.training and self.p) else 0.0
             seed = ops.next_dropout_seed() if p else 0
-            return ops.linear_act(x, self.conv.weight.squeeze(-1), self.conv.bias, self.af, p, seed)
+            return ops.linear_act(x, self.conv.weight.squeeze(-1), self.conv.bias, self.af, p, seed,
+                                  pregated=self.grad_pregated)
         if self.af == "relu" and x.dim() == 3 and x.dtype == torch.float32 and x.is_cuda and \
                 not ops.attention_logits_supported(x, self.in_channels, self.out_channels):
             if self.p:
@@ -271,7 +276,9 @@ class MutanFusion(nn.Module):
     def stack_groups(self):
         return linear_stack_groups(list(self.list_linear2)) + linear_stack_groups(list(self.list_linear1))
 
-    def forward(self, inputs1, inputs2):
+    def forward(self, inputs1, inputs2, relu_input=False):
+        """relu_input: inputs1 is the relu output of the layer in front and the gradient returned for it may come back
+        multiplied by (inputs1 > 0) already (that layer's backward then skips the gate: MyConv1d.grad_pregated)."""
         # (bf16 region tensors carry the feature dim zero-padded to a multiple of 64: see ops.pad_to)
         want = ops.pad_to(self.input_dim1) if inputs1.dtype == torch.bfloat16 else self.input_dim1
         if inputs1.size(-1) != want:
@@ -294,7 +301,7 @@ class MutanFusion(nn.Module):
             return ops.rank_product(h1, h2)
         weights = [lin.linear.weight for lin in self.list_linear1]
         biases = [lin.linear.bias for lin in self.list_linear1]
-        return ops.lowrank_bilinear_fusion(inputs1, h2, weights, biases)
+        return ops.lowrank_bilinear_fusion(inputs1, h2, weights, biases, gate_dx=relu_input)
 
 
 class MyATT(nn.Module):

@@ -320,7 +320,10 @@ class LowRankBilinearFusion(torch.autograd.Function):
     Replaces the region side of putils.MutanFusion.forward (putils/__init__.py:232-238)."""
 
     @staticmethod
-    def forward(ctx, x, h2, *params):
+    def forward(ctx, x, h2, gate_dx, *params):
+        # gate_dx: x is the relu output of the layer in front (compress_v / compress_v2); d_x comes back already multiplied
+        # by (x > 0), that layer's own relu gradient (in the store of the data-gradient kernel where the folded form runs)
+        ctx.gate_dx = bool(gate_dx)
         R = len(params) // 2
         w1 = [_prep("w1[%d]" % r, params[r]) for r in range(R)]
         b1 = [_prep("b1[%d]" % r, params[R + r]) for r in range(R)]
@@ -379,16 +382,18 @@ class LowRankBilinearFusion(torch.autograd.Function):
         if ctx.folded:
             ws_bytes = L_.vqa_lowrank_bilinear_fusion_folded_bwd_workspace_bytes(B, N, L, H, R)
             ws = torch.empty((ws_bytes + 3) // 4, device=dev, dtype=torch.float32)
-            _launch("lowrank_bilinear_fusion_bwd", (B, N, L, H, R, d_x is not None), L_.vqa_lowrank_bilinear_fusion_folded_bwd,
+            _launch("lowrank_bilinear_fusion_bwd", (B, N, L, H, R, d_x is not None), L_.vqa_lowrank_bilinear_fusion_folded_bwd_gated,
                     _p(x), L, _ptr_array(w1), _ptr_array(b1), _p(h2), _p(g), _p(d_x), _ptr_array(d_w1), _ptr_array(d_b1),
-                    _p(d_h2), _p(ws), ws_bytes, B, N, L, H, R)
-            return (d_x, d_h2, *d_w1, *d_b1)
+                    _p(d_h2), _p(ws), ws_bytes, B, N, L, H, R, int(ctx.gate_dx and d_x is not None))
+            return (d_x, d_h2, None, *d_w1, *d_b1)
         ws_bytes = L_.vqa_lowrank_bilinear_fusion_bwd_workspace_bytes(B, N, L, H, R)
         ws = torch.empty((ws_bytes + 3) // 4, device=dev, dtype=torch.float32)
         _launch("lowrank_bilinear_fusion_bwd", (B, N, L, H, R, d_x is not None), L_.vqa_lowrank_bilinear_fusion_bwd,
                 _p(x), L, _ptr_array(w1), _p(h2), _p(h1), _p(g), _p(d_x), _ptr_array(d_w1), _ptr_array(d_b1), _p(d_h2),
                 _p(ws), ws_bytes, B, N, L, H, R)
-        return (d_x, d_h2, *d_w1, *d_b1)
+        if ctx.gate_dx and d_x is not None:      # (the R-GEMM form serves small batches: the gate is a torch op there)
+            d_x = torch.ops.aten.threshold_backward(d_x, x, 0)
+        return (d_x, d_h2, None, *d_w1, *d_b1)
 
 
 def pack_bf16(src, dst, batch_stride, row_stride, col_stride, zero_fill=True, offset=0):
@@ -642,7 +647,10 @@ class LinearAct(torch.autograd.Function):
     Replaces MyConv1d(k=1).forward (config/CoR2.py:72-88) / MyLinear.forward (config/CoR2.py:106-121)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, act, p_drop, seed):
+    def forward(ctx, x, w, bias, act, p_drop, seed, pregated=False):
+        # pregated: whoever consumes y returns its gradient already multiplied by relu'(y) (ops.lowrank_bilinear_fusion with
+        # gate_dx) -- backward then runs the ungated kernels (no y operand in the weight gradient, no masking pass)
+        ctx.pregated = bool(pregated) and int(act) == 1
         x, w = _prep("x", x), _prep("w", w)
         bias = _prep("bias", bias) if bias is not None else None
         K = x.shape[-1]
@@ -662,6 +670,8 @@ class LinearAct(torch.autograd.Function):
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
         M, K, N, act, p_drop, seed, has_bias = ctx.cfg
+        if ctx.pregated:
+            act = 0
         gy = _prep("grad_y", gy)
         d_x = None
         if ctx.needs_input_grad[0] and p_drop == 0 and M >= 4096 and LinearAct.library_dgrad:
@@ -685,16 +695,16 @@ class LinearAct(torch.autograd.Function):
         _launch("linear_act_bwd", (M, K, N, p_drop > 0, in_kernel_dx), L_.vqa_linear_act_bwd,
                 _p(x), K, _p(w), _p(y), _p(gy), _p(d_x) if in_kernel_dx else None, _p(d_w), _p(d_b), _p(ws), ws_bytes,
                 M, K, N, act, p_drop, sv, sp)
-        return d_x, d_w, d_b, None, None, None
+        return d_x, d_w, d_b, None, None, None, None
 
     library_dgrad = os.environ.get("VQA_LIBRARY_DGRAD", "1") == "1"
 
 
-def linear_act(x, w, bias=None, act=None, p_drop=0.0, seed=0):
+def linear_act(x, w, bias=None, act=None, p_drop=0.0, seed=0, pregated=False):
     code = {None: 0, "": 0, "relu": 1}.get(act)
     if code is None:
         raise ValueError("linear_act: act must be None or 'relu', got %r" % (act,))
-    return LinearAct.apply(x, w, bias, code, p_drop, seed)
+    return LinearAct.apply(x, w, bias, code, p_drop, seed, pregated)
 
 
 def column_sum(x):
@@ -1164,10 +1174,11 @@ def softmax_attention_pool(logits, v):
     return SoftmaxAttentionPool.apply(logits, v)
 
 
-def lowrank_bilinear_fusion(x, h2, weights, biases):
+def lowrank_bilinear_fusion(x, h2, weights, biases, gate_dx=False):
+    """gate_dx (fp32 path): the gradient returned for x is already multiplied by (x > 0) -- see LowRankBilinearFusion."""
     if x.dtype == torch.bfloat16:
         return LowRankBilinearFusionBf16.apply(x, h2, *weights, *biases)
-    return LowRankBilinearFusion.apply(x, h2, *weights, *biases)
+    return LowRankBilinearFusion.apply(x, h2, gate_dx, *weights, *biases)
 
 
 def object_difference_attention(vl, ql, w, bias, p_drop=0.0, seed=0):
