@@ -18,4 +18,12 @@ int folded_data_gradient(const float* g, const float* const* w1t, const float* h
 // wt[r] = w1[r]^T   ([H,L] -> [L,H]), all ranks in one launch
 int folded_transpose_weights(const float* const* w1, float* wt, int L, int H, int R, hipStream_t s);
 
+// Register-tile weight-gradient kernel of the folded backward (bilinear_dw_rt.hip): dW1_r / db1_r slabs over kDwRtGroups
+// sample groups (layout [group][R][H*L] / [group][R][H], summed by bilinear_dw_reduce_kernel) and two partial sums of dh2
+// (layout [2][B*R*H], summed by bilinear_dh2_reduce_kernel).
+constexpr int kDwRtGroups = 8;
+bool dw_rt_supported(int B, int N, int L, int H, int R, int ldx);
+int dw_rt_launch(const float* g, const float* x, const float* h2, const float* const* w1, const float* const* b1, float* slab,
+                 float* dbslab, float* part, int B, int N, int L, int H, int R, hipStream_t s);
+
 }  // namespace vqa

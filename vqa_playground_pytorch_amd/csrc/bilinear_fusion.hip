@@ -800,7 +800,18 @@ extern "C" int vqa_lowrank_bilinear_fusion_folded_bwd_gated(const float* x, int 
     rc = folded_data_gradient(g, wtp, h2, d_x, B, N, L, H, R, s, gate_dx ? x : nullptr);
     if (rc != VQA_OK) return rc;
   }
-  // (2) P_b = g_b^T x_b once per sample: dW1_r, db1_r slabs and the dh2 partial sums
+  // (2) P_b = g_b^T x_b once per sample: dW1_r, db1_r slabs and dh2
+  if (dw_rt_supported(B, N, L, H, R, ldx) && dw_fold_splits(B, N, H, L, R) >= kDwRtGroups) {
+    // register-tile form (bilinear_dw_rt.hip): 8 slabs, dh2 in two partial sums (the workspace holds >= 2 of them)
+    rc = dw_rt_launch(g, x, h2, w1, b1, slab, dbslab, part, B, N, L, H, R, s);
+    if (rc != VQA_OK) return rc;
+    const int HL2 = H * L;
+    hipLaunchKernelGGL(bilinear_dw_reduce_kernel, dim3((HL2 / 2 + 255) / 256, R), dim3(256), 0, s, slab, dbslab, ro, HL2, H, R,
+                       kDwRtGroups);
+    const size_t n2 = (size_t)B * R * H;
+    hipLaunchKernelGGL(bilinear_dh2_reduce_kernel, dim3((unsigned)((n2 / 2 + 255) / 256)), dim3(256), 0, s, part, d_h2, n2, 2);
+    return check_launch("lowrank_bilinear_fusion_folded_bwd");
+  }
   const int S = dw_fold_splits(B, N, H, L, R);
   const int tiles_m = (H + 63) / 64, tiles_n = (L + 63) / 64;
   static const int pf = [] {   // register sets in flight (experiment knob; 1 keeps three waves per SIMD at R = 2)

@@ -12,8 +12,16 @@
 // round(p*256)/256 -- and contracts against the four filter rows immediately.  Backward regenerates
 // the same mask from the same (seed, index).
 //
-// VALU-bound (~14 lane-ops per mask element, N*N*L = 401 760 elements per sample); compulsory HBM
-// traffic is only vl, ql, logits per sample plus the 178 KB filter, which stays in L2.
+// VALU-bound (N*N*L = 401 760 mask elements per sample); compulsory HBM traffic is only vl, ql, logits per sample plus
+// the 178 KB filter, which stays in L2.
+//
+// Two mask layouts.  p = 0.5 (the rate the model uses, p8 == 128): ONE BIT per element -- keep iff bit (i & 31) of the
+// hash word of counter ((b*NI + i/32)*N + j)*L + d, NI = ceil(N/32); a word serves up to 32 regions i of one (j, d), the
+// kept difference is AND-ed with the sign-extended bit (2 lane-ops) and the factor 2 is applied once per output: ~8
+// lane-ops per element (1 subtract, 2 mask, G = 4 FMAs, hash amortised).  Any other rate: one BYTE per element, four
+// regions per word (~14 lane-ops per element: byte extract, compare, select, multiply + a hash per 4 elements).
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace vqa {
@@ -27,6 +35,208 @@ __device__ __forceinline__ uint64_t mask_counter(int b, int iq, int j, int d, in
 }
 __device__ __forceinline__ float keep_scale(uint32_t word, int k, uint32_t p8, float scale) {
   return ((word >> (8 * k)) & 255u) >= p8 ? scale : 0.f;
+}
+
+// ---- p = 0.5: one bit per element --------------------------------------------------------------------------------
+constexpr int kIB = 18;   // regions i per workgroup pass of the forward (two passes cover the reference's 36)
+// the mask bits of regions i0 .. i0 + 31 of one (b, j, d), bit k <-> region i0 + k: word i0/32 shifted down, topped up
+// from word i0/32 + 1 when the range straddles it (`straddle` is workgroup-uniform)
+__device__ __forceinline__ uint32_t oda_bits(uint32_t cnt_lo, uint32_t word_stride, int sh, bool straddle, uint32_t key) {
+  uint32_t bits = mask_word32(cnt_lo, key) >> sh;
+  if (straddle) bits |= mask_word32(cnt_lo + word_stride, key) << (32 - sh);   // (straddle implies sh > 0)
+  return bits;
+}
+__device__ __forceinline__ float keep_bit(float v, uint32_t bits, int k) {
+  return __uint_as_float(__float_as_uint(v) & (0u - ((bits >> k) & 1u)));      // v_bfe_i32 + v_and_b32; unscaled
+}
+
+// forward, bit mask: grid (ceil(N/kIB), B), lane <-> feature d
+template <int G>
+__global__ void oda_fwd_bits_kernel(const float* __restrict__ vl, const float* __restrict__ ql, const float* __restrict__ w,
+                                    const float* __restrict__ bias, float* __restrict__ logits, DropCfg dc, int N, int L) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red_s = reinterpret_cast<float*>(smem);  // [nwaves][kIB*G]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int b = blockIdx.y, i0 = blockIdx.x * kIB;
+  const int NI = (N + 31) >> 5;
+  const uint32_t key = drop_key(dc);
+  const int sh = i0 & 31;
+  const bool straddle = ((min(i0 + kIB, N) - 1) >> 5) != (i0 >> 5);
+  const uint32_t stride = (uint32_t)N * (uint32_t)L;
+  const uint32_t base = ((uint32_t)b * NI + (uint32_t)(i0 >> 5)) * stride;
+  const float* vlb = vl + (size_t)b * N * L;
+  float acc[kIB][G];
+#pragma unroll
+  for (int ic = 0; ic < kIB; ++ic)
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[ic][g] = 0.f;
+
+  for (int d = tid; d < L; d += blockDim.x) {
+    const float qd = ql[(size_t)b * L + d];
+    float Ti[kIB];
+#pragma unroll
+    for (int ic = 0; ic < kIB; ++ic) Ti[ic] = (i0 + ic < N) ? vlb[(size_t)(i0 + ic) * L + d] * qd : 0.f;
+#pragma unroll 2
+    for (int j = 0; j < N; ++j) {
+      const float Tj = vlb[(size_t)j * L + d] * qd;
+      float wv[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) wv[g] = w[((size_t)g * N + j) * L + d];
+      const uint32_t bits = oda_bits(base + (uint32_t)(j * L + d), stride, sh, straddle, key);
+#pragma unroll
+      for (int ic = 0; ic < kIB; ++ic) {
+        const float val = keep_bit(Ti[ic] - Tj, bits, ic);
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[ic][g] = fmaf(wv[g], val, acc[ic][g]);
+      }
+    }
+  }
+#pragma unroll
+  for (int ic = 0; ic < kIB; ++ic)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float r = wave_sum(acc[ic][g]);
+      if (lane == 0) red_s[wave * (kIB * G) + ic * G + g] = r;
+    }
+  __syncthreads();
+  for (int t = tid; t < kIB * G; t += blockDim.x) {
+    const int ic = t / G, g = t % G;
+    if (i0 + ic < N) {
+      float sum = 0.f;
+      for (int wv = 0; wv < nwaves; ++wv) sum += red_s[wv * (kIB * G) + t];
+      logits[((size_t)b * N + i0 + ic) * G + g] = fmaf(dc.scale, sum, bias[g]);     // the kept values' factor 2
+    }
+  }
+}
+
+// backward d_vl, d_ql, bit mask: as oda_bwd_data_kernel
+template <int G>
+__global__ void oda_bwd_data_bits_kernel(const float* __restrict__ vl, const float* __restrict__ ql,
+                                         const float* __restrict__ w, const float* __restrict__ dS,
+                                         float* __restrict__ d_vl, float* __restrict__ d_ql, DropCfg dc, int N, int L) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* dT_s = reinterpret_cast<float*>(smem);        // [N][blockDim]
+  float* dS_s = dT_s + (size_t)N * blockDim.x;          // [N][G]
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int b = blockIdx.x;
+  const int NI = (N + 31) >> 5;
+  const uint32_t key = drop_key(dc);
+  const uint32_t stride = (uint32_t)N * (uint32_t)L;
+  const float* vlb = vl + (size_t)b * N * L;
+  for (int t = tid; t < N * G; t += nt) dS_s[t] = dS[(size_t)b * N * G + t];
+  __syncthreads();
+  for (int d = tid; d < L; d += nt) {
+    for (int n = 0; n < N; ++n) dT_s[n * nt + tid] = 0.f;
+    for (int i0 = 0; i0 < N; i0 += kIC) {
+      const int sh = i0 & 31;
+      const bool straddle = ((min(i0 + kIC, N) - 1) >> 5) != (i0 >> 5);
+      const uint32_t base = ((uint32_t)b * NI + (uint32_t)(i0 >> 5)) * stride;
+      float ds[kIC][G], dTi[kIC];
+#pragma unroll
+      for (int ic = 0; ic < kIC; ++ic) {
+        dTi[ic] = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) ds[ic][g] = (i0 + ic < N) ? dS_s[(i0 + ic) * G + g] : 0.f;
+      }
+#pragma unroll 2
+      for (int j = 0; j < N; ++j) {
+        float wv[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) wv[g] = w[((size_t)g * N + j) * L + d];
+        const uint32_t bits = oda_bits(base + (uint32_t)(j * L + d), stride, sh, straddle, key);
+        float pj = 0.f;
+#pragma unroll
+        for (int ic = 0; ic < kIC; ++ic) {
+          float u = 0.f;
+#pragma unroll
+          for (int g = 0; g < G; ++g) u = fmaf(ds[ic][g], wv[g], u);
+          u = keep_bit(u, bits, ic);
+          dTi[ic] += u;
+          pj += u;
+        }
+        dT_s[j * nt + tid] -= pj;
+      }
+#pragma unroll
+      for (int ic = 0; ic < kIC; ++ic)
+        if (i0 + ic < N) dT_s[(i0 + ic) * nt + tid] += dTi[ic];
+    }
+    const float qd = ql[(size_t)b * L + d] * dc.scale;      // (the kept values' factor 2 rides on q here)
+    float dq = 0.f;
+    for (int n = 0; n < N; ++n) {
+      const float t = dT_s[n * nt + tid];
+      d_vl[((size_t)b * N + n) * L + d] = t * qd;
+      dq = fmaf(t, vlb[(size_t)n * L + d], dq);
+    }
+    d_ql[(size_t)b * L + d] = dq * dc.scale;
+  }
+}
+
+// backward d_w slabs, bit mask: as oda_bwd_weight_kernel; the hash words of the chunk's kIC regions j are drawn once per
+// 32 regions i
+template <int G>
+__global__ void oda_bwd_weight_bits_kernel(const float* __restrict__ vl, const float* __restrict__ ql,
+                                           const float* __restrict__ dS, float* __restrict__ slab, DropCfg dc, int B, int N,
+                                           int L, int samples_per_group) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* dS_s = reinterpret_cast<float*>(smem);  // [N + 3][G] (zero padded to a multiple of 4 rows)
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int j0 = blockIdx.x * kIC, sg = blockIdx.y;
+  const int NQ = (N + 3) >> 2, NI = (N + 31) >> 5;
+  const uint32_t key = drop_key(dc);
+  const uint32_t stride = (uint32_t)N * (uint32_t)L;
+  const int b_lo = sg * samples_per_group, b_hi = min(B, b_lo + samples_per_group);
+  const int d = tid;  // the launcher guarantees blockDim >= L, so one feature per lane
+  const bool active = d < L;
+  float dw[kIC][G];
+#pragma unroll
+  for (int jc = 0; jc < kIC; ++jc)
+#pragma unroll
+    for (int g = 0; g < G; ++g) dw[jc][g] = 0.f;
+  for (int b = b_lo; b < b_hi; ++b) {
+    __syncthreads();
+    for (int t = tid; t < NQ * 4 * G; t += nt) dS_s[t] = (t < N * G) ? dS[(size_t)b * N * G + t] : 0.f;
+    __syncthreads();
+    if (!active) continue;
+    const float* vlb = vl + (size_t)b * N * L;
+    const float qd = ql[(size_t)b * L + d];
+    float Tj[kIC];
+#pragma unroll
+    for (int jc = 0; jc < kIC; ++jc) Tj[jc] = (j0 + jc < N) ? vlb[(size_t)(j0 + jc) * L + d] * qd : 0.f;
+    for (int iw = 0; iw < NI; ++iw) {
+      uint32_t words[kIC];
+#pragma unroll
+      for (int jc = 0; jc < kIC; ++jc)
+        words[jc] = mask_word32(((uint32_t)b * NI + iw) * stride + (uint32_t)(min(j0 + jc, N - 1) * L + d), key);
+      const int q_hi = min(NQ, (iw + 1) * 8);
+      for (int iq = iw * 8; iq < q_hi; ++iq) {
+        const int sh = (iq & 7) * 4;
+        float Ti[4], ds[4][G];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = iq * 4 + k;
+          Ti[k] = (i < N) ? vlb[(size_t)i * L + d] * qd : 0.f;
+#pragma unroll
+          for (int g = 0; g < G; ++g) ds[k][g] = dS_s[i * G + g];  // zero rows beyond N
+        }
+#pragma unroll
+        for (int jc = 0; jc < kIC; ++jc) {
+          const uint32_t bits = words[jc] >> sh;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float val = keep_bit(Ti[k] - Tj[jc], bits, k);
+#pragma unroll
+            for (int g = 0; g < G; ++g) dw[jc][g] = fmaf(ds[k][g], val, dw[jc][g]);
+          }
+        }
+      }
+    }
+  }
+  if (!active) return;
+#pragma unroll
+  for (int jc = 0; jc < kIC; ++jc)
+    if (j0 + jc < N)
+#pragma unroll
+      for (int g = 0; g < G; ++g) slab[(((size_t)sg * G + g) * N + j0 + jc) * L + d] = dw[jc][g] * dc.scale;
 }
 
 // ------------------------------------------------------------------------------------------ forward
@@ -283,7 +493,7 @@ __global__ __launch_bounds__(1024) void oda_dbias_kernel(const float* __restrict
 }
 
 // mask[b][i][j*L+d] = keep/(1-p) exactly as the fused kernels draw it (test / debugging aid)
-__global__ __launch_bounds__(256) void oda_mask_kernel(float* __restrict__ mask, DropCfg dc, int N, int L) {
+__global__ __launch_bounds__(256) void oda_mask_kernel(float* __restrict__ mask, DropCfg dc, int N, int L, bool bits_mode) {
   const int b = blockIdx.z, i = blockIdx.y;
   const int e = blockIdx.x * 256 + threadIdx.x;  // j*L + d
   if (e >= N * L) return;
@@ -291,8 +501,19 @@ __global__ __launch_bounds__(256) void oda_mask_kernel(float* __restrict__ mask,
   const int NQ = (N + 3) >> 2;
   const uint64_t seed_eff = dc.effective();
   float m = 1.f;
-  if (dc.p8 > 0) m = keep_scale(mask_word(mask_counter(b, i >> 2, j, d, NQ, N, L), seed_eff), i & 3, dc.p8, dc.scale);
+  if (bits_mode) {
+    const int NI = (N + 31) >> 5;
+    const uint32_t cnt = (((uint32_t)b * NI + (uint32_t)(i >> 5)) * N + j) * L + d;
+    m = ((mask_word32(cnt, drop_key(dc)) >> (i & 31)) & 1u) != 0u ? dc.scale : 0.f;
+  } else if (dc.p8 > 0) {
+    m = keep_scale(mask_word(mask_counter(b, i >> 2, j, d, NQ, N, L), seed_eff), i & 3, dc.p8, dc.scale);
+  }
   mask[((size_t)b * N + i) * N * L + e] = m;
+}
+
+// p = 0.5 and 32-bit element counters: the one-bit-per-element layout (VQA_K2_BYTE_MASK=1 keeps the byte layout)
+static bool oda_bits_mode(const DropCfg& dc, int B, int N, int L) {
+  return dc.p8 == kDropHalf && (size_t)B * ((N + 31) / 32) * N * L < (1ull << 32) && std::getenv("VQA_K2_BYTE_MASK") == nullptr;
 }
 
 static int oda_threads(int L) {
@@ -305,6 +526,12 @@ template <int G>
 static int launch_fwd(const float* vl, const float* ql, const float* w, const float* bias, float* logits, DropCfg dc,
                       int B, int N, int L, hipStream_t s) {
   const int nt = oda_threads(L);
+  if (oda_bits_mode(dc, B, N, L)) {
+    const size_t lds_b = (size_t)(nt / 64) * kIB * G * sizeof(float);
+    hipLaunchKernelGGL((oda_fwd_bits_kernel<G>), dim3((N + kIB - 1) / kIB, B), dim3(nt), lds_b, s, vl, ql, w, bias, logits, dc, N,
+                       L);
+    return check_launch("object_difference_attention_fwd");
+  }
   const size_t lds = (size_t)(nt / 64) * kIC * G * sizeof(float);
   dim3 grid((N + kIC - 1) / kIC, B);
   if (dc.p8 > 0)
@@ -321,7 +548,10 @@ static int launch_bwd(const float* vl, const float* ql, const float* w, const fl
   {
     const size_t lds = ((size_t)N * nt + (size_t)N * G) * sizeof(float);
     VQA_REQUIRE(lds <= 160 * 1024, VQA_E_UNSUPPORTED, "object_difference_attention_bwd: N=%d L=%d need %zu B of LDS", N, L, lds);
-    if (dc.p8 > 0) {
+    if (oda_bits_mode(dc, B, N, L)) {
+      VQA_ENSURE_LDS((oda_bwd_data_bits_kernel<G>), lds);
+      hipLaunchKernelGGL((oda_bwd_data_bits_kernel<G>), dim3(B), dim3(nt), lds, s, vl, ql, w, dS, d_vl, d_ql, dc, N, L);
+    } else if (dc.p8 > 0) {
       VQA_ENSURE_LDS((oda_bwd_data_kernel<G, true>), lds);
       hipLaunchKernelGGL((oda_bwd_data_kernel<G, true>), dim3(B), dim3(nt), lds, s, vl, ql, w, dS, d_vl, d_ql, dc, N, L);
     } else {
@@ -334,7 +564,9 @@ static int launch_bwd(const float* vl, const float* ql, const float* w, const fl
     const int spg = (B + SG - 1) / SG;
     const size_t lds = (size_t)(N + 3) * G * sizeof(float);
     dim3 grid((N + kIC - 1) / kIC, SG);
-    if (dc.p8 > 0)
+    if (oda_bits_mode(dc, B, N, L))
+      hipLaunchKernelGGL((oda_bwd_weight_bits_kernel<G>), grid, dim3(nt), lds, s, vl, ql, dS, slab, dc, B, N, L, spg);
+    else if (dc.p8 > 0)
       hipLaunchKernelGGL((oda_bwd_weight_kernel<G, true>), grid, dim3(nt), lds, s, vl, ql, dS, slab, dc, B, N, L, spg);
     else
       hipLaunchKernelGGL((oda_bwd_weight_kernel<G, false>), grid, dim3(nt), lds, s, vl, ql, dS, slab, dc, B, N, L, spg);
@@ -415,6 +647,6 @@ extern "C" int vqa_object_difference_dropout_mask(float* mask, float p_drop, uin
   if (rc != VQA_OK) return rc;
   const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
   hipLaunchKernelGGL(oda_mask_kernel, dim3((N * L + 255) / 256, N, B), dim3(256), 0, static_cast<hipStream_t>(stream), mask,
-                     dc, N, L);
+                     dc, N, L, oda_bits_mode(dc, B, N, L));
   return check_launch("object_difference_dropout_mask");
 }
