@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VQA_ABI_VERSION 4
+#define VQA_ABI_VERSION 5
 
 #define VQA_OK 0
 #define VQA_E_BADARG (-1)      /* null pointer, non-positive size, size over a documented limit */
@@ -347,13 +347,13 @@ int vqa_column_sum_bf16(const vqa_bf16_t* x, int ld, float* out, void* workspace
  * library GEMM: config/CoR2.py:94-122, putils/__init__.py:16-33).
  *   vqa_bias_act:       out = act(y[g,b,:] + bias[g,:]);  y [G,B,A]; bias row g at bias + g*bias_stride or NULL;
  *                       out [G,B,A] (group_first != 0) or [B,G,A].  act: 0 none, 1 relu, 2 sigmoid.
- *   vqa_act_bwd_colsum: gz[g,b,:] = gy * act'(out) written [G,B,A]; d_bias[g,:] = sum_b gz[g,b,:] (fixed order) or
- *                       NULL; gy and out in the layout vqa_bias_act wrote (group_first).
+ *   vqa_act_bwd_colsum: gz[g,b,:] = gy * act'(out) written [G,B,A]; d_bias row g (at d_bias + g*d_bias_stride) =
+ *                       sum_b gz[g,b,:] (fixed order), or NULL; gy and out in the layout vqa_bias_act wrote (group_first).
  * ------------------------------------------------------------------------------------------- */
 int vqa_bias_act(const float* y, const float* bias, int bias_stride, float* out, int G, int B, int A,
                  int act, int group_first, vqa_stream_t stream);
-int vqa_act_bwd_colsum(const float* gy, const float* out, float* gz, float* d_bias, int G, int B, int A,
-                       int act, int group_first, vqa_stream_t stream);
+int vqa_act_bwd_colsum(const float* gy, const float* out, float* gz, float* d_bias, int d_bias_stride, int G, int B,
+                       int A, int act, int group_first, vqa_stream_t stream);
 
 /* Rank sum of the vector-vector Mutan fusion (putils.MutanFusion.forward, putils/__init__.py:232-238, with 2-D inputs --
  * fusion_final of config/CoR2.py:182 / config/ODA.py:197):  out[b,:] = sum_r h1[b,r,:] * h2[b,r,:]  (the reference's

@@ -285,6 +285,35 @@ def test_stacked_parameters_are_views_of_the_flat_buffer():
     assert sd["att1.list_linear_v_fusion.2.linear.weight"].shape == (155, 2048)
 
 
+@pytest.mark.parametrize("name,nans", [("cor2", 300), ("oda", 300)])
+def test_parameter_gradients_are_written_into_the_flat_buffer(name, nans):
+    """The backward kernels write every parameter gradient at its offset of the trainer's flat gradient buffer
+    (ops._grad_like): the per-step gather has nothing to copy, and the buffer holds what a plain backward computes."""
+    from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
+    model = build(name, nans).eval()                      # eval: no dropout, the two backward passes see the same function
+    v, q, a = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(6, answers=nans, seed=11))
+    sample = {"v": v, "q_idxes": q}
+    from vqa_playground_pytorch_amd import ops
+    loss = ops.kld_sum_loss(model(sample), a)
+    ref = torch.autograd.grad(loss, [p for p in model.parameters() if p.requires_grad])   # separate tensors: no slots registered
+    tr = DataParallelTrainer(model, lr=0.0, clip=0.0)
+    f = tr.flat
+    loss = ops.kld_sum_loss(model(sample), a)
+    f.begin_backward()
+    try:
+        loss.backward()
+    finally:
+        f.end_backward()
+    in_place = sum(p.grad is not None and p.grad.data_ptr() == g.data_ptr() for p, g in zip(f.params, f.g_views))
+    names = {id(p): n for n, p in model.named_parameters()}
+    copied = [names[id(p)] for p, g in zip(f.params, f.g_views) if p.grad is None or p.grad.data_ptr() != g.data_ptr()]
+    f.gather_grads()
+    assert f.last_gathered == 0 and in_place == len(f.params), copied
+    by_id = {id(p): g for p, g in zip([p for p in model.parameters() if p.requires_grad], ref)}
+    for p, view in zip(f.params, f.g_views):
+        torch.testing.assert_close(view, by_id[id(p)], rtol=1e-4, atol=1e-6)
+
+
 def test_graph_trainer_fed_by_prefetcher_matches_eager():
     """Distinct batches streamed from pinned host memory through feed.DevicePrefetcher (which recycles its two device
     slots) into the graph-replayed trainer: the loss sequence equals the eager trainer's on the same batches, and the

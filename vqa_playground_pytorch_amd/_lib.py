@@ -9,7 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VQA_LIB_PATH", os.path.join(_HERE, "libvqa_mi355x.so"))  # env override: profiling builds
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c_f = ctypes.c_void_p          # device pointer to fp32
 _c_pp = ctypes.c_void_p         # host array of device pointers
@@ -86,7 +86,7 @@ SIGNATURES = {
     "vqa_gru_gates_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_f, _c_f,
                                  _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_bias_act": (_c_i, [_c_f, _c_f, _c_i, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
-    "vqa_act_bwd_colsum": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_act_bwd_colsum": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_column_sum_workspace_bytes": (_c_sz, [_c_i, _c_i]),
     "vqa_column_sum": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_sz, _c_i, _c_i, _c_st]),
     "vqa_column_sum_bf16": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_sz, _c_i, _c_i, _c_st]),

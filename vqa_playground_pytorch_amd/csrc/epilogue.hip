@@ -36,8 +36,9 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const float* __restrict__
 
 // grid (ceil(A/16), G); gy / out are [G,B,A] (group_first) or [B,G,A]
 __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const float* __restrict__ gy, const float* __restrict__ out,
-                                                             float* __restrict__ gz, float* __restrict__ d_bias, int G, int B,
-                                                             int A, int act, int group_first) {
+                                                             float* __restrict__ gz, float* __restrict__ d_bias,
+                                                             int d_bias_stride, int G, int B, int A, int act,
+                                                             int group_first) {
   __shared__ float part[16][17];
   const int c = threadIdx.x & 15, slice = threadIdx.x >> 4;
   const int g = blockIdx.y;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const float* __rest
     float t = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) t += part[q][c];
-    d_bias[(size_t)g * A + a] = t;
+    d_bias[(size_t)g * d_bias_stride + a] = t;
   }
 }
 
@@ -123,13 +124,14 @@ extern "C" int vqa_bias_act(const float* y, const float* bias, int bias_stride, 
   return check_launch("bias_act");
 }
 
-extern "C" int vqa_act_bwd_colsum(const float* gy, const float* out, float* gz, float* d_bias, int G, int B, int A, int act,
-                                  int group_first, vqa_stream_t stream) {
+extern "C" int vqa_act_bwd_colsum(const float* gy, const float* out, float* gz, float* d_bias, int d_bias_stride, int G, int B,
+                                  int A, int act, int group_first, vqa_stream_t stream) {
   VQA_REQUIRE(gy && out && gz, VQA_E_BADARG, "act_bwd_colsum: null pointer");
+  VQA_REQUIRE(d_bias == nullptr || d_bias_stride >= A, VQA_E_BADARG, "act_bwd_colsum: d_bias_stride %d < A = %d", d_bias_stride, A);
   VQA_REQUIRE(G > 0 && B > 0 && A > 0 && G <= 65535, VQA_E_BADARG, "act_bwd_colsum: bad sizes G=%d B=%d A=%d", G, B, A);
   VQA_REQUIRE(act >= 0 && act <= 2, VQA_E_BADARG, "act_bwd_colsum: act must be 0, 1 or 2, got %d", act);
   hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3((A + 15) / 16, G), dim3(256), 0, static_cast<hipStream_t>(stream), gy, out, gz,
-                     d_bias, G, B, A, act, group_first);
+                     d_bias, d_bias_stride, G, B, A, act, group_first);
   return check_launch("act_bwd_colsum");
 }
 

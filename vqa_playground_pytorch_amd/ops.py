@@ -118,6 +118,50 @@ def pad_to(n, multiple=BF16_PAD):
     return (n + multiple - 1) // multiple * multiple
 
 
+# ---- gradient slots ---------------------------------------------------------------------------------------------
+# A trainer that keeps all parameters in ONE flat buffer and all gradients in another (trainer.FlatState) registers the
+# pair here.  The backward of every op that produces a parameter gradient then asks `_grad_like(w)` for its output
+# tensor: when `w` lives in the flat parameter buffer the answer is the view of the flat GRADIENT buffer at the same
+# offset, so the kernel writes the gradient where the all-reduce / clip / Adam kernels read it.  autograd's
+# AccumulateGrad adopts a freshly produced gradient as `.grad` without a copy, so the per-step gather of ~70 gradients
+# (one 48 MB multi-tensor copy, 31 us at B = 512) has nothing left to move.  A slot is handed out once per backward
+# pass (`begin_backward`): a parameter used twice gets a fresh tensor the second time and autograd adds it in.
+_grad_slots = None
+_slots_taken = []
+
+
+def set_grad_slots(p_flat, g_flat):
+    """Register (or, with None, drop) the flat parameter / gradient buffers whose offsets correspond."""
+    global _grad_slots
+    _grad_slots = None if p_flat is None else (p_flat, g_flat)
+    del _slots_taken[:]
+
+
+def begin_backward():
+    del _slots_taken[:]
+
+
+def _grad_like(w, rows_strided=False):
+    """rows_strided: a 2-D `w` whose rows are contiguous but spaced (a stack of odd-sized biases, padded apart in the flat
+    buffer) is matched too -- for callers whose kernel takes a row stride."""
+    s = _grad_slots
+    if s is not None and w.dtype == torch.float32 and w.device == s[0].device and w.numel() > 0:
+        dense = w.is_contiguous()
+        spaced = (not dense) and rows_strided and w.dim() == 2 and w.stride(1) == 1 and w.stride(0) >= w.shape[1]
+        if dense or spaced:
+            p_flat, g_flat = s
+            off = w.data_ptr() - p_flat.data_ptr()
+            n = w.numel() if dense else (w.shape[0] - 1) * w.stride(0) + w.shape[1]
+            if off >= 0 and off % 4 == 0 and off // 4 + n <= p_flat.numel():
+                lo = off // 4
+                if all(lo + n <= a or lo >= b for a, b in _slots_taken):
+                    _slots_taken.append((lo, lo + n))
+                    if dense:
+                        return g_flat[lo:lo + n].view(w.shape)
+                    return g_flat.as_strided(tuple(w.shape), tuple(w.stride()), lo)
+    return torch.empty_like(w) if w.is_contiguous() else torch.empty(w.shape, device=w.device, dtype=w.dtype)
+
+
 def _seed_args(seed):
     """seed: an int (host seed), or (device int64 tensor [1], int salt) -> (c_uint64 value, device pointer or None).
     With a device tensor the kernels read the step's seed at run time (*tensor + salt), which is what lets a captured
@@ -279,6 +323,7 @@ class AttentionLogits(torch.autograd.Function):
         _launch(name, (M, K, G, float(p_drop) > 0), getattr(_lib.lib(), "vqa_" + name), _p(x), ld, _p(w), _p(bias),
                 _p(logits), float(p_drop), sv, sp, M, K, G)
         ctx.save_for_backward(x, w)
+        ctx.bias = bias
         ctx.cfg = (float(p_drop), seed, M, K, G, ld)
         return logits
 
@@ -288,8 +333,8 @@ class AttentionLogits(torch.autograd.Function):
         p_drop, seed, M, K, G, ld = ctx.cfg
         d_logits = _prep("grad_logits", d_logits)
         d_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        d_w = torch.empty_like(w)
-        d_b = torch.empty(G, device=x.device, dtype=torch.float32)
+        d_w = _grad_like(w)
+        d_b = _grad_like(ctx.bias)
         L_ = _lib.lib()
         ws_bytes = L_.vqa_attention_logits_bwd_workspace_bytes(M, K, G)
         ws = torch.empty((ws_bytes + 3) // 4, device=x.device, dtype=torch.float32)
@@ -360,6 +405,7 @@ class LowRankBilinearFusion(torch.autograd.Function):
                     _p(x), L, _ptr_array(w1), _ptr_array(b1), _p(h2), _p(out), _p(h1), B, N, L, H, R)
             if need_bwd:
                 ctx.save_for_backward(x, h2, h1, *w1)
+                ctx.b1 = b1
         ctx.dims = (B, N, L, H, R)
         return out
 
@@ -377,8 +423,8 @@ class LowRankBilinearFusion(torch.autograd.Function):
         dev = x.device
         d_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         d_h2 = torch.empty_like(h2)
-        d_w1 = [torch.empty_like(w) for w in w1]
-        d_b1 = [torch.empty(H, device=dev, dtype=torch.float32) for _ in range(R)]
+        d_w1 = [_grad_like(w) for w in w1]
+        d_b1 = [_grad_like(b) for b in (b1 if ctx.folded else ctx.b1)]
         if ctx.folded:
             ws_bytes = L_.vqa_lowrank_bilinear_fusion_folded_bwd_workspace_bytes(B, N, L, H, R)
             ws = torch.empty((ws_bytes + 3) // 4, device=dev, dtype=torch.float32)
@@ -621,6 +667,7 @@ class ObjectDifferenceAttention(torch.autograd.Function):
                 _lib.lib().vqa_object_difference_attention_fwd, _p(vl), _p(ql), _p(w), _p(bias), _p(logits),
                 float(p_drop), sv, sp, B, N, L, G)
         ctx.save_for_backward(vl, ql, w)
+        ctx.bias = bias
         ctx.cfg = (float(p_drop), seed, G)
         return logits
 
@@ -630,8 +677,8 @@ class ObjectDifferenceAttention(torch.autograd.Function):
         p_drop, seed, G = ctx.cfg
         B, N, L = vl.shape
         d_logits = _prep("grad_logits", d_logits)
-        d_vl, d_ql, d_w = torch.empty_like(vl), torch.empty_like(ql), torch.empty_like(w)
-        d_bias = torch.empty(G, device=vl.device, dtype=torch.float32)
+        d_vl, d_ql, d_w = torch.empty_like(vl), torch.empty_like(ql), _grad_like(w)
+        d_bias = _grad_like(ctx.bias)
         L_ = _lib.lib()
         ws_bytes = L_.vqa_object_difference_attention_bwd_workspace_bytes(B, N, L, G)
         ws = torch.empty((ws_bytes + 3) // 4, device=vl.device, dtype=torch.float32)
@@ -663,6 +710,7 @@ class LinearAct(torch.autograd.Function):
         _launch("linear_act_fwd", (M, K, N, float(p_drop) > 0), _lib.lib().vqa_linear_act_fwd,
                 _p(x), K, _p(w), _p(bias), _p(y), M, K, N, int(act), float(p_drop), sv, sp)
         ctx.save_for_backward(x, w, y)
+        ctx.bias = bias
         ctx.cfg = (M, K, N, int(act), float(p_drop), seed, bias is not None)
         return y
 
@@ -686,8 +734,8 @@ class LinearAct(torch.autograd.Function):
         elif ctx.needs_input_grad[0]:
             d_x = torch.empty_like(x)
         in_kernel_dx = d_x is not None and not (p_drop == 0 and M >= 4096 and LinearAct.library_dgrad)
-        d_w = torch.empty_like(w)
-        d_b = torch.empty(N, device=x.device, dtype=torch.float32) if has_bias else None
+        d_w = _grad_like(w)
+        d_b = _grad_like(ctx.bias) if has_bias else None
         L_ = _lib.lib()
         ws_bytes = L_.vqa_linear_act_bwd_workspace_bytes(M, K, N)
         ws = torch.empty((ws_bytes + 3) // 4, device=x.device, dtype=torch.float32)
@@ -707,7 +755,7 @@ def linear_act(x, w, bias=None, act=None, p_drop=0.0, seed=0, pregated=False):
     return LinearAct.apply(x, w, bias, code, p_drop, seed, pregated)
 
 
-def column_sum(x):
+def column_sum(x, out=None):
     """out[n] = sum_m x[m,n] for a 2-D fp32 / bf16 matrix -> fp32 [N]; fixed-order reduction, safe under graph replay."""
     x = _prep("x", x, _REGION_DTYPES)
     if x.dim() != 2:
@@ -716,7 +764,8 @@ def column_sum(x):
     L_ = _lib.lib()
     ws_bytes = L_.vqa_column_sum_workspace_bytes(M, N)
     ws = torch.empty((ws_bytes + 3) // 4, device=x.device, dtype=torch.float32) if ws_bytes else None
-    out = torch.empty(N, device=x.device, dtype=torch.float32)
+    if out is None or out.dtype != torch.float32 or out.shape != (N,) or not out.is_contiguous():
+        out = torch.empty(N, device=x.device, dtype=torch.float32)
     name = "column_sum" + _sfx(x.dtype)
     _launch(name, (M, N), getattr(L_, "vqa_" + name), _p(x), N, _p(out), _p(ws), ws_bytes, M, N)
     return out
@@ -743,8 +792,10 @@ class LinearFn(torch.autograd.Function):
                 else:
                     y = torch.relu(torch.nn.functional.linear(x, w, b))
             ctx.save_for_backward(x, w, y)
+            ctx.bias = b
             return y
         ctx.save_for_backward(x, w)
+        ctx.bias = b
         with timed("library_gemm", gemm):
             return torch.nn.functional.linear(x, w, b)
 
@@ -771,8 +822,8 @@ class LinearFn(torch.autograd.Function):
             # data gradient needs the masked grad_output as a tensor, applies the relu mask while it stages the operand
             gy2, x2 = gy2.contiguous(), x2.contiguous()
             y2 = y.reshape(-1, N).contiguous() if mask_in_kernel else gy2
-            d_w = torch.empty_like(w)
-            d_b = torch.empty(N, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+            d_w = _grad_like(w)
+            d_b = _grad_like(ctx.bias) if ctx.has_bias else None
             L_ = _lib.lib()
             ws_bytes = L_.vqa_linear_act_bwd_workspace_bytes(M, K, N)
             ws = torch.empty((ws_bytes + 3) // 4, device=x.device, dtype=torch.float32)
@@ -782,8 +833,13 @@ class LinearFn(torch.autograd.Function):
         d_w = None
         if ctx.needs_input_grad[1]:
             with timed("library_gemm", (N, K, M)):
-                d_w = gy2.t() @ x2
-        d_b = column_sum(gy2).to(gy.dtype) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+                if gy2.dtype == torch.float32 and x2.dtype == torch.float32 and w.dtype == torch.float32:
+                    d_w = torch.mm(gy2.t(), x2, out=_grad_like(w))      # (straight into the flat gradient buffer, if any)
+                else:
+                    d_w = gy2.t() @ x2
+        d_b = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            d_b = column_sum(gy2, out=_grad_like(ctx.bias) if ctx.bias.dtype == torch.float32 else None).to(gy.dtype)
         return d_x, d_w, d_b, None
 
     engine_dw = __import__("os").environ.get("VQA_ENGINE_DW", "1") == "1"
@@ -838,6 +894,7 @@ class BatchedLinearFn(torch.autograd.Function):
         G, B, A = y.shape
         code = _ACT_CODES[act]
         out = torch.empty((G, B, A) if group_first else (B, G, A), device=y.device, dtype=torch.float32)
+        ctx.bias = b
         if b is not None and b.stride(-1) != 1:
             b = b.contiguous()
         _launch("bias_act", (G, B, A, code), _lib.lib().vqa_bias_act, _p(y), _p(b), b.stride(0) if b is not None else 0,
@@ -853,9 +910,12 @@ class BatchedLinearFn(torch.autograd.Function):
         gy = _prep("grad_out", gy)
         G, B, A = out.shape if group_first else (out.shape[1], out.shape[0], out.shape[2])
         gz = torch.empty(G, B, A, device=gy.device, dtype=torch.float32)
-        d_b = torch.empty(G, A, device=gy.device, dtype=torch.float32) if (has_bias and ctx.needs_input_grad[2]) else None
-        _launch("act_bwd_colsum", (G, B, A, code), _lib.lib().vqa_act_bwd_colsum, _p(gy), _p(out), _p(gz), _p(d_b), G, B, A,
-                code, int(group_first))
+        d_b = None
+        if has_bias and ctx.needs_input_grad[2]:
+            d_b = _grad_like(ctx.bias, rows_strided=True) if tuple(ctx.bias.shape) == (G, A) else \
+                torch.empty(G, A, device=gy.device, dtype=torch.float32)
+        _launch("act_bwd_colsum", (G, B, A, code), _lib.lib().vqa_act_bwd_colsum, _p(gy), _p(out), _p(gz), _p(d_b),
+                d_b.stride(0) if d_b is not None else A, G, B, A, code, int(group_first))
         d_x = None
         if ctx.needs_input_grad[0]:
             # written in the consumer's [B,G,K] layout (row stride G*K, batch stride K: a layout the strided-batched GEMM
@@ -866,7 +926,10 @@ class BatchedLinearFn(torch.autograd.Function):
         d_w = None
         if ctx.needs_input_grad[1]:
             with timed("library_gemm", (G * A, w.shape[2], B)):
-                d_w = torch.bmm(gz.transpose(1, 2), x.transpose(0, 1))
+                if w.dtype == torch.float32 and x.dtype == torch.float32:
+                    d_w = torch.bmm(gz.transpose(1, 2), x.transpose(0, 1), out=_grad_like(w))   # (flat gradient buffer, if any)
+                else:
+                    d_w = torch.bmm(gz.transpose(1, 2), x.transpose(0, 1))
         return d_x, d_w, d_b, None, None
 
 

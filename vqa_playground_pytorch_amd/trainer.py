@@ -163,7 +163,7 @@ class FlatState:
             view = self._view_of[id(p)]
             if g is None:
                 view.zero_()
-            else:
+            elif g.data_ptr() != view.data_ptr() or g.stride() != view.stride():
                 src.append(g)
                 dst.append(view)
             p.grad = view
@@ -174,16 +174,31 @@ class FlatState:
         return self.offsets[next(i for i, q in enumerate(self.params) if q is p)]
 
     def gather_grads(self):
+        """Whatever backward left in p.grad -> the flat gradient buffer.  Gradients the kernels wrote there themselves
+        (ops._grad_like: autograd adopted the slot as .grad) are in place already; only the rest is copied."""
         src, dst = [], []
         for p, view in zip(self.params, self.g_views):
             if p.grad is None:
                 view.zero_()
-            else:
+            elif p.grad.data_ptr() != view.data_ptr() or p.grad.stride() != view.stride():
                 src.append(p.grad)
                 dst.append(view)
-        torch._foreach_copy_(dst, src)
+        self.last_gathered = len(src)       # (tests: 0 when every gradient was written in place)
+        if src:
+            torch._foreach_copy_(dst, src)
         for p, view in zip(self.params, self.g_views):
             p.grad = view
+
+    def begin_backward(self):
+        """Called right before a backward pass: parameter gradients may be written straight into the flat buffer."""
+        from . import ops
+        ops.set_grad_slots(self.p, self.g)
+        self.drop_grads()
+
+    @staticmethod
+    def end_backward():
+        from . import ops
+        ops.set_grad_slots(None, None)
 
 
 class DataParallelTrainer:
@@ -293,8 +308,11 @@ class DataParallelTrainer:
         if self.hip:
             from . import ops
             f = self.flat
-            f.drop_grads()
-            loss.backward()
+            f.begin_backward()
+            try:
+                loss.backward()
+            finally:
+                f.end_backward()
             f.gather_grads()
             if self.world > 1:
                 dist.all_reduce(f.g, op=dist.ReduceOp.SUM, group=self.group)
@@ -321,8 +339,11 @@ class DataParallelTrainer:
             loss = kld_sum_loss(self.model(sample), target)
         finally:
             ops.set_device_seed(None)
-        f.drop_grads()
-        loss.backward()
+        f.begin_backward()
+        try:
+            loss.backward()
+        finally:
+            f.end_backward()
         f.gather_grads()
         return loss.detach()
 
@@ -458,7 +479,11 @@ class DataParallelTrainer:
             if device_seed:
                 ops.set_device_seed(None)
         live = [(o, i) for o, i in zip(outs, ins) if i.requires_grad]
-        grads = torch.autograd.grad(loss, self._late + [i for _, i in live], allow_unused=True)
+        ops.set_grad_slots(self.flat.p, self.flat.g)
+        try:
+            grads = torch.autograd.grad(loss, self._late + [i for _, i in live], allow_unused=True)
+        finally:
+            ops.set_grad_slots(None, None)
         self.flat.store_grads(self._late, grads[:len(self._late)])
         pairs = [(o, g) for (o, _), g in zip(live, grads[len(self._late):]) if g is not None]
         self._cut = ([o for o, _ in pairs], [g for _, g in pairs])
@@ -468,7 +493,12 @@ class DataParallelTrainer:
         """backward from the cut to the inputs + gather of the early parameters' gradients."""
         tensors, grads_in = self._cut
         self._cut = None
-        grads = torch.autograd.grad(tensors, self._early, grad_outputs=grads_in, allow_unused=True)
+        from . import ops
+        ops.set_grad_slots(self.flat.p, self.flat.g)
+        try:
+            grads = torch.autograd.grad(tensors, self._early, grad_outputs=grads_in, allow_unused=True)
+        finally:
+            ops.set_grad_slots(None, None)
         self.flat.store_grads(self._early, grads)
 
     def _reduce_late_async(self):
