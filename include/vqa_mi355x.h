@@ -129,6 +129,31 @@ int vqa_softmax_attention_pool_bwd(const float* alpha, const float* v, const flo
                                    const float* d_alpha_ext, float* d_logits, float* d_v,
                                    int B, int N, int D, int G, vqa_stream_t stream);
 
+/* K3 with what MyATT does to the pooled features next folded in (config/CoR2.py:143-147: every glimpse's MyLinear
+ * starts with F.dropout(p=0.5) on its slice of `pooled`), plus the undropped glimpse 0 that CoR2's relation step reads
+ * (config/CoR2.py:216 with alpha1[..., 0]):
+ *   pooled[b,g,:] = keep(b,g,:) * sum_n alpha[b,n,g] v[b,n,:]        keep: the counter-hash dropout of K2 / K5 over the
+ *                                                                    element index of the [B,G,D] tensor (seed, seed_ptr
+ *                                                                    as there); p_drop = 0: plain K3
+ *   first[b,:]    = sum_n alpha[b,n,0] v[b,n,:]                       [B,D] or NULL
+ * Backward: d_pooled is the gradient of the DROPPED pooled (the mask is re-applied in the load), d_first [B,D] or NULL
+ * the gradient of `first`; the rest as vqa_softmax_attention_pool_bwd.  Limit with dropout: B*G*D < 2^32. */
+int vqa_softmax_attention_pool_drop_fwd(const float* logits, const float* v, float* alpha, float* pooled,
+                                        float* first, float p_drop, uint64_t seed, const uint64_t* seed_ptr,
+                                        int B, int N, int D, int G, vqa_stream_t stream);
+int vqa_softmax_attention_pool_drop_bwd(const float* alpha, const float* v, const float* d_pooled,
+                                        const float* d_first, const float* d_alpha_ext, float* d_logits,
+                                        float* d_v, float p_drop, uint64_t seed, const uint64_t* seed_ptr, int B,
+                                        int N, int D, int G, vqa_stream_t stream);
+int vqa_softmax_attention_pool_drop_fwd_bf16(const float* logits, const vqa_bf16_t* v, float* alpha, float* pooled,
+                                             float* first, float p_drop, uint64_t seed, const uint64_t* seed_ptr,
+                                             int B, int N, int D, int G, vqa_stream_t stream);
+int vqa_softmax_attention_pool_drop_bwd_bf16(const float* alpha, const vqa_bf16_t* v, const float* d_pooled,
+                                             const float* d_first, const float* d_alpha_ext, float* d_logits,
+                                             vqa_bf16_t* d_v, float p_drop, uint64_t seed,
+                                             const uint64_t* seed_ptr, int B, int N, int D, int G,
+                                             vqa_stream_t stream);
+
 /* K3 with v / d_v stored as bf16 (logits, alpha, pooled and their gradients stay fp32). */
 int vqa_softmax_attention_pool_fwd_bf16(const float* logits, const vqa_bf16_t* v, float* alpha,
                                         float* pooled, int B, int N, int D, int G, vqa_stream_t stream);

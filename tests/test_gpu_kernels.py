@@ -154,6 +154,39 @@ def test_softmax_attention_pool(ops, B, N, D, G, with_ext, need_dv):
         assert vt.grad is None
 
 
+@pytest.mark.parametrize("p_drop", [0.0, 0.5, 0.25])
+@pytest.mark.parametrize("B,N,D,G,want_first", [(3, 36, 2048, 4, True), (2, 7, 72, 3, False), (5, 100, 256, 4, True)])
+def test_softmax_attention_pool_with_glimpse_dropout(ops, B, N, D, G, want_first, p_drop):
+    """K3 with MyATT's glimpse-projection dropout in its store and the undropped glimpse 0 as a second output: equal to
+    the plain kernel followed by the exported mask; backward against the oracle fed the masked gradient."""
+    logits = 2.0 * seeded.seeded_array((B, N, G), 221)
+    v = seeded.seeded_array((B, N, D), 222)
+    gp = seeded.seeded_array((B, G, D), 223)
+    gf = seeded.seeded_array((B, D), 224)
+    seed = 1234567
+    lt = g(logits, True)
+    res = ops.softmax_attention_pool_drop(lt, g(v), p_drop, seed, want_first)
+    alpha, pooled = res[0], res[1]
+    mask = ops.linear_dropout_mask(B * G, D, p_drop, seed, lt.device).view(B, G, D) if p_drop else torch.ones(B, G, D, device=lt.device)
+    a_np, p_np = K.softmax_attention_pool_fwd(logits, v)
+    m_np = mask.cpu().numpy()
+    close("alpha", alpha, a_np)
+    close("pooled", pooled, p_np * m_np)
+    if p_drop:
+        frac = float((m_np == 0).mean())
+        assert abs(frac - p_drop) < 0.02 and set(np.unique(m_np)) <= {0.0, np.float32(1.0 / (1.0 - p_drop))}
+    loss = (pooled * g(gp)).sum()
+    if want_first:
+        close("first", res[2], p_np[:, 0])
+        loss = loss + (res[2] * g(gf)).sum()
+    loss.backward()
+    gp_total = gp * m_np
+    if want_first:
+        gp_total[:, 0] += gf
+    dl, _ = K.softmax_attention_pool_bwd(a_np, v, gp_total, None)
+    close("d_logits", lt.grad, dl)
+
+
 def test_softmax_attention_pool_large_logits(ops):
     """softmax must be max-shifted: logits around +/-80 would overflow a naive exp."""
     B, N, D, G = 2, 36, 64, 4

@@ -70,6 +70,13 @@ SIGNATURES = {
     "vqa_pairwise_relation_reduce_fwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_pairwise_relation_reduce_bwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
                                                      _c_i, _c_i, _c_i, _c_st]),
+    "vqa_softmax_attention_pool_drop_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_softmax_attention_pool_drop_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_i,
+                                            _c_i, _c_st]),
+    "vqa_softmax_attention_pool_drop_fwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_i, _c_i,
+                                                 _c_st]),
+    "vqa_softmax_attention_pool_drop_bwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i,
+                                                 _c_i, _c_i, _c_st]),
     "vqa_softmax_attention_pool_fwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_softmax_attention_pool_bwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_pack_bf16": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_f, _c_l, _c_l, _c_l, _c_sz, _c_i, _c_st]),

@@ -56,7 +56,8 @@ __device__ __forceinline__ void block_softmax_regions(const float* __restrict__ 
 template <typename T, int NT, int G>
 __global__ __launch_bounds__(NT) void attention_pool_fwd_kernel(const float* __restrict__ logits,
                                                                 const T* __restrict__ v, float* __restrict__ alpha,
-                                                                float* __restrict__ pooled, int N, int D) {
+                                                                float* __restrict__ pooled, float* __restrict__ first,
+                                                                int N, int D, DropCfg dc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* alpha_s = reinterpret_cast<float*>(smem);  // [N][G]
   float* stat_s = alpha_s + N * G;                  // [2*kMaxG]
@@ -93,8 +94,19 @@ __global__ __launch_bounds__(NT) void attention_pool_fwd_kernel(const float* __r
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = fma4(alpha_s[n * G + g], x, acc[g]);
   }
+  // `first`: glimpse 0 as pooled (CoR2's relation step reads it undropped); `pooled` carries the glimpse projections'
+  // input dropout when dc asks for one (element index (b G + g) D + d of the [B,G,D] tensor)
+  if (first != nullptr) st4(first + (size_t)b * D + d, acc[0]);
 #pragma unroll
-  for (int g = 0; g < G; ++g) st4(pooled + ((size_t)b * G + g) * D + d, acc[g]);
+  for (int g = 0; g < G; ++g) {
+    const size_t e = ((size_t)b * G + g) * D + d;
+    float4 o = acc[g];
+    if (dc.p8 > 0) {
+      const float4 k = drop_quad((uint32_t)e, dc);
+      o = make_float4(o.x * k.x, o.y * k.y, o.z * k.z, o.w * k.w);
+    }
+    st4(pooled + e, o);
+  }
 }
 
 // Backward, streaming form.  Kernel A: grid (D/1024, B), lane = one float4 column with the G rows of d_pooled in
@@ -108,8 +120,9 @@ template <typename T, int NT, int G, int RS>
 __global__ __launch_bounds__(NT) void attention_pool_bwd_stream_kernel(const float* __restrict__ alpha,
                                                                        const T* __restrict__ v,
                                                                        const float* __restrict__ d_pooled,
+                                                                       const float* __restrict__ d_first,
                                                                        float* __restrict__ dal_acc, T* __restrict__ d_v,
-                                                                       int N, int D) {
+                                                                       int N, int D, DropCfg dc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* alpha_s = reinterpret_cast<float*>(smem);  // [N][G]
   float* red_s = alpha_s + N * G;                   // [N][G]
@@ -119,7 +132,7 @@ __global__ __launch_bounds__(NT) void attention_pool_bwd_stream_kernel(const flo
   const int rs = tid / COLS;     // which rows: n = rs, rs + RS, ...
   const int d = (blockIdx.x * COLS + tid % COLS) * 4;
   const bool active = d < D;
-  const int dc = active ? d : 0;
+  const int dcol = active ? d : 0;
   const int NG = N * G;
   for (int t = tid; t < NG; t += NT) {
     alpha_s[t] = alpha[(size_t)b * NG + t];
@@ -128,12 +141,21 @@ __global__ __launch_bounds__(NT) void attention_pool_bwd_stream_kernel(const flo
   float4 p[G];
 #pragma unroll
   for (int gI = 0; gI < G; ++gI) {
-    const float4 t = ld4(d_pooled + ((size_t)b * G + gI) * D + dc);
+    const size_t e = ((size_t)b * G + gI) * D + dcol;
+    float4 t = ld4(d_pooled + e);
+    if (dc.p8 > 0) {        // the forward's dropout of `pooled`: its gradient passes the same mask
+      const float4 k = drop_quad((uint32_t)e, dc);
+      t = make_float4(t.x * k.x, t.y * k.y, t.z * k.z, t.w * k.w);
+    }
+    if (gI == 0 && d_first != nullptr) {   // the gradient that arrived on the undropped glimpse 0
+      const float4 f = ld4(d_first + (size_t)b * D + dcol);
+      t = make_float4(t.x + f.x, t.y + f.y, t.z + f.z, t.w + f.w);
+    }
     p[gI] = active ? t : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
-  const T* vb = v + (size_t)b * N * D + dc;
-  T* dvb = d_v ? d_v + (size_t)b * N * D + dc : nullptr;
+  const T* vb = v + (size_t)b * N * D + dcol;
+  T* dvb = d_v ? d_v + (size_t)b * N * D + dcol : nullptr;
   constexpr int RB = 4;  // rows per batch: RB independent 16-byte loads in flight per lane, then RB*G wave reductions
   for (int n0 = rs; n0 < N; n0 += RB * RS) {
     float4 x[RB];
@@ -189,17 +211,18 @@ __global__ __launch_bounds__(256) void attention_softmax_bwd_kernel(const float*
 }
 
 template <typename T, int G>
-static int launch_fwd(const float* logits, const T* v, float* alpha, float* pooled, int B, int N, int D, hipStream_t s) {
+static int launch_fwd(const float* logits, const T* v, float* alpha, float* pooled, float* first, const DropCfg& dc, int B,
+                      int N, int D, hipStream_t s) {
   constexpr int NT = 256;
   const size_t lds = ((size_t)N * G + 2 * kMaxG) * sizeof(float);
   dim3 grid((D / 4 + NT - 1) / NT, B);
-  hipLaunchKernelGGL((attention_pool_fwd_kernel<T, NT, G>), grid, dim3(NT), lds, s, logits, v, alpha, pooled, N, D);
+  hipLaunchKernelGGL((attention_pool_fwd_kernel<T, NT, G>), grid, dim3(NT), lds, s, logits, v, alpha, pooled, first, N, D, dc);
   return check_launch("softmax_attention_pool_fwd");
 }
 
 template <typename T, int G>
-static int launch_bwd(const float* alpha, const T* v, const float* d_pooled, const float* d_alpha_ext, float* d_logits,
-                      T* d_v, int B, int N, int D, hipStream_t s) {
+static int launch_bwd(const float* alpha, const T* v, const float* d_pooled, const float* d_first, const float* d_alpha_ext,
+                      float* d_logits, T* d_v, const DropCfg& dc, int B, int N, int D, hipStream_t s) {
   constexpr int NT = 256;
   // d_logits doubles as the zeroed accumulator of the first kernel (same [B,N,G] shape; kernel B reads each of its
   // elements before overwriting it)
@@ -209,10 +232,10 @@ static int launch_bwd(const float* alpha, const T* v, const float* d_pooled, con
   if ((long)B * D / 4 < 4 * 65536) {  // fewer than 4 waves per CU worth of lanes: split the rows over the waves
     constexpr int RS = NT / 64;
     hipLaunchKernelGGL((attention_pool_bwd_stream_kernel<T, NT, G, RS>), dim3((D / 4 + 63) / 64, B), dim3(NT), lds, s, alpha,
-                       v, d_pooled, d_logits, d_v, N, D);
+                       v, d_pooled, d_first, d_logits, d_v, N, D, dc);
   } else {
     hipLaunchKernelGGL((attention_pool_bwd_stream_kernel<T, NT, G, 1>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), lds, s, alpha,
-                       v, d_pooled, d_logits, d_v, N, D);
+                       v, d_pooled, d_first, d_logits, d_v, N, D, dc);
   }
   hipLaunchKernelGGL(attention_softmax_bwd_kernel, dim3(B), dim3(256), lds + kMaxG * sizeof(float), s, alpha, d_logits,
                      d_alpha_ext, d_logits, N, G);
@@ -220,8 +243,8 @@ static int launch_bwd(const float* alpha, const T* v, const float* d_pooled, con
 }
 
 template <typename T>
-static int pool_fwd_impl(const char* who, const float* logits, const T* v, float* alpha, float* pooled, int B, int N, int D,
-                         int G, vqa_stream_t stream) {
+static int pool_fwd_impl(const char* who, const float* logits, const T* v, float* alpha, float* pooled, float* first,
+                         float p_drop, uint64_t seed, const uint64_t* seed_ptr, int B, int N, int D, int G, vqa_stream_t stream) {
   constexpr size_t kAlign = 4 * sizeof(T);
   VQA_REQUIRE(logits && v && alpha && pooled, VQA_E_BADARG, "%s: null pointer", who);
   VQA_REQUIRE(B > 0 && N > 0 && D > 0 && G > 0, VQA_E_BADARG, "%s: bad sizes B=%d N=%d D=%d G=%d", who, B, N, D, G);
@@ -229,8 +252,12 @@ static int pool_fwd_impl(const char* who, const float* logits, const T* v, float
   VQA_REQUIRE(D % 4 == 0 && aligned(v, kAlign) && aligned(pooled, 16), VQA_E_UNSUPPORTED,
               "%s: needs D %% 4 == 0, %zu-byte aligned v and 16-byte aligned pooled (D=%d)", who, kAlign, D);
   VQA_REQUIRE(B <= 65535, VQA_E_UNSUPPORTED, "%s: B=%d exceeds 65535", who, B);
+  VQA_REQUIRE(p_drop >= 0.f && p_drop < 1.f, VQA_E_BADARG, "%s: p_drop=%f outside [0,1)", who, (double)p_drop);
+  VQA_REQUIRE(p_drop == 0.f || (size_t)B * G * D < (1ull << 32), VQA_E_UNSUPPORTED, "%s: dropout needs B*G*D < 2^32", who);
+  VQA_REQUIRE(first == nullptr || aligned(first, 16), VQA_E_UNSUPPORTED, "%s: first is not 16-byte aligned", who);
   hipStream_t s = static_cast<hipStream_t>(stream);
-#define CALL_FWD(G_) launch_fwd<T, G_>(logits, v, alpha, pooled, B, N, D, s)
+  const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
+#define CALL_FWD(G_) launch_fwd<T, G_>(logits, v, alpha, pooled, first, dc, B, N, D, s)
   switch (G) {
     case 1: return CALL_FWD(1);
     case 2: return CALL_FWD(2);
@@ -245,8 +272,9 @@ static int pool_fwd_impl(const char* who, const float* logits, const T* v, float
 }
 
 template <typename T>
-static int pool_bwd_impl(const char* who, const float* alpha, const T* v, const float* d_pooled, const float* d_alpha_ext,
-                         float* d_logits, T* d_v, int B, int N, int D, int G, vqa_stream_t stream) {
+static int pool_bwd_impl(const char* who, const float* alpha, const T* v, const float* d_pooled, const float* d_first,
+                         const float* d_alpha_ext, float* d_logits, T* d_v, float p_drop, uint64_t seed, const uint64_t* seed_ptr,
+                         int B, int N, int D, int G, vqa_stream_t stream) {
   constexpr size_t kAlign = 4 * sizeof(T);
   VQA_REQUIRE(alpha && v && d_pooled && d_logits, VQA_E_BADARG, "%s: null pointer", who);
   VQA_REQUIRE(B > 0 && N > 0 && D > 0 && G > 0, VQA_E_BADARG, "%s: bad sizes B=%d N=%d D=%d G=%d", who, B, N, D, G);
@@ -255,8 +283,12 @@ static int pool_bwd_impl(const char* who, const float* alpha, const T* v, const 
               VQA_E_UNSUPPORTED, "%s: needs D %% 4 == 0, 16-byte aligned d_pooled and %zu-byte aligned v/d_v (D=%d)", who,
               kAlign, D);
   VQA_REQUIRE(B <= 65535, VQA_E_UNSUPPORTED, "%s: B=%d exceeds 65535", who, B);
+  VQA_REQUIRE(p_drop >= 0.f && p_drop < 1.f, VQA_E_BADARG, "%s: p_drop=%f outside [0,1)", who, (double)p_drop);
+  VQA_REQUIRE(p_drop == 0.f || (size_t)B * G * D < (1ull << 32), VQA_E_UNSUPPORTED, "%s: dropout needs B*G*D < 2^32", who);
+  VQA_REQUIRE(d_first == nullptr || aligned(d_first, 16), VQA_E_UNSUPPORTED, "%s: d_first is not 16-byte aligned", who);
   hipStream_t s = static_cast<hipStream_t>(stream);
-#define CALL_BWD(G_) launch_bwd<T, G_>(alpha, v, d_pooled, d_alpha_ext, d_logits, d_v, B, N, D, s)
+  const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
+#define CALL_BWD(G_) launch_bwd<T, G_>(alpha, v, d_pooled, d_first, d_alpha_ext, d_logits, d_v, dc, B, N, D, s)
   switch (G) {
     case 1: return CALL_BWD(1);
     case 2: return CALL_BWD(2);
@@ -276,25 +308,57 @@ using namespace vqa;
 
 extern "C" int vqa_softmax_attention_pool_fwd(const float* logits, const float* v, float* alpha, float* pooled, int B,
                                               int N, int D, int G, vqa_stream_t stream) {
-  return pool_fwd_impl<float>("softmax_attention_pool_fwd", logits, v, alpha, pooled, B, N, D, G, stream);
+  return pool_fwd_impl<float>("softmax_attention_pool_fwd", logits, v, alpha, pooled, nullptr, 0.f, 0, nullptr, B, N, D, G, stream);
 }
 
 extern "C" int vqa_softmax_attention_pool_fwd_bf16(const float* logits, const vqa_bf16_t* v, float* alpha, float* pooled,
                                                    int B, int N, int D, int G, vqa_stream_t stream) {
-  return pool_fwd_impl<bf16>("softmax_attention_pool_fwd_bf16", logits, reinterpret_cast<const bf16*>(v), alpha, pooled, B, N,
-                             D, G, stream);
+  return pool_fwd_impl<bf16>("softmax_attention_pool_fwd_bf16", logits, reinterpret_cast<const bf16*>(v), alpha, pooled, nullptr,
+                             0.f, 0, nullptr, B, N, D, G, stream);
 }
 
 extern "C" int vqa_softmax_attention_pool_bwd(const float* alpha, const float* v, const float* d_pooled,
                                               const float* d_alpha_ext, float* d_logits, float* d_v, int B, int N,
                                               int D, int G, vqa_stream_t stream) {
-  return pool_bwd_impl<float>("softmax_attention_pool_bwd", alpha, v, d_pooled, d_alpha_ext, d_logits, d_v, B, N, D, G,
-                              stream);
+  return pool_bwd_impl<float>("softmax_attention_pool_bwd", alpha, v, d_pooled, nullptr, d_alpha_ext, d_logits, d_v, 0.f, 0,
+                              nullptr, B, N, D, G, stream);
 }
 
 extern "C" int vqa_softmax_attention_pool_bwd_bf16(const float* alpha, const vqa_bf16_t* v, const float* d_pooled,
                                                    const float* d_alpha_ext, float* d_logits, vqa_bf16_t* d_v, int B,
                                                    int N, int D, int G, vqa_stream_t stream) {
-  return pool_bwd_impl<bf16>("softmax_attention_pool_bwd_bf16", alpha, reinterpret_cast<const bf16*>(v), d_pooled,
-                             d_alpha_ext, d_logits, reinterpret_cast<bf16*>(d_v), B, N, D, G, stream);
+  return pool_bwd_impl<bf16>("softmax_attention_pool_bwd_bf16", alpha, reinterpret_cast<const bf16*>(v), d_pooled, nullptr,
+                             d_alpha_ext, d_logits, reinterpret_cast<bf16*>(d_v), 0.f, 0, nullptr, B, N, D, G, stream);
+}
+
+// MyATT with its glimpse projections' input dropout folded in (config/CoR2.py:142-147): see include/vqa_mi355x.h
+extern "C" int vqa_softmax_attention_pool_drop_fwd(const float* logits, const float* v, float* alpha, float* pooled,
+                                                   float* first, float p_drop, uint64_t seed, const uint64_t* seed_ptr,
+                                                   int B, int N, int D, int G, vqa_stream_t stream) {
+  return pool_fwd_impl<float>("softmax_attention_pool_drop_fwd", logits, v, alpha, pooled, first, p_drop, seed, seed_ptr, B, N,
+                              D, G, stream);
+}
+
+extern "C" int vqa_softmax_attention_pool_drop_fwd_bf16(const float* logits, const vqa_bf16_t* v, float* alpha, float* pooled,
+                                                        float* first, float p_drop, uint64_t seed, const uint64_t* seed_ptr,
+                                                        int B, int N, int D, int G, vqa_stream_t stream) {
+  return pool_fwd_impl<bf16>("softmax_attention_pool_drop_fwd_bf16", logits, reinterpret_cast<const bf16*>(v), alpha, pooled,
+                             first, p_drop, seed, seed_ptr, B, N, D, G, stream);
+}
+
+extern "C" int vqa_softmax_attention_pool_drop_bwd(const float* alpha, const float* v, const float* d_pooled,
+                                                   const float* d_first, const float* d_alpha_ext, float* d_logits,
+                                                   float* d_v, float p_drop, uint64_t seed, const uint64_t* seed_ptr, int B,
+                                                   int N, int D, int G, vqa_stream_t stream) {
+  return pool_bwd_impl<float>("softmax_attention_pool_drop_bwd", alpha, v, d_pooled, d_first, d_alpha_ext, d_logits, d_v, p_drop,
+                              seed, seed_ptr, B, N, D, G, stream);
+}
+
+extern "C" int vqa_softmax_attention_pool_drop_bwd_bf16(const float* alpha, const vqa_bf16_t* v, const float* d_pooled,
+                                                        const float* d_first, const float* d_alpha_ext, float* d_logits,
+                                                        vqa_bf16_t* d_v, float p_drop, uint64_t seed,
+                                                        const uint64_t* seed_ptr, int B, int N, int D, int G,
+                                                        vqa_stream_t stream) {
+  return pool_bwd_impl<bf16>("softmax_attention_pool_drop_bwd_bf16", alpha, reinterpret_cast<const bf16*>(v), d_pooled, d_first,
+                             d_alpha_ext, d_logits, reinterpret_cast<bf16*>(d_v), p_drop, seed, seed_ptr, B, N, D, G, stream);
 }

@@ -186,4 +186,15 @@ __device__ __forceinline__ float2 drop_pair(uint32_t e, const DropCfg& dc) {
   return make_float2((w & 255u) >= dc.p8 ? dc.scale : 0.f, ((w >> 8) & 255u) >= dc.p8 ? dc.scale : 0.f);
 }
 
+// the four consecutive elements e .. e + 3 (e a multiple of 4): one hash word either way
+__device__ __forceinline__ float4 drop_quad(uint32_t e, const DropCfg& dc) {
+  if (dc.p8 == kDropHalf) {
+    const uint32_t w = mask_word32(e >> 5, drop_key(dc)) >> (e & 31u);
+    return make_float4((w & 1u) != 0u ? 2.f : 0.f, (w & 2u) != 0u ? 2.f : 0.f, (w & 4u) != 0u ? 2.f : 0.f, (w & 8u) != 0u ? 2.f : 0.f);
+  }
+  const uint32_t w = mask_word32(e >> 2, drop_key(dc));
+  return make_float4((w & 255u) >= dc.p8 ? dc.scale : 0.f, ((w >> 8) & 255u) >= dc.p8 ? dc.scale : 0.f,
+                     ((w >> 16) & 255u) >= dc.p8 ? dc.scale : 0.f, (w >> 24) >= dc.p8 ? dc.scale : 0.f);
+}
+
 }  // namespace vqa

@@ -328,6 +328,12 @@ class MyATT(nn.Module):
         first = self.list_linear_v_fusion[0]
         return float(first.p) if (self.training and getattr(first, "p", None)) else 0.0
 
+    def _fused_dropout_ok(self):
+        """The G glimpse layers share one dropout rate (else each draws its own mask at its own rate: the batched form and
+        the fused store do not apply)."""
+        mods = list(self.list_linear_v_fusion)
+        return os.environ.get("VQA_FUSE_POOL_DROPOUT", "1") == "1" and all(getattr(m, "p", None) == mods[0].p for m in mods)
+
     def glimpse_projection(self, pooled, predropped=False):
         """cat_g MyLinear_g(pooled[:, g, :]) (config/CoR2.py:143-147).  The G layers have one shape, so they run as ONE
         batched GEMM over the [B,G,D] tensor (one dropout draw over all of it, one bias add, one activation) instead of
@@ -340,8 +346,18 @@ class MyATT(nn.Module):
         ``pooled_map(pooled, p) -> tensor`` transforms the pooled features before the glimpse projections AND applies
         their input dropout at rate p (so the two share one pass).  (Nothing that carries an autograd graph is kept on
         the module: a tensor stashed across steps would pin the previous step's graph.)"""
-        alpha, pooled = ops.softmax_attention_pool(logits, inputs)                     # [B,N,G], [B,G,D]
         first = None
+        pd = self.glimpse_dropout()
+        if pooled_map is None and inputs.is_cuda and (pd > 0 or return_pooled) and self._fused_dropout_ok():
+            # the glimpse projections' input dropout rides in the pooling kernel's store (one pass fewer each way), and
+            # glimpse 0 comes back undropped as its own tensor for the caller (CoR2's relation step)
+            res = ops.softmax_attention_pool_drop(logits, inputs, pd, ops.next_dropout_seed() if pd else 0, return_pooled)
+            alpha, pooled = res[0], res[1]
+            x_v = self.glimpse_projection(pooled, predropped=True)
+            if return_pooled:
+                return x_v, torch.split(alpha, 1, dim=2), alpha, res[2]
+            return x_v, torch.split(alpha, 1, dim=2), alpha
+        alpha, pooled = ops.softmax_attention_pool(logits, inputs)                     # [B,N,G], [B,G,D]
         if return_pooled:       # glimpse 0 for the caller (CoR2's relation step), the whole tensor for the projections
             pooled, first = ops.with_first_group(pooled)
         if pooled_map is None:

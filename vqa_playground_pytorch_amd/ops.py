@@ -304,6 +304,56 @@ class SoftmaxAttentionPool(torch.autograd.Function):
         return d_logits, d_v
 
 
+class SoftmaxAttentionPoolDrop(torch.autograd.Function):
+    """K3 + the input dropout of MyATT's glimpse projections (config/CoR2.py:143-147) + the undropped glimpse 0 for CoR2's
+    relation step: (alpha, pooled_dropped [B,G,D], first [B,D] or None).  Replaces softmax_attention_pool followed by a
+    dropout pass over [B,G,D] and, backward, the mask multiply, a clone of the full gradient and the slice add."""
+
+    @staticmethod
+    def forward(ctx, logits, v, p_drop, seed, want_first):
+        logits, v = _prep("logits", logits), _prep("v", v, _REGION_DTYPES)
+        B, N, G = logits.shape
+        if v.dim() != 3 or v.shape[0] != B or v.shape[1] != N:
+            raise ValueError("v must be [B,N,D] matching logits [B,N,G]")
+        D = v.shape[2]
+        alpha = torch.empty_like(logits)
+        pooled = torch.empty(B, G, D, device=v.device, dtype=torch.float32)
+        first = torch.empty(B, D, device=v.device, dtype=torch.float32) if want_first else None
+        sv, sp = _seed_args(seed)
+        name = "softmax_attention_pool_drop_fwd" + _sfx(v.dtype)
+        _launch(name, (B, N, D, G), getattr(_lib.lib(), "vqa_" + name), _p(logits), _p(v), _p(alpha), _p(pooled), _p(first),
+                float(p_drop), sv, sp, B, N, D, G)
+        ctx.save_for_backward(alpha, v)
+        ctx.cfg = (float(p_drop), seed)
+        ctx.set_materialize_grads(False)
+        if first is None:
+            return alpha, pooled
+        return alpha, pooled, first
+
+    @staticmethod
+    def backward(ctx, d_alpha, d_pooled, d_first=None):
+        alpha, v = ctx.saved_tensors
+        p_drop, seed = ctx.cfg
+        B, N, G = alpha.shape
+        D = v.shape[2]
+        if d_pooled is None:
+            d_pooled = torch.zeros(B, G, D, device=v.device, dtype=torch.float32)
+        d_pooled = _prep("grad_pooled", d_pooled)
+        d_alpha = _prep("grad_alpha", d_alpha) if d_alpha is not None else None
+        d_first = _prep("grad_first", d_first) if d_first is not None else None
+        d_logits = torch.empty_like(alpha)
+        d_v = torch.empty_like(v) if ctx.needs_input_grad[1] else None
+        sv, sp = _seed_args(seed)
+        name = "softmax_attention_pool_drop_bwd" + _sfx(v.dtype)
+        _launch(name, (B, N, D, G, d_v is not None), getattr(_lib.lib(), "vqa_" + name), _p(alpha), _p(v), _p(d_pooled),
+                _p(d_first), _p(d_alpha), _p(d_logits), _p(d_v), p_drop, sv, sp, B, N, D, G)
+        return d_logits, d_v, None, None, None
+
+
+def softmax_attention_pool_drop(logits, v, p_drop=0.0, seed=0, want_first=False):
+    return SoftmaxAttentionPoolDrop.apply(logits, v, p_drop, seed, want_first)
+
+
 class AttentionLogits(torch.autograd.Function):
     """K3a.  logits[..., g] = bias[g] + sum_k w[g,k] * keep * x[..., k] -- the dropout + 1x1 conv in front of MyATT's
     softmax (config/CoR2.py:72-82 as configured at :132) in one pass over x; x fp32 [.., K] or bf16 [.., Kp >= K]."""
