@@ -380,6 +380,18 @@ int vqa_bias_act(const float* y, const float* bias, int bias_stride, float* out,
 int vqa_act_bwd_colsum(const float* gy, const float* out, float* gz, float* d_bias, int d_bias_stride, int G, int B,
                        int A, int act, int group_first, vqa_stream_t stream);
 
+/* MyLinear's input dropout (config/CoR2.py:108-110, F.dropout(x, p, training)) on the [B,.]-sized tensors of the path, with
+ * the counter-hash mask of K2 / K5 (seed / seed_ptr as there) instead of a Philox stream; G > 1 = the G independent draws
+ * that G same-shaped MyLinear layers make over ONE shared input (CoR2's four question projections, config/CoR2.py:205,
+ * :193-194,:230):
+ *   out[g,m,k] = x[m,k] * keep((g M + m) K + k)       x [M,K] row stride ldx; out [G,M,K] dense
+ *   d_x[m,k]   = sum_g keep(.) * gy[g,m,k]             gy [G,M,K], d_x [M,K] dense
+ * vqa_linear_dropout_mask(mask, p, seed, seed_ptr, G*M, K) writes the same keep() as fp32.  Limit: G*M*K < 2^32. */
+int vqa_dropout_groups_fwd(const float* x, int ldx, float* out, float p_drop, uint64_t seed, const uint64_t* seed_ptr,
+                           int G, int M, int K, vqa_stream_t stream);
+int vqa_dropout_groups_bwd(const float* gy, float* d_x, float p_drop, uint64_t seed, const uint64_t* seed_ptr, int G,
+                           int M, int K, vqa_stream_t stream);
+
 /* Rank sum of the vector-vector Mutan fusion (putils.MutanFusion.forward, putils/__init__.py:232-238, with 2-D inputs --
  * fusion_final of config/CoR2.py:182 / config/ODA.py:197):  out[b,:] = sum_r h1[b,r,:] * h2[b,r,:]  (the reference's
  * bmul + `total +=` over the ranks);  backward d_h1 = g * h2, d_h2 = g * h1.  h1 / h2 [B,R,H] dense, H even. */

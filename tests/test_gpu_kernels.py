@@ -199,6 +199,30 @@ def test_softmax_attention_pool_large_logits(ops):
     assert abs(alpha.sum(dim=1).cpu().numpy() - 1.0).max() < 1e-5
 
 
+@pytest.mark.parametrize("p_drop", [0.5, 0.25])
+@pytest.mark.parametrize("shape,groups", [((64, 2400), 4), ((33, 510), 0), ((7, 3, 310), 0), ((6, 31), 3), ((16, 2048), 2)])
+def test_dropout_groups(ops, shape, groups, p_drop, monkeypatch):
+    """ops.dropout: G independent hash-mask draws over one input (or one, groups = 0); forward equals x times the exported
+    mask, backward is the masked sum over the groups; the drop rate is p."""
+    x = seeded.seeded_array(shape, 231)
+    seed = 424242
+    monkeypatch.setattr(ops, "next_dropout_seed", lambda: seed)
+    xt = g(x, True)
+    y = ops.dropout(xt, p_drop, groups=groups)
+    G = max(groups, 1)
+    K = shape[-1]
+    M = int(np.prod(shape[:-1]))
+    # (the mask is a function of the flat element index: export it as one even-length row when K is odd)
+    mask = (ops.linear_dropout_mask(G * M, K, p_drop, seed, xt.device) if K % 2 == 0 else
+            ops.linear_dropout_mask(1, G * M * K, p_drop, seed, xt.device)).cpu().numpy().reshape((G,) + tuple(shape))
+    assert tuple(y.shape) == ((groups,) + tuple(shape) if groups else tuple(shape))
+    close("out", y.reshape((G,) + tuple(shape)), x[None] * mask)
+    assert abs(float((mask == 0).mean()) - p_drop) < (0.03 if mask.size > 20000 else 0.12)
+    gy = seeded.seeded_array(tuple(y.shape), 232)
+    y.backward(g(gy))
+    close("d_x", xt.grad, (gy.reshape((G,) + tuple(shape)) * mask).sum(0))
+
+
 # ----------------------------------------------------------------------------------------------- K4
 def _fusion_case(ops, B, N, L, H, R, seed, need_dx=True, two_d=False):
     x = seeded.seeded_array((B, L) if two_d else (B, N, L), seed)

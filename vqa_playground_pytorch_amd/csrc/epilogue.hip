@@ -108,6 +108,54 @@ __global__ __launch_bounds__(256) void rank_product_bwd_kernel(const float* __re
   }
 }
 
+// F.dropout of the [B,.]-sized tensors of the path (config/CoR2.py:108-110: MyLinear's input dropout) with the counter-hash
+// mask of K2 / K5 instead of torch's Philox stream, and -- G > 1 -- the G independent draws over ONE input that G
+// same-shaped MyLinear layers reading the same tensor make (the four question projections of CoR2 read q_feature):
+//   out[g][m][k] = x[m][k] * keep((g M + m) K + k);     backward  d_x[m][k] = sum_g keep(.) * gy[g][m][k]
+// VEC elements per lane (K % VEC == 0).
+template <int VEC>
+__device__ __forceinline__ void drop_vec(uint32_t e, const DropCfg& dc, float (&k)[VEC]) {
+  if constexpr (VEC == 4) {
+    const float4 t = drop_quad(e, dc);
+    k[0] = t.x, k[1] = t.y, k[2] = t.z, k[3] = t.w;
+  } else if constexpr (VEC == 2) {
+    const float2 t = drop_pair(e, dc);
+    k[0] = t.x, k[1] = t.y;
+  } else {
+    k[0] = drop_one(e, dc);
+  }
+}
+template <int VEC>
+__global__ __launch_bounds__(256) void dropout_groups_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ out,
+                                                                 int G, int M, int K, DropCfg dc) {
+  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * VEC;     // element of out [G,M,K]
+  if (e >= (size_t)G * M * K) return;
+  const int k = (int)(e % K);
+  const int m = (int)((e / K) % M);
+  float kp[VEC];
+  drop_vec<VEC>((uint32_t)e, dc, kp);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) out[e + j] = x[(size_t)m * ldx + k + j] * kp[j];
+}
+template <int VEC>
+__global__ __launch_bounds__(256) void dropout_groups_bwd_kernel(const float* __restrict__ gy, float* __restrict__ d_x, int G,
+                                                                 int M, int K, DropCfg dc) {
+  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * VEC;     // element of d_x [M,K]
+  const size_t n = (size_t)M * K;
+  if (e >= n) return;
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  for (int g = 0; g < G; ++g) {
+    float kp[VEC];
+    drop_vec<VEC>((uint32_t)(g * n + e), dc, kp);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = fmaf(gy[g * n + e + j], kp[j], acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) d_x[e + j] = acc[j];
+}
+
 }  // namespace vqa
 
 using namespace vqa;
@@ -155,4 +203,40 @@ extern "C" int vqa_rank_product_bwd(const float* g, const float* h1, const float
   hipLaunchKernelGGL(rank_product_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      g, h1, h2, d_h1, d_h2, B, R, H);
   return check_launch("rank_product_bwd");
+}
+
+extern "C" int vqa_dropout_groups_fwd(const float* x, int ldx, float* out, float p_drop, uint64_t seed, const uint64_t* seed_ptr,
+                                      int G, int M, int K, vqa_stream_t stream) {
+  VQA_REQUIRE(x && out, VQA_E_BADARG, "dropout_groups_fwd: null pointer");
+  VQA_REQUIRE(G > 0 && M > 0 && K > 0 && ldx >= K, VQA_E_BADARG, "dropout_groups_fwd: bad sizes G=%d M=%d K=%d ldx=%d", G, M, K, ldx);
+  VQA_REQUIRE(p_drop >= 0.f && p_drop < 1.f, VQA_E_BADARG, "dropout_groups_fwd: p_drop=%f outside [0,1)", (double)p_drop);
+  VQA_REQUIRE((size_t)G * M * K < (1ull << 32), VQA_E_UNSUPPORTED, "dropout_groups_fwd: needs G*M*K < 2^32");
+  const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
+  const size_t n = (size_t)G * M * K;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (K % 4 == 0)
+    hipLaunchKernelGGL(dropout_groups_fwd_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x, ldx, out, G, M, K, dc);
+  else if (K % 2 == 0)
+    hipLaunchKernelGGL(dropout_groups_fwd_kernel<2>, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, s, x, ldx, out, G, M, K, dc);
+  else
+    hipLaunchKernelGGL(dropout_groups_fwd_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, ldx, out, G, M, K, dc);
+  return check_launch("dropout_groups_fwd");
+}
+
+extern "C" int vqa_dropout_groups_bwd(const float* gy, float* d_x, float p_drop, uint64_t seed, const uint64_t* seed_ptr, int G,
+                                      int M, int K, vqa_stream_t stream) {
+  VQA_REQUIRE(gy && d_x, VQA_E_BADARG, "dropout_groups_bwd: null pointer");
+  VQA_REQUIRE(G > 0 && M > 0 && K > 0, VQA_E_BADARG, "dropout_groups_bwd: bad sizes G=%d M=%d K=%d", G, M, K);
+  VQA_REQUIRE(p_drop >= 0.f && p_drop < 1.f, VQA_E_BADARG, "dropout_groups_bwd: p_drop=%f outside [0,1)", (double)p_drop);
+  VQA_REQUIRE((size_t)G * M * K < (1ull << 32), VQA_E_UNSUPPORTED, "dropout_groups_bwd: needs G*M*K < 2^32");
+  const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
+  const size_t n = (size_t)M * K;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n % 4 == 0)
+    hipLaunchKernelGGL(dropout_groups_bwd_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, gy, d_x, G, M, K, dc);
+  else if (n % 2 == 0)
+    hipLaunchKernelGGL(dropout_groups_bwd_kernel<2>, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, s, gy, d_x, G, M, K, dc);
+  else
+    hipLaunchKernelGGL(dropout_groups_bwd_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gy, d_x, G, M, K, dc);
+  return check_launch("dropout_groups_bwd");
 }

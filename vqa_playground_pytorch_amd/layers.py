@@ -86,10 +86,20 @@ def my_linears(mods, x, group_first=False, predropped=False):
                 b = ops.stack_params([l.bias for l in lins]).reshape(G * first.out_features)
             y = ops.linear(x, w.view(G * first.out_features, first.in_features), b)
             return y.view(x.size(0), G, first.out_features)
-    if x.dim() == 2:
+    drop = bool(p) and training and not predropped
+    if x.dim() == 2 and drop and x.dtype == torch.float32:
+        x = ops.dropout(x, p, groups=G).transpose(0, 1)              # G independent draws over the one input: [B,G,K] view
+        drop = False
+    elif x.dim() == 2:
         x = x.unsqueeze(1).expand(x.size(0), G, x.size(1))          # stride-0 group axis: no copy
-    if p and training and not predropped:
-        x = F.dropout(x, p=p, training=True)                         # one draw over [B,G,K]: G independent masks
+    if drop:
+        # one draw over [B,G,K]: G independent masks (hash mask on the GPU fp32 path; torch's generator otherwise)
+        if x.dtype != torch.float32:
+            x = F.dropout(x, p=p, training=True)
+        elif x.dim() == 3 and not x.is_contiguous() and x.transpose(0, 1).is_contiguous():
+            x = ops.dropout(x.transpose(0, 1), p).transpose(0, 1)    # a [G,B,K] tensor seen as [B,G,K]: mask it as stored
+        else:
+            x = ops.dropout(x, p)
     w = ops.stack_params([l.weight for l in lins])                   # [G,A,K]: a view of the flat parameter buffer
     b = ops.stack_params([l.bias for l in lins]) if lins[0].bias is not None else None   # when the trainer laid it out
     if af in (None, "", "relu", "sigmoid"):
@@ -145,8 +155,8 @@ class MyLinear(nn.Module):
             raise ValueError(
                 "[error] putils.Linear(%s, %s): last dimension of input(%s) should equal to in_features(%s)"
                 % (self.in_features, self.out_features, x.size(-1), self.in_features))
-        if self.p:
-            x = F.dropout(x, p=self.p, training=self.training)
+        if self.p and self.training:
+            x = ops.dropout(x, self.p) if (x.is_cuda and x.dtype == torch.float32) else F.dropout(x, p=self.p, training=True)
         return _activation(ops.linear(x, self.linear.weight, self.linear.bias), self.af, self.dim)
 
 

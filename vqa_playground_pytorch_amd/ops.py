@@ -989,6 +989,39 @@ def batched_linear(x, w, b=None, group_first=False, act=None):
     return BatchedLinearFn.apply(x, w, b, group_first, act)
 
 
+class DropoutGroups(torch.autograd.Function):
+    """F.dropout(x, p) with the counter-hash mask of the fused kernels, G independent draws over one input at once:
+    x [..., K] -> [G, ..., K] (G = 0: a single draw, same shape as x).  csrc/epilogue.hip."""
+
+    @staticmethod
+    def forward(ctx, x, p_drop, seed, groups):
+        x = _prep("x", x)
+        K = x.shape[-1]
+        M = x.numel() // K
+        G = max(int(groups), 1)
+        out = torch.empty(((G,) if groups else ()) + tuple(x.shape), device=x.device, dtype=torch.float32)
+        sv, sp = _seed_args(seed)
+        _launch("dropout_groups_fwd", (G, M, K), _lib.lib().vqa_dropout_groups_fwd, _p(x), K, _p(out), float(p_drop), sv, sp, G, M, K)
+        ctx.cfg = (float(p_drop), seed, G, M, K, tuple(x.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        p_drop, seed, G, M, K, shape = ctx.cfg
+        gy = _prep("grad_out", gy)
+        d_x = torch.empty(shape, device=gy.device, dtype=torch.float32)
+        sv, sp = _seed_args(seed)
+        _launch("dropout_groups_bwd", (G, M, K), _lib.lib().vqa_dropout_groups_bwd, _p(gy), _p(d_x), p_drop, sv, sp, G, M, K)
+        return d_x, None, None, None
+
+
+def dropout(x, p_drop, groups=0):
+    """Training-mode dropout of an fp32 GPU tensor (a fresh seed per call from the step's seed stream)."""
+    if not p_drop:
+        return x if not groups else x.unsqueeze(0).expand((groups,) + tuple(x.shape))
+    return DropoutGroups.apply(x.contiguous(), p_drop, next_dropout_seed(), groups)
+
+
 class RankProduct(torch.autograd.Function):
     """out[b,:] = sum_r h1[b,r,:] * h2[b,r,:] -- the rank sum of the vector-vector Mutan fusion (fusion_final), one kernel
     each way (csrc/epilogue.hip) instead of multiply + reduce forward and two broadcast multiplies backward."""
