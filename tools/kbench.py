@@ -2,7 +2,7 @@
 """Per-kernel micro-benchmark of libvqa_mi355x.so at the BASELINE shapes (B=512, N=36, D=2048, L=310, H=510, G=4, R=2).
 Interleaved rounds in ONE process (guide rule 24); prints median / min per variant and the roofline fraction.
 
-    python tools/kbench.py [--only k4fwd,k1,...] [--tiles 128x128,64x64] [--rounds 20]
+    python tools/kbench.py [--only k4fwd,k4bwd,k1,k2,k3,k3a,k5] [--tiles 128x128,64x64] [--rounds 20]
 """
 import argparse
 import os
@@ -158,6 +158,17 @@ def main():
         res = timeit(fns, args.rounds)
         report("K3 backward (no dv)", {"bwd (no dv)": res["bwd (no dv)"]}, B * (N * D + G * D + 3 * N * G) * 4, "GB")
         report("K3 backward (+dv)", {"bwd (+dv)": res["bwd (+dv)"]}, B * (2 * N * D + G * D + 3 * N * G) * 4, "GB")
+    if want("k3a"):
+        fz = torch.randn(B, N, H, device=dev)
+        wa, ba = torch.randn(G, H, device=dev) / H ** 0.5, torch.zeros(G, device=dev)
+        pa = float(os.environ.get("K3A_P", "0.5"))
+        fns = {"fwd (p=%g)" % pa: lambda: ops.attention_logits(fz, wa, ba, pa, 7)}
+        report("K3a logits forward", timeit(fns, args.rounds), B * N * (H + G) * 4, "GB")
+        fr, wr_ = fz.clone().requires_grad_(), wa.clone().requires_grad_()
+        out = ops.attention_logits(fr, wr_, ba, pa, 7)
+        gl = torch.randn(B, N, G, device=dev)
+        fns = {"bwd (dx + dw)": lambda: torch.autograd.grad(out, [fr, wr_], gl, retain_graph=True)}
+        report("K3a logits backward", timeit(fns, args.rounds), B * N * (2 * H + G) * 4, "GB")
     if want("k5"):
         w = torch.randn(L, D, device=dev) / D ** 0.5
         bias = torch.randn(L, device=dev) * 0.1

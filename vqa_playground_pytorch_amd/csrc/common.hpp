@@ -75,6 +75,30 @@ __device__ __forceinline__ float wave_sum(float x) {
          __int_as_float(__builtin_amdgcn_readlane(xi, 32)) + __int_as_float(__builtin_amdgcn_readlane(xi, 48));
 }
 
+// lane-wise sum over the four 16-lane rows of the wave: every lane l ends with x[l & 15] + x[(l & 15) + 16] + ... (gfx950's
+// v_permlane16_swap / v_permlane32_swap: the odd rows of one copy change places with the even rows of the other)
+__device__ __forceinline__ float rows_sum(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const unsigned v = __float_as_uint(s);
+  const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+// Butterfly reduce-scatter of 16 per-lane values over a 16-lane DPP row: lane l ends with value (l & 15) summed over the 16
+// lanes of its row.  15 exchanges (8 + 4 + 2 + 1: quad_perm, quad_perm, row_ror:4, row_ror:8) instead of 16 x 4.
+__device__ __forceinline__ float row_reduce_scatter16(const float (&val)[16], int lane) {
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0, b3 = (lane & 8) != 0;
+  float s8[8], s4[4], s2[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s8[i] = (b0 ? val[2 * i + 1] : val[2 * i]) + dpp_mov<0xB1>(b0 ? val[2 * i] : val[2 * i + 1]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s4[i] = (b1 ? s8[2 * i + 1] : s8[2 * i]) + dpp_mov<0x4E>(b1 ? s8[2 * i] : s8[2 * i + 1]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) s2[i] = (b2 ? s4[2 * i + 1] : s4[2 * i]) + dpp_mov<0x124>(b2 ? s4[2 * i] : s4[2 * i + 1]);
+  return (b3 ? s2[1] : s2[0]) + dpp_mov<0x128>(b3 ? s2[0] : s2[1]);
+}
+
 __device__ __forceinline__ float wave_max(float x) {
   x = fmaxf(x, dpp_mov<0xB1>(x));
   x = fmaxf(x, dpp_mov<0x4E>(x));
