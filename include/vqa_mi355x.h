@@ -98,6 +98,18 @@ int vqa_relation_apply_bwd_bf16(const vqa_bf16_t* v, const float* c2, const vqa_
                                 float* d_c2, vqa_bf16_t* d_v, float p_drop, uint64_t seed,
                                 const uint64_t* seed_ptr, int B, int N, int D, vqa_stream_t stream);
 
+/* K1 -> K5 fusion, backward.  When relation_apply's output x = keep * (t + c2 * v) feeds the second region projection
+ * (compress_v2, config/CoR2.py:218) and nothing else, the projection's data gradient is only ever reduced to d_t and d_c2:
+ *   dx[m,:] = sum_l gz[m,l] w[l,:];   d_t[b,:] = sum_n keep(m,:) dx[m,:];   d_c2[b,:] = sum_n keep(m,:) dx[m,:] v[m,:]
+ * with gz [B*N, L] the gradient at the projection's pre-activation (relu gate applied), w [L, D] its weight
+ * (nn.Conv1d(D, L, 1).weight), v [B,N,D], keep = the (p_drop, seed) mask of vqa_relation_apply_fwd.  ONE kernel: the
+ * GEMM tile is four whole samples (144 rows) and is reduced in registers; dx (B*N*D*4 bytes) is never written.
+ * vqa_relation_projection_dgrad_supported(): N == 36, D % 64 == 0, even L >= 32, tensors < 4 GiB. */
+int vqa_relation_projection_dgrad_supported(int B, int N, int D, int L);
+int vqa_relation_projection_dgrad(const float* gz, const float* w, const float* v, float* d_t, float* d_c2,
+                                  float p_drop, uint64_t seed, const uint64_t* seed_ptr, int B, int N, int D, int L,
+                                  vqa_stream_t stream);
+
 /* K1 with the region tensors (v, v2, g_v2, d_v) stored as bf16 -- the mixed-precision path of BASELINE
  * configs[4] (bf16 storage, fp32 arithmetic and accumulation; q1, q2, alpha and their gradients stay
  * fp32).  Same semantics and limits, with 8-byte instead of 16-byte alignment of the bf16 tensors. */

@@ -815,3 +815,42 @@ def test_relation_apply(ops, B, N, D, p, dtype):
     close("d_t", tt.grad, gm.sum(1))
     close("d_c2", ct.grad, (gm * v).sum(1))
     close("d_v", vt.grad.float(), c2[:, None, :].astype(np.float64) * gm, tol)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.5, 0.25])
+@pytest.mark.parametrize("B,D,L", [(4, 2048, 310), (5, 256, 310), (33, 128, 34), (1, 64, 32), (8, 320, 48)])
+def test_relation_projection_fused_backward(ops, B, D, L, p):
+    """relation step + second region projection as one node (K1 -> K5): the output equals relation_apply followed by
+    linear_act, and d_t / d_c2 / dW / db equal the gradients of that composition (fp64 closed form of the data gradient:
+    the masked grad_x summed over the 36 regions) -- without the [B,36,D] data gradient ever being written."""
+    N = 36
+    v = seeded.seeded_array((B, N, D), 411)
+    t = seeded.seeded_array((B, D), 412)
+    c2 = 1 / (1 + np.exp(-seeded.seeded_array((B, D), 413)))
+    w = seeded.seeded_array((L, D), 414, scale=1.0 / np.sqrt(D))
+    bias = seeded.seeded_array((L,), 415, scale=0.1)
+    gy = seeded.seeded_array((B, N, L), 416)
+    seed = 777
+    vt = g(v)
+    assert ops.relation_projection_supported(vt, g(w))
+    tt, ct, wt, bt = g(t, True), g(c2, True), g(w, True), g(bias, True)
+    y = ops.relation_projection(vt, tt, ct, wt, bt, p, seed)
+    # the same function from the two separate ops
+    t2, c2_, w2, b2 = g(t, True), g(c2, True), g(w, True), g(bias, True)
+    x2 = ops.relation_apply(vt, t2, c2_, p, seed)
+    y2 = ops.linear_act(x2, w2, b2, "relu", 0.0, 0)
+    assert torch.equal(y, y2)
+    y.backward(g(gy))
+    y2.backward(g(gy))
+    # fp64 closed form
+    mask = ops.linear_dropout_mask(B * N, D, p, seed, dev()).cpu().numpy().reshape(B, N, D).astype(np.float64) if p else 1.0
+    x = (t[:, None, :].astype(np.float64) + c2[:, None, :] * v.astype(np.float64)) * mask
+    pre = x @ w.astype(np.float64).T + bias
+    gz = gy * (pre > 0)
+    dx = (gz @ w.astype(np.float64)) * mask
+    close("d_t", tt.grad, dx.sum(1), 2e-4)
+    close("d_c2", ct.grad, (dx * v).sum(1), 2e-4)
+    close("d_t vs two-op path", tt.grad, t2.grad.cpu().numpy(), 2e-4)
+    close("d_c2 vs two-op path", ct.grad, c2_.grad.cpu().numpy(), 2e-4)
+    close("d_w", wt.grad, np.einsum("bnl,bnd->ld", gz, x), 2e-4)
+    close("d_b", bt.grad, gz.sum((0, 1)), 2e-4)

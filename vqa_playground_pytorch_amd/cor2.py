@@ -129,8 +129,16 @@ class Model(nn.Module):
             t = q_gate_1 * pooled1_first
             c2 = q_gate_2
             p = self.compress_v2.p if (self.training and self.compress_v2.p) else 0.0
-            v2_dropped = ops.relation_apply(v_feature, t, c2, p, ops.next_dropout_seed() if p else 0)
-            v2_feature_low = self.compress_v2(v2_dropped, predropped=True)
+            cv2 = self.compress_v2
+            w2 = cv2.conv.weight.squeeze(-1)
+            if cv2.af == "relu" and cv2.fused and b * v_feature.size(1) >= 1024 and ops.relation_projection_supported(v_feature, w2):
+                # relation step + projection as one autograd node: backward reduces the projection's data gradient to
+                # d_t / d_c2 inside the GEMM tile (csrc/relation_dgrad.hip) instead of writing and re-reading [B,N,2048]
+                v2_feature_low = ops.relation_projection(v_feature, t, c2, w2, cv2.conv.bias, p,
+                                                         ops.next_dropout_seed() if p else 0, cv2.grad_pregated)
+            else:
+                v2_dropped = ops.relation_apply(v_feature, t, c2, p, ops.next_dropout_seed() if p else 0)
+                v2_feature_low = cv2(v2_dropped, predropped=True)
             fuse2 = self.fusion_vq2(v2_feature_low, q_feature_low, relu_input=self.compress_v2.grad_pregated)
             v2_att, alpha2, _ = self.att2.attend(v_feature, self.att2.conv_att.pre_activation(fuse2),
                                                  lambda pooled, pd: ops.relation_apply(

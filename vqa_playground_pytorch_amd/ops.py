@@ -805,6 +805,67 @@ def linear_act(x, w, bias=None, act=None, p_drop=0.0, seed=0, pregated=False):
     return LinearAct.apply(x, w, bias, code, p_drop, seed, pregated)
 
 
+class RelationProjection(torch.autograd.Function):
+    """K1 -> K5: y = relu(keep * (t + c2 * v) W^T + b) -- the closed-form relation step (RelationApply) feeding the second
+    region projection (LinearAct) as ONE autograd node, so that backward can skip the projection's data gradient as a
+    tensor: d_t and d_c2 come out of the GEMM tile directly (csrc/relation_dgrad.hip; [B,N,D] is neither written nor
+    re-read).  v must not need a gradient (it is the model's input); shapes vqa_relation_projection_dgrad_supported()."""
+
+    @staticmethod
+    def forward(ctx, v, t, c2, w, bias, p_drop, seed, pregated):
+        v, t, c2, w = _prep("v", v), _prep("t", t), _prep("c2", c2), _prep("w", w)
+        bias = _prep("bias", bias) if bias is not None else None
+        B, N, D = v.shape
+        L = w.shape[0]
+        if t.shape != (B, D) or c2.shape != (B, D) or w.shape != (L, D):
+            raise ValueError("relation_projection: t, c2 must be [B,D] and w [L,D] for v [B,N,D]")
+        L_ = _lib.lib()
+        x = torch.empty_like(v)
+        sv, sp = _seed_args(seed)
+        _launch("relation_apply_fwd", (B, N, D, float(p_drop) > 0), L_.vqa_relation_apply_fwd, _p(v), _p(t), _p(c2), _p(x),
+                float(p_drop), sv, sp, B, N, D)
+        M = B * N
+        y = torch.empty(B, N, L, device=v.device, dtype=torch.float32)
+        _launch("linear_act_fwd", (M, D, L, False), L_.vqa_linear_act_fwd, _p(x), D, _p(w), _p(bias), _p(y), M, D, L, 1, 0.0, 0, None)
+        ctx.save_for_backward(v, x, w, y)
+        ctx.bias = bias
+        ctx.cfg = (float(p_drop), seed, bool(pregated))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        v, x, w, y = ctx.saved_tensors
+        p_drop, seed, pregated = ctx.cfg
+        B, N, D = v.shape
+        L = w.shape[0]
+        M = B * N
+        gy = _prep("grad_y", gy)
+        gz = gy if pregated else torch.ops.aten.threshold_backward(gy, y, 0)     # one gated tensor for both gradients
+        L_ = _lib.lib()
+        d_w = _grad_like(w)
+        d_b = _grad_like(ctx.bias) if ctx.bias is not None else None
+        ws_bytes = L_.vqa_linear_act_bwd_workspace_bytes(M, D, L)
+        ws = torch.empty((ws_bytes + 3) // 4, device=v.device, dtype=torch.float32)
+        _launch("linear_act_bwd", (M, D, L, False, False), L_.vqa_linear_act_bwd, _p(x), D, _p(w), _p(y), _p(gz), None, _p(d_w),
+                _p(d_b), _p(ws), ws_bytes, M, D, L, 0, 0.0, 0, None)
+        d_t = torch.empty(B, D, device=v.device, dtype=torch.float32)
+        d_c2 = torch.empty(B, D, device=v.device, dtype=torch.float32)
+        sv, sp = _seed_args(seed)
+        _launch("relation_projection_dgrad", (B, N, D, L, p_drop > 0), L_.vqa_relation_projection_dgrad, _p(gz), _p(w), _p(v),
+                _p(d_t), _p(d_c2), p_drop, sv, sp, B, N, D, L)
+        return None, d_t, d_c2, d_w, d_b, None, None, None
+
+
+def relation_projection_supported(v, w):
+    """Can relation_projection serve v [B,N,D] (fp32, no gradient wanted) and the projection weight w [L,D]?"""
+    return (v.is_cuda and v.dtype == torch.float32 and v.dim() == 3 and not v.requires_grad and w.dtype == torch.float32 and
+            bool(_lib.lib().vqa_relation_projection_dgrad_supported(v.shape[0], v.shape[1], v.shape[2], w.shape[0])))
+
+
+def relation_projection(v, t, c2, w, bias, p_drop=0.0, seed=0, pregated=False):
+    return RelationProjection.apply(v, t, c2, w, bias, p_drop, seed, pregated)
+
+
 def column_sum(x, out=None):
     """out[n] = sum_m x[m,n] for a 2-D fp32 / bf16 matrix -> fp32 [N]; fixed-order reduction, safe under graph replay."""
     x = _prep("x", x, _REGION_DTYPES)
