@@ -60,6 +60,9 @@ def work_of(name, shape):
     if base == "linear_act_bwd":
         M, K, N, _drop, dx = s[:5]
         return "mfma", 2 * M * K * N * (2 if dx else 1)                              # dW (+ dx)
+    if base == "relation_projection_dgrad":
+        B, N, D, L = s[:4]
+        return "mfma", 2 * B * N * D * L                                              # the data-gradient contraction
     if base == "library_gemm":
         M, N, K = s[:3]
         return "mfma", 2 * M * N * K
@@ -128,6 +131,10 @@ PMC_KERNELS = {  # C-ABI entry -> [(kernel-name prefix, fetch multiplier)]
     "lowrank_bilinear_fusion_fwd": [("vqa::bilinear_folded_kernel<3, 2, true", 1.0)],
     "linear_act_fwd": [("vqa::rt::gemm_nt_kernel<9, 5, 1, 2, 2", 2.0)],
     "linear_act_bwd": [("vqa::rt::gemm_tn_kernel<5, 2", 2.0)],
+    "lowrank_bilinear_fusion_bwd": [("vqa::(anonymous namespace)::bilinear_dw_rt_kernel", 2.0)],
+    "relation_projection_dgrad": [("vqa::(anonymous namespace)::relation_dgrad_kernel", 2.0)],
+    "attention_logits_fwd": [("vqa::attention_logits_fwd_kernel", 2.0)],
+    "attention_logits_bwd": [("vqa::attention_logits_bwd_kernel", 2.0)],
     "relation_apply_fwd": [("vqa::relation_apply_fwd_kernel", 2.0)],
     "relation_apply_bwd": [("vqa::relation_apply_bwd_kernel", 2.0)],
     "pairwise_relation_reduce_fwd": [("vqa::pairwise_fwd", 2.0)],

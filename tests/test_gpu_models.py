@@ -397,7 +397,8 @@ def test_graph_replays_far_behind_the_host_keep_their_step_scalars():
     # update of the 24 steps (~9e-3 per weight) would move by tens of per cent, far above it.
     noise = (finals[0] - finals[1]).abs().max().item()
     diff = (finals[0] - finals[2]).abs().max().item()
-    assert diff <= 3.0 * noise + 1e-6, (diff, noise)
+    # (one noise sample is itself noisy: the bound is the larger of 5 x it and 1e-4 -- a twentieth of what a stale slot does)
+    assert diff <= max(5.0 * noise, 1e-4), (diff, noise)
     assert diff <= 1e-3, (diff, noise)
 
 

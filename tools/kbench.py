@@ -169,6 +169,15 @@ def main():
         gl = torch.randn(B, N, G, device=dev)
         fns = {"bwd (dx + dw)": lambda: torch.autograd.grad(out, [fr, wr_], gl, retain_graph=True)}
         report("K3a logits backward", timeit(fns, args.rounds), B * N * (2 * H + G) * 4, "GB")
+    if want("k1k5"):
+        wp = torch.randn(L, D, device=dev) / D ** 0.5
+        bp = torch.zeros(L, device=dev)
+        tt, cc = torch.randn(B, D, device=dev).requires_grad_(), torch.rand(B, D, device=dev).requires_grad_()
+        wr2 = wp.clone().requires_grad_()
+        yy = ops.relation_projection(v, tt, cc, wr2, bp, 0.5, 11)
+        gyy = torch.randn(B, N, L, device=dev)
+        fns = {"bwd (dW + fused d_t/d_c2)": lambda: torch.autograd.grad(yy, [tt, cc, wr2], gyy, retain_graph=True)}
+        report("K1->K5 backward", timeit(fns, args.rounds), 2 * 2 * B * N * D * L, "TF")
     if want("k5"):
         w = torch.randn(L, D, device=dev) / D ** 0.5
         bias = torch.randn(L, device=dev) * 0.1

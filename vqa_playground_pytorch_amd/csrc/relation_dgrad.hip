@@ -14,8 +14,11 @@
 // Register-tile engine, NN form: A = gz, K-contiguous (one 16-byte load per row block and 16-deep chunk, component kb =
 // contraction step kb); B = W, contraction index = row: lane (r, g) loads W[16 c + 4 g + kb][n0 + 4 r .. + 3] as one
 // 16-byte load per step, component e feeds accumulator block e (the column permutation of gemm_tn_kernel).  A wave owns
-// 144 rows x 64 columns (36 blocks, 144 accumulator registers), a workgroup 144 x 256; no LDS, no barrier.  The 36 16-byte
-// loads of the wave's v tile go out ahead of the main loop.  512 registers per lane: one wave per SIMD.
+// 144 rows x 64 columns (36 blocks, 144 accumulator registers), a workgroup 144 x 256; no barrier.  The wave's tile of v
+// (36 loads of 1 KB) is streamed into LDS by buffer_load ... lds (no registers, no wait before the epilogue), two loads
+// per chunk of the main loop: requested in one burst at the top of the tile they cost 36 us (every wave of the chip
+// asking HBM for 36 KB at once, the first MFMA behind it: memory operations retire in order), and kept in registers a
+// runtime row-block index cannot address them.  One wave per SIMD.
 #include <cstdlib>
 
 #include "gemm_f32_rt.hpp"
@@ -35,7 +38,9 @@ struct RelDgradArgs {
 
 constexpr int kRegions = 36;                 // regions per sample: 4 samples = 144 rows = 9 row blocks
 constexpr int kRB = 9, kSamples = 4, kBM = 16 * kRB;
+constexpr int kVAux = 2;   // cache policy of the v stream: nt (read once: keep it from displacing W and gz in L2)
 
+template <int TUNE>
 __global__ __launch_bounds__(rt::kThreads, 1) void relation_dgrad_kernel(RelDgradArgs p, DropCfg dc) {
   using rt::f32x4;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
@@ -59,7 +64,6 @@ __global__ __launch_bounds__(rt::kThreads, 1) void relation_dgrad_kernel(RelDgra
   for (int i = 0; i < kRB; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[i][e] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 vt[kRB][4];    // the wave's tile of v: [row block][t] = v[m0 + 16 i + 4 g + t][n0 + 4 r .. + 3]
 
   struct Frag {
     f32x4 a[kRB];      // component kb = contraction step kb
@@ -71,10 +75,13 @@ __global__ __launch_bounds__(rt::kThreads, 1) void relation_dgrad_kernel(RelDgra
 #pragma unroll
     for (int i = 0; i < kRB; ++i) f.a[i] = rt::ldg16(Ab, offA[i], (uint32_t)c * 64u);
   };
-  auto load_v = [&](int i) {                 // rows clamped: a row beyond M is never added up
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-      vt[i][t] = rt::ldg16(Vb, (uint32_t)(n0 + 4 * r) * 4u, (uint32_t)min(m0 + 16 * i + 4 * g + t, M - 1) * (uint32_t)D * 4u);
+  // the wave's tile of v in LDS: slot idx = 4 i + t (1 KB: lane l at byte 16 l) = v[m0 + 16 i + 4 g + t][n0 + 4 r .. + 3]
+  extern __shared__ __attribute__((aligned(16))) char rd_smem[];
+  char* vslots = rd_smem + (size_t)wave * (4 * kRB) * 1024;
+  auto load_v = [&](int idx) {               // idx is wave-uniform (a loop counter); rows clamped per lane
+    const int row = min(m0 + 16 * (idx >> 2) + 4 * g + (idx & 3), M - 1);
+    const uint32_t voff = ((uint32_t)row * (uint32_t)D + (uint32_t)(n0 + 4 * r)) * 4u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(Vb, (__attribute__((address_space(3))) void*)(vslots + idx * 1024), 16, (int)voff, 0, 0, kVAux);
   };
   auto mfmas = [&](const Frag& f) {
 #pragma unroll
@@ -85,11 +92,17 @@ __global__ __launch_bounds__(rt::kThreads, 1) void relation_dgrad_kernel(RelDgra
         for (int e = 0; e < 4; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[i][kb], f.b[kb][e], acc[i][e], 0, 0, 0);
   };
   // one pipeline step (gemm_nt_kernel): chunk cn is requested in the shadow of the first MFMAs of chunk c, one load per
-  // PER MFMAs
-  auto step = [&](Frag& fn, int cn, const Frag& f) {
+  // PER MFMAs; two slots of the v tile follow the fragment loads
+  auto step = [&](Frag& fn, int cn, const Frag& f, int vidx) {
     load(fn, cn);
+    if constexpr ((TUNE & 1) == 0) {
+      if (vidx < 4 * kRB) {                  // (uniform; 4 kRB is even)
+        load_v(vidx);
+        load_v(vidx + 1);
+      }
+    }
     mfmas(f);
-    constexpr int NL = kRB + 4, NM = 16 * kRB, PER = 5;
+    constexpr int NL = kRB + 4 + 2, NM = 16 * kRB, PER = 5;
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            // MFMA
@@ -98,23 +111,22 @@ __global__ __launch_bounds__(rt::kThreads, 1) void relation_dgrad_kernel(RelDgra
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // The v tile is requested first: 36 loads that nothing reads before the epilogue.  (Memory operations retire in order,
-  // so the first fragment wait also waits for them -- one HBM latency per tile; spreading them over the loop would need
-  // one copy of the unrolled MFMA block per row block, and copies on separate control-flow paths spill.)
-#pragma unroll
-  for (int i = 0; i < kRB; ++i) load_v(i);
-
   const int nfull = L >> 4;                  // whole 16-deep chunks
   const int c_pairs = nfull & ~1;
   {
     Frag f0, f1;
+    int vidx = 0;
     if (c_pairs > 0) {
       load(f0, 0);
       __builtin_amdgcn_sched_barrier(0);
       for (int c = 0; c < c_pairs; c += 2) {
-        step(f1, c + 1, f0);
-        step(f0, min(c + 2, c_pairs - 1), f1);     // (last pair: a harmless reload)
+        step(f1, c + 1, f0, vidx);
+        step(f0, min(c + 2, c_pairs - 1), f1, vidx + 2);     // (last pair: a harmless reload)
+        vidx += 4;
       }
+    }
+    if constexpr ((TUNE & 1) == 0) {
+      for (; vidx < 4 * kRB; ++vidx) load_v(vidx);           // (a contraction shorter than 18 chunks)
     }
     if (c_pairs < nfull) {
       load(f0, c_pairs);
@@ -141,49 +153,83 @@ __global__ __launch_bounds__(rt::kThreads, 1) void relation_dgrad_kernel(RelDgra
   }
 
   // ---- epilogue: mask, multiply by v, add the rows of each sample up ----
+  __builtin_amdgcn_s_waitcnt(0);             // the LDS-bound loads of the v tile have landed (nobody else reads these slots)
+  auto vt = [&](int i, int t) -> f32x4 {
+    if constexpr ((TUNE & 1) != 0) return f32x4{1.f, 1.f, 1.f, 1.f};
+    return *reinterpret_cast<const f32x4*>(vslots + (4 * i + t) * 1024 + lane * 16);
+  };
+  if constexpr ((TUNE & 2) != 0) {   // (experiment: no epilogue math)
+    f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < kRB; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum += acc[i][e] * vt(i, e);
+    if (g == 0) *reinterpret_cast<f32x4*>(p.d_t + (size_t)(m0 / kRegions) * D + n0 + 4 * r) = sum;
+    return;
+  }
   const uint32_t key = dc.p8 > 0 ? drop_key(dc) : 0u;
+  if (m0 + kBM > M) {                        // last, partial tile: the rows beyond M (clamped duplicates) count as zero
+#pragma unroll
+    for (int i = 0; i < kRB; ++i)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (m0 + 16 * i + 4 * g + t >= M) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][e][t] = 0.f;
+        }
+  }
   f32x4 st[kSamples], sc[kSamples];   // per sample: sum keep dx, sum keep dx v  (components = the 4 columns of the lane)
 #pragma unroll
   for (int s = 0; s < kSamples; ++s) st[s] = sc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // MODE: 0 no dropout, 1 the one-bit-per-element p = 0.5 mask, 2 a byte per element -- ONE uniform branch around the whole
+  // reduction (a test per row left 70 branches in it and nothing for the scheduler to overlap)
+  auto reduce = [&](auto mode) {
+    constexpr int MODE = decltype(mode)::value;
 #pragma unroll
-  for (int i = 0; i < kRB; ++i) {
-    f32x4 xt = f32x4{0.f, 0.f, 0.f, 0.f}, xc = f32x4{0.f, 0.f, 0.f, 0.f};   // the 4 rows of group 4 i + g, one sample
+    for (int i = 0; i < kRB; ++i) {
+      f32x4 xt = f32x4{0.f, 0.f, 0.f, 0.f}, xc = f32x4{0.f, 0.f, 0.f, 0.f};   // the 4 rows of group 4 i + g, one sample
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int m = m0 + 16 * i + 4 * g + t;
-      f32x4 x = f32x4{acc[i][0][t], acc[i][1][t], acc[i][2][t], acc[i][3][t]};
-      f32x4 k4 = f32x4{1.f, 1.f, 1.f, 1.f};
-      if (dc.p8 > 0) {
-        const uint32_t e = (uint32_t)min(m, M - 1) * (uint32_t)D + (uint32_t)(n0 + 4 * r);   // a multiple of 4
-        if (dc.p8 == kDropHalf) {
-          const uint32_t w = mask_word32(e >> 5, key) >> (e & 31u);
-          k4 = f32x4{(w & 1u) ? 2.f : 0.f, (w & 2u) ? 2.f : 0.f, (w & 4u) ? 2.f : 0.f, (w & 8u) ? 2.f : 0.f};
-        } else {
-          const uint32_t w = mask_word32(e >> 2, key);
-          k4 = f32x4{(w & 255u) >= dc.p8 ? dc.scale : 0.f, ((w >> 8) & 255u) >= dc.p8 ? dc.scale : 0.f,
-                     ((w >> 16) & 255u) >= dc.p8 ? dc.scale : 0.f, (w >> 24) >= dc.p8 ? dc.scale : 0.f};
+      for (int t = 0; t < 4; ++t) {
+        f32x4 x = f32x4{acc[i][0][t], acc[i][1][t], acc[i][2][t], acc[i][3][t]};
+        if constexpr (MODE != 0) {
+          const int m = min(m0 + 16 * i + 4 * g + t, M - 1);
+          const uint32_t e = (uint32_t)m * (uint32_t)D + (uint32_t)(n0 + 4 * r);   // a multiple of 4
+          if constexpr (MODE == 1) {         // kept values are scaled by 2 at the end
+            const uint32_t w = mask_word32(e >> 5, key) >> (e & 31u);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float xe = x[c];
+              x[c] = __uint_as_float(__float_as_uint(xe) & (0u - ((w >> c) & 1u)));
+            }
+          } else {
+            const uint32_t w = mask_word32(e >> 2, key);
+            x *= f32x4{(w & 255u) >= dc.p8 ? dc.scale : 0.f, ((w >> 8) & 255u) >= dc.p8 ? dc.scale : 0.f,
+                       ((w >> 16) & 255u) >= dc.p8 ? dc.scale : 0.f, (w >> 24) >= dc.p8 ? dc.scale : 0.f};
+          }
         }
+        xt += x;
+        xc += x * vt(i, t);
       }
-      if (m >= M) k4 = f32x4{0.f, 0.f, 0.f, 0.f};
-      x *= k4;
-      xt += x;
-      xc += x * vt[i][t];
+      // group q = 4 i + g belongs to sample q / 9; for a fixed row block that is one of at most two samples
+      constexpr int kGroups = kRegions / 4;
+      const int s_lo = (4 * i) / kGroups, s_hi = (4 * i + 3) / kGroups;
+      if (s_lo == s_hi) {
+        st[s_lo] += xt;
+        sc[s_lo] += xc;
+      } else {
+        const bool hi = (4 * i + g) / kGroups == s_hi;
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        st[s_lo] += hi ? z : xt;
+        sc[s_lo] += hi ? z : xc;
+        st[s_hi] += hi ? xt : z;
+        sc[s_hi] += hi ? xc : z;
+      }
     }
-    // group q = 4 i + g belongs to sample q / 9; for a fixed row block that is one of at most two samples
-    constexpr int kGroups = kRegions / 4;
-    const int s_lo = (4 * i) / kGroups, s_hi = (4 * i + 3) / kGroups;
-    if (s_lo == s_hi) {
-      st[s_lo] += xt;
-      sc[s_lo] += xc;
-    } else {
-      const bool hi = (4 * i + g) / kGroups == s_hi;
-      const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-      st[s_lo] += hi ? z : xt;
-      sc[s_lo] += hi ? z : xc;
-      st[s_hi] += hi ? xt : z;
-      sc[s_hi] += hi ? xc : z;
-    }
-  }
+  };
+  if (dc.p8 == 0) reduce(std::integral_constant<int, 0>{});
+  else if (dc.p8 == kDropHalf) reduce(std::integral_constant<int, 1>{});
+  else reduce(std::integral_constant<int, 2>{});
+  const float post = dc.p8 == kDropHalf ? 2.f : 1.f;
   // the four lane groups hold different rows of the same columns: lane-wise sum over the 16-lane rows of the wave
   const int b0 = m0 / kRegions;
 #pragma unroll
@@ -191,8 +237,8 @@ __global__ __launch_bounds__(rt::kThreads, 1) void relation_dgrad_kernel(RelDgra
     f32x4 a, b;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      a[e] = rows_sum(st[s][e]);
-      b[e] = rows_sum(sc[s][e]);
+      a[e] = rows_sum(st[s][e]) * post;
+      b[e] = rows_sum(sc[s][e]) * post;
     }
     if (g == 0 && b0 + s < p.B) {
       *reinterpret_cast<f32x4*>(p.d_t + (size_t)(b0 + s) * D + n0 + 4 * r) = a;
@@ -236,7 +282,19 @@ extern "C" int vqa_relation_projection_dgrad(const float* gz, const float* w, co
   a.tiles_n = (D + 255) / 256;
   const int tiles_m = (a.M + kBM - 1) / kBM;
   const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
-  hipLaunchKernelGGL(relation_dgrad_kernel, dim3((unsigned)(tiles_m * a.tiles_n)), dim3(rt::kThreads), 0,
-                     static_cast<hipStream_t>(stream), a, dc);
+  const int tune = std::getenv("VQA_RELDG_TUNE") ? std::atoi(std::getenv("VQA_RELDG_TUNE")) : 0;   // (experiments)
+  const dim3 grid((unsigned)(tiles_m * a.tiles_n));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  constexpr size_t lds = (size_t)4 * 4 * kRB * 1024;      // 4 waves x 36 slots of 1 KB
+#define VQA_RD_LAUNCH(T_)                                                                \
+  {                                                                                      \
+    VQA_ENSURE_LDS(relation_dgrad_kernel<T_>, lds);                                      \
+    hipLaunchKernelGGL(relation_dgrad_kernel<T_>, grid, dim3(rt::kThreads), lds, s, a, dc); \
+  }
+  if (tune == 1) VQA_RD_LAUNCH(1)
+  else if (tune == 2) VQA_RD_LAUNCH(2)
+  else if (tune == 3) VQA_RD_LAUNCH(3)
+  else VQA_RD_LAUNCH(0)
+#undef VQA_RD_LAUNCH
   return check_launch("relation_projection_dgrad");
 }
