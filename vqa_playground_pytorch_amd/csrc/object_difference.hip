@@ -22,6 +22,9 @@
 // regions per word (~14 lane-ops per element: byte extract, compare, select, multiply + a hash per 4 elements).
 #include <cstdlib>
 
+#include <type_traits>
+#include <utility>
+
 #include "common.hpp"
 
 namespace vqa {
@@ -46,8 +49,23 @@ __device__ __forceinline__ uint32_t oda_bits(uint32_t cnt_lo, uint32_t word_stri
   if (straddle) bits |= mask_word32(cnt_lo + word_stride, key) << (32 - sh);   // (straddle implies sh > 0)
   return bits;
 }
-__device__ __forceinline__ float keep_bit(float v, uint32_t bits, int k) {
-  return __uint_as_float(__float_as_uint(v) & (0u - ((bits >> k) & 1u)));      // v_bfe_i32 + v_and_b32; unscaled
+// v & (bit K of bits ? ~0 : 0): v_bfe_i32 (bit K sign-extended) + v_and_b32, unscaled.  Inline assembly on purpose: written
+// in C (0 - ((bits >> K) & 1), or the sbfe builtin) the compiler canonicalises the AND with a sign splat into a select and
+// emits v_and + v_cmp + v_cndmask through VCC -- four issue slots and a hazard nop per element instead of two.
+template <int K>
+__device__ __forceinline__ float keep_bit(float v, uint32_t bits) {
+  uint32_t m;
+  asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(bits), "n"(K));
+  return __uint_as_float(__float_as_uint(v) & m);
+}
+// f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}): a loop whose index is a constant expression
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
 }
 
 // forward, bit mask: grid (ceil(N/kIB), B), lane <-> feature d
@@ -76,19 +94,28 @@ __global__ void oda_fwd_bits_kernel(const float* __restrict__ vl, const float* _
     float Ti[kIB];
 #pragma unroll
     for (int ic = 0; ic < kIB; ++ic) Ti[ic] = (i0 + ic < N) ? vlb[(size_t)(i0 + ic) * L + d] * qd : 0.f;
-#pragma unroll 2
+    // region j + 1's operands are requested before region j's 18 x 7 VALU instructions (left to the compiler the loads sit
+    // right in front of their use: with at most four waves per SIMD -- 117 registers -- an L2 round trip per region shows)
+    float vn = vlb[d];
+    float wn[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) wn[g] = w[(size_t)g * N * L + d];
     for (int j = 0; j < N; ++j) {
-      const float Tj = vlb[(size_t)j * L + d] * qd;
+      const float Tj = vn * qd;
       float wv[G];
 #pragma unroll
-      for (int g = 0; g < G; ++g) wv[g] = w[((size_t)g * N + j) * L + d];
-      const uint32_t bits = oda_bits(base + (uint32_t)(j * L + d), stride, sh, straddle, key);
+      for (int g = 0; g < G; ++g) wv[g] = wn[g];
+      const int jn = min(j + 1, N - 1);
+      vn = vlb[(size_t)jn * L + d];
 #pragma unroll
-      for (int ic = 0; ic < kIB; ++ic) {
-        const float val = keep_bit(Ti[ic] - Tj, bits, ic);
+      for (int g = 0; g < G; ++g) wn[g] = w[((size_t)g * N + jn) * L + d];
+      const uint32_t bits = oda_bits(base + (uint32_t)(j * L + d), stride, sh, straddle, key);
+      static_for<kIB>([&](auto ic_) {
+        constexpr int ic = decltype(ic_)::value;
+        const float val = keep_bit<ic>(Ti[ic] - Tj, bits);
 #pragma unroll
         for (int g = 0; g < G; ++g) acc[ic][g] = fmaf(wv[g], val, acc[ic][g]);
-      }
+      });
     }
   }
 #pragma unroll
@@ -138,22 +165,21 @@ __global__ void oda_bwd_data_bits_kernel(const float* __restrict__ vl, const flo
 #pragma unroll
         for (int g = 0; g < G; ++g) ds[ic][g] = (i0 + ic < N) ? dS_s[(i0 + ic) * G + g] : 0.f;
       }
-#pragma unroll 2
       for (int j = 0; j < N; ++j) {
         float wv[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) wv[g] = w[((size_t)g * N + j) * L + d];
         const uint32_t bits = oda_bits(base + (uint32_t)(j * L + d), stride, sh, straddle, key);
         float pj = 0.f;
-#pragma unroll
-        for (int ic = 0; ic < kIC; ++ic) {
+        static_for<kIC>([&](auto ic_) {
+          constexpr int ic = decltype(ic_)::value;
           float u = 0.f;
 #pragma unroll
           for (int g = 0; g < G; ++g) u = fmaf(ds[ic][g], wv[g], u);
-          u = keep_bit(u, bits, ic);
+          u = keep_bit<ic>(u, bits);
           dTi[ic] += u;
           pj += u;
-        }
+        });
         dT_s[j * nt + tid] -= pj;
       }
 #pragma unroll
@@ -221,12 +247,12 @@ __global__ void oda_bwd_weight_bits_kernel(const float* __restrict__ vl, const f
 #pragma unroll
         for (int jc = 0; jc < kIC; ++jc) {
           const uint32_t bits = words[jc] >> sh;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float val = keep_bit(Ti[k] - Tj[jc], bits, k);
+          static_for<4>([&](auto k_) {
+            constexpr int k = decltype(k_)::value;
+            const float val = keep_bit<k>(Ti[k] - Tj[jc], bits);
 #pragma unroll
             for (int g = 0; g < G; ++g) dw[jc][g] = fmaf(ds[k][g], val, dw[jc][g]);
-          }
+          });
         }
       }
     }
