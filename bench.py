@@ -86,10 +86,10 @@ def work_of(name, shape):
     if base == "pairwise_relation_reduce_bwd":
         B, N, D, dv, gb = s[:5]
         return "hbm", B * ((2 + (1 if dv else 0) + (1 if gb else 0)) * N * D * fv + (4 * D + 2 * N) * f)
-    if base == "softmax_attention_pool_fwd":
+    if base in ("softmax_attention_pool_fwd", "softmax_attention_pool_drop_fwd"):
         B, N, D, G = s[:4]
         return "hbm", B * (N * D * fv + (2 * N * G + G * D) * f)                     # 328 832 B/sample at fp32
-    if base == "softmax_attention_pool_bwd":
+    if base in ("softmax_attention_pool_bwd", "softmax_attention_pool_drop_bwd"):
         B, N, D, G, dv = s[:5]
         return "hbm", B * ((1 + (1 if dv else 0)) * N * D * fv + (G * D + 3 * N * G) * f)
     if base == "attention_logits_fwd":
@@ -131,8 +131,8 @@ PMC_KERNELS = {  # C-ABI entry -> [(kernel-name prefix, fetch multiplier)]
     "lowrank_bilinear_fusion_fwd": [("vqa::bilinear_folded_kernel<3, 2, true", 1.0)],
     "linear_act_fwd": [("vqa::rt::gemm_nt_kernel<9, 5, 1, 2, 2", 2.0)],
     "linear_act_bwd": [("vqa::rt::gemm_tn_kernel<5, 2", 2.0)],
-    "lowrank_bilinear_fusion_bwd": [("vqa::(anonymous namespace)::bilinear_dw_rt_kernel", 2.0)],
-    "relation_projection_dgrad": [("vqa::(anonymous namespace)::relation_dgrad_kernel", 2.0)],
+    "lowrank_bilinear_fusion_bwd": [("vqa::bilinear_dw_rt_kernel", 2.0)],
+    "relation_projection_dgrad": [("vqa::relation_dgrad_kernel", 2.0)],
     "attention_logits_fwd": [("vqa::attention_logits_fwd_kernel", 2.0)],
     "attention_logits_bwd": [("vqa::attention_logits_bwd_kernel", 2.0)],
     "relation_apply_fwd": [("vqa::relation_apply_fwd_kernel", 2.0)],
@@ -141,6 +141,8 @@ PMC_KERNELS = {  # C-ABI entry -> [(kernel-name prefix, fetch multiplier)]
     "pairwise_relation_reduce_bwd": [("vqa::pairwise_bwd_stream_kernel", 2.0)],
     "softmax_attention_pool_fwd": [("vqa::attention_pool_fwd_kernel", 2.0)],
     "softmax_attention_pool_bwd": [("vqa::attention_pool_bwd_stream_kernel", 2.0)],
+    "softmax_attention_pool_drop_fwd": [("vqa::attention_pool_fwd_kernel", 2.0)],
+    "softmax_attention_pool_drop_bwd": [("vqa::attention_pool_bwd_stream_kernel", 2.0)],
 }
 _tables = {}
 

@@ -19,7 +19,7 @@ def main():
         name = row["Kernel_Name"]
         if not name.startswith(("vqa::", "void vqa::")):
             continue
-        name = name.replace("void ", "").split("(")[0]
+        name = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         if "Grid_Size" in row:
             grid = int(row["Grid_Size"])
         else:

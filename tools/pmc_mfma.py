@@ -30,7 +30,7 @@ def main():
     for d in dirs:
         for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             for row in csv.DictReader(open(path)):
-                name = re.sub(r"^void ", "", row["Kernel_Name"]).split("(")[0]
+                name = re.sub(r"^void ", "", row["Kernel_Name"]).replace("(anonymous namespace)::", "").split("(")[0]
                 if "vqa" not in name:
                     continue
                 key = "%s|grid=%s" % (name, row.get("Grid_Size", "?"))

@@ -22,7 +22,7 @@ def load(directory, counter):
         for row in csv.DictReader(open(path)):
             if row.get("Counter_Name") != counter:
                 continue
-            name = re.sub(r"^void ", "", row["Kernel_Name"]).split("(")[0]
+            name = re.sub(r"^void ", "", row["Kernel_Name"]).replace("(anonymous namespace)::", "").split("(")[0]
             if not name.startswith("vqa::") and "vqa" not in name:
                 continue
             grid = row.get("Grid_Size") or row.get("Grid_Size_X") or "?"
