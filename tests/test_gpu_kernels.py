@@ -187,6 +187,36 @@ def test_softmax_attention_pool_with_glimpse_dropout(ops, B, N, D, G, want_first
     close("d_logits", lt.grad, dl)
 
 
+@pytest.mark.parametrize("p_drop", [0.0, 0.5])
+@pytest.mark.parametrize("B,N,D,G,with_ext,need_dv", [(3, 36, 2048, 4, True, False), (2, 7, 1028, 2, False, True),
+                                                      (4, 100, 2048, 4, True, True), (2, 36, 1540, 8, False, False)])
+def test_softmax_attention_pool_backward_single_launch(ops, monkeypatch, B, N, D, G, with_ext, need_dv, p_drop):
+    """The one-launch backward (a workgroup owns a sample: dot products, d_v and the softmax backward together; taken from
+    B = 512 on, here forced for small batches) against the oracle, with the gradient on alpha, d_v, glimpse dropout and
+    the gradient of the undropped glimpse 0."""
+    monkeypatch.setenv("VQA_K3_FUSED_MIN_B", "1")
+    logits = 2.0 * seeded.seeded_array((B, N, G), 241)
+    v = seeded.seeded_array((B, N, D), 242)
+    gp = seeded.seeded_array((B, G, D), 243)
+    ga = seeded.seeded_array((B, N, G), 244)
+    gf = seeded.seeded_array((B, D), 245)
+    seed = 99
+    lt, vt = g(logits, True), g(v, need_dv)
+    alpha, pooled, first = ops.softmax_attention_pool_drop(lt, vt, p_drop, seed, True)
+    mask = ops.linear_dropout_mask(B * G, D, p_drop, seed, lt.device).view(B, G, D).cpu().numpy() if p_drop else np.ones((B, G, D))
+    loss = (pooled * g(gp)).sum() + (first * g(gf)).sum()
+    if with_ext:
+        loss = loss + (alpha * g(ga)).sum()
+    loss.backward()
+    a_np, _ = K.softmax_attention_pool_fwd(logits, v)
+    gp_total = gp * mask
+    gp_total[:, 0] += gf
+    dl, dv = K.softmax_attention_pool_bwd(a_np, v, gp_total, ga if with_ext else None)
+    close("d_logits", lt.grad, dl)
+    if need_dv:
+        close("d_v", vt.grad, dv)
+
+
 def test_softmax_attention_pool_large_logits(ops):
     """softmax must be max-shifted: logits around +/-80 would overflow a naive exp."""
     B, N, D, G = 2, 36, 64, 4

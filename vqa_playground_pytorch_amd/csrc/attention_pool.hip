@@ -17,6 +17,8 @@
 //
 // The stream kernels are templates on the storage type T of the region tensors v / d_v (float, or bf16 for the
 // mixed-precision path: half the bytes of the dominant stream); logits, alpha, pooled and their gradients are fp32.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace vqa {
@@ -215,6 +217,104 @@ __global__ __launch_bounds__(NT) void attention_pool_bwd_stream_kernel(const flo
   for (int t = tid; t < NG; t += NT) atomicAdd(&dal_acc[(size_t)b * NG + t], red_s[t]);
 }
 
+// Backward in ONE kernel when a workgroup can own a whole sample (D <= 4 NT CG columns: D = 2048 at NT = 256, CG = 2):
+// every lane keeps CG float4 columns of the G rows of d_pooled, the sample's N x G dot products are complete inside the
+// workgroup (LDS), and the softmax backward d_logits = alpha (dal - sum_n alpha dal) closes in the same launch -- no
+// zeroed accumulator, no atomics to global memory, no second kernel (three launches -> one: the two small ones were
+// launch-latency floors of ~5 us each).
+template <typename T, int NT, int G, int CG>
+__global__ __launch_bounds__(NT) void attention_pool_bwd_fused_kernel(const float* __restrict__ alpha, const T* __restrict__ v,
+                                                                      const float* __restrict__ d_pooled,
+                                                                      const float* __restrict__ d_first,
+                                                                      const float* __restrict__ d_alpha_ext,
+                                                                      float* __restrict__ d_logits, T* __restrict__ d_v, int N,
+                                                                      int D, DropCfg dc) {
+  static_assert(G == 1 || G == 2 || G == 4 || G == 8, "the butterfly takes 16 / G rows per batch");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* alpha_s = reinterpret_cast<float*>(smem);  // [N][G]
+  float* red_s = alpha_s + N * G;                   // [N][G]
+  float* inner_s = red_s + N * G;                   // [G]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const int NG = N * G;
+  for (int t = tid; t < NG; t += NT) {
+    alpha_s[t] = alpha[(size_t)b * NG + t];
+    red_s[t] = 0.f;
+  }
+  float4 p[CG][G];
+  int dcol[CG];
+  bool active[CG];
+#pragma unroll
+  for (int c = 0; c < CG; ++c) {
+    const int d = (c * NT + tid) * 4;
+    active[c] = d < D;
+    dcol[c] = active[c] ? d : 0;
+#pragma unroll
+    for (int gI = 0; gI < G; ++gI) {
+      const size_t e = ((size_t)b * G + gI) * D + dcol[c];
+      float4 t = ld4(d_pooled + e);
+      if (dc.p8 > 0) {
+        const float4 k = drop_quad((uint32_t)e, dc);
+        t = make_float4(t.x * k.x, t.y * k.y, t.z * k.z, t.w * k.w);
+      }
+      if (gI == 0 && d_first != nullptr) {
+        const float4 f = ld4(d_first + (size_t)b * D + dcol[c]);
+        t = make_float4(t.x + f.x, t.y + f.y, t.z + f.z, t.w + f.w);
+      }
+      p[c][gI] = active[c] ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __syncthreads();
+  const T* vb = v + (size_t)b * N * D;
+  T* dvb = d_v ? d_v + (size_t)b * N * D : nullptr;
+  constexpr int RB = 16 / G;
+  const int my_k = (lane & 15) / G, my_g = (lane & 15) % G;
+  for (int n0 = 0; n0 < N; n0 += RB) {
+    float4 x[CG][RB];
+#pragma unroll
+    for (int c = 0; c < CG; ++c)
+#pragma unroll
+      for (int k = 0; k < RB; ++k) x[c][k] = ld4(vb + (size_t)min(n0 + k, N - 1) * D + dcol[c]);
+    float val[16];
+#pragma unroll
+    for (int k = 0; k < RB; ++k) {
+      const int n = n0 + k;
+#pragma unroll
+      for (int gI = 0; gI < G; ++gI) {
+        float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) t += dot4(x[c][k], p[c][gI]);     // (p = 0 in inactive columns)
+        val[k * G + gI] = t;
+      }
+      if (dvb != nullptr && n < N) {
+#pragma unroll
+        for (int c = 0; c < CG; ++c)
+          if (active[c]) {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int gI = 0; gI < G; ++gI) o = fma4(alpha_s[n * G + gI], p[c][gI], o);
+            st4(dvb + (size_t)n * D + dcol[c], o);
+          }
+      }
+    }
+    const float s1 = row_reduce_scatter16(val, lane);
+    const int n = n0 + my_k;
+    if (n < N) atomicAdd(&red_s[n * G + my_g], s1);
+  }
+  __syncthreads();
+  // softmax backward on the sample's [N][G]: dal = <d_pooled_g, v_n> (+ what arrived on alpha directly)
+  for (int t = tid; t < NG; t += NT) red_s[t] += d_alpha_ext != nullptr ? d_alpha_ext[(size_t)b * NG + t] : 0.f;
+  __syncthreads();
+  for (int gI = wave; gI < G; gI += NT / 64) {
+    float sum = 0.f;
+    for (int n = lane; n < N; n += 64) sum += alpha_s[n * G + gI] * red_s[n * G + gI];
+    sum = wave_sum(sum);
+    if (lane == 0) inner_s[gI] = sum;
+  }
+  __syncthreads();
+  for (int t = tid; t < NG; t += NT) d_logits[(size_t)b * NG + t] = alpha_s[t] * (red_s[t] - inner_s[t % G]);
+}
+
 // d_logits = alpha * (dal - sum_n alpha*dal),  dal = accumulated <d_pooled, v> (+ the gradient arriving on alpha)
 __global__ __launch_bounds__(256) void attention_softmax_bwd_kernel(const float* __restrict__ alpha,
                                                                     const float* __restrict__ dal_acc,
@@ -254,6 +354,18 @@ template <typename T, int G>
 static int launch_bwd(const float* alpha, const T* v, const float* d_pooled, const float* d_first, const float* d_alpha_ext,
                       float* d_logits, T* d_v, const DropCfg& dc, int B, int N, int D, hipStream_t s) {
   constexpr int NT = 256;
+  if constexpr (G == 1 || G == 2 || G == 4 || G == 8) {
+    // one workgroup per sample, everything in one launch -- when the batch alone fills the chip (>= 2 workgroups per CU)
+    // (VQA_K3_FUSED_MIN_B: the smallest batch that takes this form; tests set 1, a huge value keeps the three-launch form)
+    const char* env = std::getenv("VQA_K3_FUSED_MIN_B");
+    const int min_b = env != nullptr ? std::atoi(env) : 512;
+    const size_t lds_f = ((size_t)2 * N * G + kMaxG) * sizeof(float);
+    if (B >= min_b && D % 4 == 0 && D <= 4 * NT * 2 && D > 4 * NT) {
+      hipLaunchKernelGGL((attention_pool_bwd_fused_kernel<T, NT, G, 2>), dim3(B), dim3(NT), lds_f, s, alpha, v, d_pooled, d_first,
+                         d_alpha_ext, d_logits, d_v, N, D, dc);
+      return check_launch("softmax_attention_pool_bwd");
+    }
+  }
   // d_logits doubles as the zeroed accumulator of the first kernel (same [B,N,G] shape; kernel B reads each of its
   // elements before overwriting it)
   int rc = zero_async(d_logits, (size_t)B * N * G * sizeof(float), s);

@@ -259,15 +259,19 @@ class DataParallelTrainer:
                     split = min(self.flat.offset_of(p) for p in early)
                     if all(self.flat.offset_of(p) + p.numel() <= split for p in late):
                         self.overlap, self._late, self._early, self._split = True, late, early, split
-            self.step_scalars = torch.zeros(2, device=first.device, dtype=torch.float32)
-            # pinned staging for the tiny per-step H2D copies: a ring, so a slot is not rewritten while an earlier
-            # (asynchronous) copy from it may still be pending on the stream
+            # the per-step device words the replayed graphs read -- Adam's two step scalars (fp32) and the dropout seed of the
+            # fused kernels (int64; every replay reads the current value) -- are ONE 16-byte block, refreshed by ONE
+            # host-to-device copy per step (a pinned-memory copy is a blit kernel of ~8 us that the step waits for)
+            self._step_block = torch.zeros(16, device=first.device, dtype=torch.uint8)
+            self.step_scalars = self._step_block[:8].view(torch.float32)
+            self.seed_word = self._step_block[8:].view(torch.int64)
+            # pinned staging: a ring, so a slot is not rewritten while an earlier (asynchronous) copy from it may still be
+            # pending on the stream
             self._ring = 8
-            self._ring_events = [None] * self._ring       # recorded behind a slot's copies; waited for before it is rewritten
-            self._step_scalars_host = torch.zeros(self._ring, 2, dtype=torch.float32).pin_memory()
-            # per-step dropout seed of the fused kernels (K2, K5) in device memory: replays read the current value
-            self.seed_word = torch.zeros(1, device=first.device, dtype=torch.int64)
-            self._seed_host = torch.zeros(self._ring, 1, dtype=torch.int64).pin_memory()
+            self._ring_events = [None] * self._ring       # recorded behind a slot's copy; waited for before it is rewritten
+            self._step_block_host = torch.zeros(self._ring, 16, dtype=torch.uint8).pin_memory()
+            self._step_scalars_host = self._step_block_host[:, :8].view(torch.float32)      # [ring, 2]
+            self._seed_host = self._step_block_host[:, 8:].view(torch.int64)                # [ring, 1]
             self.grads = None
             self.optimizer = None
         else:
@@ -369,9 +373,8 @@ class DataParallelTrainer:
             pending.synchronize()
         self._step_scalars_host[slot, 0] = lr / (1.0 - self.betas[0] ** self.adam_steps)
         self._step_scalars_host[slot, 1] = 1.0 / (1.0 - self.betas[1] ** self.adam_steps) ** 0.5
-        self.step_scalars.copy_(self._step_scalars_host[slot], non_blocking=True)
         self._seed_host[slot, 0] = int(torch.randint(0, 2 ** 62, (1,), device="cpu").item())   # torch.manual_seed governs it
-        self.seed_word.copy_(self._seed_host[slot], non_blocking=True)
+        self._step_block.copy_(self._step_block_host[slot], non_blocking=True)
         done = torch.cuda.Event()
         done.record()
         self._ring_events[slot] = done
