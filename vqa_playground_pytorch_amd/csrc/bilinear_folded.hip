@@ -365,6 +365,7 @@ int folded_transpose_weights(const float* const* w1, float* wt, int L, int H, in
 
 int folded_data_gradient(const float* g, const float* const* w1t, const float* h2, float* d_x, int B, int N, int L, int H,
                          int R, hipStream_t s, const float* gate) {
+  if (gate == nullptr && fold_rt_supported(B, N, H, L, R, H, H, L)) return fold_rt_data_gradient(g, w1t, h2, d_x, B, N, L, H, R, s);
   FoldPtrs wp{};
   for (int r = 0; r < R; ++r) wp.w[r] = w1t[r];
   return launch_folded<false>("lowrank_bilinear_fusion_folded_bwd (dx)", g, H, wp, H, h2, H, d_x, L, B, N, H, L, R, s, gate);
@@ -395,6 +396,8 @@ extern "C" int vqa_lowrank_bilinear_fusion_folded_fwd(const float* x, int ldx, c
   }
   VQA_REQUIRE(aligned(x, 8) && aligned(h2, 8) && aligned(out, 8), VQA_E_UNSUPPORTED,
               "lowrank_bilinear_fusion_folded_fwd: x/h2/out must be 8-byte aligned");
+  if (fold_rt_supported(B, N, L, H, R, ldx, L, H))
+    return fold_rt_forward(x, ldx, w1, b1, h2, out, B, N, L, H, R, static_cast<hipStream_t>(stream));
   return launch_folded<true>("lowrank_bilinear_fusion_folded_fwd", x, ldx, wp, L, h2, H, out, H, B, N, L, H, R,
                              static_cast<hipStream_t>(stream));
 }

@@ -26,4 +26,11 @@ bool dw_rt_supported(int B, int N, int L, int H, int R, int ldx);
 int dw_rt_launch(const float* g, const float* x, const float* h2, const float* const* w1, const float* const* b1, float* slab,
                  float* dbslab, float* part, int B, int N, int L, int H, int R, hipStream_t s);
 
+// Register-tile forms of the folded forward and data gradient (bilinear_rt.hip); K = contraction length, NO = output rows
+bool fold_rt_supported(int B, int N, int K, int NO, int R, int ldx, int ldw, int ldo);
+int fold_rt_forward(const float* x, int ldx, const float* const* w1, const float* const* b1, const float* h2, float* out, int B,
+                    int N, int L, int H, int R, hipStream_t s);
+int fold_rt_data_gradient(const float* g, const float* const* w1t, const float* h2, float* d_x, int B, int N, int L, int H, int R,
+                          hipStream_t s);
+
 }  // namespace vqa
