@@ -128,7 +128,7 @@ def work_of(name, shape):
 # is stated per kernel.  Counters cannot be collected inside the driver's own run of this file (no profiler is attached
 # there): the table is the committed evidence of the same command, and `traffic_source` says so in the output line.
 PMC_KERNELS = {  # C-ABI entry -> [(kernel-name prefix, fetch multiplier)]
-    "lowrank_bilinear_fusion_fwd": [("vqa::bilinear_folded_kernel<3, 2, true", 1.0)],
+    "lowrank_bilinear_fusion_fwd": [("vqa::bilinear_fold_rt_kernel<true", 2.0)],
     "linear_act_fwd": [("vqa::rt::gemm_nt_kernel<9, 5, 1, 2, 2", 2.0)],
     "linear_act_bwd": [("vqa::rt::gemm_tn_kernel<5, 2", 2.0)],
     "lowrank_bilinear_fusion_bwd": [("vqa::bilinear_dw_rt_kernel", 2.0)],

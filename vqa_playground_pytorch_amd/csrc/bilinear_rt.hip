@@ -20,6 +20,14 @@
 // 16-deep chunk and wave: 20 fragment loads, 8 VALU instructions of fold per (sample, row block) in front of its 12 MFMAs
 // (the fold is inherent to the folded form: 0.67 VALU instructions per MFMA), no LDS, no barrier.  The forward's bias
 // rides as contraction column L (x = 1, W = b1_r), part of the guarded tail chunk.
+//
+// Measured at B = 512, N = 36, L = 310, H = 510, R = 2 (rocprofv3, kernels launched back to back): forward 85 us, data
+// gradient 81 us (the LDS-tile kernels: 99 / 100; in the step 90 / ~80 against 98 / 91).  With the fold placed by the compiler
+// (three VALU instructions + a hazard nop in front of every group of three MFMAs) the same kernels took 94 / 96 us; without
+// any fold arithmetic 81 / 77 -- what is left above the 56 us of pure MFMA issue at 2.2 GHz is the sustained clock under
+// this load (~1.9 GHz) and the fixed cost of a one-round grid (prologue, the guarded tail chunk, the output stores: ~8 us).
+// Tried and dropped: two samples per workgroup with two workgroups per CU (83 us forward); requesting the tail chunk
+// before the main loop (80 more live registers: the forward spills).
 #include <cstdlib>
 
 #include "bilinear_folded.hpp"
@@ -41,7 +49,7 @@ struct FoldRtArgs {
 
 constexpr int kNB = 3;     // region blocks of 16 (N <= 48)
 
-template <bool FWD, int S, int IB, int R, int TUNE = 0>
+template <bool FWD, int S, int IB, int R>
 __global__ __launch_bounds__(rt::kThreads, 1) void bilinear_fold_rt_kernel(FoldRtArgs p) {
   using rt::f32x4;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
@@ -111,7 +119,6 @@ __global__ __launch_bounds__(rt::kThreads, 1) void bilinear_fold_rt_kernel(FoldR
   // the folded weight fragment of (sample s, row block i): one packed multiply + one packed fma per pair of components
   auto fold = [&](const Frag& f, int s, int i) -> f32x4 {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    if constexpr ((TUNE & 1) != 0) return f.w[0][i] + f.w[R - 1][i];   // (experiment: no fold arithmetic to speak of)
     f32x4 we;
     if constexpr (FWD) {
       const f32x2 h0 = f32x2{hrow[s][0][i], hrow[s][0][i]};
@@ -271,11 +278,8 @@ int launch(const FoldRtArgs& a0, int R, hipStream_t s) {
   constexpr int S = FWD ? 4 : 2, IB = FWD ? 4 : 5;
   a.tiles_o = (a.NO + 64 * IB - 1) / (64 * IB);
   const dim3 grid((unsigned)(((a.B + S - 1) / S) * a.tiles_o));
-  const int tune = std::getenv("VQA_K4_RT_TUNE") ? std::atoi(std::getenv("VQA_K4_RT_TUNE")) : 0;   // (experiments)
   if (R == 1)
     hipLaunchKernelGGL((bilinear_fold_rt_kernel<FWD, S, IB, 1>), grid, dim3(rt::kThreads), 0, s, a);
-  else if (tune == 1)
-    hipLaunchKernelGGL((bilinear_fold_rt_kernel<FWD, S, IB, 2, 1>), grid, dim3(rt::kThreads), 0, s, a);
   else
     hipLaunchKernelGGL((bilinear_fold_rt_kernel<FWD, S, IB, 2>), grid, dim3(rt::kThreads), 0, s, a);
   return check_launch(FWD ? "lowrank_bilinear_fusion_folded_fwd (register-tile)" : "lowrank_bilinear_fusion_folded_bwd (dx, register-tile)");
