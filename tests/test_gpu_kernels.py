@@ -884,3 +884,51 @@ def test_relation_projection_fused_backward(ops, B, D, L, p):
     close("d_c2 vs two-op path", ct.grad, c2_.grad.cpu().numpy(), 2e-4)
     close("d_w", wt.grad, np.einsum("bnl,bnd->ld", gz, x), 2e-4)
     close("d_b", bt.grad, gz.sum((0, 1)), 2e-4)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.5, 0.25])
+def test_relation_projection_pairwise_forward(ops, p):
+    """The fused relation + projection node with its forward on the PAIRWISE kernel (every (i, j) term, dropout in the
+    store): the same output and gradients as the closed-form forward it stands in for (t = q1 sum_i alpha_i v_i, c2 = q2
+    for a softmax alpha), and the dropped relation tensor equals the oracle's pairwise reduce times the exported mask."""
+    B, N, D, L, G = 260, 36, 2048, 310, 4         # B * D >= 2^19: the in-register pairwise kernel
+    v = seeded.seeded_array((B, N, D), 421)
+    q1 = 1 / (1 + np.exp(-seeded.seeded_array((B, D), 422)))
+    q2 = 1 / (1 + np.exp(-seeded.seeded_array((B, D), 423)))
+    logits = seeded.seeded_array((B, N, G), 424)
+    w = seeded.seeded_array((L, D), 425, scale=1.0 / np.sqrt(D))
+    bias = seeded.seeded_array((L,), 426, scale=0.1)
+    gy = seeded.seeded_array((B, N, L), 427)
+    seed = 31337
+    vt = g(v)
+    alpha = torch.softmax(g(logits), dim=1)
+    s0 = torch.einsum("bn,bnd->bd", alpha[:, :, 0], vt)
+    assert ops.pairwise_projection_supported(vt) and ops.relation_projection_supported(vt, g(w))
+    outs = []
+    for pairwise in (False, True):
+        q1t, q2t, wt, bt = g(q1, True), g(q2, True), g(w, True), g(bias, True)
+        s_ = s0.clone().requires_grad_()
+        y = ops.relation_projection(vt, q1t * s_, q2t, wt, bt, p, seed, False, (q1t, q2t, alpha, 0) if pairwise else None)
+        y.backward(g(gy))
+        outs.append((y.detach(), q1t.grad, q2t.grad, s_.grad, wt.grad, bt.grad))
+    # y agrees to rounding.  The gradients agree up to the relu gates that the two forwards' last-bit differences flip
+    # (pre-activations within 1e-7 of zero; the same effect as any reordering of the forward GEMM): direction and size.
+    close("y (pairwise forward vs closed form)", outs[1][0], outs[0][0].cpu().numpy(), 5e-5)
+    for name, a, b in zip(("d_q1", "d_q2", "d_s", "d_w", "d_b"), outs[0][1:], outs[1][1:]):
+        a64, b64 = a.double().flatten(), b.double().flatten()
+        cos = float((a64 @ b64) / (a64.norm() * b64.norm()))
+        assert cos > 0.99999, (name, cos)
+        close(name + " (pairwise forward vs closed form)", b, a.cpu().numpy(), 6e-2)   # (one flipped gate moves an element by ~1-2 %)
+    # the relation tensor itself: pairwise kernel with dropout in the store == oracle pairwise reduce x exported mask
+    x = torch.empty_like(vt)
+    from vqa_playground_pytorch_amd import _lib
+    import ctypes
+    a_ptr = ctypes.c_void_p(alpha.data_ptr())
+    sv, sp = ops._seed_args(seed)
+    q1d, q2d = g(q1), g(q2)                        # (kept alive across the asynchronous launch)
+    _lib.check(_lib.lib().vqa_pairwise_relation_reduce_drop_fwd(ops._p(vt), ops._p(q1d), ops._p(q2d), a_ptr, G, ops._p(x), p, sv,
+                                                               sp, B, N, D, ops._stream()), "pairwise_drop_fwd")
+    torch.cuda.synchronize()
+    mask = ops.linear_dropout_mask(B * N, D, p, seed, dev()).cpu().numpy().reshape(B, N, D) if p else 1.0
+    want = K.pairwise_relation_reduce_fwd(v[:8], q1[:8], q2[:8], alpha[:8, :, 0].cpu().numpy().astype(np.float64))
+    close("relation tensor", x[:8], want * (mask[:8] if p else 1.0))

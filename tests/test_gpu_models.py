@@ -314,6 +314,29 @@ def test_parameter_gradients_are_written_into_the_flat_buffer(name, nans):
         torch.testing.assert_close(view, by_id[id(p)], rtol=1e-4, atol=1e-6)
 
 
+def test_relation_modes_agree_on_the_fused_node():
+    """At batches the fused relation + projection node serves (B * 36 >= 1024 rows), relation_mode 0 runs the node's forward
+    on the pairwise kernel and shares the rest with the closed form: logits and every parameter gradient of the two modes
+    agree (eval mode: no dropout)."""
+    torch.manual_seed(3)
+    v, q, a = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(32, answers=300, seed=13))
+    v = v.repeat(9, 1, 1)[:260].contiguous()                # 260 samples: the in-register pairwise kernel wants B * D >= 2^19
+    q, a = q.repeat(9, 1)[:260].contiguous(), a.repeat(9, 1)[:260].contiguous()
+    from vqa_playground_pytorch_amd import ops
+    m1 = build("cor2", 300).eval()
+    m0 = build("cor2", 300, relation_mode=0).eval()
+    m0.load_state_dict(m1.state_dict())
+    grads = []
+    for m in (m1, m0):
+        loss = ops.kld_sum_loss(m({"v": v, "q_idxes": q}), a)
+        gs = torch.autograd.grad(loss, [p for p in m.parameters() if p.requires_grad])
+        grads.append((loss.item(), gs))
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-4 * abs(grads[0][0])
+    for (n, _), g1, g0 in zip(m1.named_parameters(), grads[0][1], grads[1][1]):
+        scale = g1.abs().max().item() + 1e-12
+        assert (g1 - g0).abs().max().item() <= 1e-3 * scale + 1e-7, n
+
+
 def test_graph_trainer_fed_by_prefetcher_matches_eager():
     """Distinct batches streamed from pinned host memory through feed.DevicePrefetcher (which recycles its two device
     slots) into the graph-replayed trainer: the loss sequence equals the eager trainer's on the same batches, and the

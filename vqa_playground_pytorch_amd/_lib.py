@@ -55,6 +55,8 @@ SIGNATURES = {
                                                             _c_f, _c_sz, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_dropout_groups_fwd": (_c_i, [_c_f, _c_i, _c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_i, _c_st]),
     "vqa_dropout_groups_bwd": (_c_i, [_c_f, _c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_pairwise_relation_reduce_drop_supported": (_c_i, [_c_i, _c_i, _c_i]),
+    "vqa_pairwise_relation_reduce_drop_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_i, _c_st]),
     "vqa_relation_projection_dgrad_supported": (_c_i, [_c_i, _c_i, _c_i, _c_i]),
     "vqa_relation_projection_dgrad": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_rank_product_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_st]),

@@ -119,7 +119,11 @@ class Model(nn.Module):
             _cut.extend([outs, ins])
             q_feature_low, q_final, q_gate_1, q_gate_2, pooled1_first, v1_att, alpha1_full = ins
 
-        if self.relation_mode == 1:
+        cv2 = self.compress_v2
+        w2 = cv2.conv.weight.squeeze(-1)
+        fused_node = cv2.af == "relu" and cv2.fused and b * v_feature.size(1) >= 1024 and v_feature.dtype == torch.float32 and \
+            ops.relation_projection_supported(v_feature, w2)
+        if self.relation_mode == 1 or (fused_node and ops.pairwise_projection_supported(v_feature)):
             # Closed form of the relation step (config/CoR2.py:191-199 + :216).  Only glimpse 0 of alpha1 weights it, and
             # sum_i alpha1[i,0] v_i is exactly glimpse 0 of the pooled features att1 has just produced, while a softmax
             # alpha sums to 1 -- so v2[b,n] = t[b] + q2[b] * v[b,n] with t = q1 * pooled1[:,0].  (The two unit sums only
@@ -129,13 +133,15 @@ class Model(nn.Module):
             t = q_gate_1 * pooled1_first
             c2 = q_gate_2
             p = self.compress_v2.p if (self.training and self.compress_v2.p) else 0.0
-            cv2 = self.compress_v2
-            w2 = cv2.conv.weight.squeeze(-1)
-            if cv2.af == "relu" and cv2.fused and b * v_feature.size(1) >= 1024 and ops.relation_projection_supported(v_feature, w2):
+            if fused_node:
                 # relation step + projection as one autograd node: backward reduces the projection's data gradient to
-                # d_t / d_c2 inside the GEMM tile (csrc/relation_dgrad.hip) instead of writing and re-reading [B,N,2048]
+                # d_t / d_c2 inside the GEMM tile (csrc/relation_dgrad.hip) instead of writing and re-reading [B,N,2048].
+                # relation_mode 0: the node's forward builds the relation tensor with the PAIRWISE kernel (every (i, j) term,
+                # the reference's structure); everything else -- the backward through (t, c2), the second attention pooling v
+                # itself -- is shared with the closed form, which it equals.
+                pairwise = (q_gate_1, q_gate_2, alpha1_full, 0) if self.relation_mode != 1 else None
                 v2_feature_low = ops.relation_projection(v_feature, t, c2, w2, cv2.conv.bias, p,
-                                                         ops.next_dropout_seed() if p else 0, cv2.grad_pregated)
+                                                         ops.next_dropout_seed() if p else 0, cv2.grad_pregated, pairwise)
             else:
                 v2_dropped = ops.relation_apply(v_feature, t, c2, p, ops.next_dropout_seed() if p else 0)
                 v2_feature_low = cv2(v2_dropped, predropped=True)

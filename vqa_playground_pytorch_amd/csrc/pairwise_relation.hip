@@ -171,11 +171,12 @@ __global__ __launch_bounds__(64, 3) void pairwise_fwd_pairs_reg_kernel(const T* 
 __global__ __launch_bounds__(64, 5) void pairwise_fwd_pairs_reg2_kernel(const float* __restrict__ v, const float* __restrict__ q1,
                                                                      const float* __restrict__ q2,
                                                                      const float* __restrict__ alpha, int astride,
-                                                                     float* __restrict__ v2, int N, int D) {
+                                                                     float* __restrict__ v2, int N, int D, DropCfg dc) {
   const int b = blockIdx.y;
   const int d = (blockIdx.x * 64 + threadIdx.x) * 2;
   if (d >= D) return;
   const size_t base = (size_t)b * N * D + d;
+  const uint32_t key = dc.p8 > 0 ? drop_key(dc) : 0u;      // (dc.p8 > 0: the consumer's input dropout in the store, as relation_apply)
   f32x2 r[kRegN];
 #pragma unroll
   for (int i = 0; i < kRegN; ++i) r[i] = *reinterpret_cast<const f32x2*>(v + base + (size_t)min(i, N - 1) * D);
@@ -198,6 +199,16 @@ __global__ __launch_bounds__(64, 5) void pairwise_fwd_pairs_reg2_kernel(const fl
     for (int i = 0; i < kRegN; ++i) {
       const f32x2 ai = {a[i], a[i]};
       acc = __builtin_elementwise_fma(ai, __builtin_elementwise_fma(r[i], q1v, tj), acc);
+    }
+    if (dc.p8 > 0) {
+      const uint32_t e = (uint32_t)(base + (size_t)j * D);   // even
+      if (dc.p8 == kDropHalf) {
+        const uint32_t w = mask_word32(e >> 5, key) >> (e & 31u);
+        acc *= f32x2{(w & 1u) ? 2.f : 0.f, (w & 2u) ? 2.f : 0.f};
+      } else {
+        const uint32_t w = mask_word32(e >> 2, key) >> (8 * (e & 3));
+        acc *= f32x2{(w & 255u) >= dc.p8 ? dc.scale : 0.f, ((w >> 8) & 255u) >= dc.p8 ? dc.scale : 0.f};
+      }
     }
     *reinterpret_cast<f32x2*>(v2 + base + (size_t)j * D) = acc;
   }
@@ -442,7 +453,7 @@ static int pairwise_fwd_impl(const char* who, const T* v, const float* q1, const
     if constexpr (sizeof(T) == 4) {
       if ((long)B * D >= (1L << 19) && std::getenv("VQA_K1_PAIRWISE_REG4") == nullptr) {   // enough columns for half-sized waves
         hipLaunchKernelGGL(pairwise_fwd_pairs_reg2_kernel, dim3((D / 2 + 63) / 64, B), dim3(64), 0, s, v, q1, q2, alpha,
-                           alpha_stride, v2, N, D);
+                           alpha_stride, v2, N, D, make_drop(0.f, 0));
         return check_launch(who);
       }
     }
@@ -613,4 +624,24 @@ extern "C" int vqa_relation_apply_bwd_bf16(const vqa_bf16_t* v, const float* c2,
   return relation_apply_bwd_impl<bf16>("relation_apply_bwd_bf16", reinterpret_cast<const bf16*>(v), c2,
                                        reinterpret_cast<const bf16*>(g), d_t, d_c2, reinterpret_cast<bf16*>(d_v), p_drop, seed,
                                        seed_ptr, B, N, D, stream);
+}
+
+// The pairwise forward with the consumer's input dropout in its store (mode 0 of the fused relation + projection node:
+// ops.relation_projection(..., pairwise=...)): v2[b,j,:] = keep * sum_i alpha_i (v_i q1 + v_j q2), keep over the element
+// index (b N + j) D + d as vqa_relation_apply_fwd draws it.
+extern "C" int vqa_pairwise_relation_reduce_drop_supported(int B, int N, int D) {
+  return N >= 1 && N <= kRegN && D % 4 == 0 && (long)B * D >= (1L << 19) && B <= 65535 && (size_t)B * N * D < (1ull << 32);
+}
+extern "C" int vqa_pairwise_relation_reduce_drop_fwd(const float* v, const float* q1, const float* q2, const float* alpha,
+                                                     int alpha_stride, float* v2, float p_drop, uint64_t seed,
+                                                     const uint64_t* seed_ptr, int B, int N, int D, vqa_stream_t stream) {
+  VQA_REQUIRE(v && q1 && q2 && alpha && v2, VQA_E_BADARG, "pairwise_relation_reduce_drop_fwd: null pointer");
+  VQA_REQUIRE(B > 0 && N > 0 && D > 0 && alpha_stride > 0, VQA_E_BADARG, "pairwise_relation_reduce_drop_fwd: bad sizes");
+  VQA_REQUIRE(p_drop >= 0.f && p_drop < 1.f, VQA_E_BADARG, "pairwise_relation_reduce_drop_fwd: p_drop=%f outside [0,1)", (double)p_drop);
+  VQA_REQUIRE(vqa_pairwise_relation_reduce_drop_supported(B, N, D) && aligned(v, 16) && aligned(q1, 16) && aligned(q2, 16) &&
+                  aligned(v2, 16),
+              VQA_E_UNSUPPORTED, "pairwise_relation_reduce_drop_fwd: needs N <= %d, D %% 4 == 0, B*D >= 2^19, aligned tensors", kRegN);
+  hipLaunchKernelGGL(pairwise_fwd_pairs_reg2_kernel, dim3((D / 2 + 63) / 64, B), dim3(64), 0, static_cast<hipStream_t>(stream), v, q1,
+                     q2, alpha, alpha_stride, v2, N, D, make_drop(p_drop, seed, seed_ptr));
+  return check_launch("pairwise_relation_reduce_drop_fwd");
 }

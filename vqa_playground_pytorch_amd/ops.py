@@ -812,7 +812,11 @@ class RelationProjection(torch.autograd.Function):
     re-read).  v must not need a gradient (it is the model's input); shapes vqa_relation_projection_dgrad_supported()."""
 
     @staticmethod
-    def forward(ctx, v, t, c2, w, bias, p_drop, seed, pregated):
+    def forward(ctx, v, t, c2, w, bias, p_drop, seed, pregated, pairwise=None):
+        # pairwise = (q1, q2, alpha [B,N,G], glimpse): the relation tensor is built by the PAIRWISE kernel -- every (i, j) term
+        # alpha_i (v_i q1 + v_j q2) summed, the reference's structure (config/CoR2.py:191-199,216) -- instead of the closed
+        # form t + c2 v that equals it for t = q1 sum_i alpha_i v_i, c2 = (sum_i alpha_i) q2; the gradient still flows through
+        # (t, c2), whose producers carry it on to q1, q2 and alpha
         v, t, c2, w = _prep("v", v), _prep("t", t), _prep("c2", c2), _prep("w", w)
         bias = _prep("bias", bias) if bias is not None else None
         B, N, D = v.shape
@@ -822,8 +826,15 @@ class RelationProjection(torch.autograd.Function):
         L_ = _lib.lib()
         x = torch.empty_like(v)
         sv, sp = _seed_args(seed)
-        _launch("relation_apply_fwd", (B, N, D, float(p_drop) > 0), L_.vqa_relation_apply_fwd, _p(v), _p(t), _p(c2), _p(x),
-                float(p_drop), sv, sp, B, N, D)
+        if pairwise is not None:
+            q1, q2, alpha, glimpse = pairwise
+            q1, q2, alpha = _prep("q1", q1.detach()), _prep("q2", q2.detach()), _prep("alpha", alpha.detach())
+            a_ptr = ctypes.c_void_p(alpha.data_ptr() + 4 * glimpse)
+            _launch("pairwise_relation_reduce_fwd", (B, N, D, 0), L_.vqa_pairwise_relation_reduce_drop_fwd, _p(v), _p(q1), _p(q2),
+                    a_ptr, alpha.shape[2], _p(x), float(p_drop), sv, sp, B, N, D)
+        else:
+            _launch("relation_apply_fwd", (B, N, D, float(p_drop) > 0), L_.vqa_relation_apply_fwd, _p(v), _p(t), _p(c2), _p(x),
+                    float(p_drop), sv, sp, B, N, D)
         M = B * N
         y = torch.empty(B, N, L, device=v.device, dtype=torch.float32)
         _launch("linear_act_fwd", (M, D, L, False), L_.vqa_linear_act_fwd, _p(x), D, _p(w), _p(bias), _p(y), M, D, L, 1, 0.0, 0, None)
@@ -853,7 +864,7 @@ class RelationProjection(torch.autograd.Function):
         sv, sp = _seed_args(seed)
         _launch("relation_projection_dgrad", (B, N, D, L, p_drop > 0), L_.vqa_relation_projection_dgrad, _p(gz), _p(w), _p(v),
                 _p(d_t), _p(d_c2), p_drop, sv, sp, B, N, D, L)
-        return None, d_t, d_c2, d_w, d_b, None, None, None
+        return None, d_t, d_c2, d_w, d_b, None, None, None, None
 
 
 def relation_projection_supported(v, w):
@@ -862,8 +873,13 @@ def relation_projection_supported(v, w):
             bool(_lib.lib().vqa_relation_projection_dgrad_supported(v.shape[0], v.shape[1], v.shape[2], w.shape[0])))
 
 
-def relation_projection(v, t, c2, w, bias, p_drop=0.0, seed=0, pregated=False):
-    return RelationProjection.apply(v, t, c2, w, bias, p_drop, seed, pregated)
+def relation_projection(v, t, c2, w, bias, p_drop=0.0, seed=0, pregated=False, pairwise=None):
+    return RelationProjection.apply(v, t, c2, w, bias, p_drop, seed, pregated, pairwise)
+
+
+def pairwise_projection_supported(v):
+    """Can relation_projection's pairwise forward (the in-register N x N kernel with dropout in its store) take v?"""
+    return bool(_lib.lib().vqa_pairwise_relation_reduce_drop_supported(v.shape[0], v.shape[1], v.shape[2]))
 
 
 def column_sum(x, out=None):
