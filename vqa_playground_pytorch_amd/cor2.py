@@ -10,7 +10,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .layers import MutanFusion, MyATT, MyConv1d, MyLinear, QuestionVectorInput, linear_stack_groups, my_linears, question_feature
+from .layers import MutanFusion, MyATT, MyConv1d, MyLinear, QuestionVectorInput, SideOutputs, linear_stack_groups, my_linears, \
+    question_feature
 
 
 class Model(nn.Module):
@@ -149,7 +150,10 @@ class Model(nn.Module):
             v2_att, alpha2, _ = self.att2.attend(v_feature, self.att2.conv_att.pre_activation(fuse2),
                                                  lambda pooled, pd: ops.relation_apply(
                                                      pooled, t, c2, pd, ops.next_dropout_seed() if pd else 0))
-            feature = torch.addcmul(t.unsqueeze(1), c2.unsqueeze(1), v_feature[:, 0:2, :].float()).detach()
+            # (computed when read: a training step never looks at it.  Under graph replay t and c2 are the graph's own
+            #  buffers, i.e. they hold the latest step's values when the entry is read after it)
+            t_d, c2_d, v_d = t.detach(), c2.detach(), v_feature.detach()
+            feature = lambda: torch.addcmul(t_d.unsqueeze(1), c2_d.unsqueeze(1), v_d[:, 0:2, :].float())  # noqa: E731
         else:
             # pairwise form: every (i, j) term of the relation tensor summed in the kernel, as the reference structures it;
             # v2 has two consumers, each gets its own alias (see ops.pairwise_relation_reduce)
@@ -161,8 +165,8 @@ class Model(nn.Module):
 
         # side output read by visu.py:198-207; detached so it does not pin the autograd graph of the step
         # (feature = the reference's v2_feature[:, [0, 1], :])
-        self.alpha_dict = {"alpha1": tuple(t_.detach() for t_ in alpha1), "alpha2": tuple(t_.detach() for t_ in alpha2),
-                           "feature": feature}
+        self.alpha_dict = SideOutputs({"alpha1": tuple(t_.detach() for t_ in alpha1), "alpha2": tuple(t_.detach() for t_ in alpha2),
+                                       "feature": feature})
 
         v_f = torch.cat([v1_att, v2_att], dim=1)
         x = self.fusion_final(v_f, q_final)

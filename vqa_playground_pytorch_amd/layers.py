@@ -383,6 +383,31 @@ class MyATT(nn.Module):
         return x_v, list_att
 
 
+class SideOutputs(dict):
+    """The ``alpha_dict`` side output of a model (read by visu.py:198-207 after a forward) with entries that are computed
+    on first access: a value stored as a zero-argument callable is replaced by its result when it is read.  A training
+    step never reads ``alpha_dict['feature']``, so the kernel that would materialise it does not run in the step."""
+
+    def _resolve(self, key):
+        value = dict.__getitem__(self, key)
+        if callable(value) and not isinstance(value, torch.Tensor):
+            value = value()
+            dict.__setitem__(self, key, value)
+        return value
+
+    def __getitem__(self, key):
+        return self._resolve(key)
+
+    def get(self, key, default=None):
+        return self._resolve(key) if key in self else default
+
+    def items(self):
+        return [(k, self._resolve(k)) for k in list(self.keys())]
+
+    def values(self):
+        return [self._resolve(k) for k in list(self.keys())]
+
+
 class QuestionVectorInput(nn.Module):
     """Stand-in for the question encoder slot ``seq2vec`` (putils.SkipThoughts, putils/__init__.py:878-985,
     is upstream of the hot path and needs weight files that are not available offline): the sample's

@@ -1308,6 +1308,21 @@ class KldSumLoss(torch.autograd.Function):
         return d_logits * g, None
 
 
+def kld_sum_loss_and_grad(logits, target):
+    """(loss, dL/dlogits) of the KLD-sum loss from ONE pass, outside autograd: a train step that backpropagates from the
+    logits with this gradient (``torch.autograd.backward(logits, d_logits)``) skips the loss node's multiply by the
+    incoming scalar 1."""
+    lg, target = _prep("logits", logits.detach()), _prep("target", target)
+    if lg.dim() != 2 or target.shape != lg.shape:
+        raise ValueError("kld_sum_loss: logits and target must both be [B,C], got %s and %s" % (tuple(lg.shape), tuple(target.shape)))
+    B, C = lg.shape
+    loss = torch.empty((), device=lg.device, dtype=torch.float32)
+    d_logits = torch.empty_like(lg)
+    ws = torch.empty(B, device=lg.device, dtype=torch.float32)
+    _launch("kld_sum_loss", (B, C, True), _lib.lib().vqa_kld_sum_loss, _p(lg), _p(target), _p(loss), _p(d_logits), _p(ws), 4 * B, B, C)
+    return loss, d_logits
+
+
 def kld_sum_loss(logits, target):
     return KldSumLoss.apply(logits, target)
 

@@ -342,16 +342,17 @@ class DataParallelTrainer:
         ops.set_device_seed(self.seed_word)
         ops.begin_step_salts()
         try:
-            loss = kld_sum_loss(self.model(sample), target)
+            logits = self.model(sample)
+            loss, d_logits = ops.kld_sum_loss_and_grad(logits, target)     # (loss and its gradient from one kernel)
         finally:
             ops.set_device_seed(None)
         f.begin_backward()
         try:
-            loss.backward()
+            torch.autograd.backward(logits, d_logits)
         finally:
             f.end_backward()
         f.gather_grads()
-        return loss.detach()
+        return loss
 
     def _tail(self):
         """clip + Adam with the per-step scalars read from device memory (graph 2)."""
@@ -479,20 +480,20 @@ class DataParallelTrainer:
             ops.begin_step_salts()
         try:
             logits, outs, ins = self.model.forward_with_cut(sample)
-            loss = kld_sum_loss(logits, target)
+            loss, d_logits = ops.kld_sum_loss_and_grad(logits, target)
         finally:
             if device_seed:
                 ops.set_device_seed(None)
         live = [(o, i) for o, i in zip(outs, ins) if i.requires_grad]
         ops.set_grad_slots(self.flat.p, self.flat.g)
         try:
-            grads = torch.autograd.grad(loss, self._late + [i for _, i in live], allow_unused=True)
+            grads = torch.autograd.grad(logits, self._late + [i for _, i in live], grad_outputs=d_logits, allow_unused=True)
         finally:
             ops.set_grad_slots(None, None)
         self.flat.store_grads(self._late, grads[:len(self._late)])
         pairs = [(o, g) for (o, _), g in zip(live, grads[len(self._late):]) if g is not None]
         self._cut = ([o for o, _ in pairs], [g for _, g in pairs])
-        return loss.detach()
+        return loss
 
     def _front_b(self):
         """backward from the cut to the inputs + gather of the early parameters' gradients."""
