@@ -25,7 +25,7 @@
 #include <type_traits>
 #include <utility>
 
-#include "common.hpp"
+#include "gemm_f32_rt.hpp"
 
 namespace vqa {
 
@@ -133,6 +133,151 @@ __global__ void oda_fwd_bits_kernel(const float* __restrict__ vl, const float* _
       for (int wv = 0; wv < nwaves; ++wv) sum += red_s[wv * (kIB * G) + t];
       logits[((size_t)b * N + i0 + ic) * G + g] = fmaf(dc.scale, sum, bias[g]);     // the kept values' factor 2
     }
+  }
+}
+
+// ---- forward on the 4x4 matrix instruction ------------------------------------------------------------------------
+// The G = 4 glimpse FMAs of every masked difference are a 4x4 outer product: v_mfma_f32_4x4x1_16B_f32 does sixteen of them
+// per instruction (blocks k = lane >> 2; D[k][i][g] += A[k][i] B[k][g]; lane (k, r) supplies A[k][r] and B[k][r], 8 cycles),
+// so the VALU is left with the 3 instructions that MAKE the masked difference (subtract, v_bfe_i32, v_and) instead of 7.
+//   block k <-> feature d = 16 ds + k of the wave's current set of 16 features,  row r <-> region i = 4 ig + r of region
+//   group ig,  column r <-> glimpse g = r:   acc[ig] += (keep (T_i[d] - T_j[d])) (outer) w[g][j][d]   for j = 0 .. N-1.
+// A lane keeps T_i[d] of its 9 regions (N <= 36) in registers for a whole feature set; per j it loads T_j[d] and w[r][j][d].
+// Mask words: ONE 32-bit hash word holds the bits of regions 0..31 of a (j, d) (a second one regions 32..35); the four
+// lanes of a block need the same words, so lane r hashes for j = j0 + r and the quad exchanges them by DPP (quad_perm).
+// A workgroup = one sample, its waves share the feature sets; the 16 blocks of a wave and the waves meet at the end.
+typedef float oda_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kOdaIG = 9;    // region groups of 4 (N <= 36)
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, true);
+}
+
+template <bool MASK>
+__global__ __launch_bounds__(256) void oda_fwd_mfma_kernel(const float* __restrict__ vl, const float* __restrict__ ql,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ logits, DropCfg dc, int N, int L, int G) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red_s = reinterpret_cast<float*>(smem);      // [nwaves][4 kOdaIG][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int k = lane >> 2, r = lane & 3;
+  const int b = blockIdx.x;
+  const int NI = (N + 31) >> 5;
+  const uint32_t key = MASK ? drop_key(dc) : 0u;
+  const uint32_t stride = (uint32_t)N * (uint32_t)L;
+  const float* vlb = vl + (size_t)b * N * L;
+  oda_f32x4 acc[kOdaIG];
+#pragma unroll
+  for (int ig = 0; ig < kOdaIG; ++ig) acc[ig] = oda_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // buffer addressing: a per-lane byte offset (feature column; glimpse row of w) + a scalar offset for the region row
+  const rt::rsrc_t Vb = rt::make_rsrc(vlb, (size_t)N * L * 4);
+  const rt::rsrc_t Wb = rt::make_rsrc(w, (size_t)G * N * L * 4);
+  const int nsets = (L + 15) >> 4;
+  // per feature set: the lane's column, its T_i (raw v values; q is multiplied in when the set starts) and the first group of
+  // regions j -- all requested one SET ahead, so that only the wave's first set waits for memory
+  struct SetRegs {
+    float ti[kOdaIG], tj[4], wv[4], qd;
+  };
+  auto set_offsets = [&](int ds, uint32_t& vo, uint32_t& wo, int& dcl, bool& dok) {
+    const int d = 16 * min(ds, nsets - 1) + k;
+    dok = d < L && ds < nsets;
+    dcl = d < L ? d : 0;
+    vo = (uint32_t)dcl * 4u;
+    wo = ((uint32_t)min(r, G - 1) * stride + (uint32_t)dcl) * 4u;
+  };
+  auto load_group = [&](float (&t)[4], float (&wg)[4], uint32_t vo, uint32_t wo, int j0) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const uint32_t so = (uint32_t)min(j0 + jj, N - 1) * (uint32_t)L * 4u;
+      t[jj] = rt::ldg4(Vb, vo, so);
+      wg[jj] = rt::ldg4(Wb, wo, so);
+    }
+  };
+  auto load_set = [&](SetRegs& sr, int ds) {
+    uint32_t vo, wo;
+    int dcl;
+    bool dok;
+    set_offsets(ds, vo, wo, dcl, dok);
+    sr.qd = ql[(size_t)b * L + dcl];
+#pragma unroll
+    for (int ig = 0; ig < kOdaIG; ++ig) sr.ti[ig] = rt::ldg4(Vb, vo + (uint32_t)min(4 * ig + r, N - 1) * (uint32_t)L * 4u, 0u);
+    load_group(sr.tj, sr.wv, vo, wo, 0);
+  };
+  SetRegs nx;
+  if (wave < nsets) load_set(nx, wave);
+  for (int ds = wave; ds < nsets; ds += nwaves) {
+    uint32_t vo, wo;
+    int dcl;
+    bool dok;
+    set_offsets(ds, vo, wo, dcl, dok);
+    const float qd = dok ? nx.qd : 0.f;
+    float Ti[kOdaIG], tj[4], wv[4];
+#pragma unroll
+    for (int ig = 0; ig < kOdaIG; ++ig) Ti[ig] = 4 * ig + r < N ? nx.ti[ig] * qd : 0.f;      // (qd = 0 beyond L)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      tj[jj] = nx.tj[jj];
+      wv[jj] = nx.wv[jj];
+    }
+    load_set(nx, ds + nwaves);                               // (past the last set: a clamped reload nobody uses)
+    const bool gok = dok && r < G;
+    const uint32_t cnt_d = (uint32_t)b * (uint32_t)NI * stride + (uint32_t)dcl;   // + j L (+ stride for the second word)
+    for (int j0 = 0; j0 < N; j0 += 4) {
+      float tn[4], wn[4];
+      load_group(tn, wn, vo, wo, min(j0 + 4, N - 1));
+      uint32_t hw0 = 0u, hw1 = 0u;
+      if constexpr (MASK) {
+        const uint32_t cnt = cnt_d + (uint32_t)min(j0 + r, N - 1) * (uint32_t)L;
+        hw0 = mask_word32(cnt, key);
+        if (NI > 1) hw1 = mask_word32(cnt + stride, key);
+      }
+      static_for<4>([&](auto jj_) {
+        constexpr int jj = decltype(jj_)::value;
+        constexpr int kCtrl = jj * 0x55;                     // quad_perm [jj, jj, jj, jj]
+        const uint32_t b0 = dpp_u32<kCtrl>(hw0) >> r, b1 = dpp_u32<kCtrl>(hw1) >> r;   // bit 4 ig <-> region 4 ig + r
+        const float Tj = tj[jj] * qd;
+        const float wg = (gok && j0 + jj < N) ? wv[jj] : 0.f;                             // (a region beyond N adds nothing)
+        // the nine masked differences of this j in one burst, then nine independent MFMAs back to back: an MFMA that reads
+        // a register the VALU has just written stalls on it (two wait states each in the interleaved order)
+        float x[kOdaIG];
+        static_for<kOdaIG>([&](auto ig_) {
+          constexpr int ig = decltype(ig_)::value;
+          x[ig] = Ti[ig] - Tj;
+          if constexpr (MASK) x[ig] = ig < 8 ? keep_bit<(4 * ig) & 31>(x[ig], b0) : keep_bit<0>(x[ig], b1);
+        });
+        __builtin_amdgcn_sched_group_barrier(0x002, MASK ? 3 * kOdaIG + 6 : kOdaIG + 2, 0);
+        static_for<kOdaIG>([&](auto ig_) {
+          constexpr int ig = decltype(ig_)::value;
+          acc[ig] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[ig], wg, acc[ig], 0, 0, 0);
+        });
+        __builtin_amdgcn_sched_group_barrier(0x008, kOdaIG, 0);
+      });
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        tj[jj] = tn[jj];
+        wv[jj] = wn[jj];
+      }
+    }
+  }
+  // the 16 blocks of the wave: blocks 0..3 of a 16-lane row by two rotations, the four rows lane-wise
+#pragma unroll
+  for (int ig = 0; ig < kOdaIG; ++ig)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float v = acc[ig][t];
+      v += dpp_mov<0x124>(v);      // row_ror:4
+      v += dpp_mov<0x128>(v);      // row_ror:8
+      v = rows_sum(v);
+      if (lane < 4) red_s[(wave * 4 * kOdaIG + 4 * ig + t) * 4 + lane] = v;       // region 4 ig + t, glimpse lane
+    }
+  __syncthreads();
+  for (int t = tid; t < N * G; t += blockDim.x) {
+    const int i = t / G, g = t % G;
+    float sum = 0.f;
+    for (int wv_ = 0; wv_ < nwaves; ++wv_) sum += red_s[(wv_ * 4 * kOdaIG + i) * 4 + g];
+    logits[((size_t)b * N + i) * G + g] = fmaf(MASK ? dc.scale : 1.f, sum, bias[g]);    // the kept values' factor 2
   }
 }
 
@@ -552,6 +697,23 @@ template <int G>
 static int launch_fwd(const float* vl, const float* ql, const float* w, const float* bias, float* logits, DropCfg dc,
                       int B, int N, int L, hipStream_t s) {
   const int nt = oda_threads(L);
+  {
+    // the 4x4-MFMA form: G <= 4 glimpses, N <= 36 regions, no dropout or the one-bit p = 0.5 mask (VQA_K2_MFMA=0: VALU kernels)
+    static const bool off = std::getenv("VQA_K2_MFMA") != nullptr && std::getenv("VQA_K2_MFMA")[0] == '0';
+    const bool bits = oda_bits_mode(dc, B, N, L);
+    if (!off && G <= 4 && N <= 4 * kOdaIG && (dc.p8 == 0 || bits) && B <= 65535 * 32) {
+      const int nsets = (L + 15) / 16;
+      // waves per sample: 4 = one per SIMD (2 x B workgroups of 4 waves spread evenly; five waves -- one feature set less per
+      // wave at L = 310 -- leave the SIMDs of a CU with 3, 3, 2, 2 waves: 56 us against 53)
+      int nw = nsets < 4 ? nsets : 4;
+      const size_t lds_m = (size_t)nw * 4 * kOdaIG * 4 * sizeof(float);
+      if (bits)
+        hipLaunchKernelGGL(oda_fwd_mfma_kernel<true>, dim3(B), dim3(64 * nw), lds_m, s, vl, ql, w, bias, logits, dc, N, L, G);
+      else
+        hipLaunchKernelGGL(oda_fwd_mfma_kernel<false>, dim3(B), dim3(64 * nw), lds_m, s, vl, ql, w, bias, logits, dc, N, L, G);
+      return check_launch("object_difference_attention_fwd");
+    }
+  }
   if (oda_bits_mode(dc, B, N, L)) {
     const size_t lds_b = (size_t)(nt / 64) * kIB * G * sizeof(float);
     hipLaunchKernelGGL((oda_fwd_bits_kernel<G>), dim3((N + kIB - 1) / kIB, B), dim3(nt), lds_b, s, vl, ql, w, bias, logits, dc, N,
