@@ -160,7 +160,8 @@ __global__ __launch_bounds__(256) void oda_fwd_mfma_kernel(const float* __restri
                                                            float* __restrict__ logits, DropCfg dc, int N, int L, int G) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red_s = reinterpret_cast<float*>(smem);      // [nwaves][4 kOdaIG][4]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k = lane >> 2, r = lane & 3;
   const int b = blockIdx.x;
   const int NI = (N + 31) >> 5;
@@ -278,6 +279,138 @@ __global__ __launch_bounds__(256) void oda_fwd_mfma_kernel(const float* __restri
     float sum = 0.f;
     for (int wv_ = 0; wv_ < nwaves; ++wv_) sum += red_s[(wv_ * 4 * kOdaIG + i) * 4 + g];
     logits[((size_t)b * N + i) * G + g] = fmaf(MASK ? dc.scale : 1.f, sum, bias[g]);    // the kept values' factor 2
+  }
+}
+
+// ---- weight gradient on the 4x4 matrix instruction ------------------------------------------------------------------
+//   dw[g][j][d] = scale sum_{b,i} dS[b,i,g] keep(b,i,j,d) (T_i[d] - T_j[d])
+// block k <-> feature d = 16 ds + k, row r <-> glimpse g = r (A = dS[b][i][r]), column r <-> region j = 4 jg + r of region group
+// jg (B = the masked difference of the lane's own j):  acc[jg] += dS[b][i][.] (outer) X[i][4 jg + .][d]  for every sample b
+// of the group and region i.  A lane keeps T_j[d] of its 9 regions and their mask words for the sample (a word holds the
+// bits of all regions i of one (j, d): hashed once per sample, the bit picked per i with a register offset).
+// Workgroup = 4 waves = one group of samples, the 20 feature sets of L = 310 split 5 per wave: 256 groups of 2 samples at
+// B = 512 = one workgroup per CU, the same work for every wave.  slab[sg][g][j][d], summed by oda_reduce_kernel.
+template <bool MASK>
+__global__ __launch_bounds__(512) void oda_bwd_weight_mfma_kernel(const float* __restrict__ vl, const float* __restrict__ ql,
+                                                                  const float* __restrict__ dS, float* __restrict__ slab,
+                                                                  DropCfg dc, int B, int N, int L, int G,
+                                                                  int samples_per_group) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ex_s = reinterpret_cast<float*>(smem);            // [nwaves][4 kOdaIG][64]: the odd half's accumulators of a set
+  // 2 nwaves waves: wave = (sample slot sw, feature-set quarter): the two slots take alternate samples of the group and meet
+  // in LDS after every set -- two waves per SIMD (one alone shows every dependent-issue latency: 89 us against 5x us)
+  const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 7;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform for the compiler too: scalar offsets below)
+  const int wave = wid % nwaves, sw = wid / nwaves;
+  const int k = lane >> 2, r = lane & 3;
+  const int sg = blockIdx.x;
+  const int NI = (N + 31) >> 5;
+  const uint32_t key = MASK ? drop_key(dc) : 0u;
+  const uint32_t stride = (uint32_t)N * (uint32_t)L;
+  const int b_lo = sg * samples_per_group, b_hi = min(B, b_lo + samples_per_group);
+  const rt::rsrc_t Vb = rt::make_rsrc(vl, (size_t)B * N * L * 4);
+  const rt::rsrc_t Sb = rt::make_rsrc(dS, (size_t)B * N * G * 4);
+  const int nsets = (L + 15) >> 4;
+  const int nb_all = b_hi - b_lo;
+  const int nb = (nb_all - sw + 1) / 2;                      // samples b_lo + sw, b_lo + sw + 2, ... of this slot
+  oda_f32x4 acc[kOdaIG];
+  const int max_sets = (nsets + nwaves - 1) / nwaves;       // every wave runs the same number of set rounds (barriers inside)
+  for (int si = 0; si < max_sets; ++si) {
+    const int ds = wave + si * nwaves;
+    const int d = 16 * ds + k;
+    const bool set_ok = ds < nsets;
+    const bool dok = set_ok && d < L;
+    const int dcl = dok ? d : 0;
+    const uint32_t vo = (uint32_t)dcl * 4u;
+#pragma unroll
+    for (int jg = 0; jg < kOdaIG; ++jg) acc[jg] = oda_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int bi = 0; bi < (set_ok ? nb : 0); ++bi) {
+      const int b = b_lo + sw + 2 * bi;
+      const uint32_t row0 = (uint32_t)b * stride * 4u;                    // byte offset of vl[b][0][0]
+      const float qd = dok ? ql[(size_t)b * L + dcl] : 0.f;
+      // regions i in groups of four: T_i[d] (one value per block) and the glimpse gradients dS[b][i][r], a group ahead
+      float ta[4], sa[4];
+      auto load_group = [&](float (&t)[4], float (&a)[4], int i0) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int ic = min(i0 + ii, N - 1);
+          t[ii] = rt::ldg4(Vb, vo, row0 + (uint32_t)ic * (uint32_t)L * 4u);
+          a[ii] = rt::ldg4(Sb, (uint32_t)min(r, G - 1) * 4u, (uint32_t)(b * N + ic) * (uint32_t)G * 4u);
+        }
+      };
+      load_group(ta, sa, 0);
+      float Tj[kOdaIG];
+      uint32_t w0[kOdaIG], w1[kOdaIG];
+#pragma unroll
+      for (int jg = 0; jg < kOdaIG; ++jg) {
+        const int j = min(4 * jg + r, N - 1);
+        Tj[jg] = rt::ldg4(Vb, vo + (uint32_t)j * (uint32_t)L * 4u, row0) * qd;
+        asm("" : "+v"(Tj[jg]));             // (a ROUNDED product on both sides of T_i - T_j -- no fma contraction --: T_i - T_i is
+                                            //  exactly zero, as in the reference)
+        if constexpr (MASK) {
+          const uint32_t cnt = (uint32_t)b * (uint32_t)NI * stride + (uint32_t)j * (uint32_t)L + (uint32_t)dcl;
+          w0[jg] = mask_word32(cnt, key);
+          w1[jg] = NI > 1 ? mask_word32(cnt + stride, key) : 0u;
+        }
+      }
+      // (a loop, not nine unrolled groups: with constant bit indices the code is 9x as long and ran 76 us against 72)
+      for (int i0 = 0; i0 < N; i0 += 4) {
+        float tn[4], sn[4];
+        load_group(tn, sn, min(i0 + 4, N - 1));
+        // the mask words of this group of regions, shifted so that region i0 + ii is bit ii
+        uint32_t ws[kOdaIG];
+        if constexpr (MASK) {
+          const bool hi = i0 >= 32;                                        // (uniform)
+          const uint32_t sh = (uint32_t)(i0 & 31);
+#pragma unroll
+          for (int jg = 0; jg < kOdaIG; ++jg) ws[jg] = (hi ? w1[jg] : w0[jg]) >> sh;
+        }
+        static_for<4>([&](auto ii_) {
+          constexpr int ii = decltype(ii_)::value;
+          float Ti = ta[ii] * qd;
+          asm("" : "+v"(Ti));
+          const float av = (r < G && dok && i0 + ii < N) ? sa[ii] : 0.f;   // (zero beyond N, G, L: such terms add nothing)
+          float x[kOdaIG];
+          static_for<kOdaIG>([&](auto jg_) {
+            constexpr int jg = decltype(jg_)::value;
+            x[jg] = Ti - Tj[jg];
+            if constexpr (MASK) x[jg] = keep_bit<ii>(x[jg], ws[jg]);
+          });
+          __builtin_amdgcn_sched_group_barrier(0x002, MASK ? 3 * kOdaIG + 2 : kOdaIG + 2, 0);
+#pragma unroll
+          for (int jg = 0; jg < kOdaIG; ++jg) acc[jg] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, x[jg], acc[jg], 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, kOdaIG, 0);
+        });
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          ta[ii] = tn[ii];
+          sa[ii] = sn[ii];
+        }
+      }
+    }
+    // the two sample slots of a set meet: slot 1 hands its accumulators over, slot 0 adds and stores
+    float* ex = ex_s + (size_t)wave * (4 * kOdaIG) * 64 + lane;
+    if (sw == 1) {
+#pragma unroll
+      for (int jg = 0; jg < kOdaIG; ++jg)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ex[(4 * jg + t) * 64] = acc[jg][t];
+    }
+    __syncthreads();
+    if (sw == 0 && dok) {
+      // acc[jg][t]: glimpse t, region 4 jg + r, feature d
+      const float sc = MASK ? dc.scale : 1.f;
+#pragma unroll
+      for (int jg = 0; jg < kOdaIG; ++jg) {
+        const int j = 4 * jg + r;
+        if (j < N) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (t < G) slab[(((size_t)sg * G + t) * N + j) * L + d] = (acc[jg][t] + ex[(4 * jg + t) * 64]) * sc;
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -692,6 +825,12 @@ static int oda_threads(int L) {
   return (t + 63) / 64 * 64;
 }
 static int oda_groups(int B) { return B < 128 ? B : 128; }
+// the 4x4-MFMA kernels (forward, weight gradient): G <= 4 glimpses, N <= 36 regions, no dropout or the one-bit p = 0.5 mask
+static bool oda_mfma_ok(const DropCfg& dc, int B, int N, int L, int G) {
+  static const bool off = std::getenv("VQA_K2_MFMA") != nullptr && std::getenv("VQA_K2_MFMA")[0] == '0';
+  return !off && G <= 4 && N <= 4 * kOdaIG && (dc.p8 == 0 || oda_bits_mode(dc, B, N, L)) && (size_t)B * N * L * 4 < (1ull << 32);
+}
+static int oda_mfma_groups(int B) { return B < 256 ? B : 256; }   // sample groups of the MFMA weight gradient: one workgroup per CU
 
 template <int G>
 static int launch_fwd(const float* vl, const float* ql, const float* w, const float* bias, float* logits, DropCfg dc,
@@ -699,9 +838,8 @@ static int launch_fwd(const float* vl, const float* ql, const float* w, const fl
   const int nt = oda_threads(L);
   {
     // the 4x4-MFMA form: G <= 4 glimpses, N <= 36 regions, no dropout or the one-bit p = 0.5 mask (VQA_K2_MFMA=0: VALU kernels)
-    static const bool off = std::getenv("VQA_K2_MFMA") != nullptr && std::getenv("VQA_K2_MFMA")[0] == '0';
     const bool bits = oda_bits_mode(dc, B, N, L);
-    if (!off && G <= 4 && N <= 4 * kOdaIG && (dc.p8 == 0 || bits) && B <= 65535 * 32) {
+    if (oda_mfma_ok(dc, B, N, L, G)) {
       const int nsets = (L + 15) / 16;
       // waves per sample: 4 = one per SIMD (2 x B workgroups of 4 waves spread evenly; five waves -- one feature set less per
       // wave at L = 310 -- leave the SIMDs of a CU with 3, 3, 2, 2 waves: 56 us against 53)
@@ -748,11 +886,21 @@ static int launch_bwd(const float* vl, const float* ql, const float* w, const fl
     }
   }
   {
-    const int SG = oda_groups(B);
-    const int spg = (B + SG - 1) / SG;
+    int SG = oda_groups(B);
+    int spg = (B + SG - 1) / SG;
     const size_t lds = (size_t)(N + 3) * G * sizeof(float);
     dim3 grid((N + kIC - 1) / kIC, SG);
-    if (oda_bits_mode(dc, B, N, L))
+    if (oda_mfma_ok(dc, B, N, L, G)) {
+      SG = oda_mfma_groups(B);
+      spg = (B + SG - 1) / SG;
+      SG = (B + spg - 1) / spg;
+      const int nsets = (L + 15) / 16, nw = nsets < 4 ? nsets : 4;
+      const size_t lds_m = (size_t)nw * 4 * kOdaIG * 64 * sizeof(float);
+      if (dc.p8 > 0)
+        hipLaunchKernelGGL(oda_bwd_weight_mfma_kernel<true>, dim3(SG), dim3(128 * nw), lds_m, s, vl, ql, dS, slab, dc, B, N, L, G, spg);
+      else
+        hipLaunchKernelGGL(oda_bwd_weight_mfma_kernel<false>, dim3(SG), dim3(128 * nw), lds_m, s, vl, ql, dS, slab, dc, B, N, L, G, spg);
+    } else if (oda_bits_mode(dc, B, N, L))
       hipLaunchKernelGGL((oda_bwd_weight_bits_kernel<G>), grid, dim3(nt), lds, s, vl, ql, dS, slab, dc, B, N, L, spg);
     else if (dc.p8 > 0)
       hipLaunchKernelGGL((oda_bwd_weight_kernel<G, true>), grid, dim3(nt), lds, s, vl, ql, dS, slab, dc, B, N, L, spg);
@@ -805,7 +953,7 @@ extern "C" int vqa_object_difference_attention_fwd(const float* vl, const float*
 
 extern "C" size_t vqa_object_difference_attention_bwd_workspace_bytes(int B, int N, int L, int G) {
   if (B <= 0 || N <= 0 || L <= 0 || G <= 0) return 0;
-  return (size_t)oda_groups(B) * G * N * L * sizeof(float);
+  return (size_t)(oda_mfma_groups(B) > oda_groups(B) ? oda_mfma_groups(B) : oda_groups(B)) * G * N * L * sizeof(float);
 }
 
 extern "C" int vqa_object_difference_attention_bwd(const float* vl, const float* ql, const float* w,
