@@ -414,6 +414,9 @@ __global__ __launch_bounds__(512) void oda_bwd_weight_mfma_kernel(const float* _
   }
 }
 
+// (The data gradient was tried on the same instruction too -- u[i][j][d] = sum_g dS[b,i,g] w[g,j,d] as four chained 4x4x1 MFMAs
+//  per pair of region groups, masked and summed along rows and columns by the VALU: 77-79 us, the same as the VALU kernel
+//  below, whose 8 lane-operations per element it only reshuffles (4 MFMA reads + 2 mask + 2 adds).  Not kept.)
 // backward d_vl, d_ql, bit mask: as oda_bwd_data_kernel
 template <int G>
 __global__ void oda_bwd_data_bits_kernel(const float* __restrict__ vl, const float* __restrict__ ql,
