@@ -334,7 +334,8 @@ def test_relation_modes_agree_on_the_fused_node():
     assert abs(grads[0][0] - grads[1][0]) <= 1e-4 * abs(grads[0][0])
     for (n, _), g1, g0 in zip(m1.named_parameters(), grads[0][1], grads[1][1]):
         scale = g1.abs().max().item() + 1e-12
-        assert (g1 - g0).abs().max().item() <= 1e-3 * scale + 1e-7, n
+        # (+ 1e-6 absolute: the bias in front of a softmax over regions has a mathematically zero gradient -- rounding noise)
+        assert (g1 - g0).abs().max().item() <= 1e-3 * scale + 1e-6, n
 
 
 def test_graph_trainer_fed_by_prefetcher_matches_eager():

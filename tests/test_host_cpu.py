@@ -29,7 +29,9 @@ def test_workspace_queries_need_no_gpu():
     n = handle.vqa_lowrank_bilinear_fusion_bwd_workspace_bytes(512, 36, 310, 510, 2)
     assert n >= 512 * 510 * 4 + 2 * 510 * 310 * 4
     assert handle.vqa_lowrank_bilinear_fusion_bwd_workspace_bytes(0, 36, 310, 510, 2) == 0
-    assert handle.vqa_object_difference_attention_bwd_workspace_bytes(512, 36, 310, 4) == 128 * 4 * 36 * 310 * 4
+    # (weight-gradient slabs: 256 sample groups on the 4x4-MFMA kernel, 128 on the VALU kernels; the query covers both)
+    assert handle.vqa_object_difference_attention_bwd_workspace_bytes(512, 36, 310, 4) == 256 * 4 * 36 * 310 * 4
+    assert handle.vqa_object_difference_attention_bwd_workspace_bytes(100, 36, 310, 4) == 100 * 4 * 36 * 310 * 4
 
 
 def test_bad_arguments_return_error_codes_without_gpu():
