@@ -29,6 +29,7 @@
 
 namespace vqa {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kOdaMaxG = 8;
 constexpr int kIC = 12;  // regions i (forward, dT) or j (dW) kept in registers per workgroup pass
 
@@ -414,6 +415,9 @@ __global__ __launch_bounds__(512) void oda_bwd_weight_mfma_kernel(const float* _
   }
 }
 
+// (Measured on the data-gradient kernel below, B = 512: 14 us of prologue + epilogue, 60 us in the j loop, 4 us of it the hash;
+//  removing a third of its lane-operations (packed pairs, independent chains) or prefetching the filter rows one or two
+//  regions ahead moves it by 2 us -- the SIMDs that hold 3 of the 10 waves of a CU set the time.)
 // (The data gradient was tried on the same instruction too -- u[i][j][d] = sum_g dS[b,i,g] w[g,j,d] as four chained 4x4x1 MFMAs
 //  per pair of region groups, masked and summed along rows and columns by the VALU: 77-79 us, the same as the VALU kernel
 //  below, whose 8 lane-operations per element it only reshuffles (4 MFMA reads + 2 mask + 2 adds).  Not kept.)
@@ -431,7 +435,7 @@ __global__ void oda_bwd_data_bits_kernel(const float* __restrict__ vl, const flo
   const uint32_t key = drop_key(dc);
   const uint32_t stride = (uint32_t)N * (uint32_t)L;
   const float* vlb = vl + (size_t)b * N * L;
-  for (int t = tid; t < N * G; t += nt) dS_s[t] = dS[(size_t)b * N * G + t];
+  for (int t = tid; t < (N + kIC) * G; t += nt) dS_s[t] = t < N * G ? dS[(size_t)b * N * G + t] : 0.f;   // (zero rows pad the last chunk)
   __syncthreads();
   for (int d = tid; d < L; d += nt) {
     for (int n = 0; n < N; ++n) dT_s[n * nt + tid] = 0.f;
@@ -439,33 +443,58 @@ __global__ void oda_bwd_data_bits_kernel(const float* __restrict__ vl, const flo
       const int sh = i0 & 31;
       const bool straddle = ((min(i0 + kIC, N) - 1) >> 5) != (i0 >> 5);
       const uint32_t base = ((uint32_t)b * NI + (uint32_t)(i0 >> 5)) * stride;
-      float ds[kIC][G], dTi[kIC];
+      // two regions i per packed lane-operation (v_pk_fma_f32 / v_pk_add_f32); the kIC/2 accumulation chains of one filter
+      // row are independent, so no dependent-issue bubbles
+      f32x2 ds[kIC / 2][G], dTi[kIC / 2];
 #pragma unroll
-      for (int ic = 0; ic < kIC; ++ic) {
-        dTi[ic] = 0.f;
+      for (int ip = 0; ip < kIC / 2; ++ip) {
+        dTi[ip] = f32x2{0.f, 0.f};
 #pragma unroll
-        for (int g = 0; g < G; ++g) ds[ic][g] = (i0 + ic < N) ? dS_s[(i0 + ic) * G + g] : 0.f;
+        for (int g = 0; g < G; ++g) ds[ip][g] = f32x2{dS_s[(i0 + 2 * ip) * G + g], dS_s[(i0 + 2 * ip + 1) * G + g]};
       }
-      for (int j = 0; j < N; ++j) {
-        float wv[G];
+      // the filter rows of regions j + 1, j + 2 are in flight under the arithmetic of region j (L2 latency > one j): three
+      // named buffers taken in turn, so no register rotation makes the compiler wait for the newest load
+      auto load_w = [&](float (&wr)[G], int j) {
+        const int jc = min(j, N - 1);
 #pragma unroll
-        for (int g = 0; g < G; ++g) wv[g] = w[((size_t)g * N + j) * L + d];
+        for (int g = 0; g < G; ++g) wr[g] = w[((size_t)g * N + jc) * L + d];
+      };
+      auto one_j = [&](int j, const float (&wv)[G]) {
+        const float dtj = dT_s[j * nt + tid];
         const uint32_t bits = oda_bits(base + (uint32_t)(j * L + d), stride, sh, straddle, key);
-        float pj = 0.f;
-        static_for<kIC>([&](auto ic_) {
-          constexpr int ic = decltype(ic_)::value;
-          float u = 0.f;
+        f32x2 u[kIC / 2];
 #pragma unroll
-          for (int g = 0; g < G; ++g) u = fmaf(ds[ic][g], wv[g], u);
-          u = keep_bit<ic>(u, bits);
-          dTi[ic] += u;
-          pj += u;
+        for (int ip = 0; ip < kIC / 2; ++ip) u[ip] = ds[ip][0] * f32x2{wv[0], wv[0]};
+#pragma unroll
+        for (int g = 1; g < G; ++g)
+#pragma unroll
+          for (int ip = 0; ip < kIC / 2; ++ip) u[ip] = __builtin_elementwise_fma(ds[ip][g], f32x2{wv[g], wv[g]}, u[ip]);
+        f32x2 pj = f32x2{0.f, 0.f};
+        static_for<kIC / 2>([&](auto ip_) {
+          constexpr int ip = decltype(ip_)::value;
+          const f32x2 m = f32x2{keep_bit<2 * ip>(u[ip].x, bits), keep_bit<2 * ip + 1>(u[ip].y, bits)};
+          dTi[ip] += m;
+          pj += m;
         });
-        dT_s[j * nt + tid] -= pj;
+        dT_s[j * nt + tid] = dtj - (pj.x + pj.y);
+      };
+      float wa[G], wb[G], wc[G];
+      load_w(wa, 0);
+      load_w(wb, 1);
+      load_w(wc, 2);
+      for (int j = 0; j < N; j += 3) {
+        one_j(j, wa);
+        load_w(wa, j + 3);
+        if (j + 1 < N) one_j(j + 1, wb);
+        load_w(wb, j + 4);
+        if (j + 2 < N) one_j(j + 2, wc);
+        load_w(wc, j + 5);
       }
 #pragma unroll
-      for (int ic = 0; ic < kIC; ++ic)
-        if (i0 + ic < N) dT_s[(i0 + ic) * nt + tid] += dTi[ic];
+      for (int ip = 0; ip < kIC / 2; ++ip) {
+        if (i0 + 2 * ip < N) dT_s[(i0 + 2 * ip) * nt + tid] += dTi[ip].x;
+        if (i0 + 2 * ip + 1 < N) dT_s[(i0 + 2 * ip + 1) * nt + tid] += dTi[ip].y;
+      }
     }
     const float qd = ql[(size_t)b * L + d] * dc.scale;      // (the kept values' factor 2 rides on q here)
     float dq = 0.f;
@@ -875,7 +904,7 @@ static int launch_bwd(const float* vl, const float* ql, const float* w, const fl
                       float* d_w, float* d_bias, float* slab, DropCfg dc, int B, int N, int L, hipStream_t s) {
   const int nt = oda_threads(L);
   {
-    const size_t lds = ((size_t)N * nt + (size_t)N * G) * sizeof(float);
+    const size_t lds = ((size_t)N * nt + (size_t)(N + kIC) * G) * sizeof(float);   // (+ kIC zero rows of dS, bit-mask kernel)
     VQA_REQUIRE(lds <= 160 * 1024, VQA_E_UNSUPPORTED, "object_difference_attention_bwd: N=%d L=%d need %zu B of LDS", N, L, lds);
     if (oda_bits_mode(dc, B, N, L)) {
       VQA_ENSURE_LDS((oda_bwd_data_bits_kernel<G>), lds);
