@@ -706,3 +706,24 @@ def test_two_half_backward_oda(graph):
         assert abs(l0 - l1) <= 1e-4 * abs(l0) and abs(n0 - n1) <= 1e-4 * max(abs(n0), 1e-6), (out[False][0], out["force"][0])
     for p0, p1 in zip(out[False][1], out["force"][1]):
         assert (p0 - p1).abs().max().item() <= 2e-3 * max(p0.abs().max().item(), 1e-3)
+
+
+def test_trainer_switches_the_tuned_gemm_table_on():
+    """DataParallelTrainer turns TunableOp on in look-up mode (no tuning at run time) and the shipped table is accepted by
+    this box's libraries (its validator rows match), so the [B,*] layers of the BASELINE batch get their recorded solutions."""
+    import torch.cuda.tunable as tn
+    from vqa_playground_pytorch_amd import tuned_gemms
+    from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
+    DataParallelTrainer(build("oda", 50).train(), lr=1e-4)
+    assert tuned_gemms.enable() in ("1", "tune", "user")
+    if tuned_gemms.enable() == "1":
+        assert tn.is_enabled() and not tn.tuning_is_enabled()
+        x = torch.randn(512, 510, device=dev())
+        w = torch.randn(2000, 510, device=dev())
+        b = torch.randn(2000, device=dev())
+        torch.nn.functional.linear(x, w, b)                   # (TunableOp reads its table at the first GEMM)
+        rows = [line.strip().split(",") for line in open(tuned_gemms.TABLE) if line.strip()]
+        mine = {r[1]: r[2] for r in rows if r[0] == "Validator"}
+        theirs = {k: v for k, v in tn.get_validators()}
+        assert all(theirs.get(k) == v for k, v in mine.items()), (mine, theirs)
+        assert len(tn.get_results()) >= 50

@@ -145,3 +145,18 @@ def test_my_linears_cpu_path_and_stack_groups():
             assert len(group) >= 2 and all(p.shape == group[0].shape for p in group)
             assert not (seen & {id(p) for p in group})
             seen |= {id(p) for p in group}
+
+
+def test_tuned_gemm_table_is_well_formed():
+    """The shipped TunableOp table (tuned_gemms.py): validator rows for gfx950 + one row per GEMM shape, the classifier and the
+    question projections of the BASELINE batch among them."""
+    from vqa_playground_pytorch_amd import tuned_gemms
+    rows = [line.rstrip("\n").split(",") for line in open(tuned_gemms.TABLE) if line.strip()]
+    validators = {r[1]: r[2] for r in rows if r[0] == "Validator"}
+    assert validators["GCN_ARCH_NAME"].startswith("gfx950") and "ROCBLAS_VERSION" in validators and "HIPBLASLT_VERSION" in validators
+    shapes = [r for r in rows if r[0] != "Validator"]
+    assert len(shapes) >= 50 and all(len(r) == 4 and float(r[3]) > 0 for r in shapes)
+    assert len({(r[0], r[1]) for r in shapes}) == len(shapes)                      # one solution per (op, shape)
+    keys = {r[1] for r in shapes}
+    assert "tn_2000_512_510_ld_510_510_2000" in keys                              # CoR2 classifier forward at B = 512
+    assert any(k.startswith("tn_310_512_2400_B_4") for k in keys)                  # the four question projections, batched

@@ -222,6 +222,10 @@ class DataParallelTrainer:
         self.betas, self.eps = (0.9, 0.999), 1e-8           # torch.optim.Adam defaults (train.py:290)
         first = next(p for p in model.parameters() if p.requires_grad)
         self.hip = first.is_cuda                              # GPU: fused HIP tail; CPU (gloo tests): torch ops
+        if self.hip:
+            # the [B,*]-sized layers stay on library GEMMs: look their shapes up in the shipped solution table (tuned_gemms.py)
+            from . import tuned_gemms
+            tuned_gemms.enable()
         # graph=True: after a few eager steps the step is captured into two hipGraphs (forward+loss+backward+gather,
         # and clip+Adam) with the all-reduce launched eagerly between them; replays cost ~3 host launches instead of
         # ~600.  Falls back to eager if a forward draws a host-side dropout seed (fused K2/K5 masks).

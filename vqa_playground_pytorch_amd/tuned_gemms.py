@@ -1,0 +1,46 @@
+"""Library-GEMM solution table for the ``[B,*]``-sized layers.
+
+The question-side projections, the per-glimpse linears, Mutan's question-side ranks and the classifier are plain fp32
+GEMMs of 0.3-3 GFLOP that stay on rocBLAS / hipBLASLt (a hand-written family for them lost to the library).
+The library's default heuristic picks poor tilings for several of these shapes (0.13-0.44 of peak); PyTorch's TunableOp
+can time every rocBLAS / hipBLASLt solution for a shape once and remember the winner.  ``tuned_gemms_gfx950.csv`` is that
+table for the BASELINE shapes (CoR2 / ODA at 512 per rank, the 100-region / 128-per-rank variant, the question encoder),
+recorded on an MI355X with this image's libraries by ``tools/tune_library_gemms.sh``; the file carries the library versions
+it is valid for and is ignored when they differ.
+
+    VQA_TUNED_GEMMS=1 (default)  look shapes up in the shipped table, no tuning at run time (unknown shapes: library default)
+    VQA_TUNED_GEMMS=tune         also tune unknown shapes on first use and append them to VQA_TUNED_GEMMS_FILE
+    VQA_TUNED_GEMMS=0            leave the library's own heuristic alone
+A PYTORCH_TUNABLEOP_ENABLED already set in the environment wins: the user is driving TunableOp themselves.
+"""
+import os
+
+import torch
+
+TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gemms_gfx950.csv")
+_state = {"done": False, "mode": None}
+
+
+def enable():
+    """Idempotent; called by the trainer.  -> the mode in effect ('0', '1', 'tune' or 'user')."""
+    if _state["done"]:
+        return _state["mode"]
+    _state["done"] = True
+    mode = os.environ.get("VQA_TUNED_GEMMS", "1")
+    if "PYTORCH_TUNABLEOP_ENABLED" in os.environ:
+        mode = "user"
+    elif mode not in ("0", "1", "tune"):
+        raise ValueError("VQA_TUNED_GEMMS must be 0, 1 or tune, got %r" % (mode,))
+    if mode in ("1", "tune") and torch.cuda.is_available():
+        import torch.cuda.tunable as tn
+        tn.enable(True)
+        tn.tuning_enable(mode == "tune")
+        if mode == "tune":
+            tn.set_filename(os.environ.get("VQA_TUNED_GEMMS_FILE", TABLE), insert_device_ordinal=False)
+        if os.path.exists(TABLE):
+            try:
+                tn.read_file(TABLE)      # (validators differ -> the table is ignored, with TunableOp's own warning)
+            except RuntimeError:
+                pass
+    _state["mode"] = mode
+    return mode
