@@ -33,12 +33,16 @@ ATOL = 1e-7  # gradients that are mathematically zero (the region-side Mutan bia
 #              noise on both sides; every other gradient here is O(1e-4..1), so 1e-7 absolute is fp32 noise
 
 
-def grad_err(got, want):
-    """max |got-want| measured against RTOL*scale + ATOL; <= 1 passes."""
+def grad_err(got, want, atol=ATOL):
+    """max |got-want| measured against RTOL*scale + atol; <= 1 passes."""
     got = got.detach().cpu().numpy().astype(np.float64) if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
     want = np.asarray(want, np.float64)
     assert got.shape == want.shape and np.isfinite(got).all()
-    return np.abs(got - want).max() / (RTOL * np.abs(want).max() + ATOL)
+    return np.abs(got - want).max() / (RTOL * np.abs(want).max() + atol)
+
+
+ATOL_512 = 2e-6  # the same mathematically-zero gradients summed over 512 x 36 rows (with the dropout factor 2): float32 noise of
+#                  a few 1e-7; every other gradient of these models is O(1e-3..1) at its maximum
 
 
 def check_grads(model, gold):
@@ -184,7 +188,125 @@ def test_baseline_batch_against_oracle(cls, nans):
     assert int(keep.sum()) >= B // 8, int(keep.sum())     # (CoR2 keeps ~230, ODA ~400)
     RF.kld_sum_loss(got[keep.to(dev())], torch.from_numpy(a)[keep].to(dev())).backward()
     for (n, p), (_, p64) in zip(model.named_parameters(), o64.named_parameters()):
-        assert grad_err(p.grad, p64.grad.numpy()) <= 1.0, (n, int(keep.sum()))
+        assert grad_err(p.grad, p64.grad.numpy(), ATOL_512) <= 1.0, (n, int(keep.sum()))
+
+
+def test_training_step_with_shared_masks_against_oracle():
+    """The configuration the benchmark times -- CoR2, 512 x 36 x 2048, TRAINING mode, dropout 0.5 at all fifteen sites --
+    against the float64 restatement of the reference fed the SAME masks.  Every mask of the HIP path is a pure function of
+    (seed, element index) (`vqa_linear_dropout_mask` writes it for any [M,K] site), so the seeds the forward drew are
+    enough to rebuild them: the restatement's own F.dropout is switched off and each Drop* layer's input is multiplied by the
+    mask of the corresponding site instead.  Checks the wiring the per-kernel masked tests cannot: one seed per site, the
+    site-to-mask layouts (four question projections sharing one draw, the gates' [2,B,310] draw, the pooled glimpses masked
+    inside K3 / inside the relation map), backward regenerating the forward's masks.  Knife-edge relu samples are left out of
+    the loss as in test_baseline_batch_against_oracle."""
+    from vqa_playground_pytorch_amd import ops
+    B, N, nans, EPS = 512, 36, 2000, 3e-5
+    model = build("cor2", nans).train()
+    v, q, a = seeded.seeded_inputs(B, answers=nans, seed=513)
+    seeds, rec, orig = [], [], {}
+    for name in ("next_dropout_seed", "dropout", "linear_act", "attention_logits", "softmax_attention_pool_drop",
+                 "relation_projection", "relation_apply"):
+        orig[name] = getattr(ops, name)
+
+    def next_seed():
+        seeds.append(orig["next_dropout_seed"]())
+        return seeds[-1]
+
+    def spy_dropout(x, p_drop, groups=0):
+        n0 = len(seeds)
+        out = orig["dropout"](x, p_drop, groups)
+        if len(seeds) > n0:
+            rec.append(("dropout", ops.DropoutGroups.apply(torch.ones_like(x.contiguous()), p_drop, seeds[-1], groups)))
+        return out
+
+    def flat_mask(kind, like, p_drop, seed):
+        if p_drop:
+            K = like.shape[-1]
+            rec.append((kind, ops.linear_dropout_mask(like.numel() // K, K, p_drop, seed, like.device).view(like.shape)))
+
+    def spy_linear_act(x, w, bias=None, act=None, p_drop=0.0, seed=0, pregated=False):
+        flat_mask("linear_act", x, p_drop, seed)
+        return orig["linear_act"](x, w, bias, act, p_drop, seed, pregated)
+
+    def spy_attention_logits(x, w, bias, p_drop=0.0, seed=0):
+        flat_mask("attention_logits", x, p_drop, seed)
+        return orig["attention_logits"](x, w, bias, p_drop, seed)
+
+    def spy_pool_drop(logits, inputs, p_drop, seed, *rest):
+        flat_mask("pool_drop", torch.empty(inputs.shape[0], logits.shape[2], inputs.shape[2], device=inputs.device), p_drop, seed)
+        return orig["softmax_attention_pool_drop"](logits, inputs, p_drop, seed, *rest)
+
+    def spy_relation_projection(vv, t, c2, w, bias, p_drop=0.0, seed=0, *rest):
+        flat_mask("relation_projection", vv, p_drop, seed)
+        return orig["relation_projection"](vv, t, c2, w, bias, p_drop, seed, *rest)
+
+    def spy_relation_apply(x, t, c2, p_drop=0.0, seed=0):
+        flat_mask("relation_apply", x, p_drop, seed)
+        return orig["relation_apply"](x, t, c2, p_drop, seed)
+
+    spies = {"next_dropout_seed": next_seed, "dropout": spy_dropout, "linear_act": spy_linear_act,
+             "attention_logits": spy_attention_logits, "softmax_attention_pool_drop": spy_pool_drop,
+             "relation_projection": spy_relation_projection, "relation_apply": spy_relation_apply}
+    for name, f in spies.items():
+        setattr(ops, name, f)
+    try:
+        torch.manual_seed(5)
+        got = model({"v": torch.from_numpy(v).to(dev()), "q_idxes": torch.from_numpy(q).to(dev())})
+    finally:
+        for name, f in orig.items():
+            setattr(ops, name, f)
+    assert [k for k, _ in rec] == ["dropout", "dropout", "linear_act", "attention_logits", "pool_drop", "relation_projection",
+                                   "attention_logits", "relation_apply", "dropout"], [k for k, _ in rec]
+    assert len(set(seeds)) == len(seeds) == 9
+    m = [t.cpu() for _, t in rec]
+    assert m[0].shape == (4, B, 2400) and m[1].shape == (2, B, 310) and m[4].shape == (B, 4, 2048) and m[7].shape == (B, 4, 2048)
+    for t in m:
+        assert set(torch.unique(t).tolist()) == {0.0, 2.0} and abs(float(t.mean()) - 1.0) < 0.01
+    masks = {"compress_q": m[0][0], "linear_q": m[0][1], "compress_q_1": m[0][2], "compress_q_2": m[0][3],
+             "expand_q_1": m[1][0], "expand_q_2": m[1][1], "compress_v": m[2], "att1.conv_att": m[3], "compress_v2": m[5],
+             "att2.conv_att": m[6], "linear_classif": m[8]}
+    for g in range(4):
+        masks["att1.list_linear_v_fusion.%d" % g] = m[4][:, g]
+        masks["att2.list_linear_v_fusion.%d" % g] = m[7][:, g]
+
+    o64 = seeded.load_state(RF.CoR2Oracle(nans), 0).train().double()
+    rng = [0, 0]
+    sites = 0
+    for name, mod in o64.named_modules():
+        if isinstance(mod, (RF.DropLinear, RF.DropConv1x1)):
+            assert mod.p == 0.5 and name in masks, name
+            mod.p = None                                    # (its own F.dropout off: the site's input is masked by the hook)
+            mod.register_forward_pre_hook(lambda _m, args, name=name: (args[0] * masks[name][rng[0]:rng[1]].double(),))
+            sites += 1
+    assert sites == len(masks) == 19
+    closest = []
+    activate = RF._activate
+
+    def spy(x, af, dim):
+        if af == "relu":
+            closest.append(x.detach().abs().reshape(x.size(0), -1).amin(1))
+        return activate(x, af, dim)
+
+    RF._activate = spy
+    keep, want = [], []
+    try:
+        for lo in range(0, B, 64):
+            rng[0], rng[1] = lo, lo + 64
+            del closest[:]
+            w64 = o64({"v": torch.from_numpy(v[lo:lo + 64]).double(), "q": torch.from_numpy(q[lo:lo + 64]).double()})
+            k = torch.stack(closest).amin(0) >= EPS
+            RF.kld_sum_loss(w64[k], torch.from_numpy(a[lo:lo + 64]).double()[k]).backward()
+            keep.append(k)
+            want.append(w64.detach())
+    finally:
+        RF._activate = activate
+    keep, want = torch.cat(keep), torch.cat(want)
+    assert rel(got, want.numpy()) <= RTOL
+    assert int(keep.sum()) >= B // 8, int(keep.sum())
+    RF.kld_sum_loss(got[keep.to(dev())], torch.from_numpy(a)[keep].to(dev())).backward()
+    for (n, p), (_, p64) in zip(model.named_parameters(), o64.named_parameters()):
+        assert grad_err(p.grad, p64.grad.numpy(), ATOL_512) <= 1.0, (n, int(keep.sum()))
 
 
 def test_cor2_100_regions_against_oracle():
