@@ -191,22 +191,23 @@ def test_baseline_batch_against_oracle(cls, nans):
         assert grad_err(p.grad, p64.grad.numpy(), ATOL_512) <= 1.0, (n, int(keep.sum()))
 
 
-def test_training_step_with_shared_masks_against_oracle():
-    """The configuration the benchmark times -- CoR2, 512 x 36 x 2048, TRAINING mode, dropout 0.5 at all fifteen sites --
+@pytest.mark.parametrize("cls,nans", [("cor2", 2000), ("oda", 3000)])
+def test_training_step_with_shared_masks_against_oracle(cls, nans):
+    """The configuration the benchmark times -- CoR2 / ODA, 512 x 36 x 2048, TRAINING mode, dropout 0.5 at every site --
     against the float64 restatement of the reference fed the SAME masks.  Every mask of the HIP path is a pure function of
     (seed, element index) (`vqa_linear_dropout_mask` writes it for any [M,K] site), so the seeds the forward drew are
     enough to rebuild them: the restatement's own F.dropout is switched off and each Drop* layer's input is multiplied by the
     mask of the corresponding site instead.  Checks the wiring the per-kernel masked tests cannot: one seed per site, the
     site-to-mask layouts (four question projections sharing one draw, the gates' [2,B,310] draw, the pooled glimpses masked
-    inside K3 / inside the relation map), backward regenerating the forward's masks.  Knife-edge relu samples are left out of
+    inside K3 / inside the relation map, K2's one-bit mask over [B,N,N*L]), backward regenerating the forward's masks.  Knife-edge relu samples are left out of
     the loss as in test_baseline_batch_against_oracle."""
     from vqa_playground_pytorch_amd import ops
-    B, N, nans, EPS = 512, 36, 2000, 3e-5
-    model = build("cor2", nans).train()
+    B, N, EPS = 512, 36, 3e-5
+    model = build(cls, nans).train()
     v, q, a = seeded.seeded_inputs(B, answers=nans, seed=513)
     seeds, rec, orig = [], [], {}
     for name in ("next_dropout_seed", "dropout", "linear_act", "attention_logits", "softmax_attention_pool_drop",
-                 "relation_projection", "relation_apply"):
+                 "relation_projection", "relation_apply", "object_difference_attention"):
         orig[name] = getattr(ops, name)
 
     def next_seed():
@@ -245,7 +246,12 @@ def test_training_step_with_shared_masks_against_oracle():
         flat_mask("relation_apply", x, p_drop, seed)
         return orig["relation_apply"](x, t, c2, p_drop, seed)
 
-    spies = {"next_dropout_seed": next_seed, "dropout": spy_dropout, "linear_act": spy_linear_act,
+    def spy_k2(vl, ql, w, bias, p_drop=0.0, seed=0):
+        if p_drop:
+            rec.append(("k2", ops.object_difference_dropout_mask(vl.shape[0], vl.shape[1], vl.shape[2], p_drop, seed, vl.device)))
+        return orig["object_difference_attention"](vl, ql, w, bias, p_drop, seed)
+
+    spies = {"next_dropout_seed": next_seed, "object_difference_attention": spy_k2, "dropout": spy_dropout, "linear_act": spy_linear_act,
              "attention_logits": spy_attention_logits, "softmax_attention_pool_drop": spy_pool_drop,
              "relation_projection": spy_relation_projection, "relation_apply": spy_relation_apply}
     for name, f in spies.items():
@@ -256,21 +262,29 @@ def test_training_step_with_shared_masks_against_oracle():
     finally:
         for name, f in orig.items():
             setattr(ops, name, f)
-    assert [k for k, _ in rec] == ["dropout", "dropout", "linear_act", "attention_logits", "pool_drop", "relation_projection",
-                                   "attention_logits", "relation_apply", "dropout"], [k for k, _ in rec]
-    assert len(set(seeds)) == len(seeds) == 9
+    kinds = [k for k, _ in rec]
     m = [t.cpu() for _, t in rec]
-    assert m[0].shape == (4, B, 2400) and m[1].shape == (2, B, 310) and m[4].shape == (B, 4, 2048) and m[7].shape == (B, 4, 2048)
+    assert len(set(seeds)) == len(seeds) == len(rec)
     for t in m:
         assert set(torch.unique(t).tolist()) == {0.0, 2.0} and abs(float(t.mean()) - 1.0) < 0.01
-    masks = {"compress_q": m[0][0], "linear_q": m[0][1], "compress_q_1": m[0][2], "compress_q_2": m[0][3],
-             "expand_q_1": m[1][0], "expand_q_2": m[1][1], "compress_v": m[2], "att1.conv_att": m[3], "compress_v2": m[5],
-             "att2.conv_att": m[6], "linear_classif": m[8]}
-    for g in range(4):
-        masks["att1.list_linear_v_fusion.%d" % g] = m[4][:, g]
-        masks["att2.list_linear_v_fusion.%d" % g] = m[7][:, g]
+    if cls == "cor2":
+        assert kinds == ["dropout", "dropout", "linear_act", "attention_logits", "pool_drop", "relation_projection",
+                         "attention_logits", "relation_apply", "dropout"], kinds
+        assert m[0].shape == (4, B, 2400) and m[1].shape == (2, B, 310) and m[4].shape == (B, 4, 2048) and m[7].shape == (B, 4, 2048)
+        masks = {"compress_q": m[0][0], "linear_q": m[0][1], "compress_q_1": m[0][2], "compress_q_2": m[0][3],
+                 "expand_q_1": m[1][0], "expand_q_2": m[1][1], "compress_v": m[2], "att1.conv_att": m[3], "compress_v2": m[5],
+                 "att2.conv_att": m[6], "linear_classif": m[8]}
+        for g in range(4):
+            masks["att1.list_linear_v_fusion.%d" % g] = m[4][:, g]
+            masks["att2.list_linear_v_fusion.%d" % g] = m[7][:, g]
+    else:
+        assert kinds == ["linear_act", "dropout", "k2", "pool_drop", "dropout"], kinds
+        assert m[1].shape == (2, B, 2400) and m[2].shape == (B, N, N * 310) and m[3].shape == (B, 4, 2048)
+        masks = {"compress_v": m[0], "compress_q": m[1][0], "linear_q": m[1][1], "att.conv_att": m[2], "linear_classif": m[4]}
+        for g in range(4):
+            masks["att.list_linear_v_fusion.%d" % g] = m[3][:, g]
 
-    o64 = seeded.load_state(RF.CoR2Oracle(nans), 0).train().double()
+    o64 = seeded.load_state({"cor2": RF.CoR2Oracle, "oda": RF.ODAOracle}[cls](nans), 0).train().double()
     rng = [0, 0]
     sites = 0
     for name, mod in o64.named_modules():
@@ -279,7 +293,7 @@ def test_training_step_with_shared_masks_against_oracle():
             mod.p = None                                    # (its own F.dropout off: the site's input is masked by the hook)
             mod.register_forward_pre_hook(lambda _m, args, name=name: (args[0] * masks[name][rng[0]:rng[1]].double(),))
             sites += 1
-    assert sites == len(masks) == 19
+    assert sites == len(masks) == {"cor2": 19, "oda": 9}[cls]
     closest = []
     activate = RF._activate
 
