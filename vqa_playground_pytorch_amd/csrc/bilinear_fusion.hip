@@ -438,9 +438,9 @@ __global__ __launch_bounds__(kGemmThreads) void bilinear_dw_dh2_kernel(
 }
 
 // dh2[e] = sum_p part[p][e]   (e over B*R*H, float2 lanes; fixed order)
-__global__ __launch_bounds__(256) void bilinear_dh2_reduce_kernel(const float* __restrict__ part, float* __restrict__ dh2,
-                                                                  size_t n, int parts) {
-  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+__device__ __forceinline__ void dh2_reduce_block(const float* __restrict__ part, float* __restrict__ dh2, size_t n, int parts,
+                                                 unsigned block) {
+  const size_t e = ((size_t)block * 256 + threadIdx.x) * 2;
   if (e >= n) return;
   float2 a = make_float2(0.f, 0.f);
   for (int p = 0; p < parts; ++p) {
@@ -452,11 +452,9 @@ __global__ __launch_bounds__(256) void bilinear_dh2_reduce_kernel(const float* _
 }
 
 // d_w1[r][h][l] = sum_s slab[s][r][h][l]   (fixed order: bitwise reproducible)
-__global__ __launch_bounds__(256) void bilinear_dw_reduce_kernel(const float* __restrict__ slab,
-                                                                 const float* __restrict__ dbslab, RankOutPtrs out,
-                                                                 int HL, int H, int R, int S) {
-  const int r = blockIdx.y;
-  const int e = (blockIdx.x * 256 + threadIdx.x) * 2;
+__device__ __forceinline__ void dw_reduce_block(const float* __restrict__ slab, const float* __restrict__ dbslab,
+                                                const RankOutPtrs& out, int HL, int H, int R, int S, int r, int block) {
+  const int e = (block * 256 + threadIdx.x) * 2;
   if (e < H) {  // bias gradient: the first H/2 lanes also fold the db partials (same fixed order)
     float2 a = make_float2(0.f, 0.f);
     for (int s = 0; s < S; ++s) {
@@ -474,6 +472,29 @@ __global__ __launch_bounds__(256) void bilinear_dw_reduce_kernel(const float* __
     a.y += t.y;
   }
   st2(out.w[r] + e, a);
+}
+
+__global__ __launch_bounds__(256) void bilinear_dh2_reduce_kernel(const float* __restrict__ part, float* __restrict__ dh2,
+                                                                  size_t n, int parts) {
+  dh2_reduce_block(part, dh2, n, parts, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void bilinear_dw_reduce_kernel(const float* __restrict__ slab,
+                                                                 const float* __restrict__ dbslab, RankOutPtrs out,
+                                                                 int HL, int H, int R, int S) {
+  dw_reduce_block(slab, dbslab, out, HL, H, R, S, blockIdx.y, blockIdx.x);
+}
+// both fixed-order reductions of the folded backward in ONE launch (they are independent and ~5 us each, i.e. launch-sized):
+// blocks [0, R * nb_dw) take the weight slabs, the rest the dh2 partial sums
+__global__ __launch_bounds__(256) void bilinear_dw_dh2_reduce_kernel(const float* __restrict__ slab,
+                                                                     const float* __restrict__ dbslab, RankOutPtrs out, int HL,
+                                                                     int H, int R, int S, int nb_dw,
+                                                                     const float* __restrict__ part, float* __restrict__ dh2,
+                                                                     size_t n, int parts) {
+  const int id = blockIdx.x;
+  if (id < R * nb_dw)
+    dw_reduce_block(slab, dbslab, out, HL, H, R, S, id / nb_dw, id % nb_dw);
+  else
+    dh2_reduce_block(part, dh2, n, parts, (unsigned)(id - R * nb_dw));
 }
 
 // dh2[b][r][h] = sum_n g[b,n,h] * h1[b,n,r,h].  grid (ceil(H/128), B); 256 lanes = 64 feature pairs x 4 region
@@ -806,10 +827,10 @@ extern "C" int vqa_lowrank_bilinear_fusion_folded_bwd_gated(const float* x, int 
     rc = dw_rt_launch(g, x, h2, w1, b1, slab, dbslab, part, B, N, L, H, R, s);
     if (rc != VQA_OK) return rc;
     const int HL2 = H * L;
-    hipLaunchKernelGGL(bilinear_dw_reduce_kernel, dim3((HL2 / 2 + 255) / 256, R), dim3(256), 0, s, slab, dbslab, ro, HL2, H, R,
-                       kDwRtGroups);
     const size_t n2 = (size_t)B * R * H;
-    hipLaunchKernelGGL(bilinear_dh2_reduce_kernel, dim3((unsigned)((n2 / 2 + 255) / 256)), dim3(256), 0, s, part, d_h2, n2, 2);
+    const int nb_dw = (HL2 / 2 + 255) / 256, nb_dh2 = (int)((n2 / 2 + 255) / 256);
+    hipLaunchKernelGGL(bilinear_dw_dh2_reduce_kernel, dim3(R * nb_dw + nb_dh2), dim3(256), 0, s, slab, dbslab, ro, HL2, H, R,
+                       kDwRtGroups, nb_dw, part, d_h2, n2, 2);
     return check_launch("lowrank_bilinear_fusion_folded_bwd");
   }
   const int S = dw_fold_splits(B, N, H, L, R);
@@ -843,9 +864,9 @@ extern "C" int vqa_lowrank_bilinear_fusion_folded_bwd_gated(const float* x, int 
 #undef LAUNCH_K
   // (3) fixed-order reductions
   const int HL = H * L;
-  hipLaunchKernelGGL(bilinear_dw_reduce_kernel, dim3((HL / 2 + 255) / 256, R), dim3(256), 0, s, slab, dbslab, ro, HL, H, R, S);
   const size_t n = (size_t)B * R * H;
-  hipLaunchKernelGGL(bilinear_dh2_reduce_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, s, part, d_h2, n,
-                     2 * tiles_n);
+  const int nb_dw = (HL / 2 + 255) / 256, nb_dh2 = (int)((n / 2 + 255) / 256);
+  hipLaunchKernelGGL(bilinear_dw_dh2_reduce_kernel, dim3(R * nb_dw + nb_dh2), dim3(256), 0, s, slab, dbslab, ro, HL, H, R, S, nb_dw,
+                     part, d_h2, n, 2 * tiles_n);
   return check_launch("lowrank_bilinear_fusion_folded_bwd");
 }
