@@ -41,7 +41,7 @@ constexpr int kRB = 9, kSamples = 4, kBM = 16 * kRB;
 constexpr int kVAux = 2;   // cache policy of the v stream: nt (read once: keep it from displacing W and gz in L2)
 
 template <int TUNE>
-__global__ __launch_bounds__(rt::kThreads, 1) void relation_dgrad_kernel(RelDgradArgs p, DropCfg dc) {
+__global__ __launch_bounds__(rt::kThreads, (TUNE & 4) ? 2 : 1) void relation_dgrad_kernel(RelDgradArgs p, DropCfg dc) {
   using rt::f32x4;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -112,8 +112,63 @@ __global__ __launch_bounds__(rt::kThreads, 1) void relation_dgrad_kernel(RelDgra
   };
 
   const int nfull = L >> 4;                  // whole 16-deep chunks
-  const int c_pairs = nfull & ~1;
-  {
+  const int c_pairs = (TUNE & 4) ? 0 : (nfull & ~1);
+  if constexpr ((TUNE & 4) != 0) {
+    // two workgroups per CU (<= 256 registers), no v tile in LDS (v is read in the epilogue, under the other wave's main loop).
+    // One fragment set, refilled in halves: the A fragments of row blocks 5..8 land under the MFMAs of row blocks 0..4 and
+    // the next chunk's B and A 0..4 under those of 5..8; what latency is left is covered by the SIMD's other wave.
+    constexpr int kLo = 5, kHi = kRB - kLo;
+    f32x4 lo[kLo], hi[kHi], b0[4], b1[4];
+    auto load_b = [&](f32x4 (&b)[4], int c) {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) b[kb] = rt::ldg16(Bb, offB, (uint32_t)(16 * c + kb) * (uint32_t)D * 4u);
+    };
+    auto load_lo = [&](int c) {
+#pragma unroll
+      for (int i = 0; i < kLo; ++i) lo[i] = rt::ldg16(Ab, offA[i], (uint32_t)c * 64u);
+    };
+    auto load_hi = [&](int c) {
+#pragma unroll
+      for (int i = 0; i < kHi; ++i) hi[i] = rt::ldg16(Ab, offA[kLo + i], (uint32_t)c * 64u);
+    };
+    auto mf_lo = [&](const f32x4 (&b)[4]) {
+#pragma unroll
+      for (int i = 0; i < kLo; ++i)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(lo[i][kb], b[kb][e], acc[i][e], 0, 0, 0);
+    };
+    auto mf_hi = [&](const f32x4 (&b)[4]) {
+#pragma unroll
+      for (int i = 0; i < kHi; ++i)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[kLo + i][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(hi[i][kb], b[kb][e], acc[kLo + i][e], 0, 0, 0);
+    };
+    auto half = [&](const f32x4 (&b)[4], f32x4 (&bn)[4], int c) {
+      load_hi(c);
+      __builtin_amdgcn_sched_barrier(0);
+      mf_lo(b);
+      __builtin_amdgcn_sched_barrier(0);
+      const int cn = min(c + 1, nfull - 1);          // (last chunk: a harmless reload)
+      load_b(bn, cn);
+      load_lo(cn);
+      __builtin_amdgcn_sched_barrier(0);
+      mf_hi(b);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (nfull > 0) {
+      load_b(b0, 0);
+      load_lo(0);
+      for (int c = 0; c < nfull; c += 2) {
+        half(b0, b1, c);
+        if (c + 1 < nfull) half(b1, b0, c + 1);
+      }
+    }
+  } else {
     Frag f0, f1;
     int vidx = 0;
     if (c_pairs > 0) {
@@ -156,6 +211,10 @@ __global__ __launch_bounds__(rt::kThreads, 1) void relation_dgrad_kernel(RelDgra
   __builtin_amdgcn_s_waitcnt(0);             // the LDS-bound loads of the v tile have landed (nobody else reads these slots)
   auto vt = [&](int i, int t) -> f32x4 {
     if constexpr ((TUNE & 1) != 0) return f32x4{1.f, 1.f, 1.f, 1.f};
+    if constexpr ((TUNE & 4) != 0) {
+      const int row = min(m0 + 16 * i + 4 * g + t, M - 1);
+      return rt::ldg16(Vb, (uint32_t)(n0 + 4 * r) * 4u + (uint32_t)row * (uint32_t)D * 4u, 0u);
+    }
     return *reinterpret_cast<const f32x4*>(vslots + (4 * i + t) * 1024 + lane * 16);
   };
   if constexpr ((TUNE & 2) != 0) {   // (experiment: no epilogue math)
@@ -282,7 +341,9 @@ extern "C" int vqa_relation_projection_dgrad(const float* gz, const float* w, co
   a.tiles_n = (D + 255) / 256;
   const int tiles_m = (a.M + kBM - 1) / kBM;
   const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
-  const int tune = std::getenv("VQA_RELDG_TUNE") ? std::atoi(std::getenv("VQA_RELDG_TUNE")) : 0;   // (experiments)
+  // 4 (default): two workgroups per CU, fragments refilled in halves, v read in the epilogue; 0: one workgroup per CU, double-
+  // buffered fragments, v streamed into LDS (the first form: 230 us against 199 at B = 512); 1..3: ablations of the latter
+  const int tune = std::getenv("VQA_RELDG_TUNE") ? std::atoi(std::getenv("VQA_RELDG_TUNE")) : 4;
   const dim3 grid((unsigned)(tiles_m * a.tiles_n));
   hipStream_t s = static_cast<hipStream_t>(stream);
   constexpr size_t lds = (size_t)4 * 4 * kRB * 1024;      // 4 waves x 36 slots of 1 KB
@@ -294,6 +355,7 @@ extern "C" int vqa_relation_projection_dgrad(const float* gz, const float* w, co
   if (tune == 1) VQA_RD_LAUNCH(1)
   else if (tune == 2) VQA_RD_LAUNCH(2)
   else if (tune == 3) VQA_RD_LAUNCH(3)
+  else if (tune == 4) hipLaunchKernelGGL(relation_dgrad_kernel<4>, grid, dim3(rt::kThreads), 0, s, a, dc);
   else VQA_RD_LAUNCH(0)
 #undef VQA_RD_LAUNCH
   return check_launch("relation_projection_dgrad");
