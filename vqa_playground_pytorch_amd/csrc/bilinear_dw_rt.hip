@@ -34,6 +34,10 @@
 // per rank), prologue 3.6 us (the W tile comes through buffer loads with an out-of-range offset for the padding: a
 // conditional load per element serialised 22 memory latencies, 7.6 us), 85 us per launch at the ~1.8-1.95 GHz the part
 // sustains under this load.
+// (Tried: four sample slices per workgroup = two waves per SIMD, 3-step ring to stay within 256 registers -- 81 us, no change.
+//  The waves are not waiting for latency: every one of the 32 feature blocks streams all of x through its CU, 0.73 GB of
+//  L2 -> register traffic per launch, ~9.6 TB/s at 80 us.  More reuse per workgroup -- 32 features, i.e. twice the
+//  accumulators -- is what would move it, not occupancy.)
 #include <cstdlib>
 
 #include "bilinear_folded.hpp"
