@@ -14,11 +14,21 @@
 // Register-tile engine, NN form: A = gz, K-contiguous (one 16-byte load per row block and 16-deep chunk, component kb =
 // contraction step kb); B = W, contraction index = row: lane (r, g) loads W[16 c + 4 g + kb][n0 + 4 r .. + 3] as one
 // 16-byte load per step, component e feeds accumulator block e (the column permutation of gemm_tn_kernel).  A wave owns
-// 144 rows x 64 columns (36 blocks, 144 accumulator registers), a workgroup 144 x 256; no barrier.  The wave's tile of v
-// (36 loads of 1 KB) is streamed into LDS by buffer_load ... lds (no registers, no wait before the epilogue), two loads
-// per chunk of the main loop: requested in one burst at the top of the tile they cost 36 us (every wave of the chip
-// asking HBM for 36 KB at once, the first MFMA behind it: memory operations retire in order), and kept in registers a
-// runtime row-block index cannot address them.  One wave per SIMD.
+// 144 rows x 64 columns (36 blocks, 144 accumulator registers), a workgroup 144 x 256; no barrier.
+//
+// Two forms of the main loop (VQA_RELDG_TUNE selects; template parameter TUNE):
+//  * TUNE = 4, the default -- TWO workgroups per CU.  A third of this kernel is not matrix work (per tile: a prologue of
+//    two memory latencies, and the epilogue's mask + multiply by v + per-sample sums), and with one wave per SIMD the
+//    matrix pipe idles through all of it (72 % busy).  Within 256 registers (236 used: the 144 accumulators, ONE fragment
+//    set, addresses) a wave refills its fragments in halves -- the A fragments of row blocks 5..8 land under the MFMAs of
+//    blocks 0..4, the next chunk's B and A 0..4 under those of 5..8 -- and reads its tile of v straight from memory in
+//    the epilogue; whatever latency that leaves is covered by the SIMD's other wave, whose main loop also runs under this
+//    wave's epilogue.  199 us against 230 at B = 512.
+//  * TUNE = 0 -- one workgroup per CU, double-buffered fragment sets (340 registers), the wave's tile of v (36 loads of
+//    1 KB) streamed into LDS by buffer_load ... lds (no registers, no wait before the epilogue), two loads per chunk of the
+//    main loop: requested in one burst at the top of the tile they cost 36 us (every wave of the chip asking HBM for 36 KB
+//    at once, the first MFMA behind it: memory operations retire in order), and kept in registers a runtime row-block
+//    index cannot address them.  TUNE = 1..3 are ablations of this form.
 #include <cstdlib>
 
 #include "gemm_f32_rt.hpp"
