@@ -553,11 +553,7 @@ def main():
                        "launch": ("hipGraph replay (3 graphs: backward in two halves, the first all-reduce under the second)"
                                   if trainer.overlap else "hipGraph replay (2 graphs + eager all-reduce)") if graphed else "eager",
                        "relation_mode": "factored" if args.relation_mode == 1 else "pairwise",
-                       "library_gemms": {"1": "rocBLAS / hipBLASLt solutions from the recorded TunableOp table "
-                                              "(vqa_playground_pytorch_amd/tuned_gemms_gfx950.csv), no tuning at run time",
-                                         "tune": "TunableOp, tuning unknown shapes in the warm-up steps",
-                                         "0": "library default heuristic", "user": "TunableOp as set in the environment"}[
-                           __import__("vqa_playground_pytorch_amd.tuned_gemms", fromlist=["enable"]).enable()],
+                       "library_gemms": __import__("vqa_playground_pytorch_amd.tuned_gemms", fromlist=["describe"]).describe(),
                        "inputs": "ONE resident batch (%.0f MB of regions) re-read every step: it fits the 256 MB Infinity "
                                  "Cache, so the HBM-bound kernels' GB/s are upper bounds; `rotating_inputs` times the same "
                                  "steps over %d different resident batches" % (v.numel() * v.element_size() / 1e6, ROTATE)},

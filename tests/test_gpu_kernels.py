@@ -190,11 +190,11 @@ def test_softmax_attention_pool_with_glimpse_dropout(ops, B, N, D, G, want_first
 @pytest.mark.parametrize("p_drop", [0.0, 0.5])
 @pytest.mark.parametrize("B,N,D,G,with_ext,need_dv", [(3, 36, 2048, 4, True, False), (2, 7, 1028, 2, False, True),
                                                       (4, 100, 2048, 4, True, True), (2, 36, 1540, 8, False, False)])
-def test_softmax_attention_pool_backward_single_launch(ops, monkeypatch, B, N, D, G, with_ext, need_dv, p_drop):
+def test_softmax_attention_pool_backward_single_launch(ops, lib_option, B, N, D, G, with_ext, need_dv, p_drop):
     """The one-launch backward (a workgroup owns a sample: dot products, d_v and the softmax backward together; taken from
     B = 512 on, here forced for small batches) against the oracle, with the gradient on alpha, d_v, glimpse dropout and
     the gradient of the undropped glimpse 0."""
-    monkeypatch.setenv("VQA_K3_FUSED_MIN_B", "1")
+    lib_option("VQA_K3_FUSED_MIN_B", 1)
     logits = 2.0 * seeded.seeded_array((B, N, G), 241)
     v = seeded.seeded_array((B, N, D), 242)
     gp = seeded.seeded_array((B, G, D), 243)
@@ -322,8 +322,8 @@ def test_lowrank_bilinear_fusion_2d(ops, B, L, H, R):
 
 
 @pytest.mark.parametrize("tile", ["128x128", "64x128", "128x64", "64x64"])
-def test_lowrank_bilinear_fusion_every_tile_shape(ops, tile, monkeypatch):
-    monkeypatch.setenv("VQA_GEMM_TILE", tile)
+def test_lowrank_bilinear_fusion_every_tile_shape(ops, tile, monkeypatch, lib_option):
+    lib_option("VQA_GEMM_TILE", tile)
     monkeypatch.setattr(ops, "_K4_FORM", "engine")
     _fusion_case(ops, 6, 36, 310, 510, 2, 340)
     _fusion_case(ops, 3, 50, 70, 130, 2, 350, need_dx=False)
@@ -850,13 +850,13 @@ def test_relation_apply(ops, B, N, D, p, dtype):
 @pytest.mark.parametrize("form", ["two workgroups per CU", "one workgroup per CU"])
 @pytest.mark.parametrize("p", [0.0, 0.5, 0.25])
 @pytest.mark.parametrize("B,D,L", [(4, 2048, 310), (5, 256, 310), (33, 128, 34), (1, 64, 32), (8, 320, 48)])
-def test_relation_projection_fused_backward(ops, B, D, L, p, form, monkeypatch):
+def test_relation_projection_fused_backward(ops, B, D, L, p, form, lib_option):
     """relation step + second region projection as one node (K1 -> K5): the output equals relation_apply followed by
     linear_act, and d_t / d_c2 / dW / db equal the gradients of that composition (fp64 closed form of the data gradient:
     the masked grad_x summed over the 36 regions) -- without the [B,36,D] data gradient ever being written.  Both forms of
-    the data-gradient kernel (csrc/relation_dgrad.hip: the default, and VQA_RELDG_TUNE=0, read at every launch)."""
+    the data-gradient kernel (csrc/relation_dgrad.hip: the default, and VQA_RELDG_TUNE=0)."""
     if form == "one workgroup per CU":
-        monkeypatch.setenv("VQA_RELDG_TUNE", "0")
+        lib_option("VQA_RELDG_TUNE", 0)
     N = 36
     v = seeded.seeded_array((B, N, D), 411)
     t = seeded.seeded_array((B, D), 412)

@@ -160,3 +160,69 @@ def test_tuned_gemm_table_is_well_formed():
     keys = {r[1] for r in shapes}
     assert "tn_2000_512_510_ld_510_510_2000" in keys                              # CoR2 classifier forward at B = 512
     assert any(k.startswith("tn_310_512_2400_B_4") for k in keys)                  # the four question projections, batched
+
+
+def test_side_outputs_resolve_on_every_way_out():
+    """alpha_dict entries stored as callables (training forwards only) never leak as callables: dict(), ** unpacking, copy,
+    deepcopy and pickling all see the resolved value (cor2.py alpha_dict['feature'])."""
+    import copy
+    import pickle
+    from vqa_playground_pytorch_amd.layers import SideOutputs
+    make = lambda: SideOutputs({"alpha1": (torch.ones(2),), "feature": lambda: torch.zeros(3)})  # noqa: E731
+    assert torch.equal(make()["feature"], torch.zeros(3))
+    assert torch.equal(dict(make())["feature"], torch.zeros(3))
+    assert torch.equal({**make()}["feature"], torch.zeros(3))
+    assert torch.equal(make().copy()["feature"], torch.zeros(3))
+    assert torch.equal(copy.deepcopy(make())["feature"], torch.zeros(3))
+    assert torch.equal(pickle.loads(pickle.dumps(make()))["feature"], torch.zeros(3))
+    assert all(torch.is_tensor(v) or isinstance(v, tuple) for v in make().values())
+    assert all(torch.is_tensor(v) or isinstance(v, tuple) for _, v in make().items())
+
+
+def test_library_options_are_read_once(monkeypatch):
+    """The library's VQA_* knobs come from the environment ONCE (first use) and change afterwards only through
+    vqa_set_option (per-launch getenv let backward diverge from forward)."""
+    import glob
+    from vqa_playground_pytorch_amd import _lib
+    csrc = os.path.join(ROOT, "vqa_playground_pytorch_amd", "csrc")
+    for path in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")):
+        text = open(path).read()
+        if os.path.basename(path) != "api.hip":
+            assert "getenv(" not in text, "%s reads the environment at launch time: use vqa::option()" % path
+    _lib.set_option("VQA_TEST_KNOB", 3)
+    _lib.set_option("VQA_TEST_KNOB", None)
+    with pytest.raises(_lib.VqaLibraryError):
+        _lib.check(_lib.lib().vqa_set_option(b"", b"1"), "set_option")
+
+
+def test_tune_mode_never_targets_the_shipped_table(monkeypatch):
+    from vqa_playground_pytorch_amd import tuned_gemms
+    monkeypatch.setattr(tuned_gemms, "_state", {"done": False, "mode": None, "loaded": None})
+    monkeypatch.setenv("VQA_TUNED_GEMMS", "tune")
+    monkeypatch.delenv("VQA_TUNED_GEMMS_FILE", raising=False)
+    monkeypatch.delenv("PYTORCH_TUNABLEOP_ENABLED", raising=False)
+    with pytest.raises(ValueError, match="VQA_TUNED_GEMMS_FILE"):
+        tuned_gemms.enable()
+
+
+def test_grad_slots_are_keyed_by_the_flat_buffer():
+    """Two registrations live side by side; ending one backward window leaves the other's slots and hand-out list alone, and
+    a parameter is handed its slot once per pass (module-global slot registry)."""
+    from vqa_playground_pytorch_amd import ops
+    p1, g1, p2, g2 = (torch.zeros(16) for _ in range(4))
+    ops.set_grad_slots(p1, g1)
+    ops.set_grad_slots(p2, g2)
+    try:
+        w1, w2 = p1[4:8], p2[8:12]
+        a = ops._grad_like(w1)
+        assert a.data_ptr() == g1[4:8].data_ptr()
+        ops.set_grad_slots(p1, None)                       # trainer 1 leaves its window
+        b = ops._grad_like(w2)
+        assert b.data_ptr() == g2[8:12].data_ptr()         # trainer 2's registration is intact
+        assert ops._grad_like(w2).data_ptr() != b.data_ptr()   # second use in one pass: a fresh tensor
+        assert ops._grad_like(w1).data_ptr() != a.data_ptr()   # dropped registration: fresh tensor
+        ops.begin_backward(p2)
+        assert ops._grad_like(w2).data_ptr() == b.data_ptr()
+    finally:
+        ops.set_grad_slots(p1, None)
+        ops.set_grad_slots(p2, None)

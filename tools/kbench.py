@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-from vqa_playground_pytorch_amd import ops  # noqa: E402
+from vqa_playground_pytorch_amd import _lib, ops  # noqa: E402
 
 B, N, D, L, H, G, R = 512, 36, 2048, 310, 510, 4, 2
 dev = torch.device("cuda:0")
@@ -57,9 +57,9 @@ def bf16_section(rounds):
         b = (torch.randn(n, k, device=dev) / k ** 0.5).to(torch.bfloat16)
         fns = {"torch (hipBLASLt)": lambda: torch.nn.functional.linear(a, b)}
         for t in ("128x128", "128x64", "64x128", "64x64"):
-            fns["engine NT " + t] = (lambda t=t: (os.environ.__setitem__("VQA_BF16_TILE", t), ops.gemm_bf16_nt(a, b))[1])
+            fns["engine NT " + t] = (lambda t=t: (_lib.set_option("VQA_BF16_TILE", t), ops.gemm_bf16_nt(a, b))[1])
         res = timeit(fns, rounds)
-        os.environ.pop("VQA_BF16_TILE", None)
+        _lib.set_option("VQA_BF16_TILE", None)
         print("== bf16 NT " + title)
         for key, ms in res.items():
             med = statistics.median(ms)
@@ -70,9 +70,9 @@ def bf16_section(rounds):
         b = torch.randn(kd, n2, device=dev).to(torch.bfloat16)
         fns = {"torch (hipBLASLt)": lambda: a.t() @ b}
         for t in ("128x128", "128x64", "64x128", "64x64"):
-            fns["engine TN " + t] = (lambda t=t: (os.environ.__setitem__("VQA_BF16_TILE", t), ops.gemm_bf16_tn(a, b))[1])
+            fns["engine TN " + t] = (lambda t=t: (_lib.set_option("VQA_BF16_TILE", t), ops.gemm_bf16_tn(a, b))[1])
         res = timeit(fns, rounds)
-        os.environ.pop("VQA_BF16_TILE", None)
+        _lib.set_option("VQA_BF16_TILE", None)
         print("== bf16 TN " + title)
         for key, ms in res.items():
             med = statistics.median(ms)
@@ -103,11 +103,8 @@ def main():
     gout = torch.randn(B, N, H, device=dev)
     gp = torch.randn(B, G, D, device=dev)
 
-    def set_tile(t):
-        if t:
-            os.environ["VQA_GEMM_TILE"] = t
-        else:
-            os.environ.pop("VQA_GEMM_TILE", None)
+    def set_tile(t):      # (the library reads its knobs from the environment once: switch them through vqa_set_option)
+        _lib.set_option("VQA_GEMM_TILE", t or None)
 
     if want("k4fwd"):
         fns = {}

@@ -9,7 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VQA_LIB_PATH", os.path.join(_HERE, "libvqa_mi355x.so"))  # env override: profiling builds
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c_f = ctypes.c_void_p          # device pointer to fp32
 _c_pp = ctypes.c_void_p         # host array of device pointers
@@ -24,6 +24,7 @@ _c_st = ctypes.c_void_p         # hipStream_t
 SIGNATURES = {
     "vqa_version": (_c_i, []),
     "vqa_last_error": (ctypes.c_char_p, []),
+    "vqa_set_option": (_c_i, [ctypes.c_char_p, ctypes.c_char_p]),
     "vqa_pairwise_relation_reduce_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_pairwise_relation_reduce_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
                                                 _c_i, _c_i, _c_i, _c_st]),
@@ -146,6 +147,14 @@ def lib():
             raise VqaLibraryError("ABI version mismatch: library %d, binding %d" % (handle.vqa_version(), ABI_VERSION))
         _lib = handle
     return _lib
+
+
+def set_option(name, value):
+    """Override (str / int) or clear (None) one of the library's VQA_* knobs for the rest of the process.  The library
+    reads each knob from the environment once, at its first use; this is the explicit way to change one afterwards
+    (tests, tools) -- never between the forward and the backward of an op."""
+    v = None if value is None else str(value).encode()
+    check(lib().vqa_set_option(name.encode(), v), "set_option")
 
 
 def check(rc, what):

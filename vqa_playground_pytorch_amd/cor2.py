@@ -150,10 +150,16 @@ class Model(nn.Module):
             v2_att, alpha2, _ = self.att2.attend(v_feature, self.att2.conv_att.pre_activation(fuse2),
                                                  lambda pooled, pd: ops.relation_apply(
                                                      pooled, t, c2, pd, ops.next_dropout_seed() if pd else 0))
-            # (computed when read: a training step never looks at it.  Under graph replay t and c2 are the graph's own
-            #  buffers, i.e. they hold the latest step's values when the entry is read after it)
-            t_d, c2_d, v_d = t.detach(), c2.detach(), v_feature.detach()
-            feature = lambda: torch.addcmul(t_d.unsqueeze(1), c2_d.unsqueeze(1), v_d[:, 0:2, :].float())  # noqa: E731
+            # the reference's v2_feature[:, [0, 1], :] (visu.py:198-207 reads it after an eval forward).  Eval: computed here,
+            # like the reference does.  Training: a step never looks at it, so it is computed when read, from copies of the
+            # two region rows and of t / c2 rows that belong to THIS forward only when it ran eagerly -- under graph replay
+            # t and c2 are the graph's own buffers and hold the latest replay's values (documented on SideOutputs).  Only
+            # the [:, 0:2] slice of v is kept alive, not the [B,N,2048] input.
+            t_d, c2_d, v_d = t.detach(), c2.detach(), v_feature.detach()[:, 0:2, :].float()
+            if self.training:
+                feature = lambda: torch.addcmul(t_d.unsqueeze(1), c2_d.unsqueeze(1), v_d)  # noqa: E731
+            else:
+                feature = torch.addcmul(t_d.unsqueeze(1), c2_d.unsqueeze(1), v_d)
         else:
             # pairwise form: every (i, j) term of the relation tensor summed in the kernel, as the reference structures it;
             # v2 has two consumers, each gets its own alias (see ops.pairwise_relation_reduce)

@@ -1,10 +1,42 @@
-// Version and per-thread error text of libvqa_mi355x.so.
+// Version, per-thread error text and the process-wide option table of libvqa_mi355x.so.
+#include <cstdlib>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+
 #include "common.hpp"
 
 namespace vqa {
 char* error_buffer() {
   static thread_local char buf[512] = {0};
   return buf;
+}
+
+// Option table.  Every tuning / diagnostic knob of the kernels (VQA_K3_FUSED_MIN_B, VQA_K2_BYTE_MASK, VQA_RELDG_TUNE ...)
+// is looked up here and nowhere else.  The environment is read ONCE per name, at the first query, and the answer is
+// kept: a later os.environ change cannot make the backward of an op pick another kernel form or mask layout than its
+// forward did, and no launch calls getenv (which is not safe beside another thread's putenv).  Tests and tools switch
+// a knob explicitly through vqa_set_option().
+namespace {
+struct OptionTable {
+  std::mutex mu;
+  std::unordered_map<std::string, std::pair<bool, std::string>> values;  // name -> (is set, value)
+};
+OptionTable& options() {
+  static OptionTable* t = new OptionTable();  // never destroyed: launches may outlive static destruction order
+  return *t;
+}
+}  // namespace
+
+const char* option(const char* name) {
+  OptionTable& t = options();
+  std::lock_guard<std::mutex> lock(t.mu);
+  auto it = t.values.find(name);
+  if (it == t.values.end()) {
+    const char* e = std::getenv(name);
+    it = t.values.emplace(name, std::make_pair(e != nullptr, std::string(e != nullptr ? e : ""))).first;
+  }
+  return it->second.first ? it->second.second.c_str() : nullptr;
 }
 
 // Zero-fill as a plain kernel.  hipMemsetAsync must not be used in this library: captured into a hipGraph (memset
@@ -35,4 +67,11 @@ int zero_async(void* ptr, size_t bytes, hipStream_t s) {
 }  // namespace vqa
 
 extern "C" int vqa_version(void) { return VQA_ABI_VERSION; }
+extern "C" int vqa_set_option(const char* name, const char* value) {
+  VQA_REQUIRE(name != nullptr && name[0] != 0, VQA_E_BADARG, "set_option: empty name");
+  vqa::OptionTable& t = vqa::options();
+  std::lock_guard<std::mutex> lock(t.mu);
+  t.values[name] = std::make_pair(value != nullptr, std::string(value != nullptr ? value : ""));
+  return VQA_OK;
+}
 extern "C" const char* vqa_last_error(void) { return vqa::error_buffer(); }

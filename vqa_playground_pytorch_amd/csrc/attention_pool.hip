@@ -357,7 +357,7 @@ static int launch_bwd(const float* alpha, const T* v, const float* d_pooled, con
   if constexpr (G == 1 || G == 2 || G == 4 || G == 8) {
     // one workgroup per sample, everything in one launch -- when the batch alone fills the chip (>= 2 workgroups per CU)
     // (VQA_K3_FUSED_MIN_B: the smallest batch that takes this form; tests set 1, a huge value keeps the three-launch form)
-    const char* env = std::getenv("VQA_K3_FUSED_MIN_B");
+    const char* env = vqa::option("VQA_K3_FUSED_MIN_B");
     const int min_b = env != nullptr ? std::atoi(env) : 512;
     const size_t lds_f = ((size_t)2 * N * G + kMaxG) * sizeof(float);
     if (B >= min_b && D % 4 == 0 && D <= 4 * NT * 2 && D > 4 * NT) {

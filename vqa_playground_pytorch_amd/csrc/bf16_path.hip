@@ -24,7 +24,7 @@ struct BfTileChoice {
   int bm, bn;
 };
 static bool bf_tile_override(BfTileChoice* t) {
-  if (const char* e = std::getenv("VQA_BF16_TILE")) {  // experiment knob, e.g. "128x64"
+  if (const char* e = vqa::option("VQA_BF16_TILE")) {  // experiment knob, e.g. "128x64"
     int bm = 0, bn = 0;
     if (std::sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) {
       *t = {bm, bn};

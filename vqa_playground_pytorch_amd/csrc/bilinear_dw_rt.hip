@@ -312,7 +312,7 @@ __global__ __launch_bounds__(rt::kThreads, 1) void bilinear_dw_rt_kernel(DwRtArg
 }  // namespace
 
 bool dw_rt_supported(int B, int N, int L, int H, int R, int ldx) {
-  static const bool off = std::getenv("VQA_K4_DW_RT") != nullptr && std::getenv("VQA_K4_DW_RT")[0] == '0';
+  static const bool off = vqa::option("VQA_K4_DW_RT") != nullptr && vqa::option("VQA_K4_DW_RT")[0] == '0';
   return !off && (R == 1 || R == 2) && (N == 36 || N == 100) && L > 256 && L < kCols && ldx == L && L % 2 == 0 && H >= 16 &&
          B >= 64 && (size_t)B * N * H * 4 < (1ull << 32);
 }
@@ -339,7 +339,7 @@ int dw_rt_launch(const float* g, const float* x, const float* h2, const float* c
   a.HB = (H + 15) / 16;
   a.spl = (B + 2 * kDwRtGroups - 1) / (2 * kDwRtGroups);
   const dim3 grid(a.HB * kDwRtGroups);
-  const int tune = std::getenv("VQA_K4_DW_TUNE") ? std::atoi(std::getenv("VQA_K4_DW_TUNE")) : 0;   // (diagnostic only)
+  const int tune = vqa::option("VQA_K4_DW_TUNE") ? std::atoi(vqa::option("VQA_K4_DW_TUNE")) : 0;   // (diagnostic only)
 #define LAUNCH(R_, NS_)                                                                                         \
   {                                                                                                             \
     /* LDS: the W tile [R][16][320] floats, then 2 boxes of R x 10 blocks x 64 float4 for the cross-slice sum */ \

@@ -272,8 +272,8 @@ static FoldCfg folded_config(int B, int N, int O, int R, bool h2_rows) {
       }
     }
   }
-  const char* ew = std::getenv("VQA_K4_FOLD_WAVES");   // experiment knobs
-  const char* eo = std::getenv("VQA_K4_FOLD_OB");
+  const char* ew = vqa::option("VQA_K4_FOLD_WAVES");   // experiment knobs
+  const char* eo = vqa::option("VQA_K4_FOLD_OB");
   FoldCfg forced = pick;
   if (ew != nullptr && (std::atoi(ew) == 4 || std::atoi(ew) == 8)) forced.waves = std::atoi(ew);
   if (eo != nullptr && (std::atoi(eo) == 4 || (std::atoi(eo) == 5 && !h2_rows && N <= 48))) forced.ob = std::atoi(eo);

@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void bilinear_dh2_kernel(const float* __restri
 static int splits_for_dw(int M, int H, int L, int R, TileChoice t) {
   const long tiles = (long)((H + t.bm - 1) / t.bm) * ((L + t.bn - 1) / t.bn) * R;
   long s = (1280 + tiles - 1) / tiles;  // 5 workgroups per CU
-  if (const char* e = std::getenv("VQA_K4_DW_SPLITS")) s = std::atol(e);  // experiment knob
+  if (const char* e = vqa::option("VQA_K4_DW_SPLITS")) s = std::atol(e);  // experiment knob
   const long max_by_rows = (M + 255) / 256;  // keep >= 256 rows (16 stages) per split
   if (s > max_by_rows) s = max_by_rows;
   if (s > 64) s = 64;
@@ -563,14 +563,14 @@ static TileChoice dw_tile() { return tile_override_or({64, 64, 2}); }
 // per-sample form: worth it when a sample fills most of its padded stages and the ranks fit in registers
 static bool dw_per_sample(int N, int R) {
   const int padded = (N + 15) / 16 * 16;
-  if (const char* e = std::getenv("VQA_K4_DW_FORM")) return std::atoi(e) != 0 && R <= 4;  // experiment knob
+  if (const char* e = vqa::option("VQA_K4_DW_FORM")) return std::atoi(e) != 0 && R <= 4;  // experiment knob
   return R >= 2 && R <= 4 && N * 4 >= padded * 3;
 }
 static long dw_max_samples_per_slab(int R) { return 65536 / ((long)R * 64 * (long)sizeof(float)); }
 static int dw_sample_splits(int B, int H, int L, TileChoice t, int R) {
   const long tiles = (long)((H + t.bm - 1) / t.bm) * ((L + t.bn - 1) / t.bn);
   long s = (1280 + tiles - 1) / tiles;  // 5 workgroups per CU: 32 slabs of 16 samples at B = 512 (sweep: 20..64)
-  if (const char* e = std::getenv("VQA_K4_DW_SPLITS")) s = std::atol(e);  // experiment knob
+  if (const char* e = vqa::option("VQA_K4_DW_SPLITS")) s = std::atol(e);  // experiment knob
   if (s > 64) s = 64;
   // the question-side factors of a slab's samples wait in LDS ([samples][R][BM] floats): at most 64 KB of them
   const long per = dw_max_samples_per_slab(R) * 64 / t.bm;
@@ -731,7 +731,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd(const float* x, int ldx, const fl
 // bound by the L2 -> LDS operand traffic of its 64x64 tiles (16 FLOP per byte), not by barriers or padding.
 static int dw_fold_bk(int N, int R) {
   static const int knob = [] {   // experiment knob: 16 forces the three-stage form at 32 < N <= 40
-    const char* e = std::getenv("VQA_K4_FOLD_DW_BK");
+    const char* e = vqa::option("VQA_K4_FOLD_DW_BK");
     return e != nullptr ? std::atoi(e) : 0;
   }();
   return (N > 32 && N <= 40 && R <= 2 && knob != 16) ? 40 : 16;
@@ -740,7 +740,7 @@ static int dw_fold_splits(int B, int N, int H, int L, int R) {
   const long tiles = (long)((H + 63) / 64) * ((L + 63) / 64);
   const int resident = dw_fold_bk(N, R) == 40 ? 2 : (R <= 2 ? 3 : 2);   // workgroups per CU (register budget)
   long s = (256L * resident) / tiles;
-  if (const char* e = std::getenv("VQA_K4_DW_SPLITS")) s = std::atol(e);  // experiment knob
+  if (const char* e = vqa::option("VQA_K4_DW_SPLITS")) s = std::atol(e);  // experiment knob
   if (s > 64) s = 64;
   // the question-side factors of a slab's samples wait in LDS ([samples][R][64] floats): at most 64 KB of them
   const long by_lds = (B + dw_max_samples_per_slab(R) - 1) / dw_max_samples_per_slab(R);
@@ -836,7 +836,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_folded_bwd_gated(const float* x, int 
   const int S = dw_fold_splits(B, N, H, L, R);
   const int tiles_m = (H + 63) / 64, tiles_n = (L + 63) / 64;
   static const int pf = [] {   // register sets in flight (experiment knob; 1 keeps three waves per SIMD at R = 2)
-    const char* e = std::getenv("VQA_K4_FOLD_DW_PF");
+    const char* e = vqa::option("VQA_K4_FOLD_DW_PF");
     return e != nullptr && std::atoi(e) == 2 ? 2 : 1;
   }();
   const int bk = dw_fold_bk(N, R);

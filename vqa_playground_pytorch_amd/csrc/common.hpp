@@ -28,6 +28,10 @@ inline int check_launch(const char* what) {
   return VQA_OK;
 }
 
+// api.hip: value of a tuning / diagnostic knob -- the environment variable of that name as it was at the FIRST query (or
+// what vqa_set_option() installed since), nullptr when unset.  Launchers never read the environment themselves.
+const char* option(const char* name);
+
 int zero_async(void* ptr, size_t bytes, hipStream_t s);  // api.hip: zero-fill kernel (never hipMemsetAsync: see there)
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }

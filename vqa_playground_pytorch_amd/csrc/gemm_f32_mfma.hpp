@@ -273,7 +273,7 @@ inline TileChoice choose_tile(long M, long N, long splits) {
 }
 
 inline TileChoice tile_override_or(TileChoice c) {
-  const char* e = std::getenv("VQA_GEMM_TILE");  // experiment knob, e.g. "128x64" or "64x64x3" (BM x BN [x PF])
+  const char* e = vqa::option("VQA_GEMM_TILE");  // experiment knob, e.g. "128x64" or "64x64x3" (BM x BN [x PF])
   if (e != nullptr) {
     int bm = 0, bn = 0, pf = 0;
     const int n = std::sscanf(e, "%dx%dx%d", &bm, &bn, &pf);

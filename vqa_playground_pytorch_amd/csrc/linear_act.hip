@@ -231,7 +231,7 @@ static int splits_for_linear_dw(int M, int K, int N, TileChoice t) {
   const long tiles = (long)((N + t.bm - 1) / t.bm) * ((K + t.bn - 1) / t.bn);
   long s = (2560 + tiles - 1) / tiles;  // 10 workgroups per CU (sweep 4..24 at N x K = 310 x 2048, M = 18432: 16 splits, 256 us
                                         // with the slab reduction against 267 at 8; the curve is flat from 12 to 24)
-  if (const char* e = std::getenv("VQA_LINEAR_DW_SPLITS")) s = std::atol(e);  // experiment knob
+  if (const char* e = vqa::option("VQA_LINEAR_DW_SPLITS")) s = std::atol(e);  // experiment knob
   const long max_by_rows = (M + 255) / 256;
   if (s > max_by_rows) s = max_by_rows;
   if (s > 64) s = 64;
@@ -240,7 +240,7 @@ static int splits_for_linear_dw(int M, int K, int N, TileChoice t) {
 }
 static TileChoice linear_dw_tile() {
   TileChoice t = tile_override_or({64, 64, 2});
-  if (const char* e = std::getenv("VQA_LINEAR_DW_TILE")) {  // experiment knob
+  if (const char* e = vqa::option("VQA_LINEAR_DW_TILE")) {  // experiment knob
     int bm = 0, bn = 0, pf = 2;
     const int got = std::sscanf(e, "%dx%dx%d", &bm, &bn, &pf);
     if (got >= 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128) && pf >= 1 && pf <= 3) t = {bm, bn, pf};
@@ -264,7 +264,7 @@ struct EpiBiasAct {
 // "0" = never, "1" (default) = where it applies (tall matrices with 4-element-aligned rows; everything else stays on
 // the 64 x 64 LDS-tile engine above)
 static bool rt_enabled() {
-  const char* e = std::getenv("VQA_RT_ENGINE");
+  const char* e = vqa::option("VQA_RT_ENGINE");
   return e == nullptr || e[0] != '0';
 }
 // p8: 0 (no dropout) or 128 (p = 0.5, the one-bit mask; needs rows of whole 32-element hash words); other rates stay on
@@ -275,7 +275,7 @@ static bool rt_fwd_ok(int M, int K, int N, int ldx, uint32_t p8) {
 }
 static int rt_dw_splits(int M) {
   int s = 16;   // 4 n1 tiles x 16 n2 tiles x 16 row splits = 1024 waves for 310 x 2048 (one per SIMD)
-  if (const char* e = std::getenv("VQA_RT_DW_SPLITS")) s = std::atoi(e);
+  if (const char* e = vqa::option("VQA_RT_DW_SPLITS")) s = std::atoi(e);
   const int max_by_rows = M / 64 > 0 ? M / 64 : 1;
   if (s > max_by_rows) s = max_by_rows;
   if (s > 64) s = 64;

@@ -849,7 +849,7 @@ __global__ __launch_bounds__(256) void oda_mask_kernel(float* __restrict__ mask,
 
 // p = 0.5 and 32-bit element counters: the one-bit-per-element layout (VQA_K2_BYTE_MASK=1 keeps the byte layout)
 static bool oda_bits_mode(const DropCfg& dc, int B, int N, int L) {
-  return dc.p8 == kDropHalf && (size_t)B * ((N + 31) / 32) * N * L < (1ull << 32) && std::getenv("VQA_K2_BYTE_MASK") == nullptr;
+  return dc.p8 == kDropHalf && (size_t)B * ((N + 31) / 32) * N * L < (1ull << 32) && vqa::option("VQA_K2_BYTE_MASK") == nullptr;
 }
 
 static int oda_threads(int L) {
@@ -859,7 +859,7 @@ static int oda_threads(int L) {
 static int oda_groups(int B) { return B < 128 ? B : 128; }
 // the 4x4-MFMA kernels (forward, weight gradient): G <= 4 glimpses, N <= 36 regions, no dropout or the one-bit p = 0.5 mask
 static bool oda_mfma_ok(const DropCfg& dc, int B, int N, int L, int G) {
-  static const bool off = std::getenv("VQA_K2_MFMA") != nullptr && std::getenv("VQA_K2_MFMA")[0] == '0';
+  static const bool off = vqa::option("VQA_K2_MFMA") != nullptr && vqa::option("VQA_K2_MFMA")[0] == '0';
   return !off && G <= 4 && N <= 4 * kOdaIG && (dc.p8 == 0 || oda_bits_mode(dc, B, N, L)) && (size_t)B * N * L * 4 < (1ull << 32);
 }
 static int oda_mfma_groups(int B) { return B < 256 ? B : 256; }   // sample groups of the MFMA weight gradient: one workgroup per CU

@@ -448,10 +448,10 @@ static int pairwise_fwd_impl(const char* who, const T* v, const float* q1, const
                        alpha, alpha_stride, v2, N, D);
     return check_launch(who);
   }
-  if (N <= kRegN && std::getenv("VQA_K1_PAIRWISE_LDS") == nullptr) {   // (the env knob keeps the LDS-tile form reachable)
+  if (N <= kRegN && vqa::option("VQA_K1_PAIRWISE_LDS") == nullptr) {   // (the env knob keeps the LDS-tile form reachable)
     const int tiles_d = (D / 4 + 63) / 64;
     if constexpr (sizeof(T) == 4) {
-      if ((long)B * D >= (1L << 19) && std::getenv("VQA_K1_PAIRWISE_REG4") == nullptr) {   // enough columns for half-sized waves
+      if ((long)B * D >= (1L << 19) && vqa::option("VQA_K1_PAIRWISE_REG4") == nullptr) {   // enough columns for half-sized waves
         hipLaunchKernelGGL(pairwise_fwd_pairs_reg2_kernel, dim3((D / 2 + 63) / 64, B), dim3(64), 0, s, v, q1, q2, alpha,
                            alpha_stride, v2, N, D, make_drop(0.f, 0));
         return check_launch(who);

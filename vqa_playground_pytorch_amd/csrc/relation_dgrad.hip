@@ -323,7 +323,7 @@ using namespace vqa;
 
 // include/vqa_mi355x.h
 extern "C" int vqa_relation_projection_dgrad_supported(int B, int N, int D, int L) {
-  static const bool off = std::getenv("VQA_FUSE_RELATION_DGRAD") != nullptr && std::getenv("VQA_FUSE_RELATION_DGRAD")[0] == '0';
+  static const bool off = vqa::option("VQA_FUSE_RELATION_DGRAD") != nullptr && vqa::option("VQA_FUSE_RELATION_DGRAD")[0] == '0';
   return !off && N == kRegions && B >= 1 && D % 64 == 0 && D >= 64 && L >= 32 && L % 2 == 0 && (size_t)B * N * D * 4 < (1ull << 32) &&
          (size_t)L * D * 4 < (1ull << 32);
 }
@@ -353,7 +353,7 @@ extern "C" int vqa_relation_projection_dgrad(const float* gz, const float* w, co
   const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
   // 4 (default): two workgroups per CU, fragments refilled in halves, v read in the epilogue; 0: one workgroup per CU, double-
   // buffered fragments, v streamed into LDS (the first form: 230 us against 199 at B = 512); 1..3: ablations of the latter
-  const int tune = std::getenv("VQA_RELDG_TUNE") ? std::atoi(std::getenv("VQA_RELDG_TUNE")) : 4;
+  const int tune = vqa::option("VQA_RELDG_TUNE") ? std::atoi(vqa::option("VQA_RELDG_TUNE")) : 4;
   const dim3 grid((unsigned)(tiles_m * a.tiles_n));
   hipStream_t s = static_cast<hipStream_t>(stream);
   constexpr size_t lds = (size_t)4 * 4 * kRB * 1024;      // 4 waves x 36 slots of 1 KB

@@ -384,9 +384,12 @@ class MyATT(nn.Module):
 
 
 class SideOutputs(dict):
-    """The ``alpha_dict`` side output of a model (read by visu.py:198-207 after a forward) with entries that are computed
-    on first access: a value stored as a zero-argument callable is replaced by its result when it is read.  A training
-    step never reads ``alpha_dict['feature']``, so the kernel that would materialise it does not run in the step."""
+    """The ``alpha_dict`` side output of a model (read by visu.py:198-207 after a forward) with entries that may be computed
+    on first access: a value stored as a zero-argument callable is replaced by its result when it is read.  Only a
+    TRAINING forward stores such an entry (``alpha_dict['feature']``: a training step never reads it, so the kernel that
+    would materialise it does not run in the step; read after a graph-replayed step it reflects the latest replay); an
+    eval forward -- the visualisation path -- stores plain tensors like the reference.  Every way of getting the values
+    out (indexing, get, items, values, iteration-based copies, dict(), ``**``, copy, pickling) resolves them first."""
 
     def _resolve(self, key):
         value = dict.__getitem__(self, key)
@@ -395,6 +398,10 @@ class SideOutputs(dict):
             dict.__setitem__(self, key, value)
         return value
 
+    def _resolve_all(self):
+        for k in list(dict.keys(self)):
+            self._resolve(k)
+
     def __getitem__(self, key):
         return self._resolve(key)
 
@@ -402,10 +409,28 @@ class SideOutputs(dict):
         return self._resolve(key) if key in self else default
 
     def items(self):
-        return [(k, self._resolve(k)) for k in list(self.keys())]
+        self._resolve_all()
+        return dict.items(self)
 
     def values(self):
-        return [self._resolve(k) for k in list(self.keys())]
+        self._resolve_all()
+        return dict.values(self)
+
+    def keys(self):          # dict(d) / {**d} walk keys() and then index: resolve up front so C-level fast paths see tensors
+        self._resolve_all()
+        return dict.keys(self)
+
+    def __iter__(self):
+        self._resolve_all()
+        return dict.__iter__(self)
+
+    def copy(self):
+        self._resolve_all()
+        return SideOutputs(dict.copy(self))
+
+    def __reduce__(self):
+        self._resolve_all()
+        return (SideOutputs, (dict(dict.items(self)),))
 
 
 class QuestionVectorInput(nn.Module):

@@ -126,39 +126,58 @@ def pad_to(n, multiple=BF16_PAD):
 # AccumulateGrad adopts a freshly produced gradient as `.grad` without a copy, so the per-step gather of ~70 gradients
 # (one 48 MB multi-tensor copy, 31 us at B = 512) has nothing left to move.  A slot is handed out once per backward
 # pass (`begin_backward`): a parameter used twice gets a fresh tensor the second time and autograd adds it in.
-_grad_slots = None
-_slots_taken = []
+# Registrations are keyed by the flat parameter buffer (several trainers -- one per replica thread, say -- may be inside
+# their backward windows at once; autograd runs the nodes on its own per-device threads, so the calling thread says nothing):
+# `_grad_like` looks for the registration whose parameter buffer holds `w`, and ending one trainer's window neither drops
+# another's registration nor resets its hand-out list.
+_slot_lock = threading.Lock()
+_slot_regs = {}       # (device index, p_flat.data_ptr()) -> [p_flat, g_flat, [(lo, hi) handed out this backward pass]]
+
+
+def _slot_key(p_flat):
+    return (p_flat.device.index, p_flat.data_ptr())
 
 
 def set_grad_slots(p_flat, g_flat):
-    """Register (or, with None, drop) the flat parameter / gradient buffers whose offsets correspond."""
-    global _grad_slots
-    _grad_slots = None if p_flat is None else (p_flat, g_flat)
-    del _slots_taken[:]
+    """Register the flat parameter / gradient buffer pair whose offsets correspond (g_flat None: drop p_flat's
+    registration).  A fresh registration starts with nothing handed out."""
+    with _slot_lock:
+        if g_flat is None:
+            if p_flat is not None:
+                _slot_regs.pop(_slot_key(p_flat), None)
+        else:
+            _slot_regs[_slot_key(p_flat)] = [p_flat, g_flat, []]
 
 
-def begin_backward():
-    del _slots_taken[:]
+def begin_backward(p_flat=None):
+    """Forget which slots were handed out (of p_flat's registration; of all when None)."""
+    with _slot_lock:
+        for key, reg in _slot_regs.items():
+            if p_flat is None or key == _slot_key(p_flat):
+                reg[2] = []
 
 
 def _grad_like(w, rows_strided=False):
     """rows_strided: a 2-D `w` whose rows are contiguous but spaced (a stack of odd-sized biases, padded apart in the flat
     buffer) is matched too -- for callers whose kernel takes a row stride."""
-    s = _grad_slots
-    if s is not None and w.dtype == torch.float32 and w.device == s[0].device and w.numel() > 0:
+    if _slot_regs and w.dtype == torch.float32 and w.numel() > 0:
         dense = w.is_contiguous()
         spaced = (not dense) and rows_strided and w.dim() == 2 and w.stride(1) == 1 and w.stride(0) >= w.shape[1]
         if dense or spaced:
-            p_flat, g_flat = s
-            off = w.data_ptr() - p_flat.data_ptr()
             n = w.numel() if dense else (w.shape[0] - 1) * w.stride(0) + w.shape[1]
-            if off >= 0 and off % 4 == 0 and off // 4 + n <= p_flat.numel():
-                lo = off // 4
-                if all(lo + n <= a or lo >= b for a, b in _slots_taken):
-                    _slots_taken.append((lo, lo + n))
-                    if dense:
-                        return g_flat[lo:lo + n].view(w.shape)
-                    return g_flat.as_strided(tuple(w.shape), tuple(w.stride()), lo)
+            ptr, dev = w.data_ptr(), w.device.index
+            with _slot_lock:
+                for (rdev, base), (p_flat, g_flat, taken) in _slot_regs.items():
+                    off = ptr - base
+                    if rdev != dev or off < 0 or off % 4 or off // 4 + n > p_flat.numel():
+                        continue            # `w` does not live in this registration's parameter buffer
+                    lo = off // 4
+                    if all(lo + n <= a or lo >= b for a, b in taken):
+                        taken.append((lo, lo + n))
+                        if dense:
+                            return g_flat[lo:lo + n].view(w.shape)
+                        return g_flat.as_strided(tuple(w.shape), tuple(w.stride()), lo)
+                    break                   # a second use in this pass: a fresh tensor, autograd adds it in
     return torch.empty_like(w) if w.is_contiguous() else torch.empty(w.shape, device=w.device, dtype=w.dtype)
 
 

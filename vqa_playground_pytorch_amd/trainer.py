@@ -195,10 +195,9 @@ class FlatState:
         ops.set_grad_slots(self.p, self.g)
         self.drop_grads()
 
-    @staticmethod
-    def end_backward():
+    def end_backward(self):
         from . import ops
-        ops.set_grad_slots(None, None)
+        ops.set_grad_slots(self.p, None)
 
 
 class DataParallelTrainer:
@@ -240,13 +239,16 @@ class DataParallelTrainer:
         self._eager_steps = 0
         # overlap (GPU path, models that offer late_parameters() / forward_with_cut(): CoR2, ODA): backward runs in two halves;
         # the gradients of the second reasoning step -- complete after the first half -- are all-reduced while the second
-        # half runs.  ON by default whenever there is more than one rank (VQA_DP_OVERLAP=0 or overlap=False turns it off):
-        # what it costs a single GPU is the split of the backward graph (0.03 ms at B = 512), what it hides is ~60 % of the
-        # all-reduce payload behind ~40 % of the backward.  Its gain over xGMI is not measured yet (no multi-GPU box in this
-        # build's reach); tests/test_gpu_dp2.py runs it on two ranks sharing one GPU.  "force" also splits at world size 1.
+        # half runs.  OPT-IN (overlap=True or VQA_DP_OVERLAP=1): what it costs a single GPU is the split of the backward
+        # graph (0.03 ms at B = 512), what it could hide is ~60 % of the all-reduce payload behind ~40 % of the backward --
+        # but its gain over xGMI has never been measured (no multi-GPU node in this build's reach) and the register-tile
+        # kernels run one or two workgroups per CU, so a concurrent RCCL kernel can also slow the backward it hides behind.
+        # Until a scaling run says otherwise the default is the single all-reduce between backward and clip.
+        # tests/test_gpu_dp2.py runs both on two ranks sharing one GPU.  "force" also splits at world size 1.
+        requested = overlap
         if overlap is None:
             import os
-            overlap = os.environ.get("VQA_DP_OVERLAP", "1") == "1"
+            requested = overlap = os.environ.get("VQA_DP_OVERLAP", "0") == "1"
         self.overlap = False
         if self.hip:
             params = list(model.parameters())
@@ -263,6 +265,24 @@ class DataParallelTrainer:
                     split = min(self.flat.offset_of(p) for p in early)
                     if all(self.flat.offset_of(p) + p.numel() <= split for p in late):
                         self.overlap, self._late, self._early, self._split = True, late, early, split
+            # say once which reduction schedule is in effect -- also when the split was asked for and could not be had
+            # (the model offers no cut, or a stack group mixes late and early parameters so the late bucket is not a prefix)
+            if self.overlap:
+                self.overlap_note = "two-half backward, late bucket %d of %d floats reduced under the second half" % (
+                    self._split, self.flat.total)
+            elif requested:
+                if not (hasattr(model, "late_parameters") and hasattr(model, "forward_with_cut")):
+                    why = "model has no late_parameters()/forward_with_cut()"
+                elif not can_split:
+                    why = "world size 1"
+                else:
+                    why = "late parameters are not a prefix of the flat buffer"
+                self.overlap_note = "single all-reduce after backward (overlap requested but unavailable: %s)" % why
+            else:
+                self.overlap_note = "single all-reduce after backward"
+            if (self.world > 1 or requested) and (not dist.is_initialized() or dist.get_rank(group) == 0):
+                import sys
+                print("[vqa trainer] gradient reduction: %s (world %d)" % (self.overlap_note, self.world), file=sys.stderr)
             # the per-step device words the replayed graphs read -- Adam's two step scalars (fp32) and the dropout seed of the
             # fused kernels (int64; every replay reads the current value) -- are ONE 16-byte block, refreshed by ONE
             # host-to-device copy per step (a pinned-memory copy is a blit kernel of ~8 us that the step waits for)
@@ -493,7 +513,7 @@ class DataParallelTrainer:
         try:
             grads = torch.autograd.grad(logits, self._late + [i for _, i in live], grad_outputs=d_logits, allow_unused=True)
         finally:
-            ops.set_grad_slots(None, None)
+            ops.set_grad_slots(self.flat.p, None)
         self.flat.store_grads(self._late, grads[:len(self._late)])
         pairs = [(o, g) for (o, _), g in zip(live, grads[len(self._late):]) if g is not None]
         self._cut = ([o for o, _ in pairs], [g for _, g in pairs])
@@ -508,7 +528,7 @@ class DataParallelTrainer:
         try:
             grads = torch.autograd.grad(tensors, self._early, grad_outputs=grads_in, allow_unused=True)
         finally:
-            ops.set_grad_slots(None, None)
+            ops.set_grad_slots(self.flat.p, None)
         self.flat.store_grads(self._early, grads)
 
     def _reduce_late_async(self):
