@@ -247,38 +247,111 @@ def cpu_baseline_worker(batch, threads, budget_s):
                                 "%d threads on a host with %d cores" % (batch, steps, threads, os.cpu_count() or 1)}))
 
 
-def _cpu_baseline_run(batch, threads, budget_s, hard_timeout_s):
+def _cpu_baseline_start(batch, threads, budget_s):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(batch), str(threads), str(budget_s)]
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))
+    return subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+
+
+def _cpu_baseline_collect(proc, batch, threads, hard_timeout_s):
+    import subprocess
     try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=hard_timeout_s, env=env, cwd=ROOT)
-        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-        if out.returncode == 0 and line:
+        out, err = proc.communicate(timeout=hard_timeout_s)
+        line = [ln for ln in out.splitlines() if ln.startswith("{")]
+        if proc.returncode == 0 and line:
             return json.loads(line[-1])
         return {"value": None, "unit": "samples/s", "cores": threads, "kind": "port",
-                "sample": "failed: rc=%d %s" % (out.returncode, out.stderr[-200:])}
+                "sample": "failed: rc=%d %s" % (proc.returncode, err[-200:])}
     except subprocess.TimeoutExpired:
+        proc.kill()             # (the exact child started above)
+        proc.communicate()
         return {"value": None, "unit": "samples/s", "cores": threads, "kind": "port",
                 "sample": "did not finish 3 steps of batch %d within %.0f s" % (batch, hard_timeout_s)}
 
 
-def cpu_baseline(batch=16, budget_s=10.0, hard_timeout_s=90.0):
+class CpuBaseline:
     """The reference cannot travel to the GPU box; time its op-for-op torch-CPU port (validated against the
-    reference's golden vectors in tests/) on the host cores.  Bounded: child processes with a hard timeout, so a
-    slow host can never stall the benchmark.  Two thread counts: 16 (the reference's thousands of tiny per-sample ops
-    get slower with more) and every core of the host (os.cpu_count() threads, batch 32); the better one is
-    `value`, the other is reported next to it."""
-    cores = os.cpu_count() or 1
-    runs = [_cpu_baseline_run(batch, min(cores, 16), budget_s, hard_timeout_s)]
-    if cores > 16:      # (on a 256-core host the all-core run is several times slower: bounded tightly, reported either way)
-        runs.append(_cpu_baseline_run(batch, cores, budget_s / 2, 45.0))
-    ok = [r for r in runs if r.get("value")]
-    best = max(ok, key=lambda r: r["value"]) if ok else runs[0]
-    best = dict(best)
-    best["host_cores"] = cores
-    best["all_runs"] = [{"cores": r["cores"], "value": r["value"], "sample": r["sample"]} for r in runs]
-    return best
+    reference's golden vectors in tests/) on the host cores.  Bounded: child processes (no GPU) with a hard timeout, so a
+    slow host can never stall the benchmark; started right after the timed region so that they run beside the GPU
+    sub-records of the same invocation.  Two thread counts, one after the other: 16 (the reference's thousands of tiny
+    per-sample ops get slower with more) and every core of the host (os.cpu_count() threads); the better one
+    is `value`, the other is reported next to it."""
+
+    def __init__(self, batch=16, budget_s=10.0):
+        self.batch, self.budget_s = batch, budget_s
+        self.cores = os.cpu_count() or 1
+        self.first = (_cpu_baseline_start(batch, min(self.cores, 16), budget_s), min(self.cores, 16))
+
+    def result(self, hard_timeout_s=90.0):
+        runs = [_cpu_baseline_collect(self.first[0], self.batch, self.first[1], hard_timeout_s)]
+        if self.cores > 16:   # (on a 256-core host the all-core run is several times slower: bounded tightly, reported either way)
+            runs.append(_cpu_baseline_collect(_cpu_baseline_start(self.batch, self.cores, self.budget_s / 2), self.batch,
+                                              self.cores, 45.0))
+        ok = [r for r in runs if r.get("value")]
+        best = dict(max(ok, key=lambda r: r["value"]) if ok else runs[0])
+        best["host_cores"] = self.cores
+        best["all_runs"] = [{"cores": r["cores"], "value": r["value"], "sample": r["sample"]} for r in runs]
+        return best
+
+
+# The other single-GPU BASELINE configs, attached to the headline line as sub-records (each a child run of this file on the
+# same GPU, after the headline's timed region): SURVEY 8d config 3 (the ODA attention op), the ODA head at batch 512
+# (configs[2]), the CoR2 step with the relation step's forward on the pairwise kernel, and one rank's share of configs[4].
+SUB_RECORDS = [
+    ("oda_b512", ["--model", "oda"]),
+    ("oda_attention_b512", ["--model", "oda-attention"]),
+    ("cor2_pairwise_b512", ["--relation-mode", "0"]),
+    ("cor2_bf16_n100_b128", ["--dtype", "bf16", "--regions", "100", "--batch", "128"]),
+]
+
+
+def run_sub_records(steps, warmup, timeout_s=150.0):
+    import subprocess
+    out = {}
+    for tag, extra in SUB_RECORDS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup),
+               "--no-cpu-baseline", "--no-rotate", "--no-sub-records"] + extra
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[tag] = {"error": "rc=%d %s" % (r.returncode, r.stderr[-300:])}
+                continue
+            full = json.loads(line[-1])
+            keep = ("metric", "value", "unit", "ms_per_step", "dtype", "steps", "warmup", "roofline", "step_coverage",
+                    "final_loss", "final_grad_norm")
+            rec = {k: full[k] for k in keep if k in full}
+            rec["workload"] = full.get("config", {}).get("workload")
+            rec["launch"] = full.get("config", {}).get("launch")
+            rec["command"] = "bench.py " + " ".join(extra)
+            rec["wall_s"] = round(time.perf_counter() - t0, 1)
+            out[tag] = rec
+        except subprocess.TimeoutExpired:
+            out[tag] = {"error": "did not finish within %.0f s" % timeout_s}
+    return out
+
+
+def launch_ranks(args):
+    """`bench.py --gpus N` started WITHOUT a launcher: start the N ranks here (torch.distributed.run as a child process,
+    before this process has touched the GPU), relay their output and exit with their code.  Fails loudly when the node
+    has fewer than N GPUs -- never a silent one-GPU measurement."""
+    import socket
+    import subprocess
+    rehearsal = os.environ.get("VQA_ONE_GPU_REHEARSAL") == "1"
+    n_dev = torch.cuda.device_count()           # (counting devices does not initialise the GPU)
+    if n_dev < args.gpus and not rehearsal:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node; refusing to measure fewer ranks than asked"
+                         % (args.gpus, n_dev))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    rc = subprocess.run(cmd, env=env, cwd=ROOT).returncode
+    raise SystemExit(rc)
 
 
 def bench_oda_attention(args, world, rank, dev, ops):
@@ -371,8 +444,12 @@ def main():
     ap.add_argument("--no-rotate", action="store_true", help="skip the rotating-inputs pass")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying "
                     "the captured hipGraphs of the step")
+    ap.add_argument("--no-sub-records", action="store_true", help="headline only: do not attach the other single-GPU "
+                    "BASELINE configs (ODA, the ODA attention op, CoR2 pairwise, CoR2 bf16 N=100) as sub-records")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)          # no launcher around us: start the ranks ourselves (never measure 1 GPU silently)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -381,7 +458,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d but the launcher started %d rank(s): the two must agree" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -392,6 +470,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("process group has %d rank(s), --gpus says %d" % (dist.get_world_size(), args.gpus))
 
     from vqa_playground_pytorch_amd import CoR2Model, ODAModel, ops
     from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
@@ -470,6 +550,8 @@ def main():
         barrier()
         ops.set_kernel_timer(None)
     final_loss, final_gnorm = float(loss.item()), float(gnorm.item())
+    headline = world == 1 and args.model == "cor2" and not bf16 and args.regions == REGIONS and not args.encoder
+    cpu_job = CpuBaseline() if (rank == 0 and headline and not args.no_cpu_baseline) else None   # runs beside what follows
     # The same steps over ROTATE different resident batches: every step's batch then comes from HBM, not from the Infinity
     # Cache.  The replayed graphs read fixed input buffers, so each step starts with one device-to-device copy of the
     # batch into them (151 MB read + written, inside the timed region) -- an upper bound on what cold inputs cost.
@@ -518,10 +600,31 @@ def main():
     if rank == 0:
         steps_timed = min(args.steps, 10) if (graphed or not args.no_graph) else args.steps
         entries = step_table(timer.summary(), steps_timed, B, args.regions, bf16)
-        # `roofline` = the hand-written kernel that takes the largest share of the step (mean duration x launches), not a
-        # favourite; library GEMMs (hipBLASLt through torch) are listed in roofline_all with their time and rate as well
+        # `roofline` = the hand-written OP that takes the largest share of the step -- its launches summed over every shape
+        # it runs at (linear_act_fwd runs once with and once without the in-register dropout mask: two entries of
+        # roofline_all, one op) -- not a favourite; library GEMMs (hipBLASLt through torch) are listed in roofline_all with
+        # their time and rate as well
         ours = [e for e in entries if e["bound"] is not None and e["kernel"] != "library_gemm"]
-        dominant = ours[0] if ours else entries[0]
+        by_op = {}
+        for e in ours:
+            by_op.setdefault(e["kernel"], []).append(e)
+        dominant = None
+        if by_op:
+            name, group = max(by_op.items(), key=lambda kv: sum(e["ms_per_step"] for e in kv[1]))
+            launches = sum(e["launches"] for e in group)
+            total_ms = sum(e["mean_ms"] * e["launches"] for e in group)
+            work = sum(e["achieved"] * e["mean_ms"] * e["launches"] for e in group)        # (rate x time = work, per entry)
+            lead = max(group, key=lambda e: e["ms_per_step"])
+            dominant = {"bound": lead["bound"], "achieved": round(work / total_ms, 2), "peak": lead["peak"], "unit": lead["unit"],
+                        "frac": round(work / total_ms / lead["peak"], 4),
+                        "traffic": lead["traffic"], "kernel": name, "mean_ms": round(total_ms / launches, 5),
+                        "launches": launches, "ms_per_step": round(sum(e["ms_per_step"] for e in group), 5),
+                        "shapes": [e["shape"] for e in group],
+                        "device_kernels": [k for k, _ in PMC_KERNELS.get(name, [])]}
+            if "mfma_busy_pct" in lead:
+                dominant["mfma_busy_pct"] = lead["mfma_busy_pct"]
+        else:
+            dominant = dict(entries[0])
         kernel_ms = sum(e["ms_per_step"] for e in entries)
         lib_ms = sum(e["ms_per_step"] for e in entries if e["kernel"] == "library_gemm")
         ms_step = 1e3 * elapsed / args.steps
@@ -558,9 +661,7 @@ def main():
                                  "Cache, so the HBM-bound kernels' GB/s are upper bounds; `rotating_inputs` times the same "
                                  "steps over %d different resident batches" % (v.numel() * v.element_size() / 1e6, ROTATE)},
             "final_loss": round(final_loss, 3), "final_grad_norm": round(final_gnorm, 3),
-            "roofline": dict({k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
-                                                       "mean_ms", "launches", "ms_per_step")},
-                             **{k: dominant[k] for k in ("mfma_busy_pct",) if k in dominant}),
+            "roofline": dominant,
             "traffic_source": "profiles/%s_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
                               "(committed evidence; no profiler is attached in this run)" % EVIDENCE_TAG,
             # how much of the step the per-kernel table accounts for (its durations come from the kernel-by-kernel pass,
@@ -573,8 +674,11 @@ def main():
             result["rotating_inputs"] = rotating
         if world > 1:
             result["distributed"] = dist_info
-        if world == 1 and not args.no_cpu_baseline and args.model == "cor2" and not bf16 and args.regions == REGIONS:
-            result["cpu_baseline"] = cpu_baseline()
+        if headline and B == BATCH and not args.no_sub_records and graphed:
+            # the other single-GPU BASELINE configs, measured on this GPU in the same invocation (child runs of this file)
+            result["sub_records"] = run_sub_records(args.steps, args.warmup)
+        if cpu_job is not None:
+            result["cpu_baseline"] = cpu_job.result()
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

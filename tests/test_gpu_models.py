@@ -140,25 +140,45 @@ def test_batch_of_one_and_odd_batches(cls, nans):
         assert rel(got, want.numpy()) <= RTOL
 
 
-@pytest.mark.parametrize("cls,nans", [("cor2", 2000), ("oda", 3000)])
-def test_baseline_batch_against_oracle(cls, nans):
-    """BASELINE configs[1] size -- 512 samples of 36 x 2048 regions -- through the whole head, eval mode (the dropout masks are
-    the one thing the two sides cannot share): logits and EVERY parameter gradient against the restatement of the reference
-    run in float64 on the CPU.  At this size the model dispatches to the kernels the benchmark times (rank-folded K4 on the
-    register-tile engine, the fused relation + projection node and its in-tile data gradient, the single-launch K3
-    backward, K2 on the 4x4 MFMA), which the B = 4 reference goldens do not reach.
+# ---- the heads at the BASELINE batch (512 x 36 x 2048) against the float64 restatement -------------------------------------
+EPS_EDGE = 3e-5        # a relu pre-activation closer to zero than this (float64 run) makes its sample a "knife-edge" sample
+KEEP_MIN = {"cor2": 0.4, "oda": 0.7}   # share of the 512 samples that must be free of them (measured: ~0.45 / ~0.78)
+RTOL_EDGE_MAX = 3e-2   # knife-edge samples: max-abs error of a gradient tensor, on the tensor's own scale ...
+RTOL_EDGE_FRO = 1e-2   # ... and its relative Frobenius error (a handful of flipped units does not move the norm)
+VARIANTS = [("cor2", 2000, "default"), ("cor2", 2000, "pairwise"), ("cor2", 2000, "k4_engine"), ("oda", 3000, "default")]
+_oracle_cache = {}
 
-    Among the 6-11 million relu pre-activations of such a batch a few dozen lie within float32 rounding of zero, and which
-    side they fall on decides whether that unit's gradient exists: there the reference's own float32 arithmetic is 2e-3
-    (CoR2 compress_v2) to 2e-2 (one unit of an ODA glimpse layer) away from its float64 value, and so is any float32
-    implementation.  The samples that own such a pre-activation (|x| < EPS in the float64 run) are left out of the LOSS on both
-    sides -- the batch that runs through the kernels is still 512 -- and samples are independent, so what remains is
-    compared at RTOL."""
-    B, EPS = 512, 3e-5
-    model = build(cls, nans)
-    o64 = seeded.load_state({"cor2": RF.CoR2Oracle, "oda": RF.ODAOracle}[cls](nans), 0).eval().double()
-    v, q, a = seeded.seeded_inputs(B, answers=nans, seed=512)
-    got = model({"v": torch.from_numpy(v).to(dev()), "q_idxes": torch.from_numpy(q).to(dev())})
+
+def build_variant(cls, nans, variant, monkeypatch):
+    """default = what bench.py times; pairwise = relation_mode 0 (the relation tensor built from every (i,j) term);
+    k4_engine = the Mutan fusion in its R-GEMM form on the LDS tile engine (VQA_K4_FORM=engine)."""
+    from vqa_playground_pytorch_amd import ops
+    if variant == "k4_engine":
+        monkeypatch.setattr(ops, "_K4_FORM", "engine")
+    return build(cls, nans, **({"relation_mode": 0} if variant == "pairwise" else {}))
+
+
+def oracle_at_512(cls, nans, v, q, a, key, masks=None):
+    """The float64 restatement over the batch, 64 samples at a time (the reference's [B,N,N,2048] relation tensor is 11 GB in
+    float64 at B = 512; the loss is a sum over samples, so chunk gradients add up).  -> logits, the mask of the samples
+    free of knife-edge relu units, and TWO gradient sets: of the loss over those samples, and of the loss over the rest.
+    masks: {site: mask tensor [B, ...]} switches the restatement's own dropout off and multiplies every Drop* layer's
+    input by the given mask (training-mode comparison).  Cached per key: the variants of one head share it."""
+    if key in _oracle_cache:
+        return _oracle_cache[key]
+    B = v.shape[0]
+    o64 = seeded.load_state({"cor2": RF.CoR2Oracle, "oda": RF.ODAOracle}[cls](nans), 0)
+    o64 = (o64.train() if masks is not None else o64.eval()).double()
+    rng = [0, 0]
+    if masks is not None:
+        sites = 0
+        for name, mod in o64.named_modules():
+            if isinstance(mod, (RF.DropLinear, RF.DropConv1x1)):
+                assert mod.p == 0.5 and name in masks, name
+                mod.p = None                                    # (its own F.dropout off: the site's input is masked by the hook)
+                mod.register_forward_pre_hook(lambda _m, args, name=name: (args[0] * masks[name][rng[0]:rng[1]].double(),))
+                sites += 1
+        assert sites == len(masks) == {"cor2": 19, "oda": 9}[cls]
     closest = []
     activate = RF._activate
 
@@ -167,43 +187,101 @@ def test_baseline_batch_against_oracle(cls, nans):
             closest.append(x.detach().abs().reshape(x.size(0), -1).amin(1))
         return activate(x, af, dim)
 
-    # the float64 side takes the batch 64 samples at a time (the reference's [B,N,N,2048] relation tensor is 11 GB in
-    # float64 at B = 512); the loss is a sum over samples, so the chunks' gradients add up in .grad
+    params = [p for _, p in o64.named_parameters()]
+    g_keep = [torch.zeros_like(p) for p in params]
+    g_edge = [torch.zeros_like(p) for p in params]
     RF._activate = spy
     keep, want = [], []
     try:
         for lo in range(0, B, 64):
+            rng[0], rng[1] = lo, lo + 64
             del closest[:]
             w64 = o64({"v": torch.from_numpy(v[lo:lo + 64]).double(), "q": torch.from_numpy(q[lo:lo + 64]).double()})
             assert len(closest) >= 4
-            k = torch.stack(closest).amin(0) >= EPS
-            RF.kld_sum_loss(w64[k], torch.from_numpy(a[lo:lo + 64]).double()[k]).backward()
+            k = torch.stack(closest).amin(0) >= EPS_EDGE
+            t64 = torch.from_numpy(a[lo:lo + 64]).double()
+            for sel, acc in ((k, g_keep), (~k, g_edge)):
+                if bool(sel.any()):
+                    gs = torch.autograd.grad(RF.kld_sum_loss(w64[sel], t64[sel]), params, retain_graph=True, allow_unused=True)
+                    for dst, g in zip(acc, gs):
+                        if g is not None:
+                            dst.add_(g)
             keep.append(k)
             want.append(w64.detach())
     finally:
         RF._activate = activate
-    keep, want = torch.cat(keep), torch.cat(want)
-    assert got.shape == (B, nans)
+    names = [n for n, _ in o64.named_parameters()]
+    out = (torch.cat(want), torch.cat(keep), dict(zip(names, (g.numpy() for g in g_keep))),
+           dict(zip(names, (g.numpy() for g in g_edge))))
+    _oracle_cache[key] = out
+    return out
+
+
+def compare_at_512(cls, model, got, a, want, keep, g_keep, g_edge, tag):
+    """Logits on all 512 samples at RTOL; parameter gradients of the loss over the knife-edge-free samples at RTOL; and -- so
+    that no sample's gradient goes unverified -- of the loss over the knife-edge samples at the looser stated bars."""
+    B = got.shape[0]
     assert rel(got, want.numpy()) <= RTOL
-    assert int(keep.sum()) >= B // 8, int(keep.sum())     # (CoR2 keeps ~230, ODA ~400)
-    RF.kld_sum_loss(got[keep.to(dev())], torch.from_numpy(a)[keep].to(dev())).backward()
-    for (n, p), (_, p64) in zip(model.named_parameters(), o64.named_parameters()):
-        assert grad_err(p.grad, p64.grad.numpy(), ATOL_512) <= 1.0, (n, int(keep.sum()))
+    n_keep = int(keep.sum())
+    assert n_keep >= KEEP_MIN[cls] * B, (tag, n_keep)
+    kd = keep.to(dev())
+    at = torch.from_numpy(a).to(dev())
+    params = dict(model.named_parameters())
+    gs = torch.autograd.grad(RF.kld_sum_loss(got[kd], at[kd]), list(params.values()), retain_graph=True)
+    for (n, _), g in zip(params.items(), gs):
+        assert grad_err(g, g_keep[n], ATOL_512) <= 1.0, (tag, n, n_keep)
+    if n_keep < B:
+        gs = torch.autograd.grad(RF.kld_sum_loss(got[~kd], at[~kd]), list(params.values()))
+        worst = 0.0
+        for (n, _), g in zip(params.items(), gs):
+            g64 = g.detach().cpu().numpy().astype(np.float64)
+            w = g_edge[n]
+            assert np.isfinite(g64).all()
+            e_max = np.abs(g64 - w).max() / (RTOL_EDGE_MAX * np.abs(w).max() + ATOL_512)
+            e_fro = np.sqrt(((g64 - w) ** 2).sum()) / (RTOL_EDGE_FRO * np.sqrt((w ** 2).sum()) + ATOL_512 * np.sqrt(w.size))
+            assert e_max <= 1.0 and e_fro <= 1.0, (tag, n, B - n_keep, e_max, e_fro)
+            worst = max(worst, e_max * RTOL_EDGE_MAX)
+        print("[%s] knife-edge samples: %d of %d, worst max-abs gradient error %.2e of the tensor's scale" % (tag, B - n_keep, B, worst))
 
 
-@pytest.mark.parametrize("cls,nans", [("cor2", 2000), ("oda", 3000)])
-def test_training_step_with_shared_masks_against_oracle(cls, nans):
+@pytest.mark.parametrize("cls,nans,variant", VARIANTS)
+def test_baseline_batch_against_oracle(cls, nans, variant, monkeypatch):
+    """BASELINE configs[1] size -- 512 samples of 36 x 2048 regions -- through the whole head, eval mode (the dropout masks are
+    the one thing the two sides cannot share): logits and EVERY parameter gradient against the restatement of the reference
+    run in float64 on the CPU.  At this size the model dispatches to the kernels the benchmark times (rank-folded K4 on the
+    register-tile engine, the fused relation + projection node and its in-tile data gradient, the single-launch K3
+    backward, K2 on the 4x4 MFMA), which the B = 4 reference goldens do not reach; the `pairwise` and `k4_engine` variants
+    run the same comparison with the relation step's forward on the pairwise kernel and with K4 in its R-GEMM form.
+
+    Among the 6-11 million relu pre-activations of such a batch a few dozen lie within float32 rounding of zero, and which
+    side they fall on decides whether that unit's gradient exists: there the reference's own float32 arithmetic is 2e-3
+    (CoR2 compress_v2) to 2e-2 (one unit of an ODA glimpse layer) away from its float64 value, and so is any float32
+    implementation.  The samples that own such a pre-activation (|x| < EPS_EDGE in the float64 run) are split off: the
+    gradient of the loss over the other samples (>= 40 % of the batch for CoR2, >= 70 % for ODA, asserted) is compared at
+    RTOL, the gradient of the loss over the knife-edge samples at RTOL_EDGE_MAX of each tensor's scale and RTOL_EDGE_FRO in
+    the Frobenius norm.  Samples are independent and the batch that runs through the kernels is 512 in both passes."""
+    B = 512
+    model = build_variant(cls, nans, variant, monkeypatch)
+    v, q, a = seeded.seeded_inputs(B, answers=nans, seed=512)
+    got = model({"v": torch.from_numpy(v).to(dev()), "q_idxes": torch.from_numpy(q).to(dev())})
+    assert got.shape == (B, nans)
+    want, keep, g_keep, g_edge = oracle_at_512(cls, nans, v, q, a, (cls, "eval"))
+    compare_at_512(cls, model, got, a, want, keep, g_keep, g_edge, "%s/%s/eval" % (cls, variant))
+
+
+@pytest.mark.parametrize("cls,nans,variant", VARIANTS)
+def test_training_step_with_shared_masks_against_oracle(cls, nans, variant, monkeypatch):
     """The configuration the benchmark times -- CoR2 / ODA, 512 x 36 x 2048, TRAINING mode, dropout 0.5 at every site --
     against the float64 restatement of the reference fed the SAME masks.  Every mask of the HIP path is a pure function of
     (seed, element index) (`vqa_linear_dropout_mask` writes it for any [M,K] site), so the seeds the forward drew are
     enough to rebuild them: the restatement's own F.dropout is switched off and each Drop* layer's input is multiplied by the
     mask of the corresponding site instead.  Checks the wiring the per-kernel masked tests cannot: one seed per site, the
     site-to-mask layouts (four question projections sharing one draw, the gates' [2,B,310] draw, the pooled glimpses masked
-    inside K3 / inside the relation map, K2's one-bit mask over [B,N,N*L]), backward regenerating the forward's masks.  Knife-edge relu samples are left out of
-    the loss as in test_baseline_batch_against_oracle."""
+    inside K3 / inside the relation map, K2's one-bit mask over [B,N,N*L]), backward regenerating the forward's masks.  Knife-edge
+    relu samples are compared separately, as in test_baseline_batch_against_oracle; the variants are the same as there."""
     from vqa_playground_pytorch_amd import ops
-    B, N, EPS = 512, 36, 3e-5
-    model = build(cls, nans).train()
+    B, N = 512, 36
+    model = build_variant(cls, nans, variant, monkeypatch).train()
     v, q, a = seeded.seeded_inputs(B, answers=nans, seed=513)
     seeds, rec, orig = [], [], {}
     for name in ("next_dropout_seed", "dropout", "linear_act", "attention_logits", "softmax_attention_pool_drop",
@@ -284,43 +362,8 @@ def test_training_step_with_shared_masks_against_oracle(cls, nans):
         for g in range(4):
             masks["att.list_linear_v_fusion.%d" % g] = m[3][:, g]
 
-    o64 = seeded.load_state({"cor2": RF.CoR2Oracle, "oda": RF.ODAOracle}[cls](nans), 0).train().double()
-    rng = [0, 0]
-    sites = 0
-    for name, mod in o64.named_modules():
-        if isinstance(mod, (RF.DropLinear, RF.DropConv1x1)):
-            assert mod.p == 0.5 and name in masks, name
-            mod.p = None                                    # (its own F.dropout off: the site's input is masked by the hook)
-            mod.register_forward_pre_hook(lambda _m, args, name=name: (args[0] * masks[name][rng[0]:rng[1]].double(),))
-            sites += 1
-    assert sites == len(masks) == {"cor2": 19, "oda": 9}[cls]
-    closest = []
-    activate = RF._activate
-
-    def spy(x, af, dim):
-        if af == "relu":
-            closest.append(x.detach().abs().reshape(x.size(0), -1).amin(1))
-        return activate(x, af, dim)
-
-    RF._activate = spy
-    keep, want = [], []
-    try:
-        for lo in range(0, B, 64):
-            rng[0], rng[1] = lo, lo + 64
-            del closest[:]
-            w64 = o64({"v": torch.from_numpy(v[lo:lo + 64]).double(), "q": torch.from_numpy(q[lo:lo + 64]).double()})
-            k = torch.stack(closest).amin(0) >= EPS
-            RF.kld_sum_loss(w64[k], torch.from_numpy(a[lo:lo + 64]).double()[k]).backward()
-            keep.append(k)
-            want.append(w64.detach())
-    finally:
-        RF._activate = activate
-    keep, want = torch.cat(keep), torch.cat(want)
-    assert rel(got, want.numpy()) <= RTOL
-    assert int(keep.sum()) >= B // 8, int(keep.sum())
-    RF.kld_sum_loss(got[keep.to(dev())], torch.from_numpy(a)[keep].to(dev())).backward()
-    for (n, p), (_, p64) in zip(model.named_parameters(), o64.named_parameters()):
-        assert grad_err(p.grad, p64.grad.numpy(), ATOL_512) <= 1.0, (n, int(keep.sum()))
+    want, keep, g_keep, g_edge = oracle_at_512(cls, nans, v, q, a, (cls, "train", tuple(str(x) for x in seeds)), masks)
+    compare_at_512(cls, model, got, a, want, keep, g_keep, g_edge, "%s/%s/train" % (cls, variant))
 
 
 def test_cor2_100_regions_against_oracle():

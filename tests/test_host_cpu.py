@@ -226,3 +226,19 @@ def test_grad_slots_are_keyed_by_the_flat_buffer():
     finally:
         ops.set_grad_slots(p1, None)
         ops.set_grad_slots(p2, None)
+
+
+def test_bench_refuses_to_measure_fewer_gpus_than_asked():
+    """`bench.py --gpus N` without a launcher starts its own ranks and must fail loudly when the node has fewer than N
+    GPUs (here: none) instead of printing an n_gpus=1 line (missing #1)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VQA_ONE_GPU_REHEARSAL")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "only 0 GPU(s) visible" in r.stderr and "{" not in r.stdout
+    # and a launcher whose rank count disagrees with --gpus is refused as well
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode != 0 and "must agree" in r.stderr

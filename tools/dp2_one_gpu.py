@@ -5,8 +5,11 @@ second half -- on a single-GPU box.  Rank 0 prints ONE JSON line with the global
 
     python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/dp2_one_gpu.py
     python tools/dp2_one_gpu.py            # the same steps in one process on the whole batch (the expected record)
-  env: G=1|0 graph replay or kernel by kernel;  VQA_DP_OVERLAP=1: backward in two halves;  MODEL=cor2|oda
-(tests/test_gpu_dp2.py runs all combinations and compares them with the single-process record.)"""
+    NCCL1=1 python tools/dp2_one_gpu.py    # one process, a ONE-rank "nccl" (= RCCL) group, the all-reduce forced
+  env: G=1|0 graph replay or kernel by kernel;  VQA_DP_OVERLAP=1: backward in two halves (forced at world size 1);  MODEL=cor2|oda
+(tests/test_gpu_dp2.py runs all combinations and compares them with the single-process record; tests/test_gpu_nccl1.py
+runs the single-process steps with the all-reduce issued through a one-rank RCCL communicator and demands bit-identical
+results: RCCL init, the collective between the replayed graphs, the async work handle beside the second backward graph.)"""
 import json
 import os
 import sys
@@ -25,12 +28,23 @@ if multi:
 rank = dist.get_rank() if multi else 0
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
+nccl1 = not multi and os.environ.get("NCCL1") == "1"
+if nccl1:
+    import socket
+    with socket.socket() as _s:
+        _s.bind(("127.0.0.1", 0))
+        _port = _s.getsockname()[1]
+    os.environ["VQA_FORCE_ALLREDUCE"] = "1"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _port, rank=0, world_size=1, device_id=dev)
 torch.manual_seed(100 + rank)              # different initial weights per rank: the trainer broadcasts rank 0's
 cls = {"cor2": CoR2Model, "oda": ODAModel}[os.environ.get("MODEL", "cor2")]
 if rank == 0:
     torch.manual_seed(100)
 model = cls(["PAD"], 300).to(dev).eval()    # eval mode: no dropout, so N ranks on shards == 1 process on the batch
-tr = DataParallelTrainer(model, lr=1e-4, graph=os.environ.get("G", "1") == "1")
+split = os.environ.get("VQA_DP_OVERLAP", "0") == "1"
+tr = DataParallelTrainer(model, lr=1e-4, graph=os.environ.get("G", "1") == "1",
+                         overlap=("force" if not multi else True) if split else False)
 torch.manual_seed(5)
 v, q = torch.randn(8, 36, 2048, device=dev), torch.randn(8, 2400, device=dev)
 a = torch.softmax(torch.randn(8, 300, device=dev), 1)
@@ -49,7 +63,9 @@ if multi:
     assert torch.equal(w, w0), "replicas diverged"
 if rank == 0:
     print(json.dumps({"world": dist.get_world_size() if multi else 1, "graph": tr._graph is not None, "overlap": bool(tr.overlap),
+                      "reduce": bool(tr.reduce), "backend": dist.get_backend() if dist.is_initialized() else None,
+                      "graphs": sorted(k for k in (tr._graph or {}) if k in ("front", "front_a", "front_b", "tail")),
                       "losses": losses, "norms": norms, "weight_digest": float(w.double().sum().item())}), flush=True)
-if multi:
+if multi or nccl1:
     dist.barrier()
     dist.destroy_process_group()

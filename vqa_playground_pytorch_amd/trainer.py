@@ -209,6 +209,12 @@ class DataParallelTrainer:
         self.group = group
         self.clip = clip
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # the gradient all-reduce runs whenever there is more than one rank; VQA_FORCE_ALLREDUCE=1 also issues it in a
+        # process group of ONE rank (an identity), which is how a single-GPU box exercises the real RCCL path -- init, the
+        # collective between / beside the replayed hipGraphs, the async work handle (tests/test_gpu_nccl1.py)
+        import os as _os
+        self.reduce = self.world > 1 or (_os.environ.get("VQA_FORCE_ALLREDUCE") == "1" and dist.is_available()
+                                         and dist.is_initialized())
         if broadcast and self.world > 1:
             # identical initial weights on every rank, once (replaces DataParallel's per-step broadcast)
             for t in list(model.parameters()) + list(model.buffers()):
@@ -344,7 +350,7 @@ class DataParallelTrainer:
             finally:
                 f.end_backward()
             f.gather_grads()
-            if self.world > 1:
+            if self.reduce:
                 dist.all_reduce(f.g, op=dist.ReduceOp.SUM, group=self.group)
             ops.grad_norm_clip_coef(f.g, self.clip if self.clip else 0.0, f.norm_and_coef, f.workspace)
             ops.adam_step(f.p, f.g, f.m, f.v, f.norm_and_coef, lr, self.betas[0], self.betas[1], self.eps, self.adam_steps)
@@ -413,7 +419,7 @@ class DataParallelTrainer:
             seeds_before = ops.host_seed_draws
             self._set_step_scalars()
             loss = self._front(sample, target)
-            if self.world > 1:
+            if self.reduce:
                 dist.all_reduce(f.g, op=dist.ReduceOp.SUM, group=self.group)
             self._tail()
             self._eager_steps += 1
@@ -444,7 +450,7 @@ class DataParallelTrainer:
             g["target"].copy_(target, non_blocking=True)
         self._set_step_scalars()
         g["front"].replay()
-        if self.world > 1:
+        if self.reduce:
             dist.all_reduce(f.g, op=dist.ReduceOp.SUM, group=self.group)
         g["tail"].replay()
         return g["loss"], f.norm_and_coef[0]
@@ -464,7 +470,7 @@ class DataParallelTrainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         mode = "global"
-        if self.world > 1:
+        if self.reduce:
             # the collective library's watchdog thread polls events of outstanding work; let every rank drain its
             # work list first and capture in thread-local mode so another thread's query cannot invalidate the capture
             import time
@@ -532,12 +538,12 @@ class DataParallelTrainer:
         self.flat.store_grads(self._early, grads)
 
     def _reduce_late_async(self):
-        if self.world > 1:
+        if self.reduce:
             return dist.all_reduce(self.flat.g[:self._split], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return None
 
     def _reduce_early(self, pending):
-        if self.world > 1:
+        if self.reduce:
             dist.all_reduce(self.flat.g[self._split:], op=dist.ReduceOp.SUM, group=self.group)
         if pending is not None:
             pending.wait()
@@ -611,7 +617,7 @@ class DataParallelTrainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         mode = "global"
-        if self.world > 1:
+        if self.reduce:
             import time
             dist.barrier(group=self.group)
             torch.cuda.synchronize()
