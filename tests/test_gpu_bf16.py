@@ -168,6 +168,81 @@ def test_linear_bf16(ops, M, Kd, N, act):
     close_f32("d_b", bt.grad, db)
 
 
+@pytest.mark.parametrize("M,Kd,N", [(200, 2048, 310), (3600, 2048, 310), (12800, 2048, 310)])
+def test_linear_bf16_with_in_kernel_dropout(ops, M, Kd, N):
+    """compress_v in the mixed-precision training step: the p = 0.5 input dropout (config/CoR2.py:72-75) is applied while
+    the GEMM kernels stage x -- forward (NT, A operand) and weight gradient (TN, B operand) regenerate the same counter-hash
+    mask, which vqa_linear_dropout_mask exports for the oracle.  The gradients land in master-shaped tensors (cropped)."""
+    x = bf_round(seeded.seeded_array((M, Kd), 271))
+    w = bf_round(seeded.seeded_array((N, Kd), 272) / np.sqrt(Kd))
+    b = (0.1 * seeded.seeded_array((N,), 273)).astype(np.float32)
+    gy = bf_round(seeded.seeded_array((M, N), 274))
+    seed = 4242
+    xt, wt, bt = gbf(x), g32(w, True), g32(b, True)
+    y = ops.linear_bf16(xt, wt, bt, "relu", 0.5, seed)
+    mask = npy(ops.linear_dropout_mask(M, Kd, 0.5, seed, dev()))
+    assert set(np.unique(mask).tolist()) == {0.0, 2.0} and abs(mask.mean() - 1.0) < 0.02
+    xd = x.astype(np.float64) * mask
+    Np = ops.pad_to(N)
+    close_bf16("y", y[:, :N], K.linear_act_fwd(xd, w, b, "relu"))
+    assert float(y[:, N:].detach().float().abs().max()) == 0.0
+    gp = np.zeros((M, Np), np.float32)
+    gp[:, :N] = gy
+    y.backward(gbf(gp))
+    _, dw, db = K.linear_act_bwd(xd, w, npy(y[:, :N]), gy, "relu")
+    assert wt.grad.shape == (N, Kd) and wt.grad.is_contiguous()
+    close_f32("d_w", wt.grad, dw)
+    close_f32("d_b", bt.grad, db)
+
+
+def test_gemm_bf16_nt_gate_and_tn_groups(ops):
+    """The relu gate in the NT store (zero where gate <= 0, incl. -0 and negative values) and the grouped / cropped output of
+    the TN reduction (R padded ranks -> R master-shaped gradients)."""
+    M, N, Kd = 300, 320, 128
+    a = bf_round(seeded.seeded_array((M, Kd), 281))
+    b = bf_round(seeded.seeded_array((N, Kd), 282) / np.sqrt(Kd))
+    gate = bf_round(seeded.seeded_array((M, N), 283))
+    gate[::7, ::3] = 0.0
+    gate[1::7, 1::3] = -0.0
+    c = ops.gemm_bf16_nt(gbf(a), gbf(b), gate=gbf(gate))
+    ref = (a.astype(np.float64) @ b.astype(np.float64).T) * (gate > 0)
+    close_bf16("gated c", c, ref)
+    assert float(npy(c)[gate <= 0].__abs__().max()) == 0.0
+    Kr, R, Hp, H, Lp, L = 500, 2, 256, 250, 128, 70
+    ga = bf_round(seeded.seeded_array((Kr, R * Hp), 284))
+    xb = bf_round(seeded.seeded_array((Kr, Lp), 285))
+    outs = [torch.full((H, L), 9.0, device=dev()) for _ in range(R)]
+    ops.gemm_bf16_tn(gbf(ga), gbf(xb), outs=outs, out_rows=H, out_cols=L)
+    full = ga.astype(np.float64).T @ xb.astype(np.float64)
+    for r in range(R):
+        close_f32("group %d" % r, outs[r], full[r * Hp:r * Hp + H, :L])
+
+
+def test_shadow_plan_packs_like_the_single_kernels(ops):
+    """ops.ShadowPlan (one vqa_pack_many launch per step) fills the same bf16 / padded-fp32 shadows as the per-weight
+    pack_bf16 launches it replaces: padded, transposed-with-offset, and fp32 bias rows."""
+    w = [g32(seeded.seeded_array((10, 7), 291 + r)) for r in range(2)]
+    bias = [g32(seeded.seeded_array((10,), 295 + r)) for r in range(2)]
+    plan = ops.ShadowPlan()
+    wp = torch.zeros(2, 16, 64, device=dev(), dtype=torch.bfloat16)
+    wt = torch.zeros(64, 2 * 16, device=dev(), dtype=torch.bfloat16)
+    bp = torch.zeros(2, 16, device=dev())
+    for r in range(2):
+        plan.add(w[r], wp, 64, 1, offset=r * 16 * 64)
+        plan.add(w[r], wt, 1, 2 * 16, offset=r * 16)
+        plan.add(bias[r], bp, 16, 1, offset=r * 16)
+    plan.pack()
+    want_p, want_t = torch.zeros_like(wp), torch.zeros_like(wt)
+    for r in range(2):
+        ops.pack_bf16(w[r], want_p, 0, 64, 1, zero_fill=False, offset=r * 16 * 64)
+        ops.pack_bf16(w[r], want_t, 0, 1, 2 * 16, zero_fill=False, offset=r * 16)
+    assert torch.equal(wp, want_p) and torch.equal(wt, want_t)
+    assert torch.equal(bp[:, :10], torch.stack(bias)) and float(bp[:, 10:].abs().max()) == 0.0
+    w[0].mul_(2.0)                   # the masters moved on (an optimizer step): the next pack sees it
+    plan.pack()
+    assert torch.equal(wp[0, :10, :7].float(), w[0].to(torch.bfloat16).float())
+
+
 def test_pack_bf16(ops):
     w = seeded.seeded_array((3, 10, 7), 241).astype(np.float32)
     dst = torch.full((3, 16, 64), 7.0, device=dev(), dtype=torch.bfloat16)
@@ -213,6 +288,46 @@ def test_lowrank_bilinear_fusion_bf16(ops, B, N, L, H, R):
     assert Lp == L or float(xt.grad[..., L:].float().abs().max()) == 0.0
     close_f32("d_h2", h2t.grad, dh2, RTOL_MID)
     for r in range(R):
+        close_f32("d_w1[%d]" % r, ws[r].grad, dw1[r], RTOL_MID)
+        close_f32("d_b1[%d]" % r, bs[r].grad, db1[r], RTOL_MID)
+
+
+def test_lowrank_bilinear_fusion_bf16_gated_and_prepacked(ops):
+    """K4 bf16 with the shadows handed over by a ShadowPlan and the relu gate of the layer in front applied in the store of
+    the data gradient: same outputs / weight gradients, d_x = (x > 0) * d_x."""
+    B, N, L, H, R = 3, 36, 310, 510, 2
+    Lp, Hp = ops.pad_to(L), ops.pad_to(H, 256)
+    x = np.maximum(bf_round(seeded.seeded_array((B, N, L), 351)), 0)        # a relu output: about half zeros
+    w1 = bf_round(seeded.seeded_array((R, H, L), 352) / np.sqrt(L))
+    b1 = (0.1 * seeded.seeded_array((R, H), 353)).astype(np.float32)
+    h2 = seeded.seeded_array((B, R, H), 354).astype(np.float32)
+    gout = bf_round(seeded.seeded_array((B, N, H), 355))
+    xp = np.zeros((B, N, Lp), np.float32)
+    xp[..., :L] = x
+    ws = [g32(w1[r], True) for r in range(R)]
+    bs = [g32(b1[r], True) for r in range(R)]
+    plan = ops.ShadowPlan()
+    w1p = torch.zeros(R, Hp, Lp, device=dev(), dtype=torch.bfloat16)
+    b1p = torch.zeros(R, Hp, device=dev())
+    w1t = torch.zeros(Lp, R * Hp, device=dev(), dtype=torch.bfloat16)
+    for r in range(R):
+        plan.add(ws[r].detach(), w1p, Lp, 1, offset=r * Hp * Lp)
+        plan.add(bs[r].detach(), b1p, Hp, 1, offset=r * Hp)
+        plan.add(ws[r].detach(), w1t, 1, R * Hp, offset=r * Hp)
+    plan.pack()
+    xt, h2t = gbf(xp, True), g32(h2, True)
+    out = ops.lowrank_bilinear_fusion(xt, h2t, ws, bs, gate_dx=True, packed=(w1p, b1p, w1t))
+    ref, _ = K.lowrank_bilinear_fusion_fwd(x, w1, b1, h2)
+    close_bf16("out", out[..., :H], ref)
+    gp = np.zeros((B, N, Hp), np.float32)
+    gp[..., :H] = gout
+    out.backward(gbf(gp))
+    dx, dw1, db1, dh2 = K.lowrank_bilinear_fusion_bwd(x, w1, b1, h2, gout)
+    close_f32("d_x", xt.grad[..., :L], dx * (x > 0), RTOL_MID)
+    assert float(npy(xt.grad[..., :L])[x <= 0].__abs__().max()) == 0.0
+    close_f32("d_h2", h2t.grad, dh2, RTOL_MID)
+    for r in range(R):
+        assert ws[r].grad.shape == (H, L)
         close_f32("d_w1[%d]" % r, ws[r].grad, dw1[r], RTOL_MID)
         close_f32("d_b1[%d]" % r, bs[r].grad, db1[r], RTOL_MID)
 
@@ -277,6 +392,56 @@ def test_cor2_bf16_against_fp32_oracle(B, N, gemm):
             assert err <= GRAD_RELF and cos >= GRAD_COS, "%s: relative Frobenius error %.3e, cosine %.5f" % (n, err, cos)
     finally:
         layers.MyConv1d.bf16_gemm = old
+
+
+RTOL_AWARE = 2e-2     # against the bf16-AWARE oracle (oracle/mixed_precision.py: the same tensors rounded to bf16 at the same
+#                       points, forward and backward): max-abs error of each tensor on its own scale, and the relative
+#                       Frobenius error.  What is left between the two sides is fp32-vs-float64 accumulation straddling a
+#                       bf16 rounding boundary or a relu gate (measured values are printed by the test).
+
+
+@pytest.mark.parametrize("B,N", [(128, 100), (16, 36)])
+def test_cor2_bf16_at_size_against_bf16_aware_oracle(B, N):
+    """BASELINE configs[4] at the size it is benchmarked at -- one rank's share of batch 1024: B = 128 samples of 100 x 2048
+    regions, bf16 compute -- eval mode: logits, attention maps and EVERY parameter gradient against the bf16-aware
+    restatement at RTOL_AWARE (the comparison with the plain fp32 oracle is reported, not asserted: relu gates flipped by
+    bf16 roundings make it a 3-8 % Frobenius matter, see test_cor2_bf16_against_fp32_oracle)."""
+    from oracle import mixed_precision as MP
+    from oracle import reference_faithful as RF
+    nans = 2000
+    model = _build_cor2(nans, compute_dtype=torch.bfloat16)
+    aware = seeded.load_state(MP.CoR2MixedOracle(nans), 0).eval().double()
+    v, q, a = seeded.seeded_inputs(B, regions=N, answers=nans, seed=1024)
+    got = model({"v": torch.from_numpy(v).to(dev()), "q_idxes": torch.from_numpy(q).to(dev())})
+    assert got.dtype == torch.float32 and got.shape == (B, nans)
+    RF.kld_sum_loss(got, torch.from_numpy(a).to(dev())).backward()
+    want = []
+    for lo in range(0, B, 32):                 # float64 on the CPU, 32 samples at a time; the loss is a sum over samples
+        w = aware({"v": torch.from_numpy(v[lo:lo + 32]).double(), "q": torch.from_numpy(q[lo:lo + 32]).double()})
+        RF.kld_sum_loss(w, torch.from_numpy(a[lo:lo + 32]).double()).backward()
+        want.append(w.detach())
+        if lo == 0:
+            alpha2 = torch.cat(aware.alpha_dict["alpha2"], 2).detach().numpy()
+    want = torch.cat(want).numpy()
+    close_f32("logits", got, want, RTOL_AWARE)
+    k = min(B, 32)
+    close_f32("alpha2", torch.cat(model.alpha_dict["alpha2"], 2)[:k], alpha2[:k], RTOL_AWARE)
+    worst = (0.0, 0.0, "")
+    for (n, p), (_, po) in zip(model.named_parameters(), aware.named_parameters()):
+        ref = po.grad.numpy().astype(np.float64)
+        g = npy(p.grad)
+        assert np.isfinite(g).all(), n
+        scale = np.abs(ref).max()
+        if scale < 1e-7 * np.sqrt(B * N):          # mathematically-zero gradients (biases in front of the softmax)
+            assert np.abs(g).max() < 1e-5 * np.sqrt(B * N), n
+            continue
+        e_max = np.abs(g - ref).max() / scale
+        e_fro = np.sqrt(((g - ref) ** 2).sum()) / np.sqrt((ref ** 2).sum())
+        assert e_max <= RTOL_AWARE and e_fro <= RTOL_AWARE, "%s: max-abs %.3e of scale, Frobenius %.3e" % (n, e_max, e_fro)
+        if e_max > worst[0]:
+            worst = (e_max, e_fro, n)
+    print("[cor2 bf16 B=%d N=%d] logits rel err %.2e; worst gradient: %s max-abs %.2e, Frobenius %.2e"
+          % (B, N, np.abs(npy(got) - want).max() / np.abs(want).max(), worst[2], worst[0], worst[1]))
 
 
 def test_cor2_bf16_train_steps():

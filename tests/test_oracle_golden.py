@@ -279,3 +279,29 @@ def test_golden_recipe_regenerates_committed_fixtures(golden_dir, tmp_path):
         assert sorted(new.files) == sorted(old.files)
         for k in new.files:
             assert np.array_equal(new[k], old[k]), (name, k)
+
+
+def test_mixed_precision_oracle_is_anchored_to_the_pinned_one():
+    """oracle/mixed_precision.py (the checker of the bf16 configuration) with its roundings switched off computes the same
+    function as the reference-faithful restatement above -- logits, attention maps and every parameter gradient, float64,
+    1e-9 -- and with them on stays within bf16 distance of it.  This is what ties the bf16 GPU tests to the reference."""
+    import torch
+    from oracle import mixed_precision as MP
+    v, q, a = (torch.from_numpy(x).double() for x in seeded.seeded_inputs(3, answers=120, seed=9))
+    ref = seeded.load_state(RF.CoR2Oracle(120), 0).eval().double()
+    exact = seeded.load_state(MP.CoR2MixedOracle(120, rounding=False), 0).eval().double()
+    rounded = seeded.load_state(MP.CoR2MixedOracle(120, rounding=True), 0).eval().double()
+    out = {}
+    for name, m in (("ref", ref), ("exact", exact), ("rounded", rounded)):
+        lo = m({"v": v, "q": q})
+        RF.kld_sum_loss(lo, a).backward()
+        out[name] = (lo.detach(), {n: p.grad.clone() for n, p in m.named_parameters()},
+                     torch.cat(m.alpha_dict["alpha2"], 2).detach())
+
+    def rel(x, y):
+        return float((x - y).abs().max() / y.abs().max().clamp_min(1e-30))
+
+    assert rel(out["exact"][0], out["ref"][0]) < 1e-9 and rel(out["exact"][2], out["ref"][2]) < 1e-9
+    for n, g in out["ref"][1].items():
+        assert float((out["exact"][1][n] - g).abs().max()) <= 1e-9 * float(g.abs().max()) + 1e-12, n
+    assert 1e-6 < rel(out["rounded"][0], out["ref"][0]) < 3e-2        # really rounds, and only by bf16-sized amounts

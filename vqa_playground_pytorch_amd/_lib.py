@@ -88,13 +88,18 @@ SIGNATURES = {
     "vqa_softmax_attention_pool_bwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_pack_bf16": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_f, _c_l, _c_l, _c_l, _c_sz, _c_i, _c_st]),
     "vqa_gemm_bf16_nt": (_c_i, [_c_f, _c_i, _c_f, _c_i, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_pack_many": (_c_i, [_c_f, _c_i, _c_sz, _c_st]),
+    "vqa_gemm_bf16_nt_ex": (_c_i, [_c_f, _c_i, _c_f, _c_i, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_i,
+                                   _c_fl, _c_u64, _c_f, _c_st]),
+    "vqa_gemm_bf16_tn_ex": (_c_i, [_c_f, _c_i, _c_f, _c_i, _c_pp, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_sz,
+                                   _c_i, _c_i, _c_i, _c_fl, _c_u64, _c_f, _c_st]),
     "vqa_gemm_bf16_tn_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i]),
     "vqa_gemm_bf16_tn": (_c_i, [_c_f, _c_i, _c_f, _c_i, _c_f, _c_f, _c_sz, _c_i, _c_i, _c_i, _c_st]),
     "vqa_lowrank_bilinear_fusion_fwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
                                                     _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_lowrank_bilinear_fusion_bwd_bf16_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i, _c_i, _c_i]),
-    "vqa_lowrank_bilinear_fusion_bwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz,
-                                                    _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_lowrank_bilinear_fusion_bwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_pp, _c_pp, _c_f, _c_f, _c_sz,
+                                                    _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_gru_gates_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_f, _c_f, _c_f, _c_f,
                                  _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_gru_gates_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_f, _c_f,

@@ -59,7 +59,43 @@ class Model(nn.Module):
         # gradient can apply the relu gate in its store (ops.lowrank_bilinear_fusion, gate_dx) and the projections' backward
         # kernels run ungated.  Measured at B = 512 (profiles/README.md): what the projections save (25 us) the fusion's
         # epilogue pays back in dependent loads of the gate (2 x 13 us) -- off by default, VQA_FUSE_RELU_GATE=1 turns it on.
-        self.compress_v.grad_pregated = self.compress_v2.grad_pregated = os.environ.get("VQA_FUSE_RELU_GATE", "0") == "1"
+        # (bf16: the gate rides in the 16-byte row stores of K4's data-gradient GEMM for free -- always on there)
+        self.compress_v.grad_pregated = self.compress_v2.grad_pregated = \
+            os.environ.get("VQA_FUSE_RELU_GATE", "0") == "1" or self.compute_dtype == torch.bfloat16
+        self._plan = None
+
+    def _bf16_shadows(self):
+        """The bf16 / padded-fp32 shadows of the region-side masters (compress_v, compress_v2, the two region fusions), all
+        packed by ONE kernel (ops.ShadowPlan): -> {layer: the `packed` tuple its op takes}.  Called at the top of every
+        mixed-precision forward; the backward of the same step reads the transposed ones."""
+        if self._plan is None or self._plan_dev != self.compress_v.conv.weight.device:
+            plan, shad = ops.ShadowPlan(), {}
+            for name in ("compress_v", "compress_v2"):
+                conv = getattr(self, name).conv
+                out_f, in_f = conv.weight.shape[0], conv.weight.shape[1]
+                Np, Kp = ops.pad_to(out_f), ops.pad_to(in_f)
+                wp = plan.add(conv.weight, ops._shadow(conv.weight, (Np, Kp), "nk"), Kp)
+                bp = plan.add(conv.bias, ops._shadow(conv.bias, (Np,), "b", torch.float32), Np)
+                wpt = None
+                if name == "compress_v2":       # (compress_v reads the model input: no data gradient, no W^T)
+                    wpt = plan.add(conv.weight, ops._shadow(conv.weight, (Kp, Np), "kn"), 1, Np)
+                shad[name] = (wp, bp, wpt)
+            for name in ("fusion_vq1", "fusion_vq2"):
+                mf = getattr(self, name)
+                R, H, L = mf.R, mf.hidden_dim, mf.input_dim1
+                Hp, Lp = ops.pad_to(H, 256), ops.pad_to(L)
+                w0 = mf.list_linear1[0].linear.weight
+                w1p = ops._shadow(w0, (R, Hp, Lp), "k4")
+                b1p = ops._shadow(mf.list_linear1[0].linear.bias, (R, Hp), "k4b", torch.float32)
+                w1t = ops._shadow(w0, (Lp, R * Hp), "k4t")
+                for r, lin in enumerate(mf.list_linear1):
+                    plan.add(lin.linear.weight, w1p, Lp, 1, offset=r * Hp * Lp)
+                    plan.add(lin.linear.bias, b1p, Hp, 1, offset=r * Hp)
+                    plan.add(lin.linear.weight, w1t, 1, R * Hp, offset=r * Hp)      # w1t[l, r*Hp + h] = W1_r[h, l]
+                shad[name] = (w1p, b1p, w1t)
+            self._plan, self._shad, self._plan_dev = plan, shad, self.compress_v.conv.weight.device
+        self._plan.pack()
+        return self._shad
 
     def late_parameters(self):
         """Parameters of the second reasoning step.  Their gradients are complete once backward has walked from the loss
@@ -104,9 +140,11 @@ class Model(nn.Module):
             v_feature = v_feature.to(self.compute_dtype)
         q_feature = question_feature(self.seq2vec, sample["q_idxes"] if "q_idxes" in sample else sample["q"])
 
+        shad = self._bf16_shadows() if v_feature.dtype == torch.bfloat16 and v_feature.is_cuda else {}
         q_feature_low, q_final, q_gate_1, q_gate_2 = self.question_projections(q_feature)
-        v_feature_low = self.compress_v(v_feature)
-        fuse1 = self.fusion_vq1(v_feature_low, q_feature_low, relu_input=self.compress_v.grad_pregated)
+        v_feature_low = self.compress_v(v_feature, packed=shad.get("compress_v"))
+        fuse1 = self.fusion_vq1(v_feature_low, q_feature_low, relu_input=self.compress_v.grad_pregated,
+                                packed=shad.get("fusion_vq1"))
         v1_att, alpha1, alpha1_full, pooled1_first = self.att1.attend(v_feature, self.att1.conv_att.pre_activation(fuse1),
                                                                 return_pooled=True)
         if _cut is not None:
@@ -145,8 +183,9 @@ class Model(nn.Module):
                                                          ops.next_dropout_seed() if p else 0, cv2.grad_pregated, pairwise)
             else:
                 v2_dropped = ops.relation_apply(v_feature, t, c2, p, ops.next_dropout_seed() if p else 0)
-                v2_feature_low = cv2(v2_dropped, predropped=True)
-            fuse2 = self.fusion_vq2(v2_feature_low, q_feature_low, relu_input=self.compress_v2.grad_pregated)
+                v2_feature_low = cv2(v2_dropped, predropped=True, packed=shad.get("compress_v2"))
+            fuse2 = self.fusion_vq2(v2_feature_low, q_feature_low, relu_input=self.compress_v2.grad_pregated,
+                                    packed=shad.get("fusion_vq2"))
             v2_att, alpha2, _ = self.att2.attend(v_feature, self.att2.conv_att.pre_activation(fuse2),
                                                  lambda pooled, pd: ops.relation_apply(
                                                      pooled, t, c2, pd, ops.next_dropout_seed() if pd else 0))
@@ -164,8 +203,9 @@ class Model(nn.Module):
             # pairwise form: every (i, j) term of the relation tensor summed in the kernel, as the reference structures it;
             # v2 has two consumers, each gets its own alias (see ops.pairwise_relation_reduce)
             v2_feature, v2_for_pooling = self.relation_reduce(v_feature, q_gate_1, q_gate_2, alpha1_full)
-            v2_feature_low = self.compress_v2(v2_feature)
-            fuse2 = self.fusion_vq2(v2_feature_low, q_feature_low, relu_input=self.compress_v2.grad_pregated)
+            v2_feature_low = self.compress_v2(v2_feature, packed=shad.get("compress_v2"))
+            fuse2 = self.fusion_vq2(v2_feature_low, q_feature_low, relu_input=self.compress_v2.grad_pregated,
+                                    packed=shad.get("fusion_vq2"))
             v2_att, alpha2, _ = self.att2.attend(v2_for_pooling, self.att2.conv_att.pre_activation(fuse2))
             feature = v2_feature[:, 0:2, :].detach().float()
 

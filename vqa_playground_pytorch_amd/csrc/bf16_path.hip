@@ -66,32 +66,46 @@ static BfTileChoice choose_bf_tile_tn(long N1, long N2) {
   } while (0)
 
 // ------------------------------------------------------------------------------------- generic NT
-// C[M,N] (bf16, row stride ldc) = act(A[M,K] * B[N,K]^T + bias[N]);  act: 0 none, 1 relu
-template <int BM, int BN>
+// C[M,N] (bf16, row stride ldc) = act(scale * XA(A)[M,K] * B[N,K]^T + bias[N]);  act: 0 none, 1 relu.
+// XA: operand transform on A while it is staged (BfDropHalf: the p = 0.5 input dropout of MyConv1d, config/CoR2.py:72-75,
+// whose factor 2 is `scale`).  gate (optional, [M, ldg] bf16): the stored value is zeroed where gate[m,n] <= 0 -- the relu
+// gradient of the layer that produced `gate`, applied where its data gradient is written.
+template <int BM, int BN, class XA>
 __global__ __launch_bounds__(kBfThreads) void gemm_bf16_nt_kernel(const bf16* __restrict__ A, int lda,
                                                                   const bf16* __restrict__ B, int ldb,
                                                                   const float* __restrict__ bias, bf16* __restrict__ C,
-                                                                  int ldc, int M, int N, int K, int act, int tiles_n) {
+                                                                  int ldc, int M, int N, int K, int act, int tiles_n,
+                                                                  float scale, const bf16* __restrict__ gate, int ldg,
+                                                                  DropCfg dc, uint32_t mask_ld) {
   using T = BfTile<BM, BN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
   f32x16 acc[T::TM][T::TN];
   bf_zero_acc(acc);
-  gemm_bf16_nt_tile<BM, BN>(A, lda, M, B, ldb, N, m0, n0, K, smem, acc);
+  if constexpr (XA::kActive) {
+    gemm_bf16_nt_tile<BM, BN, XA>(A, lda, M, B, ldb, N, m0, n0, K, smem, acc, XA{drop_key(dc), mask_ld});
+  } else {
+    gemm_bf16_nt_tile<BM, BN>(A, lda, M, B, ldb, N, m0, n0, K, smem, acc);
+  }
   const BfAccCoord<BM, BN> cc(m0, n0);
-  if (n0 + BN <= N && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
+  if (n0 + BN <= N && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+      (gate == nullptr || ((ldg & 7) == 0 && (reinterpret_cast<uintptr_t>(gate) & 15) == 0))) {
     // whole column tile inside the matrix: coalesced 16-byte row stores through an LDS image (the staging ring is idle)
     float bv[T::TN];
 #pragma unroll
     for (int tn = 0; tn < T::TN; ++tn) bv[tn] = bias != nullptr ? bias[cc.col(tn)] : 0.f;
-    BfTileStore<BM, BN>::run(smem, C + (size_t)m0 * ldc + n0, ldc, M - m0, [&](int tm, int tn, int i) {
-      const float y = acc[tm][tn][i] + bv[tn];
-      return act == 1 ? fmaxf(y, 0.f) : y;
-    });
+    BfTileStore<BM, BN>::run(
+        smem, C + (size_t)m0 * ldc + n0, ldc, M - m0,
+        [&](int tm, int tn, int i) {
+          const float y = fmaf(acc[tm][tn][i], scale, bv[tn]);
+          return act == 1 ? fmaxf(y, 0.f) : y;
+        },
+        gate != nullptr ? gate + (size_t)m0 * ldg + n0 : nullptr, (size_t)ldg);
     return;
   }
   const unsigned lo = cc.loff(ldc);
+  const unsigned lg = cc.loff(ldg);
 #pragma unroll
   for (int tn = 0; tn < T::TN; ++tn) {
     const int col = cc.col(tn);
@@ -101,9 +115,12 @@ __global__ __launch_bounds__(kBfThreads) void gemm_bf16_nt_kernel(const bf16* __
       for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          float y = acc[tm][tn][i] + bv;
+          float y = fmaf(acc[tm][tn][i], scale, bv);
           if (act == 1) y = fmaxf(y, 0.f);
-          if (cc.row(tm, i) < M) (C + cc.uoff(tm, tn, i, ldc))[lo] = (bf16)y;
+          if (cc.row(tm, i) < M) {
+            if (gate != nullptr && !((float)(gate + cc.uoff(tm, tn, i, ldg))[lg] > 0.f)) y = 0.f;
+            (C + cc.uoff(tm, tn, i, ldc))[lo] = (bf16)y;
+          }
         }
     }
   }
@@ -111,11 +128,14 @@ __global__ __launch_bounds__(kBfThreads) void gemm_bf16_nt_kernel(const bf16* __
 
 // ------------------------------------------------------------------------------------- generic TN
 // slab[s][N1][N2] (fp32) = A[rows of split s, 0:N1)^T * B[rows of split s, 0:N2)
-template <int BM, int BN>
+// XB: operand transform on B while it is staged (BfDropHalf: B is the dropped-out input of the layer whose weight gradient
+// this is; the factor 2 is applied by the slab reduction).
+template <int BM, int BN, class XB>
 __global__ __launch_bounds__(kBfThreads) void gemm_bf16_tn_kernel(const bf16* __restrict__ A, int lda,
                                                                   const bf16* __restrict__ B, int ldb,
                                                                   float* __restrict__ slab, int Kdim, int N1, int N2,
-                                                                  int rows_per_split, int tiles_n) {
+                                                                  int rows_per_split, int tiles_n, DropCfg dc,
+                                                                  uint32_t mask_ld) {
   using T = BfTile<BM, BN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -124,7 +144,11 @@ __global__ __launch_bounds__(kBfThreads) void gemm_bf16_tn_kernel(const bf16* __
   const int k_lo = s * rows_per_split, k_hi = min(Kdim, k_lo + rows_per_split);
   f32x16 acc[T::TM][T::TN];
   bf_zero_acc(acc);
-  gemm_bf16_tn_tile<BM, BN>(A, lda, N1, B, ldb, N2, m0, n0, k_lo, k_hi, smem, acc);
+  if constexpr (XB::kActive) {
+    gemm_bf16_tn_tile<BM, BN, XB>(A, lda, N1, B, ldb, N2, m0, n0, k_lo, k_hi, smem, acc, XB{drop_key(dc), mask_ld});
+  } else {
+    gemm_bf16_tn_tile<BM, BN>(A, lda, N1, B, ldb, N2, m0, n0, k_lo, k_hi, smem, acc);
+  }
   float* __restrict__ dst = slab + (size_t)s * N1 * N2;
   const BfAccCoord<BM, BN> cc(m0, n0);
   const unsigned lo = cc.loff(N2);
@@ -140,14 +164,29 @@ __global__ __launch_bounds__(kBfThreads) void gemm_bf16_tn_kernel(const bf16* __
   }
 }
 
-// out[e] = sum_s slab[s][e]   (fixed order: bitwise reproducible); count % 4 == 0
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
-                                                          size_t count, int S) {
-  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (e >= count) return;
-  float4 a = ld4(slab + e);
-  for (int s = 1; s < S; ++s) a = add4(a, ld4(slab + (size_t)s * count + e));
-  st4(out + e, a);
+// Fixed-order (bitwise reproducible) reduction of the S slabs [N1, N2], written CROPPED and per group: row n1 = g * gp + r
+// (r < out_rows) goes to outs[g][r * out_ld + c] for c < out_cols, times `scale`.  One group with gp = N1 is the plain
+// case; K4 hands R groups (one nn.Linear weight gradient each), a padded layer a single cropped one -- the gradients land
+// in the master-shaped tensors the optimizer reads, with no slice / copy kernels behind the GEMM.
+struct BfOuts {
+  float* p[kBfMaxR];
+};
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, BfOuts outs, int S, int N1, int N2,
+                                                          int gp, int out_rows, int out_cols, int out_ld, float scale) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 2;
+  const int n1 = blockIdx.y;
+  const int g = n1 / gp, r = n1 - g * gp;
+  if (c >= out_cols || r >= out_rows) return;
+  const size_t e = (size_t)n1 * N2 + c, count = (size_t)N1 * N2;
+  float2 a = ld2(slab + e);
+  for (int s = 1; s < S; ++s) {
+    const float2 t = ld2(slab + (size_t)s * count + e);
+    a.x += t.x;
+    a.y += t.y;
+  }
+  float* o = outs.p[g] + (size_t)r * out_ld + c;
+  o[0] = a.x * scale;
+  if (c + 1 < out_cols) o[1] = a.y * scale;
 }
 
 static int tn_splits(int Kdim, int N1, int N2, BfTileChoice t) {
@@ -161,49 +200,78 @@ static int tn_splits(int Kdim, int N1, int N2, BfTileChoice t) {
 }
 static BfTileChoice tn_tile(int N1, int N2) { return choose_bf_tile_tn(N1, N2); }
 
+struct NtExtra {          // optional parts of an NT launch
+  float scale = 1.f;      // factor on the accumulator (1/(1-p) of a dropout applied to A)
+  const bf16* gate = nullptr;
+  int ldg = 0;
+  bool drop = false;      // A is dropped out in its p = 0.5 one-bit form while staged
+  DropCfg dc{};
+  uint32_t mask_ld = 0;
+};
+
 static int launch_nt(const char* who, const bf16* A, int lda, const bf16* B, int ldb, const float* bias, bf16* C, int ldc,
-                     int M, int N, int K, int act, hipStream_t s) {
+                     int M, int N, int K, int act, hipStream_t s, const NtExtra& ex = NtExtra()) {
   const BfTileChoice t = choose_bf_tile(M, N, K);
   const int tiles_m = (M + t.bm - 1) / t.bm, tiles_n = (N + t.bn - 1) / t.bn;
-#define LAUNCH(BM_, BN_)                                                                                                 \
-  {                                                                                                                      \
-    const size_t lds = BfTile<BM_, BN_>::kSmemBytes;                                                                     \
-    VQA_ENSURE_LDS((gemm_bf16_nt_kernel<BM_, BN_>), lds);                                                                \
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM_, BN_>), dim3(tiles_m * tiles_n), dim3(kBfThreads), lds, s, A, lda, B, ldb, \
-                       bias, C, ldc, M, N, K, act, tiles_n);                                                             \
+#define LAUNCH_X(BM_, BN_, XA_)                                                                                            \
+  {                                                                                                                        \
+    const size_t lds = BfTile<BM_, BN_>::kSmemBytes;                                                                       \
+    VQA_ENSURE_LDS((gemm_bf16_nt_kernel<BM_, BN_, XA_>), lds);                                                             \
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM_, BN_, XA_>), dim3(tiles_m * tiles_n), dim3(kBfThreads), lds, s, A, lda, B, \
+                       ldb, bias, C, ldc, M, N, K, act, tiles_n, ex.scale, ex.gate, ex.ldg, ex.dc, ex.mask_ld);            \
+  }
+#define LAUNCH(BM_, BN_)                   \
+  if (ex.drop) {                           \
+    LAUNCH_X(BM_, BN_, BfDropHalf)         \
+  } else {                                 \
+    LAUNCH_X(BM_, BN_, BfNoTransform)      \
   }
   VQA_BF_TILE_SWITCH(t, LAUNCH);
 #undef LAUNCH
+#undef LAUNCH_X
   return check_launch(who);
 }
 
-static size_t tn_workspace_bytes(int Kdim, int N1, int N2) {
+static size_t tn_workspace_bytes(int Kdim, int N1, int N2) {   // always at least one slab: the reduction also crops
   const int S = tn_splits(Kdim, N1, N2, tn_tile(N1, N2));
-  return S > 1 ? (size_t)S * N1 * N2 * sizeof(float) : 0;
+  return (size_t)S * N1 * N2 * sizeof(float);
 }
 
-// C[N1,N2] fp32 dense.  workspace: tn_workspace_bytes (may be null when that is 0)
-static int launch_tn(const char* who, const bf16* A, int lda, const bf16* B, int ldb, float* C, float* workspace, int Kdim,
-                     int N1, int N2, hipStream_t s) {
+struct TnExtra {
+  float scale = 1.f;
+  bool drop = false;      // B is dropped out (p = 0.5 one-bit form) while staged
+  DropCfg dc{};
+  uint32_t mask_ld = 0;
+};
+
+// outs: `groups` output matrices [out_rows, out_cols] (row stride out_ld); row n1 of the product belongs to group n1 / gp.
+static int launch_tn(const char* who, const bf16* A, int lda, const bf16* B, int ldb, const BfOuts& outs, int groups, int gp,
+                     int out_rows, int out_cols, int out_ld, float* workspace, int Kdim, int N1, int N2, hipStream_t s,
+                     const TnExtra& ex = TnExtra()) {
   const BfTileChoice t = tn_tile(N1, N2);
   const int S = tn_splits(Kdim, N1, N2, t);
   const int tiles_m = (N1 + t.bm - 1) / t.bm, tiles_n = (N2 + t.bn - 1) / t.bn;
   int rows_per_split = (Kdim + S - 1) / S;
   rows_per_split = (rows_per_split + kBfBK - 1) / kBfBK * kBfBK;
-  float* dst = S > 1 ? workspace : C;
-#define LAUNCH(BM_, BN_)                                                                                                    \
+#define LAUNCH_X(BM_, BN_, XB_)                                                                                             \
   {                                                                                                                         \
     const size_t lds = BfTile<BM_, BN_>::kSmemBytes;                                                                        \
-    VQA_ENSURE_LDS((gemm_bf16_tn_kernel<BM_, BN_>), lds);                                                                   \
-    hipLaunchKernelGGL((gemm_bf16_tn_kernel<BM_, BN_>), dim3(tiles_m * tiles_n, 1, S), dim3(kBfThreads), lds, s, A, lda, B, ldb, \
-                       dst, Kdim, N1, N2, rows_per_split, tiles_n);                                                         \
+    VQA_ENSURE_LDS((gemm_bf16_tn_kernel<BM_, BN_, XB_>), lds);                                                              \
+    hipLaunchKernelGGL((gemm_bf16_tn_kernel<BM_, BN_, XB_>), dim3(tiles_m * tiles_n, 1, S), dim3(kBfThreads), lds, s, A, lda, \
+                       B, ldb, workspace, Kdim, N1, N2, rows_per_split, tiles_n, ex.dc, ex.mask_ld);                        \
+  }
+#define LAUNCH(BM_, BN_)                   \
+  if (ex.drop) {                           \
+    LAUNCH_X(BM_, BN_, BfDropHalf)         \
+  } else {                                 \
+    LAUNCH_X(BM_, BN_, BfNoTransform)      \
   }
   VQA_BF_TILE_SWITCH(t, LAUNCH);
 #undef LAUNCH
-  if (S > 1) {
-    const size_t count = (size_t)N1 * N2;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s, workspace, C, count, S);
-  }
+#undef LAUNCH_X
+  (void)groups;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((out_cols + 511) / 512), (unsigned)N1), dim3(256), 0, s, workspace,
+                     outs, S, N1, N2, gp, out_rows, out_cols, out_ld, ex.scale);
   return check_launch(who);
 }
 
@@ -320,8 +388,9 @@ __global__ __launch_bounds__(256) void bilinear_bwd_prep_bf16_kernel(const bf16*
 
 // db1[r][h] = sum_b h2[b,r,h] * gsum[b,h].  256 lanes = 64 columns x 4 sample slices (a serial loop over B per
 // column is a chain of B dependent L2 round trips: 36 us at B = 128); slices meet in LDS, fixed order.
+// (db1: one output vector per rank, Hout <= H values each -- the nn.Linear bias gradients themselves)
 __global__ __launch_bounds__(256) void bilinear_db_bf16_kernel(const float* __restrict__ h2, const float* __restrict__ gsum,
-                                                               float* __restrict__ db1, int B, int H, int R) {
+                                                               BfOuts db1, int B, int H, int R, int Hout) {
   __shared__ float part[3][64];
   const int c = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + c;  // < R*H: H % 256 == 0
@@ -338,7 +407,7 @@ __global__ __launch_bounds__(256) void bilinear_db_bf16_kernel(const float* __re
   const float a = (a0 + a1) + (a2 + a3);
   if (slice > 0) part[slice - 1][c] = a;
   __syncthreads();
-  if (slice == 0) db1[e] = a + part[0][c] + part[1][c] + part[2][c];
+  if (slice == 0 && h < Hout) db1.p[e / H][h] = a + part[0][c] + part[1][c] + part[2][c];
 }
 
 // fp32 [batch, rows, cols] -> bf16 at dst[b*sb + r*sr + c*sc]  (dst zero-filled beforehand: the pads)
@@ -351,6 +420,31 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
   const int r = (int)(t % rows);
   const size_t b = t / rows;
   dst[b * sb + (size_t)r * sr + (size_t)c * sc] = (bf16)src[e];
+}
+
+// Every bf16 / padded-fp32 shadow of a step's master weights in ONE launch.  table[j] = {src (fp32 [rows, cols] dense),
+// dst, rows, cols, dst row stride, dst column stride (elements), dst kind (0 bf16, 1 fp32), first flat element of the
+// job}; the jobs' elements are numbered consecutively and a thread finds its job by scanning the (short) table.
+struct PackJob {
+  const float* src;
+  void* dst;
+  long long rows, cols, row_stride, col_stride, kind, first;
+};
+__global__ __launch_bounds__(256) void pack_many_kernel(const PackJob* __restrict__ table, int jobs, size_t total) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  int j = 0;
+  while (j + 1 < jobs && (size_t)table[j + 1].first <= e) ++j;
+  const PackJob job = table[j];
+  const size_t local = e - (size_t)job.first;
+  const long long r = (long long)(local / (size_t)job.cols), c = (long long)(local % (size_t)job.cols);
+  const float v = job.src[local];
+  const size_t o = (size_t)(r * job.row_stride + c * job.col_stride);
+  if (job.kind == 0) {
+    static_cast<bf16*>(job.dst)[o] = (bf16)v;
+  } else {
+    static_cast<float*>(job.dst)[o] = v;
+  }
 }
 
 static int check_k4(const char* who, int B, int N, int L, int H, int R) {
@@ -388,17 +482,55 @@ extern "C" int vqa_pack_bf16(const float* src, int batch, int rows, int cols, vq
   return check_launch("pack_bf16");
 }
 
-extern "C" int vqa_gemm_bf16_nt(const vqa_bf16_t* a, int lda, const vqa_bf16_t* b, int ldb, const float* bias,
-                                vqa_bf16_t* c, int ldc, int M, int N, int K, int act, vqa_stream_t stream) {
-  VQA_REQUIRE(a && b && c, VQA_E_BADARG, "gemm_bf16_nt: null pointer");
-  VQA_REQUIRE(M > 0 && N > 0 && K > 0, VQA_E_BADARG, "gemm_bf16_nt: bad sizes M=%d N=%d K=%d", M, N, K);
-  VQA_REQUIRE(act == 0 || act == 1, VQA_E_BADARG, "gemm_bf16_nt: act must be 0 (none) or 1 (relu), got %d", act);
+extern "C" int vqa_pack_many(const void* table, int jobs, size_t total, vqa_stream_t stream) {
+  VQA_REQUIRE(table != nullptr && jobs > 0 && total > 0, VQA_E_BADARG, "pack_many: empty job table");
+  VQA_REQUIRE(aligned(table, 8), VQA_E_UNSUPPORTED, "pack_many: the table must be 8-byte aligned");
+  hipLaunchKernelGGL(pack_many_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const PackJob*>(table), jobs, total);
+  return check_launch("pack_many");
+}
+
+static int check_nt(const char* who, const void* a, int lda, const void* b, int ldb, const void* c, int ldc, int M, int N, int K,
+                    int act) {
+  VQA_REQUIRE(a && b && c, VQA_E_BADARG, "%s: null pointer", who);
+  VQA_REQUIRE(M > 0 && N > 0 && K > 0, VQA_E_BADARG, "%s: bad sizes M=%d N=%d K=%d", who, M, N, K);
+  VQA_REQUIRE(act == 0 || act == 1, VQA_E_BADARG, "%s: act must be 0 (none) or 1 (relu), got %d", who, act);
   VQA_REQUIRE(K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K && ldc >= N && aligned(a, 16) &&
                   aligned(b, 16),
-              VQA_E_UNSUPPORTED, "gemm_bf16_nt: needs K %% 64 == 0, lda/ldb %% 8 == 0 and 16-byte aligned a/b (K=%d lda=%d ldb=%d)",
+              VQA_E_UNSUPPORTED, "%s: needs K %% 64 == 0, lda/ldb %% 8 == 0 and 16-byte aligned a/b (K=%d lda=%d ldb=%d)", who,
               K, lda, ldb);
+  return VQA_OK;
+}
+
+extern "C" int vqa_gemm_bf16_nt(const vqa_bf16_t* a, int lda, const vqa_bf16_t* b, int ldb, const float* bias,
+                                vqa_bf16_t* c, int ldc, int M, int N, int K, int act, vqa_stream_t stream) {
+  const int rc = check_nt("gemm_bf16_nt", a, lda, b, ldb, c, ldc, M, N, K, act);
+  if (rc != VQA_OK) return rc;
   return launch_nt("gemm_bf16_nt", reinterpret_cast<const bf16*>(a), lda, reinterpret_cast<const bf16*>(b), ldb, bias,
                    reinterpret_cast<bf16*>(c), ldc, M, N, K, act, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int vqa_gemm_bf16_nt_ex(const vqa_bf16_t* a, int lda, const vqa_bf16_t* b, int ldb, const float* bias,
+                                   vqa_bf16_t* c, int ldc, int M, int N, int K, int act, const vqa_bf16_t* gate, int ldg,
+                                   float p_drop, uint64_t seed, const uint64_t* seed_ptr, vqa_stream_t stream) {
+  const int rc = check_nt("gemm_bf16_nt_ex", a, lda, b, ldb, c, ldc, M, N, K, act);
+  if (rc != VQA_OK) return rc;
+  VQA_REQUIRE(gate == nullptr || ldg >= N, VQA_E_BADARG, "gemm_bf16_nt_ex: gate row stride %d < N=%d", ldg, N);
+  VQA_REQUIRE(p_drop == 0.f || p_drop == 0.5f, VQA_E_UNSUPPORTED,
+              "gemm_bf16_nt_ex: the in-kernel input dropout exists in its one-bit form only (p_drop 0 or 0.5, got %f)", (double)p_drop);
+  VQA_REQUIRE(p_drop == 0.f || ((long)M * lda < (1L << 32) && lda == K), VQA_E_UNSUPPORTED,
+              "gemm_bf16_nt_ex: dropout needs a dense a (lda == K) of fewer than 2^32 elements");
+  NtExtra ex;
+  ex.gate = reinterpret_cast<const bf16*>(gate);
+  ex.ldg = ldg;
+  if (p_drop > 0.f) {
+    ex.drop = true;
+    ex.dc = make_drop(p_drop, seed, seed_ptr);
+    ex.scale = ex.dc.scale;
+    ex.mask_ld = (uint32_t)lda;
+  }
+  return launch_nt("gemm_bf16_nt_ex", reinterpret_cast<const bf16*>(a), lda, reinterpret_cast<const bf16*>(b), ldb, bias,
+                   reinterpret_cast<bf16*>(c), ldc, M, N, K, act, static_cast<hipStream_t>(stream), ex);
 }
 
 extern "C" size_t vqa_gemm_bf16_tn_workspace_bytes(int K, int N1, int N2) {
@@ -406,18 +538,63 @@ extern "C" size_t vqa_gemm_bf16_tn_workspace_bytes(int K, int N1, int N2) {
   return tn_workspace_bytes(K, N1, N2);
 }
 
+static int check_tn(const char* who, const void* a, int lda, const void* b, int ldb, const void* workspace,
+                    size_t workspace_bytes, int K, int N1, int N2) {
+  VQA_REQUIRE(a && b, VQA_E_BADARG, "%s: null pointer", who);
+  VQA_REQUIRE(K > 0 && N1 > 0 && N2 > 0, VQA_E_BADARG, "%s: bad sizes K=%d N1=%d N2=%d", who, K, N1, N2);
+  VQA_REQUIRE(N1 % 8 == 0 && N2 % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= N1 && ldb >= N2 && aligned(a, 16) &&
+                  aligned(b, 16),
+              VQA_E_UNSUPPORTED, "%s: needs N1, N2, lda, ldb %% 8 == 0 and 16-byte aligned pointers", who);
+  const size_t need = tn_workspace_bytes(K, N1, N2);
+  VQA_REQUIRE(workspace_bytes >= need && workspace && aligned(workspace, 16), VQA_E_BADARG,
+              "%s: workspace of %zu B is too small (needs %zu)", who, workspace_bytes, need);
+  return VQA_OK;
+}
+
 extern "C" int vqa_gemm_bf16_tn(const vqa_bf16_t* a, int lda, const vqa_bf16_t* b, int ldb, float* c, void* workspace,
                                 size_t workspace_bytes, int K, int N1, int N2, vqa_stream_t stream) {
-  VQA_REQUIRE(a && b && c, VQA_E_BADARG, "gemm_bf16_tn: null pointer");
-  VQA_REQUIRE(K > 0 && N1 > 0 && N2 > 0, VQA_E_BADARG, "gemm_bf16_tn: bad sizes K=%d N1=%d N2=%d", K, N1, N2);
-  VQA_REQUIRE(N1 % 8 == 0 && N2 % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= N1 && ldb >= N2 && aligned(a, 16) &&
-                  aligned(b, 16) && aligned(c, 16),
-              VQA_E_UNSUPPORTED, "gemm_bf16_tn: needs N1, N2, lda, ldb %% 8 == 0 and 16-byte aligned pointers");
-  const size_t need = tn_workspace_bytes(K, N1, N2);
-  VQA_REQUIRE(workspace_bytes >= need && (need == 0 || (workspace && aligned(workspace, 16))), VQA_E_BADARG,
-              "gemm_bf16_tn: workspace of %zu B is too small (needs %zu)", workspace_bytes, need);
-  return launch_tn("gemm_bf16_tn", reinterpret_cast<const bf16*>(a), lda, reinterpret_cast<const bf16*>(b), ldb, c,
-                   static_cast<float*>(workspace), K, N1, N2, static_cast<hipStream_t>(stream));
+  VQA_REQUIRE(c != nullptr, VQA_E_BADARG, "gemm_bf16_tn: null pointer");
+  const int rc = check_tn("gemm_bf16_tn", a, lda, b, ldb, workspace, workspace_bytes, K, N1, N2);
+  if (rc != VQA_OK) return rc;
+  BfOuts outs{};
+  outs.p[0] = c;
+  return launch_tn("gemm_bf16_tn", reinterpret_cast<const bf16*>(a), lda, reinterpret_cast<const bf16*>(b), ldb, outs, 1, N1,
+                   N1, N2, N2, static_cast<float*>(workspace), K, N1, N2, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int vqa_gemm_bf16_tn_ex(const vqa_bf16_t* a, int lda, const vqa_bf16_t* b, int ldb, float* const* outs, int groups,
+                                   int rows_per_group, int out_rows, int out_cols, int out_ld, void* workspace,
+                                   size_t workspace_bytes, int K, int N1, int N2, float p_drop, uint64_t seed,
+                                   const uint64_t* seed_ptr, vqa_stream_t stream) {
+  VQA_REQUIRE(outs != nullptr && groups >= 1 && groups <= kBfMaxR, VQA_E_BADARG, "gemm_bf16_tn_ex: 1..%d output groups", kBfMaxR);
+  const int rc = check_tn("gemm_bf16_tn_ex", a, lda, b, ldb, workspace, workspace_bytes, K, N1, N2);
+  if (rc != VQA_OK) return rc;
+  VQA_REQUIRE(rows_per_group > 0 && groups * rows_per_group <= N1 && out_rows > 0 && out_rows <= rows_per_group &&
+                  out_cols > 0 && out_cols <= N2 && out_ld >= out_cols,
+              VQA_E_BADARG, "gemm_bf16_tn_ex: output window %d x %d (stride %d) of %d groups x %d rows does not fit [%d,%d]",
+              out_rows, out_cols, out_ld, groups, rows_per_group, N1, N2);
+  VQA_REQUIRE(p_drop == 0.f || p_drop == 0.5f, VQA_E_UNSUPPORTED,
+              "gemm_bf16_tn_ex: the in-kernel dropout of b exists in its one-bit form only (p_drop 0 or 0.5, got %f)", (double)p_drop);
+  VQA_REQUIRE(p_drop == 0.f || ((long)K * ldb < (1L << 32) && ldb % 32 == 0), VQA_E_UNSUPPORTED,
+              "gemm_bf16_tn_ex: dropout needs ldb %% 32 == 0 and fewer than 2^32 elements");
+  BfOuts o{};
+  for (int g = 0; g < groups; ++g) {
+    VQA_REQUIRE(outs[g] != nullptr, VQA_E_BADARG, "gemm_bf16_tn_ex: null output %d", g);
+    o.p[g] = outs[g];
+  }
+  TnExtra ex;
+  if (p_drop > 0.f) {
+    ex.drop = true;
+    ex.dc = make_drop(p_drop, seed, seed_ptr);
+    ex.scale = ex.dc.scale;
+    ex.mask_ld = (uint32_t)ldb;
+  }
+  // rows past groups * rows_per_group (if any) belong to no group: the reduction skips them (r >= out_rows for g >= groups
+  // cannot happen because N1 / gp < kBfMaxR is not guaranteed -- so clamp by requiring an exact cover)
+  VQA_REQUIRE(groups * rows_per_group == N1, VQA_E_BADARG, "gemm_bf16_tn_ex: groups * rows_per_group must equal N1");
+  return launch_tn("gemm_bf16_tn_ex", reinterpret_cast<const bf16*>(a), lda, reinterpret_cast<const bf16*>(b), ldb, o, groups,
+                   rows_per_group, out_rows, out_cols, out_ld, static_cast<float*>(workspace), K, N1, N2,
+                   static_cast<hipStream_t>(stream), ex);
 }
 
 extern "C" int vqa_lowrank_bilinear_fusion_fwd_bf16(const vqa_bf16_t* x, const vqa_bf16_t* w1, const float* b1,
@@ -456,21 +633,29 @@ extern "C" size_t vqa_lowrank_bilinear_fusion_bwd_bf16_workspace_bytes(int B, in
 
 extern "C" int vqa_lowrank_bilinear_fusion_bwd_bf16(const vqa_bf16_t* x, const vqa_bf16_t* w1t, const float* h2,
                                                     const vqa_bf16_t* h1, const vqa_bf16_t* g, vqa_bf16_t* d_x,
-                                                    float* d_w1, float* d_b1, float* d_h2, void* workspace,
-                                                    size_t workspace_bytes, int B, int N, int L, int H, int R,
-                                                    vqa_stream_t stream) {
+                                                    float* const* d_w1, float* const* d_b1, float* d_h2, void* workspace,
+                                                    size_t workspace_bytes, int B, int N, int L, int H, int R, int H_out,
+                                                    int L_out, int gate_dx, vqa_stream_t stream) {
   VQA_REQUIRE(x && h2 && h1 && g && d_w1 && d_b1 && d_h2 && workspace, VQA_E_BADARG,
               "lowrank_bilinear_fusion_bwd_bf16: null pointer");
   VQA_REQUIRE(d_x == nullptr || w1t != nullptr, VQA_E_BADARG, "lowrank_bilinear_fusion_bwd_bf16: d_x needs w1t");
   int rc = check_k4("lowrank_bilinear_fusion_bwd_bf16", B, N, L, H, R);
   if (rc != VQA_OK) return rc;
+  VQA_REQUIRE(H_out > 0 && H_out <= H && L_out > 0 && L_out <= L, VQA_E_BADARG,
+              "lowrank_bilinear_fusion_bwd_bf16: master shape [%d,%d] exceeds the padded one [%d,%d]", H_out, L_out, H, L);
   VQA_REQUIRE(workspace_bytes >= vqa_lowrank_bilinear_fusion_bwd_bf16_workspace_bytes(B, N, L, H, R), VQA_E_BADARG,
               "lowrank_bilinear_fusion_bwd_bf16: workspace of %zu B is too small", workspace_bytes);
   VQA_REQUIRE(aligned(x, 16) && aligned(g, 16) && aligned(h1, 16) && aligned(h2, 16) && aligned(workspace, 256) &&
-                  aligned(d_w1, 16) && aligned(d_h2, 16) && (d_x == nullptr || (aligned(d_x, 16) && aligned(w1t, 16))),
+                  aligned(d_h2, 16) && (d_x == nullptr || (aligned(d_x, 16) && aligned(w1t, 16))),
               VQA_E_UNSUPPORTED, "lowrank_bilinear_fusion_bwd_bf16: tensors must be 16-byte aligned (workspace 256)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int M = B * N, RH = R * H;
+  BfOuts dw{}, db{};
+  for (int r = 0; r < R; ++r) {
+    VQA_REQUIRE(d_w1[r] != nullptr && d_b1[r] != nullptr, VQA_E_BADARG, "lowrank_bilinear_fusion_bwd_bf16: null gradient %d", r);
+    dw.p[r] = d_w1[r];
+    db.p[r] = d_b1[r];
+  }
   char* ws = static_cast<char*>(workspace);
   bf16* gs = reinterpret_cast<bf16*>(ws);
   float* gsum = reinterpret_cast<float*>(ws + k4_gs_bytes(B, N, H, R));
@@ -482,12 +667,17 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd_bf16(const vqa_bf16_t* x, const v
     hipLaunchKernelGGL(bilinear_bwd_prep_bf16_kernel<4>, dim3(H / 256, B), dim3(256), 0, s, reinterpret_cast<const bf16*>(g),
                        reinterpret_cast<const bf16*>(h1), h2, gs, d_h2, gsum, N, H, R);
   }
-  hipLaunchKernelGGL(bilinear_db_bf16_kernel, dim3(RH / 64), dim3(256), 0, s, h2, gsum, d_b1, B, H, R);
+  hipLaunchKernelGGL(bilinear_db_bf16_kernel, dim3(RH / 64), dim3(256), 0, s, h2, gsum, db, B, H, R, H_out);
   if (d_x != nullptr) {
+    NtExtra ex;
+    if (gate_dx) {   // x is the relu output of the layer in front: its gradient gate rides in this store
+      ex.gate = reinterpret_cast<const bf16*>(x);
+      ex.ldg = L;
+    }
     rc = launch_nt("lowrank_bilinear_fusion_bwd_bf16(dx)", gs, RH, reinterpret_cast<const bf16*>(w1t), RH, nullptr,
-                   reinterpret_cast<bf16*>(d_x), L, M, L, RH, 0, s);
+                   reinterpret_cast<bf16*>(d_x), L, M, L, RH, 0, s, ex);
     if (rc != VQA_OK) return rc;
   }
-  return launch_tn("lowrank_bilinear_fusion_bwd_bf16(dw)", gs, RH, reinterpret_cast<const bf16*>(x), L, d_w1, slabs, M, RH, L,
-                   s);
+  return launch_tn("lowrank_bilinear_fusion_bwd_bf16(dw)", gs, RH, reinterpret_cast<const bf16*>(x), L, dw, R, H, H_out, L_out,
+                   L_out, slabs, M, RH, L, s);
 }

@@ -37,6 +37,32 @@ struct BfTile {
   static constexpr int kSmemBytes = 2 * kStageBytes;
 };
 
+// Operand transforms applied while a chunk of 8 consecutive bf16 of one source row travels from its registers into LDS.
+// `row` is the (clamped) source row, `col` the first of the 8 columns.
+struct BfNoTransform {
+  static constexpr bool kActive = false;
+  __device__ __forceinline__ u32x4 operator()(u32x4 v, int, int) const { return v; }
+};
+// p = 0.5 dropout of a row-major [rows, ld] tensor in the library's one-bit counter-hash form (common.hpp: keep element e
+// iff bit e & 31 of mask_word32(e >> 5, key) is set).  Only ZEROES the dropped elements: the factor 1/(1-p) = 2 is uniform
+// and is applied to the accumulator by the kernel's epilogue.  ld % 8 == 0, so a chunk's 8 bits sit in one hash word.
+struct BfDropHalf {
+  static constexpr bool kActive = true;
+  uint32_t key;
+  uint32_t ld;
+  __device__ __forceinline__ u32x4 operator()(u32x4 v, int row, int col) const {
+    const uint32_t e = (uint32_t)row * ld + (uint32_t)col;
+    const uint32_t bits = mask_word32(e >> 5, key) >> (e & 31u);
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t lo = (bits >> (2 * i)) & 1u, hi = (bits >> (2 * i + 1)) & 1u;
+      o[i] = v[i] & (((0u - lo) & 0x0000FFFFu) | ((0u - hi) & 0xFFFF0000u));
+    }
+    return o;
+  }
+};
+
 // MFMA side of one stage: all fragments of LDS stage `base`, then the TM x TN x 4 MFMAs.
 template <int BM, int BN>
 __device__ __forceinline__ void bf_stage_mfma(const char* base, f32x16 (&acc)[BM / 64][BN / 64]) {
@@ -70,10 +96,14 @@ struct NtStager {
   int oa[T::CA], ob[T::CB];  // element offsets of the (clamped) source rows
   int lds_a, lds_b;          // byte offsets of chunk 0 in an LDS stage; chunk p is 32 rows further
   int nsteps;
+  int arow0, acol0;          // first A row of this thread (chunk p: + 32 p, clamped to a_rows - 1) / its column inside a stage
+  int a_last;
   __device__ __forceinline__ NtStager(const bf16* A, int lda, int a_rows, const bf16* B, int ldb, int b_rows, int m0, int n0,
                                       int K)
-      : a(A), b(B), nsteps(K / kBfBK) {
+      : a(A), b(B), nsteps(K / kBfBK), a_last(a_rows - 1) {
     const int row = threadIdx.x >> 3, kc = threadIdx.x & 7;
+    arow0 = m0 + row;
+    acol0 = kc * 8;
 #pragma unroll
     for (int p = 0; p < T::CA; ++p) oa[p] = min(m0 + row + 32 * p, a_rows - 1) * lda + kc * 8;
 #pragma unroll
@@ -88,9 +118,14 @@ struct NtStager {
 #pragma unroll
     for (int p = 0; p < T::CB; ++p) rb[p] = *reinterpret_cast<const u32x4*>(b + ob[p] + k0);
   }
-  __device__ __forceinline__ void store(const u32x4 (&ra)[T::CA], const u32x4 (&rb)[T::CB], char* base) const {
+  // `step`: the K stage these registers hold (the A transform sees the chunk's source row and first column)
+  template <class XA>
+  __device__ __forceinline__ void store(const u32x4 (&ra)[T::CA], const u32x4 (&rb)[T::CB], char* base, int step,
+                                        const XA& xa) const {
+    const int col = min(step, nsteps - 1) * kBfBK + acol0;
 #pragma unroll
-    for (int p = 0; p < T::CA; ++p) *reinterpret_cast<u32x4*>(base + lds_a + p * 32 * kBfPitch) = ra[p];
+    for (int p = 0; p < T::CA; ++p)
+      *reinterpret_cast<u32x4*>(base + lds_a + p * 32 * kBfPitch) = xa(ra[p], min(arow0 + 32 * p, a_last), col);
 #pragma unroll
     for (int p = 0; p < T::CB; ++p) *reinterpret_cast<u32x4*>(base + lds_b + p * 32 * kBfPitch) = rb[p];
   }
@@ -109,27 +144,27 @@ __device__ __forceinline__ void bf_interleave() {
 
 // acc += A[m0 : m0+BM, 0 : K) * B[n0 : n0+BN, 0 : K)^T.  K % 64 == 0; element offsets must fit 31 bits.  Two register
 // sets run the global loads two stages ahead of the MFMAs.  Ends on a barrier (LDS reusable at once).
-template <int BM, int BN>
+template <int BM, int BN, class XA = BfNoTransform>
 __device__ __forceinline__ void gemm_bf16_nt_tile(const bf16* __restrict__ A, int lda, int a_rows,
                                                   const bf16* __restrict__ B, int ldb, int b_rows, int m0, int n0, int K,
-                                                  char* smem, f32x16 (&acc)[BM / 64][BN / 64]) {
+                                                  char* smem, f32x16 (&acc)[BM / 64][BN / 64], const XA& xa = XA()) {
   using T = BfTile<BM, BN>;
   const NtStager<BM, BN> st(A, lda, a_rows, B, ldb, b_rows, m0, n0, K);
   u32x4 ra0[T::CA], rb0[T::CB], ra1[T::CA], rb1[T::CB];
   st.load(ra0, rb0, 0);
-  st.store(ra0, rb0, smem);
+  st.store(ra0, rb0, smem, 0, xa);
   st.load(ra1, rb1, 1);  // stage 1 -> set 1, stage 2 -> set 0, ...
   st.load(ra0, rb0, 2);
   __syncthreads();
   for (int s = 0; s < st.nsteps; s += 2) {
     bf_stage_mfma<BM, BN>(smem, acc);
-    st.store(ra1, rb1, smem + T::kStageBytes);
+    st.store(ra1, rb1, smem + T::kStageBytes, s + 1, xa);
     st.load(ra1, rb1, s + 3);
     bf_interleave<4 * T::TM * T::TN, 4>();
     __syncthreads();
     if (s + 1 < st.nsteps) {
       bf_stage_mfma<BM, BN>(smem + T::kStageBytes, acc);
-      st.store(ra0, rb0, smem);
+      st.store(ra0, rb0, smem, s + 2, xa);
       st.load(ra0, rb0, s + 4);
       bf_interleave<4 * T::TM * T::TN, 4>();
       __syncthreads();
@@ -156,6 +191,8 @@ template <int BM, int BN>
 struct TnStager {
   const bf16* src;  // first element of this thread's column block, row 0
   int ld, kb, lds_off, k_lo, k_hi;
+  int col0;         // first source column of this thread's block
+  bool is_b;        // the block belongs to the B operand (transforms apply to B only)
   __device__ __forceinline__ TnStager(const bf16* A, int lda, int a_cols, const bf16* B, int ldb, int b_cols, int m0, int n0,
                                       int k_lo_, int k_hi_)
       : k_lo(k_lo_), k_hi(k_hi_) {
@@ -168,6 +205,8 @@ struct TnStager {
     const int mb = ob >> 3;
     ld = is_a ? lda : ldb;
     const int col = min((is_a ? m0 : n0) + mb * 8, (is_a ? a_cols : b_cols) - 8);
+    col0 = col;
+    is_b = !is_a;
     src = (is_a ? A : B) + col;
     lds_off = ((is_a ? 0 : BM) + mb * 8) * kBfPitch + kb * 16;
   }
@@ -176,13 +215,21 @@ struct TnStager {
 #pragma unroll
     for (int j = 0; j < 8; ++j) r[j] = *reinterpret_cast<const uint4*>(src + (size_t)min(k0 + j, k_hi - 1) * ld);
   }
-  __device__ __forceinline__ void store(const uint4 (&r)[8], int step, char* base) const {
+  template <class XB>
+  __device__ __forceinline__ void store(const uint4 (&r)[8], int step, char* base, const XB& xb) const {
     const int k0 = k_lo + step * kBfBK + kb * 8;
     uint4 m[8], t[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const bool ok = k0 + j < k_hi;
       m[j] = make_uint4(ok ? r[j].x : 0u, ok ? r[j].y : 0u, ok ? r[j].z : 0u, ok ? r[j].w : 0u);
+      if constexpr (XB::kActive) {
+        if (is_b) {   // (wave-uniform: a wave's 64 threads stage blocks of one operand)
+          const u32x4 v = {m[j].x, m[j].y, m[j].z, m[j].w};
+          const u32x4 o = xb(v, min(k0 + j, k_hi - 1), col0);
+          m[j] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+      }
     }
     transpose8x8_b16(m, t);
 #pragma unroll
@@ -192,28 +239,29 @@ struct TnStager {
 
 // acc += A[k_lo : k_hi, m0 : m0+BM)^T * B[k_lo : k_hi, n0 : n0+BN).  a_cols / b_cols: widths of A / B (multiples of 8,
 // >= 8).  Rows >= k_hi contribute zero.  Ends on a barrier.
-template <int BM, int BN>
+template <int BM, int BN, class XB = BfNoTransform>
 __device__ __forceinline__ void gemm_bf16_tn_tile(const bf16* __restrict__ A, int lda, int a_cols,
                                                   const bf16* __restrict__ B, int ldb, int b_cols, int m0, int n0,
-                                                  int k_lo, int k_hi, char* smem, f32x16 (&acc)[BM / 64][BN / 64]) {
+                                                  int k_lo, int k_hi, char* smem, f32x16 (&acc)[BM / 64][BN / 64],
+                                                  const XB& xb = XB()) {
   using T = BfTile<BM, BN>;
   const TnStager<BM, BN> st(A, lda, a_cols, B, ldb, b_cols, m0, n0, k_lo, k_hi);
   const int nsteps = (k_hi - k_lo + kBfBK - 1) / kBfBK;
   uint4 r0[8], r1[8];
   st.load(r0, 0);
-  st.store(r0, 0, smem);
+  st.store(r0, 0, smem, xb);
   st.load(r1, 1);
   st.load(r0, 2);
   __syncthreads();
   for (int s = 0; s < nsteps; s += 2) {
     bf_stage_mfma<BM, BN>(smem, acc);
-    st.store(r1, s + 1, smem + T::kStageBytes);
+    st.store(r1, s + 1, smem + T::kStageBytes, xb);
     st.load(r1, s + 3);
     bf_interleave<4 * T::TM * T::TN, 8>();
     __syncthreads();
     if (s + 1 < nsteps) {
       bf_stage_mfma<BM, BN>(smem + T::kStageBytes, acc);
-      st.store(r0, s + 2, smem);
+      st.store(r0, s + 2, smem, xb);
       st.load(r0, s + 4);
       bf_interleave<4 * T::TM * T::TN, 8>();
       __syncthreads();
@@ -254,8 +302,11 @@ template <int BM, int BN>
 struct BfTileStore {
   static constexpr int kPitch = BN * 2 + 16;
   static constexpr int kBytes = BM * kPitch;
+  // gate (optional, same tile origin as dst, row stride ldg, 16-byte aligned rows): elements whose gate value is not > 0
+  // are stored as zero (a relu gradient applied in the store)
   template <class F>
-  __device__ __forceinline__ static void run(char* tile_s, bf16* __restrict__ dst, size_t ld, int rows_valid, F value) {
+  __device__ __forceinline__ static void run(char* tile_s, bf16* __restrict__ dst, size_t ld, int rows_valid, F value,
+                                             const bf16* __restrict__ gate = nullptr, size_t ldg = 0) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = (wave >> 1) * (BM / 2) + 4 * (lane >> 5), c0 = (wave & 1) * (BN / 2) + (lane & 31);
 #pragma unroll
@@ -274,8 +325,19 @@ struct BfTileStore {
 #pragma unroll
     for (int p = 0; p < BM / RPP; ++p) {
       const int row = p * RPP + cr;
-      if (row < rows_valid)
-        *reinterpret_cast<u32x4*>(dst + (size_t)row * ld + cc * 8) = *reinterpret_cast<const u32x4*>(tile_s + row * kPitch + cc * 16);
+      if (row < rows_valid) {
+        u32x4 val = *reinterpret_cast<const u32x4*>(tile_s + row * kPitch + cc * 16);
+        if (gate != nullptr) {
+          const u32x4 gv = *reinterpret_cast<const u32x4*>(gate + (size_t)row * ldg + cc * 8);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {   // bf16 > 0  <=>  sign clear and magnitude bits non-zero
+            const uint32_t lo = gv[i] & 0xFFFFu, hi = gv[i] >> 16;
+            const uint32_t keep_lo = (lo - 1u) < 0x7FFFu ? 0x0000FFFFu : 0u, keep_hi = (hi - 1u) < 0x7FFFu ? 0xFFFF0000u : 0u;
+            val[i] &= keep_lo | keep_hi;
+          }
+        }
+        *reinterpret_cast<u32x4*>(dst + (size_t)row * ld + cc * 8) = val;
+      }
     }
     __syncthreads();
   }

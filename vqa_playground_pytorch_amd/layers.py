@@ -185,13 +185,20 @@ class MyConv1d(nn.Module):
     # bf16 path: "engine" = the hand-written bf16 MFMA GEMMs (ops.LinearBf16), "library" = hipBLASLt through F.linear
     bf16_gemm = os.environ.get("VQA_BF16_GEMM", "engine")
 
-    def _linear_bf16(self, x, af):
+    def _linear_bf16(self, x, af, p=0.0, packed=None):
         """Mixed-precision form (x bf16, last dim possibly zero-padded past in_channels): bf16 operands, fp32
         accumulate, fp32 master weights.  Wide layers return the output padded to a multiple of 64 (pad = 0) so the
-        next bf16 GEMM needs no tail; narrow ones (the G attention logits) come back as fp32."""
+        next bf16 GEMM needs no tail; narrow ones (the G attention logits) come back as fp32.  p: this layer's input
+        dropout rate in the current mode (0 in eval / when the producer dropped x already); at 0.5 it runs inside the GEMM
+        kernels (ops.LinearBf16).  packed: the layer's shadows from the model's ShadowPlan, or None."""
         w = self.conv.weight.squeeze(-1)
-        if self.out_channels >= 32 and self.bf16_gemm == "engine":
-            return ops.linear_bf16(x, w, self.conv.bias, af)
+        if self.out_channels >= 32 and self.bf16_gemm == "engine" and af in (None, "", "relu"):
+            if p and p != 0.5:
+                x, p = F.dropout(x, p=p, training=True), 0.0
+            return ops.linear_bf16(x, w, self.conv.bias, af, p, ops.next_dropout_seed() if p else 0,
+                                   pregated=self.grad_pregated, packed=packed)
+        if p:
+            x = F.dropout(x, p=p, training=True)
         n_p = ops.pad_to(self.out_channels) if self.out_channels >= 32 else self.out_channels
         wp = ops.PackedWeightBf16.apply(w, n_p, x.size(-1))
         bp = F.pad(self.conv.bias, (0, n_p - self.out_channels)).to(torch.bfloat16)
@@ -209,10 +216,10 @@ class MyConv1d(nn.Module):
             p = self.p if (self.training and self.p) else 0.0
             return ops.attention_logits(x, self.conv.weight.squeeze(-1), self.conv.bias, p,
                                         ops.next_dropout_seed() if p else 0)
+        if x.dtype == torch.bfloat16:
+            return self._linear_bf16(x, None, self.p if (self.training and self.p) else 0.0)
         if self.p:
             x = F.dropout(x, p=self.p, training=self.training)
-        if x.dtype == torch.bfloat16:
-            return self._linear_bf16(x, None)
         return ops.linear(x, self.conv.weight.squeeze(-1), self.conv.bias)
 
     # K5 (fused dropout+GEMM+bias+relu on the hand-written fp32 MFMA engines) vs the library GEMM + a separate dropout
@@ -228,14 +235,15 @@ class MyConv1d(nn.Module):
         return self.fused and self.af in (None, "relu") and x.dim() == 3 and x.is_cuda and x.dtype == torch.float32 \
             and self.out_channels >= 32 and x.size(0) * x.size(1) >= 1024
 
-    def forward(self, x, predropped=False):
-        """predropped=True: the producer of x has already applied this layer's input dropout (ops.relation_apply)."""
+    def forward(self, x, predropped=False, packed=None):
+        """predropped=True: the producer of x has already applied this layer's input dropout (ops.relation_apply).
+        packed (bf16 inputs): this layer's shadows from the model's ops.ShadowPlan (else they are packed here)."""
         if predropped:
             if x.dim() != 3:
                 raise ValueError("[error] putils.Conv1d(%s, %s, %s, %s): input_dim (%s) should equal to 3"
                                  % (self.in_channels, self.out_channels, self.kernel_size, self.stride, x.dim()))
             if x.dtype == torch.bfloat16:
-                return self._linear_bf16(x, self.af)
+                return self._linear_bf16(x, self.af, 0.0, packed)
             if self._fused_ok(x):
                 return ops.linear_act(x, self.conv.weight.squeeze(-1), self.conv.bias, self.af, 0.0, 0,
                                       pregated=self.grad_pregated)
@@ -244,9 +252,7 @@ class MyConv1d(nn.Module):
             if x.dim() != 3:
                 raise ValueError("[error] putils.Conv1d(%s, %s, %s, %s): input_dim (%s) should equal to 3"
                                  % (self.in_channels, self.out_channels, self.kernel_size, self.stride, x.dim()))
-            if self.p:
-                x = F.dropout(x, p=self.p, training=self.training)
-            return self._linear_bf16(x, self.af)
+            return self._linear_bf16(x, self.af, self.p if (self.training and self.p) else 0.0, packed)
         if self._fused_ok(x):
             # large region-side projection (compress_v / compress_v2): dropout + GEMM + bias + relu in ONE kernel
             # on the fp32 MFMA tile engine (K5); the dropout mask is a counter hash keyed by a seed drawn from
@@ -286,9 +292,10 @@ class MutanFusion(nn.Module):
     def stack_groups(self):
         return linear_stack_groups(list(self.list_linear2)) + linear_stack_groups(list(self.list_linear1))
 
-    def forward(self, inputs1, inputs2, relu_input=False):
+    def forward(self, inputs1, inputs2, relu_input=False, packed=None):
         """relu_input: inputs1 is the relu output of the layer in front and the gradient returned for it may come back
-        multiplied by (inputs1 > 0) already (that layer's backward then skips the gate: MyConv1d.grad_pregated)."""
+        multiplied by (inputs1 > 0) already (that layer's backward then skips the gate: MyConv1d.grad_pregated).
+        packed (bf16 inputs1): the region-side shadows from the model's ops.ShadowPlan."""
         # (bf16 region tensors carry the feature dim zero-padded to a multiple of 64: see ops.pad_to)
         want = ops.pad_to(self.input_dim1) if inputs1.dtype == torch.bfloat16 else self.input_dim1
         if inputs1.size(-1) != want:
@@ -311,7 +318,7 @@ class MutanFusion(nn.Module):
             return ops.rank_product(h1, h2)
         weights = [lin.linear.weight for lin in self.list_linear1]
         biases = [lin.linear.bias for lin in self.list_linear1]
-        return ops.lowrank_bilinear_fusion(inputs1, h2, weights, biases, gate_dx=relu_input)
+        return ops.lowrank_bilinear_fusion(inputs1, h2, weights, biases, gate_dx=relu_input, packed=packed)
 
 
 class MyATT(nn.Module):

@@ -531,20 +531,65 @@ _shadows = {}
 _shadow_lock = threading.Lock()
 
 
-def _shadow(master, shape, tag):
-    """Persistent zero-initialised bf16 buffer for the padded (or transposed) shadow of an fp32 master weight.  The pads
-    never change, so they are zeroed ONCE; every step only repacks the interior (pack_bf16 with zero_fill=False) -- instead
-    of an allocation, a zero-fill kernel and a pack kernel per weight and step.  Keyed by the master's address: parameters
+def _shadow(master, shape, tag, dtype=torch.bfloat16):
+    """Persistent zero-initialised buffer for the padded (or transposed) bf16 shadow -- or padded fp32 copy -- of an fp32
+    master parameter.  The pads never change, so they are zeroed ONCE; every step only repacks the interior -- instead of
+    an allocation, a zero-fill kernel and a pack kernel per weight and step.  Keyed by the master's address: parameters
     keep theirs (views of the trainer's flat buffer), and a stale entry only ever has its interior overwritten."""
-    key = (master.data_ptr(), tuple(shape), tag, master.device.index)
+    key = (master.data_ptr(), tuple(shape), tag, master.device.index, dtype)
     with _shadow_lock:      # (nn.DataParallel-style callers drive one replica per thread)
         buf = _shadows.get(key)
         if buf is None:
             # never evicted: a captured hipGraph holds the ADDRESS of a shadow and no Python reference to it, so freeing
             # one would let replays write packed weights into memory the allocator has handed to someone else.  The set
             # is bounded by (weights x layouts) of the models alive in the process.
-            buf = _shadows[key] = torch.zeros(shape, device=master.device, dtype=torch.bfloat16)
+            buf = _shadows[key] = torch.zeros(shape, device=master.device, dtype=dtype)
     return buf
+
+
+class ShadowPlan:
+    """Every bf16 / padded-fp32 shadow a model's mixed-precision forward + backward reads, packed from the fp32 masters by
+    ONE kernel per step (vqa_pack_many) instead of one pack kernel -- plus a bias copy -- per weight and layout (11 + 11
+    launches per CoR2 step).  The model builds the plan once, calls ``pack()`` at the top of every forward (the masters
+    change only in the optimizer step) and hands each layer its shadows explicitly."""
+
+    def __init__(self):
+        self.jobs = []          # (src parameter, dst buffer, element offset into dst, row stride, col stride)
+        self._table = None
+        self._key = None
+        self._total = 0
+
+    def add(self, src, dst, row_stride, col_stride=1, offset=0):
+        if src.dim() == 1:
+            rows, cols = 1, src.numel()
+        else:
+            rows, cols = src.shape[0], src.numel() // src.shape[0]
+        last = offset + (rows - 1) * row_stride + (cols - 1) * col_stride
+        if dst.dtype not in (torch.bfloat16, torch.float32) or not dst.is_contiguous() or last >= dst.numel():
+            raise ValueError("ShadowPlan.add: destination too small or of the wrong kind")
+        self.jobs.append((src, dst, int(offset), int(row_stride), int(col_stride)))
+        self._key = None
+        return dst
+
+    def pack(self):
+        if not self.jobs:
+            return
+        key = tuple((s.data_ptr(), d.data_ptr()) for s, d, *_ in self.jobs)
+        if key != self._key:        # first use, or the parameters moved (trainer.FlatState re-homes them once)
+            rows, first = [], 0
+            for src, dst, off, rs, cs in self.jobs:
+                if not (src.is_cuda and src.dtype == torch.float32 and src.is_contiguous()):
+                    raise _lib.VqaLibraryError("ShadowPlan: masters must be contiguous fp32 GPU tensors")
+                r, c = (1, src.numel()) if src.dim() == 1 else (src.shape[0], src.numel() // src.shape[0])
+                rows.append([src.data_ptr(), dst.data_ptr() + off * dst.element_size(), r, c, rs, cs,
+                             0 if dst.dtype == torch.bfloat16 else 1, first])
+                first += r * c
+            dev = self.jobs[0][0].device
+            self._table = torch.tensor(rows, dtype=torch.int64).to(dev)
+            self._total = first
+            self._key = key
+        _launch("pack_many", (len(self.jobs), self._total), _lib.lib().vqa_pack_many, _p(self._table), len(self.jobs),
+                self._total)
 
 
 class PackedWeightBf16(torch.autograd.Function):
@@ -566,8 +611,10 @@ class PackedWeightBf16(torch.autograd.Function):
         return g[:rows, :cols].float(), None, None
 
 
-def gemm_bf16_nt(a, b, bias=None, act=None, out=None):
-    """act(a[M,K] @ b[N,K]^T + bias) -> bf16 [M,N] on the bf16 MFMA tile engine (K % 64 == 0)."""
+def gemm_bf16_nt(a, b, bias=None, act=None, out=None, gate=None, p_drop=0.0, seed=0):
+    """act(drop_p(a)[M,K] @ b[N,K]^T + bias) -> bf16 [M,N] on the bf16 MFMA tile engine (K % 64 == 0).  p_drop = 0.5: the
+    input dropout is applied to `a` inside the kernel (the counter-hash mask linear_dropout_mask exports).  gate [M,>=N]
+    bf16: the result is zeroed where gate <= 0 (a relu gradient applied in the store)."""
     a, b = _prep("a", a, (torch.bfloat16,)), _prep("b", b, (torch.bfloat16,))
     bias = _prep("bias", bias) if bias is not None else None
     M, K = a.shape
@@ -579,13 +626,25 @@ def gemm_bf16_nt(a, b, bias=None, act=None, out=None):
         raise ValueError("gemm_bf16_nt: act must be None or 'relu', got %r" % (act,))
     if out is None:
         out = torch.empty(M, N, device=a.device, dtype=torch.bfloat16)
-    _launch("gemm_bf16_nt", (M, N, K, code), _lib.lib().vqa_gemm_bf16_nt, _p(a), K, _p(b), K, _p(bias), _p(out), N,
-            M, N, K, code)
+    if gate is None and not p_drop:
+        _launch("gemm_bf16_nt", (M, N, K, code), _lib.lib().vqa_gemm_bf16_nt, _p(a), K, _p(b), K, _p(bias), _p(out), N,
+                M, N, K, code)
+        return out
+    if gate is not None:
+        gate = _prep("gate", gate, (torch.bfloat16,))
+        if gate.dim() != 2 or gate.shape[0] != M or gate.shape[1] < N:
+            raise ValueError("gemm_bf16_nt: gate must be [M, >= N] = [%d, >= %d]" % (M, N))
+    sv, sp = _seed_args(seed)
+    _launch("gemm_bf16_nt", (M, N, K, code), _lib.lib().vqa_gemm_bf16_nt_ex, _p(a), K, _p(b), K, _p(bias), _p(out), N,
+            M, N, K, code, _p(gate), gate.shape[1] if gate is not None else 0, float(p_drop), sv, sp)
     return out
 
 
-def gemm_bf16_tn(a, b):
-    """a[K,N1]^T @ b[K,N2] -> fp32 [N1,N2] (weight-gradient contraction over the batch rows; fixed-order split-K)."""
+def gemm_bf16_tn(a, b, outs=None, out_rows=None, out_cols=None, p_drop=0.0, seed=0):
+    """a[K,N1]^T @ drop_p(b)[K,N2] -> fp32 (weight-gradient contraction over the batch rows; fixed-order split-K).
+    outs None: one dense [N1,N2] tensor is returned.  outs = G fp32 tensors [out_rows, out_cols] (dense): rows
+    [g*N1/G, g*N1/G + out_rows) x columns [0, out_cols) of the product go to outs[g] -- the master-shaped gradients of G
+    padded layers, written in place (no slice / copy kernels).  p_drop = 0.5: `b` is dropped out inside the kernel."""
     a, b = _prep("a", a, (torch.bfloat16,)), _prep("b", b, (torch.bfloat16,))
     K, N1 = a.shape
     N2 = b.shape[1]
@@ -593,19 +652,35 @@ def gemm_bf16_tn(a, b):
         raise ValueError("gemm_bf16_tn: a [K,N1] and b [K,N2] must share K")
     L_ = _lib.lib()
     ws_bytes = L_.vqa_gemm_bf16_tn_workspace_bytes(K, N1, N2)
-    ws = torch.empty((ws_bytes + 3) // 4, device=a.device, dtype=torch.float32) if ws_bytes else None
-    c = torch.empty(N1, N2, device=a.device, dtype=torch.float32)
-    _launch("gemm_bf16_tn", (K, N1, N2), L_.vqa_gemm_bf16_tn, _p(a), N1, _p(b), N2, _p(c), _p(ws), ws_bytes, K, N1, N2)
-    return c
+    ws = torch.empty((ws_bytes + 3) // 4, device=a.device, dtype=torch.float32)
+    if outs is None and not p_drop:
+        c = torch.empty(N1, N2, device=a.device, dtype=torch.float32)
+        _launch("gemm_bf16_tn", (K, N1, N2), L_.vqa_gemm_bf16_tn, _p(a), N1, _p(b), N2, _p(c), _p(ws), ws_bytes, K, N1, N2)
+        return c
+    single = outs is None
+    if single:
+        outs, out_rows, out_cols = [torch.empty(N1, N2, device=a.device, dtype=torch.float32)], N1, N2
+    G = len(outs)
+    if N1 % G or any(o.dtype != torch.float32 or not o.is_contiguous() or tuple(o.shape) != (out_rows, out_cols) for o in outs):
+        raise ValueError("gemm_bf16_tn: outs must be %d dense fp32 [%s,%s] tensors" % (G, out_rows, out_cols))
+    sv, sp = _seed_args(seed)
+    _launch("gemm_bf16_tn", (K, N1, N2), L_.vqa_gemm_bf16_tn_ex, _p(a), N1, _p(b), N2, _ptr_array(outs), G, N1 // G,
+            int(out_rows), int(out_cols), int(out_cols), _p(ws), ws_bytes, K, N1, N2, float(p_drop), sv, sp)
+    return outs[0] if single else outs
 
 
 class LinearBf16(torch.autograd.Function):
-    """y = act(x W^T + b) on the bf16 MFMA engine: x bf16 [..., Kp] (Kp >= in_features, zero-padded), master W fp32
+    """y = act(drop_p(x) W^T + b) on the bf16 MFMA engine: x bf16 [..., Kp] (Kp >= in_features, zero-padded), master W fp32
     [out, in] / b fp32 [out]; returns bf16 [..., Np] with Np = out padded to 64 (pad columns exactly zero).
-    The nn.Linear / 1x1 nn.Conv1d contraction of MyLinear / MyConv1d (config/CoR2.py:56-122) in mixed precision."""
+    The nn.Linear / 1x1 nn.Conv1d contraction of MyLinear / MyConv1d (config/CoR2.py:56-122) in mixed precision, with the
+    layer's input dropout (config/CoR2.py:72-75) inside the kernels at p = 0.5: the forward masks x while it stages it,
+    the weight gradient regenerates the mask the same way -- no dropped copy of x, no mask tensor.
+    packed = (wp [Np,Kp] bf16, bp [Np] fp32 or None, wpt [Kp,Np] bf16 or None): the shadows of W / b / W^T when a
+    ShadowPlan of the caller has packed them already this step; None: packed here.
+    pregated: whoever consumes y returns its gradient already multiplied by relu'(y) (K4's data gradient with gate_dx)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, act):
+    def forward(ctx, x, w, bias, act, p_drop, seed, pregated, packed):
         x, w = _prep("x", x, (torch.bfloat16,)), _prep("w", w)
         Kp = x.shape[-1]
         out_f, in_f = w.shape
@@ -613,49 +688,65 @@ class LinearBf16(torch.autograd.Function):
             raise ValueError("linear_bf16: x's last dim (%d) must be in_features=%d zero-padded to a multiple of %d"
                              % (Kp, in_f, BF16_PAD))
         Np = pad_to(out_f)
-        dev = x.device
-        wp = pack_bf16(w, _shadow(w, (Np, Kp), "nk"), 0, Kp, 1, zero_fill=False)
-        bp = None
-        if bias is not None:
-            bp = torch.zeros(Np, device=dev, dtype=torch.float32)
-            bp[:out_f] = _prep("bias", bias)
+        if packed is not None:
+            wp, bp, wpt = packed
+        else:
+            wp = pack_bf16(w, _shadow(w, (Np, Kp), "nk"), 0, Kp, 1, zero_fill=False)
+            bp, wpt = None, None
+            if bias is not None:
+                bp = _shadow(bias, (Np,), "b", torch.float32)
+                bp[:out_f].copy_(_prep("bias", bias))
         x2 = x.reshape(-1, Kp)
-        y = gemm_bf16_nt(x2, wp, bp, act)
+        y = gemm_bf16_nt(x2, wp, bp, act, p_drop=p_drop, seed=seed)
         ctx.save_for_backward(x2, w, y)
-        ctx.cfg = (act, bias is not None, Np)
+        ctx.bias = bias
+        ctx.wpt = wpt
+        ctx.cfg = (act, Np, float(p_drop), seed, bool(pregated) and act == "relu")
         return y.view(*x.shape[:-1], Np)
 
     @staticmethod
     def backward(ctx, gy):
         x2, w, y = ctx.saved_tensors
-        act, has_bias, Np = ctx.cfg
+        act, Np, p_drop, seed, pregated = ctx.cfg
         out_f, in_f = w.shape
         Kp = x2.shape[1]
         gz = gy.reshape(-1, Np).to(torch.bfloat16)
-        if act == "relu":
+        if act == "relu" and not pregated:
             gz = gz * (y > 0)
         gz = gz.contiguous()
         d_x = None
         if ctx.needs_input_grad[0]:
-            wpt = pack_bf16(w, _shadow(w, (Kp, Np), "kn"), 0, 1, Np, zero_fill=False)   # [Kp, Np] = W^T
+            if p_drop:
+                raise _lib.VqaLibraryError("linear_bf16: the data gradient of a layer with in-kernel input dropout is not "
+                                           "implemented (no model on the path needs it: compress_v reads the model input)")
+            wpt = ctx.wpt
+            if wpt is None:
+                wpt = pack_bf16(w, _shadow(w, (Kp, Np), "kn"), 0, 1, Np, zero_fill=False)   # [Kp, Np] = W^T
             d_x = gemm_bf16_nt(gz, wpt).view(*gy.shape[:-1], Kp)
-        d_w = gemm_bf16_tn(gz, x2)[:out_f, :in_f]
-        d_b = column_sum(gz)[:out_f] if has_bias else None
-        return d_x, d_w, d_b, None
+        d_w = _grad_like(w)
+        gemm_bf16_tn(gz, x2, outs=[d_w], out_rows=out_f, out_cols=in_f, p_drop=p_drop, seed=seed)
+        d_b = None
+        if ctx.bias is not None:
+            d_b = column_sum(gz, out=_grad_like(ctx.bias), cols=out_f)
+        return d_x, d_w, d_b, None, None, None, None, None
 
 
-def linear_bf16(x, w, bias=None, act=None):
+def linear_bf16(x, w, bias=None, act=None, p_drop=0.0, seed=0, pregated=False, packed=None):
     if act not in (None, "", "relu"):
         raise ValueError("linear_bf16: act must be None or 'relu', got %r" % (act,))
-    return LinearBf16.apply(x, w, bias, act or None)
+    if p_drop and float(p_drop) != 0.5:
+        raise ValueError("linear_bf16: in-kernel dropout exists at p = 0.5 only; drop the input beforehand for p=%r" % (p_drop,))
+    return LinearBf16.apply(x, w, bias, act or None, float(p_drop or 0.0), seed, pregated, packed)
 
 
 class LowRankBilinearFusionBf16(torch.autograd.Function):
     """K4 on the bf16 MFMA engine.  x bf16 [B,(N,)Lp] with Lp >= L zero-padded to a multiple of 64; h2 fp32 [B,R,H];
-    master weights / biases fp32 ([H,L] / [H] per rank).  Returns bf16 [B,(N,)Hp], Hp = H padded to 256 (pad = 0)."""
+    master weights / biases fp32 ([H,L] / [H] per rank).  Returns bf16 [B,(N,)Hp], Hp = H padded to 256 (pad = 0).
+    packed = (w1p [R,Hp,Lp] bf16, b1p [R,Hp] fp32, w1t [Lp,R*Hp] bf16): shadows a ShadowPlan packed this step, or None.
+    gate_dx: x is the relu output of the layer in front and d_x comes back multiplied by (x > 0)."""
 
     @staticmethod
-    def forward(ctx, x, h2, *params):
+    def forward(ctx, x, h2, gate_dx, packed, *params):
         R = len(params) // 2
         w1 = [_prep("w1[%d]" % r, params[r]) for r in range(R)]
         b1 = [_prep("b1[%d]" % r, params[R + r]) for r in range(R)]
@@ -671,15 +762,20 @@ class LowRankBilinearFusionBf16(torch.autograd.Function):
             raise ValueError("bf16 fusion: x's last dim (%d) must be L=%d zero-padded to a multiple of %d" % (Lp, L, BF16_PAD))
         if h2.shape != (B, R, H):
             raise ValueError("h2 must be [B,R,H] = %s, got %s" % ((B, R, H), tuple(h2.shape)))
-        dev = x.device
-        w1p = _shadow(w1[0], (R, Hp, Lp), "k4")
-        b1p = torch.zeros(R, Hp, device=dev, dtype=torch.float32)
         for r in range(R):
             if w1[r].shape != (H, L) or b1[r].shape != (H,):
                 raise ValueError("rank %d: weight %s / bias %s do not match (H=%d, L=%d)"
                                  % (r, tuple(w1[r].shape), tuple(b1[r].shape), H, L))
-            pack_bf16(w1[r], w1p, 0, Lp, 1, zero_fill=False, offset=r * Hp * Lp)
-            b1p[r, :H] = b1[r]
+        dev = x.device
+        if packed is not None:
+            w1p, b1p, w1t = packed
+        else:
+            w1p = _shadow(w1[0], (R, Hp, Lp), "k4")
+            b1p = _shadow(b1[0], (R, Hp), "k4b", torch.float32)
+            for r in range(R):
+                pack_bf16(w1[r], w1p, 0, Lp, 1, zero_fill=False, offset=r * Hp * Lp)
+                b1p[r, :H].copy_(b1[r])
+            w1t = None
         h2p = torch.nn.functional.pad(h2, (0, Hp - H)) if Hp != H else h2
         need_bwd = any(ctx.needs_input_grad)
         out = torch.empty(*lead, Hp, device=dev, dtype=torch.bfloat16)
@@ -689,12 +785,14 @@ class LowRankBilinearFusionBf16(torch.autograd.Function):
                 B, N, Lp, Hp, R)
         if need_bwd:
             ctx.save_for_backward(x, h2p, h1, *w1)
-        ctx.dims = (B, N, L, Lp, H, Hp, R)
+            ctx.b1 = b1
+            ctx.w1t = w1t
+        ctx.dims = (B, N, L, Lp, H, Hp, R, bool(gate_dx))
         return out
 
     @staticmethod
     def backward(ctx, g):
-        B, N, L, Lp, H, Hp, R = ctx.dims
+        B, N, L, Lp, H, Hp, R, gate_dx = ctx.dims
         x, h2p, h1 = ctx.saved_tensors[:3]
         w1 = ctx.saved_tensors[3:]
         g = _prep("grad_out", g.to(torch.bfloat16), (torch.bfloat16,))
@@ -702,20 +800,22 @@ class LowRankBilinearFusionBf16(torch.autograd.Function):
         w1t = None
         d_x = None
         if ctx.needs_input_grad[0]:
-            w1t = _shadow(w1[0], (Lp, R * Hp), "k4t")   # w1t[l, r*Hp+h] = w1[r][h,l]; pads zeroed once
-            for r in range(R):   # rank r fills columns r*Hp .. r*Hp+H of every row
-                pack_bf16(w1[r], w1t, 0, 1, R * Hp, zero_fill=False, offset=r * Hp)
+            w1t = ctx.w1t
+            if w1t is None:
+                w1t = _shadow(w1[0], (Lp, R * Hp), "k4t")   # w1t[l, r*Hp+h] = w1[r][h,l]; pads zeroed once
+                for r in range(R):   # rank r fills columns r*Hp .. r*Hp+H of every row
+                    pack_bf16(w1[r], w1t, 0, 1, R * Hp, zero_fill=False, offset=r * Hp)
             d_x = torch.empty_like(x)
-        d_w1 = torch.empty(R, Hp, Lp, device=dev, dtype=torch.float32)
-        d_b1 = torch.empty(R, Hp, device=dev, dtype=torch.float32)
+        d_w1 = [_grad_like(w) for w in w1]
+        d_b1 = [_grad_like(b) for b in ctx.b1]
         d_h2 = torch.empty(B, R, Hp, device=dev, dtype=torch.float32)
         L_ = _lib.lib()
         ws_bytes = L_.vqa_lowrank_bilinear_fusion_bwd_bf16_workspace_bytes(B, N, Lp, Hp, R)
         ws = torch.empty((ws_bytes + 3) // 4, device=dev, dtype=torch.float32)
         _launch("lowrank_bilinear_fusion_bwd_bf16", (B, N, Lp, Hp, R, d_x is not None),
-                L_.vqa_lowrank_bilinear_fusion_bwd_bf16, _p(x), _p(w1t), _p(h2p), _p(h1), _p(g), _p(d_x), _p(d_w1),
-                _p(d_b1), _p(d_h2), _p(ws), ws_bytes, B, N, Lp, Hp, R)
-        return (d_x, d_h2[:, :, :H], *[d_w1[r, :H, :L] for r in range(R)], *[d_b1[r, :H] for r in range(R)])
+                L_.vqa_lowrank_bilinear_fusion_bwd_bf16, _p(x), _p(w1t), _p(h2p), _p(h1), _p(g), _p(d_x), _ptr_array(d_w1),
+                _ptr_array(d_b1), _p(d_h2), _p(ws), ws_bytes, B, N, Lp, Hp, R, H, L, int(gate_dx and d_x is not None))
+        return (d_x, d_h2[:, :, :H], None, None, *d_w1, *d_b1)
 
 
 class ObjectDifferenceAttention(torch.autograd.Function):
@@ -901,19 +1001,23 @@ def pairwise_projection_supported(v):
     return bool(_lib.lib().vqa_pairwise_relation_reduce_drop_supported(v.shape[0], v.shape[1], v.shape[2]))
 
 
-def column_sum(x, out=None):
-    """out[n] = sum_m x[m,n] for a 2-D fp32 / bf16 matrix -> fp32 [N]; fixed-order reduction, safe under graph replay."""
+def column_sum(x, out=None, cols=None):
+    """out[n] = sum_m x[m,n] for a 2-D fp32 / bf16 matrix -> fp32 [N]; fixed-order reduction, safe under graph replay.
+    cols: only the first `cols` columns are summed (a padded activation's real width)."""
     x = _prep("x", x, _REGION_DTYPES)
     if x.dim() != 2:
         raise ValueError("column_sum: x must be 2-D, got %s" % (tuple(x.shape),))
-    M, N = x.shape
+    M, ld = x.shape
+    N = ld if cols is None else int(cols)
+    if not 0 < N <= ld:
+        raise ValueError("column_sum: cols=%r outside (0, %d]" % (cols, ld))
     L_ = _lib.lib()
     ws_bytes = L_.vqa_column_sum_workspace_bytes(M, N)
     ws = torch.empty((ws_bytes + 3) // 4, device=x.device, dtype=torch.float32) if ws_bytes else None
     if out is None or out.dtype != torch.float32 or out.shape != (N,) or not out.is_contiguous():
         out = torch.empty(N, device=x.device, dtype=torch.float32)
     name = "column_sum" + _sfx(x.dtype)
-    _launch(name, (M, N), getattr(L_, "vqa_" + name), _p(x), N, _p(out), _p(ws), ws_bytes, M, N)
+    _launch(name, (M, N), getattr(L_, "vqa_" + name), _p(x), ld, _p(out), _p(ws), ws_bytes, M, N)
     return out
 
 
@@ -1431,10 +1535,11 @@ def softmax_attention_pool(logits, v):
     return SoftmaxAttentionPool.apply(logits, v)
 
 
-def lowrank_bilinear_fusion(x, h2, weights, biases, gate_dx=False):
-    """gate_dx (fp32 path): the gradient returned for x is already multiplied by (x > 0) -- see LowRankBilinearFusion."""
+def lowrank_bilinear_fusion(x, h2, weights, biases, gate_dx=False, packed=None):
+    """gate_dx: the gradient returned for x is already multiplied by (x > 0) -- see LowRankBilinearFusion.
+    packed (bf16 path): the layer's shadows from the caller's ShadowPlan (LowRankBilinearFusionBf16)."""
     if x.dtype == torch.bfloat16:
-        return LowRankBilinearFusionBf16.apply(x, h2, *weights, *biases)
+        return LowRankBilinearFusionBf16.apply(x, h2, gate_dx, packed, *weights, *biases)
     return LowRankBilinearFusion.apply(x, h2, gate_dx, *weights, *biases)
 
 
