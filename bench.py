@@ -63,6 +63,10 @@ def work_of(name, shape):
     if base == "relation_projection_dgrad":
         B, N, D, L = s[:4]
         return "mfma", 2 * B * N * D * L                                              # the data-gradient contraction
+    if base == "grouped_gemm":                                                            # K6: every GEMM of a phase of the
+        return "mfma", s[2]                                                               # [B,.] layers (head.py), FLOPs summed
+    if base == "grouped_epilogue":
+        return "hbm", s[2] * f                                                            # slabs read + outputs written
     if base == "library_gemm":
         M, N, K = s[:3]
         return "mfma", 2 * M * N * K

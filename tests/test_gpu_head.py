@@ -1,0 +1,195 @@
+"""GPU parity of the grouped head (K6: csrc/grouped_gemm.hip + vqa_playground_pytorch_amd/head.py) -- the [B,.]-sized
+layers of CoR2 / ODA as phases of one grouped GEMM launch + one grouped epilogue launch -- against float64 matmuls and
+against the same layers written with plain torch ops (MyLinear / putils.Linear / MutanFusion semantics: config/CoR2.py:
+94-122, putils/__init__.py:16-33,232-238).  The whole-model comparisons with the reference's goldens and the float64
+restatement (tests/test_gpu_models.py) run through these phases as well."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import seeded
+
+pytestmark = pytest.mark.gpu
+RTOL = 2e-4      # fp32 MFMA products against float64, on the output's scale
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def g(a, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev())
+    return t.requires_grad_() if grad else t
+
+
+def close(name, got, want, rtol=RTOL):
+    got = got.detach().double().cpu().numpy()
+    want = np.asarray(want.detach().double().cpu().numpy() if isinstance(want, torch.Tensor) else want, np.float64)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    assert np.isfinite(got).all(), name
+    err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-20)
+    assert err <= rtol, "%s: rel err %.3e" % (name, err)
+
+
+@pytest.fixture(scope="module")
+def head():
+    from vqa_playground_pytorch_amd import head as h
+    return h
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 310, 2400), (3, 155, 2048), (64, 64, 16), (130, 2000, 510), (1, 310, 310), (77, 620, 1240)])
+def test_grouped_gemm_all_forms_against_float64(head, M, N, K):
+    """One launch holding an NT, an NN and a TN product (and the 4-byte-aligned-A variants), each split over its contraction:
+    sum of the slabs == the float64 product; the TN problems' column sums == the bias gradient."""
+    x = seeded.seeded_array((M, K), 501)
+    w = seeded.seeded_array((N, K), 502) / np.sqrt(K)
+    dy = seeded.seeded_array((M, N), 503)
+    xt, wt, dyt = g(x), g(w), g(dy)
+    ph = head.Phase(dev(), "test")
+    t_nt = ph.target(M, N)
+    ph.gemm(t_nt, head.NT, xt, K, wt, K, K)
+    y = torch.empty(M, N, device=dev())
+    ph.job(head.EPI_SUM, t_nt, y, N)
+    outs = {}
+    if N % 2 == 0:
+        t_nn = ph.target(M, K)
+        ph.gemm(t_nn, head.NN, dyt, N, wt, K, N)
+        outs["dx"] = torch.empty(M, K, device=dev())
+        ph.job(head.EPI_SUM, t_nn, outs["dx"], K)
+        t_tn = ph.target(N, K)
+        ph.gemm(t_tn, head.TN, dyt, N, xt, K, M, colsum=True)
+        outs["dw"], outs["db"] = torch.empty(N, K, device=dev()), torch.empty(N, device=dev())
+        ph.job(head.EPI_SUM, t_tn, outs["dw"], K)
+        ph.job(head.EPI_SUM, t_tn, outs["db"], N, colsum=True)
+    t_nn4 = ph.target(M, K)
+    ph.gemm(t_nn4, head.NN_A4, dyt, N, wt, K, N)
+    outs["dx4"] = torch.empty(M, K, device=dev())
+    ph.job(head.EPI_SUM, t_nn4, outs["dx4"], K)
+    t_tn4 = ph.target(N, K)
+    ph.gemm(t_tn4, head.TN_A4, dyt, N, xt, K, M, colsum=True)
+    outs["dw4"], outs["db4"] = torch.empty(N, K, device=dev()), torch.empty(N, device=dev())
+    ph.job(head.EPI_SUM, t_tn4, outs["dw4"], K)
+    ph.job(head.EPI_SUM, t_tn4, outs["db4"], N, colsum=True)
+    ph.run()
+    x64, w64, dy64 = x.astype(np.float64), w.astype(np.float64), dy.astype(np.float64)
+    close("y", y, x64 @ w64.T)
+    for k, want in (("dx", dy64 @ w64), ("dw", dy64.T @ x64), ("db", dy64.sum(0)), ("dx4", dy64 @ w64), ("dw4", dy64.T @ x64),
+                    ("db4", dy64.sum(0))):
+        if k in outs:
+            close(k, outs[k], want)
+
+
+def test_grouped_gemm_shared_target_and_offsets(head):
+    """Two problems adding into ONE output (a K-concatenated product whose operands live in different tensors) and operands
+    addressed at element offsets inside larger tensors (a glimpse block of [B,G,D], a column block of W)."""
+    B, Gn, D, A = 37, 4, 256, 155
+    pooled = seeded.seeded_array((B, Gn, D), 511)
+    w = seeded.seeded_array((A, D), 512) / np.sqrt(D)
+    x1, x2 = seeded.seeded_array((B, 100), 513), seeded.seeded_array((B, 60), 514)
+    wf = seeded.seeded_array((90, 160), 515)
+    pt, wt, x1t, x2t, wft = g(pooled), g(w), g(x1), g(x2), g(wf)
+    ph = head.Phase(dev(), "test")
+    t1 = ph.target(B, A)
+    ph.gemm(t1, head.NT, pt, Gn * D, wt, D, D, a_off=2 * D)                 # glimpse 2 of the pooled tensor
+    y1 = torch.zeros(B, 4 * A, device=dev())
+    ph.job(head.EPI_SUM, t1, y1, 4 * A, out_off=A)                         # written at column block 1 of a wider output
+    t2 = ph.target(B, 90)
+    ph.gemm(t2, head.NT, x1t, 100, wft, 160, 100)                           # [x1 | x2] @ wf^T without the concatenation
+    ph.gemm(t2, head.NT, x2t, 60, wft, 160, 60, b_off=100)
+    y2 = torch.empty(B, 90, device=dev())
+    ph.job(head.EPI_SUM, t2, y2, 90)
+    ph.run()
+    close("glimpse block", y1[:, A:2 * A], pooled[:, 2].astype(np.float64) @ w.astype(np.float64).T)
+    assert float(y1[:, :A].abs().max()) == 0.0 and float(y1[:, 2 * A:].abs().max()) == 0.0
+    close("concatenated", y2, np.concatenate([x1, x2], 1).astype(np.float64) @ wf.astype(np.float64).T)
+
+
+def _mask(ops, rows, cols, p, seed):
+    return ops.linear_dropout_mask(rows, cols, p, seed, dev())
+
+
+@pytest.mark.parametrize("B", [5, 130])
+@pytest.mark.parametrize("train", [False, True])
+def test_head_phases_match_plain_layers(head, B, train):
+    """The six phases chained as CoR2 chains them, against the same layers written with torch ops and fed the SAME dropout
+    masks (exported through the head's mask spy): outputs and every gradient, 1e-3 of each tensor's scale."""
+    from vqa_playground_pytorch_amd import ops
+    Q, A, D, H, R, Gn, GA, C = 96, 62, 128, 102, 2, 4, 31, 50
+    p = 0.5 if train else 0.0
+    rng = np.random.RandomState(7)
+    P = {}
+
+    def par(name, *shape, scale=None):
+        a = rng.standard_normal(shape).astype(np.float32) * (scale if scale is not None else 1.0 / np.sqrt(shape[-1]))
+        P[name] = g(a, True)
+        return P[name]
+
+    wq = [par("wq%d" % i, A, Q) for i in range(4)]
+    bq = [par("bq%d" % i, A, scale=0.1) for i in range(4)]
+    we = [par("we%d" % i, D, A) for i in range(2)]
+    be = [par("be%d" % i, D, scale=0.1) for i in range(2)]
+    w2 = [[par("w2_%d_%d" % (f, r), H, A) for r in range(R)] for f in range(3)]
+    b2 = [[par("b2_%d_%d" % (f, r), H, scale=0.1) for r in range(R)] for f in range(3)]
+    wg = [[par("wg%d_%d" % (a_, i), GA, D) for i in range(Gn)] for a_ in range(2)]
+    bg = [[par("bg%d_%d" % (a_, i), GA, scale=0.1) for i in range(Gn)] for a_ in range(2)]
+    w1 = [par("w1f_%d" % r, H, 2 * Gn * GA) for r in range(R)]
+    b1 = [par("b1f_%d" % r, H, scale=0.1) for r in range(R)]
+    wc, bc = par("wc", C, H), par("bc", C, scale=0.1)
+    q = g(rng.standard_normal((B, Q)))
+    pooled = [g(rng.standard_normal((B, Gn, D)), True) for _ in range(2)]
+    g_q1, g_q2 = g(rng.standard_normal((B, D))), g(rng.standard_normal((B, D)))
+    g_h2 = [g(rng.standard_normal((B, R, H))) for _ in range(2)]
+    g_logits = g(rng.standard_normal((B, C)))
+
+    masks = {}
+    head._mask_spy = lambda site, rows, cols, p_, seed: masks.__setitem__(site, _mask(ops, rows, cols, p_, seed))
+    try:
+        low = head.QuestionProjections.apply(q, p, 11, (2, 3), p, 12, (), *wq, *bq)
+        s = 1.0 / (1.0 - p) if p else 1.0
+        flat = we[0], be[0], we[1], be[1]
+        for f in range(3):
+            flat += tuple(w2[f]) + tuple(b2[f])
+        q1, q2, h2a, h2b, h2f = head.GatesAndRankFactors.apply(low, (2, 3), ((0, R), (0, R), (1, R)), (1.0, 1.0, s, s), *flat)
+        v_att = [head.GlimpseProjections.apply(pooled[a_], *wg[a_], *bg[a_]) for a_ in range(2)]
+        x = head.VectorFusion.apply(h2f, p, 13, 2, v_att[0], v_att[1], *w1, *b1)
+        logits = head.Classifier.apply(x, wc, bc, p, 13)
+    finally:
+        head._mask_spy = None
+    loss = (logits * g_logits).sum() + (q1 * g_q1).sum() + (q2 * g_q2).sum() + (h2a * g_h2[0]).sum() + (h2b * g_h2[1]).sum()
+    loss.backward()
+    got = {k: v.grad.clone() for k, v in P.items()}
+    got_pooled = [t.grad.clone() for t in pooled]
+    for v in list(P.values()) + pooled:
+        v.grad = None
+
+    # the same computation with plain torch ops (float64) and the exported masks
+    d = lambda t: t.detach().double().requires_grad_(t.requires_grad)  # noqa: E731
+    P64 = {k: d(v) for k, v in P.items()}
+    q64 = q.double()
+    m_in = masks["question_in"].double().view(4, B, Q) if p else torch.ones(4, B, Q, device=dev(), dtype=torch.float64)
+    m_g = masks["question_out"].double().view(2, B, A) if p else torch.ones(2, B, A, device=dev(), dtype=torch.float64)
+    m_x = masks["fusion_out"].double() if p else torch.ones(B, H, device=dev(), dtype=torch.float64)
+    lows = [torch.relu((q64 * m_in[i]) @ P64["wq%d" % i].t() + P64["bq%d" % i]) for i in range(4)]
+    gates = [torch.sigmoid((lows[2 + i] * m_g[i]) @ P64["we%d" % i].t() + P64["be%d" % i]) for i in range(2)]
+    h2s = [torch.stack([lows[0 if f < 2 else 1] @ P64["w2_%d_%d" % (f, r)].t() + P64["b2_%d_%d" % (f, r)] for r in range(R)], 1)
+           for f in range(3)]
+    pooled64 = [d(t) for t in pooled]
+    v64 = [torch.cat([torch.relu(pooled64[a_][:, i] @ P64["wg%d_%d" % (a_, i)].t() + P64["bg%d_%d" % (a_, i)]) for i in range(Gn)], 1)
+           for a_ in range(2)]
+    vf = torch.cat(v64, 1)
+    x64 = sum((vf @ P64["w1f_%d" % r].t() + P64["b1f_%d" % r]) * h2s[2][:, r] for r in range(R))
+    logits64 = (x64 * m_x) @ P64["wc"].t() + P64["bc"]
+    loss64 = (logits64 * g_logits.double()).sum() + (gates[0] * g_q1.double()).sum() + (gates[1] * g_q2.double()).sum() + \
+        (h2s[0] * g_h2[0].double()).sum() + (h2s[1] * g_h2[1].double()).sum()
+    loss64.backward()
+    close("logits", logits, logits64, 1e-3)
+    close("q1", q1, gates[0], 1e-3)
+    close("h2 (fusion 2)", h2b, h2s[1], 1e-3)
+    for k in P:
+        close("d " + k, got[k], P64[k].grad, 1e-3)
+    for a_ in range(2):
+        close("d pooled%d" % a_, got_pooled[a_], pooled64[a_].grad, 1e-3)
+    if p:
+        for site, m in masks.items():
+            assert set(torch.unique(m).tolist()) == {0.0, 2.0}, site

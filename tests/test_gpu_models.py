@@ -145,16 +145,20 @@ EPS_EDGE = 3e-5        # a relu pre-activation closer to zero than this (float64
 KEEP_MIN = {"cor2": 0.4, "oda": 0.7}   # share of the 512 samples that must be free of them (measured: ~0.45 / ~0.78)
 RTOL_EDGE_MAX = 3e-2   # knife-edge samples: max-abs error of a gradient tensor, on the tensor's own scale ...
 RTOL_EDGE_FRO = 1e-2   # ... and its relative Frobenius error (a handful of flipped units does not move the norm)
-VARIANTS = [("cor2", 2000, "default"), ("cor2", 2000, "pairwise"), ("cor2", 2000, "k4_engine"), ("oda", 3000, "default")]
+VARIANTS = [("cor2", 2000, "default"), ("cor2", 2000, "pairwise"), ("cor2", 2000, "k4_engine"), ("cor2", 2000, "legacy_head"),
+            ("oda", 3000, "default")]
 _oracle_cache = {}
 
 
 def build_variant(cls, nans, variant, monkeypatch):
     """default = what bench.py times; pairwise = relation_mode 0 (the relation tensor built from every (i,j) term);
-    k4_engine = the Mutan fusion in its R-GEMM form on the LDS tile engine (VQA_K4_FORM=engine)."""
-    from vqa_playground_pytorch_amd import ops
+    k4_engine = the Mutan fusion in its R-GEMM form on the LDS tile engine (VQA_K4_FORM=engine); legacy_head = the
+    [B,.]-sized layers on library GEMMs + epilogue kernels instead of the grouped phases (VQA_HEAD=legacy)."""
+    from vqa_playground_pytorch_amd import head, ops
     if variant == "k4_engine":
         monkeypatch.setattr(ops, "_K4_FORM", "engine")
+    if variant == "legacy_head":
+        monkeypatch.setattr(head, "ENABLED", False)
     return build(cls, nans, **({"relation_mode": 0} if variant == "pairwise" else {}))
 
 
@@ -332,12 +336,17 @@ def test_training_step_with_shared_masks_against_oracle(cls, nans, variant, monk
     spies = {"next_dropout_seed": next_seed, "object_difference_attention": spy_k2, "dropout": spy_dropout, "linear_act": spy_linear_act,
              "attention_logits": spy_attention_logits, "softmax_attention_pool_drop": spy_pool_drop,
              "relation_projection": spy_relation_projection, "relation_apply": spy_relation_apply}
+    from vqa_playground_pytorch_amd import head
     for name, f in spies.items():
         setattr(ops, name, f)
+    # (the grouped head -- the [B,.]-sized layers -- reports the masks its kernels apply through its own spy)
+    head._mask_spy = lambda site, rows, cols, p_, seed: rec.append(
+        ("head:" + site, ops.linear_dropout_mask(rows, cols, p_, seed, dev())))
     try:
         torch.manual_seed(5)
         got = model({"v": torch.from_numpy(v).to(dev()), "q_idxes": torch.from_numpy(q).to(dev())})
     finally:
+        head._mask_spy = None
         for name, f in orig.items():
             setattr(ops, name, f)
     kinds = [k for k, _ in rec]
@@ -346,8 +355,13 @@ def test_training_step_with_shared_masks_against_oracle(cls, nans, variant, monk
     for t in m:
         assert set(torch.unique(t).tolist()) == {0.0, 2.0} and abs(float(t.mean()) - 1.0) < 0.01
     if cls == "cor2":
-        assert kinds == ["dropout", "dropout", "linear_act", "attention_logits", "pool_drop", "relation_projection",
-                         "attention_logits", "relation_apply", "dropout"], kinds
+        if kinds[0].startswith("head:"):       # the grouped head (default): same sites, same layouts, reported by name
+            assert kinds == ["head:question_in", "head:question_out", "linear_act", "attention_logits", "pool_drop",
+                             "relation_projection", "attention_logits", "relation_apply", "head:fusion_out"], kinds
+            m[0], m[1] = m[0].view(4, B, 2400), m[1].view(2, B, 310)
+        else:
+            assert kinds == ["dropout", "dropout", "linear_act", "attention_logits", "pool_drop", "relation_projection",
+                             "attention_logits", "relation_apply", "dropout"], kinds
         assert m[0].shape == (4, B, 2400) and m[1].shape == (2, B, 310) and m[4].shape == (B, 4, 2048) and m[7].shape == (B, 4, 2048)
         masks = {"compress_q": m[0][0], "linear_q": m[0][1], "compress_q_1": m[0][2], "compress_q_2": m[0][3],
                  "expand_q_1": m[1][0], "expand_q_2": m[1][1], "compress_v": m[2], "att1.conv_att": m[3], "compress_v2": m[5],

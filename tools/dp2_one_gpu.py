@@ -10,9 +10,13 @@ second half -- on a single-GPU box.  Rank 0 prints ONE JSON line with the global
 (tests/test_gpu_dp2.py runs all combinations and compares them with the single-process record; tests/test_gpu_nccl1.py
 runs the single-process steps with the all-reduce issued through a one-rank RCCL communicator and demands bit-identical
 results: RCCL init, the collective between the replayed graphs, the async work handle beside the second backward graph.)"""
+import faulthandler
 import json
 import os
 import sys
+
+if os.environ.get("VQA_DUMP_AFTER"):       # debugging aid: every thread's stack after N seconds, then exit (a hang shows where)
+    faulthandler.dump_traceback_later(int(os.environ["VQA_DUMP_AFTER"]), exit=True)
 
 import torch
 import torch.distributed as dist

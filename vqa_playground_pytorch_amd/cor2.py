@@ -9,7 +9,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import head, ops
 from .layers import MutanFusion, MyATT, MyConv1d, MyLinear, QuestionVectorInput, SideOutputs, linear_stack_groups, my_linears, \
     question_feature
 
@@ -126,6 +126,48 @@ class Model(nn.Module):
         q_gate_1, q_gate_2 = ops.split_groups(gates, (1, 1))
         return q_feature_low, q_final, q_gate_1, q_gate_2
 
+    def _grouped_head_ok(self, q_feature, cut):
+        """The [B,.]-sized layers run as grouped phases (head.py) whenever the tensors are fp32 on the GPU, the question
+        vector needs no gradient (no trainable encoder in front), the backward is not cut in two (the cut crosses the
+        phases) and the layer widths are even (8-byte operand loads)."""
+        mods = [self.compress_q, self.linear_q, self.compress_q_1, self.compress_q_2, self.expand_q_1, self.expand_q_2]
+        return (cut is None and q_feature.is_cuda and q_feature.dtype == torch.float32 and not q_feature.requires_grad
+                and all(m.af == ("sigmoid" if i >= 4 else "relu") for i, m in enumerate(mods))
+                and all(m.p == mods[0].p for m in mods) and self.linear_classif.af in (None, "")
+                and self.att1.grouped_ok(q_feature) and self.att2.grouped_ok(q_feature)
+                and head.supported(q_feature.size(1), self.compress_q.out_features, self.expand_q_1.out_features,
+                                   self.fusion_vq1.hidden_dim, self.fusion_final.hidden_dim, self.fusion_final.input_dim1,
+                                   self.att1.att_dim, self.num_classes))
+
+    def _question_phases(self, q_feature):
+        """Phases 1 and 2 of the grouped head: the four question projections, then everything that reads them -- the two
+        sigmoid gates and the question-side rank factors of all three Mutan fusions.
+        -> (q_gate_1, q_gate_2, h2 of fusion_vq1, of fusion_vq2, of fusion_final)."""
+        proj = [self.compress_q, self.linear_q, self.compress_q_1, self.compress_q_2]
+        p_in = float(proj[0].p) if (self.training and proj[0].p) else 0.0
+        p_g = float(self.expand_q_1.p) if (self.training and self.expand_q_1.p) else 0.0
+        low = head.QuestionProjections.apply(q_feature.contiguous(), p_in, ops.next_dropout_seed() if p_in else 0, (2, 3), p_g,
+                                             ops.next_dropout_seed() if p_g else 0, (),
+                                             *[m.linear.weight for m in proj], *[m.linear.bias for m in proj])
+        s = 1.0 / (1.0 - p_g) if p_g else 1.0
+        fus = [self.fusion_vq1, self.fusion_vq2, self.fusion_final]
+        params = [self.expand_q_1.linear.weight, self.expand_q_1.linear.bias, self.expand_q_2.linear.weight,
+                  self.expand_q_2.linear.bias]
+        for mf in fus:
+            params += [lin.linear.weight for lin in mf.list_linear2] + [lin.linear.bias for lin in mf.list_linear2]
+        return head.GatesAndRankFactors.apply(low, (2, 3), ((0, fus[0].R), (0, fus[1].R), (1, fus[2].R)), (1.0, 1.0, s, s),
+                                              *params)
+
+    def _final_phases(self, v1_att, v2_att, h2_final):
+        """Phases 5 and 6: fusion_final (its first input is cat(v1_att, v2_att), never materialised) with the rank product and
+        the classifier's input dropout in its epilogue, then the classifier."""
+        p_c = float(self.linear_classif.p) if (self.training and self.linear_classif.p) else 0.0
+        seed = ops.next_dropout_seed() if p_c else 0
+        lins = list(self.fusion_final.list_linear1)
+        x = head.VectorFusion.apply(h2_final, p_c, seed, 2, v1_att, v2_att, *[l.linear.weight for l in lins],
+                                    *[l.linear.bias for l in lins])
+        return head.Classifier.apply(x, self.linear_classif.linear.weight, self.linear_classif.linear.bias, p_c, seed)
+
     def relation_reduce(self, v_feature, q_gate_1, q_gate_2, alpha):
         """config/CoR2.py:191-199 (decare_cat) + :216 fused: v2[b,j] = sum_i alpha[b,i,0] *
         (v[b,i]*q1[b] + v[b,j]*q2[b]); the [B,N,N,D] tensor is never built (HIP kernel K1)."""
@@ -141,12 +183,17 @@ class Model(nn.Module):
         q_feature = question_feature(self.seq2vec, sample["q_idxes"] if "q_idxes" in sample else sample["q"])
 
         shad = self._bf16_shadows() if v_feature.dtype == torch.bfloat16 and v_feature.is_cuda else {}
-        q_feature_low, q_final, q_gate_1, q_gate_2 = self.question_projections(q_feature)
+        grouped = self._grouped_head_ok(q_feature, _cut)
+        h2_1 = h2_2 = h2_final = q_feature_low = q_final = None
+        if grouped:
+            q_gate_1, q_gate_2, h2_1, h2_2, h2_final = self._question_phases(q_feature)
+        else:
+            q_feature_low, q_final, q_gate_1, q_gate_2 = self.question_projections(q_feature)
         v_feature_low = self.compress_v(v_feature, packed=shad.get("compress_v"))
         fuse1 = self.fusion_vq1(v_feature_low, q_feature_low, relu_input=self.compress_v.grad_pregated,
-                                packed=shad.get("fusion_vq1"))
+                                packed=shad.get("fusion_vq1"), h2=h2_1)
         v1_att, alpha1, alpha1_full, pooled1_first = self.att1.attend(v_feature, self.att1.conv_att.pre_activation(fuse1),
-                                                                return_pooled=True)
+                                                                return_pooled=True, grouped=grouped)
         if _cut is not None:
             # everything the second reasoning step (relation, compress_v2, fusion_vq2, att2, fusion_final, classifier)
             # reads from the first.  The second step runs on detached aliases of these tensors, so a backward pass from the
@@ -185,10 +232,11 @@ class Model(nn.Module):
                 v2_dropped = ops.relation_apply(v_feature, t, c2, p, ops.next_dropout_seed() if p else 0)
                 v2_feature_low = cv2(v2_dropped, predropped=True, packed=shad.get("compress_v2"))
             fuse2 = self.fusion_vq2(v2_feature_low, q_feature_low, relu_input=self.compress_v2.grad_pregated,
-                                    packed=shad.get("fusion_vq2"))
+                                    packed=shad.get("fusion_vq2"), h2=h2_2)
             v2_att, alpha2, _ = self.att2.attend(v_feature, self.att2.conv_att.pre_activation(fuse2),
                                                  lambda pooled, pd: ops.relation_apply(
-                                                     pooled, t, c2, pd, ops.next_dropout_seed() if pd else 0))
+                                                     pooled, t, c2, pd, ops.next_dropout_seed() if pd else 0),
+                                                 grouped=grouped)
             # the reference's v2_feature[:, [0, 1], :] (visu.py:198-207 reads it after an eval forward).  Eval: computed here,
             # like the reference does.  Training: a step never looks at it, so it is computed when read, from copies of the
             # two region rows and of t / c2 rows that belong to THIS forward only when it ran eagerly -- under graph replay
@@ -205,8 +253,8 @@ class Model(nn.Module):
             v2_feature, v2_for_pooling = self.relation_reduce(v_feature, q_gate_1, q_gate_2, alpha1_full)
             v2_feature_low = self.compress_v2(v2_feature, packed=shad.get("compress_v2"))
             fuse2 = self.fusion_vq2(v2_feature_low, q_feature_low, relu_input=self.compress_v2.grad_pregated,
-                                    packed=shad.get("fusion_vq2"))
-            v2_att, alpha2, _ = self.att2.attend(v2_for_pooling, self.att2.conv_att.pre_activation(fuse2))
+                                    packed=shad.get("fusion_vq2"), h2=h2_2)
+            v2_att, alpha2, _ = self.att2.attend(v2_for_pooling, self.att2.conv_att.pre_activation(fuse2), grouped=grouped)
             feature = v2_feature[:, 0:2, :].detach().float()
 
         # side output read by visu.py:198-207; detached so it does not pin the autograd graph of the step
@@ -214,6 +262,8 @@ class Model(nn.Module):
         self.alpha_dict = SideOutputs({"alpha1": tuple(t_.detach() for t_ in alpha1), "alpha2": tuple(t_.detach() for t_ in alpha2),
                                        "feature": feature})
 
+        if grouped:
+            return self._final_phases(v1_att, v2_att, h2_final)
         v_f = torch.cat([v1_att, v2_att], dim=1)
         x = self.fusion_final(v_f, q_final)
         return self.linear_classif(x)

@@ -1,0 +1,576 @@
+"""The [B, .]-sized layers of the heads as grouped launches (K6; csrc/grouped_gemm.hip).
+
+Everything of CoR2 / ODA that is not region-sized -- the question projections, the sigmoid gates, Mutan's question-side
+rank factors, the per-glimpse projections, fusion_final's two sides with its rank product, the classifier (MyLinear /
+putils.Linear / MutanFusion: config/CoR2.py:94-122,133-134,170,180-189, config/ODA.py:183-198, putils/__init__.py:16-33,
+205-241) -- runs here in PHASES.  A phase is every GEMM whose inputs are ready at the same point of the step: one
+``vqa_grouped_gemm`` launch (all of them, forward / data-gradient / weight-gradient forms mixed, split over their
+contraction so the union fills the chip) and one ``vqa_grouped_epilogue`` launch (fixed-order reduction of the partial
+products + bias, activation, the consumer's input dropout, rank products, activation gradients, layouts).  Per layer the
+reference issues dropout -> linear -> activation and autograd four more kernels backward; per step that was 28 library
+GEMMs surrounded by ~40 launch-floor kernels.
+
+Each phase is one ``torch.autograd.Function``.  Contract between consecutive phases (they are each other's only
+consumers, which the models guarantee by construction): a phase returns the gradient of its input ALREADY multiplied by
+the producing layer's activation / dropout gradient -- it holds the producer's stored output, whose sign carries both --
+so the producer's backward starts at its GEMMs.  Activations that feed a dropout layer are stored dropped out (0 or
+x/(1-p)), like K3 stores the pooled glimpses: "stored value > 0" is then "kept and active".
+"""
+import ctypes
+import math
+import os
+
+import torch
+
+from . import _lib, ops
+
+_c = ctypes
+MAX_GROUP = 24
+
+
+class GemmProblem(_c.Structure):          # VqaGemmProblem (include/vqa_mi355x.h)
+    _fields_ = [("A", _c.c_void_p), ("B", _c.c_void_p), ("slab", _c.c_void_p), ("colsum", _c.c_void_p),
+                ("slab_stride", _c.c_longlong), ("lda", _c.c_int), ("ldb", _c.c_int), ("M", _c.c_int), ("N", _c.c_int),
+                ("K", _c.c_int), ("form", _c.c_int), ("ksplit", _c.c_int), ("slab_base", _c.c_int), ("Ka", _c.c_int),
+                ("Kb", _c.c_int), ("Ma", _c.c_int), ("Nb", _c.c_int)]
+
+
+class EpilogueJob(_c.Structure):          # VqaEpilogueJob
+    _fields_ = [("slab", _c.c_void_p), ("bias", _c.c_void_p), ("aux", _c.c_void_p), ("aux2", _c.c_void_p),
+                ("out", _c.c_void_p), ("out2", _c.c_void_p), ("seed_ptr", _c.c_void_p), ("seed", _c.c_uint64),
+                ("slab_stride", _c.c_longlong), ("S", _c.c_int), ("M", _c.c_int), ("N", _c.c_int), ("kind", _c.c_int),
+                ("ldo", _c.c_int), ("ld_aux", _c.c_int), ("act", _c.c_int), ("gate", _c.c_int), ("R", _c.c_int),
+                ("seg", _c.c_int), ("seg_ld", _c.c_int), ("drop_base", _c.c_uint32), ("drop_ld", _c.c_uint32),
+                ("p_drop", _c.c_float), ("gate_scale", _c.c_float)]
+
+
+NT, NN, TN, NN_A4, TN_A4 = 0, 1, 2, 3, 4
+EPI_SUM, EPI_LINEAR, EPI_RANK_PRODUCT, EPI_GRAD, EPI_RANK_PRODUCT_BWD = 0, 1, 2, 3, 4
+ACT = {None: 0, "": 0, "relu": 1, "sigmoid": 2}
+
+ENABLED = os.environ.get("VQA_HEAD", "grouped") != "legacy"
+_mask_spy = None      # tests: callable(site, rows, cols, p, seed) told about every dropout mask an epilogue applies
+
+
+def _ptr(t, offset=0):
+    return t.data_ptr() + 4 * int(offset)
+
+
+class _Target:
+    """One accumulation target of a phase: sum of the partial products of every problem added to it."""
+
+    def __init__(self, M, N):
+        self.M, self.N = int(M), int(N)
+        self.problems = []
+        self.slab = None
+        self.colsum = None
+        self.S = 0
+
+
+class Phase:
+    """Collects the GEMM problems and epilogue jobs of one phase, sizes the contraction splits so that the phase's tiles
+    fill the chip, allocates the slabs and launches the two kernels."""
+
+    TARGET_ITEMS = 768      # ~3 workgroups of 64x64 tiles per CU (256 CUs, 4 resident per CU)
+
+    def __init__(self, device, name):
+        self.device, self.name = device, name
+        self.targets, self.pre_jobs, self.jobs = [], [], []
+
+    def target(self, M, N):
+        t = _Target(M, N)
+        self.targets.append(t)
+        return t
+
+    def gemm(self, target, form, A, lda, B, ldb, K, a_off=0, b_off=0, colsum=False, Ka=0, Kb=0, Ma=0, Nb=0):
+        """target (+)= A (.) B over K.  A, B: tensors; a_off / b_off: element offsets of the operand's first element."""
+        target.problems.append(dict(form=form, A=A, a_off=a_off, lda=int(lda), B=B, b_off=b_off, ldb=int(ldb), K=int(K),
+                                    colsum=bool(colsum), Ka=Ka, Kb=Kb, Ma=Ma, Nb=Nb))
+
+    def job(self, kind, source, out, ldo, out_off=0, pre=False, **kw):
+        """source: a _Target (its reduced slabs) or a tensor [M,N] (S = 1: an elementwise job on existing data)."""
+        (self.pre_jobs if pre else self.jobs).append(dict(kind=kind, source=source, out=out, ldo=int(ldo), out_off=out_off, **kw))
+
+    def _size(self):
+        probs = [(t, p) for t in self.targets for p in t.problems]
+        tiles = lambda t: math.ceil(t.M / 64) * math.ceil(t.N / 64)  # noqa: E731
+        kmax = max(p["K"] for _, p in probs)
+        best = None
+        for chunk in sorted({max(128, math.ceil(kmax / d / 16) * 16) for d in (1, 2, 3, 4, 6, 8, 12, 16)}, reverse=True):
+            items = sum(tiles(t) * math.ceil(p["K"] / chunk) for t, p in probs)
+            best = chunk
+            if items >= self.TARGET_ITEMS:
+                break
+        for t, p in probs:
+            splits = math.ceil(p["K"] / best)
+            p["ksplit"] = math.ceil(p["K"] / splits / 16) * 16
+            p["splits"] = math.ceil(p["K"] / p["ksplit"])
+        return probs
+
+    def run(self):
+        L_ = _lib.lib()
+        if self.pre_jobs:
+            self._epilogue(L_, self.pre_jobs, "pre")
+        if self.targets:
+            probs = self._size()
+            flops = 0
+            for t in self.targets:
+                t.S = sum(p["splits"] for p in t.problems)
+                t.slab = torch.empty(t.S, t.M, t.N, device=self.device, dtype=torch.float32)
+                if any(p["colsum"] for p in t.problems):
+                    t.colsum = torch.empty(t.S, t.M, device=self.device, dtype=torch.float32)
+                base = 0
+                for p in t.problems:
+                    p["slab_base"] = base
+                    base += p["splits"]
+                    flops += 2 * t.M * t.N * p["K"]
+            if len(probs) > MAX_GROUP:
+                raise _lib.VqaLibraryError("phase %s: %d GEMM problems exceed the group limit %d" % (self.name, len(probs), MAX_GROUP))
+            arr = (GemmProblem * len(probs))()
+            for i, (t, p) in enumerate(probs):
+                arr[i] = GemmProblem(_ptr(p["A"], p["a_off"]), _ptr(p["B"], p["b_off"]), t.slab.data_ptr(),
+                                     t.colsum.data_ptr() if (p["colsum"] and t.colsum is not None) else None,
+                                     t.M * t.N, p["lda"], p["ldb"], t.M, t.N, p["K"], p["form"], p["ksplit"], p["slab_base"],
+                                     p["Ka"], p["Kb"], p["Ma"], p["Nb"])
+            ops._launch("grouped_gemm", (self.name, len(probs), flops), L_.vqa_grouped_gemm, arr, len(probs))
+        if self.jobs:
+            self._epilogue(L_, self.jobs, "post")
+
+    def _epilogue(self, L_, jobs, tag):
+        if len(jobs) > MAX_GROUP:
+            raise _lib.VqaLibraryError("phase %s: %d epilogue jobs exceed the group limit %d" % (self.name, len(jobs), MAX_GROUP))
+        arr = (EpilogueJob * len(jobs))()
+        elems = 0
+        for i, j in enumerate(jobs):
+            src = j["source"]
+            if isinstance(src, _Target):
+                colsum = j.get("colsum", False)
+                slab = src.colsum if colsum else src.slab
+                S, M, N = src.S, (1 if colsum else src.M), (src.M if colsum else src.N)
+                stride = src.M if colsum else src.M * src.N
+            else:
+                slab, S, (M, N) = src, 1, (src.shape[0], src.numel() // src.shape[0])
+                stride = M * N
+            seed = j.get("seed", 0)
+            sv, sp = ops._seed_args(seed) if j.get("p_drop", 0.0) else (0, None)
+            aux, aux2, out2, bias = j.get("aux"), j.get("aux2"), j.get("out2"), j.get("bias")
+            arr[i] = EpilogueJob(slab.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                 _ptr(aux, j.get("aux_off", 0)) if aux is not None else None,
+                                 _ptr(aux2, j.get("aux_off", 0)) if aux2 is not None else None,
+                                 _ptr(j["out"], j["out_off"]), _ptr(out2, j.get("out2_off", 0)) if out2 is not None else None,
+                                 sp.value if sp is not None else None, sv, stride, S, M, N, j["kind"], j["ldo"],
+                                 int(j.get("ld_aux", 0)), int(j.get("act", 0)), int(j.get("gate", 0)), int(j.get("R", 1)),
+                                 int(j.get("seg", 0)), int(j.get("seg_ld", 0)), int(j.get("drop_base", 0)),
+                                 int(j.get("drop_ld", 0)), float(j.get("p_drop", 0.0)), float(j.get("gate_scale", 1.0)))
+            elems += M * N * (S + 1)
+        ops._launch("grouped_epilogue", (self.name + "/" + tag, len(jobs), elems), L_.vqa_grouped_epilogue, arr, len(jobs))
+
+
+def _note_mask(site, rows, cols, p, seed):
+    if _mask_spy is not None and p:
+        _mask_spy(site, rows, cols, p, seed)
+
+
+def _adjacent(params):
+    """The same-shaped 2-D (or 1-D) parameters lie back to back in memory (trainer.FlatState lays stack groups out so):
+    they can be addressed as ONE matrix of the concatenated rows."""
+    first = params[0]
+    n = first.numel()
+    return all(p.is_contiguous() and p.shape == first.shape and p.data_ptr() == first.data_ptr() + 4 * n * i
+               for i, p in enumerate(params))
+
+
+def _f32c(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise _lib.VqaLibraryError("grouped head: tensors must be contiguous fp32 GPU tensors (no CPU fallback)")
+
+
+def supported(*dims):
+    """Every feature dimension that ends up as the contiguous axis of an 8-byte-loaded operand is even."""
+    return ENABLED and all(int(d) % 2 == 0 for d in dims)
+
+
+# ------------------------------------------------------------------------------------------------ phase 1
+class QuestionProjections(torch.autograd.Function):
+    """low[g] = drop_g(relu(drop(q) W_g^T + b_g)) for the G MyLinear(2400 -> 310, p, relu) that read the question vector
+    (config/CoR2.py:170,180,183,186 applied at :205,:193-194,:230; config/ODA.py:186-187).  Each layer draws its own input
+    mask over q (the reference calls them one after the other); groups listed in `dropped` are stored with the input
+    dropout of THEIR consumer applied (expand_q_{1,2}, config/CoR2.py:184,187).  -> low [G,B,A].
+    The gradient handed back for `low` must arrive gated (see the module docstring); q gets no gradient here."""
+
+    @staticmethod
+    def forward(ctx, q, p_in, seed_in, dropped, p_out, seed_out, ungated, *params):
+        # ungated: groups whose consumer is NOT a phase of this module (ODA's object-difference kernel reads low[0]): their
+        # gradient arrives as the plain gradient of the stored value and is gated here, by a pre-job of the backward launch
+        G = len(params) // 2
+        ws, bs = params[:G], params[G:]
+        _f32c(q, *ws, *bs)
+        B, K = q.shape
+        A = ws[0].shape[0]
+        dev = q.device
+        if p_in:
+            qd = ops.DropoutGroups.apply(q.detach(), p_in, seed_in, G)          # [G,B,K]: G independent draws
+            _note_mask("question_in", G * B, K, p_in, seed_in)
+        else:
+            qd = q.detach()
+        low = torch.empty(G, B, A, device=dev, dtype=torch.float32)
+        ph = Phase(dev, "q_proj_fwd")
+        for g in range(G):
+            t = ph.target(B, A)
+            ph.gemm(t, NT, qd, K, ws[g], K, K, a_off=g * B * K if p_in else 0)
+            slot = dropped.index(g) if g in dropped else -1
+            ph.job(EPI_LINEAR, t, low, A, out_off=g * B * A, bias=bs[g], act=1,
+                   p_drop=p_out if slot >= 0 else 0.0, seed=seed_out, drop_base=max(slot, 0) * B * A, drop_ld=A)
+        if p_out and dropped:
+            _note_mask("question_out", len(dropped) * B, A, p_out, seed_out)
+        ph.run()
+        ctx.save_for_backward(qd, low, *ws, *bs)
+        ctx.cfg = (G, B, K, A, bool(p_in), tuple(ungated), tuple(dropped), float(p_out))
+        return low
+
+    @staticmethod
+    def backward(ctx, d_pre):
+        G, B, K, A, dropped_in, ungated, dropped, p_out = ctx.cfg
+        qd, low = ctx.saved_tensors[:2]
+        ws, bs = ctx.saved_tensors[2:2 + G], ctx.saved_tensors[2 + G:]
+        d_pre = d_pre.contiguous()
+        ph = Phase(d_pre.device, "q_proj_bwd")
+        if ungated:
+            d_pre = d_pre.clone() if d_pre._base is not None or not d_pre.is_contiguous() else d_pre
+            for g in ungated:
+                scale = 1.0 / (1.0 - p_out) if (g in dropped and p_out) else 1.0
+                ph.job(EPI_GRAD, d_pre[g], d_pre, A, out_off=g * B * A, pre=True, gate=1, aux=low, aux_off=g * B * A, ld_aux=A,
+                       gate_scale=scale)
+        grads_w, grads_b = [], []
+        for g in range(G):
+            t = ph.target(A, K)
+            ph.gemm(t, TN, d_pre, A, qd, K, B, a_off=g * B * A, b_off=g * B * K if dropped_in else 0, colsum=True)
+            gw, gb = ops._grad_like(ws[g]), ops._grad_like(bs[g])
+            ph.job(EPI_SUM, t, gw, K)
+            ph.job(EPI_SUM, t, gb, A, colsum=True)
+            grads_w.append(gw)
+            grads_b.append(gb)
+        ph.run()
+        return (None, None, None, None, None, None, None, *grads_w, *grads_b)
+
+
+# ------------------------------------------------------------------------------------------------ phase 2
+class GatesAndRankFactors(torch.autograd.Function):
+    """Everything that reads the projected question: the sigmoid gates expand_q_{1,2}(low[2]), (low[3]) (config/CoR2.py:
+    184,187: MyLinear(310 -> 2048, p, sigmoid); their input dropout is already in the stored low) and the question-side rank
+    factors h2 = Linear2_r(q) of the Mutan fusions (putils/__init__.py:232-238), each reading one group of low.
+    spec: n_gates gate layers first (group index each), then fusions as (group index, R).
+    -> (gate outputs [B,D] ..., h2 [B,R,H] per fusion).  Returns d low already gated by low's relu / dropout."""
+
+    @staticmethod
+    def forward(ctx, low, gate_groups, fusions, gate_scale, *params):
+        # params: for each gate (W [D,A], b [D]); then for each fusion R weights [H,A] followed by R biases [H]
+        G, B, A = low.shape
+        dev = low.device
+        _f32c(low, *params)
+        ph = Phase(dev, "gates_h2_fwd")
+        outs, idx = [], 0
+        gates = []
+        for g in gate_groups:
+            W, b = params[idx], params[idx + 1]
+            idx += 2
+            D = W.shape[0]
+            y = torch.empty(B, D, device=dev, dtype=torch.float32)
+            t = ph.target(B, D)
+            ph.gemm(t, NT, low, A, W, A, A, a_off=g * B * A)
+            ph.job(EPI_LINEAR, t, y, D, bias=b, act=2)
+            outs.append(y)
+            gates.append((g, W, b))
+        fus = []
+        for g, R in fusions:
+            ws, bs = params[idx:idx + R], params[idx + R:idx + 2 * R]
+            idx += 2 * R
+            H = ws[0].shape[0]
+            h2 = torch.empty(B, R, H, device=dev, dtype=torch.float32)
+            if _adjacent(ws) and _adjacent(bs):
+                t = ph.target(B, R * H)
+                ph.gemm(t, NT, low, A, ws[0], A, A, a_off=g * B * A)
+                ph.job(EPI_LINEAR, t, h2, R * H, bias=bs[0].as_strided((R * H,), (1,)))
+            else:
+                for r in range(R):
+                    t = ph.target(B, H)
+                    ph.gemm(t, NT, low, A, ws[r], A, A, a_off=g * B * A)
+                    ph.job(EPI_LINEAR, t, h2, R * H, out_off=r * H, bias=bs[r])
+            outs.append(h2)
+            fus.append((g, R, H, ws, bs))
+        ph.run()
+        ctx.save_for_backward(low, *outs[:len(gates)], *params)
+        ctx.cfg = (G, B, A, tuple(gate_groups), tuple(fusions), tuple(gate_scale))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        G, B, A, gate_groups, fusions, gate_scale = ctx.cfg
+        low = ctx.saved_tensors[0]
+        ng = len(gate_groups)
+        ys = ctx.saved_tensors[1:1 + ng]
+        params = ctx.saved_tensors[1 + ng:]
+        dev = low.device
+        ph = Phase(dev, "gates_h2_bwd")
+        d_low_t = [ph.target(B, A) for _ in range(G)]
+        touched = [False] * G
+        out_grads, idx = [], 0
+        # gates: dg = d_y * y (1 - y) first (an elementwise pre-job), then dg W (data) and dg^T low_g (weight)
+        for i, g in enumerate(gate_groups):
+            W, b = params[idx], params[idx + 1]
+            idx += 2
+            D = W.shape[0]
+            gy = grads[i]
+            if gy is None:
+                out_grads += [None, None]
+                continue
+            gy = gy.contiguous()
+            dg = torch.empty(B, D, device=dev, dtype=torch.float32)
+            ph.job(EPI_GRAD, gy, dg, D, pre=True, gate=2, aux=ys[i], ld_aux=D)
+            ph.gemm(d_low_t[g], NN, dg, D, W, A, D)
+            touched[g] = True
+            t = ph.target(D, A)
+            ph.gemm(t, TN, dg, D, low, A, B, b_off=g * B * A, colsum=True)
+            gw, gb = ops._grad_like(W), ops._grad_like(b)
+            ph.job(EPI_SUM, t, gw, A)
+            ph.job(EPI_SUM, t, gb, D, colsum=True)
+            out_grads += [gw, gb]
+        for k, (g, R) in enumerate(fusions):
+            ws, bs = params[idx:idx + R], params[idx + R:idx + 2 * R]
+            idx += 2 * R
+            H = ws[0].shape[0]
+            gh = grads[ng + k]
+            if gh is None:
+                out_grads += [None] * (2 * R)
+                continue
+            gh = gh.contiguous()           # [B,R,H]
+            gws = [ops._grad_like(w) for w in ws]
+            gbs = [ops._grad_like(b) for b in bs]
+            if _adjacent(ws):
+                ph.gemm(d_low_t[g], NN, gh, R * H, ws[0], A, R * H)
+            else:
+                for r in range(R):
+                    ph.gemm(d_low_t[g], NN, gh, R * H, ws[r], A, H, a_off=r * H)
+            touched[g] = True
+            if _adjacent(ws) and _adjacent(gws) and _adjacent(bs) and _adjacent(gbs):
+                t = ph.target(R * H, A)
+                ph.gemm(t, TN, gh, R * H, low, A, B, b_off=g * B * A, colsum=True)
+                ph.job(EPI_SUM, t, gws[0], A)
+                ph.job(EPI_SUM, t, gbs[0], R * H, colsum=True)
+            else:
+                for r in range(R):
+                    t = ph.target(H, A)
+                    ph.gemm(t, TN, gh, R * H, low, A, B, a_off=r * H, b_off=g * B * A, colsum=True)
+                    ph.job(EPI_SUM, t, gws[r], A)
+                    ph.job(EPI_SUM, t, gbs[r], H, colsum=True)
+            out_grads += gws + gbs
+        d_pre = torch.zeros(G, B, A, device=dev, dtype=torch.float32) if not all(touched) else \
+            torch.empty(G, B, A, device=dev, dtype=torch.float32)
+        for g in range(G):
+            if touched[g]:     # gate: relu of the producer; a dropped-out group's stored value carries its mask and factor
+                ph.job(EPI_GRAD, d_low_t[g], d_pre, A, out_off=g * B * A, gate=1, aux=low, aux_off=g * B * A, ld_aux=A,
+                       gate_scale=gate_scale[g])
+        ph.targets = [t for t in ph.targets if t.problems]
+        ph.run()
+        return (d_pre, None, None, None, *out_grads)
+
+
+# ------------------------------------------------------------------------------------------------ phase 3 / 4
+class GlimpseProjections(torch.autograd.Function):
+    """x_v = cat_g relu(W_g pooled[:, g, :] + b_g): MyATT's per-glimpse MyLinear list (config/CoR2.py:133-134,143-147) on the
+    pooled features, whose input dropout the producer has applied already (K3 / the relation map).  -> [B, G*A].
+    Expects its output's gradient already gated by the relu (the fusion phase that consumes x_v does that)."""
+
+    @staticmethod
+    def forward(ctx, pooled, *params):
+        G = len(params) // 2
+        ws, bs = params[:G], params[G:]
+        _f32c(pooled, *ws, *bs)
+        B, G2, D = pooled.shape
+        if G2 != G:
+            raise ValueError("glimpse projections: pooled has %d glimpses, %d layers given" % (G2, G))
+        A = ws[0].shape[0]
+        out = torch.empty(B, G * A, device=pooled.device, dtype=torch.float32)
+        ph = Phase(pooled.device, "glimpse_fwd")
+        for g in range(G):
+            t = ph.target(B, A)
+            ph.gemm(t, NT, pooled, G * D, ws[g], D, D, a_off=g * D)
+            ph.job(EPI_LINEAR, t, out, G * A, out_off=g * A, bias=bs[g], act=1)
+        ph.run()
+        ctx.save_for_backward(pooled, *ws, *bs)
+        ctx.cfg = (B, G, D, A)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_pre):
+        B, G, D, A = ctx.cfg
+        pooled = ctx.saved_tensors[0]
+        ws, bs = ctx.saved_tensors[1:1 + G], ctx.saved_tensors[1 + G:]
+        d_pre = d_pre.contiguous()                    # [B, G*A], gated
+        dev = d_pre.device
+        d_pooled = torch.empty(B, G, D, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        ph = Phase(dev, "glimpse_bwd")
+        gws, gbs = [], []
+        odd = A % 2 != 0      # a 155-wide block of the [B,620] gradient: 4-byte aligned operand -> the scalar-load forms
+        for g in range(G):
+            if d_pooled is not None:
+                t = ph.target(B, D)
+                ph.gemm(t, NN_A4 if odd else NN, d_pre, G * A, ws[g], D, A, a_off=g * A)
+                ph.job(EPI_GRAD, t, d_pooled, G * D, out_off=g * D)
+            t = ph.target(A, D)
+            ph.gemm(t, TN_A4 if odd else TN, d_pre, G * A, pooled, G * D, B, a_off=g * A, b_off=g * D, colsum=True)
+            gw, gb = ops._grad_like(ws[g]), ops._grad_like(bs[g])
+            ph.job(EPI_SUM, t, gw, D)
+            ph.job(EPI_SUM, t, gb, A, colsum=True)
+            gws.append(gw)
+            gbs.append(gb)
+        ph.run()
+        return (d_pooled, *gws, *gbs)
+
+
+# ------------------------------------------------------------------------------------------------ phase 5
+class VectorFusion(torch.autograd.Function):
+    """x = drop(sum_r (W1_r [xs...] + b1_r) * h2[:, r, :]): the vector-vector Mutan fusion (fusion_final, putils/__init__.py:
+    232-238 with 2-D inputs; config/CoR2.py:182,236, config/ODA.py:197,239) whose first input is the concatenation of
+    `xs` (never materialised: each part contracts against its column block of W1), with the classifier's input dropout
+    (config/CoR2.py:106-109 at :189) applied to the stored result.  xs are relu outputs of glimpse phases: their gradients
+    are returned gated.  Expects d x already multiplied by the dropout mask (the classifier phase does that)."""
+
+    @staticmethod
+    def forward(ctx, h2, p_out, seed_out, n_x, *rest):
+        xs = rest[:n_x]
+        params = rest[n_x:]
+        R = len(params) // 2
+        ws, bs = params[:R], params[R:]
+        _f32c(h2, *xs, *ws, *bs)
+        B = h2.shape[0]
+        H, Ktot = ws[0].shape
+        dev = h2.device
+        h1 = torch.empty(B, R, H, device=dev, dtype=torch.float32)
+        x = torch.empty(B, H, device=dev, dtype=torch.float32)
+        ph = Phase(dev, "vector_fusion_fwd")
+        adj = _adjacent(ws) and _adjacent(bs)
+        if adj:
+            t = ph.target(B, R * H)
+            off = 0
+            for xpart in xs:
+                k = xpart.shape[1]
+                ph.gemm(t, NT, xpart, k, ws[0], Ktot, k, b_off=off)
+                off += k
+            ph.job(EPI_RANK_PRODUCT, t, h1, H, bias=bs[0].as_strided((R * H,), (1,)), R=R, aux=h2, ld_aux=R * H, out2=x,
+                   p_drop=p_out, seed=seed_out, drop_ld=H)
+        else:
+            # ranks not contiguous in memory (no flat parameter buffer): one linear job per rank, then the rank product as
+            # an elementwise job of its own
+            for r in range(R):
+                t = ph.target(B, H)
+                off = 0
+                for xpart in xs:
+                    k = xpart.shape[1]
+                    ph.gemm(t, NT, xpart, k, ws[r], Ktot, k, b_off=off)
+                    off += k
+                ph.job(EPI_LINEAR, t, h1, R * H, out_off=r * H, bias=bs[r])
+        if p_out:
+            _note_mask("fusion_out", B, H, p_out, seed_out)
+        ph.run()
+        if not adj:
+            ph2 = Phase(dev, "vector_fusion_fwd")
+            zero = torch.zeros(R * H, device=dev, dtype=torch.float32)
+            ph2.job(EPI_RANK_PRODUCT, h1.view(B, R * H), torch.empty_like(h1), H, bias=zero, R=R, aux=h2, ld_aux=R * H, out2=x,
+                    p_drop=p_out, seed=seed_out, drop_ld=H)
+            ph2.run()
+        ctx.save_for_backward(h1, h2, *xs, *ws, *bs)
+        ctx.cfg = (B, R, H, Ktot, n_x)
+        return x
+
+    @staticmethod
+    def backward(ctx, d_x):
+        B, R, H, Ktot, n_x = ctx.cfg
+        h1, h2 = ctx.saved_tensors[:2]
+        xs = ctx.saved_tensors[2:2 + n_x]
+        ws = ctx.saved_tensors[2 + n_x:2 + n_x + R]
+        bs = ctx.saved_tensors[2 + n_x + R:]
+        dev = d_x.device
+        d_x = d_x.contiguous()
+        d_h1 = torch.empty(B, R, H, device=dev, dtype=torch.float32)
+        d_h2 = torch.empty(B, R, H, device=dev, dtype=torch.float32)
+        ph = Phase(dev, "vector_fusion_bwd")
+        ph.job(EPI_RANK_PRODUCT_BWD, d_x, d_h1, R * H, pre=True, R=R, aux=h2, aux2=h1, ld_aux=R * H, out2=d_h2)
+        gws = [ops._grad_like(w) for w in ws]
+        gbs = [ops._grad_like(b) for b in bs]
+        adj = _adjacent(ws) and _adjacent(gws) and _adjacent(bs) and _adjacent(gbs)
+        d_xs = []
+        off = 0
+        for i, xpart in enumerate(xs):
+            k = xpart.shape[1]
+            t = ph.target(B, k)
+            if adj:
+                ph.gemm(t, NN, d_h1, R * H, ws[0], Ktot, R * H, b_off=off)
+            else:
+                for r in range(R):
+                    ph.gemm(t, NN, d_h1, R * H, ws[r], Ktot, H, a_off=r * H, b_off=off)
+            dx = torch.empty(B, k, device=dev, dtype=torch.float32)
+            ph.job(EPI_GRAD, t, dx, k, gate=1, aux=xpart, ld_aux=k)             # relu gate of the glimpse phase's output
+            d_xs.append(dx)
+            if adj:
+                tw = ph.target(R * H, k)
+                ph.gemm(tw, TN, d_h1, R * H, xpart, k, B, colsum=(i == 0))
+                ph.job(EPI_SUM, tw, gws[0], Ktot, out_off=off)
+                if i == 0:
+                    ph.job(EPI_SUM, tw, gbs[0], R * H, colsum=True)
+            else:
+                for r in range(R):
+                    tw = ph.target(H, k)
+                    ph.gemm(tw, TN, d_h1, R * H, xpart, k, B, a_off=r * H, colsum=(i == 0))
+                    ph.job(EPI_SUM, tw, gws[r], Ktot, out_off=off)
+                    if i == 0:
+                        ph.job(EPI_SUM, tw, gbs[r], H, colsum=True)
+            off += k
+        ph.run()
+        return (d_h2, None, None, None, *d_xs, *gws, *gbs)
+
+
+# ------------------------------------------------------------------------------------------------ phase 6
+class Classifier(torch.autograd.Function):
+    """logits = W x + b for x stored already dropped out (linear_classif, config/CoR2.py:189,237: MyLinear(510 -> C, p)).
+    Returns d x multiplied by x's dropout mask (regenerated from p / seed): the gradient at the fusion's undropped
+    output."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, p_x, seed_x):
+        _f32c(x, w, b)
+        B, K = x.shape
+        C = w.shape[0]
+        logits = torch.empty(B, C, device=x.device, dtype=torch.float32)
+        ph = Phase(x.device, "classifier_fwd")
+        t = ph.target(B, C)
+        ph.gemm(t, NT, x, K, w, K, K)
+        ph.job(EPI_LINEAR, t, logits, C, bias=b)
+        ph.run()
+        ctx.save_for_backward(x, w, b)
+        ctx.cfg = (B, K, C, float(p_x), seed_x)
+        return logits
+
+    @staticmethod
+    def backward(ctx, d_logits):
+        B, K, C, p_x, seed_x = ctx.cfg
+        x, w, b = ctx.saved_tensors
+        d_logits = d_logits.contiguous()
+        dev = x.device
+        ph = Phase(dev, "classifier_bwd")
+        d_x = None
+        if ctx.needs_input_grad[0]:
+            t = ph.target(B, K)
+            ph.gemm(t, NN, d_logits, C, w, K, C)
+            d_x = torch.empty(B, K, device=dev, dtype=torch.float32)
+            ph.job(EPI_GRAD, t, d_x, K, p_drop=p_x, seed=seed_x, drop_ld=K)
+        tw = ph.target(C, K)
+        ph.gemm(tw, TN, d_logits, C, x, K, B, colsum=True)
+        gw, gb = ops._grad_like(w), ops._grad_like(b)
+        ph.job(EPI_SUM, tw, gw, K)
+        ph.job(EPI_SUM, tw, gb, C, colsum=True)
+        ph.run()
+        return d_x, gw, gb, None, None

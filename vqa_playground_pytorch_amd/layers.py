@@ -292,24 +292,27 @@ class MutanFusion(nn.Module):
     def stack_groups(self):
         return linear_stack_groups(list(self.list_linear2)) + linear_stack_groups(list(self.list_linear1))
 
-    def forward(self, inputs1, inputs2, relu_input=False, packed=None):
+    def forward(self, inputs1, inputs2, relu_input=False, packed=None, h2=None):
         """relu_input: inputs1 is the relu output of the layer in front and the gradient returned for it may come back
         multiplied by (inputs1 > 0) already (that layer's backward then skips the gate: MyConv1d.grad_pregated).
-        packed (bf16 inputs1): the region-side shadows from the model's ops.ShadowPlan."""
+        packed (bf16 inputs1): the region-side shadows from the model's ops.ShadowPlan.
+        h2 [B,R,H]: the question-side rank factors Linear2_r(inputs2) when a grouped phase of the model has computed them
+        already (head.GatesAndRankFactors); inputs2 is then not read."""
         # (bf16 region tensors carry the feature dim zero-padded to a multiple of 64: see ops.pad_to)
         want = ops.pad_to(self.input_dim1) if inputs1.dtype == torch.bfloat16 else self.input_dim1
         if inputs1.size(-1) != want:
             raise ValueError(
                 "[error] putils.Linear(%s, %s): last dimension of input(%s) should equal to in_features(%s)"
                 % (self.input_dim1, self.hidden_dim, inputs1.size(-1), self.input_dim1))
-        if inputs2.dim() != 2 or inputs2.size(0) != inputs1.size(0):
-            raise ValueError("MutanFusion: inputs2 must be [B, input_dim2] with the batch of inputs1")
-        # question side: R small [B,in2]x[in2,H] GEMMs (Linear's own check raises ValueError on a bad last dim)
-        if inputs2.size(-1) != self.input_dim2:
-            raise ValueError(
-                "[error] putils.Linear(%s, %s): last dimension of input(%s) should equal to in_features(%s)"
-                % (self.input_dim2, self.hidden_dim, inputs2.size(-1), self.input_dim2))
-        h2 = my_linears(list(self.list_linear2), inputs2)                              # [B,R,H], one batched GEMM
+        if h2 is None:
+            if inputs2.dim() != 2 or inputs2.size(0) != inputs1.size(0):
+                raise ValueError("MutanFusion: inputs2 must be [B, input_dim2] with the batch of inputs1")
+            # question side: R small [B,in2]x[in2,H] GEMMs (Linear's own check raises ValueError on a bad last dim)
+            if inputs2.size(-1) != self.input_dim2:
+                raise ValueError(
+                    "[error] putils.Linear(%s, %s): last dimension of input(%s) should equal to in_features(%s)"
+                    % (self.input_dim2, self.hidden_dim, inputs2.size(-1), self.input_dim2))
+            h2 = my_linears(list(self.list_linear2), inputs2)                          # [B,R,H], one batched GEMM
         if inputs1.dim() == 2 and inputs1.is_cuda:
             # vector-vector fusion (fusion_final: B rows, not B*N): a few hundred MFLOP, far too little for the K4 tile
             # kernels (16-64 workgroups, each walking the whole K = 1240 twice: 85 us forward).  Both sides run as
@@ -351,14 +354,30 @@ class MyATT(nn.Module):
         mods = list(self.list_linear_v_fusion)
         return os.environ.get("VQA_FUSE_POOL_DROPOUT", "1") == "1" and all(getattr(m, "p", None) == mods[0].p for m in mods)
 
-    def glimpse_projection(self, pooled, predropped=False):
+    def glimpse_projection(self, pooled, predropped=False, grouped=False):
         """cat_g MyLinear_g(pooled[:, g, :]) (config/CoR2.py:143-147).  The G layers have one shape, so they run as ONE
         batched GEMM over the [B,G,D] tensor (one dropout draw over all of it, one bias add, one activation) instead of
-        G x {slice, dropout, GEMM, activation} and, backward, G slice gradients that autograd zero-fills and adds."""
+        G x {slice, dropout, GEMM, activation} and, backward, G slice gradients that autograd zero-fills and adds.
+        grouped: as a phase of the grouped head (head.GlimpseProjections) -- ONLY when the consumer of the result is the
+        head's fusion phase, which hands the gradient back gated by the relu."""
+        if grouped:
+            from . import head
+            mods = list(self.list_linear_v_fusion)
+            pd = self.glimpse_dropout()
+            if pd and not predropped:
+                pooled = ops.dropout(pooled, pd)
+            return head.GlimpseProjections.apply(pooled.contiguous(), *[m.linear.weight for m in mods],
+                                                 *[m.linear.bias for m in mods])
         y = my_linears(list(self.list_linear_v_fusion), pooled, predropped=predropped)   # [B,G,A]
         return y.reshape(y.size(0), -1)
 
-    def attend(self, inputs, logits, pooled_map=None, return_pooled=False):
+    def grouped_ok(self, inputs):
+        """Can the glimpse projections run as a grouped phase?  (relu layers of one shape, fp32 GPU tensors)"""
+        mods = list(self.list_linear_v_fusion)
+        return inputs.is_cuda and self.af == "relu" and self.inputs_dim % 2 == 0 and \
+            all(getattr(m, "af", None) == "relu" and m.out_features == mods[0].out_features and m.p == mods[0].p for m in mods)
+
+    def attend(self, inputs, logits, pooled_map=None, return_pooled=False, grouped=False):
         """logits [B,N,G] (pre-softmax) -> (x_v, list_att, alpha [B,N,G][, pooled[:, 0] [B,D]]).  pooled_map (optional):
         ``pooled_map(pooled, p) -> tensor`` transforms the pooled features before the glimpse projections AND applies
         their input dropout at rate p (so the two share one pass).  (Nothing that carries an autograd graph is kept on
@@ -370,7 +389,7 @@ class MyATT(nn.Module):
             # glimpse 0 comes back undropped as its own tensor for the caller (CoR2's relation step)
             res = ops.softmax_attention_pool_drop(logits, inputs, pd, ops.next_dropout_seed() if pd else 0, return_pooled)
             alpha, pooled = res[0], res[1]
-            x_v = self.glimpse_projection(pooled, predropped=True)
+            x_v = self.glimpse_projection(pooled, predropped=True, grouped=grouped)
             if return_pooled:
                 return x_v, torch.split(alpha, 1, dim=2), alpha, res[2]
             return x_v, torch.split(alpha, 1, dim=2), alpha
@@ -378,9 +397,9 @@ class MyATT(nn.Module):
         if return_pooled:       # glimpse 0 for the caller (CoR2's relation step), the whole tensor for the projections
             pooled, first = ops.with_first_group(pooled)
         if pooled_map is None:
-            x_v = self.glimpse_projection(pooled)
+            x_v = self.glimpse_projection(pooled, grouped=grouped)
         else:
-            x_v = self.glimpse_projection(pooled_map(pooled, self.glimpse_dropout()), predropped=True)
+            x_v = self.glimpse_projection(pooled_map(pooled, self.glimpse_dropout()), predropped=True, grouped=grouped)
         if return_pooled:
             return x_v, torch.split(alpha, 1, dim=2), alpha, first
         return x_v, torch.split(alpha, 1, dim=2), alpha
