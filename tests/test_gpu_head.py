@@ -145,12 +145,12 @@ def test_head_phases_match_plain_layers(head, B, train):
     masks = {}
     head._mask_spy = lambda site, rows, cols, p_, seed: masks.__setitem__(site, _mask(ops, rows, cols, p_, seed))
     try:
-        low = head.QuestionProjections.apply(q, p, 11, (2, 3), p, 12, (), *wq, *bq)
+        lows = head.QuestionProjections.apply(q, p, 11, (2, 3), p, 12, (), *wq, *bq)
         s = 1.0 / (1.0 - p) if p else 1.0
         flat = we[0], be[0], we[1], be[1]
         for f in range(3):
             flat += tuple(w2[f]) + tuple(b2[f])
-        q1, q2, h2a, h2b, h2f = head.GatesAndRankFactors.apply(low, (2, 3), ((0, R), (0, R), (1, R)), (1.0, 1.0, s, s), *flat)
+        q1, q2, h2a, h2b, h2f = head.GatesAndRankFactors.apply(4, (2, 3), ((0, R), (0, R), (1, R)), (1.0, 1.0, s, s), *lows, *flat)
         v_att = [head.GlimpseProjections.apply(pooled[a_], *wg[a_], *bg[a_]) for a_ in range(2)]
         x = head.VectorFusion.apply(h2f, p, 13, 2, v_att[0], v_att[1], *w1, *b1)
         logits = head.Classifier.apply(x, wc, bc, p, 13)

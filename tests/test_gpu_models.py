@@ -146,7 +146,7 @@ KEEP_MIN = {"cor2": 0.4, "oda": 0.7}   # share of the 512 samples that must be f
 RTOL_EDGE_MAX = 3e-2   # knife-edge samples: max-abs error of a gradient tensor, on the tensor's own scale ...
 RTOL_EDGE_FRO = 1e-2   # ... and its relative Frobenius error (a handful of flipped units does not move the norm)
 VARIANTS = [("cor2", 2000, "default"), ("cor2", 2000, "pairwise"), ("cor2", 2000, "k4_engine"), ("cor2", 2000, "legacy_head"),
-            ("oda", 3000, "default")]
+            ("oda", 3000, "default"), ("oda", 3000, "legacy_head")]
 _oracle_cache = {}
 
 
@@ -370,7 +370,11 @@ def test_training_step_with_shared_masks_against_oracle(cls, nans, variant, monk
             masks["att1.list_linear_v_fusion.%d" % g] = m[4][:, g]
             masks["att2.list_linear_v_fusion.%d" % g] = m[7][:, g]
     else:
-        assert kinds == ["linear_act", "dropout", "k2", "pool_drop", "dropout"], kinds
+        if kinds[1].startswith("head:"):
+            assert kinds == ["linear_act", "head:question_in", "k2", "pool_drop", "head:fusion_out"], kinds
+            m[1] = m[1].view(2, B, 2400)
+        else:
+            assert kinds == ["linear_act", "dropout", "k2", "pool_drop", "dropout"], kinds
         assert m[1].shape == (2, B, 2400) and m[2].shape == (B, N, N * 310) and m[3].shape == (B, 4, 2048)
         masks = {"compress_v": m[0], "compress_q": m[1][0], "linear_q": m[1][1], "att.conv_att": m[2], "linear_classif": m[4]}
         for g in range(4):

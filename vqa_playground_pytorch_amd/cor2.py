@@ -146,17 +146,17 @@ class Model(nn.Module):
         proj = [self.compress_q, self.linear_q, self.compress_q_1, self.compress_q_2]
         p_in = float(proj[0].p) if (self.training and proj[0].p) else 0.0
         p_g = float(self.expand_q_1.p) if (self.training and self.expand_q_1.p) else 0.0
-        low = head.QuestionProjections.apply(q_feature.contiguous(), p_in, ops.next_dropout_seed() if p_in else 0, (2, 3), p_g,
-                                             ops.next_dropout_seed() if p_g else 0, (),
-                                             *[m.linear.weight for m in proj], *[m.linear.bias for m in proj])
+        lows = head.QuestionProjections.apply(q_feature.contiguous(), p_in, ops.next_dropout_seed() if p_in else 0, (2, 3), p_g,
+                                              ops.next_dropout_seed() if p_g else 0, (),
+                                              *[m.linear.weight for m in proj], *[m.linear.bias for m in proj])
         s = 1.0 / (1.0 - p_g) if p_g else 1.0
         fus = [self.fusion_vq1, self.fusion_vq2, self.fusion_final]
         params = [self.expand_q_1.linear.weight, self.expand_q_1.linear.bias, self.expand_q_2.linear.weight,
                   self.expand_q_2.linear.bias]
         for mf in fus:
             params += [lin.linear.weight for lin in mf.list_linear2] + [lin.linear.bias for lin in mf.list_linear2]
-        return head.GatesAndRankFactors.apply(low, (2, 3), ((0, fus[0].R), (0, fus[1].R), (1, fus[2].R)), (1.0, 1.0, s, s),
-                                              *params)
+        return head.GatesAndRankFactors.apply(4, (2, 3), ((0, fus[0].R), (0, fus[1].R), (1, fus[2].R)), (1.0, 1.0, s, s),
+                                              *lows, *params)
 
     def _final_phases(self, v1_att, v2_att, h2_final):
         """Phases 5 and 6: fusion_final (its first input is cat(v1_att, v2_att), never materialised) with the rank product and

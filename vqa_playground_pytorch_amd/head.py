@@ -195,16 +195,16 @@ def supported(*dims):
 
 # ------------------------------------------------------------------------------------------------ phase 1
 class QuestionProjections(torch.autograd.Function):
-    """low[g] = drop_g(relu(drop(q) W_g^T + b_g)) for the G MyLinear(2400 -> 310, p, relu) that read the question vector
-    (config/CoR2.py:170,180,183,186 applied at :205,:193-194,:230; config/ODA.py:186-187).  Each layer draws its own input
-    mask over q (the reference calls them one after the other); groups listed in `dropped` are stored with the input
-    dropout of THEIR consumer applied (expand_q_{1,2}, config/CoR2.py:184,187).  -> low [G,B,A].
-    The gradient handed back for `low` must arrive gated (see the module docstring); q gets no gradient here."""
+    """low_g = drop_g(relu(drop(q) W_g^T + b_g)) for the G MyLinear(2400 -> 310, p, relu) that read the question vector
+    (config/CoR2.py:170,180,183,186 applied at :205,:193-194,:230; config/ODA.py:185,193 at :207,:233).  Each layer draws its
+    own input mask over q (the reference calls them one after the other); groups listed in `dropped` are stored with the
+    input dropout of THEIR consumer applied (expand_q_{1,2}, config/CoR2.py:184,187).  -> G tensors [B,A].
+    The gradient of an output must arrive gated (see the module docstring) unless its group is listed in `ungated` (its
+    consumer is not a phase of this module: ODA's object-difference kernel reads low_0) -- those are gated here, by a
+    pre-job of the backward launch.  q gets no gradient here."""
 
     @staticmethod
     def forward(ctx, q, p_in, seed_in, dropped, p_out, seed_out, ungated, *params):
-        # ungated: groups whose consumer is NOT a phase of this module (ODA's object-difference kernel reads low[0]): their
-        # gradient arrives as the plain gradient of the stored value and is gated here, by a pre-job of the backward launch
         G = len(params) // 2
         ws, bs = params[:G], params[G:]
         _f32c(q, *ws, *bs)
@@ -229,25 +229,30 @@ class QuestionProjections(torch.autograd.Function):
         ph.run()
         ctx.save_for_backward(qd, low, *ws, *bs)
         ctx.cfg = (G, B, K, A, bool(p_in), tuple(ungated), tuple(dropped), float(p_out))
-        return low
+        return tuple(low[g] for g in range(G))
 
     @staticmethod
-    def backward(ctx, d_pre):
+    def backward(ctx, *d_lows):
         G, B, K, A, dropped_in, ungated, dropped, p_out = ctx.cfg
         qd, low = ctx.saved_tensors[:2]
         ws, bs = ctx.saved_tensors[2:2 + G], ctx.saved_tensors[2 + G:]
-        d_pre = d_pre.contiguous()
-        ph = Phase(d_pre.device, "q_proj_bwd")
-        if ungated:
-            d_pre = d_pre.clone() if d_pre._base is not None or not d_pre.is_contiguous() else d_pre
-            for g in ungated:
-                scale = 1.0 / (1.0 - p_out) if (g in dropped and p_out) else 1.0
-                ph.job(EPI_GRAD, d_pre[g], d_pre, A, out_off=g * B * A, pre=True, gate=1, aux=low, aux_off=g * B * A, ld_aux=A,
-                       gate_scale=scale)
+        dev = low.device
+        ph = Phase(dev, "q_proj_bwd")
         grads_w, grads_b = [], []
         for g in range(G):
+            d = d_lows[g]
+            if d is None:
+                grads_w.append(None)
+                grads_b.append(None)
+                continue
+            d = d.contiguous()
+            if g in ungated:
+                scale = 1.0 / (1.0 - p_out) if (g in dropped and p_out) else 1.0
+                gated = torch.empty(B, A, device=dev, dtype=torch.float32)
+                ph.job(EPI_GRAD, d, gated, A, pre=True, gate=1, aux=low, aux_off=g * B * A, ld_aux=A, gate_scale=scale)
+                d = gated
             t = ph.target(A, K)
-            ph.gemm(t, TN, d_pre, A, qd, K, B, a_off=g * B * A, b_off=g * B * K if dropped_in else 0, colsum=True)
+            ph.gemm(t, TN, d, A, qd, K, B, b_off=g * B * K if dropped_in else 0, colsum=True)
             gw, gb = ops._grad_like(ws[g]), ops._grad_like(bs[g])
             ph.job(EPI_SUM, t, gw, K)
             ph.job(EPI_SUM, t, gb, A, colsum=True)
@@ -259,32 +264,31 @@ class QuestionProjections(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------------ phase 2
 class GatesAndRankFactors(torch.autograd.Function):
-    """Everything that reads the projected question: the sigmoid gates expand_q_{1,2}(low[2]), (low[3]) (config/CoR2.py:
+    """Everything that reads the projected question: the sigmoid gates expand_q_{1,2}(low_2), (low_3) (config/CoR2.py:
     184,187: MyLinear(310 -> 2048, p, sigmoid); their input dropout is already in the stored low) and the question-side rank
-    factors h2 = Linear2_r(q) of the Mutan fusions (putils/__init__.py:232-238), each reading one group of low.
-    spec: n_gates gate layers first (group index each), then fusions as (group index, R).
-    -> (gate outputs [B,D] ..., h2 [B,R,H] per fusion).  Returns d low already gated by low's relu / dropout."""
+    factors h2 = Linear2_r(q) of the Mutan fusions (putils/__init__.py:232-238), each reading one of the n_low tensors.
+    gate_groups: which low tensor each gate reads; fusions: (low index, R) per fusion; gate_scale[g]: 1, or 1/(1-p) when
+    low_g is stored dropped out.  -> (gate outputs [B,D] ..., h2 [B,R,H] per fusion).
+    Returns the gradient of every low tensor it read already gated by that tensor's relu / dropout (None for the others)."""
 
     @staticmethod
-    def forward(ctx, low, gate_groups, fusions, gate_scale, *params):
-        # params: for each gate (W [D,A], b [D]); then for each fusion R weights [H,A] followed by R biases [H]
-        G, B, A = low.shape
-        dev = low.device
-        _f32c(low, *params)
+    def forward(ctx, n_low, gate_groups, fusions, gate_scale, *rest):
+        # rest: the n_low tensors [B,A]; then per gate (W [D,A], b [D]); then per fusion R weights [H,A] and R biases [H]
+        lows, params = rest[:n_low], rest[n_low:]
+        B, A = lows[0].shape
+        dev = lows[0].device
+        _f32c(*lows, *params)
         ph = Phase(dev, "gates_h2_fwd")
         outs, idx = [], 0
-        gates = []
         for g in gate_groups:
             W, b = params[idx], params[idx + 1]
             idx += 2
             D = W.shape[0]
             y = torch.empty(B, D, device=dev, dtype=torch.float32)
             t = ph.target(B, D)
-            ph.gemm(t, NT, low, A, W, A, A, a_off=g * B * A)
+            ph.gemm(t, NT, lows[g], A, W, A, A)
             ph.job(EPI_LINEAR, t, y, D, bias=b, act=2)
             outs.append(y)
-            gates.append((g, W, b))
-        fus = []
         for g, R in fusions:
             ws, bs = params[idx:idx + R], params[idx + R:idx + 2 * R]
             idx += 2 * R
@@ -292,31 +296,30 @@ class GatesAndRankFactors(torch.autograd.Function):
             h2 = torch.empty(B, R, H, device=dev, dtype=torch.float32)
             if _adjacent(ws) and _adjacent(bs):
                 t = ph.target(B, R * H)
-                ph.gemm(t, NT, low, A, ws[0], A, A, a_off=g * B * A)
+                ph.gemm(t, NT, lows[g], A, ws[0], A, A)
                 ph.job(EPI_LINEAR, t, h2, R * H, bias=bs[0].as_strided((R * H,), (1,)))
             else:
                 for r in range(R):
                     t = ph.target(B, H)
-                    ph.gemm(t, NT, low, A, ws[r], A, A, a_off=g * B * A)
+                    ph.gemm(t, NT, lows[g], A, ws[r], A, A)
                     ph.job(EPI_LINEAR, t, h2, R * H, out_off=r * H, bias=bs[r])
             outs.append(h2)
-            fus.append((g, R, H, ws, bs))
         ph.run()
-        ctx.save_for_backward(low, *outs[:len(gates)], *params)
-        ctx.cfg = (G, B, A, tuple(gate_groups), tuple(fusions), tuple(gate_scale))
+        ng = len(gate_groups)
+        ctx.save_for_backward(*lows, *outs[:ng], *params)
+        ctx.cfg = (n_low, B, A, tuple(gate_groups), tuple(fusions), tuple(gate_scale))
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
         G, B, A, gate_groups, fusions, gate_scale = ctx.cfg
-        low = ctx.saved_tensors[0]
+        lows = ctx.saved_tensors[:G]
         ng = len(gate_groups)
-        ys = ctx.saved_tensors[1:1 + ng]
-        params = ctx.saved_tensors[1 + ng:]
-        dev = low.device
+        ys = ctx.saved_tensors[G:G + ng]
+        params = ctx.saved_tensors[G + ng:]
+        dev = lows[0].device
         ph = Phase(dev, "gates_h2_bwd")
         d_low_t = [ph.target(B, A) for _ in range(G)]
-        touched = [False] * G
         out_grads, idx = [], 0
         # gates: dg = d_y * y (1 - y) first (an elementwise pre-job), then dg W (data) and dg^T low_g (weight)
         for i, g in enumerate(gate_groups):
@@ -331,9 +334,8 @@ class GatesAndRankFactors(torch.autograd.Function):
             dg = torch.empty(B, D, device=dev, dtype=torch.float32)
             ph.job(EPI_GRAD, gy, dg, D, pre=True, gate=2, aux=ys[i], ld_aux=D)
             ph.gemm(d_low_t[g], NN, dg, D, W, A, D)
-            touched[g] = True
             t = ph.target(D, A)
-            ph.gemm(t, TN, dg, D, low, A, B, b_off=g * B * A, colsum=True)
+            ph.gemm(t, TN, dg, D, lows[g], A, B, colsum=True)
             gw, gb = ops._grad_like(W), ops._grad_like(b)
             ph.job(EPI_SUM, t, gw, A)
             ph.job(EPI_SUM, t, gb, D, colsum=True)
@@ -354,28 +356,29 @@ class GatesAndRankFactors(torch.autograd.Function):
             else:
                 for r in range(R):
                     ph.gemm(d_low_t[g], NN, gh, R * H, ws[r], A, H, a_off=r * H)
-            touched[g] = True
             if _adjacent(ws) and _adjacent(gws) and _adjacent(bs) and _adjacent(gbs):
                 t = ph.target(R * H, A)
-                ph.gemm(t, TN, gh, R * H, low, A, B, b_off=g * B * A, colsum=True)
+                ph.gemm(t, TN, gh, R * H, lows[g], A, B, colsum=True)
                 ph.job(EPI_SUM, t, gws[0], A)
                 ph.job(EPI_SUM, t, gbs[0], R * H, colsum=True)
             else:
                 for r in range(R):
                     t = ph.target(H, A)
-                    ph.gemm(t, TN, gh, R * H, low, A, B, a_off=r * H, b_off=g * B * A, colsum=True)
+                    ph.gemm(t, TN, gh, R * H, lows[g], A, B, a_off=r * H, colsum=True)
                     ph.job(EPI_SUM, t, gws[r], A)
                     ph.job(EPI_SUM, t, gbs[r], H, colsum=True)
             out_grads += gws + gbs
-        d_pre = torch.zeros(G, B, A, device=dev, dtype=torch.float32) if not all(touched) else \
-            torch.empty(G, B, A, device=dev, dtype=torch.float32)
+        d_lows = []
         for g in range(G):
-            if touched[g]:     # gate: relu of the producer; a dropped-out group's stored value carries its mask and factor
-                ph.job(EPI_GRAD, d_low_t[g], d_pre, A, out_off=g * B * A, gate=1, aux=low, aux_off=g * B * A, ld_aux=A,
-                       gate_scale=gate_scale[g])
+            if d_low_t[g].problems:    # gate: relu of the producer; a dropped-out tensor's stored value carries mask and factor
+                d = torch.empty(B, A, device=dev, dtype=torch.float32)
+                ph.job(EPI_GRAD, d_low_t[g], d, A, gate=1, aux=lows[g], ld_aux=A, gate_scale=gate_scale[g])
+                d_lows.append(d)
+            else:
+                d_lows.append(None)
         ph.targets = [t for t in ph.targets if t.problems]
         ph.run()
-        return (d_pre, None, None, None, *out_grads)
+        return (None, None, None, None, *d_lows, *out_grads)
 
 
 # ------------------------------------------------------------------------------------------------ phase 3 / 4

@@ -7,7 +7,7 @@ its dropout mask are never built: HIP kernel K2 contracts them against the atten
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import head, ops
 from .layers import MutanFusion, MyATT, MyConv1d, MyLinear, QuestionVectorInput, linear_stack_groups, my_linears, question_feature
 
 
@@ -47,6 +47,14 @@ class Model(nn.Module):
         w = conv.conv.weight.view(conv.out_channels, -1)
         return ops.object_difference_attention(v_feature_low, q_feature_low, w, conv.conv.bias, p, seed)
 
+    def _grouped_head_ok(self, q_feature, cut):
+        """As cor2.Model._grouped_head_ok: the [B,.]-sized layers as grouped phases (head.py)."""
+        return (cut is None and q_feature.is_cuda and q_feature.dtype == torch.float32 and not q_feature.requires_grad
+                and self.compress_q.af == "relu" and self.linear_q.af == "relu" and self.compress_q.p == self.linear_q.p
+                and self.linear_classif.af in (None, "") and self.att.grouped_ok(q_feature)
+                and head.supported(q_feature.size(1), self.compress_q.out_features, self.fusion_final.hidden_dim,
+                                   self.fusion_final.input_dim1, self.num_classes))
+
     def late_parameters(self):
         """Parameters behind the attention (fusion_final, the classifier: 3.9 M of the 7.3 M): their gradients are complete
         before backward enters the attention and the region projection (see cor2.CoR2Model.late_parameters)."""
@@ -67,13 +75,33 @@ class Model(nn.Module):
         q_feature = question_feature(self.seq2vec, sample["q_idxes"] if "q_idxes" in sample else sample["q"])
 
         v_feature_low = self.compress_v(v_feature)
-        # the two MyLinear(2400 -> 310) on the question vector (config/ODA.py:185,193 applied at :207,:233): one batched GEMM
-        q_both = my_linears([self.compress_q, self.linear_q], q_feature, group_first=True)   # [2,B,310]
-        q_feature_low, q_final = ops.split_groups(q_both, (1, 1))                              # views; one cat kernel backward
+        grouped = self._grouped_head_ok(q_feature, _cut)
+        if grouped:
+            # the [B,.]-sized layers as grouped phases (head.py): the two question projections (the object-difference kernel
+            # reads the first one: its gradient comes back ungated), then fusion_final's question-side rank factors
+            proj = [self.compress_q, self.linear_q]
+            p_in = float(proj[0].p) if (self.training and proj[0].p) else 0.0
+            q_feature_low, q_final = head.QuestionProjections.apply(
+                q_feature.contiguous(), p_in, ops.next_dropout_seed() if p_in else 0, (), 0.0, 0, (0,),
+                *[m.linear.weight for m in proj], *[m.linear.bias for m in proj])
+            lin2 = list(self.fusion_final.list_linear2)
+            (h2_final,) = head.GatesAndRankFactors.apply(2, (), ((1, self.fusion_final.R),), (1.0, 1.0), q_feature_low, q_final,
+                                                         *[l.linear.weight for l in lin2], *[l.linear.bias for l in lin2])
+        else:
+            # the two MyLinear(2400 -> 310) on the question vector (config/ODA.py:185,193 applied at :207,:233): one batched GEMM
+            q_both = my_linears([self.compress_q, self.linear_q], q_feature, group_first=True)   # [2,B,310]
+            q_feature_low, q_final = ops.split_groups(q_both, (1, 1))                              # views; one cat kernel backward
         logits = self.difference_logits(v_feature_low, q_feature_low)
-        v_final, alphas, _ = self.att.attend(v_feature, logits)
+        v_final, alphas, _ = self.att.attend(v_feature, logits, grouped=grouped)
 
         self.alpha_dict = {"alphas": alphas[0].detach()}
+        if grouped:
+            p_c = float(self.linear_classif.p) if (self.training and self.linear_classif.p) else 0.0
+            seed = ops.next_dropout_seed() if p_c else 0
+            lin1 = list(self.fusion_final.list_linear1)
+            x = head.VectorFusion.apply(h2_final, p_c, seed, 1, v_final, *[l.linear.weight for l in lin1],
+                                        *[l.linear.bias for l in lin1])
+            return head.Classifier.apply(x, self.linear_classif.linear.weight, self.linear_classif.linear.bias, p_c, seed)
 
         if _cut is not None:
             outs = [v_final, q_final]
