@@ -130,7 +130,8 @@ __global__ __launch_bounds__(kBfThreads) void gemm_bf16_nt_kernel(const bf16* __
 // slab[s][N1][N2] (fp32) = A[rows of split s, 0:N1)^T * B[rows of split s, 0:N2)
 // XB: operand transform on B while it is staged (BfDropHalf: B is the dropped-out input of the layer whose weight gradient
 // this is; the factor 2 is applied by the slab reduction).
-template <int BM, int BN, class XB>
+// TR: stage the operands untransposed and transpose on the LDS read (ds_read_b64_tr_b16; default) instead of in registers
+template <int BM, int BN, class XB, bool TR>
 __global__ __launch_bounds__(kBfThreads) void gemm_bf16_tn_kernel(const bf16* __restrict__ A, int lda,
                                                                   const bf16* __restrict__ B, int ldb,
                                                                   float* __restrict__ slab, int Kdim, int N1, int N2,
@@ -144,7 +145,13 @@ __global__ __launch_bounds__(kBfThreads) void gemm_bf16_tn_kernel(const bf16* __
   const int k_lo = s * rows_per_split, k_hi = min(Kdim, k_lo + rows_per_split);
   f32x16 acc[T::TM][T::TN];
   bf_zero_acc(acc);
-  if constexpr (XB::kActive) {
+  if constexpr (TR) {
+    if constexpr (XB::kActive) {
+      gemm_bf16_tn_tile_tr<BM, BN, XB>(A, lda, N1, B, ldb, N2, m0, n0, k_lo, k_hi, smem, acc, XB{drop_key(dc), mask_ld});
+    } else {
+      gemm_bf16_tn_tile_tr<BM, BN>(A, lda, N1, B, ldb, N2, m0, n0, k_lo, k_hi, smem, acc);
+    }
+  } else if constexpr (XB::kActive) {
     gemm_bf16_tn_tile<BM, BN, XB>(A, lda, N1, B, ldb, N2, m0, n0, k_lo, k_hi, smem, acc, XB{drop_key(dc), mask_ld});
   } else {
     gemm_bf16_tn_tile<BM, BN>(A, lda, N1, B, ldb, N2, m0, n0, k_lo, k_hi, smem, acc);
@@ -253,12 +260,20 @@ static int launch_tn(const char* who, const bf16* A, int lda, const bf16* B, int
   const int tiles_m = (N1 + t.bm - 1) / t.bm, tiles_n = (N2 + t.bn - 1) / t.bn;
   int rows_per_split = (Kdim + S - 1) / S;
   rows_per_split = (rows_per_split + kBfBK - 1) / kBfBK * kBfBK;
-#define LAUNCH_X(BM_, BN_, XB_)                                                                                             \
+  const char* form = vqa::option("VQA_BF16_TN");           // "perm": the register-transpose staging (comparison knob)
+  const bool tr = !(form != nullptr && form[0] == 'p');
+#define LAUNCH_T(BM_, BN_, XB_, TR_)                                                                                        \
   {                                                                                                                         \
-    const size_t lds = BfTile<BM_, BN_>::kSmemBytes;                                                                        \
-    VQA_ENSURE_LDS((gemm_bf16_tn_kernel<BM_, BN_, XB_>), lds);                                                              \
-    hipLaunchKernelGGL((gemm_bf16_tn_kernel<BM_, BN_, XB_>), dim3(tiles_m * tiles_n, 1, S), dim3(kBfThreads), lds, s, A, lda, \
-                       B, ldb, workspace, Kdim, N1, N2, rows_per_split, tiles_n, ex.dc, ex.mask_ld);                        \
+    const size_t lds = TR_ ? (size_t)BfTileTr<BM_, BN_>::kSmemBytes : (size_t)BfTile<BM_, BN_>::kSmemBytes;                 \
+    VQA_ENSURE_LDS((gemm_bf16_tn_kernel<BM_, BN_, XB_, TR_>), lds);                                                         \
+    hipLaunchKernelGGL((gemm_bf16_tn_kernel<BM_, BN_, XB_, TR_>), dim3(tiles_m * tiles_n, 1, S), dim3(kBfThreads), lds, s,  \
+                       A, lda, B, ldb, workspace, Kdim, N1, N2, rows_per_split, tiles_n, ex.dc, ex.mask_ld);                \
+  }
+#define LAUNCH_X(BM_, BN_, XB_)    \
+  if (tr) {                        \
+    LAUNCH_T(BM_, BN_, XB_, true)  \
+  } else {                         \
+    LAUNCH_T(BM_, BN_, XB_, false) \
   }
 #define LAUNCH(BM_, BN_)                   \
   if (ex.drop) {                           \
@@ -269,6 +284,7 @@ static int launch_tn(const char* who, const bf16* A, int lda, const bf16* B, int
   VQA_BF_TILE_SWITCH(t, LAUNCH);
 #undef LAUNCH
 #undef LAUNCH_X
+#undef LAUNCH_T
   (void)groups;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((out_cols + 511) / 512), (unsigned)N1), dim3(256), 0, s, workspace,
                      outs, S, N1, N2, gp, out_rows, out_cols, out_ld, ex.scale);

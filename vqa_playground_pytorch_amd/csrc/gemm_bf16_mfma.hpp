@@ -269,6 +269,138 @@ __device__ __forceinline__ void gemm_bf16_tn_tile(const bf16* __restrict__ A, in
   }
 }
 
+// ---- TN form on transposed LDS reads (ds_read_b64_tr_b16) ---------------------------------------------------------------
+// The weight-gradient operands are K-strided (k = batch row): the form above transposes every 8x8 block in registers
+// (32 v_perm_b32 + 8 ds_write_b128 per block) to build the [mn][k] image the NT fragments read.  gfx950 can transpose on
+// the READ side instead: the tile is stored as it arrives, [k][mn] rows (16-byte global loads along mn, ds_write_b128 of
+// the same 16 bytes), and a lane gets the 4 consecutive k of its column with one ds_read_b64_tr_b16 -- two of them are the
+// 8-element MFMA operand.  Row pitch = 2 BMN + 64 bytes: the four k-rows a 32-lane half reads (4 x 64 contiguous bytes)
+// start 64 bytes apart modulo the 256-byte bank row, so the reads are conflict-free; the writes are 128 contiguous bytes
+// per 8 lanes.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN>
+struct BfTileTr {
+  static constexpr int TM = BM / 64, TN = BN / 64;
+  static constexpr int PA = BM * 2 + 64, PB = BN * 2 + 64;             // row pitches in bytes
+  static constexpr int kStageBytes = kBfBK * (PA + PB);
+  static constexpr int kSmemBytes = 2 * kStageBytes;
+  static constexpr int CA = BM * kBfBK / 8 / kBfThreads, CB = BN * kBfBK / 8 / kBfThreads;   // 16-byte chunks per thread
+};
+
+__device__ __forceinline__ bf16x8 bf_tr_frag(const char* p, int pitch) {
+  typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * pitch));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int BM, int BN>
+__device__ __forceinline__ void bf_stage_mfma_tr(const char* base, f32x16 (&acc)[BM / 64][BN / 64]) {
+  using T = BfTileTr<BM, BN>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // lane -> (k row inside a 16-deep step, first column) of its transposed 4 x 16 block: lane 4q+p of a 16-lane group
+  // addresses row q, columns 4p .. 4p+3; groups 0/1 are the low k half of the step, 2/3 the high one; odd groups take
+  // the second 16 columns of the operand's 32
+  const int krow = 8 * (lane >> 5) + ((lane & 15) >> 2);
+  const int col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const char* ap = base + krow * T::PA + (wm * (BM / 2) + col) * 2;
+  const char* bp = base + kBfBK * T::PA + krow * T::PB + (wn * (BN / 2) + col) * 2;
+  bf16x8 a[4][T::TM], b[4][T::TN];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i) a[kk][i] = bf_tr_frag(ap + kk * 16 * T::PA + i * 64, T::PA);
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) b[kk][j] = bf_tr_frag(bp + kk * 16 * T::PB + j * 64, T::PB);
+  }
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+}
+
+// Per-thread staging state: chunk c = tid + 256 p of an operand is 16 bytes (8 columns) of tile row c / (BMN/8).
+template <int BM, int BN>
+struct TrStager {
+  using T = BfTileTr<BM, BN>;
+  const bf16* a;
+  const bf16* b;
+  int lda, ldb, k_lo, k_hi;
+  int ca[T::CA], cb[T::CB];   // source column of each chunk (clamped to a whole in-range chunk)
+  __device__ __forceinline__ TrStager(const bf16* A, int lda_, int a_cols, const bf16* B, int ldb_, int b_cols, int m0, int n0,
+                                      int k_lo_, int k_hi_)
+      : a(A), b(B), lda(lda_), ldb(ldb_), k_lo(k_lo_), k_hi(k_hi_) {
+#pragma unroll
+    for (int p = 0; p < T::CA; ++p) ca[p] = min(m0 + ((threadIdx.x + kBfThreads * p) % (BM / 8)) * 8, a_cols - 8);
+#pragma unroll
+    for (int p = 0; p < T::CB; ++p) cb[p] = min(n0 + ((threadIdx.x + kBfThreads * p) % (BN / 8)) * 8, b_cols - 8);
+  }
+  __device__ __forceinline__ static int row_a(int p) { return (threadIdx.x + kBfThreads * p) / (BM / 8); }
+  __device__ __forceinline__ static int row_b(int p) { return (threadIdx.x + kBfThreads * p) / (BN / 8); }
+  __device__ __forceinline__ void load(u32x4 (&ra)[T::CA], u32x4 (&rb)[T::CB], int step) const {
+    const int k0 = k_lo + step * kBfBK;
+#pragma unroll
+    for (int p = 0; p < T::CA; ++p) ra[p] = *reinterpret_cast<const u32x4*>(a + (size_t)min(k0 + row_a(p), k_hi - 1) * lda + ca[p]);
+#pragma unroll
+    for (int p = 0; p < T::CB; ++p) rb[p] = *reinterpret_cast<const u32x4*>(b + (size_t)min(k0 + row_b(p), k_hi - 1) * ldb + cb[p]);
+  }
+  template <class XB>
+  __device__ __forceinline__ void store(const u32x4 (&ra)[T::CA], const u32x4 (&rb)[T::CB], int step, char* base, int m0, int n0,
+                                        const XB& xb) const {
+    const int k0 = k_lo + step * kBfBK;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int p = 0; p < T::CA; ++p) {
+      const int r = row_a(p), c = ((threadIdx.x + kBfThreads * p) % (BM / 8)) * 8;
+      *reinterpret_cast<u32x4*>(base + r * T::PA + c * 2) = k0 + r < k_hi ? ra[p] : z;
+    }
+#pragma unroll
+    for (int p = 0; p < T::CB; ++p) {
+      const int r = row_b(p), c = ((threadIdx.x + kBfThreads * p) % (BN / 8)) * 8;
+      u32x4 v = k0 + r < k_hi ? rb[p] : z;
+      if constexpr (XB::kActive) v = xb(v, min(k0 + r, k_hi - 1), cb[p]);
+      *reinterpret_cast<u32x4*>(base + kBfBK * T::PA + r * T::PB + c * 2) = v;
+    }
+  }
+};
+
+// acc += A[k_lo : k_hi, m0 : m0+BM)^T * B[k_lo : k_hi, n0 : n0+BN) -- same contract as gemm_bf16_tn_tile.
+template <int BM, int BN, class XB = BfNoTransform>
+__device__ __forceinline__ void gemm_bf16_tn_tile_tr(const bf16* __restrict__ A, int lda, int a_cols,
+                                                     const bf16* __restrict__ B, int ldb, int b_cols, int m0, int n0,
+                                                     int k_lo, int k_hi, char* smem, f32x16 (&acc)[BM / 64][BN / 64],
+                                                     const XB& xb = XB()) {
+  using T = BfTileTr<BM, BN>;
+  const TrStager<BM, BN> st(A, lda, a_cols, B, ldb, b_cols, m0, n0, k_lo, k_hi);
+  const int nsteps = (k_hi - k_lo + kBfBK - 1) / kBfBK;
+  u32x4 ra0[T::CA], rb0[T::CB], ra1[T::CA], rb1[T::CB];
+  st.load(ra0, rb0, 0);
+  st.store(ra0, rb0, 0, smem, m0, n0, xb);
+  st.load(ra1, rb1, 1);
+  st.load(ra0, rb0, 2);
+  __syncthreads();
+  for (int s = 0; s < nsteps; s += 2) {
+    bf_stage_mfma_tr<BM, BN>(smem, acc);
+    st.store(ra1, rb1, s + 1, smem + T::kStageBytes, m0, n0, xb);
+    st.load(ra1, rb1, s + 3);
+    bf_interleave<4 * T::TM * T::TN, 4>();
+    __syncthreads();
+    if (s + 1 < nsteps) {
+      bf_stage_mfma_tr<BM, BN>(smem + T::kStageBytes, acc);
+      st.store(ra0, rb0, s + 2, smem, m0, n0, xb);
+      st.load(ra0, rb0, s + 4);
+      bf_interleave<4 * T::TM * T::TN, 4>();
+      __syncthreads();
+    }
+  }
+}
+
 // Row / column of accumulator register i of tile (tm, tn) for the calling lane (C/D layout of the 32x32 MFMAs:
 // col = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)).  Split into a wave-uniform part (SGPRs: the
 // epilogue addresses become scalar base + one 32-bit lane offset instead of a 64-bit VGPR pair per element) and the
