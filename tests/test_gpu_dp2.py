@@ -22,13 +22,14 @@ def _free_port():
 
 
 def _run(world, env):
-    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env)
+    # (VQA_DUMP_AFTER: should a run hang, every rank prints its threads' stacks after that many seconds and exits)
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VQA_DUMP_AFTER="240", **env)
     if world == 1:
         cmd = [sys.executable, TOOL]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
                "127.0.0.1", "--master-port", str(_free_port()), TOOL]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=e, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and lines, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
     return json.loads(lines[-1])

@@ -94,17 +94,22 @@ def test_cor2_matches_reference_golden(golden_dir, mode, k4_form, monkeypatch):
     check_grads(model, gold)
 
 
-def test_cor2_intermediates_match_reference_golden(golden_dir):
+@pytest.mark.parametrize("head_form", ["grouped", "legacy"])
+def test_cor2_intermediates_match_reference_golden(golden_dir, head_form, monkeypatch):
+    """Module outputs captured by forward hooks.  With the grouped head (default) fusion_final runs inside a phase
+    (head.VectorFusion): the module itself is not called, so its hook only fires with the legacy head."""
+    from vqa_playground_pytorch_amd import head
+    monkeypatch.setattr(head, "ENABLED", head_form == "grouped")
     gold = np.load(os.path.join(golden_dir, "cor2_b4.npz"))
     model = build("cor2", 2000)
     caps = {}
-    hooks = [getattr(model, k).register_forward_hook(lambda _m, _i, o, k=k: caps.__setitem__(k, o))
-             for k in ["fusion_vq1", "fusion_vq2", "compress_v", "compress_v2", "fusion_final"]]
+    names = ["fusion_vq1", "fusion_vq2", "compress_v", "compress_v2"] + (["fusion_final"] if head_form == "legacy" else [])
+    hooks = [getattr(model, k).register_forward_hook(lambda _m, _i, o, k=k: caps.__setitem__(k, o)) for k in names]
     hooks.append(model.compress_v2.register_forward_pre_hook(lambda _m, i: caps.__setitem__("v2_feature", i[0])))
     v, q, _ = seeded.seeded_inputs(4, answers=2000, seed=1)
     with torch.no_grad():
         model({"v": torch.from_numpy(v).to(dev()), "q_idxes": torch.from_numpy(q).to(dev())})
-    for k in ["fusion_vq1", "fusion_vq2", "compress_v", "compress_v2", "fusion_final", "v2_feature"]:
+    for k in names + ["v2_feature"]:
         assert rel(caps[k], gold[k]) <= RTOL, k
     for h in hooks:
         h.remove()
@@ -143,8 +148,11 @@ def test_batch_of_one_and_odd_batches(cls, nans):
 # ---- the heads at the BASELINE batch (512 x 36 x 2048) against the float64 restatement -------------------------------------
 EPS_EDGE = 3e-5        # a relu pre-activation closer to zero than this (float64 run) makes its sample a "knife-edge" sample
 KEEP_MIN = {"cor2": 0.4, "oda": 0.7}   # share of the 512 samples that must be free of them (measured: ~0.45 / ~0.78)
-RTOL_EDGE_MAX = 3e-2   # knife-edge samples: max-abs error of a gradient tensor, on the tensor's own scale ...
-RTOL_EDGE_FRO = 1e-2   # ... and its relative Frobenius error (a handful of flipped units does not move the norm)
+RTOL_EDGE_FRO = 1e-2   # knife-edge samples: relative Frobenius error of a gradient tensor (a handful of flipped relu units does
+#                        not move the norm: this is the bar that would catch a systematic error) ...
+RTOL_EDGE_MAX = 1e-1   # ... and its max-abs error on the tensor's own scale: a sanity bound only -- ONE flipped unit moves one
+#                        row of a glimpse layer's gradient by that sample's whole contribution (measured: 1.8e-2 of the scale
+#                        for a single sample, 3.9e-2 over ODA's 149 knife-edge samples of this batch)
 VARIANTS = [("cor2", 2000, "default"), ("cor2", 2000, "pairwise"), ("cor2", 2000, "k4_engine"), ("cor2", 2000, "legacy_head"),
             ("oda", 3000, "default"), ("oda", 3000, "legacy_head")]
 _oracle_cache = {}

@@ -22,7 +22,7 @@
 namespace vqa {
 
 constexpr int kGMaxProbs = VQA_GROUPED_MAX;
-constexpr int kGBM = 64, kGBN = 64, kGBK = 16, kGPF = 2;
+constexpr int kGBN = 64, kGBK = 16, kGPF = 2;   // tile rows BM: 64 (default) or 128, one value per launch
 
 struct GProbs {
   VqaGemmProblem p[kGMaxProbs];
@@ -73,37 +73,46 @@ struct SrcMC1 {  // X[k][mn], MN-contiguous rows of stride ld; any alignment, an
   }
 };
 
-template <bool A_KC, bool B_KC, class SrcA, class SrcB>
+template <int BM, bool A_KC, bool B_KC, class SrcA, class SrcB>
 __device__ __forceinline__ void grouped_tile(const VqaGemmProblem& pr, const SrcA& sa, const SrcB& sb, int m0, int n0,
                                              int split, float* smem) {
-  f32x16 acc[1][1];
+  constexpr int TM = BM / 64;
+  f32x16 acc[TM][1];
   zero_acc(acc);
   const int k_begin = split * pr.ksplit, k_end = min(pr.K, k_begin + pr.ksplit);
-  float colsum[1] = {0.f};
+  float colsum[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) colsum[i] = 0.f;
   const bool want_colsum = pr.colsum != nullptr && n0 == 0;   // (wave-uniform; form TN only)
-  gemm_tile<kGBM, kGBN, kGBK, kGPF, A_KC, B_KC>(sa, sb, m0, n0, k_begin, k_end, smem, acc, want_colsum ? colsum : nullptr);
-  const AccCoord<kGBM, kGBN> cc(m0, n0);
+  gemm_tile<BM, kGBN, kGBK, kGPF, A_KC, B_KC>(sa, sb, m0, n0, k_begin, k_end, smem, acc, want_colsum ? colsum : nullptr);
+  const AccCoord<BM, kGBN> cc(m0, n0);
   float* __restrict__ dst = pr.slab + (size_t)(pr.slab_base + split) * pr.slab_stride;
   const int col = cc.col(0);
   if (col < pr.N) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = cc.row(0, i);
-      if (row < pr.M) dst[(size_t)row * pr.N + col] = acc[0][0][i];
-    }
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = cc.row(tm, i);
+        if (row < pr.M) dst[(size_t)row * pr.N + col] = acc[tm][0][i];
+      }
   }
   if (want_colsum) {
-    // lane l holds the sum over the staged k's with (k & 1) == l >> 5 of A[k][m0 + wave_row0 + (l & 31)]: add the halves
-    const unsigned u = __float_as_uint(colsum[0]);
-    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    const float total = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    // lane l holds the sum over the staged k's with (k & 1) == l >> 5 of A[k][m0 + wave_row0 + i*32 + (l & 31)]: add the halves
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m = m0 + (wave >> 1) * 32 + (lane & 31);
-    if ((wave & 1) == 0 && lane < 32 && m < pr.M) pr.colsum[(size_t)(pr.slab_base + split) * pr.M + m] = total;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const unsigned u = __float_as_uint(colsum[i]);
+      const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+      const float total = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+      const int m = m0 + (wave >> 1) * (TM * 32) + i * 32 + (lane & 31);
+      if ((wave & 1) == 0 && lane < 32 && m < pr.M) pr.colsum[(size_t)(pr.slab_base + split) * pr.M + m] = total;
+    }
   }
 }
 
-__global__ __launch_bounds__(kGemmThreads, 4) void grouped_gemm_kernel(GProbs g, int items) {
+template <int BM>
+__global__ __launch_bounds__(kGemmThreads, BM == 64 ? 4 : 2) void grouped_gemm_kernel(GProbs g, int items) {
   extern __shared__ __attribute__((aligned(16))) float smem_g[];
   const int bid = xcd_remap(blockIdx.x, items);
   int p = 0;
@@ -111,39 +120,160 @@ __global__ __launch_bounds__(kGemmThreads, 4) void grouped_gemm_kernel(GProbs g,
   p = __builtin_amdgcn_readfirstlane(p);
   const VqaGemmProblem& pr = g.p[p];
   const int local = bid - g.first[p];
-  const int tiles_n = (pr.N + kGBN - 1) / kGBN, tiles_m = (pr.M + kGBM - 1) / kGBM;
+  const int tiles_n = (pr.N + kGBN - 1) / kGBN, tiles_m = (pr.M + BM - 1) / BM;
   const int split = local / (tiles_m * tiles_n), t = local % (tiles_m * tiles_n);
-  const int m0 = (t / tiles_n) * kGBM, n0 = (t % tiles_n) * kGBN;
+  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * kGBN;
   if (pr.form == 0) {          // NT: A [M,K] rows K-contiguous, B [N,K] rows K-contiguous
-    grouped_tile<true, true>(pr, SrcKC{pr.A, pr.lda, pr.M, pr.Ka}, SrcKC{pr.B, pr.ldb, pr.N, pr.Kb}, m0, n0, split, smem_g);
+    grouped_tile<BM, true, true>(pr, SrcKC{pr.A, pr.lda, pr.M, pr.Ka}, SrcKC{pr.B, pr.ldb, pr.N, pr.Kb}, m0, n0, split, smem_g);
   } else if (pr.form == 1) {   // NN: A [M,K] rows K-contiguous, B [K,N] rows N-contiguous
-    grouped_tile<true, false>(pr, SrcKC{pr.A, pr.lda, pr.M, pr.Ka}, SrcMC{pr.B, pr.ldb, pr.Nb, pr.Kb}, m0, n0, split, smem_g);
+    grouped_tile<BM, true, false>(pr, SrcKC{pr.A, pr.lda, pr.M, pr.Ka}, SrcMC{pr.B, pr.ldb, pr.Nb, pr.Kb}, m0, n0, split, smem_g);
   } else if (pr.form == 2) {   // TN: A [K,M] rows M-contiguous, B [K,N] rows N-contiguous
-    grouped_tile<false, false>(pr, SrcMC{pr.A, pr.lda, pr.Ma, pr.Ka}, SrcMC{pr.B, pr.ldb, pr.Nb, pr.Kb}, m0, n0, split, smem_g);
+    grouped_tile<BM, false, false>(pr, SrcMC{pr.A, pr.lda, pr.Ma, pr.Ka}, SrcMC{pr.B, pr.ldb, pr.Nb, pr.Kb}, m0, n0, split, smem_g);
   } else if (pr.form == 3) {   // NN with a 4-byte aligned A
-    grouped_tile<true, false>(pr, SrcKC1{pr.A, pr.lda, pr.M, pr.Ka}, SrcMC{pr.B, pr.ldb, pr.Nb, pr.Kb}, m0, n0, split, smem_g);
+    grouped_tile<BM, true, false>(pr, SrcKC1{pr.A, pr.lda, pr.M, pr.Ka}, SrcMC{pr.B, pr.ldb, pr.Nb, pr.Kb}, m0, n0, split, smem_g);
   } else {                     // TN with a 4-byte aligned A
-    grouped_tile<false, false>(pr, SrcMC1{pr.A, pr.lda, pr.Ma, pr.Ka}, SrcMC{pr.B, pr.ldb, pr.Nb, pr.Kb}, m0, n0, split, smem_g);
+    grouped_tile<BM, false, false>(pr, SrcMC1{pr.A, pr.lda, pr.Ma, pr.Ka}, SrcMC{pr.B, pr.ldb, pr.Nb, pr.Kb}, m0, n0, split, smem_g);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ epilogue
+// A thread owns V consecutive elements of a row (V = 2 when the job's widths and pointers allow 8-byte accesses, which is
+// every job of the models except the 155-wide glimpse blocks; else 1).
 struct EJobs {
   VqaEpilogueJob j[kGMaxProbs];
   int first[kGMaxProbs + 1];  // first thread of each job
+  float inv_w[kGMaxProbs];    // 1 / (threads per row)
+  unsigned char vec[kGMaxProbs];
   int n;
 };
 
-__device__ __forceinline__ float slab_sum(const VqaEpilogueJob& j, size_t e) {
-  float a = j.slab[e];
-  for (int s = 1; s < j.S; ++s) a += j.slab[(size_t)s * j.slab_stride + e];
+template <int V>
+struct Vals {
+  float v[V];
+};
+template <int V>
+__device__ __forceinline__ Vals<V> ldv(const float* p) {
+  Vals<V> r;
+  if constexpr (V == 2) {
+    const float2 t = ld2(p);
+    r.v[0] = t.x;
+    r.v[1] = t.y;
+  } else {
+    r.v[0] = p[0];
+  }
+  return r;
+}
+template <int V>
+__device__ __forceinline__ void stv(float* p, const Vals<V>& x) {
+  if constexpr (V == 2) {
+    st2(p, make_float2(x.v[0], x.v[1]));
+  } else {
+    p[0] = x.v[0];
+  }
+}
+template <int V>
+__device__ __forceinline__ Vals<V> slab_sum(const VqaEpilogueJob& j, size_t e) {
+  Vals<V> a = ldv<V>(j.slab + e);
+  for (int s = 1; s < j.S; ++s) {
+    const Vals<V> t = ldv<V>(j.slab + (size_t)s * j.slab_stride + e);
+#pragma unroll
+    for (int i = 0; i < V; ++i) a.v[i] += t.v[i];
+  }
   return a;
 }
+// keep / (1 - p) factors of mask elements e .. e + V - 1 (e even when V == 2); all ones without dropout
+template <int V>
+__device__ __forceinline__ Vals<V> job_keep(const VqaEpilogueJob& j, uint32_t e) {
+  Vals<V> k;
+#pragma unroll
+  for (int i = 0; i < V; ++i) k.v[i] = 1.f;
+  if (j.p_drop > 0.f) {
+    const DropCfg dc = make_drop_dev(j.p_drop, j.seed, j.seed_ptr);
+    if constexpr (V == 2) {
+      const float2 t = drop_pair(e, dc);
+      k.v[0] = t.x;
+      k.v[1] = t.y;
+    } else {
+      k.v[0] = drop_one(e, dc);
+    }
+  }
+  return k;
+}
 
-// keep / (1 - p) factor of element `e` of the mask the job names (0: no dropout)
-__device__ __forceinline__ float job_keep(const VqaEpilogueJob& j, uint32_t e) {
-  if (j.p_drop <= 0.f) return 1.f;
-  return drop_one(e, make_drop_dev(j.p_drop, j.seed, j.seed_ptr));
+template <int V>
+__device__ __forceinline__ void epilogue_item(const VqaEpilogueJob& j, int m, int c) {   // row m, first column c
+  switch (j.kind) {
+    case VQA_EPI_LINEAR: {   // out[m, n] = drop(act(sum + bias[n]))
+      Vals<V> z = slab_sum<V>(j, (size_t)m * j.N + c);
+      const Vals<V> k = job_keep<V>(j, j.drop_base + (uint32_t)m * j.drop_ld + (uint32_t)c);
+#pragma unroll
+      for (int i = 0; i < V; ++i) z.v[i] = act_fwd_g(z.v[i] + (j.bias != nullptr ? j.bias[c + i] : 0.f), j.act) * k.v[i];
+      stv<V>(j.out + (size_t)m * j.ldo + c, z);
+      break;
+    }
+    case VQA_EPI_RANK_PRODUCT: {   // N = R * H; (m, h = c): h1 = sum + bias stored; out2[m,h] = drop(sum_r h1 * aux)
+      const int H = j.N / j.R;
+      Vals<V> x;
+#pragma unroll
+      for (int i = 0; i < V; ++i) x.v[i] = 0.f;
+      for (int r = 0; r < j.R; ++r) {
+        const size_t o = (size_t)m * j.N + (size_t)r * H + c;
+        Vals<V> h1 = slab_sum<V>(j, o);
+        const Vals<V> a = ldv<V>(j.aux + (size_t)m * j.ld_aux + (size_t)r * H + c);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          h1.v[i] += j.bias != nullptr ? j.bias[r * H + c + i] : 0.f;
+          x.v[i] = fmaf(h1.v[i], a.v[i], x.v[i]);
+        }
+        stv<V>(j.out + o, h1);
+      }
+      const Vals<V> k = job_keep<V>(j, j.drop_base + (uint32_t)m * j.drop_ld + (uint32_t)c);
+#pragma unroll
+      for (int i = 0; i < V; ++i) x.v[i] *= k.v[i];
+      stv<V>(j.out2 + (size_t)m * j.ldo + c, x);
+      break;
+    }
+    case VQA_EPI_GRAD: {   // out[m, n] = sum * gate(y[m, n]) * keep   (a data gradient, gated for the layer in front)
+      Vals<V> z = slab_sum<V>(j, (size_t)m * j.N + c);
+      if (j.gate != 0) {
+        const Vals<V> y = ldv<V>(j.aux + (size_t)m * j.ld_aux + c);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          // 1: relu, y possibly stored dropped (y > 0 <=> kept and active; gate_scale = 1 or 1/(1-p));  2: sigmoid
+          if (j.gate == 1) z.v[i] = y.v[i] > 0.f ? z.v[i] * j.gate_scale : 0.f;
+          else z.v[i] *= y.v[i] * (1.f - y.v[i]);
+        }
+      }
+      const Vals<V> k = job_keep<V>(j, j.drop_base + (uint32_t)m * j.drop_ld + (uint32_t)c);
+#pragma unroll
+      for (int i = 0; i < V; ++i) z.v[i] *= k.v[i];
+      stv<V>(j.out + (size_t)m * j.ldo + c, z);
+      break;
+    }
+    case VQA_EPI_RANK_PRODUCT_BWD: {   // N = H; (m, h = c): g = drop(sum); out[m, r*H+h] = g * aux[..]; out2[..] = g * aux2[..]
+      Vals<V> gx = slab_sum<V>(j, (size_t)m * j.N + c);
+      const Vals<V> k = job_keep<V>(j, j.drop_base + (uint32_t)m * j.drop_ld + (uint32_t)c);
+#pragma unroll
+      for (int i = 0; i < V; ++i) gx.v[i] *= k.v[i];
+      for (int r = 0; r < j.R; ++r) {
+        const size_t o = (size_t)m * j.R * j.N + (size_t)r * j.N + c, oa = (size_t)m * j.ld_aux + (size_t)r * j.N + c;
+        const Vals<V> a = ldv<V>(j.aux + oa), a2 = ldv<V>(j.aux2 + oa);
+        Vals<V> o1, o2;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          o1.v[i] = gx.v[i] * a.v[i];
+          o2.v[i] = gx.v[i] * a2.v[i];
+        }
+        stv<V>(j.out + o, o1);
+        stv<V>(j.out2 + o, o2);
+      }
+      break;
+    }
+    default: {   // VQA_EPI_SUM: out[m, n] = sum   (weight gradients into their slots; bias gradients with M = 1)
+      stv<V>(j.out + (size_t)m * j.ldo + c, slab_sum<V>(j, (size_t)m * j.N + c));
+      break;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void grouped_epilogue_kernel(EJobs g, int threads) {
@@ -153,57 +283,21 @@ __global__ __launch_bounds__(256) void grouped_epilogue_kernel(EJobs g, int thre
   while (q + 1 < g.n && g.first[q + 1] <= tid) ++q;
   const VqaEpilogueJob& j = g.j[q];
   const int e = tid - g.first[q];
-  switch (j.kind) {
-    case VQA_EPI_LINEAR: {   // out[m, n] = drop(act(sum + bias[n]))
-      const int m = e / j.N, n = e - m * j.N;
-      float z = slab_sum(j, (size_t)e) + (j.bias != nullptr ? j.bias[n] : 0.f);
-      z = act_fwd_g(z, j.act);
-      z *= job_keep(j, j.drop_base + (uint32_t)m * j.drop_ld + (uint32_t)n);
-      j.out[(size_t)m * j.ldo + n] = z;
-      break;
-    }
-    case VQA_EPI_RANK_PRODUCT: {   // N = R * H; thread = (m, h): h1 = sum + bias stored; out2[m,h] = drop(sum_r h1 * aux)
-      const int H = j.N / j.R, m = e / H, h = e - m * H;
-      float x = 0.f;
-      for (int r = 0; r < j.R; ++r) {
-        const size_t o = (size_t)m * j.N + (size_t)r * H + h;
-        const float h1 = slab_sum(j, o) + (j.bias != nullptr ? j.bias[r * H + h] : 0.f);
-        j.out[o] = h1;
-        x = fmaf(h1, j.aux[(size_t)m * j.ld_aux + (size_t)r * H + h], x);
-      }
-      j.out2[(size_t)m * j.ldo + h] = x * job_keep(j, j.drop_base + (uint32_t)m * j.drop_ld + (uint32_t)h);
-      break;
-    }
-    case VQA_EPI_GRAD: {   // out[m, seg(n)] = sum * gate(y[m, n])   (the data gradient of a layer, gated for the layer in front)
-      const int m = e / j.N, n = e - m * j.N;
-      float z = slab_sum(j, (size_t)e);
-      if (j.gate == 1) {          // relu, y possibly stored dropped: y > 0 <=> kept and active; gate_scale = 1 or 1/(1-p)
-        z = j.aux[(size_t)m * j.ld_aux + n] > 0.f ? z * j.gate_scale : 0.f;
-      } else if (j.gate == 2) {   // sigmoid
-        const float y = j.aux[(size_t)m * j.ld_aux + n];
-        z *= y * (1.f - y);
-      }
-      z *= job_keep(j, j.drop_base + (uint32_t)m * j.drop_ld + (uint32_t)n);
-      const int nn = j.seg > 0 ? (n / j.seg) * j.seg_ld + (n % j.seg) : n;
-      j.out[(size_t)m * j.ldo + nn] = z;
-      break;
-    }
-    case VQA_EPI_RANK_PRODUCT_BWD: {   // N = H; thread = (m, h): g = drop(sum); out[m, r*H+h] = g * aux[m, r*H+h]; out2[..] = g * aux2[..]
-      const int m = e / j.N, h = e - m * j.N;
-      const float gx = slab_sum(j, (size_t)e) * job_keep(j, j.drop_base + (uint32_t)m * j.drop_ld + (uint32_t)h);
-      for (int r = 0; r < j.R; ++r) {
-        const size_t o = (size_t)m * j.R * j.N + (size_t)r * j.N + h;
-        j.out[o] = gx * j.aux[(size_t)m * j.ld_aux + (size_t)r * j.N + h];
-        j.out2[o] = gx * j.aux2[(size_t)m * j.ld_aux + (size_t)r * j.N + h];
-      }
-      break;
-    }
-    default: {   // VQA_EPI_SUM: out[m, n] = sum   (weight gradients into their slots; bias gradients with M = 1)
-      const int m = e / j.N, n = e - m * j.N;
-      j.out[(size_t)m * j.ldo + n] = slab_sum(j, (size_t)e);
-      break;
-    }
+  const int V = g.vec[q];
+  int width = j.N;                                     // columns a row's threads cover
+  if (j.kind == VQA_EPI_RANK_PRODUCT) width = j.N / j.R;
+  const int tpr = width / V;                           // threads per row
+  int m = (int)(((float)e + 0.5f) * g.inv_w[q]);       // e / tpr, corrected below (no integer division in the kernel)
+  int t = e - m * tpr;
+  if (t < 0) {
+    --m;
+    t += tpr;
+  } else if (t >= tpr) {
+    ++m;
+    t -= tpr;
   }
+  if (V == 2) epilogue_item<2>(j, m, 2 * t);
+  else epilogue_item<1>(j, m, t);
 }
 
 }  // namespace vqa
@@ -217,6 +311,8 @@ extern "C" int vqa_grouped_gemm(const VqaGemmProblem* problems, int n, vqa_strea
   GProbs g{};
   g.n = n;
   int items = 0;
+  const char* tile = vqa::option("VQA_GROUPED_BM");     // tile rows: 64 (default) or 128
+  const int bm = (tile != nullptr && std::atoi(tile) == 128) ? 128 : 64;
   for (int i = 0; i < n; ++i) {
     VqaGemmProblem p = problems[i];
     VQA_REQUIRE(p.A && p.B && p.slab, VQA_E_BADARG, "grouped_gemm[%d]: null pointer", i);
@@ -242,13 +338,18 @@ extern "C" int vqa_grouped_gemm(const VqaGemmProblem* problems, int n, vqa_strea
                 "grouped_gemm[%d]: column sums exist for the TN forms only", i);
     g.p[i] = p;
     g.first[i] = items;
-    const long tiles = (long)((p.M + kGBM - 1) / kGBM) * ((p.N + kGBN - 1) / kGBN) * split_of(p);
+    const long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + kGBN - 1) / kGBN) * split_of(p);
     VQA_REQUIRE(items + tiles < (1L << 24), VQA_E_UNSUPPORTED, "grouped_gemm: too many tiles");
     items += (int)tiles;
   }
   g.first[n] = items;
-  const size_t lds = GemmTile<kGBM, kGBN, kGBK, true, true>::kSmemBytes;   // the largest of the three forms
-  hipLaunchKernelGGL(grouped_gemm_kernel, dim3(items), dim3(kGemmThreads), lds, static_cast<hipStream_t>(stream), g, items);
+  if (bm == 128) {
+    const size_t lds = GemmTile<128, kGBN, kGBK, true, true>::kSmemBytes;   // the largest of the three forms
+    hipLaunchKernelGGL(grouped_gemm_kernel<128>, dim3(items), dim3(kGemmThreads), lds, static_cast<hipStream_t>(stream), g, items);
+  } else {
+    const size_t lds = GemmTile<64, kGBN, kGBK, true, true>::kSmemBytes;
+    hipLaunchKernelGGL(grouped_gemm_kernel<64>, dim3(items), dim3(kGemmThreads), lds, static_cast<hipStream_t>(stream), g, items);
+  }
   return check_launch("grouped_gemm");
 }
 
@@ -262,17 +363,26 @@ extern "C" int vqa_grouped_epilogue(const VqaEpilogueJob* jobs, int n, vqa_strea
     VQA_REQUIRE(j.slab && j.out && j.S >= 1 && j.M > 0 && j.N > 0, VQA_E_BADARG, "grouped_epilogue[%d]: bad job", i);
     VQA_REQUIRE(j.kind >= VQA_EPI_SUM && j.kind <= VQA_EPI_RANK_PRODUCT_BWD, VQA_E_BADARG, "grouped_epilogue[%d]: kind %d", i, j.kind);
     VQA_REQUIRE(j.p_drop >= 0.f && j.p_drop < 1.f, VQA_E_BADARG, "grouped_epilogue[%d]: p_drop=%f", i, (double)j.p_drop);
-    long count = (long)j.M * j.N;
+    int width = j.N;
     if (j.kind == VQA_EPI_RANK_PRODUCT) {
       VQA_REQUIRE(j.R >= 1 && j.N % j.R == 0 && j.aux && j.out2, VQA_E_BADARG, "grouped_epilogue[%d]: rank product needs R | N, aux, out2", i);
-      count /= j.R;
+      width = j.N / j.R;
     }
     if (j.kind == VQA_EPI_RANK_PRODUCT_BWD)
       VQA_REQUIRE(j.R >= 1 && j.aux && j.aux2 && j.out2, VQA_E_BADARG, "grouped_epilogue[%d]: rank product backward needs aux, aux2, out2", i);
     if (j.kind == VQA_EPI_GRAD && j.gate != 0) VQA_REQUIRE(j.aux != nullptr, VQA_E_BADARG, "grouped_epilogue[%d]: gate needs aux", i);
+    // 8-byte accesses when every width, stride and pointer the job touches is even / 8-byte aligned
+    const bool v2 = width % 2 == 0 && j.N % 2 == 0 && j.ldo % 2 == 0 && j.ld_aux % 2 == 0 && j.slab_stride % 2 == 0 &&
+                    j.drop_ld % 2 == 0 && j.drop_base % 2 == 0 && aligned(j.slab, 8) && aligned(j.out, 8) &&
+                    (j.out2 == nullptr || aligned(j.out2, 8)) && (j.aux == nullptr || aligned(j.aux, 8)) &&
+                    (j.aux2 == nullptr || aligned(j.aux2, 8)) && (j.kind != VQA_EPI_RANK_PRODUCT_BWD || (j.R * j.N) % 2 == 0);
+    const int V = v2 ? 2 : 1;
     g.j[i] = j;
+    g.vec[i] = (unsigned char)V;
+    g.inv_w[i] = 1.0f / (float)(width / V);
     g.first[i] = (int)threads;
-    threads += count;
+    threads += (long)j.M * (width / V);
+    VQA_REQUIRE((long)j.M * (width / V) < (1L << 24), VQA_E_UNSUPPORTED, "grouped_epilogue[%d]: job too large", i);
     VQA_REQUIRE(threads < (1L << 30), VQA_E_UNSUPPORTED, "grouped_epilogue: too many elements");
   }
   g.first[n] = (int)threads;

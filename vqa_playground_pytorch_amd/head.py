@@ -71,7 +71,10 @@ class Phase:
     """Collects the GEMM problems and epilogue jobs of one phase, sizes the contraction splits so that the phase's tiles
     fill the chip, allocates the slabs and launches the two kernels."""
 
-    TARGET_ITEMS = 768      # ~3 workgroups of 64x64 tiles per CU (256 CUs, 4 resident per CU)
+    # work items (tile x contraction split) a phase is cut into: ~3 workgroups of 64x64 tiles per CU (256 CUs, 4 resident
+    # per CU).  VQA_GROUPED_ITEMS / VQA_GROUPED_BM (tile rows 64 | 128, read by the library) are measurement knobs.
+    TARGET_ITEMS = int(os.environ.get("VQA_GROUPED_ITEMS", "768"))
+    TILE_M = 128 if os.environ.get("VQA_GROUPED_BM") == "128" else 64
 
     def __init__(self, device, name):
         self.device, self.name = device, name
@@ -93,7 +96,7 @@ class Phase:
 
     def _size(self):
         probs = [(t, p) for t in self.targets for p in t.problems]
-        tiles = lambda t: math.ceil(t.M / 64) * math.ceil(t.N / 64)  # noqa: E731
+        tiles = lambda t: math.ceil(t.M / self.TILE_M) * math.ceil(t.N / 64)  # noqa: E731
         kmax = max(p["K"] for _, p in probs)
         best = None
         for chunk in sorted({max(128, math.ceil(kmax / d / 16) * 16) for d in (1, 2, 3, 4, 6, 8, 12, 16)}, reverse=True):
