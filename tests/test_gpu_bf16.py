@@ -431,13 +431,21 @@ def test_cor2_bf16_at_size_against_bf16_aware_oracle(B, N):
     k = min(B, 32)
     close_f32("alpha2", torch.cat(model.alpha_dict["alpha2"], 2)[:k], alpha2[:k], RTOL_AWARE)
     worst = (0.0, 0.0, "")
+    params = dict(model.named_parameters())
+    zero_grads = {"%s.list_linear1.%d.linear.bias" % (f, r) for f in ("fusion_vq1", "fusion_vq2") for r in range(2)} | \
+        {"att1.conv_att.conv.bias", "att2.conv_att.conv.bias"}
     for (n, p), (_, po) in zip(model.named_parameters(), aware.named_parameters()):
         ref = po.grad.numpy().astype(np.float64)
         g = npy(p.grad)
         assert np.isfinite(g).all(), n
         scale = np.abs(ref).max()
-        if scale < 1e-7 * np.sqrt(B * N):          # mathematically-zero gradients (biases in front of the softmax)
-            assert np.abs(g).max() < 1e-5 * np.sqrt(B * N), n
+        if n in zero_grads:
+            # Mathematically zero: a bias in front of the softmax over regions shifts every region's logit alike.  In fp32
+            # both sides hold ~1e-9; with bf16-rounded gradients of the fusion output the cancellation is only as exact as
+            # the roundings, so each side holds its own rounding noise -- small against the gradient of the weight next to
+            # it, and not comparable element by element.
+            w_scale = np.abs(npy(params[n.replace(".bias", ".weight")].grad)).max()
+            assert np.abs(g).max() <= 5e-2 * w_scale and scale <= 5e-2 * w_scale, (n, np.abs(g).max(), scale, w_scale)
             continue
         e_max = np.abs(g - ref).max() / scale
         e_fro = np.sqrt(((g - ref) ** 2).sum()) / np.sqrt((ref ** 2).sum())

@@ -453,8 +453,17 @@ __global__ __launch_bounds__(256) void pack_many_kernel(const PackJob* __restric
   while (j + 1 < jobs && (size_t)table[j + 1].first <= e) ++j;
   const PackJob job = table[j];
   const size_t local = e - (size_t)job.first;
-  const long long r = (long long)(local / (size_t)job.cols), c = (long long)(local % (size_t)job.cols);
-  const float v = job.src[local];
+  long long r, c;
+  if (job.row_stride == 1 && job.col_stride != 1) {
+    // a transposed shadow (dst[c][r]): number the job's elements along the DESTINATION rows, so that a wave writes
+    // contiguous bf16 (whole lines) and the strided side is the fp32 read, which the L2 serves from lines it keeps
+    c = (long long)(local / (size_t)job.rows);
+    r = (long long)(local % (size_t)job.rows);
+  } else {
+    r = (long long)(local / (size_t)job.cols);
+    c = (long long)(local % (size_t)job.cols);
+  }
+  const float v = job.src[(size_t)r * (size_t)job.cols + (size_t)c];
   const size_t o = (size_t)(r * job.row_stride + c * job.col_stride);
   if (job.kind == 0) {
     static_cast<bf16*>(job.dst)[o] = (bf16)v;

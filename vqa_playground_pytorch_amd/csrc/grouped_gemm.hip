@@ -22,11 +22,12 @@
 namespace vqa {
 
 constexpr int kGMaxProbs = VQA_GROUPED_MAX;
+constexpr int kGMaxGemms = VQA_GROUPED_GEMM_MAX;
 constexpr int kGBN = 64, kGBK = 16, kGPF = 2;   // tile rows BM: 64 (default) or 128, one value per launch
 
 struct GProbs {
-  VqaGemmProblem p[kGMaxProbs];
-  int first[kGMaxProbs + 1];  // first work item of each problem
+  VqaGemmProblem p[kGMaxGemms];
+  int first[kGMaxGemms + 1];  // first work item of each problem
   int n;
 };
 
@@ -83,30 +84,56 @@ __device__ __forceinline__ void grouped_tile(const VqaGemmProblem& pr, const Src
   float colsum[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) colsum[i] = 0.f;
-  const bool want_colsum = pr.colsum != nullptr && n0 == 0;   // (wave-uniform; form TN only)
+  const bool want_colsum = (pr.colsum != nullptr || pr.colsum_out != nullptr) && n0 == 0;   // (wave-uniform; TN forms only)
   gemm_tile<BM, kGBN, kGBK, kGPF, A_KC, B_KC>(sa, sb, m0, n0, k_begin, k_end, smem, acc, want_colsum ? colsum : nullptr);
   const AccCoord<BM, kGBN> cc(m0, n0);
-  float* __restrict__ dst = pr.slab + (size_t)(pr.slab_base + split) * pr.slab_stride;
   const int col = cc.col(0);
-  if (col < pr.N) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (pr.out != nullptr) {
+    // direct output: the layer's epilogue on the accumulators (bias, activation, gate of the layer in front, dropout)
+    if (col < pr.N) {
+      const float bv = pr.bias != nullptr ? pr.bias[col] : 0.f;
+      const bool drop = pr.p_drop > 0.f;
+      DropCfg dc{};
+      if (drop) dc = make_drop_dev(pr.p_drop, pr.seed, pr.seed_ptr);
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+      for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = cc.row(tm, i);
-        if (row < pr.M) dst[(size_t)row * pr.N + col] = acc[tm][0][i];
-      }
+        for (int i = 0; i < 16; ++i) {
+          const int row = cc.row(tm, i);
+          if (row < pr.M) {
+            float z = act_fwd_g(acc[tm][0][i] + bv, pr.act);
+            if (pr.gate != 0) {
+              const float y = pr.gate_y[(size_t)row * pr.ld_gate + col];
+              z = pr.gate == 1 ? (y > 0.f ? z * pr.gate_scale : 0.f) : z * y * (1.f - y);
+            }
+            if (drop) z *= drop_one(pr.drop_base + (uint32_t)row * pr.drop_ld + (uint32_t)col, dc);
+            pr.out[(size_t)row * pr.ldo + col] = z;
+          }
+        }
+    }
+  } else {
+    float* __restrict__ dst = pr.slab + (size_t)(pr.slab_base + split) * pr.slab_stride;
+    if (col < pr.N) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = cc.row(tm, i);
+          if (row < pr.M) dst[(size_t)row * pr.N + col] = acc[tm][0][i];
+        }
+    }
   }
   if (want_colsum) {
     // lane l holds the sum over the staged k's with (k & 1) == l >> 5 of A[k][m0 + wave_row0 + i*32 + (l & 31)]: add the halves
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* cs = pr.colsum_out != nullptr ? pr.colsum_out : pr.colsum + (size_t)(pr.slab_base + split) * pr.M;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const unsigned u = __float_as_uint(colsum[i]);
       const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
       const float total = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
       const int m = m0 + (wave >> 1) * (TM * 32) + i * 32 + (lane & 31);
-      if ((wave & 1) == 0 && lane < 32 && m < pr.M) pr.colsum[(size_t)(pr.slab_base + split) * pr.M + m] = total;
+      if ((wave & 1) == 0 && lane < 32 && m < pr.M) cs[m] = total;
     }
   }
 }
@@ -307,7 +334,7 @@ using namespace vqa;
 static int split_of(const VqaGemmProblem& p) { return (p.K + p.ksplit - 1) / p.ksplit; }
 
 extern "C" int vqa_grouped_gemm(const VqaGemmProblem* problems, int n, vqa_stream_t stream) {
-  VQA_REQUIRE(problems != nullptr && n >= 1 && n <= kGMaxProbs, VQA_E_BADARG, "grouped_gemm: 1..%d problems (got %d)", kGMaxProbs, n);
+  VQA_REQUIRE(problems != nullptr && n >= 1 && n <= kGMaxGemms, VQA_E_BADARG, "grouped_gemm: 1..%d problems (got %d)", kGMaxGemms, n);
   GProbs g{};
   g.n = n;
   int items = 0;
@@ -315,11 +342,19 @@ extern "C" int vqa_grouped_gemm(const VqaGemmProblem* problems, int n, vqa_strea
   const int bm = (tile != nullptr && std::atoi(tile) == 128) ? 128 : 64;
   for (int i = 0; i < n; ++i) {
     VqaGemmProblem p = problems[i];
-    VQA_REQUIRE(p.A && p.B && p.slab, VQA_E_BADARG, "grouped_gemm[%d]: null pointer", i);
+    VQA_REQUIRE(p.A && p.B && (p.slab || p.out), VQA_E_BADARG, "grouped_gemm[%d]: null pointer", i);
     VQA_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0 && p.form >= 0 && p.form <= 4, VQA_E_BADARG,
                 "grouped_gemm[%d]: bad sizes M=%d N=%d K=%d form=%d", i, p.M, p.N, p.K, p.form);
-    VQA_REQUIRE(p.ksplit > 0 && p.ksplit % kGBK == 0 && p.slab_base >= 0 && p.slab_stride >= (long long)p.M * p.N, VQA_E_BADARG,
-                "grouped_gemm[%d]: ksplit %d must be a positive multiple of %d, slab_stride >= M*N", i, p.ksplit, kGBK);
+    VQA_REQUIRE(p.ksplit > 0 && p.ksplit % kGBK == 0 && p.slab_base >= 0 && (p.out != nullptr || p.slab_stride >= (long long)p.M * p.N),
+                VQA_E_BADARG, "grouped_gemm[%d]: ksplit %d must be a positive multiple of %d, slab_stride >= M*N", i, p.ksplit, kGBK);
+    if (p.out != nullptr) {
+      VQA_REQUIRE(p.ksplit >= p.K, VQA_E_BADARG, "grouped_gemm[%d]: a direct output needs the contraction in one part", i);
+      VQA_REQUIRE(p.ldo >= p.N && p.act >= 0 && p.act <= 2 && p.gate >= 0 && p.gate <= 2 && (p.gate == 0 || p.gate_y != nullptr) &&
+                      p.p_drop >= 0.f && p.p_drop < 1.f,
+                  VQA_E_BADARG, "grouped_gemm[%d]: bad direct-output epilogue", i);
+    } else {
+      VQA_REQUIRE(p.colsum_out == nullptr, VQA_E_BADARG, "grouped_gemm[%d]: colsum_out needs a direct output", i);
+    }
     // source extents default to the problem's own; a caller overrides them when an operand is zero-padded past the
     // contraction / output extent (Ka, Kb: valid contraction length of A / B; Ma, Nb: valid width of an MN-contiguous A / B)
     if (p.Ka <= 0) p.Ka = p.K;
@@ -334,7 +369,7 @@ extern "C" int vqa_grouped_gemm(const VqaGemmProblem* problems, int n, vqa_strea
                 VQA_E_UNSUPPORTED,
                 "grouped_gemm[%d]: operands need even leading dimensions / contiguous extents and 8-byte aligned bases "
                 "(form %d lda=%d ldb=%d)", i, p.form, p.lda, p.ldb);
-    VQA_REQUIRE(p.colsum == nullptr || p.form == 2 || p.form == 4, VQA_E_BADARG,
+    VQA_REQUIRE((p.colsum == nullptr && p.colsum_out == nullptr) || p.form == 2 || p.form == 4, VQA_E_BADARG,
                 "grouped_gemm[%d]: column sums exist for the TN forms only", i);
     g.p[i] = p;
     g.first[i] = items;

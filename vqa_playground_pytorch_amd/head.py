@@ -25,14 +25,20 @@ import torch
 from . import _lib, ops
 
 _c = ctypes
-MAX_GROUP = 24
+MAX_GROUP = 24          # epilogue jobs per launch (VQA_GROUPED_MAX)
+MAX_GEMMS = 16          # GEMM problems per launch (VQA_GROUPED_GEMM_MAX)
 
 
 class GemmProblem(_c.Structure):          # VqaGemmProblem (include/vqa_mi355x.h)
     _fields_ = [("A", _c.c_void_p), ("B", _c.c_void_p), ("slab", _c.c_void_p), ("colsum", _c.c_void_p),
                 ("slab_stride", _c.c_longlong), ("lda", _c.c_int), ("ldb", _c.c_int), ("M", _c.c_int), ("N", _c.c_int),
                 ("K", _c.c_int), ("form", _c.c_int), ("ksplit", _c.c_int), ("slab_base", _c.c_int), ("Ka", _c.c_int),
-                ("Kb", _c.c_int), ("Ma", _c.c_int), ("Nb", _c.c_int)]
+                ("Kb", _c.c_int), ("Ma", _c.c_int), ("Nb", _c.c_int),
+                # direct output (the tile is finished in the GEMM kernel; no slab, no epilogue job)
+                ("out", _c.c_void_p), ("colsum_out", _c.c_void_p), ("bias", _c.c_void_p), ("gate_y", _c.c_void_p),
+                ("seed_ptr", _c.c_void_p), ("seed", _c.c_uint64), ("ldo", _c.c_int), ("ld_gate", _c.c_int), ("act", _c.c_int),
+                ("gate", _c.c_int), ("drop_base", _c.c_uint32), ("drop_ld", _c.c_uint32), ("p_drop", _c.c_float),
+                ("gate_scale", _c.c_float)]
 
 
 class EpilogueJob(_c.Structure):          # VqaEpilogueJob
@@ -65,16 +71,23 @@ class _Target:
         self.slab = None
         self.colsum = None
         self.S = 0
+        self.direct = None
 
 
 class Phase:
     """Collects the GEMM problems and epilogue jobs of one phase, sizes the contraction splits so that the phase's tiles
     fill the chip, allocates the slabs and launches the two kernels."""
 
-    # work items (tile x contraction split) a phase is cut into: ~3 workgroups of 64x64 tiles per CU (256 CUs, 4 resident
-    # per CU).  VQA_GROUPED_ITEMS / VQA_GROUPED_BM (tile rows 64 | 128, read by the library) are measurement knobs.
-    TARGET_ITEMS = int(os.environ.get("VQA_GROUPED_ITEMS", "768"))
+    # How a phase is cut into work items (64x64 tile x contraction part).  No item is longer than MAX_PART contraction
+    # steps (a phase mixes K = 155 .. 2400: the longest items would otherwise set the launch time), and when the phase has
+    # fewer than MIN_ITEMS items the parts are shortened until it has (256 CUs x 4 resident workgroups want >= ~2 per CU).
+    # A product that ends up in ONE part and is the only contribution to its result is finished inside the GEMM kernel
+    # (direct output: bias / activation / gate / dropout on the accumulators) and needs neither slab nor epilogue job.
+    # VQA_GROUPED_ITEMS / VQA_GROUPED_PART / VQA_GROUPED_BM (tile rows 64 | 128, read by the library): measurement knobs.
+    MIN_ITEMS = int(os.environ.get("VQA_GROUPED_ITEMS", "512"))
+    MAX_PART = int(os.environ.get("VQA_GROUPED_PART", "640"))
     TILE_M = 128 if os.environ.get("VQA_GROUPED_BM") == "128" else 64
+    DIRECT = os.environ.get("VQA_GROUPED_DIRECT", "1") == "1"
 
     def __init__(self, device, name):
         self.device, self.name = device, name
@@ -97,15 +110,14 @@ class Phase:
     def _size(self):
         probs = [(t, p) for t in self.targets for p in t.problems]
         tiles = lambda t: math.ceil(t.M / self.TILE_M) * math.ceil(t.N / 64)  # noqa: E731
-        kmax = max(p["K"] for _, p in probs)
-        best = None
-        for chunk in sorted({max(128, math.ceil(kmax / d / 16) * 16) for d in (1, 2, 3, 4, 6, 8, 12, 16)}, reverse=True):
-            items = sum(tiles(t) * math.ceil(p["K"] / chunk) for t, p in probs)
-            best = chunk
-            if items >= self.TARGET_ITEMS:
+        part = self.MAX_PART
+        while True:
+            items = sum(tiles(t) * math.ceil(p["K"] / part) for t, p in probs)
+            if items >= self.MIN_ITEMS or part <= 128:
                 break
+            part = max(128, part - 64)
         for t, p in probs:
-            splits = math.ceil(p["K"] / best)
+            splits = math.ceil(p["K"] / part)
             p["ksplit"] = math.ceil(p["K"] / splits / 16) * 16
             p["splits"] = math.ceil(p["K"] / p["ksplit"])
         return probs
@@ -114,34 +126,62 @@ class Phase:
         L_ = _lib.lib()
         if self.pre_jobs:
             self._epilogue(L_, self.pre_jobs, "pre")
+        jobs = list(self.jobs)
         if self.targets:
             probs = self._size()
             flops = 0
             for t in self.targets:
                 t.S = sum(p["splits"] for p in t.problems)
-                t.slab = torch.empty(t.S, t.M, t.N, device=self.device, dtype=torch.float32)
-                if any(p["colsum"] for p in t.problems):
-                    t.colsum = torch.empty(t.S, t.M, device=self.device, dtype=torch.float32)
+                mine = [j for j in jobs if j["source"] is t]
+                main = [j for j in mine if not j.get("colsum")]
+                t.direct = None
+                if (self.DIRECT and t.S == 1 and len(main) == 1 and main[0]["kind"] in (EPI_SUM, EPI_LINEAR, EPI_GRAD)
+                        and all(j["kind"] == EPI_SUM for j in mine if j.get("colsum")) and len(mine) <= 2):
+                    t.direct = (main[0], next((j for j in mine if j.get("colsum")), None))
+                    jobs = [j for j in jobs if j["source"] is not t]
+                else:
+                    t.slab = torch.empty(t.S, t.M, t.N, device=self.device, dtype=torch.float32)
+                    if any(p["colsum"] for p in t.problems):
+                        t.colsum = torch.empty(t.S, t.M, device=self.device, dtype=torch.float32)
                 base = 0
                 for p in t.problems:
                     p["slab_base"] = base
                     base += p["splits"]
                     flops += 2 * t.M * t.N * p["K"]
-            if len(probs) > MAX_GROUP:
-                raise _lib.VqaLibraryError("phase %s: %d GEMM problems exceed the group limit %d" % (self.name, len(probs), MAX_GROUP))
-            arr = (GemmProblem * len(probs))()
-            for i, (t, p) in enumerate(probs):
-                arr[i] = GemmProblem(_ptr(p["A"], p["a_off"]), _ptr(p["B"], p["b_off"]), t.slab.data_ptr(),
+            for lo in range(0, len(probs), MAX_GEMMS):
+                chunk = probs[lo:lo + MAX_GEMMS]
+                arr = (GemmProblem * len(chunk))()
+                for i, (t, p) in enumerate(chunk):
+                    gp = GemmProblem(_ptr(p["A"], p["a_off"]), _ptr(p["B"], p["b_off"]),
+                                     t.slab.data_ptr() if t.slab is not None else None,
                                      t.colsum.data_ptr() if (p["colsum"] and t.colsum is not None) else None,
                                      t.M * t.N, p["lda"], p["ldb"], t.M, t.N, p["K"], p["form"], p["ksplit"], p["slab_base"],
                                      p["Ka"], p["Kb"], p["Ma"], p["Nb"])
-            ops._launch("grouped_gemm", (self.name, len(probs), flops), L_.vqa_grouped_gemm, arr, len(probs))
-        if self.jobs:
-            self._epilogue(L_, self.jobs, "post")
+                    if t.direct is not None:
+                        j, jc = t.direct
+                        gp.out = _ptr(j["out"], j["out_off"])
+                        gp.ldo = j["ldo"]
+                        if jc is not None:
+                            gp.colsum_out = _ptr(jc["out"], jc["out_off"])
+                        bias, aux = j.get("bias"), j.get("aux")
+                        gp.bias = bias.data_ptr() if bias is not None else None
+                        gp.act = int(j.get("act", 0))
+                        gp.gate = int(j.get("gate", 0))
+                        gp.gate_y = _ptr(aux, j.get("aux_off", 0)) if aux is not None else None
+                        gp.ld_gate = int(j.get("ld_aux", 0))
+                        gp.gate_scale = float(j.get("gate_scale", 1.0))
+                        gp.p_drop = float(j.get("p_drop", 0.0))
+                        if gp.p_drop:
+                            sv, sp = ops._seed_args(j.get("seed", 0))
+                            gp.seed, gp.seed_ptr = sv, (sp.value if sp is not None else None)
+                            gp.drop_base, gp.drop_ld = int(j.get("drop_base", 0)), int(j.get("drop_ld", 0))
+                    arr[i] = gp
+                ops._launch("grouped_gemm", (self.name, len(probs), flops if lo == 0 else 0), L_.vqa_grouped_gemm, arr, len(chunk))
+        if jobs:
+            for lo in range(0, len(jobs), MAX_GROUP):
+                self._epilogue(L_, jobs[lo:lo + MAX_GROUP], "post")
 
     def _epilogue(self, L_, jobs, tag):
-        if len(jobs) > MAX_GROUP:
-            raise _lib.VqaLibraryError("phase %s: %d epilogue jobs exceed the group limit %d" % (self.name, len(jobs), MAX_GROUP))
         arr = (EpilogueJob * len(jobs))()
         elems = 0
         for i, j in enumerate(jobs):
