@@ -76,6 +76,28 @@ def test_encoder_feeds_the_hip_head(golden_dir):
 
 
 @pytest.mark.gpu
+def test_gpu_encoder_gradients_match_reference_golden(golden_dir):
+    """SkipThoughts at its real size (620 -> 2400, the reference's BayesianGRU outputs in encoder.npz) on the GPU form --
+    batched input projections, ops.GruSequence (one batched recurrent GEMM + one HIP gate kernel per step, each way),
+    ops.embedding -- forward AND the gradients the golden holds: the embedding table, the norm of weight_hn's gradient,
+    weight_ir's bias gradient (putils/__init__.py:627-646,691-731,975-982)."""
+    dev = torch.device("cuda:0")
+    gold = np.load(os.path.join(golden_dir, "encoder.npz"))
+    enc = build(dev)
+    q = enc(torch.tensor(IDX, device=dev))
+    (q * torch.from_numpy(seeded.seeded_array((4, 2400), 92)).to(dev)).sum().backward()
+    assert np.abs(q.detach().cpu().numpy() - gold["q"]).max() <= 1e-4 * np.abs(gold["q"]).max()
+    assert abs(enc.gru.all_hiddens.double().norm().item() - gold["all_hiddens_norm"]) <= 1e-4 * gold["all_hiddens_norm"]
+    g = enc.embedding.weight.grad.cpu().numpy()
+    assert np.abs(g - gold["g.embedding"]).max() <= 1e-3 * np.abs(gold["g.embedding"]).max()
+    assert np.all(g[0] == 0)                                   # padding row gets no gradient
+    gn = enc.gru.gru_cell.weight_hn.weight.grad.double().norm().item()
+    assert abs(gn - gold["g.weight_hn.norm"]) <= 1e-3 * gold["g.weight_hn.norm"]
+    gb = enc.gru.gru_cell.weight_ir.bias.grad.cpu().numpy()
+    assert np.abs(gb - gold["g.weight_ir.bias"]).max() <= 1e-3 * np.abs(gold["g.weight_ir.bias"]).max()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("af", ["relu", "tanh"])
 @pytest.mark.parametrize("train", [False, True])
 def test_gpu_gru_sequence_matches_the_torch_path(af, train):
