@@ -180,6 +180,13 @@ class Phase:
         if jobs:
             for lo in range(0, len(jobs), MAX_GROUP):
                 self._epilogue(L_, jobs[lo:lo + MAX_GROUP], "post")
+        # break the target <-> job reference cycle: the jobs hold saved tensors of the autograd graph, and a cycle would keep
+        # that graph (and its AccumulateGrad nodes) alive until the garbage collector runs -- into the next step, which is
+        # what makes a later hipGraph capture of the step fail ("AccumulateGrad node's stream does not match")
+        for t in self.targets:
+            t.direct = None
+            t.problems = []
+        self.targets, self.pre_jobs, self.jobs = [], [], []
 
     def _epilogue(self, L_, jobs, tag):
         arr = (EpilogueJob * len(jobs))()
