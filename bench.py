@@ -37,7 +37,7 @@ LOW, HID, GLIMPSES, RANK = 310, 510, 4, 2
 
 
 K4_FOLDED = os.environ.get("VQA_K4_FORM", "auto") != "engine"
-EVIDENCE_TAG = "r02"      # profiles/<tag>_pmc_traffic.json / <tag>_pmc_mfma.json: rocprofv3 --pmc passes of this command
+EVIDENCE_TAG = "r03"      # profiles/<tag>_pmc_traffic.json / <tag>_pmc_mfma.json: rocprofv3 --pmc passes of this command
 
 
 def work_of(name, shape):
@@ -147,6 +147,8 @@ PMC_KERNELS = {  # C-ABI entry -> [(kernel-name prefix, fetch multiplier)]
     "softmax_attention_pool_bwd": [("vqa::attention_pool_bwd_stream_kernel", 2.0)],
     "softmax_attention_pool_drop_fwd": [("vqa::attention_pool_fwd_kernel", 2.0)],
     "softmax_attention_pool_drop_bwd": [("vqa::attention_pool_bwd_stream_kernel", 2.0)],
+    "grouped_gemm": [("vqa::grouped_gemm_kernel<64>", 2.0)],
+    "grouped_epilogue": [("vqa::grouped_epilogue_kernel", 2.0)],
 }
 _tables = {}
 

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates the measured evidence of a round on the MI355X box (run through gpurun from the repo root):
-#   bash tools/refresh_evidence.sh r02_a
+#   bash tools/refresh_evidence.sh r03_a
 # Writes everything under gpurun_out/<tag>/ ; copy what is to be judged into profiles/.
 set -u
-TAG=${1:-r02_x}
+TAG=${1:-r03_x}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -12,34 +12,35 @@ cd /tmp && export TMPDIR=/tmp
 # 1. HBM traffic counters: two separate --pmc passes (never combined with trace domains), kernel by kernel
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate > "$OUT/pmc_$c.log" 2>&1
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records > "$OUT/pmc_$c.log" 2>&1
 done
 python3 "$ROOT/tools/pmc_table.py" /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE "$OUT/pmc_traffic.json" > "$OUT/pmc_table.log" 2>&1
 # 1b. matrix-pipe occupancy counters (their own pass), CoR2 and ODA steps
 rm -rf /tmp/pmc_mfma /tmp/pmc_mfma_oda
 MFMA_CTRS="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
-timeout 600 rocprofv3 --pmc $MFMA_CTRS --output-format csv -d /tmp/pmc_mfma -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate > "$OUT/pmc_mfma.log" 2>&1
+timeout 600 rocprofv3 --pmc $MFMA_CTRS --output-format csv -d /tmp/pmc_mfma -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records > "$OUT/pmc_mfma.log" 2>&1
 python3 "$ROOT/tools/pmc_mfma.py" /tmp/pmc_mfma "$OUT/pmc_mfma.json" > "$OUT/pmc_mfma_table.log" 2>&1
 
 # 2. bench lines
 cd "$ROOT"
 run() { name=$1; shift; timeout 900 python3 bench.py "$@" > "$OUT/$name.log" 2>&1; tail -1 "$OUT/$name.log" > "$OUT/$name.json"; }
 run bench_b512 --steps 20 --warmup 5
-run bench_b512_eager --steps 20 --warmup 5 --no-graph --no-cpu-baseline --no-rotate
-run bench_b512_pairwise --steps 20 --warmup 5 --relation-mode 0 --no-cpu-baseline
-run bench_f32_n100_b128 --regions 100 --batch 128 --steps 20 --warmup 5 --no-cpu-baseline
-run bench_bf16_n100_b128 --dtype bf16 --regions 100 --batch 128 --steps 20 --warmup 5 --no-cpu-baseline
-run bench_b512_encoder --encoder --steps 10 --warmup 5 --no-cpu-baseline
-run bench_oda_b512 --model oda --steps 20 --warmup 5 --no-cpu-baseline
+VQA_HEAD=legacy run bench_b512_legacy_head --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records
+run bench_b512_eager --steps 20 --warmup 5 --no-graph --no-cpu-baseline --no-rotate --no-sub-records
+run bench_b512_pairwise --no-sub-records --steps 20 --warmup 5 --relation-mode 0 --no-cpu-baseline
+run bench_f32_n100_b128 --no-sub-records --regions 100 --batch 128 --steps 20 --warmup 5 --no-cpu-baseline
+run bench_bf16_n100_b128 --no-sub-records --dtype bf16 --regions 100 --batch 128 --steps 20 --warmup 5 --no-cpu-baseline
+run bench_b512_encoder --no-sub-records --encoder --steps 10 --warmup 5 --no-cpu-baseline
+run bench_oda_b512 --no-sub-records --model oda --steps 20 --warmup 5 --no-cpu-baseline
 run bench_oda_attention_b512 --model oda-attention --steps 20 --warmup 5
-VQA_K4_FORM=engine run bench_b512_k4_engine --steps 20 --warmup 5 --no-cpu-baseline
+VQA_K4_FORM=engine run bench_b512_k4_engine --no-sub-records --steps 20 --warmup 5 --no-cpu-baseline
 
 # 3. rocprofv3 kernel traces of the same commands (graph replay and kernel by kernel)
 cd /tmp
 for mode in graph eager; do
   extra=""; [ $mode = eager ] && extra="--no-graph"
   rm -rf /tmp/kt_$mode
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$mode -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline $extra > "$OUT/kt_$mode.log" 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$mode -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records $extra > "$OUT/kt_$mode.log" 2>&1
   f=$(find /tmp/kt_$mode -name "*kernel_stats.csv" | sort | sed -n 1p)
   [ -n "$f" ] && cp "$f" "$OUT/bench_b512_${mode}_kernel_stats.csv"
   python3 "$ROOT/tools/by_grid.py" /tmp/kt_$mode 1 "hand-written kernels, per-dispatch durations by (kernel, grid work-items); rocprofv3 --kernel-trace of bench.py --steps 20 --warmup 5 --no-cpu-baseline $extra (the last column is the total over the run)" > "$OUT/vqa_kernels_by_grid_$mode.txt" 2>&1
@@ -48,7 +49,7 @@ done
 for cfg in "oda_b512|--model oda" "bf16_n100_b128|--dtype bf16 --regions 100 --batch 128"; do
   name=${cfg%%|*}; args=${cfg#*|}
   rm -rf /tmp/kt_$name
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$name -- python3 "$ROOT/bench.py" $args --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/kt_$name.log" 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$name -- python3 "$ROOT/bench.py" $args --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records > "$OUT/kt_$name.log" 2>&1
   f=$(find /tmp/kt_$name -name "*kernel_stats.csv" | sort | sed -n 1p)
   [ -n "$f" ] && cp "$f" "$OUT/bench_${name}_kernel_stats.csv"
   python3 "$ROOT/tools/by_grid.py" /tmp/kt_$name 1 "hand-written kernels, per-dispatch durations by (kernel, grid work-items); rocprofv3 --kernel-trace of bench.py $args --steps 20 --warmup 5 --no-cpu-baseline (the last column is the total over the run)" > "$OUT/vqa_kernels_by_grid_$name.txt" 2>&1
