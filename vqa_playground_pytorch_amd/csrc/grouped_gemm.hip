@@ -684,13 +684,28 @@ static int launch_group(const VqaGemmProblem* probs, int n, bool use_rt, int bm,
     VQA_REQUIRE(items < (1L << 24), VQA_E_UNSUPPORTED, "grouped_gemm: too many tiles");
   }
   g.first[n] = (int)items;
+  // Occupancy shaping.  A phase is a SMALL grid (a few hundred workgroups), and the dispatcher fills a CU up to the
+  // kernel's occupancy before it moves on: 256 workgroups of a kernel that fits twice per CU land on 128 CUs and take
+  // twice as long (measured on the register-tile form: 49 us instead of the 24 us of its MFMA stream).  Asking for
+  // dynamic LDS the kernel does not need caps the workgroups per CU at ceil(workgroups / 256), which spreads the grid
+  // over the whole chip.  (VQA_GROUPED_SPREAD=0 turns it off.)
+  const long wgs = use_rt ? (items + 3) / 4 : items;
+  const char* spread = vqa::option("VQA_GROUPED_SPREAD");
+  const long per_cu = (wgs + 255) / 256;
+  size_t pad = 0;
+  if (!(spread != nullptr && spread[0] == '0') && per_cu >= 1 && per_cu <= 6) pad = (size_t)(160 * 1024 / per_cu) / 1024 * 1024 - 1024;
   if (use_rt) {
-    hipLaunchKernelGGL(grouped_rt_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, g, (int)items);
+    VQA_ENSURE_LDS(grouped_rt_kernel, pad);
+    hipLaunchKernelGGL(grouped_rt_kernel, dim3((unsigned)wgs), dim3(256), pad, s, g, (int)items);
   } else if (bm == 128) {
-    const size_t lds = GemmTile<128, kGBN, kGBK, true, true>::kSmemBytes;   // the largest of the three forms
+    size_t lds = GemmTile<128, kGBN, kGBK, true, true>::kSmemBytes;   // the largest of the three forms
+    if (pad > lds) lds = pad;
+    VQA_ENSURE_LDS(grouped_gemm_kernel<128>, lds);
     hipLaunchKernelGGL(grouped_gemm_kernel<128>, dim3((unsigned)items), dim3(kGemmThreads), lds, s, g, (int)items);
   } else {
-    const size_t lds = GemmTile<64, kGBN, kGBK, true, true>::kSmemBytes;
+    size_t lds = GemmTile<64, kGBN, kGBK, true, true>::kSmemBytes;
+    if (pad > lds) lds = pad;
+    VQA_ENSURE_LDS(grouped_gemm_kernel<64>, lds);
     hipLaunchKernelGGL(grouped_gemm_kernel<64>, dim3((unsigned)items), dim3(kGemmThreads), lds, s, g, (int)items);
   }
   return check_launch("grouped_gemm");
