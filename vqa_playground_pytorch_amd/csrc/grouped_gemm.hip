@@ -270,19 +270,25 @@ __device__ __forceinline__ void nt_item(const VqaGemmProblem& pr, int m0, int n0
     __builtin_amdgcn_sched_barrier(0);
   };
   {
-    f32x4 a0[RB], b0[CB], a1[RB], b1[CB];
-    const int c_pairs = c_lo + ((c_hi - c_lo) & ~1);
+    // THREE register sets: chunk c + 2 is requested while chunk c computes.  With two sets a load has ~44 MFMAs (0.7 us) to
+    // land -- an item's 80-MFMA chunk is less than half of the 180 of the region projections' 9 x 5 tile -- and every chunk
+    // waited ~1.3 us for L2 / fabric latency (measured: 5.4 k cycles per chunk instead of 2.6 k).  The loop is branch-free
+    // over triples of chunks; the 0-2 chunks left over follow one by one.
+    f32x4 a0[RB], b0[CB], a1[RB], b1[CB], a2[RB], b2[CB];
+    const int n3 = (c_hi - c_lo) / 3 * 3, c_end = c_lo + n3;
     int c = c_lo;
-    if (c < c_pairs) {
+    if (c < c_end) {
       load(a0, b0, c);
+      load(a1, b1, c + 1);
       __builtin_amdgcn_sched_barrier(0);
-      for (; c < c_pairs; c += 2) {
-        step(a1, b1, c + 1, a0, b0);
-        step(a0, b0, min(c + 2, c_pairs - 1), a1, b1);   // (last pair: a harmless reload)
+      for (; c < c_end; c += 3) {
+        step(a2, b2, c + 2, a0, b0);
+        step(a0, b0, min(c + 3, c_end - 1), a1, b1);   // (last triple: harmless reloads)
+        step(a1, b1, min(c + 4, c_end - 1), a2, b2);
       }
     }
-    if (c_pairs < c_hi) {
-      load(a0, b0, c_pairs);
+    for (c = c_end; c < c_hi; ++c) {
+      load(a0, b0, c);
       compute(a0, b0);
     }
   }
@@ -398,20 +404,22 @@ __device__ __forceinline__ void xn_item(const VqaGemmProblem& pr, int m0, int n0
     __builtin_amdgcn_sched_barrier(0);
   };
   {
-    Set s0, s1;   // branch-free over pairs of chunks
+    Set s0, s1, s2;   // three sets, branch-free over triples of chunks (see nt_item)
+    const int n3 = nfull / 3 * 3;
     int c = 0;
-    if ((nfull & 1) != 0) {
+    if (c < n3) {
       load(s0, k_begin);
-      compute(s0);
-      ++c;
-    }
-    if (c < nfull) {
-      load(s0, k_begin + 16 * c);
+      load(s1, k_begin + 16);
       __builtin_amdgcn_sched_barrier(0);
-      for (; c < nfull; c += 2) {
-        step(s1, k_begin + 16 * (c + 1), s0);
-        step(s0, k_begin + 16 * min(c + 2, nfull - 1), s1);
+      for (; c < n3; c += 3) {
+        step(s2, k_begin + 16 * (c + 2), s0);
+        step(s0, k_begin + 16 * min(c + 3, n3 - 1), s1);
+        step(s1, k_begin + 16 * min(c + 4, n3 - 1), s2);
       }
+    }
+    for (c = n3; c < nfull; ++c) {
+      load(s0, k_begin + 16 * c);
+      compute(s0);
     }
   }
   if (((k_end - k_begin) & 15) != 0) {   // contraction tail of the part: clamped loads, indices >= k_end contribute zero through A
