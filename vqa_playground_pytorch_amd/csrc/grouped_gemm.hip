@@ -240,28 +240,39 @@ __device__ __forceinline__ void nt_item(const VqaGemmProblem& pr, int m0, int n0
   const int k_begin = split * pr.ksplit, k_end = min(pr.K, k_begin + pr.ksplit);
   const int c_lo = k_begin >> 4, c_hi = k_end >> 4;      // whole 16-deep chunks (k_begin is a multiple of 16)
 
-  auto load = [&](f32x4(&a)[RB], f32x4(&b)[CB], int c) {
-    const uint32_t so = (uint32_t)c * 64u;
-#pragma unroll
-    for (int j = 0; j < CB; ++j) b[j] = ldg16(Bb, offB[j], so);
-#pragma unroll
-    for (int i = 0; i < RB; ++i) a[i] = ldg16(Ab, offA[i], so);
+  // A step is a PAIR of 16-deep chunks (32 contraction indices = one 128-byte line of every operand row): both halves of a
+  // line are requested back to back, so the second is served by the line the first brought into L1.  Requested one chunk
+  // (~1.2 us) apart they were two separate L2 fetches -- the 4 waves of a CU walk 72 KB of lines per chunk through a 32 KB
+  // L1 -- and the kernel ran at the L2 -> L1 rate (2.3 us per chunk instead of the 1.2 us of its 80 MFMAs).
+  struct Frag {
+    f32x4 a[2][RB], b[2][CB];
   };
-  auto mfma_row = [&](const f32x4& ai, f32x4(&b)[CB], int i) {
+  auto load = [&](Frag& f, int c) {      // chunks c, c + 1 (c + 1 clamped by the caller's range: see below)
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t so = (uint32_t)(c + h) * 64u;
 #pragma unroll
-      for (int j = 0; j < CB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[kb], b[j][kb], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < CB; ++j) f.b[h][j] = ldg16(Bb, offB[j], so);
+#pragma unroll
+      for (int i = 0; i < RB; ++i) f.a[h][i] = ldg16(Ab, offA[i], so);
+    }
   };
-  auto compute = [&](f32x4(&a)[RB], f32x4(&b)[CB]) {
+  auto mfma_half = [&](const f32x4(&a)[RB], const f32x4(&b)[CB]) {
 #pragma unroll
-    for (int i = 0; i < RB; ++i) mfma_row(a[i], b, i);
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int j = 0; j < CB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][kb], b[j][kb], acc[i][j], 0, 0, 0);
   };
-  // chunk cn is loaded in the shadow of chunk c's MFMAs (one load per few MFMAs: see rt::gemm_nt_kernel)
-  auto step = [&](f32x4(&an)[RB], f32x4(&bn)[CB], int cn, f32x4(&a)[RB], f32x4(&b)[CB]) {
-    load(an, bn, cn);
-    compute(a, b);
-    constexpr int NL = RB + CB, NM = 4 * RB * CB, PER = NM / (2 * NL);
+  auto compute = [&](Frag& f) {
+    mfma_half(f.a[0], f.b[0]);
+    mfma_half(f.a[1], f.b[1]);
+  };
+  auto step = [&](Frag& fn, int cn, Frag& f) {   // pair cn is loaded in the shadow of pair f's 160 MFMAs
+    load(fn, cn);
+    compute(f);
+    constexpr int NL = 2 * (RB + CB), NM = 8 * RB * CB, PER = NM / (2 * NL);
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -270,26 +281,30 @@ __device__ __forceinline__ void nt_item(const VqaGemmProblem& pr, int m0, int n0
     __builtin_amdgcn_sched_barrier(0);
   };
   {
-    // THREE register sets: chunk c + 2 is requested while chunk c computes.  With two sets a load has ~44 MFMAs (0.7 us) to
-    // land -- an item's 80-MFMA chunk is less than half of the 180 of the region projections' 9 x 5 tile -- and every chunk
-    // waited ~1.3 us for L2 / fabric latency (measured: 5.4 k cycles per chunk instead of 2.6 k).  The loop is branch-free
-    // over triples of chunks; the 0-2 chunks left over follow one by one.
-    f32x4 a0[RB], b0[CB], a1[RB], b1[CB], a2[RB], b2[CB];
-    const int n3 = (c_hi - c_lo) / 3 * 3, c_end = c_lo + n3;
+    Frag f0, f1;
+    const int npair = (c_hi - c_lo) >> 1, c_end = c_lo + 2 * npair;   // whole pairs; a last single chunk follows
+    const int n2 = npair & ~1;                                        // pairs taken two per loop iteration (branch-free)
     int c = c_lo;
-    if (c < c_end) {
-      load(a0, b0, c);
-      load(a1, b1, c + 1);
+    if (n2 > 0) {
+      load(f0, c);
       __builtin_amdgcn_sched_barrier(0);
-      for (; c < c_end; c += 3) {
-        step(a2, b2, c + 2, a0, b0);
-        step(a0, b0, min(c + 3, c_end - 1), a1, b1);   // (last triple: harmless reloads)
-        step(a1, b1, min(c + 4, c_end - 1), a2, b2);
+      for (int q = 0; q < n2; q += 2, c += 4) {
+        step(f1, c + 2, f0);
+        step(f0, min(c + 4, c_lo + 2 * n2 - 2), f1);   // (last iteration: a harmless reload)
       }
     }
-    for (c = c_end; c < c_hi; ++c) {
-      load(a0, b0, c);
-      compute(a0, b0);
+    if (c < c_end) {       // an odd pair left over
+      load(f0, c);
+      compute(f0);
+      c += 2;
+    }
+    if (c < c_hi) {        // a last single chunk: its second half is a (valid, unused) reload of itself
+      const uint32_t so = (uint32_t)c * 64u;
+#pragma unroll
+      for (int j = 0; j < CB; ++j) f0.b[0][j] = ldg16(Bb, offB[j], so);
+#pragma unroll
+      for (int i = 0; i < RB; ++i) f0.a[0][i] = ldg16(Ab, offA[i], so);
+      mfma_half(f0.a[0], f0.b[0]);
     }
   }
   if ((k_end & 15) != 0) {   // K tail (< 16; the last part only): per-component guarded loads, zero beyond K
@@ -311,7 +326,7 @@ __device__ __forceinline__ void nt_item(const VqaGemmProblem& pr, int m0, int n0
         const float v = ldg4(Bb, offB[j] - 16u * g + 4u * (uint32_t)min(k, pr.K - 1), 0u);
         b[j][e] = k < pr.K ? v : 0.f;
       }
-    compute(a, b);
+    mfma_half(a, b);
   }
   const Store st(pr, split);
 #pragma unroll
