@@ -281,24 +281,29 @@ __device__ __forceinline__ void nt_item(const VqaGemmProblem& pr, int m0, int n0
     __builtin_amdgcn_sched_barrier(0);
   };
   {
-    Frag f0, f1;
+    // three fragment sets (pair p + 2 is requested while pair p computes); > 256 registers, i.e. ONE wave per SIMD: with two
+    // waves allowed per SIMD the four waves of a workgroup were not spread over the four SIMDs (the kernel ran at exactly
+    // half its MFMA rate whatever the prefetch depth)
+    Frag f0, f1, f2;
     const int npair = (c_hi - c_lo) >> 1, c_end = c_lo + 2 * npair;   // whole pairs; a last single chunk follows
-    const int n2 = npair & ~1;                                        // pairs taken two per loop iteration (branch-free)
+    const int n3 = npair / 3 * 3;                                      // pairs taken three per loop iteration (branch-free)
+    const int c_last = c_lo + 2 * n3 - 2;
     int c = c_lo;
-    if (n2 > 0) {
+    if (n3 > 0) {
       load(f0, c);
+      load(f1, c + 2);
       __builtin_amdgcn_sched_barrier(0);
-      for (int q = 0; q < n2; q += 2, c += 4) {
-        step(f1, c + 2, f0);
-        step(f0, min(c + 4, c_lo + 2 * n2 - 2), f1);   // (last iteration: a harmless reload)
+      for (int q = 0; q < n3; q += 3, c += 6) {
+        step(f2, c + 4, f0);
+        step(f0, min(c + 6, c_last), f1);   // (last iteration: harmless reloads)
+        step(f1, min(c + 8, c_last), f2);
       }
     }
-    if (c < c_end) {       // an odd pair left over
+    for (; c < c_end; c += 2) {   // 0-2 pairs left over
       load(f0, c);
       compute(f0);
-      c += 2;
     }
-    if (c < c_hi) {        // a last single chunk: its second half is a (valid, unused) reload of itself
+    if (c < c_hi) {        // a last single chunk
       const uint32_t so = (uint32_t)c * 64u;
 #pragma unroll
       for (int j = 0; j < CB; ++j) f0.b[0][j] = ldg16(Bb, offB[j], so);
@@ -487,7 +492,7 @@ __device__ __forceinline__ int cols_of(int form) { return form == 0 ? NT_COLS : 
 
 }  // namespace grt
 
-__global__ __launch_bounds__(256, 2) void grouped_rt_kernel(GProbs g_arg, int items) {
+__global__ __launch_bounds__(256, 1) void grouped_rt_kernel(GProbs g_arg, int items) {
   const GProbs& g = kernarg_table<GProbs>();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;     // wave-uniform; the four waves are independent
