@@ -13,12 +13,18 @@
 //                         NEXT layer's input dropout (stored dropped: relu and mask gate the backward together), the rank
 //                         product of the vector-vector Mutan fusion, activation / dropout gradients, layouts.
 //
+// Tried and removed (round 3, measured on the MI355X): the same grouped launch on the register-tile engine -- one WAVE per
+// 64 x 80 (NT) / 64 x 64 (NN, TN) item, operand fragments straight from L2 -- was correct and no faster than this form
+// (q-projection phase 49 us on either; whole step 2.62 ms against 2.46): at 8-9 sixteen-byte fragment loads per 64-80
+// MFMAs the kernel runs at half its MFMA stream whatever the prefetch depth (2 / 3 register sets), the line usage (16- /
+// 32-deep steps), the waves per SIMD or the workgroup placement -- the L1 / address path of 16-row fragment loads, as
+// DESIGN.md 5c had found for small tiles; M = 512 rows leave no room for the 9 x 5-block tiles that make that engine pay.
+//
 // M = 512 rows, N = 155..2048, K = 310..2400: 0.3-3 GFLOP per product.  One product cannot fill 256 CUs without a deep
 // K split; a phase's products together can (a few hundred 64x64 tiles x 2-8 splits), and the 2-6 launch-floor kernels
 // that used to surround each library GEMM (dropout, bias + activation, activation gradient + column sums, slices, adds)
 // become arithmetic in the one epilogue launch.
 #include "gemm_f32_mfma.hpp"
-#include "gemm_f32_rt.hpp"
 
 namespace vqa {
 
@@ -171,349 +177,6 @@ __global__ __launch_bounds__(kGemmThreads, BM == 64 ? 4 : 2) void grouped_gemm_k
     grouped_tile<BM, true, false>(pr, SrcKC1{pr.A, pr.lda, pr.M, pr.Ka}, SrcMC{pr.B, pr.ldb, pr.Nb, pr.Kb}, m0, n0, split, smem_g);
   } else {                     // TN with a 4-byte aligned A
     grouped_tile<BM, false, false>(pr, SrcMC1{pr.A, pr.lda, pr.Ma, pr.Ka}, SrcMC{pr.B, pr.ldb, pr.Nb, pr.Kb}, m0, n0, split, smem_g);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ register-tile form
-// The same grouped launch on the register-tile engine (gemm_f32_rt.hpp): ONE WAVE owns a work item -- a 64 x 80 (NT) or
-// 64 x 64 (NN, TN) output tile of one contraction part -- as 20 / 16 accumulator blocks of v_mfma_f32_16x16x4_f32 and fetches
-// its operand fragments straight from L2 with buffer loads (8-9 sixteen-byte loads per 64-80 MFMAs): no LDS, no barrier,
-// almost no vector-ALU work next to the fp32 MFMAs (which is what holds the LDS-tile form at ~40 % of the matrix peak on
-// these shapes: ~26 VALU instructions per 8 MFMAs for addresses, clamps and zero-fills).  Four independent waves per
-// workgroup, two workgroups per CU.  Forms 3 / 4 (4-byte aligned A) and operands with padded extents stay on the LDS form.
-namespace grt {
-using rt::f32x4;
-using rt::ldg16;
-using rt::ldg4;
-using rt::make_rsrc;
-using rt::rsrc_t;
-
-constexpr int RB = 4;        // 64 output rows per item
-constexpr int CB = 5;        // NT: 80 output columns (5 blocks of 16)
-constexpr int NT_COLS = 16 * CB, SPAN = 64;
-
-// element (row, col) of the item's result: into the part's slab, or -- direct output -- through the layer's epilogue
-struct Store {
-  const VqaGemmProblem& pr;
-  float* dst;        // slab of this part (nullptr: direct)
-  DropCfg dc;
-  bool drop;
-  __device__ __forceinline__ Store(const VqaGemmProblem& p, int split) : pr(p), dc{}, drop(false) {
-    dst = p.out != nullptr ? nullptr : p.slab + (size_t)(p.slab_base + split) * p.slab_stride;
-    if (p.out != nullptr && p.p_drop > 0.f) {
-      drop = true;
-      dc = make_drop_dev(p.p_drop, p.seed, p.seed_ptr);
-    }
-  }
-  __device__ __forceinline__ void operator()(int row, int col, float v) const {
-    if (dst != nullptr) {
-      dst[(size_t)row * pr.N + col] = v;
-      return;
-    }
-    float z = act_fwd_g(v + (pr.bias != nullptr ? pr.bias[col] : 0.f), pr.act);
-    if (pr.gate != 0) {
-      const float y = pr.gate_y[(size_t)row * pr.ld_gate + col];
-      z = pr.gate == 1 ? (y > 0.f ? z * pr.gate_scale : 0.f) : z * y * (1.f - y);
-    }
-    if (drop) z *= drop_one(pr.drop_base + (uint32_t)row * pr.drop_ld + (uint32_t)col, dc);
-    pr.out[(size_t)row * pr.ldo + col] = z;
-  }
-};
-
-__device__ __forceinline__ void interleave(int mfmas, int loads) {}   // (placeholder: the schedules are spelled out below)
-
-// ---- NT: A [M,K] and B [N,K] K-contiguous.  acc[i][j] += A[m0+16i+., k] B[n0+16j+., k]
-__device__ __forceinline__ void nt_item(const VqaGemmProblem& pr, int m0, int n0, int split) {
-  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  uint32_t offA[RB], offB[CB];
-#pragma unroll
-  for (int i = 0; i < RB; ++i) offA[i] = ((uint32_t)min(m0 + 16 * i + r, pr.M - 1) * (uint32_t)pr.lda + 4u * g) * 4u;
-#pragma unroll
-  for (int j = 0; j < CB; ++j) offB[j] = ((uint32_t)min(n0 + 16 * j + r, pr.N - 1) * (uint32_t)pr.ldb + 4u * g) * 4u;
-  const rsrc_t Ab = make_rsrc(pr.A, ((size_t)(pr.M - 1) * pr.lda + pr.K) * 4);
-  const rsrc_t Bb = make_rsrc(pr.B, ((size_t)(pr.N - 1) * pr.ldb + pr.K) * 4);
-  f32x4 acc[RB][CB];
-#pragma unroll
-  for (int i = 0; i < RB; ++i)
-#pragma unroll
-    for (int j = 0; j < CB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int k_begin = split * pr.ksplit, k_end = min(pr.K, k_begin + pr.ksplit);
-  const int c_lo = k_begin >> 4, c_hi = k_end >> 4;      // whole 16-deep chunks (k_begin is a multiple of 16)
-
-  // A step is a PAIR of 16-deep chunks (32 contraction indices = one 128-byte line of every operand row): both halves of a
-  // line are requested back to back, so the second is served by the line the first brought into L1.  Requested one chunk
-  // (~1.2 us) apart they were two separate L2 fetches -- the 4 waves of a CU walk 72 KB of lines per chunk through a 32 KB
-  // L1 -- and the kernel ran at the L2 -> L1 rate (2.3 us per chunk instead of the 1.2 us of its 80 MFMAs).
-  struct Frag {
-    f32x4 a[2][RB], b[2][CB];
-  };
-  auto load = [&](Frag& f, int c) {      // chunks c, c + 1 (c + 1 clamped by the caller's range: see below)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const uint32_t so = (uint32_t)(c + h) * 64u;
-#pragma unroll
-      for (int j = 0; j < CB; ++j) f.b[h][j] = ldg16(Bb, offB[j], so);
-#pragma unroll
-      for (int i = 0; i < RB; ++i) f.a[h][i] = ldg16(Ab, offA[i], so);
-    }
-  };
-  auto mfma_half = [&](const f32x4(&a)[RB], const f32x4(&b)[CB]) {
-#pragma unroll
-    for (int i = 0; i < RB; ++i)
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-        for (int j = 0; j < CB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][kb], b[j][kb], acc[i][j], 0, 0, 0);
-  };
-  auto compute = [&](Frag& f) {
-    mfma_half(f.a[0], f.b[0]);
-    mfma_half(f.a[1], f.b[1]);
-  };
-  auto step = [&](Frag& fn, int cn, Frag& f) {   // pair cn is loaded in the shadow of pair f's 160 MFMAs
-    load(fn, cn);
-    compute(f);
-    constexpr int NL = 2 * (RB + CB), NM = 8 * RB * CB, PER = NM / (2 * NL);
-#pragma unroll
-    for (int m = 0; m < NM; ++m) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (m % PER == PER - 1 && m / PER < NL) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  {
-    // three fragment sets (pair p + 2 is requested while pair p computes); > 256 registers, i.e. ONE wave per SIMD: with two
-    // waves allowed per SIMD the four waves of a workgroup were not spread over the four SIMDs (the kernel ran at exactly
-    // half its MFMA rate whatever the prefetch depth)
-    Frag f0, f1, f2;
-    const int npair = (c_hi - c_lo) >> 1, c_end = c_lo + 2 * npair;   // whole pairs; a last single chunk follows
-    const int n3 = npair / 3 * 3;                                      // pairs taken three per loop iteration (branch-free)
-    const int c_last = c_lo + 2 * n3 - 2;
-    int c = c_lo;
-    if (n3 > 0) {
-      load(f0, c);
-      load(f1, c + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      for (int q = 0; q < n3; q += 3, c += 6) {
-        step(f2, c + 4, f0);
-        step(f0, min(c + 6, c_last), f1);   // (last iteration: harmless reloads)
-        step(f1, min(c + 8, c_last), f2);
-      }
-    }
-    for (; c < c_end; c += 2) {   // 0-2 pairs left over
-      load(f0, c);
-      compute(f0);
-    }
-    if (c < c_hi) {        // a last single chunk
-      const uint32_t so = (uint32_t)c * 64u;
-#pragma unroll
-      for (int j = 0; j < CB; ++j) f0.b[0][j] = ldg16(Bb, offB[j], so);
-#pragma unroll
-      for (int i = 0; i < RB; ++i) f0.a[0][i] = ldg16(Ab, offA[i], so);
-      mfma_half(f0.a[0], f0.b[0]);
-    }
-  }
-  if ((k_end & 15) != 0) {   // K tail (< 16; the last part only): per-component guarded loads, zero beyond K
-    const int kbase = c_hi * 16 + 4 * g;
-    f32x4 a[RB], b[CB];
-#pragma unroll
-    for (int i = 0; i < RB; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = kbase + e;
-        const float v = ldg4(Ab, offA[i] - 16u * g + 4u * (uint32_t)min(k, pr.K - 1), 0u);
-        a[i][e] = k < pr.K ? v : 0.f;
-      }
-#pragma unroll
-    for (int j = 0; j < CB; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = kbase + e;
-        const float v = ldg4(Bb, offB[j] - 16u * g + 4u * (uint32_t)min(k, pr.K - 1), 0u);
-        b[j][e] = k < pr.K ? v : 0.f;
-      }
-    mfma_half(a, b);
-  }
-  const Store st(pr, split);
-#pragma unroll
-  for (int i = 0; i < RB; ++i)
-#pragma unroll
-    for (int j = 0; j < CB; ++j) {
-      const int col = n0 + 16 * j + r;
-      if (col < pr.N) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int row = m0 + 16 * i + 4 * g + t;
-          if (row < pr.M) st(row, col, acc[i][j][t]);
-        }
-      }
-    }
-}
-
-// ---- NN and TN share the B side: B [K,N] rows N-contiguous -- lane (r, g) reads the 4 columns n0 + 4 r .. + 3 of row
-// k = chunk + 4 g + kb as one 16-byte load; component e feeds accumulator block e (columns {n0 + 4 r + e}).
-//   NN: A [M,K] K-contiguous: one 16-byte load per row block and chunk, component kb = contraction step kb.
-//   TN: A [K,M] M-contiguous: a 4-byte load per (row block, step).  colsum[m] = sum_k A[k, m] when asked for.
-template <bool TN>
-__device__ __forceinline__ void xn_item(const VqaGemmProblem& pr, int m0, int n0, int split, bool want_colsum) {
-  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  uint32_t offA[RB];
-#pragma unroll
-  for (int i = 0; i < RB; ++i) {
-    const uint32_t m = (uint32_t)min(m0 + 16 * i + r, pr.M - 1);
-    offA[i] = TN ? ((uint32_t)(4 * g) * (uint32_t)pr.lda + m) * 4u : (m * (uint32_t)pr.lda + 4u * g) * 4u;
-  }
-  const uint32_t offB = ((uint32_t)(4 * g) * (uint32_t)pr.ldb + (uint32_t)(n0 + 4 * r)) * 4u;   // (columns past N: loaded, never stored)
-  const rsrc_t Ab = TN ? make_rsrc(pr.A, ((size_t)(pr.K - 1) * pr.lda + pr.M) * 4) : make_rsrc(pr.A, ((size_t)(pr.M - 1) * pr.lda + pr.K) * 4);
-  const rsrc_t Bb = make_rsrc(pr.B, ((size_t)(pr.K - 1) * pr.ldb + pr.N) * 4);
-  f32x4 acc[RB][4];
-#pragma unroll
-  for (int i = 0; i < RB; ++i)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc[i][e] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float dbp[RB];
-#pragma unroll
-  for (int i = 0; i < RB; ++i) dbp[i] = 0.f;
-  const int k_begin = split * pr.ksplit, k_end = min(pr.K, k_begin + pr.ksplit);
-  const int nfull = (k_end - k_begin) >> 4;
-
-  struct Set {
-    float a[4][RB];     // a[kb][i]: the A operand of step kb for row block i
-    f32x4 q[4];         // q[kb]: the B row of step kb
-  };
-  auto load = [&](Set& s, int kc) {     // chunk starting at contraction index kc
-    if constexpr (TN) {
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        const uint32_t sa = (uint32_t)(kc + kb) * (uint32_t)pr.lda * 4u;
-#pragma unroll
-        for (int i = 0; i < RB; ++i) s.a[kb][i] = ldg4(Ab, offA[i], sa);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < RB; ++i) {
-        const f32x4 v = ldg16(Ab, offA[i], (uint32_t)kc * 4u);
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) s.a[kb][i] = v[kb];
-      }
-    }
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) s.q[kb] = ldg16(Bb, offB, (uint32_t)(kc + kb) * (uint32_t)pr.ldb * 4u);
-  };
-  auto compute = [&](Set& s) {
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      if constexpr (TN) {
-#pragma unroll
-        for (int i = 0; i < RB; ++i) dbp[i] += s.a[kb][i];
-      }
-#pragma unroll
-      for (int i = 0; i < RB; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(s.a[kb][i], s.q[kb][e], acc[i][e], 0, 0, 0);
-    }
-  };
-  auto step = [&](Set& sn, int kn, Set& s) {
-    load(sn, kn);
-    compute(s);
-    constexpr int NL = (TN ? 4 * RB : RB) + 4, NM = 16 * RB, PER = (3 * NM) / (4 * NL) > 0 ? (3 * NM) / (4 * NL) : 1;
-#pragma unroll
-    for (int m = 0; m < NM; ++m) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (m % PER == PER - 1 && m / PER < NL) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  {
-    Set s0, s1, s2;   // three sets, branch-free over triples of chunks (see nt_item)
-    const int n3 = nfull / 3 * 3;
-    int c = 0;
-    if (c < n3) {
-      load(s0, k_begin);
-      load(s1, k_begin + 16);
-      __builtin_amdgcn_sched_barrier(0);
-      for (; c < n3; c += 3) {
-        step(s2, k_begin + 16 * (c + 2), s0);
-        step(s0, k_begin + 16 * min(c + 3, n3 - 1), s1);
-        step(s1, k_begin + 16 * min(c + 4, n3 - 1), s2);
-      }
-    }
-    for (c = n3; c < nfull; ++c) {
-      load(s0, k_begin + 16 * c);
-      compute(s0);
-    }
-  }
-  if (((k_end - k_begin) & 15) != 0) {   // contraction tail of the part: clamped loads, indices >= k_end contribute zero through A
-    const int kc = k_begin + 16 * nfull;
-    Set s;
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const int k = kc + 4 * g + kb;
-      const bool ok = k < k_end;
-      const uint32_t kcl = (uint32_t)min(k, k_end - 1);
-#pragma unroll
-      for (int i = 0; i < RB; ++i) {
-        const uint32_t m = (uint32_t)min(m0 + 16 * i + r, pr.M - 1);
-        const uint32_t o = TN ? (kcl * (uint32_t)pr.lda + m) * 4u : (m * (uint32_t)pr.lda + kcl) * 4u;
-        const float v = ldg4(Ab, o, 0u);
-        s.a[kb][i] = ok ? v : 0.f;
-      }
-      s.q[kb] = ldg16(Bb, (kcl * (uint32_t)pr.ldb + (uint32_t)(n0 + 4 * r)) * 4u, 0u);
-    }
-    compute(s);
-  }
-  const Store st(pr, split);
-#pragma unroll
-  for (int i = 0; i < RB; ++i)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int row = m0 + 16 * i + 4 * g + t;
-      if (row < pr.M) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int col = n0 + 4 * r + e;
-          if (col < pr.N) st(row, col, acc[i][e][t]);
-        }
-      }
-    }
-  if (TN && want_colsum) {
-    float* cs = pr.colsum_out != nullptr ? pr.colsum_out : pr.colsum + (size_t)(pr.slab_base + split) * pr.M;
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      float v = dbp[i];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      const int m = m0 + 16 * i + r;
-      if (g == 0 && m < pr.M) cs[m] = v;
-    }
-  }
-}
-
-__device__ __forceinline__ int cols_of(int form) { return form == 0 ? NT_COLS : SPAN; }
-
-}  // namespace grt
-
-__global__ __launch_bounds__(256, 1) void grouped_rt_kernel(GProbs g_arg, int items) {
-  const GProbs& g = kernarg_table<GProbs>();
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;     // wave-uniform; the four waves are independent
-  if (item >= items) return;
-  int p = 0;
-  while (p + 1 < g.n && g.first[p + 1] <= item) ++p;
-  p = __builtin_amdgcn_readfirstlane(p);
-  const VqaGemmProblem& pr = g.p[p];
-  const int local = item - g.first[p];
-  const int tw = grt::cols_of(pr.form);
-  const int tiles_n = (pr.N + tw - 1) / tw, tiles_m = (pr.M + 63) / 64;
-  const int split = local / (tiles_m * tiles_n), t = local % (tiles_m * tiles_n);
-  if (pr.form == 0) {
-    // column tile fastest: the waves of a workgroup share their A rows
-    grt::nt_item(pr, (t / tiles_n) * 64, (t % tiles_n) * tw, split);
-  } else {
-    // row tile fastest: the waves of a workgroup share their B rows; the first column tile of a TN part owns the column sums
-    const int m0 = (t % tiles_m) * 64, n0 = (t / tiles_m) * tw;
-    const bool cs = (pr.colsum != nullptr || pr.colsum_out != nullptr) && n0 == 0;
-    if (pr.form == 1) grt::xn_item<false>(pr, m0, n0, split, false);
-    else grt::xn_item<true>(pr, m0, n0, split, cs);
   }
 }
 
@@ -686,67 +349,15 @@ __global__ __launch_bounds__(256) void grouped_epilogue_kernel(EJobs g_arg, int 
 
 using namespace vqa;
 
-static bool rt_capable(const VqaGemmProblem& p) {
-  // forms NT / NN / TN with 8-byte aligned operands of their natural extents and an even output width; 32-bit byte offsets
-  if (p.form < 0 || p.form > 2) return false;
-  if (p.Ka != p.K || p.Kb != p.K || p.Ma != p.M || p.Nb != p.N) return false;
-  if (p.lda % 2 != 0 || p.ldb % 2 != 0 || !aligned(p.A, 8) || !aligned(p.B, 8)) return false;
-  if (p.form != 0 && (p.N % 2 != 0 || p.N < 4)) return false;
-  if (p.form == 0 && p.K % 2 != 0) return false;
-  const size_t ra = p.form == 2 ? (size_t)p.K : (size_t)p.M, rb = p.form == 0 ? (size_t)p.N : (size_t)p.K;
-  return ra * p.lda * 4 < (1ull << 32) && rb * p.ldb * 4 < (1ull << 32);
-}
-
-static int launch_group(const VqaGemmProblem* probs, int n, bool use_rt, int bm, hipStream_t s) {
-  GProbs g{};
-  g.n = n;
-  long items = 0;
-  for (int i = 0; i < n; ++i) {
-    const VqaGemmProblem& p = probs[i];
-    g.p[i] = p;
-    g.first[i] = (int)items;
-    const int parts = (p.K + p.ksplit - 1) / p.ksplit;
-    const long tiles = use_rt ? (long)((p.M + 63) / 64) * ((p.N + (p.form == 0 ? grt::NT_COLS : grt::SPAN) - 1) / (p.form == 0 ? grt::NT_COLS : grt::SPAN))
-                              : (long)((p.M + bm - 1) / bm) * ((p.N + kGBN - 1) / kGBN);
-    items += tiles * parts;
-    VQA_REQUIRE(items < (1L << 24), VQA_E_UNSUPPORTED, "grouped_gemm: too many tiles");
-  }
-  g.first[n] = (int)items;
-  // Occupancy shaping.  A phase is a SMALL grid (a few hundred workgroups), and the dispatcher fills a CU up to the
-  // kernel's occupancy before it moves on: 256 workgroups of a kernel that fits twice per CU land on 128 CUs and take
-  // twice as long (measured on the register-tile form: 49 us instead of the 24 us of its MFMA stream).  Asking for
-  // dynamic LDS the kernel does not need caps the workgroups per CU at ceil(workgroups / 256), which spreads the grid
-  // over the whole chip.  (VQA_GROUPED_SPREAD=0 turns it off.)
-  const long wgs = use_rt ? (items + 3) / 4 : items;
-  const char* spread = vqa::option("VQA_GROUPED_SPREAD");
-  const long per_cu = (wgs + 255) / 256;
-  size_t pad = 0;
-  if (!(spread != nullptr && spread[0] == '0') && per_cu >= 1 && per_cu <= 6) pad = (size_t)(160 * 1024 / per_cu) / 1024 * 1024 - 1024;
-  if (use_rt) {
-    VQA_ENSURE_LDS(grouped_rt_kernel, pad);
-    hipLaunchKernelGGL(grouped_rt_kernel, dim3((unsigned)wgs), dim3(256), pad, s, g, (int)items);
-  } else if (bm == 128) {
-    size_t lds = GemmTile<128, kGBN, kGBK, true, true>::kSmemBytes;   // the largest of the three forms
-    if (pad > lds) lds = pad;
-    VQA_ENSURE_LDS(grouped_gemm_kernel<128>, lds);
-    hipLaunchKernelGGL(grouped_gemm_kernel<128>, dim3((unsigned)items), dim3(kGemmThreads), lds, s, g, (int)items);
-  } else {
-    size_t lds = GemmTile<64, kGBN, kGBK, true, true>::kSmemBytes;
-    if (pad > lds) lds = pad;
-    VQA_ENSURE_LDS(grouped_gemm_kernel<64>, lds);
-    hipLaunchKernelGGL(grouped_gemm_kernel<64>, dim3((unsigned)items), dim3(kGemmThreads), lds, s, g, (int)items);
-  }
-  return check_launch("grouped_gemm");
-}
+static int split_of(const VqaGemmProblem& p) { return (p.K + p.ksplit - 1) / p.ksplit; }
 
 extern "C" int vqa_grouped_gemm(const VqaGemmProblem* problems, int n, vqa_stream_t stream) {
   VQA_REQUIRE(problems != nullptr && n >= 1 && n <= kGMaxGemms, VQA_E_BADARG, "grouped_gemm: 1..%d problems (got %d)", kGMaxGemms, n);
-  const char* tile = vqa::option("VQA_GROUPED_BM");     // LDS form: tile rows 64 (default) or 128
+  GProbs g{};
+  g.n = n;
+  int items = 0;
+  const char* tile = vqa::option("VQA_GROUPED_BM");     // tile rows: 64 (default) or 128
   const int bm = (tile != nullptr && std::atoi(tile) == 128) ? 128 : 64;
-  const char* eng = vqa::option("VQA_GROUPED_ENGINE");  // "lds": every problem on the LDS-tile form (comparison knob)
-  const bool want_rt = !(eng != nullptr && eng[0] == 'l');
-  VqaGemmProblem rtp[kGMaxGemms], ldp[kGMaxGemms];
-  int nrt = 0, nld = 0;
   for (int i = 0; i < n; ++i) {
     VqaGemmProblem p = problems[i];
     VQA_REQUIRE(p.A && p.B && (p.slab || p.out), VQA_E_BADARG, "grouped_gemm[%d]: null pointer", i);
@@ -768,13 +379,7 @@ extern "C" int vqa_grouped_gemm(const VqaGemmProblem* problems, int n, vqa_strea
     if (p.Kb <= 0) p.Kb = p.K;
     if (p.Ma <= 0) p.Ma = p.M;
     if (p.Nb <= 0) p.Nb = p.N;
-    VQA_REQUIRE((p.colsum == nullptr && p.colsum_out == nullptr) || p.form == 2 || p.form == 4, VQA_E_BADARG,
-                "grouped_gemm[%d]: column sums exist for the TN forms only", i);
-    if (want_rt && rt_capable(p)) {
-      rtp[nrt++] = p;
-      continue;
-    }
-    // LDS form, 8-byte operand loads: even leading dimensions, 8-byte aligned bases, even extents along the contiguous axis
+    // 8-byte operand loads: even leading dimensions, 8-byte aligned bases, even extents along the contiguous axis
     // (forms 3 / 4 read A with 4-byte loads: no requirement on A)
     const bool a_kc = p.form != 2 && p.form != 4, b_kc = p.form == 0, a_free = p.form >= 3;
     VQA_REQUIRE(aligned(p.A, 4) && aligned(p.B, 8) && p.ldb % 2 == 0 && (b_kc ? p.Kb : p.Nb) % 2 == 0 && (b_kc ? p.Kb : p.Nb) >= 2 &&
@@ -782,15 +387,23 @@ extern "C" int vqa_grouped_gemm(const VqaGemmProblem* problems, int n, vqa_strea
                 VQA_E_UNSUPPORTED,
                 "grouped_gemm[%d]: operands need even leading dimensions / contiguous extents and 8-byte aligned bases "
                 "(form %d lda=%d ldb=%d)", i, p.form, p.lda, p.ldb);
-    ldp[nld++] = p;
+    VQA_REQUIRE((p.colsum == nullptr && p.colsum_out == nullptr) || p.form == 2 || p.form == 4, VQA_E_BADARG,
+                "grouped_gemm[%d]: column sums exist for the TN forms only", i);
+    g.p[i] = p;
+    g.first[i] = items;
+    const long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + kGBN - 1) / kGBN) * split_of(p);
+    VQA_REQUIRE(items + tiles < (1L << 24), VQA_E_UNSUPPORTED, "grouped_gemm: too many tiles");
+    items += (int)tiles;
   }
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (nrt > 0) {
-    const int rc = launch_group(rtp, nrt, true, bm, s);
-    if (rc != VQA_OK) return rc;
+  g.first[n] = items;
+  if (bm == 128) {
+    const size_t lds = GemmTile<128, kGBN, kGBK, true, true>::kSmemBytes;   // the largest of the three forms
+    hipLaunchKernelGGL(grouped_gemm_kernel<128>, dim3(items), dim3(kGemmThreads), lds, static_cast<hipStream_t>(stream), g, items);
+  } else {
+    const size_t lds = GemmTile<64, kGBN, kGBK, true, true>::kSmemBytes;
+    hipLaunchKernelGGL(grouped_gemm_kernel<64>, dim3(items), dim3(kGemmThreads), lds, static_cast<hipStream_t>(stream), g, items);
   }
-  if (nld > 0) return launch_group(ldp, nld, false, bm, s);
-  return VQA_OK;
+  return check_launch("grouped_gemm");
 }
 
 extern "C" int vqa_grouped_epilogue(const VqaEpilogueJob* jobs, int n, vqa_stream_t stream) {

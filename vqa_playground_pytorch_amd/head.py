@@ -83,10 +83,8 @@ class Phase:
     # fewer than MIN_ITEMS items the parts are shortened until it has (256 CUs x 4 resident workgroups want >= ~2 per CU).
     # A product that ends up in ONE part and is the only contribution to its result is finished inside the GEMM kernel
     # (direct output: bias / activation / gate / dropout on the accumulators) and needs neither slab nor epilogue job.
-    # VQA_GROUPED_ENGINE (rt | lds), VQA_GROUPED_ITEMS / VQA_GROUPED_PART / VQA_GROUPED_BM (LDS form's tile rows): knobs.
-    ENGINE = "lds" if os.environ.get("VQA_GROUPED_ENGINE", "rt").startswith("l") else "rt"   # (the library reads the same knob)
-    # rt form: an item is ONE wave (1024 SIMDs want >= 1 each); LDS form: an item is a 4-wave workgroup
-    MIN_ITEMS = int(os.environ.get("VQA_GROUPED_ITEMS", "1024" if ENGINE == "rt" else "512"))
+    # VQA_GROUPED_ITEMS / VQA_GROUPED_PART / VQA_GROUPED_BM (tile rows 64 | 128, read by the library): measurement knobs.
+    MIN_ITEMS = int(os.environ.get("VQA_GROUPED_ITEMS", "512"))
     MAX_PART = int(os.environ.get("VQA_GROUPED_PART", "640"))
     TILE_M = 128 if os.environ.get("VQA_GROUPED_BM") == "128" else 64
     DIRECT = os.environ.get("VQA_GROUPED_DIRECT", "1") == "1"
@@ -111,13 +109,10 @@ class Phase:
 
     def _size(self):
         probs = [(t, p) for t in self.targets for p in t.problems]
-        if self.ENGINE == "rt":      # 64 x 80 (NT) / 64 x 64 (NN, TN) tiles, one wave each
-            tiles = lambda t, p: math.ceil(t.M / 64) * math.ceil(t.N / (80 if p["form"] == NT else 64))  # noqa: E731
-        else:
-            tiles = lambda t, p: math.ceil(t.M / self.TILE_M) * math.ceil(t.N / 64)  # noqa: E731
+        tiles = lambda t: math.ceil(t.M / self.TILE_M) * math.ceil(t.N / 64)  # noqa: E731
         part = self.MAX_PART
         while True:
-            items = sum(tiles(t, p) * math.ceil(p["K"] / part) for t, p in probs)
+            items = sum(tiles(t) * math.ceil(p["K"] / part) for t, p in probs)
             if items >= self.MIN_ITEMS or part <= 128:
                 break
             part = max(128, part - 64)
