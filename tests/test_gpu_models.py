@@ -94,12 +94,12 @@ def test_cor2_matches_reference_golden(golden_dir, mode, k4_form, monkeypatch):
     check_grads(model, gold)
 
 
-@pytest.mark.parametrize("head_form", ["grouped", "legacy"])
+@pytest.mark.parametrize("head_form", ["auto", "grouped", "legacy"])
 def test_cor2_intermediates_match_reference_golden(golden_dir, head_form, monkeypatch):
-    """Module outputs captured by forward hooks.  With the grouped head (default) fusion_final runs inside a phase
+    """Module outputs captured by forward hooks.  With the grouped head (auto: CoR2's default) fusion_final runs inside a phase
     (head.VectorFusion): the module itself is not called, so its hook only fires with the legacy head."""
     from vqa_playground_pytorch_amd import head
-    monkeypatch.setattr(head, "ENABLED", head_form == "grouped")
+    monkeypatch.setattr(head, "MODE", head_form)
     gold = np.load(os.path.join(golden_dir, "cor2_b4.npz"))
     model = build("cor2", 2000)
     caps = {}
@@ -154,19 +154,20 @@ RTOL_EDGE_MAX = 1e-1   # ... and its max-abs error on the tensor's own scale: a 
 #                        row of a glimpse layer's gradient by that sample's whole contribution (measured: 1.8e-2 of the scale
 #                        for a single sample, 3.9e-2 over ODA's 149 knife-edge samples of this batch)
 VARIANTS = [("cor2", 2000, "default"), ("cor2", 2000, "pairwise"), ("cor2", 2000, "k4_engine"), ("cor2", 2000, "legacy_head"),
-            ("oda", 3000, "default"), ("oda", 3000, "legacy_head")]
+            ("cor2", 2000, "grouped_head"), ("oda", 3000, "default"), ("oda", 3000, "grouped_head")]
 _oracle_cache = {}
 
 
 def build_variant(cls, nans, variant, monkeypatch):
     """default = what bench.py times; pairwise = relation_mode 0 (the relation tensor built from every (i,j) term);
-    k4_engine = the Mutan fusion in its R-GEMM form on the LDS tile engine (VQA_K4_FORM=engine); legacy_head = the
-    [B,.]-sized layers on library GEMMs + epilogue kernels instead of the grouped phases (VQA_HEAD=legacy)."""
+    k4_engine = the Mutan fusion in its R-GEMM form on the LDS tile engine (VQA_K4_FORM=engine); legacy_head / grouped_head =
+    the [B,.]-sized layers all on library GEMMs + epilogue kernels / all as grouped phases (VQA_HEAD=legacy / grouped; the
+    default, auto, groups CoR2's phases except the glimpse projections and keeps ODA on the library)."""
     from vqa_playground_pytorch_amd import head, ops
     if variant == "k4_engine":
         monkeypatch.setattr(ops, "_K4_FORM", "engine")
-    if variant == "legacy_head":
-        monkeypatch.setattr(head, "ENABLED", False)
+    if variant in ("legacy_head", "grouped_head"):
+        monkeypatch.setattr(head, "MODE", variant.split("_")[0])
     return build(cls, nans, **({"relation_mode": 0} if variant == "pairwise" else {}))
 
 

@@ -135,7 +135,7 @@ class Model(nn.Module):
                 and all(m.af == ("sigmoid" if i >= 4 else "relu") for i, m in enumerate(mods))
                 and all(m.p == mods[0].p for m in mods) and self.linear_classif.af in (None, "")
                 and self.att1.grouped_ok(q_feature) and self.att2.grouped_ok(q_feature)
-                and head.supported(q_feature.size(1), self.compress_q.out_features, self.expand_q_1.out_features,
+                and head.supported("cor2", q_feature.size(1), self.compress_q.out_features, self.expand_q_1.out_features,
                                    self.fusion_vq1.hidden_dim, self.fusion_final.hidden_dim, self.fusion_final.input_dim1,
                                    self.att1.att_dim, self.num_classes))
 

@@ -24,13 +24,15 @@
 // K split; a phase's products together can (a few hundred 64x64 tiles x 2-8 splits), and the 2-6 launch-floor kernels
 // that used to surround each library GEMM (dropout, bias + activation, activation gradient + column sums, slices, adds)
 // become arithmetic in the one epilogue launch.
+#include <cstring>
+
 #include "gemm_f32_mfma.hpp"
 
 namespace vqa {
 
 constexpr int kGMaxProbs = VQA_GROUPED_MAX;
 constexpr int kGMaxGemms = VQA_GROUPED_GEMM_MAX;
-constexpr int kGBN = 64, kGBK = 16, kGPF = 2;   // tile rows BM: 64 (default) or 128, one value per launch
+constexpr int kGBN = 64;   // tile rows BM: 64 (default) or 128; K step BK x register sets PF: VQA_GROUPED_PIPE; one value per launch
 
 struct GProbs {
   VqaGemmProblem p[kGMaxGemms];
@@ -90,7 +92,7 @@ struct SrcMC1 {  // X[k][mn], MN-contiguous rows of stride ld; any alignment, an
   }
 };
 
-template <int BM, bool A_KC, bool B_KC, class SrcA, class SrcB>
+template <int BM, int BK, int PF, bool A_KC, bool B_KC, class SrcA, class SrcB>
 __device__ __forceinline__ void grouped_tile(const VqaGemmProblem& pr, const SrcA& sa, const SrcB& sb, int m0, int n0,
                                              int split, float* smem) {
   constexpr int TM = BM / 64;
@@ -101,7 +103,7 @@ __device__ __forceinline__ void grouped_tile(const VqaGemmProblem& pr, const Src
 #pragma unroll
   for (int i = 0; i < TM; ++i) colsum[i] = 0.f;
   const bool want_colsum = (pr.colsum != nullptr || pr.colsum_out != nullptr) && n0 == 0;   // (wave-uniform; TN forms only)
-  gemm_tile<BM, kGBN, kGBK, kGPF, A_KC, B_KC>(sa, sb, m0, n0, k_begin, k_end, smem, acc, want_colsum ? colsum : nullptr);
+  gemm_tile<BM, kGBN, BK, PF, A_KC, B_KC>(sa, sb, m0, n0, k_begin, k_end, smem, acc, want_colsum ? colsum : nullptr);
   const AccCoord<BM, kGBN> cc(m0, n0);
   const int col = cc.col(0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -154,7 +156,7 @@ __device__ __forceinline__ void grouped_tile(const VqaGemmProblem& pr, const Src
   }
 }
 
-template <int BM>
+template <int BM, int BK, int PF>
 __global__ __launch_bounds__(kGemmThreads, BM == 64 ? 4 : 2) void grouped_gemm_kernel(GProbs g_arg, int items) {
   const GProbs& g = kernarg_table<GProbs>();
   extern __shared__ __attribute__((aligned(16))) float smem_g[];
@@ -168,15 +170,15 @@ __global__ __launch_bounds__(kGemmThreads, BM == 64 ? 4 : 2) void grouped_gemm_k
   const int split = local / (tiles_m * tiles_n), t = local % (tiles_m * tiles_n);
   const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * kGBN;
   if (pr.form == 0) {          // NT: A [M,K] rows K-contiguous, B [N,K] rows K-contiguous
-    grouped_tile<BM, true, true>(pr, SrcKC{pr.A, pr.lda, pr.M, pr.Ka}, SrcKC{pr.B, pr.ldb, pr.N, pr.Kb}, m0, n0, split, smem_g);
+    grouped_tile<BM, BK, PF, true, true>(pr, SrcKC{pr.A, pr.lda, pr.M, pr.Ka}, SrcKC{pr.B, pr.ldb, pr.N, pr.Kb}, m0, n0, split, smem_g);
   } else if (pr.form == 1) {   // NN: A [M,K] rows K-contiguous, B [K,N] rows N-contiguous
-    grouped_tile<BM, true, false>(pr, SrcKC{pr.A, pr.lda, pr.M, pr.Ka}, SrcMC{pr.B, pr.ldb, pr.Nb, pr.Kb}, m0, n0, split, smem_g);
+    grouped_tile<BM, BK, PF, true, false>(pr, SrcKC{pr.A, pr.lda, pr.M, pr.Ka}, SrcMC{pr.B, pr.ldb, pr.Nb, pr.Kb}, m0, n0, split, smem_g);
   } else if (pr.form == 2) {   // TN: A [K,M] rows M-contiguous, B [K,N] rows N-contiguous
-    grouped_tile<BM, false, false>(pr, SrcMC{pr.A, pr.lda, pr.Ma, pr.Ka}, SrcMC{pr.B, pr.ldb, pr.Nb, pr.Kb}, m0, n0, split, smem_g);
+    grouped_tile<BM, BK, PF, false, false>(pr, SrcMC{pr.A, pr.lda, pr.Ma, pr.Ka}, SrcMC{pr.B, pr.ldb, pr.Nb, pr.Kb}, m0, n0, split, smem_g);
   } else if (pr.form == 3) {   // NN with a 4-byte aligned A
-    grouped_tile<BM, true, false>(pr, SrcKC1{pr.A, pr.lda, pr.M, pr.Ka}, SrcMC{pr.B, pr.ldb, pr.Nb, pr.Kb}, m0, n0, split, smem_g);
+    grouped_tile<BM, BK, PF, true, false>(pr, SrcKC1{pr.A, pr.lda, pr.M, pr.Ka}, SrcMC{pr.B, pr.ldb, pr.Nb, pr.Kb}, m0, n0, split, smem_g);
   } else {                     // TN with a 4-byte aligned A
-    grouped_tile<BM, false, false>(pr, SrcMC1{pr.A, pr.lda, pr.Ma, pr.Ka}, SrcMC{pr.B, pr.ldb, pr.Nb, pr.Kb}, m0, n0, split, smem_g);
+    grouped_tile<BM, BK, PF, false, false>(pr, SrcMC1{pr.A, pr.lda, pr.Ma, pr.Ka}, SrcMC{pr.B, pr.ldb, pr.Nb, pr.Kb}, m0, n0, split, smem_g);
   }
 }
 
@@ -358,13 +360,22 @@ extern "C" int vqa_grouped_gemm(const VqaGemmProblem* problems, int n, vqa_strea
   int items = 0;
   const char* tile = vqa::option("VQA_GROUPED_BM");     // tile rows: 64 (default) or 128
   const int bm = (tile != nullptr && std::atoi(tile) == 128) ? 128 : 64;
+  // K step x register sets in flight ("16x2" default, "16x3", "32x2", "32x3"): a global load has PF stages of BK/2 MFMAs per
+  // wave to land; 64-row tiles only
+  const char* pipe = vqa::option("VQA_GROUPED_PIPE");
+  int bk = 16, pf = 2;
+  if (pipe != nullptr && bm == 64) {
+    if (std::strcmp(pipe, "16x3") == 0) pf = 3;
+    else if (std::strcmp(pipe, "32x2") == 0) bk = 32;
+    else if (std::strcmp(pipe, "32x3") == 0) bk = 32, pf = 3;
+  }
   for (int i = 0; i < n; ++i) {
     VqaGemmProblem p = problems[i];
     VQA_REQUIRE(p.A && p.B && (p.slab || p.out), VQA_E_BADARG, "grouped_gemm[%d]: null pointer", i);
     VQA_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0 && p.form >= 0 && p.form <= 4, VQA_E_BADARG,
                 "grouped_gemm[%d]: bad sizes M=%d N=%d K=%d form=%d", i, p.M, p.N, p.K, p.form);
-    VQA_REQUIRE(p.ksplit > 0 && p.ksplit % kGBK == 0 && p.slab_base >= 0 && (p.out != nullptr || p.slab_stride >= (long long)p.M * p.N),
-                VQA_E_BADARG, "grouped_gemm[%d]: ksplit %d must be a positive multiple of %d, slab_stride >= M*N", i, p.ksplit, kGBK);
+    VQA_REQUIRE(p.ksplit > 0 && p.ksplit % bk == 0 && p.slab_base >= 0 && (p.out != nullptr || p.slab_stride >= (long long)p.M * p.N),
+                VQA_E_BADARG, "grouped_gemm[%d]: ksplit %d must be a positive multiple of %d, slab_stride >= M*N", i, p.ksplit, bk);
     if (p.out != nullptr) {
       VQA_REQUIRE(p.ksplit >= p.K, VQA_E_BADARG, "grouped_gemm[%d]: a direct output needs the contraction in one part", i);
       VQA_REQUIRE(p.ldo >= p.N && p.act >= 0 && p.act <= 2 && p.gate >= 0 && p.gate <= 2 && (p.gate == 0 || p.gate_y != nullptr) &&
@@ -396,13 +407,15 @@ extern "C" int vqa_grouped_gemm(const VqaGemmProblem* problems, int n, vqa_strea
     items += (int)tiles;
   }
   g.first[n] = items;
-  if (bm == 128) {
-    const size_t lds = GemmTile<128, kGBN, kGBK, true, true>::kSmemBytes;   // the largest of the three forms
-    hipLaunchKernelGGL(grouped_gemm_kernel<128>, dim3(items), dim3(kGemmThreads), lds, static_cast<hipStream_t>(stream), g, items);
-  } else {
-    const size_t lds = GemmTile<64, kGBN, kGBK, true, true>::kSmemBytes;
-    hipLaunchKernelGGL(grouped_gemm_kernel<64>, dim3(items), dim3(kGemmThreads), lds, static_cast<hipStream_t>(stream), g, items);
-  }
+  const auto launch = [&](auto kernel, size_t lds) {
+    hipLaunchKernelGGL(kernel, dim3(items), dim3(kGemmThreads), lds, static_cast<hipStream_t>(stream), g, items);
+  };
+  // LDS: the largest of the three operand forms
+  if (bm == 128) launch(grouped_gemm_kernel<128, 16, 2>, GemmTile<128, kGBN, 16, true, true>::kSmemBytes);
+  else if (bk == 16 && pf == 2) launch(grouped_gemm_kernel<64, 16, 2>, GemmTile<64, kGBN, 16, true, true>::kSmemBytes);
+  else if (bk == 16) launch(grouped_gemm_kernel<64, 16, 3>, GemmTile<64, kGBN, 16, true, true>::kSmemBytes);
+  else if (pf == 2) launch(grouped_gemm_kernel<64, 32, 2>, GemmTile<64, kGBN, 32, true, true>::kSmemBytes);
+  else launch(grouped_gemm_kernel<64, 32, 3>, GemmTile<64, kGBN, 32, true, true>::kSmemBytes);
   return check_launch("grouped_gemm");
 }
 

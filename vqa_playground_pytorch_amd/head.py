@@ -54,7 +54,17 @@ NT, NN, TN, NN_A4, TN_A4 = 0, 1, 2, 3, 4
 EPI_SUM, EPI_LINEAR, EPI_RANK_PRODUCT, EPI_GRAD, EPI_RANK_PRODUCT_BWD = 0, 1, 2, 3, 4
 ACT = {None: 0, "": 0, "relu": 1, "sigmoid": 2}
 
-ENABLED = os.environ.get("VQA_HEAD", "grouped") != "legacy"
+# VQA_HEAD: which of a model's [B,.]-sized layers run as grouped phases.
+#   auto (default)  what measured fastest per model on one MI355X at B = 512 (profiles/): CoR2 runs its
+#                   question / gate / rank-factor / fusion / classifier phases grouped (4-10 products per launch) and its
+#                   glimpse projections as the one batched library GEMM (155-wide blocks: odd widths force 4-byte operand
+#                   loads and three 64-column tiles for 155 columns); ODA, whose phases hold one or two products each (no
+#                   grouping to gain, a split-K epilogue to pay), keeps library GEMMs + the per-layer epilogue kernels
+#   grouped         every phase of both models grouped (glimpses included)
+#   legacy          library GEMMs + per-layer epilogue kernels everywhere
+MODE = os.environ.get("VQA_HEAD", "auto")
+if MODE not in ("auto", "grouped", "legacy"):
+    raise ValueError("VQA_HEAD must be auto, grouped or legacy (got %r)" % MODE)
 _mask_spy = None      # tests: callable(site, rows, cols, p, seed) told about every dropout mask an epilogue applies
 
 
@@ -83,11 +93,13 @@ class Phase:
     # fewer than MIN_ITEMS items the parts are shortened until it has (256 CUs x 4 resident workgroups want >= ~2 per CU).
     # A product that ends up in ONE part and is the only contribution to its result is finished inside the GEMM kernel
     # (direct output: bias / activation / gate / dropout on the accumulators) and needs neither slab nor epilogue job.
-    # VQA_GROUPED_ITEMS / VQA_GROUPED_PART / VQA_GROUPED_BM (tile rows 64 | 128, read by the library): measurement knobs.
+    # VQA_GROUPED_ITEMS / VQA_GROUPED_PART / VQA_GROUPED_BM (tile rows 64 | 128) / VQA_GROUPED_PIPE (K step x register sets
+    # in flight, "16x2" | "16x3" | "32x2" | "32x3"; the last two read by the library as well): measurement knobs.
     MIN_ITEMS = int(os.environ.get("VQA_GROUPED_ITEMS", "512"))
     MAX_PART = int(os.environ.get("VQA_GROUPED_PART", "640"))
     TILE_M = 128 if os.environ.get("VQA_GROUPED_BM") == "128" else 64
     DIRECT = os.environ.get("VQA_GROUPED_DIRECT", "1") == "1"
+    STEP_K = 32 if os.environ.get("VQA_GROUPED_PIPE", "").startswith("32") and TILE_M == 64 else 16
 
     def __init__(self, device, name):
         self.device, self.name = device, name
@@ -118,7 +130,7 @@ class Phase:
             part = max(128, part - 64)
         for t, p in probs:
             splits = math.ceil(p["K"] / part)
-            p["ksplit"] = math.ceil(p["K"] / splits / 16) * 16
+            p["ksplit"] = math.ceil(p["K"] / splits / self.STEP_K) * self.STEP_K
             p["splits"] = math.ceil(p["K"] / p["ksplit"])
         return probs
 
@@ -238,9 +250,16 @@ def _f32c(*tensors):
             raise _lib.VqaLibraryError("grouped head: tensors must be contiguous fp32 GPU tensors (no CPU fallback)")
 
 
-def supported(*dims):
-    """Every feature dimension that ends up as the contiguous axis of an 8-byte-loaded operand is even."""
-    return ENABLED and all(int(d) % 2 == 0 for d in dims)
+def supported(model, *dims):
+    """Does `model` ("cor2" | "oda") run its [B,.]-sized layers as grouped phases under VQA_HEAD?  Every feature
+    dimension that ends up as the contiguous axis of an 8-byte-loaded operand must be even."""
+    on = MODE == "grouped" or (MODE == "auto" and model == "cor2")
+    return on and all(int(d) % 2 == 0 for d in dims)
+
+
+def glimpses_grouped():
+    """The per-glimpse projections as a grouped phase (VQA_HEAD=grouped) or as one batched library GEMM (auto)."""
+    return MODE == "grouped"
 
 
 # ------------------------------------------------------------------------------------------------ phase 1

@@ -358,10 +358,11 @@ class MyATT(nn.Module):
         """cat_g MyLinear_g(pooled[:, g, :]) (config/CoR2.py:143-147).  The G layers have one shape, so they run as ONE
         batched GEMM over the [B,G,D] tensor (one dropout draw over all of it, one bias add, one activation) instead of
         G x {slice, dropout, GEMM, activation} and, backward, G slice gradients that autograd zero-fills and adds.
-        grouped: as a phase of the grouped head (head.GlimpseProjections) -- ONLY when the consumer of the result is the
-        head's fusion phase, which hands the gradient back gated by the relu."""
-        if grouped:
-            from . import head
+        grouped: the caller runs the grouped head; under VQA_HEAD=grouped the projections are a phase of it
+        (head.GlimpseProjections) -- ONLY when the consumer of the result is the head's fusion phase, which hands the
+        gradient back gated by the relu (gating it again, as the batched form does, changes nothing)."""
+        from . import head
+        if grouped and head.glimpses_grouped():
             mods = list(self.list_linear_v_fusion)
             pd = self.glimpse_dropout()
             if pd and not predropped:

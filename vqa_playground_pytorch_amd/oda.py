@@ -52,7 +52,7 @@ class Model(nn.Module):
         return (cut is None and q_feature.is_cuda and q_feature.dtype == torch.float32 and not q_feature.requires_grad
                 and self.compress_q.af == "relu" and self.linear_q.af == "relu" and self.compress_q.p == self.linear_q.p
                 and self.linear_classif.af in (None, "") and self.att.grouped_ok(q_feature)
-                and head.supported(q_feature.size(1), self.compress_q.out_features, self.fusion_final.hidden_dim,
+                and head.supported("oda", q_feature.size(1), self.compress_q.out_features, self.fusion_final.hidden_dim,
                                    self.fusion_final.input_dim1, self.num_classes))
 
     def late_parameters(self):
