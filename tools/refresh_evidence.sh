@@ -26,6 +26,8 @@ cd "$ROOT"
 run() { name=$1; shift; timeout 900 python3 bench.py "$@" > "$OUT/$name.log" 2>&1; tail -1 "$OUT/$name.log" > "$OUT/$name.json"; }
 run bench_b512 --steps 20 --warmup 5
 VQA_HEAD=legacy run bench_b512_legacy_head --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records
+VQA_HEAD=grouped run bench_b512_grouped_head --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records
+VQA_HEAD=grouped run bench_oda_b512_grouped_head --model oda --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records
 run bench_b512_eager --steps 20 --warmup 5 --no-graph --no-cpu-baseline --no-rotate --no-sub-records
 run bench_b512_pairwise --no-sub-records --steps 20 --warmup 5 --relation-mode 0 --no-cpu-baseline
 run bench_f32_n100_b128 --no-sub-records --regions 100 --batch 128 --steps 20 --warmup 5 --no-cpu-baseline
