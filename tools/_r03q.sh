@@ -1,0 +1,3 @@
+mkdir -p gpurun_out/r03q
+timeout 900 python -m pytest tests/test_gpu_bf16.py -q 2>&1 | tail -4 > gpurun_out/r03q/bf16_tests.txt
+for i in 1 2; do timeout 300 python bench.py --dtype bf16 --regions 100 --batch 128 --no-sub-records --no-cpu-baseline > gpurun_out/r03q/b_bf16_$i.json 2> gpurun_out/r03q/b_bf16.err; done

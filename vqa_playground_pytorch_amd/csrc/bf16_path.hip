@@ -198,7 +198,14 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 
 static int tn_splits(int Kdim, int N1, int N2, BfTileChoice t) {
   const long tiles = (long)((N1 + t.bm - 1) / t.bm) * ((N2 + t.bn - 1) / t.bn);
-  long s = (512 + tiles - 1) / tiles;
+  // Workgroups a launch aims for.  The 128x128 transposed-read tile holds 80 KB of LDS: ONE workgroup per CU, so the split
+  // count is the largest that keeps the grid within one round of the 256 CUs (measured at K = 12800, B = 128 x 100 regions:
+  // [320 x 2048] 48.1 -> 41.4 us, [1024 x 320] 28.1 -> 21.8 us against the former "at least 512 workgroups", and the slab
+  // reduction behind it shrinks with the split count); the smaller tiles fit two or more per CU.  VQA_BF16_TN_ITEMS overrides.
+  const char* opt = vqa::option("VQA_BF16_TN_ITEMS");
+  const bool one_per_cu = t.bm == 128 && t.bn == 128;
+  const long want = opt != nullptr && std::atol(opt) > 0 ? std::atol(opt) : (one_per_cu ? 256 : 512);
+  long s = one_per_cu ? want / tiles : (want + tiles - 1) / tiles;
   const long max_by_rows = (Kdim + 511) / 512;  // keep >= 512 rows (8 stages) per split
   if (s > max_by_rows) s = max_by_rows;
   if (s > 64) s = 64;
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(kBfThreads) void bilinear_fwd_bf16_kernel(const bf1
                                                                        const float* __restrict__ b1,
                                                                        const float* __restrict__ h2, bf16* __restrict__ out,
                                                                        bf16* __restrict__ h1, int M, int N, int L, int H,
-                                                                       int R, int tiles_n) {
+                                                                       int R, int tiles_n, int Hin) {
   using T = BfTile<BM, BN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* h2_s = reinterpret_cast<float*>(smem);                  // [samples in tile][BN], overlays the staging ring
@@ -321,8 +328,10 @@ __global__ __launch_bounds__(kBfThreads) void bilinear_fwd_bf16_kernel(const bf1
     f32x16 acc[T::TM][T::TN];
     bf_zero_acc(acc);
     gemm_bf16_nt_tile<BM, BN>(x, L, M, w1 + (size_t)r * H * L, L, H, m0, n0, L, smem, acc);
-    for (int t = threadIdx.x; t < ns * BN; t += kBfThreads)
-      h2_s[t] = h2[((size_t)(b0 + t / BN) * R + r) * H + n0 + (t % BN)];
+    for (int t = threadIdx.x; t < ns * BN; t += kBfThreads) {   // h2 is the unpadded [B,R,Hin]: the pad columns multiply by 0
+      const int col = n0 + (t % BN);
+      h2_s[t] = col < Hin ? h2[((size_t)(b0 + t / BN) * R + r) * Hin + col] : 0.f;
+    }
     __syncthreads();
     // epilogue of rank r: h1_r = acc + b1_r (kept in acc), total += h1_r * h2[b(row), r, :]
 #pragma unroll
@@ -354,7 +363,7 @@ template <int SL>
 __global__ __launch_bounds__(256) void bilinear_bwd_prep_bf16_kernel(const bf16* __restrict__ g, const bf16* __restrict__ h1,
                                                                      const float* __restrict__ h2, bf16* __restrict__ gs,
                                                                      float* __restrict__ dh2, float* __restrict__ gsum,
-                                                                     int N, int H, int R) {
+                                                                     int N, int H, int R, int Hin) {
   constexpr int COLS = 256 / SL;
   __shared__ float4 part[SL - 1][kBfMaxR + 1][COLS];
   const int b = blockIdx.y;
@@ -365,7 +374,12 @@ __global__ __launch_bounds__(256) void bilinear_bwd_prep_bf16_kernel(const bf16*
 #pragma unroll
   for (int r = 0; r < kBfMaxR; ++r) {
     acc[r] = z;
-    q[r] = r < R ? ld4(h2 + ((size_t)b * R + r) * H + h) : z;
+    if (r < R) {   // h2 / dh2 are the unpadded [B,R,Hin]
+      const float* hr = h2 + ((size_t)b * R + r) * Hin;
+      q[r] = make_float4(h < Hin ? hr[h] : 0.f, h + 1 < Hin ? hr[h + 1] : 0.f, h + 2 < Hin ? hr[h + 2] : 0.f, h + 3 < Hin ? hr[h + 3] : 0.f);
+    } else {
+      q[r] = z;
+    }
   }
 #pragma unroll 4
   for (int n = slice; n < N; n += SL) {
@@ -394,11 +408,98 @@ __global__ __launch_bounds__(256) void bilinear_bwd_prep_bf16_kernel(const bf16*
       if (r < R) {
         float4 t = acc[r];
         for (int s = 0; s < SL - 1; ++s) t = add4(t, part[s][r][c]);
-        st4(dh2 + ((size_t)b * R + r) * H + h, t);
+        float* dr = dh2 + ((size_t)b * R + r) * Hin;
+        if (h < Hin) dr[h] = t.x;
+        if (h + 1 < Hin) dr[h + 1] = t.y;
+        if (h + 2 < Hin) dr[h + 2] = t.z;
+        if (h + 3 < Hin) dr[h + 3] = t.w;
       }
     }
     for (int s = 0; s < SL - 1; ++s) gt = add4(gt, part[s][kBfMaxR][c]);
     st4(gsum + (size_t)b * H + h, gt);
+  }
+}
+
+// The same for a compile-time rank count (1..5: every fusion of the models) with 16-byte accesses: 256 lanes = 16 column
+// groups of 8 (128 columns) x 16 region slices, grid (H/128, B); a lane's loads of one region are independent of the next
+// region's, so the unrolled loop keeps ~3 (1 + RT) x 16 B x 4 per lane in flight.  (The 8-byte form above moved 65 MB in
+// 30 us at B = 128, N = 100 -- 2.2 TB/s.)
+template <int RT>
+__global__ __launch_bounds__(256) void bilinear_bwd_prep8_bf16_kernel(const bf16* __restrict__ g, const bf16* __restrict__ h1,
+                                                                      const float* __restrict__ h2, bf16* __restrict__ gs,
+                                                                      float* __restrict__ dh2, float* __restrict__ gsum,
+                                                                      int N, int H, int Hin) {
+  constexpr int SL = 16, COLS = 16;
+  __shared__ float part[SL - 1][RT + 1][COLS][8];
+  const int b = blockIdx.y;
+  const int c = threadIdx.x % COLS, slice = threadIdx.x / COLS;
+  const int h = (blockIdx.x * COLS + c) * 8;  // < H: H % 256 == 0
+  float q[RT][8], acc[RT][8], gt[8];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    const float* hr = h2 + ((size_t)b * RT + r) * Hin;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      q[r][j] = h + j < Hin ? hr[h + j] : 0.f;
+      acc[r][j] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) gt[j] = 0.f;
+  const auto unpack = [](u32x4 w, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = bf16_lo(w[i]);
+      v[2 * i + 1] = bf16_hi(w[i]);
+    }
+  };
+#pragma unroll 4
+  for (int n = slice; n < N; n += SL) {
+    const size_t m = (size_t)b * N + n;
+    float gv[8];
+    unpack(*reinterpret_cast<const u32x4*>(g + m * H + h), gv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gt[j] += gv[j];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      float hv[8];
+      unpack(*reinterpret_cast<const u32x4*>(h1 + (m * RT + r) * H + h), hv);
+      u32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[r][2 * i] = fmaf(gv[2 * i], hv[2 * i], acc[r][2 * i]);
+        acc[r][2 * i + 1] = fmaf(gv[2 * i + 1], hv[2 * i + 1], acc[r][2 * i + 1]);
+        o[i] = pack_bf16(gv[2 * i] * q[r][2 * i], gv[2 * i + 1] * q[r][2 * i + 1]);
+      }
+      *reinterpret_cast<u32x4*>(gs + (m * RT + r) * H + h) = o;
+    }
+  }
+  if (slice > 0) {
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part[slice - 1][r][c][j] = acc[r][j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[slice - 1][RT][c][j] = gt[j];
+  }
+  __syncthreads();
+  if (slice == 0) {
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      float* dr = dh2 + ((size_t)b * RT + r) * Hin;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = acc[r][j];
+        for (int s = 0; s < SL - 1; ++s) t += part[s][r][c][j];
+        if (h + j < Hin) dr[h + j] = t;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = gt[j];
+      for (int s = 0; s < SL - 1; ++s) t += part[s][RT][c][j];
+      gsum[(size_t)b * H + h + j] = t;
+    }
   }
 }
 
@@ -411,15 +512,16 @@ __global__ __launch_bounds__(256) void bilinear_db_bf16_kernel(const float* __re
   const int c = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + c;  // < R*H: H % 256 == 0
   const int h = e % H;
+  const int eo = (e / H) * Hout + min(h, Hout - 1);   // h2 is the unpadded [B,R,Hout] (pad columns: a clamped read, not stored)
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int b = slice;
   for (; b + 12 < B; b += 16) {
-    a0 = fmaf(h2[(size_t)b * R * H + e], gsum[(size_t)b * H + h], a0);
-    a1 = fmaf(h2[(size_t)(b + 4) * R * H + e], gsum[(size_t)(b + 4) * H + h], a1);
-    a2 = fmaf(h2[(size_t)(b + 8) * R * H + e], gsum[(size_t)(b + 8) * H + h], a2);
-    a3 = fmaf(h2[(size_t)(b + 12) * R * H + e], gsum[(size_t)(b + 12) * H + h], a3);
+    a0 = fmaf(h2[(size_t)b * R * Hout + eo], gsum[(size_t)b * H + h], a0);
+    a1 = fmaf(h2[(size_t)(b + 4) * R * Hout + eo], gsum[(size_t)(b + 4) * H + h], a1);
+    a2 = fmaf(h2[(size_t)(b + 8) * R * Hout + eo], gsum[(size_t)(b + 8) * H + h], a2);
+    a3 = fmaf(h2[(size_t)(b + 12) * R * Hout + eo], gsum[(size_t)(b + 12) * H + h], a3);
   }
-  for (; b < B; b += 4) a0 = fmaf(h2[(size_t)b * R * H + e], gsum[(size_t)b * H + h], a0);
+  for (; b < B; b += 4) a0 = fmaf(h2[(size_t)b * R * Hout + eo], gsum[(size_t)b * H + h], a0);
   const float a = (a0 + a1) + (a2 + a3);
   if (slice > 0) part[slice - 1][c] = a;
   __syncthreads();
@@ -624,10 +726,11 @@ extern "C" int vqa_gemm_bf16_tn_ex(const vqa_bf16_t* a, int lda, const vqa_bf16_
 
 extern "C" int vqa_lowrank_bilinear_fusion_fwd_bf16(const vqa_bf16_t* x, const vqa_bf16_t* w1, const float* b1,
                                                     const float* h2, vqa_bf16_t* out, vqa_bf16_t* h1, int B, int N, int L,
-                                                    int H, int R, vqa_stream_t stream) {
+                                                    int H, int R, int H_in, vqa_stream_t stream) {
   VQA_REQUIRE(x && w1 && b1 && h2 && out, VQA_E_BADARG, "lowrank_bilinear_fusion_fwd_bf16: null pointer");
   int rc = check_k4("lowrank_bilinear_fusion_fwd_bf16", B, N, L, H, R);
   if (rc != VQA_OK) return rc;
+  VQA_REQUIRE(H_in > 0 && H_in <= H, VQA_E_BADARG, "lowrank_bilinear_fusion_fwd_bf16: h2 width %d exceeds the padded H = %d", H_in, H);
   VQA_REQUIRE(aligned(x, 16) && aligned(w1, 16), VQA_E_UNSUPPORTED, "lowrank_bilinear_fusion_fwd_bf16: x/w1 must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int M = B * N;
@@ -640,7 +743,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_fwd_bf16(const vqa_bf16_t* x, const v
     VQA_ENSURE_LDS((bilinear_fwd_bf16_kernel<BM_, BN_>), lds);                                                            \
     hipLaunchKernelGGL((bilinear_fwd_bf16_kernel<BM_, BN_>), dim3(tiles_m * tiles_n), dim3(kBfThreads), lds, s,           \
                        reinterpret_cast<const bf16*>(x), reinterpret_cast<const bf16*>(w1), b1, h2,                       \
-                       reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(h1), M, N, L, H, R, tiles_n);               \
+                       reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(h1), M, N, L, H, R, tiles_n, H_in);         \
   }
   VQA_BF_TILE_SWITCH(t, LAUNCH);
 #undef LAUNCH
@@ -670,8 +773,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd_bf16(const vqa_bf16_t* x, const v
               "lowrank_bilinear_fusion_bwd_bf16: master shape [%d,%d] exceeds the padded one [%d,%d]", H_out, L_out, H, L);
   VQA_REQUIRE(workspace_bytes >= vqa_lowrank_bilinear_fusion_bwd_bf16_workspace_bytes(B, N, L, H, R), VQA_E_BADARG,
               "lowrank_bilinear_fusion_bwd_bf16: workspace of %zu B is too small", workspace_bytes);
-  VQA_REQUIRE(aligned(x, 16) && aligned(g, 16) && aligned(h1, 16) && aligned(h2, 16) && aligned(workspace, 256) &&
-                  aligned(d_h2, 16) && (d_x == nullptr || (aligned(d_x, 16) && aligned(w1t, 16))),
+  VQA_REQUIRE(aligned(x, 16) && aligned(g, 16) && aligned(h1, 16) && aligned(workspace, 256) && (d_x == nullptr || (aligned(d_x, 16) && aligned(w1t, 16))),
               VQA_E_UNSUPPORTED, "lowrank_bilinear_fusion_bwd_bf16: tensors must be 16-byte aligned (workspace 256)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int M = B * N, RH = R * H;
@@ -685,13 +787,27 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd_bf16(const vqa_bf16_t* x, const v
   bf16* gs = reinterpret_cast<bf16*>(ws);
   float* gsum = reinterpret_cast<float*>(ws + k4_gs_bytes(B, N, H, R));
   float* slabs = reinterpret_cast<float*>(ws + k4_gs_bytes(B, N, H, R) + k4_gsum_bytes(B, H));
-  if ((long)B * H < 4 * 65536) {
-    hipLaunchKernelGGL(bilinear_bwd_prep_bf16_kernel<16>, dim3(H / 64, B), dim3(256), 0, s, reinterpret_cast<const bf16*>(g),
-                       reinterpret_cast<const bf16*>(h1), h2, gs, d_h2, gsum, N, H, R);
-  } else {
-    hipLaunchKernelGGL(bilinear_bwd_prep_bf16_kernel<4>, dim3(H / 256, B), dim3(256), 0, s, reinterpret_cast<const bf16*>(g),
-                       reinterpret_cast<const bf16*>(h1), h2, gs, d_h2, gsum, N, H, R);
+  const bf16* gb = reinterpret_cast<const bf16*>(g);
+  const bf16* h1b = reinterpret_cast<const bf16*>(h1);
+#define PREP8(RT_)                                                                                                        \
+  hipLaunchKernelGGL(bilinear_bwd_prep8_bf16_kernel<RT_>, dim3(H / 128, B), dim3(256), 0, s, gb, h1b, h2, gs, d_h2, gsum, \
+                     N, H, H_out)
+  switch (R) {
+    case 1: PREP8(1); break;
+    case 2: PREP8(2); break;
+    case 3: PREP8(3); break;
+    case 4: PREP8(4); break;
+    case 5: PREP8(5); break;
+    default:
+      if ((long)B * H < 4 * 65536) {
+        hipLaunchKernelGGL(bilinear_bwd_prep_bf16_kernel<16>, dim3(H / 64, B), dim3(256), 0, s, gb, h1b, h2, gs, d_h2, gsum, N, H,
+                           R, H_out);
+      } else {
+        hipLaunchKernelGGL(bilinear_bwd_prep_bf16_kernel<4>, dim3(H / 256, B), dim3(256), 0, s, gb, h1b, h2, gs, d_h2, gsum, N, H,
+                           R, H_out);
+      }
   }
+#undef PREP8
   hipLaunchKernelGGL(bilinear_db_bf16_kernel, dim3(RH / 64), dim3(256), 0, s, h2, gsum, db, B, H, R, H_out);
   if (d_x != nullptr) {
     NtExtra ex;

@@ -42,17 +42,23 @@ struct BfTile {
 struct BfNoTransform {
   static constexpr bool kActive = false;
   __device__ __forceinline__ u32x4 operator()(u32x4 v, int, int) const { return v; }
+  __device__ __forceinline__ uint32_t word(int, int) const { return 0u; }
+  __device__ __forceinline__ static u32x4 apply(u32x4 v, uint32_t) { return v; }
 };
 // p = 0.5 dropout of a row-major [rows, ld] tensor in the library's one-bit counter-hash form (common.hpp: keep element e
 // iff bit e & 31 of mask_word32(e >> 5, key) is set).  Only ZEROES the dropped elements: the factor 1/(1-p) = 2 is uniform
-// and is applied to the accumulator by the kernel's epilogue.  ld % 8 == 0, so a chunk's 8 bits sit in one hash word.
+// and is applied to the accumulator by the kernel's epilogue.  ld % 32 == 0, so the 32 columns [32 q, 32 q + 32) of a row
+// sit in one hash word and a chunk's 8 bits in one byte of it.
 struct BfDropHalf {
   static constexpr bool kActive = true;
   uint32_t key;
   uint32_t ld;
-  __device__ __forceinline__ u32x4 operator()(u32x4 v, int row, int col) const {
-    const uint32_t e = (uint32_t)row * ld + (uint32_t)col;
-    const uint32_t bits = mask_word32(e >> 5, key) >> (e & 31u);
+  // the hash word that holds element (row, col)
+  __device__ __forceinline__ uint32_t word(int row, int col) const {
+    return mask_word32(((uint32_t)row * ld + (uint32_t)col) >> 5, key);
+  }
+  // bits: bit i <-> element i of the chunk
+  __device__ __forceinline__ static u32x4 apply(u32x4 v, uint32_t bits) {
     u32x4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -61,7 +67,26 @@ struct BfDropHalf {
     }
     return o;
   }
+  __device__ __forceinline__ u32x4 operator()(u32x4 v, int row, int col) const {
+    return apply(v, word(row, col) >> ((uint32_t)col & 31u));
+  }
 };
+// The hash (two quarter-rate 32-bit multiplies) is what the mask costs.  Both staging layouts give the four lanes of a quad
+// the four 8-column chunks of ONE 32-column group, and a lane's C chunks (C <= 4) are that group in C different rows: lane j of
+// the quad hashes the word of chunk j % C only and the quad exchanges them (DPP quad_perm broadcast) -- one hash per lane and
+// stage instead of C.
+template <int P>
+__device__ __forceinline__ uint32_t bf_quad_bcast(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, P * 0x55, 0xF, 0xF, true);   // quad_perm [P, P, P, P]
+}
+template <int C>
+__device__ __forceinline__ void bf_quad_words(uint32_t own, uint32_t (&w)[C]) {
+  static_assert(C >= 1 && C <= 4, "a quad exchanges at most four words");
+  w[0] = bf_quad_bcast<0>(own);
+  if constexpr (C > 1) w[1] = bf_quad_bcast<1>(own);
+  if constexpr (C > 2) w[2] = bf_quad_bcast<2>(own);
+  if constexpr (C > 3) w[3] = bf_quad_bcast<3>(own);
+}
 
 // MFMA side of one stage: all fragments of LDS stage `base`, then the TM x TN x 4 MFMAs.
 template <int BM, int BN>
@@ -123,9 +148,15 @@ struct NtStager {
   __device__ __forceinline__ void store(const u32x4 (&ra)[T::CA], const u32x4 (&rb)[T::CB], char* base, int step,
                                         const XA& xa) const {
     const int col = min(step, nsteps - 1) * kBfBK + acol0;
+    uint32_t words[T::CA];
+    if constexpr (XA::kActive) {   // lanes 8 i .. 8 i + 3 hold columns [32 q, 32 q + 32) of rows arow0 + 32 p
+      const int pj = (threadIdx.x & 3) % T::CA;
+      bf_quad_words<T::CA>(xa.word(min(arow0 + 32 * pj, a_last), col), words);
+    }
 #pragma unroll
     for (int p = 0; p < T::CA; ++p)
-      *reinterpret_cast<u32x4*>(base + lds_a + p * 32 * kBfPitch) = xa(ra[p], min(arow0 + 32 * p, a_last), col);
+      *reinterpret_cast<u32x4*>(base + lds_a + p * 32 * kBfPitch) =
+          XA::kActive ? XA::apply(ra[p], words[p] >> ((uint32_t)col & 31u)) : ra[p];
 #pragma unroll
     for (int p = 0; p < T::CB; ++p) *reinterpret_cast<u32x4*>(base + lds_b + p * 32 * kBfPitch) = rb[p];
   }
@@ -360,11 +391,19 @@ struct TrStager {
       const int r = row_a(p), c = ((threadIdx.x + kBfThreads * p) % (BM / 8)) * 8;
       *reinterpret_cast<u32x4*>(base + r * T::PA + c * 2) = k0 + r < k_hi ? ra[p] : z;
     }
+    uint32_t words[T::CB];
+    if constexpr (XB::kActive) {
+      // a lane's CB chunks are ONE column chunk (kBfThreads % (BN/8) == 0) in CB rows, and the four lanes of a quad hold the
+      // four chunks of one 32-column group (n0 % 32 == 0, ldb % 32 == 0; a chunk clamped at the matrix edge only feeds output
+      // columns that are not stored)
+      const int pj = (threadIdx.x & 3) % T::CB;
+      bf_quad_words<T::CB>(xb.word(min(k0 + row_b(pj), k_hi - 1), cb[0]), words);
+    }
 #pragma unroll
     for (int p = 0; p < T::CB; ++p) {
       const int r = row_b(p), c = ((threadIdx.x + kBfThreads * p) % (BN / 8)) * 8;
       u32x4 v = k0 + r < k_hi ? rb[p] : z;
-      if constexpr (XB::kActive) v = xb(v, min(k0 + r, k_hi - 1), cb[p]);
+      if constexpr (XB::kActive) v = XB::apply(v, words[p] >> ((uint32_t)cb[0] & 31u));
       *reinterpret_cast<u32x4*>(base + kBfBK * T::PA + r * T::PB + c * 2) = v;
     }
   }

@@ -776,15 +776,14 @@ class LowRankBilinearFusionBf16(torch.autograd.Function):
                 pack_bf16(w1[r], w1p, 0, Lp, 1, zero_fill=False, offset=r * Hp * Lp)
                 b1p[r, :H].copy_(b1[r])
             w1t = None
-        h2p = torch.nn.functional.pad(h2, (0, Hp - H)) if Hp != H else h2
         need_bwd = any(ctx.needs_input_grad)
         out = torch.empty(*lead, Hp, device=dev, dtype=torch.bfloat16)
         h1 = torch.empty(B * N, R, Hp, device=dev, dtype=torch.bfloat16) if need_bwd else None
         _launch("lowrank_bilinear_fusion_fwd_bf16", (B, N, Lp, Hp, R, need_bwd),
-                _lib.lib().vqa_lowrank_bilinear_fusion_fwd_bf16, _p(x), _p(w1p), _p(b1p), _p(h2p), _p(out), _p(h1),
-                B, N, Lp, Hp, R)
+                _lib.lib().vqa_lowrank_bilinear_fusion_fwd_bf16, _p(x), _p(w1p), _p(b1p), _p(h2), _p(out), _p(h1),
+                B, N, Lp, Hp, R, H)
         if need_bwd:
-            ctx.save_for_backward(x, h2p, h1, *w1)
+            ctx.save_for_backward(x, h2, h1, *w1)
             ctx.b1 = b1
             ctx.w1t = w1t
         ctx.dims = (B, N, L, Lp, H, Hp, R, bool(gate_dx))
@@ -793,7 +792,7 @@ class LowRankBilinearFusionBf16(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         B, N, L, Lp, H, Hp, R, gate_dx = ctx.dims
-        x, h2p, h1 = ctx.saved_tensors[:3]
+        x, h2, h1 = ctx.saved_tensors[:3]
         w1 = ctx.saved_tensors[3:]
         g = _prep("grad_out", g.to(torch.bfloat16), (torch.bfloat16,))
         dev = x.device
@@ -808,14 +807,14 @@ class LowRankBilinearFusionBf16(torch.autograd.Function):
             d_x = torch.empty_like(x)
         d_w1 = [_grad_like(w) for w in w1]
         d_b1 = [_grad_like(b) for b in ctx.b1]
-        d_h2 = torch.empty(B, R, Hp, device=dev, dtype=torch.float32)
+        d_h2 = torch.empty(B, R, H, device=dev, dtype=torch.float32)
         L_ = _lib.lib()
         ws_bytes = L_.vqa_lowrank_bilinear_fusion_bwd_bf16_workspace_bytes(B, N, Lp, Hp, R)
         ws = torch.empty((ws_bytes + 3) // 4, device=dev, dtype=torch.float32)
         _launch("lowrank_bilinear_fusion_bwd_bf16", (B, N, Lp, Hp, R, d_x is not None),
-                L_.vqa_lowrank_bilinear_fusion_bwd_bf16, _p(x), _p(w1t), _p(h2p), _p(h1), _p(g), _p(d_x), _ptr_array(d_w1),
+                L_.vqa_lowrank_bilinear_fusion_bwd_bf16, _p(x), _p(w1t), _p(h2), _p(h1), _p(g), _p(d_x), _ptr_array(d_w1),
                 _ptr_array(d_b1), _p(d_h2), _p(ws), ws_bytes, B, N, Lp, Hp, R, H, L, int(gate_dx and d_x is not None))
-        return (d_x, d_h2[:, :, :H], None, None, *d_w1, *d_b1)
+        return (d_x, d_h2, None, None, *d_w1, *d_b1)
 
 
 class ObjectDifferenceAttention(torch.autograd.Function):
