@@ -155,10 +155,13 @@ __device__ __forceinline__ uint32_t dpp_u32(uint32_t x) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, true);
 }
 
+// Work units: (feature set, slice of the regions j) -- the logits are sums over both, so any split is exact.  JT slices of NJ
+// regions each (NJ a multiple of 4); wave w of the workgroup takes units w, w + nwaves, ...
 template <bool MASK>
-__global__ __launch_bounds__(256) void oda_fwd_mfma_kernel(const float* __restrict__ vl, const float* __restrict__ ql,
+__global__ __launch_bounds__(512) void oda_fwd_mfma_kernel(const float* __restrict__ vl, const float* __restrict__ ql,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
-                                                           float* __restrict__ logits, DropCfg dc, int N, int L, int G) {
+                                                           float* __restrict__ logits, DropCfg dc, int N, int L, int G,
+                                                           int JT, int NJ) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red_s = reinterpret_cast<float*>(smem);      // [nwaves][4 kOdaIG][4]
   const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
@@ -197,22 +200,26 @@ __global__ __launch_bounds__(256) void oda_fwd_mfma_kernel(const float* __restri
       wg[jj] = rt::ldg4(Wb, wo, so);
     }
   };
-  auto load_set = [&](SetRegs& sr, int ds) {
+  const int nunits = nsets * JT;
+  auto load_set = [&](SetRegs& sr, int u) {
     uint32_t vo, wo;
     int dcl;
     bool dok;
+    const int ds = u / JT;
     set_offsets(ds, vo, wo, dcl, dok);
     sr.qd = ql[(size_t)b * L + dcl];
 #pragma unroll
     for (int ig = 0; ig < kOdaIG; ++ig) sr.ti[ig] = rt::ldg4(Vb, vo + (uint32_t)min(4 * ig + r, N - 1) * (uint32_t)L * 4u, 0u);
-    load_group(sr.tj, sr.wv, vo, wo, 0);
+    load_group(sr.tj, sr.wv, vo, wo, min((u - ds * JT) * NJ, N - 1));
   };
   SetRegs nx;
-  if (wave < nsets) load_set(nx, wave);
-  for (int ds = wave; ds < nsets; ds += nwaves) {
+  if (wave < nunits) load_set(nx, wave);
+  for (int u = wave; u < nunits; u += nwaves) {
     uint32_t vo, wo;
     int dcl;
     bool dok;
+    const int ds = u / JT;
+    const int jlo = (u - ds * JT) * NJ, jhi = min(N, jlo + NJ);
     set_offsets(ds, vo, wo, dcl, dok);
     const float qd = dok ? nx.qd : 0.f;
     float Ti[kOdaIG], tj[4], wv[4];
@@ -223,10 +230,10 @@ __global__ __launch_bounds__(256) void oda_fwd_mfma_kernel(const float* __restri
       tj[jj] = nx.tj[jj];
       wv[jj] = nx.wv[jj];
     }
-    load_set(nx, ds + nwaves);                               // (past the last set: a clamped reload nobody uses)
+    load_set(nx, u + nwaves);                                // (past the last unit: a clamped reload nobody uses)
     const bool gok = dok && r < G;
     const uint32_t cnt_d = (uint32_t)b * (uint32_t)NI * stride + (uint32_t)dcl;   // + j L (+ stride for the second word)
-    for (int j0 = 0; j0 < N; j0 += 4) {
+    for (int j0 = jlo; j0 < jhi; j0 += 4) {
       float tn[4], wn[4];
       load_group(tn, wn, vo, wo, min(j0 + 4, N - 1));
       uint32_t hw0 = 0u, hw1 = 0u;
@@ -873,14 +880,25 @@ static int launch_fwd(const float* vl, const float* ql, const float* w, const fl
     const bool bits = oda_bits_mode(dc, B, N, L);
     if (oda_mfma_ok(dc, B, N, L, G)) {
       const int nsets = (L + 15) / 16;
-      // waves per sample: 4 = one per SIMD (2 x B workgroups of 4 waves spread evenly; five waves -- one feature set less per
-      // wave at L = 310 -- leave the SIMDs of a CU with 3, 3, 2, 2 waves: 56 us against 53)
-      int nw = nsets < 4 ? nsets : 4;
+      // waves per sample: 8 = two per SIMD and workgroup, four per SIMD with the two workgroups a CU holds at B = 512
+      // (the 20 feature sets of L = 310 go 3,3,3,3,2,2,2,2).  Measured on the ODA attention op, forward: 4 waves 54.9 us,
+      // 8 waves 50.8; 5 or 6 waves 63-66 (a CU's 10 / 12 waves do not spread evenly over its SIMDs); slicing the region
+      // axis j as well (units of (set, 12 regions): the same work for every wave) 55.2-69.6 -- every unit pays its own
+      // nine T_i loads and pipeline fill.  The kernel is VALU-issue bound: what helps is an even wave count per SIMD, not
+      // more waves.
+      int nw = nsets < 8 ? (nsets < 4 ? nsets : 4) : 8;
+      int jt = 1;
+      // VQA_K2_FWD_WAVES / VQA_K2_FWD_JT (measurement knobs): waves per sample (<= 8) and slices of the region axis j
+      if (const char* e = vqa::option("VQA_K2_FWD_WAVES")) nw = std::atoi(e) >= 1 && std::atoi(e) <= 8 ? std::atoi(e) : nw;
+      if (const char* e = vqa::option("VQA_K2_FWD_JT")) jt = std::atoi(e) >= 1 && std::atoi(e) <= 9 ? std::atoi(e) : jt;
+      const int nj = ((N + jt - 1) / jt + 3) / 4 * 4;
+      jt = (N + nj - 1) / nj;
+      if (nw > nsets * jt) nw = nsets * jt;
       const size_t lds_m = (size_t)nw * 4 * kOdaIG * 4 * sizeof(float);
       if (bits)
-        hipLaunchKernelGGL(oda_fwd_mfma_kernel<true>, dim3(B), dim3(64 * nw), lds_m, s, vl, ql, w, bias, logits, dc, N, L, G);
+        hipLaunchKernelGGL(oda_fwd_mfma_kernel<true>, dim3(B), dim3(64 * nw), lds_m, s, vl, ql, w, bias, logits, dc, N, L, G, jt, nj);
       else
-        hipLaunchKernelGGL(oda_fwd_mfma_kernel<false>, dim3(B), dim3(64 * nw), lds_m, s, vl, ql, w, bias, logits, dc, N, L, G);
+        hipLaunchKernelGGL(oda_fwd_mfma_kernel<false>, dim3(B), dim3(64 * nw), lds_m, s, vl, ql, w, bias, logits, dc, N, L, G, jt, nj);
       return check_launch("object_difference_attention_fwd");
     }
   }
