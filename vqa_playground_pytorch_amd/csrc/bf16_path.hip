@@ -356,6 +356,61 @@ __global__ __launch_bounds__(kBfThreads) void bilinear_fwd_bf16_kernel(const bf1
                            [&](int tm, int tn, int i) { return total[tm][tn][i]; });
 }
 
+// Two ranks (every region fusion of the models): both ranks' weight rows of a 64-column block are ONE 128-row B tile,
+// interleaved in blocks of 32 so that a wave's two 32-column accumulators are rank 0 and rank 1 of the same columns
+// (NtStager, b_interleave): x is staged once instead of once per rank and a stage carries 16 MFMAs per wave instead of 8.
+// LDS: the 128x128 ring only -- h2 (both ranks) and the output image overlay it after the K loop (N >= 2 regions per sample,
+// so a 128-row tile touches <= 65 samples: 33 KB + 18 KB of the ring's 72).
+__global__ __launch_bounds__(kBfThreads) void bilinear_fwd2_bf16_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w1,
+                                                                        const float* __restrict__ b1,
+                                                                        const float* __restrict__ h2, bf16* __restrict__ out,
+                                                                        bf16* __restrict__ h1, int M, int N, int L, int H,
+                                                                        int tiles_n, int Hin) {
+  constexpr int BM = 128, BC = 64, R = 2;
+  using T = BfTile<BM, 128>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* rowoff_s = reinterpret_cast<int*>(smem + T::kSmemBytes);  // [BM] (sample of the row - b0) * BC
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BC;
+  const int b0 = m0 / N;
+  const int ns = min(m0 + BM - 1, M - 1) / N - b0 + 1;  // samples touched by this tile
+  float* h2_s = reinterpret_cast<float*>(smem);                                   // [R][ns][BC]
+  char* tile_s = smem + (((size_t)R * ns * BC * sizeof(float) + 15) / 16) * 16;   // bf16 output image
+  for (int t = threadIdx.x; t < BM; t += kBfThreads) rowoff_s[t] = (min(m0 + t, M - 1) / N - b0) * BC;
+  f32x16 acc[2][2];
+  bf_zero_acc(acc);
+  gemm_bf16_nt_tile<BM, 128>(x, L, M, w1, L, R * H, m0, n0, L, smem, acc, BfNoTransform(), H);
+  for (int t = threadIdx.x; t < R * ns * BC; t += kBfThreads) {   // h2 is the unpadded [B,R,Hin]: the pad columns multiply by 0
+    const int r = t / (ns * BC), u = t - r * ns * BC;
+    const int col = n0 + (u % BC);
+    h2_s[t] = col < Hin ? h2[((size_t)(b0 + u / BC) * R + r) * Hin + col] : 0.f;
+  }
+  __syncthreads();
+  const BfAccCoord<BM, BC> cc(m0, n0);
+  const unsigned lo_h1 = cc.loff(R * H);
+  const int col = cc.col(0);  // < H
+  const float bv0 = b1[col], bv1 = b1[(size_t)H + col];
+  const float* h2c0 = h2_s + (col - n0);
+  const float* h2c1 = h2c0 + ns * BC;
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = cc.row(tm, i);
+      const float hv0 = acc[tm][0][i] + bv0, hv1 = acc[tm][1][i] + bv1;
+      if (h1 != nullptr && row < M) {
+        bf16* hp = h1 + cc.uoff(tm, 0, i, R * H);
+        hp[lo_h1] = (bf16)hv0;
+        (hp + H)[lo_h1] = (bf16)hv1;
+      }
+      const int ro = rowoff_s[row - m0];
+      acc[tm][0][i] = fmaf(hv0, h2c0[ro], hv1 * h2c1[ro]);
+    }
+  }
+  BfTileStore<BM, BC>::run(tile_s, out + (size_t)m0 * H + n0, (size_t)H, M - m0,
+                           [&](int tm, int, int i) { return acc[tm][0][i]; });
+}
+
 // ------------------------------------------------------------------------------------------ K4 backward prep
 // 256 lanes = (256/SL) columns-of-4 x SL region slices; the slices meet in LDS.  SL = 4 at large batches (grid
 // (H/256, B)); SL = 16 (grid (H/64, B)) when that grid would leave the chip short of loads in flight.
@@ -734,6 +789,16 @@ extern "C" int vqa_lowrank_bilinear_fusion_fwd_bf16(const vqa_bf16_t* x, const v
   VQA_REQUIRE(aligned(x, 16) && aligned(w1, 16), VQA_E_UNSUPPORTED, "lowrank_bilinear_fusion_fwd_bf16: x/w1 must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int M = B * N;
+  static const bool two_rank_off = vqa::option("VQA_K4_BF16_TWO_RANK") != nullptr && vqa::option("VQA_K4_BF16_TWO_RANK")[0] == '0';
+  if (R == 2 && N >= 2 && M > 64 && !two_rank_off) {
+    const size_t lds = BfTile<128, 128>::kSmemBytes + 128 * sizeof(int);
+    VQA_ENSURE_LDS(bilinear_fwd2_bf16_kernel, lds);
+    const int tm_ = (M + 127) / 128, tn_ = H / 64;
+    hipLaunchKernelGGL(bilinear_fwd2_bf16_kernel, dim3(tm_ * tn_), dim3(kBfThreads), lds, s, reinterpret_cast<const bf16*>(x),
+                       reinterpret_cast<const bf16*>(w1), b1, h2, reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(h1), M, N,
+                       L, H, tn_, H_in);
+    return check_launch("lowrank_bilinear_fusion_fwd_bf16");
+  }
   BfTileChoice t = choose_bf_tile(M, H, L);
   if (t.bm == 128 && t.bn == 128) t.bn = 64;  // total + per-rank accumulators: 128x128 would drop to one wave per SIMD
   const int tiles_m = (M + t.bm - 1) / t.bm, tiles_n = H / t.bn;

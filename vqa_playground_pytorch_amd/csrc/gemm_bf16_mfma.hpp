@@ -123,8 +123,11 @@ struct NtStager {
   int nsteps;
   int arow0, acol0;          // first A row of this thread (chunk p: + 32 p, clamped to a_rows - 1) / its column inside a stage
   int a_last;
+  // b_interleave > 0 (BN = 128 only): the B tile is two stacked matrices' rows [n0, n0 + 64), the second one b_interleave rows
+  // below the first, laid out in blocks of 32 as {first[0:32), second[0:32), first[32:64), second[32:64)} -- every wave's two
+  // 32-column accumulators are then the SAME 32 columns of the two matrices (K4 with two ranks: one staged x tile serves both)
   __device__ __forceinline__ NtStager(const bf16* A, int lda, int a_rows, const bf16* B, int ldb, int b_rows, int m0, int n0,
-                                      int K)
+                                      int K, int b_interleave = 0)
       : a(A), b(B), nsteps(K / kBfBK), a_last(a_rows - 1) {
     const int row = threadIdx.x >> 3, kc = threadIdx.x & 7;
     arow0 = m0 + row;
@@ -132,7 +135,10 @@ struct NtStager {
 #pragma unroll
     for (int p = 0; p < T::CA; ++p) oa[p] = min(m0 + row + 32 * p, a_rows - 1) * lda + kc * 8;
 #pragma unroll
-    for (int p = 0; p < T::CB; ++p) ob[p] = min(n0 + row + 32 * p, b_rows - 1) * ldb + kc * 8;
+    for (int p = 0; p < T::CB; ++p) {
+      const int src = b_interleave > 0 ? (p & 1) * b_interleave + n0 + 32 * (p >> 1) + row : n0 + row + 32 * p;
+      ob[p] = min(src, b_rows - 1) * ldb + kc * 8;
+    }
     lds_a = row * kBfPitch + kc * 16;
     lds_b = (BM + row) * kBfPitch + kc * 16;
   }
@@ -178,9 +184,10 @@ __device__ __forceinline__ void bf_interleave() {
 template <int BM, int BN, class XA = BfNoTransform>
 __device__ __forceinline__ void gemm_bf16_nt_tile(const bf16* __restrict__ A, int lda, int a_rows,
                                                   const bf16* __restrict__ B, int ldb, int b_rows, int m0, int n0, int K,
-                                                  char* smem, f32x16 (&acc)[BM / 64][BN / 64], const XA& xa = XA()) {
+                                                  char* smem, f32x16 (&acc)[BM / 64][BN / 64], const XA& xa = XA(),
+                                                  int b_interleave = 0) {
   using T = BfTile<BM, BN>;
-  const NtStager<BM, BN> st(A, lda, a_rows, B, ldb, b_rows, m0, n0, K);
+  const NtStager<BM, BN> st(A, lda, a_rows, B, ldb, b_rows, m0, n0, K, b_interleave);
   u32x4 ra0[T::CA], rb0[T::CB], ra1[T::CA], rb1[T::CB];
   st.load(ra0, rb0, 0);
   st.store(ra0, rb0, smem, 0, xa);
