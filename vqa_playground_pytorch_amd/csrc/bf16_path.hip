@@ -136,11 +136,15 @@ __global__ __launch_bounds__(kBfThreads) void gemm_bf16_tn_kernel(const bf16* __
                                                                   const bf16* __restrict__ B, int ldb,
                                                                   float* __restrict__ slab, int Kdim, int N1, int N2,
                                                                   int rows_per_split, int tiles_n, DropCfg dc,
-                                                                  uint32_t mask_ld) {
+                                                                  uint32_t mask_ld, int tiles_m_fast) {
   using T = BfTile<BM, BN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+  // neighbouring workgroups (one XCD, one L2) walk the axis with FEWER tiles first: they share the tile of the operand that
+  // is split into more tiles -- the larger matrix ([K, 2048] regions against [K, 320] gradients), fetched once per XCD
+  const int tm_ = tiles_m_fast > 0 ? bid % tiles_m_fast : bid / tiles_n;
+  const int tn_ = tiles_m_fast > 0 ? bid / tiles_m_fast : bid % tiles_n;
+  const int m0 = tm_ * BM, n0 = tn_ * BN;
   const int s = blockIdx.z;
   const int k_lo = s * rows_per_split, k_hi = min(Kdim, k_lo + rows_per_split);
   f32x16 acc[T::TM][T::TN];
@@ -267,6 +271,8 @@ static int launch_tn(const char* who, const bf16* A, int lda, const bf16* B, int
   const int tiles_m = (N1 + t.bm - 1) / t.bm, tiles_n = (N2 + t.bn - 1) / t.bn;
   int rows_per_split = (Kdim + S - 1) / S;
   rows_per_split = (rows_per_split + kBfBK - 1) / kBfBK * kBfBK;
+  const char* order = vqa::option("VQA_BF16_TN_ORDER");    // "n": always walk the column tiles first (comparison knob)
+  const int m_fast = (tiles_m < tiles_n && !(order != nullptr && order[0] == 'n')) ? tiles_m : 0;
   const char* form = vqa::option("VQA_BF16_TN");           // "perm": the register-transpose staging (comparison knob)
   const bool tr = !(form != nullptr && form[0] == 'p');
 #define LAUNCH_T(BM_, BN_, XB_, TR_)                                                                                        \
@@ -274,7 +280,7 @@ static int launch_tn(const char* who, const bf16* A, int lda, const bf16* B, int
     const size_t lds = TR_ ? (size_t)BfTileTr<BM_, BN_>::kSmemBytes : (size_t)BfTile<BM_, BN_>::kSmemBytes;                 \
     VQA_ENSURE_LDS((gemm_bf16_tn_kernel<BM_, BN_, XB_, TR_>), lds);                                                         \
     hipLaunchKernelGGL((gemm_bf16_tn_kernel<BM_, BN_, XB_, TR_>), dim3(tiles_m * tiles_n, 1, S), dim3(kBfThreads), lds, s,  \
-                       A, lda, B, ldb, workspace, Kdim, N1, N2, rows_per_split, tiles_n, ex.dc, ex.mask_ld);                \
+                       A, lda, B, ldb, workspace, Kdim, N1, N2, rows_per_split, tiles_n, ex.dc, ex.mask_ld, m_fast);        \
   }
 #define LAUNCH_X(BM_, BN_, XB_)    \
   if (tr) {                        \
