@@ -35,15 +35,16 @@ static bool bf_tile_override(BfTileChoice* t) {
 }
 // Tile shapes from the sweeps of tools/kbench.py --only bf16 (M = 12800 rows):
 //   NT (forward / data-gradient form): 128x64 -- a 64-wide tile keeps N = 320 at 5 exact column tiles and 3 workgroups
-//      per CU; with a short K (<= 512: five stages) and a wide output the kernel is bound by its output stores and the
-//      smaller 64x64 tile (more workgroups in flight) wins.
+//      per CU; with a short K (<= 512: five stages) and a wide output (the data gradient [M,320] x [2048,320]^T) the
+//      128x128 tile wins since the output leaves through the LDS image in 16-byte row stores (34.0 us against 39.7 for
+//      64x64, which won while the stores were 2-byte scattered; hipBLASLt: 41.6).
 //   TN (weight-gradient form): 128x128 -- every staged 8x8 block costs 32 v_perm + 8 ds_write_b128, so the tile with
 //      the most MFMAs per staged element wins by 1.5-2x even where it pads N2 = 320 to 384.
 static BfTileChoice choose_bf_tile(long M, long N, long K = 1 << 20) {
   BfTileChoice t{128, 64};
   if (bf_tile_override(&t)) return t;
   if (M <= 64) t.bm = 64;
-  if (K <= 512 && N >= 1024) t.bm = 64;
+  if (K <= 512 && N >= 1024) t.bn = 128;
   return t;
 }
 static BfTileChoice choose_bf_tile_tn(long N1, long N2) {
