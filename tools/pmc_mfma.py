@@ -16,7 +16,8 @@ of 4 cycles.  Derived:
                   = 100 * SQ_VALU_MFMA_BUSY_CYCLES / (32 SIMDs per SE * SQ_BUSY_CYCLES)      (SURVEY 5.1's ratio, normalised)
 
 i.e. the share of the kernel's duration, launch to last wave, in which a SIMD's matrix pipe was executing an MFMA,
-averaged over the SIMDs of the busy CUs.  Keys are "<kernel name>|grid=<work-items>"."""
+averaged over the SIMDs of the busy CUs.  With SQ_INSTS_VALU in the pass (the K2 table): valu_issue_pct_min = 100 * 4 cycles *
+SQ_INSTS_VALU / (4 SIMDs * SQ_BUSY_CU_CYCLES).  Keys are "<kernel name>|grid=<work-items>"."""
 import csv
 import glob
 import json
@@ -48,13 +49,21 @@ def main():
             entry["mfma_busy_pct"] = round(100.0 * busy / (4.0 * cu), 2)
         if busy is not None and entry.get("SQ_BUSY_CYCLES"):
             entry["mfma_busy_over_sq_busy_per_simd"] = round(busy / (32.0 * entry["SQ_BUSY_CYCLES"]), 4)
-        if entry.get("SQ_INSTS_MFMA", 0) > 0 or "mfma" in key or "gemm" in key or "bilinear" in key or "linear" in key:
+        insts = entry.get("SQ_INSTS_VALU")
+        if insts is not None and cu:
+            # vector-ALU issue: a wave64 VALU instruction holds its SIMD's issue port for >= 4 cycles (quarter-rate ones --
+            # v_mul_lo_u32, the hash multiplies -- longer), so this is a LOWER bound of the share of a busy CU's SIMD-cycles
+            # spent issuing VALU (SQ_INSTS_VALU counts the MFMAs too)
+            entry["valu_issue_pct_min"] = round(100.0 * 4.0 * insts / (4.0 * cu), 2)
+        if (entry.get("SQ_INSTS_MFMA", 0) > 0 or "mfma" in key or "gemm" in key or "bilinear" in key or "linear" in key
+                or "oda_" in key):
             table[key] = entry
     json.dump(table, open(dest, "w"), indent=1, sort_keys=True)
     print("wrote %s: %d kernels" % (dest, len(table)))
     for k, v in table.items():
-        if v.get("mfma_busy_pct"):
-            print("  %-110s launches %4d  mfma busy %5.1f %%" % (k[:110], v["launches"], v["mfma_busy_pct"]))
+        if v.get("mfma_busy_pct") or v.get("valu_issue_pct_min"):
+            print("  %-110s launches %4d  mfma busy %5.1f %%  valu issue >= %5.1f %%"
+                  % (k[:110], v["launches"], v.get("mfma_busy_pct") or 0.0, v.get("valu_issue_pct_min") or 0.0))
 
 
 if __name__ == "__main__":

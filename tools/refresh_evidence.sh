@@ -21,6 +21,15 @@ MFMA_CTRS="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYC
 timeout 600 rocprofv3 --pmc $MFMA_CTRS --output-format csv -d /tmp/pmc_mfma -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records > "$OUT/pmc_mfma.log" 2>&1
 python3 "$ROOT/tools/pmc_mfma.py" /tmp/pmc_mfma "$OUT/pmc_mfma.json" > "$OUT/pmc_mfma_table.log" 2>&1
 
+# 1c. the bf16 / 100-region step (configs[4], one rank's share): matrix-pipe counters of its kernels
+rm -rf /tmp/pmc_mfma_bf16
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma_bf16 -- python3 "$ROOT/bench.py" --dtype bf16 --regions 100 --batch 128 --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records > "$OUT/pmc_mfma_bf16.log" 2>&1
+python3 "$ROOT/tools/pmc_mfma.py" /tmp/pmc_mfma_bf16 "$OUT/pmc_mfma_bf16_n100_b128.json" > "$OUT/pmc_mfma_bf16_table.log" 2>&1
+# 1d. K2 (the ODA attention op): VALU issue counters of its kernels
+rm -rf /tmp/pmc_valu_oda
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_valu_oda -- python3 "$ROOT/bench.py" --model oda-attention --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records > "$OUT/pmc_valu_oda.log" 2>&1
+python3 "$ROOT/tools/pmc_mfma.py" /tmp/pmc_valu_oda "$OUT/pmc_valu_oda_attention.json" > "$OUT/pmc_valu_oda_table.log" 2>&1
+
 # 2. bench lines
 cd "$ROOT"
 run() { name=$1; shift; timeout 900 python3 bench.py "$@" > "$OUT/$name.log" 2>&1; tail -1 "$OUT/$name.log" > "$OUT/$name.json"; }
@@ -56,4 +65,7 @@ for cfg in "oda_b512|--model oda" "bf16_n100_b128|--dtype bf16 --regions 100 --b
   [ -n "$f" ] && cp "$f" "$OUT/bench_${name}_kernel_stats.csv"
   python3 "$ROOT/tools/by_grid.py" /tmp/kt_$name 1 "hand-written kernels, per-dispatch durations by (kernel, grid work-items); rocprofv3 --kernel-trace of bench.py $args --steps 20 --warmup 5 --no-cpu-baseline (the last column is the total over the run)" > "$OUT/vqa_kernels_by_grid_$name.txt" 2>&1
 done
+# 5. does the replayed step still train on this build?  (student vs a fixed teacher, the reference's recipe)
+timeout 600 python3 tools/convergence.py --steps 3000 --model cor2 --out "$OUT/convergence_cor2.json" > "$OUT/convergence_cor2.log" 2>&1
+timeout 600 python3 tools/convergence.py --steps 3000 --model oda --out "$OUT/convergence_oda.json" > "$OUT/convergence_oda.log" 2>&1
 ls -la "$OUT"
