@@ -527,6 +527,30 @@ def test_object_difference_with_dropout(ops, B, N, L, G, p):
     assert 0.4 < (other == mask).mean() < 0.6 + abs(0.5 - p), "a different seed must give a different mask"
 
 
+@pytest.mark.parametrize("B,N,L,G,p", [(3, 36, 310, 4, 0.5), (2, 13, 70, 2, 0.25), (2, 36, 310, 4, 0.0)])
+def test_object_difference_gated_region_gradient(ops, B, N, L, G, p):
+    """gate_dvl: vl is a relu output (zeros where the layer in front was inactive) and d_vl comes back multiplied by
+    (vl > 0) -- the gradient with respect to that layer's pre-activation; every other output is unchanged."""
+    seed = 424242
+    vl = np.maximum(seeded.seeded_array((B, N, L), 421), 0.0)            # about half the entries exactly 0
+    ql = np.abs(seeded.seeded_array((B, L), 422))
+    w = seeded.seeded_array((G, N * L), 423, scale=1.0 / np.sqrt(N * L))
+    bias = seeded.seeded_array((G,), 424, scale=0.1)
+    gl = seeded.seeded_array((B, N, G), 425)
+    mask = ops.object_difference_dropout_mask(B, N, L, p, seed, dev()).cpu().numpy() if p else None
+    vt, qt, wt, bt = g(vl, True), g(ql, True), g(w, True), g(bias, True)
+    logits = ops.object_difference_attention(vt, qt, wt, bt, p, seed, gate_dvl=True)
+    close("logits", logits, K.object_difference_logits_fwd(vl, ql, w, bias, mask))
+    logits.backward(g(gl))
+    dvl, dql, dw, db = K.object_difference_logits_bwd(vl, ql, w, gl, mask)
+    assert 0.3 < (vl > 0).mean() < 0.7
+    close("d_vl (gated)", vt.grad, dvl * (vl > 0))
+    assert float(vt.grad.cpu()[torch.from_numpy(vl <= 0)].abs().max()) == 0.0
+    close("d_ql", qt.grad, dql)
+    close("d_w", wt.grad, dw)
+    close("d_bias", bt.grad, db)
+
+
 def test_object_difference_mask_is_unbiased(ops):
     """Statistics of the counter-hash mask at the ODA shape: per-region, per-feature and per-pair keep rates."""
     B, N, L, p = 8, 36, 310, 0.5

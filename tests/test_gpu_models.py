@@ -337,10 +337,10 @@ def test_training_step_with_shared_masks_against_oracle(cls, nans, variant, monk
         flat_mask("relation_apply", x, p_drop, seed)
         return orig["relation_apply"](x, t, c2, p_drop, seed)
 
-    def spy_k2(vl, ql, w, bias, p_drop=0.0, seed=0):
+    def spy_k2(vl, ql, w, bias, p_drop=0.0, seed=0, **kw):
         if p_drop:
             rec.append(("k2", ops.object_difference_dropout_mask(vl.shape[0], vl.shape[1], vl.shape[2], p_drop, seed, vl.device)))
-        return orig["object_difference_attention"](vl, ql, w, bias, p_drop, seed)
+        return orig["object_difference_attention"](vl, ql, w, bias, p_drop, seed, **kw)
 
     spies = {"next_dropout_seed": next_seed, "object_difference_attention": spy_k2, "dropout": spy_dropout, "linear_act": spy_linear_act,
              "attention_logits": spy_attention_logits, "softmax_attention_pool_drop": spy_pool_drop,

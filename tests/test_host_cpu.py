@@ -242,3 +242,18 @@ def test_bench_refuses_to_measure_fewer_gpus_than_asked():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=300)
     assert r.returncode != 0 and "must agree" in r.stderr
+
+
+def test_head_mode_selects_the_grouped_phases_per_model(monkeypatch):
+    """VQA_HEAD (head.MODE): auto groups CoR2's [B,.] layers except the glimpse projections and leaves ODA on the library
+    GEMMs; grouped / legacy force one form for both; odd feature widths never take the grouped kernels (8-byte operand loads)."""
+    from vqa_playground_pytorch_amd import head
+    dims = (2400, 310, 2048, 510, 620, 2000)
+    want = {"auto": (True, False, False), "grouped": (True, True, True), "legacy": (False, False, False)}
+    for mode, (cor2, oda, glimpses) in want.items():
+        monkeypatch.setattr(head, "MODE", mode)
+        assert head.supported("cor2", *dims) is cor2
+        assert head.supported("oda", *dims) is oda
+        assert head.glimpses_grouped() is glimpses
+    monkeypatch.setattr(head, "MODE", "grouped")
+    assert head.supported("cor2", 2400, 311) is False

@@ -66,6 +66,6 @@ for cfg in "oda_b512|--model oda" "bf16_n100_b128|--dtype bf16 --regions 100 --b
   python3 "$ROOT/tools/by_grid.py" /tmp/kt_$name 1 "hand-written kernels, per-dispatch durations by (kernel, grid work-items); rocprofv3 --kernel-trace of bench.py $args --steps 20 --warmup 5 --no-cpu-baseline (the last column is the total over the run)" > "$OUT/vqa_kernels_by_grid_$name.txt" 2>&1
 done
 # 5. does the replayed step still train on this build?  (student vs a fixed teacher, the reference's recipe)
-timeout 600 python3 tools/convergence.py --steps 3000 --model cor2 --out "$OUT/convergence_cor2.json" > "$OUT/convergence_cor2.log" 2>&1
-timeout 600 python3 tools/convergence.py --steps 3000 --model oda --out "$OUT/convergence_oda.json" > "$OUT/convergence_oda.log" 2>&1
+timeout 600 python3 "$ROOT/tools/convergence.py" --steps 3000 --model cor2 --out "$OUT/convergence_cor2.json" > "$OUT/convergence_cor2.log" 2>&1
+timeout 600 python3 "$ROOT/tools/convergence.py" --steps 3000 --model oda --out "$OUT/convergence_oda.json" > "$OUT/convergence_oda.log" 2>&1
 ls -la "$OUT"

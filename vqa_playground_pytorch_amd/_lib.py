@@ -66,7 +66,7 @@ SIGNATURES = {
                                                    _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_object_difference_attention_bwd_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i, _c_i]),
     "vqa_object_difference_attention_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz,
-                                                   _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
+                                                   _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_object_difference_dropout_mask": (_c_i, [_c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_i, _c_st]),
     "vqa_linear_act_fwd": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_fl, _c_u64, _c_f, _c_st]),
     "vqa_linear_act_bwd_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i]),

@@ -432,7 +432,8 @@ __global__ __launch_bounds__(512) void oda_bwd_weight_mfma_kernel(const float* _
 template <int G>
 __global__ void oda_bwd_data_bits_kernel(const float* __restrict__ vl, const float* __restrict__ ql,
                                          const float* __restrict__ w, const float* __restrict__ dS,
-                                         float* __restrict__ d_vl, float* __restrict__ d_ql, DropCfg dc, int N, int L) {
+                                         float* __restrict__ d_vl, float* __restrict__ d_ql, DropCfg dc, int N, int L,
+                                         int gate) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* dT_s = reinterpret_cast<float*>(smem);        // [N][blockDim]
   float* dS_s = dT_s + (size_t)N * blockDim.x;          // [N][G]
@@ -507,8 +508,9 @@ __global__ void oda_bwd_data_bits_kernel(const float* __restrict__ vl, const flo
     float dq = 0.f;
     for (int n = 0; n < N; ++n) {
       const float t = dT_s[n * nt + tid];
-      d_vl[((size_t)b * N + n) * L + d] = t * qd;
-      dq = fmaf(t, vlb[(size_t)n * L + d], dq);
+      const float vn = vlb[(size_t)n * L + d];
+      d_vl[((size_t)b * N + n) * L + d] = (gate != 0 && !(vn > 0.f)) ? 0.f : t * qd;   // gate: relu gradient of vl's producer
+      dq = fmaf(t, vn, dq);
     }
     d_ql[(size_t)b * L + d] = dq * dc.scale;
   }
@@ -651,7 +653,7 @@ __global__ void oda_fwd_kernel(const float* __restrict__ vl, const float* __rest
 template <int G, bool DROP>
 __global__ void oda_bwd_data_kernel(const float* __restrict__ vl, const float* __restrict__ ql,
                                     const float* __restrict__ w, const float* __restrict__ dS, float* __restrict__ d_vl,
-                                    float* __restrict__ d_ql, DropCfg dc, int N, int L) {
+                                    float* __restrict__ d_ql, DropCfg dc, int N, int L, int gate) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* dT_s = reinterpret_cast<float*>(smem);        // [N][blockDim]
   float* dS_s = dT_s + (size_t)N * blockDim.x;          // [N][G]
@@ -703,8 +705,9 @@ __global__ void oda_bwd_data_kernel(const float* __restrict__ vl, const float* _
     float dq = 0.f;
     for (int n = 0; n < N; ++n) {
       const float t = dT_s[n * nt + tid];
-      d_vl[((size_t)b * N + n) * L + d] = t * qd;
-      dq = fmaf(t, vlb[(size_t)n * L + d], dq);
+      const float vn = vlb[(size_t)n * L + d];
+      d_vl[((size_t)b * N + n) * L + d] = (gate != 0 && !(vn > 0.f)) ? 0.f : t * qd;   // gate: relu gradient of vl's producer
+      dq = fmaf(t, vn, dq);
     }
     d_ql[(size_t)b * L + d] = dq;
   }
@@ -919,20 +922,20 @@ static int launch_fwd(const float* vl, const float* ql, const float* w, const fl
 
 template <int G>
 static int launch_bwd(const float* vl, const float* ql, const float* w, const float* dS, float* d_vl, float* d_ql,
-                      float* d_w, float* d_bias, float* slab, DropCfg dc, int B, int N, int L, hipStream_t s) {
+                      float* d_w, float* d_bias, float* slab, DropCfg dc, int B, int N, int L, int gate_dvl, hipStream_t s) {
   const int nt = oda_threads(L);
   {
     const size_t lds = ((size_t)N * nt + (size_t)(N + kIC) * G) * sizeof(float);   // (+ kIC zero rows of dS, bit-mask kernel)
     VQA_REQUIRE(lds <= 160 * 1024, VQA_E_UNSUPPORTED, "object_difference_attention_bwd: N=%d L=%d need %zu B of LDS", N, L, lds);
     if (oda_bits_mode(dc, B, N, L)) {
       VQA_ENSURE_LDS((oda_bwd_data_bits_kernel<G>), lds);
-      hipLaunchKernelGGL((oda_bwd_data_bits_kernel<G>), dim3(B), dim3(nt), lds, s, vl, ql, w, dS, d_vl, d_ql, dc, N, L);
+      hipLaunchKernelGGL((oda_bwd_data_bits_kernel<G>), dim3(B), dim3(nt), lds, s, vl, ql, w, dS, d_vl, d_ql, dc, N, L, gate_dvl);
     } else if (dc.p8 > 0) {
       VQA_ENSURE_LDS((oda_bwd_data_kernel<G, true>), lds);
-      hipLaunchKernelGGL((oda_bwd_data_kernel<G, true>), dim3(B), dim3(nt), lds, s, vl, ql, w, dS, d_vl, d_ql, dc, N, L);
+      hipLaunchKernelGGL((oda_bwd_data_kernel<G, true>), dim3(B), dim3(nt), lds, s, vl, ql, w, dS, d_vl, d_ql, dc, N, L, gate_dvl);
     } else {
       VQA_ENSURE_LDS((oda_bwd_data_kernel<G, false>), lds);
-      hipLaunchKernelGGL((oda_bwd_data_kernel<G, false>), dim3(B), dim3(nt), lds, s, vl, ql, w, dS, d_vl, d_ql, dc, N, L);
+      hipLaunchKernelGGL((oda_bwd_data_kernel<G, false>), dim3(B), dim3(nt), lds, s, vl, ql, w, dS, d_vl, d_ql, dc, N, L, gate_dvl);
     }
   }
   {
@@ -1010,7 +1013,7 @@ extern "C" int vqa_object_difference_attention_bwd(const float* vl, const float*
                                                    const float* d_logits, float* d_vl, float* d_ql, float* d_w,
                                                    float* d_bias, void* workspace, size_t workspace_bytes, float p_drop,
                                                    uint64_t seed, const uint64_t* seed_ptr, int B, int N, int L, int G,
-                                                   vqa_stream_t stream) {
+                                                   int gate_dvl, vqa_stream_t stream) {
   VQA_REQUIRE(vl && ql && w && d_logits && d_vl && d_ql && d_w && d_bias && workspace, VQA_E_BADARG,
               "object_difference_attention_bwd: null pointer");
   int rc = oda_check("object_difference_attention_bwd", B, N, L, G, p_drop);
@@ -1020,7 +1023,7 @@ extern "C" int vqa_object_difference_attention_bwd(const float* vl, const float*
   const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* slab = static_cast<float*>(workspace);
-#define CALL(G_) launch_bwd<G_>(vl, ql, w, d_logits, d_vl, d_ql, d_w, d_bias, slab, dc, B, N, L, s)
+#define CALL(G_) launch_bwd<G_>(vl, ql, w, d_logits, d_vl, d_ql, d_w, d_bias, slab, dc, B, N, L, gate_dvl, s)
   VQA_G_SWITCH(G, CALL)
 #undef CALL
 }

@@ -4,6 +4,8 @@ Same constructor / forward / ``alpha_dict`` / state_dict names as the reference 
 (``att.conv_att.conv.weight`` keeps its (4, N*310, 1) shape).  The [B,N,N*310] difference tensor and
 its dropout mask are never built: HIP kernel K2 contracts them against the attention filter on the fly.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -32,6 +34,10 @@ class Model(nn.Module):
         self.linear_classif = MyLinear(510, self.num_classes, p=0.5)
         self.alpha_dict = {}
         self._mask_step = 0
+        # compress_v's relu output feeds K2 and nothing else: K2's backward holds it in registers (for d q) and hands the
+        # gradient back already multiplied by (output > 0), so the projection's weight-gradient kernel runs ungated
+        # (VQA_ODA_GATE_IN_K2=0: the gate in the projection's own backward, as in round 2)
+        self.compress_v.grad_pregated = os.environ.get("VQA_ODA_GATE_IN_K2", "1") == "1"
 
     def stack_groups(self):
         return linear_stack_groups([self.compress_q, self.linear_q])
@@ -45,7 +51,8 @@ class Model(nn.Module):
             # fresh mask every call, drawn from torch's generator so torch.manual_seed governs it
             seed = ops.next_dropout_seed()
         w = conv.conv.weight.view(conv.out_channels, -1)
-        return ops.object_difference_attention(v_feature_low, q_feature_low, w, conv.conv.bias, p, seed)
+        return ops.object_difference_attention(v_feature_low, q_feature_low, w, conv.conv.bias, p, seed,
+                                               gate_dvl=self.compress_v.grad_pregated)
 
     def _grouped_head_ok(self, q_feature, cut):
         """As cor2.Model._grouped_head_ok: the [B,.]-sized layers as grouped phases (head.py)."""

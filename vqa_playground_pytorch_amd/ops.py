@@ -819,10 +819,11 @@ class LowRankBilinearFusionBf16(torch.autograd.Function):
 
 class ObjectDifferenceAttention(torch.autograd.Function):
     """K2.  logits[b,i,g] = bias[g] + sum_{j,d} w[g,j*L+d] * keep * (vl[b,i,d]-vl[b,j,d]) * ql[b,d].
-    Replaces config/ODA.py:216-222 + the dropout and 1x1 conv of config/ODA.py:149."""
+    Replaces config/ODA.py:216-222 + the dropout and 1x1 conv of config/ODA.py:149.
+    gate_dvl: vl is the relu output of the layer in front and nothing else reads it; d_vl comes back multiplied by (vl > 0)."""
 
     @staticmethod
-    def forward(ctx, vl, ql, w, bias, p_drop, seed):
+    def forward(ctx, vl, ql, w, bias, p_drop, seed, gate_dvl=False):
         vl, ql, w, bias = _prep("vl", vl), _prep("ql", ql), _prep("w", w), _prep("bias", bias)
         B, N, L = vl.shape
         G = bias.shape[0]
@@ -836,13 +837,13 @@ class ObjectDifferenceAttention(torch.autograd.Function):
                 float(p_drop), sv, sp, B, N, L, G)
         ctx.save_for_backward(vl, ql, w)
         ctx.bias = bias
-        ctx.cfg = (float(p_drop), seed, G)
+        ctx.cfg = (float(p_drop), seed, G, bool(gate_dvl))
         return logits
 
     @staticmethod
     def backward(ctx, d_logits):
         vl, ql, w = ctx.saved_tensors
-        p_drop, seed, G = ctx.cfg
+        p_drop, seed, G, gate_dvl = ctx.cfg
         B, N, L = vl.shape
         d_logits = _prep("grad_logits", d_logits)
         d_vl, d_ql, d_w = torch.empty_like(vl), torch.empty_like(ql), _grad_like(w)
@@ -853,8 +854,8 @@ class ObjectDifferenceAttention(torch.autograd.Function):
         sv, sp = _seed_args(seed)
         _launch("object_difference_attention_bwd", (B, N, L, G, p_drop > 0), L_.vqa_object_difference_attention_bwd,
                 _p(vl), _p(ql), _p(w), _p(d_logits), _p(d_vl), _p(d_ql), _p(d_w), _p(d_bias), _p(ws), ws_bytes,
-                p_drop, sv, sp, B, N, L, G)
-        return d_vl, d_ql, d_w, d_bias, None, None
+                p_drop, sv, sp, B, N, L, G, int(gate_dvl))
+        return d_vl, d_ql, d_w, d_bias, None, None, None
 
 
 class LinearAct(torch.autograd.Function):
@@ -1542,5 +1543,5 @@ def lowrank_bilinear_fusion(x, h2, weights, biases, gate_dx=False, packed=None):
     return LowRankBilinearFusion.apply(x, h2, gate_dx, *weights, *biases)
 
 
-def object_difference_attention(vl, ql, w, bias, p_drop=0.0, seed=0):
-    return ObjectDifferenceAttention.apply(vl, ql, w, bias, p_drop, seed)
+def object_difference_attention(vl, ql, w, bias, p_drop=0.0, seed=0, gate_dvl=False):
+    return ObjectDifferenceAttention.apply(vl, ql, w, bias, p_drop, seed, gate_dvl)
