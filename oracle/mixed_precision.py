@@ -68,8 +68,11 @@ class _RankProduct(torch.autograd.Function):
 
 class CoR2MixedOracle(RF.CoR2Oracle):
     """reference_faithful.CoR2Oracle's parameters (same names: one seeded state_dict loads into both) with the forward
-    described in the module docstring.  masks: optional {site name: keep/(1-p) mask} for a training-mode comparison with
-    the product's exported dropout masks (eval mode needs none)."""
+    described in the module docstring.  Eval mode needs nothing else.  Training mode (dropout at every Drop* layer) is a
+    comparison with the product's exported masks: the caller switches the DropLinear modules' own F.dropout off and masks their
+    inputs by forward pre-hooks (as tests/test_gpu_models.py does for the float64 restatement), and hands the masks of the four
+    1x1-convolution sites -- which this forward evaluates without calling the modules -- in sample["site_masks"] =
+    {"compress_v", "compress_v2": [b,N,2048]; "att1.conv_att", "att2.conv_att": [b,N,510]} (keep / (1 - p) values: 0 or 2)."""
 
     def __init__(self, *args, rounding=True, **kw):
         super().__init__(*args, **kw)
@@ -78,9 +81,12 @@ class CoR2MixedOracle(RF.CoR2Oracle):
     def _r(self, x, both=False):
         return _Round.apply(x, both) if self.rounding else x
 
-    def _region_linear(self, mod, x):
-        """relu(x W^T + b) with the bf16 shadow of W; the output and its gradient are bf16."""
+    def _region_linear(self, mod, x, mask=None):
+        """relu(drop(x) W^T + b) with the bf16 shadow of W; the output and its gradient are bf16.  (The product zeroes the
+        dropped elements of the bf16 operand and applies the factor 2 to the accumulator: the same numbers, 2 is exact.)"""
         w = self._r(mod.conv.weight.squeeze(-1))
+        if mask is not None:
+            x = x * mask
         return self._r(F.relu(F.linear(x, w, mod.conv.bias)), both=True)
 
     def _fusion(self, mf, x_low, q_low):
@@ -89,7 +95,9 @@ class CoR2MixedOracle(RF.CoR2Oracle):
         return self._r(_RankProduct.apply(h1, h2, self.rounding), both=True)                              # [B,N,H] bf16
 
     @staticmethod
-    def _attend(att, fuse, v):
+    def _attend(att, fuse, v, mask=None):
+        if mask is not None:
+            fuse = fuse * mask
         logits = att.conv_att.conv(fuse.transpose(1, 2)).transpose(1, 2)                                  # [B,N,G]
         alpha = F.softmax(logits, dim=1)
         return alpha, torch.matmul(alpha.transpose(1, 2), v)                                              # pooled [B,G,D]
@@ -99,8 +107,10 @@ class CoR2MixedOracle(RF.CoR2Oracle):
         return torch.cat([att.list_linear_v_fusion[g](pooled[:, g, :]) for g in range(att.glimpses)], dim=1)
 
     def forward(self, sample):
-        if self.training:
-            raise NotImplementedError("CoR2MixedOracle is an eval-mode checker (dropout masks cannot be shared with torch)")
+        sm = sample.get("site_masks")
+        if self.training and sm is None:
+            raise NotImplementedError("CoR2MixedOracle in training mode needs the product's masks (see the class docstring)")
+        sm = sm or {}
         v = sample["v"]
         q = sample["q"] if "q" in sample else sample["q_idxes"]
         b, n = v.size(0), v.size(1)
@@ -108,15 +118,15 @@ class CoR2MixedOracle(RF.CoR2Oracle):
         q_low = self.compress_q(q)
         q1 = self.expand_q_1(self.compress_q_1(q))
         q2 = self.expand_q_2(self.compress_q_2(q))
-        v_low = self._region_linear(self.compress_v, v)
+        v_low = self._region_linear(self.compress_v, v, sm.get("compress_v"))
         fuse1 = self._fusion(self.fusion_vq1, v_low, q_low)
-        alpha1, pooled1 = self._attend(self.att1, fuse1, v)
+        alpha1, pooled1 = self._attend(self.att1, fuse1, v, sm.get("att1.conv_att"))
         v1_att = self._glimpses(self.att1, pooled1)
         t = q1 * pooled1[:, 0, :]
         v2 = self._r(t.unsqueeze(1) + q2.unsqueeze(1) * v, both=True)                                     # relation tensor
-        v2_low = self._region_linear(self.compress_v2, v2)
+        v2_low = self._region_linear(self.compress_v2, v2, sm.get("compress_v2"))
         fuse2 = self._fusion(self.fusion_vq2, v2_low, q_low)
-        alpha2, pooled2_v = self._attend(self.att2, fuse2, v)
+        alpha2, pooled2_v = self._attend(self.att2, fuse2, v, sm.get("att2.conv_att"))
         pooled2 = t.unsqueeze(1) + q2.unsqueeze(1) * pooled2_v               # = alpha2^T v2 for a softmax alpha2
         v2_att = self._glimpses(self.att2, pooled2)
         self.alpha_dict = {"alpha1": torch.split(alpha1, 1, dim=2), "alpha2": torch.split(alpha2, 1, dim=2),
