@@ -430,8 +430,12 @@ def main():
         return cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: a timed region of ~0.5 s (200 replayed steps) behind 10 warm-up steps -- long enough for a utilisation sampler
+    # and for the clocks to settle (measured: 20, 200 and 1000 timed steps after 10 warm-up steps agree within 0.2 %; after
+    # only 5 the first timed steps still run ~1 % slow); the whole default run, sub-records and CPU baseline included, takes
+    # about 75 s
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (BASELINE config: 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--relation-mode", type=int, default=1, help="K1: 0 = pairwise, 1 = factored")
