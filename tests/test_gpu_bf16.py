@@ -396,12 +396,28 @@ def test_cor2_bf16_against_fp32_oracle(B, N, gemm):
 
 RTOL_AWARE = 2e-2     # against the bf16-AWARE oracle (oracle/mixed_precision.py: the same tensors rounded to bf16 at the same
 #                       points, forward and backward): logits / attention maps on their scale, and the relative Frobenius
-#                       error of every parameter gradient (measured: 9e-3 at worst).  What is left between the two sides is
-#                       fp32-vs-float64 accumulation straddling a bf16 rounding boundary or a relu gate.
-RTOL_AWARE_MAX = 1e-1  # max-abs error of a gradient tensor on its own scale, a sanity bound: a flipped gate changes one ROW of
-#                       a weight gradient by one sample's (region's) whole contribution -- measured 3.2e-2 on
-#                       compress_v2.weight and 6.7e-2 on a glimpse layer at B = 128, N = 100 -- which the Frobenius norm
-#                       above does not see and a systematic error would dwarf
+#                       error of every parameter gradient once the rows hit by a flipped gate are set aside (below).  What is
+#                       left between the two sides is fp32-vs-float64 accumulation straddling a bf16 rounding boundary or a
+#                       relu gate.
+RTOL_AWARE_MAX = 1e-1  # largest element of that error on the tensor's own scale
+RTOL_AWARE_ALL = 1e-1  # relative Frobenius error of the WHOLE gradient tensor, flipped gates included (one flipped unit of a
+#                       155-unit glimpse layer alone: 4.8e-2)
+# A gate that fp32 and float64 accumulation decide differently moves ONE ROW (one output unit) of a weight gradient by one
+# sample's whole contribution; which gates those are depends on the fp32 summation order, i.e. on the kernel build and the head
+# form.  Measured over this round's builds at B = 128, N = 100: whole-tensor Frobenius 1.2e-2 / 1.9e-2 / 2.4e-2 and max-abs
+# 6.7e-2 / 1.0e-1 / 4.1e-1 at worst (all on 155-unit glimpse layers and compress_v2) -- the same code, three summation orders.
+# So the element-wise bars are applied with the rows holding the largest 1 % of the squared error set aside, and the whole
+# tensor is bounded separately.
+
+
+def _gradient_error(g, ref):
+    """-> (max-abs on the tensor's scale and relative Frobenius error without the worst 1 % of the rows, whole-tensor
+    relative Frobenius error).  Rows = the first axis (output units; a bias: one element per unit)."""
+    err = g - ref
+    rows = (err.reshape(err.shape[0], -1) ** 2).sum(1)
+    norm = np.sqrt((ref ** 2).sum())
+    kept = err[np.argsort(rows)[:-max(1, (len(rows) + 99) // 100)]]
+    return np.abs(kept).max() / np.abs(ref).max(), np.sqrt((kept ** 2).sum()) / norm, np.sqrt(rows.sum()) / norm
 
 
 @pytest.mark.parametrize("B,N", [(128, 100), (16, 36)])
@@ -414,11 +430,9 @@ def test_cor2_bf16_at_size_against_bf16_aware_oracle(B, N):
     from oracle import mixed_precision as MP
     from oracle import reference_faithful as RF
     from vqa_playground_pytorch_amd import head
-    # The bars are stated for the default step (VQA_HEAD=auto: Frobenius 1.2e-2 at worst).  Which relu gates fp32 and float64
-    # accumulation decide differently depends on the fp32 summation order, and that of the [B,.] layers differs between the
-    # head forms: forced onto the all-library head the same comparison measures 2.4e-2 on compress_v2.weight.
-    default_head = head.MODE == "auto"
-    rtol_fro = RTOL_AWARE if default_head else 1.5 * RTOL_AWARE
+    # the bars are stated for the default step; forced onto the all-library head (VQA_HEAD=legacy) the question-side factors
+    # reach the relation tensor through another fp32 summation order and compress_v2.weight measures 2.3e-2: 1.5 x there
+    slack = 1.0 if head.MODE != "legacy" else 1.5
     nans = 2000
     model = _build_cor2(nans, compute_dtype=torch.bfloat16)
     aware = seeded.load_state(MP.CoR2MixedOracle(nans), 0).eval().double()
@@ -454,18 +468,9 @@ def test_cor2_bf16_at_size_against_bf16_aware_oracle(B, N):
             w_scale = np.abs(npy(params[n.replace(".bias", ".weight")].grad)).max()
             assert np.abs(g).max() <= 5e-2 * w_scale and scale <= 5e-2 * w_scale, (n, np.abs(g).max(), scale, w_scale)
             continue
-        err = g - ref
-        if not default_head:
-            # forced head form: the single gate that flips moves ONE row (unit) of a weight gradient by a sample's whole
-            # contribution -- measured 0.41 of the tensor's scale on a 155-unit glimpse layer with the all-library head.  The
-            # element-wise bars are applied with the rows holding the largest 1 % of the squared error set aside, and the whole
-            # tensor is bounded in the Frobenius norm.
-            rows = (err.reshape(err.shape[0], -1) ** 2).sum(1)     # (a bias: one element per unit)
-            assert np.sqrt(rows.sum()) <= 1e-1 * np.sqrt((ref ** 2).sum()), (n, np.sqrt(rows.sum() / (ref ** 2).sum()))
-            err = err[np.argsort(rows)[:-max(1, (len(rows) + 99) // 100)]]
-        e_max = np.abs(err).max() / scale
-        e_fro = np.sqrt((err ** 2).sum()) / np.sqrt((ref ** 2).sum())
-        assert e_max <= RTOL_AWARE_MAX and e_fro <= rtol_fro, "%s: max-abs %.3e of scale, Frobenius %.3e" % (n, e_max, e_fro)
+        e_max, e_fro, e_all = _gradient_error(g, ref)
+        assert e_max <= RTOL_AWARE_MAX and e_fro <= slack * RTOL_AWARE and e_all <= RTOL_AWARE_ALL, \
+            "%s: max-abs %.3e of scale, Frobenius %.3e (whole tensor %.3e)" % (n, e_max, e_fro, e_all)
         if e_max > worst[0]:
             worst = (e_max, e_fro, n)
     print("[cor2 bf16 B=%d N=%d] logits rel err %.2e; worst gradient: %s max-abs %.2e, Frobenius %.2e"
@@ -493,9 +498,9 @@ def _compare_gradients(model, aware, tag, dropout=False, rtol_fro=None, rtol_max
             w_scale = np.abs(npy(params[n.replace(".bias", ".weight")].grad)).max()
             assert np.abs(g).max() <= 5e-2 * w_scale and scale <= 5e-2 * w_scale, (tag, n, np.abs(g).max(), scale, w_scale)
             continue
-        e_max = np.abs(g - ref).max() / scale
-        e_fro = np.sqrt(((g - ref) ** 2).sum()) / np.sqrt((ref ** 2).sum())
-        assert e_max <= rtol_max and e_fro <= rtol_fro, "%s %s: max-abs %.3e of scale, Frobenius %.3e" % (tag, n, e_max, e_fro)
+        e_max, e_fro, e_all = _gradient_error(g, ref)
+        assert e_max <= rtol_max and e_fro <= rtol_fro and e_all <= RTOL_AWARE_ALL, \
+            "%s %s: max-abs %.3e of scale, Frobenius %.3e (whole tensor %.3e)" % (tag, n, e_max, e_fro, e_all)
         if e_max > worst[0]:
             worst = (e_max, e_fro, n)
     return worst

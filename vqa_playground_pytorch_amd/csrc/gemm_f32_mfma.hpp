@@ -59,14 +59,22 @@ struct Stager {
 #pragma unroll
     for (int p = 0; p < NREG; ++p) reg[p] = src.fetch(mn0 + mn_of(p, tid), k0 + k_of(p, tid));
   }
-  template <class Src>
+  // ROWK (K-contiguous sources only): the LDS image keeps the source's orientation, [mn][k] rows of pitch S = BK + 4 floats,
+  // so a slot is ONE 8-byte store instead of two 4-byte stores a row apart (see gemm_tile's ROWK)
+  // CHECK = false (a tile that lies inside both matrices over its whole contraction range): the slots go to LDS as loaded
+  // (Src::plain), without the per-slot bounds arithmetic of Src::finish
+  template <bool ROWK = false, bool CHECK = true, class Src>
   __device__ __forceinline__ static void store(const typename Src::Raw (&reg)[NREG], const Src& src, int mn0, int k0,
                                                float* Xs, int S, int tid) {
 #pragma unroll
     for (int p = 0; p < NREG; ++p) {
       const int mn = mn_of(p, tid), k = k_of(p, tid);
-      const float2 v = src.finish(reg[p], mn0 + mn, k0 + k);
-      if constexpr (KC) {
+      float2 v;
+      if constexpr (CHECK) v = src.finish(reg[p], mn0 + mn, k0 + k);
+      else v = src.plain(reg[p]);
+      if constexpr (KC && ROWK) {
+        st2(&Xs[mn * S + k], v);
+      } else if constexpr (KC) {
         Xs[k * S + mn] = v.x;
         Xs[(k + 1) * S + mn] = v.y;
       } else {
@@ -75,6 +83,19 @@ struct Stager {
     }
   }
 };
+
+// LDS floats of one stage of an operand tile (BMN x BK): [k][mn] rows (pitch BMN, + 1 when the source is K-contiguous and
+// stored transposed), or with ROWK and a K-contiguous source [mn][k] rows of pitch BK + 4
+template <int BMN, int BK, bool KC, bool ROWK>
+struct OperandImage {
+  static constexpr bool kRows = KC && ROWK;
+  static constexpr int kPitch = kRows ? BK + 4 : BMN + (KC ? 1 : 0);
+  static constexpr int kFloats = kRows ? BMN * kPitch : BK * kPitch;
+};
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool ROWK>
+constexpr int gemm_stage_floats() {
+  return OperandImage<BM, BK, A_KC, ROWK>::kFloats + OperandImage<BN, BK, B_KC, ROWK>::kFloats;
+}
 
 // acc += A[m0 : m0+BM, k_begin : k_end) * B[k_begin : k_end), n0 : n0+BN].  All 256 threads call it; it
 // ends on a barrier, so the LDS ring may be reused immediately by the next call.
@@ -98,18 +119,36 @@ struct NoStageHook {
 // SWAP_AB: feed the B fragment as the instruction's A operand and vice versa -- the accumulator block then holds the
 // TRANSPOSED 32x32 tile (lane: column = its A-tile row index, 16 rows = B-tile column indices), which turns a reduction
 // over the B-side index into an in-lane sum (dh2 of the rank-folded bilinear backward).
-template <int BM, int BN, int BK, int PF, bool A_KC, bool B_KC, bool SWAP_AB = false, class SrcA, class SrcB,
-          class Hook = NoStageHook>
+// ROWK / FAST (the grouped head's kernel).  Ablation builds of a 4 x [512,310,2400] phase (56 us with its epilogue launch, 22
+// of them fixed cost): K loop 35 us; without the staging pass's LDS stores (and the bounds arithmetic that feeds them) 21 us --
+// the MFMAs alone are 19.4; without the global loads instead 29 us; without the barriers: no change.  So the loop pays ~8 us
+// for the store side of the staging pass and ~6 us waiting for loads, not for fragment reads or barriers.
+//   ROWK: a K-contiguous source stored transposed costs two 4-byte stores a row apart per slot.  ROWK keeps such an operand in
+//     its own orientation ([mn][k], pitch BK + 4: one 8-byte store per slot) and lets lane half h of the 32x32x2 MFMAs take the
+//     contraction steps k = (BK/2) h + kp instead of 2 kp + h, so that a lane's BK/2 fragment values are CONSECUTIVE floats of
+//     its row: two ds_read_b128 (conflict-free at that pitch) instead of eight ds_read_b32.  An MN-contiguous operand keeps
+//     the [k][mn] image and follows the same k order through its addresses.
+//   FAST: an interior tile skips the per-slot bounds selects (see the end of the function).
+// Measured on the CoR2 step (grouped GEMM launches per step): 0.350 ms -> 0.337 with both (either one alone: 0.345-0.350).
+template <int BM, int BN, int BK, int PF, bool A_KC, bool B_KC, bool SWAP_AB = false, bool ROWK = false, bool FAST = false,
+          class SrcA, class SrcB, class Hook = NoStageHook>
 __device__ __forceinline__ void gemm_tile(const SrcA& srcA, const SrcB& srcB, int m0, int n0, int k_begin, int k_end,
                                           float* smem, f32x16 (&acc)[BM / 64][BN / 64],
                                           float* a_colsum = nullptr, Hook hook = Hook()) {
   using T = GemmTile<BM, BN, BK, A_KC, B_KC>;
   using StA = Stager<BM, BK, A_KC>;
   using StB = Stager<BN, BK, B_KC>;
+  using ImA = OperandImage<BM, BK, A_KC, ROWK>;
+  using ImB = OperandImage<BN, BK, B_KC, ROWK>;
+  constexpr int kStage = ImA::kFloats + ImB::kFloats;      // (== T::kStageFloats without ROWK)
+  static_assert(!ROWK || BK == 16, "ROWK: a lane half's BK/2 = 8 steps are two 16-byte reads");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int a_off = (lane >> 5) * T::SA + wm * (T::TM * 32) + (lane & 31);
-  const int b_off = (lane >> 5) * T::SB + wn * (T::TN * 32) + (lane & 31);
+  // offset of (the lane's row / column, its first contraction step) in an operand image; ROWK: steps (BK/2) h .. + BK/2 - 1
+  const int a_off = ImA::kRows ? (wm * (T::TM * 32) + (lane & 31)) * ImA::kPitch + (BK / 2) * (lane >> 5)
+                               : (ROWK ? (BK / 2) : 1) * (lane >> 5) * ImA::kPitch + wm * (T::TM * 32) + (lane & 31);
+  const int b_off = ImB::kRows ? (wn * (T::TN * 32) + (lane & 31)) * ImB::kPitch + (BK / 2) * (lane >> 5)
+                               : (ROWK ? (BK / 2) : 1) * (lane >> 5) * ImB::kPitch + wn * (T::TN * 32) + (lane & 31);
   const int nsteps = (k_end - k_begin + BK - 1) / BK;
   // Pipeline (PF register sets in flight, two LDS stages, one barrier per stage):
   //   stage s:  read all fragments of LDS[s&1]  ->  MFMA chain of stage s, with, in the shadow of the MFMAs,
@@ -124,8 +163,8 @@ __device__ __forceinline__ void gemm_tile(const SrcA& srcA, const SrcB& srcB, in
   if (nsteps > 0) {
     StA::load(ra[0], srcA, m0, k_begin, tid);
     StB::load(rb[0], srcB, n0, k_begin, tid);
-    StA::store(ra[0], srcA, m0, k_begin, smem, T::SA, tid);
-    StB::store(rb[0], srcB, n0, k_begin, smem + BK * T::SA, T::SB, tid);
+    StA::template store<ROWK>(ra[0], srcA, m0, k_begin, smem, ImA::kPitch, tid);
+    StB::template store<ROWK>(rb[0], srcB, n0, k_begin, smem + ImA::kFloats, ImB::kPitch, tid);
 #pragma unroll
     for (int t = 1; t <= PF; ++t) {  // stage t -> set t % PF  (clamped loads: harmless past the end)
       StA::load(ra[t % PF], srcA, m0, k_begin + t * BK, tid);
@@ -133,17 +172,39 @@ __device__ __forceinline__ void gemm_tile(const SrcA& srcA, const SrcB& srcB, in
     }
   }
   __syncthreads();
-  auto stage = [&](int s, auto set_c) {
+  auto stage = [&](int s, auto set_c, auto check_c) {
     constexpr int q = decltype(set_c)::value;  // set holding stage s+1
-    const float* As = smem + (s & 1) * T::kStageFloats;
-    const float* Bs = As + BK * T::SA;
+    constexpr bool CHECK = decltype(check_c)::value != 0;
+    const float* As = smem + (s & 1) * kStage;
+    const float* Bs = As + ImA::kFloats;
     float a[BK / 2][T::TM], b[BK / 2][T::TN];
+    if constexpr (ImA::kRows) {
 #pragma unroll
-    for (int kp = 0; kp < BK / 2; ++kp) {
+      for (int i = 0; i < T::TM; ++i)
 #pragma unroll
-      for (int i = 0; i < T::TM; ++i) a[kp][i] = As[kp * 2 * T::SA + a_off + i * 32];
+        for (int q = 0; q < BK / 8; ++q) {
+          const float4 t = ld4(As + a_off + i * 32 * ImA::kPitch + 4 * q);
+          a[4 * q][i] = t.x, a[4 * q + 1][i] = t.y, a[4 * q + 2][i] = t.z, a[4 * q + 3][i] = t.w;
+        }
+    } else {
 #pragma unroll
-      for (int j = 0; j < T::TN; ++j) b[kp][j] = Bs[kp * 2 * T::SB + b_off + j * 32];
+      for (int kp = 0; kp < BK / 2; ++kp)
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i) a[kp][i] = As[kp * (ROWK ? 1 : 2) * ImA::kPitch + a_off + i * 32];
+    }
+    if constexpr (ImB::kRows) {
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+          const float4 t = ld4(Bs + b_off + j * 32 * ImB::kPitch + 4 * q);
+          b[4 * q][j] = t.x, b[4 * q + 1][j] = t.y, b[4 * q + 2][j] = t.z, b[4 * q + 3][j] = t.w;
+        }
+    } else {
+#pragma unroll
+      for (int kp = 0; kp < BK / 2; ++kp)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) b[kp][j] = Bs[kp * (ROWK ? 1 : 2) * ImB::kPitch + b_off + j * 32];
     }
     __builtin_amdgcn_sched_barrier(0);  // fragment reads stay above; everything below is interleaved by the groups
 #pragma unroll
@@ -164,10 +225,10 @@ __device__ __forceinline__ void gemm_tile(const SrcA& srcA, const SrcB& srcB, in
       // Unconditional on purpose: a branch here would split the basic block and nothing could be interleaved with
       // the MFMAs.  Past the last stage the loads hit clamped (valid) addresses, `finish` zero-fills, and the
       // LDS stage written is not read again before the next call's prologue overwrites it.
-      float* An = smem + ((s + 1) & 1) * T::kStageFloats;
+      float* An = smem + ((s + 1) & 1) * kStage;
       const int k_next = k_begin + (s + 1) * BK;
-      StA::store(ra[q], srcA, m0, k_next, An, T::SA, tid);
-      StB::store(rb[q], srcB, n0, k_next, An + BK * T::SA, T::SB, tid);
+      StA::template store<ROWK, CHECK>(ra[q], srcA, m0, k_next, An, ImA::kPitch, tid);
+      StB::template store<ROWK, CHECK>(rb[q], srcB, n0, k_next, An + ImA::kFloats, ImB::kPitch, tid);
       StA::load(ra[q], srcA, m0, k_next + PF * BK, tid);
       StB::load(rb[q], srcB, n0, k_next + PF * BK, tid);
     }
@@ -181,21 +242,34 @@ __device__ __forceinline__ void gemm_tile(const SrcA& srcA, const SrcB& srcB, in
     }
     __syncthreads();
   };
-  for (int s = 0; s < nsteps; s += PF) {
-    stage(s, IntC<1 % PF>{});
-    hook(s);
-    if constexpr (PF > 1) {
-      if (s + 1 < nsteps) {
-        stage(s + 1, IntC<2 % PF>{});
-        hook(s + 1);
+  auto loop = [&](auto check_c) {
+    for (int s = 0; s < nsteps; s += PF) {
+      stage(s, IntC<1 % PF>{}, check_c);
+      hook(s);
+      if constexpr (PF > 1) {
+        if (s + 1 < nsteps) {
+          stage(s + 1, IntC<2 % PF>{}, check_c);
+          hook(s + 1);
+        }
+      }
+      if constexpr (PF > 2) {
+        if (s + 2 < nsteps) {
+          stage(s + 2, IntC<3 % PF>{}, check_c);
+          hook(s + 2);
+        }
       }
     }
-    if constexpr (PF > 2) {
-      if (s + 2 < nsteps) {
-        stage(s + 2, IntC<3 % PF>{});
-        hook(s + 2);
-      }
-    }
+  };
+  if constexpr (FAST) {
+    // FAST (sources with covers() / plain()): an interior tile -- whole rows, whole columns, a contraction range of whole
+    // stages inside both operands -- runs the loop without the staging pass's bounds arithmetic: next to fp32 MFMAs those
+    // VALU instructions are not free (workgroup-uniform choice; the stage written past the last one is never read)
+    if (srcA.covers(m0, BM, k_begin, k_end) && srcB.covers(n0, BN, k_begin, k_end) && (k_end - k_begin) % BK == 0)
+      loop(IntC<0>{});
+    else
+      loop(IntC<1>{});
+  } else {
+    loop(IntC<1>{});
   }
 }
 
@@ -232,6 +306,8 @@ struct SrcKC {  // X[mn][k], K-contiguous rows of stride ld.  Needs MN >= 1, K >
   int ld, MN, K;
   __device__ __forceinline__ Raw fetch(int mn, int k) const { return ld2(p + (size_t)min(mn, MN - 1) * ld + min(k, K - 2)); }
   __device__ __forceinline__ float2 finish(Raw v, int mn, int k) const { return keep_if(mn < MN && k < K, v); }
+  __device__ __forceinline__ float2 plain(Raw v) const { return v; }
+  __device__ __forceinline__ bool covers(int mn0, int n, int k0, int k1) const { return mn0 + n <= MN && k1 <= K; }
 };
 struct SrcMC {  // X[k][mn], MN-contiguous rows of stride ld.  Needs K >= 1, MN >= 2 (even).
   using Raw = float2;
@@ -239,6 +315,8 @@ struct SrcMC {  // X[k][mn], MN-contiguous rows of stride ld.  Needs K >= 1, MN 
   int ld, MN, K;
   __device__ __forceinline__ Raw fetch(int mn, int k) const { return ld2(p + (size_t)min(k, K - 1) * ld + min(mn, MN - 2)); }
   __device__ __forceinline__ float2 finish(Raw v, int mn, int k) const { return keep_if(mn < MN && k < K, v); }
+  __device__ __forceinline__ float2 plain(Raw v) const { return v; }
+  __device__ __forceinline__ bool covers(int mn0, int n, int k0, int k1) const { return mn0 + n <= MN && k1 <= K; }
 };
 
 // Tried and rejected (round 1, measured with tools/kbench.py): BK = 32 (no gain at K = 310, fewer workgroups per CU);

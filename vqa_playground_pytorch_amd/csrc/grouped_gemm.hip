@@ -76,6 +76,8 @@ struct SrcKC1 {  // X[mn][k], K-contiguous rows of stride ld; any alignment, any
   __device__ __forceinline__ float2 finish(Raw v, int mn, int k) const {
     return make_float2(mn < MN && k < K ? v.a : 0.f, mn < MN && k + 1 < K ? v.b : 0.f);
   }
+  __device__ __forceinline__ float2 plain(Raw v) const { return make_float2(v.a, v.b); }
+  __device__ __forceinline__ bool covers(int mn0, int n, int k0, int k1) const { return mn0 + n <= MN && k1 <= K; }
 };
 struct SrcMC1 {  // X[k][mn], MN-contiguous rows of stride ld; any alignment, any MN >= 1
   struct Raw {
@@ -90,6 +92,8 @@ struct SrcMC1 {  // X[k][mn], MN-contiguous rows of stride ld; any alignment, an
   __device__ __forceinline__ float2 finish(Raw v, int mn, int k) const {
     return make_float2(k < K && mn < MN ? v.a : 0.f, k < K && mn + 1 < MN ? v.b : 0.f);
   }
+  __device__ __forceinline__ float2 plain(Raw v) const { return make_float2(v.a, v.b); }
+  __device__ __forceinline__ bool covers(int mn0, int n, int k0, int k1) const { return mn0 + n <= MN && k1 <= K; }
 };
 
 template <int BM, int BK, int PF, bool A_KC, bool B_KC, class SrcA, class SrcB>
@@ -103,7 +107,7 @@ __device__ __forceinline__ void grouped_tile(const VqaGemmProblem& pr, const Src
 #pragma unroll
   for (int i = 0; i < TM; ++i) colsum[i] = 0.f;
   const bool want_colsum = (pr.colsum != nullptr || pr.colsum_out != nullptr) && n0 == 0;   // (wave-uniform; TN forms only)
-  gemm_tile<BM, kGBN, BK, PF, A_KC, B_KC>(sa, sb, m0, n0, k_begin, k_end, smem, acc, want_colsum ? colsum : nullptr);
+  gemm_tile<BM, kGBN, BK, PF, A_KC, B_KC, false, BK == 16, true>(sa, sb, m0, n0, k_begin, k_end, smem, acc, want_colsum ? colsum : nullptr);
   const AccCoord<BM, kGBN> cc(m0, n0);
   const int col = cc.col(0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -410,12 +414,14 @@ extern "C" int vqa_grouped_gemm(const VqaGemmProblem* problems, int n, vqa_strea
   const auto launch = [&](auto kernel, size_t lds) {
     hipLaunchKernelGGL(kernel, dim3(items), dim3(kGemmThreads), lds, static_cast<hipStream_t>(stream), g, items);
   };
-  // LDS: the largest of the three operand forms
-  if (bm == 128) launch(grouped_gemm_kernel<128, 16, 2>, GemmTile<128, kGBN, 16, true, true>::kSmemBytes);
-  else if (bk == 16 && pf == 2) launch(grouped_gemm_kernel<64, 16, 2>, GemmTile<64, kGBN, 16, true, true>::kSmemBytes);
-  else if (bk == 16) launch(grouped_gemm_kernel<64, 16, 3>, GemmTile<64, kGBN, 16, true, true>::kSmemBytes);
-  else if (pf == 2) launch(grouped_gemm_kernel<64, 32, 2>, GemmTile<64, kGBN, 32, true, true>::kSmemBytes);
-  else launch(grouped_gemm_kernel<64, 32, 3>, GemmTile<64, kGBN, 32, true, true>::kSmemBytes);
+  // LDS: the largest of the three operand forms (both operands K-contiguous; with the 16-deep step in their own orientation)
+#define VQA_GG_LDS(BM_, BK_) (2 * gemm_stage_floats<BM_, kGBN, BK_, true, true, BK_ == 16>() * sizeof(float))
+  if (bm == 128) launch(grouped_gemm_kernel<128, 16, 2>, VQA_GG_LDS(128, 16));
+  else if (bk == 16 && pf == 2) launch(grouped_gemm_kernel<64, 16, 2>, VQA_GG_LDS(64, 16));
+  else if (bk == 16) launch(grouped_gemm_kernel<64, 16, 3>, VQA_GG_LDS(64, 16));
+  else if (pf == 2) launch(grouped_gemm_kernel<64, 32, 2>, VQA_GG_LDS(64, 32));
+  else launch(grouped_gemm_kernel<64, 32, 3>, VQA_GG_LDS(64, 32));
+#undef VQA_GG_LDS
   return check_launch("grouped_gemm");
 }
 
