@@ -547,6 +547,9 @@ def _shadow(master, shape, tag, dtype=torch.bfloat16):
     return buf
 
 
+PACK_BLOCK = 1024      # VQA_PACK_BLOCK (include/vqa_mi355x.h)
+
+
 class ShadowPlan:
     """Every bf16 / padded-fp32 shadow a model's mixed-precision forward + backward reads, packed from the fp32 masters by
     ONE kernel per step (vqa_pack_many) instead of one pack kernel -- plus a bias copy -- per weight and layout (11 + 11
@@ -583,10 +586,12 @@ class ShadowPlan:
                 r, c = (1, src.numel()) if src.dim() == 1 else (src.shape[0], src.numel() // src.shape[0])
                 rows.append([src.data_ptr(), dst.data_ptr() + off * dst.element_size(), r, c, rs, cs,
                              0 if dst.dtype == torch.bfloat16 else 1, first])
-                first += r * c
+                # numbers a job takes: its elements -- a transposed one: its 32 x 32 tiles x 1024 (include/vqa_mi355x.h)
+                total = first + (-(-r // 32) * -(-c // 32) * PACK_BLOCK if (rs == 1 and cs != 1) else r * c)
+                first = -(-total // PACK_BLOCK) * PACK_BLOCK      # every job starts on a multiple of VQA_PACK_BLOCK
             dev = self.jobs[0][0].device
             self._table = torch.tensor(rows, dtype=torch.int64).to(dev)
-            self._total = first
+            self._total = total
             self._key = key
         _launch("pack_many", (len(self.jobs), self._total), _lib.lib().vqa_pack_many, _p(self._table), len(self.jobs),
                 self._total)
