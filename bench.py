@@ -147,7 +147,7 @@ PMC_KERNELS = {  # C-ABI entry -> [(kernel-name prefix, fetch multiplier)]
     "softmax_attention_pool_bwd": [("vqa::attention_pool_bwd_stream_kernel", 2.0)],
     "softmax_attention_pool_drop_fwd": [("vqa::attention_pool_fwd_kernel", 2.0)],
     "softmax_attention_pool_drop_bwd": [("vqa::attention_pool_bwd_stream_kernel", 2.0)],
-    "grouped_gemm": [("vqa::grouped_gemm_kernel<64>", 2.0)],
+    "grouped_gemm": [("vqa::grouped_gemm_kernel<64", 2.0)],
     "grouped_epilogue": [("vqa::grouped_epilogue_kernel", 2.0)],
 }
 _tables = {}
@@ -203,7 +203,7 @@ def roofline_entry(name, shape, launches, mean_ms, B, regions=REGIONS, bf16=Fals
         achieved, peak, unit = work / sec / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
     entry.update({"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
                   "frac": round(achieved / peak, 4),
-                  "traffic": pmc_traffic(name, shape[0]) if regions == REGIONS and not bf16 else None})
+                  "traffic": pmc_traffic(name, B) if regions == REGIONS and not bf16 else None})
     if name == "lowrank_bilinear_fusion_fwd" and K4_FOLDED and regions <= 112 and len(shape) >= 5 and shape[1] > 1:
         # `achieved` prices the kernel at SURVEY 8d's algorithmic FLOPs (R GEMMs per fusion).  The rank-folded kernel
         # executes 1/R of them on the matrix core, plus the padding of a sample to whole 16-region blocks and of L / H to
