@@ -657,7 +657,7 @@ def test_graph_replays_far_behind_the_host_keep_their_step_scalars():
     slot before the GPU has copied it: the weights after the queued steps equal those of the same steps run one by one."""
     from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
     v, q, a = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(8, answers=300, seed=71))
-    finals = []
+    updates = []
     for queued in (False, False, True):
         model = build("cor2", 300)                          # eval mode: no dropout
         tr = DataParallelTrainer(model, lr=1e-3, clip=0.25, gamma=0.9, graph=True)     # gamma 0.9: lr moves fast per step
@@ -665,6 +665,7 @@ def test_graph_replays_far_behind_the_host_keep_their_step_scalars():
             tr.step({"v": v, "q_idxes": q}, a)
         assert tr._graph is not None
         torch.cuda.synchronize()
+        start = tr.flat.p.clone()
         if queued:
             torch.cuda._sleep(int(2.4e9))                   # ~1 s: every replay below is enqueued behind it
         for _ in range(24):
@@ -672,15 +673,16 @@ def test_graph_replays_far_behind_the_host_keep_their_step_scalars():
             if not queued:
                 torch.cuda.synchronize()
         torch.cuda.synchronize()
-        finals.append(tr.flat.p.clone())
-    # two synchronised runs differ by the float atomics of the backward kernels (amplified by Adam where a gradient is
-    # near zero): that is the noise floor.  A rewritten ring slot would apply lr * 0.9^8 = 0.43 lr in a step: the summed
-    # update of the 24 steps (~9e-3 per weight) would move by tens of per cent, far above it.
-    noise = (finals[0] - finals[1]).abs().max().item()
-    diff = (finals[0] - finals[2]).abs().max().item()
-    # (one noise sample is itself noisy: the bound is the larger of 5 x it and 1e-4 -- a twentieth of what a stale slot does)
-    assert diff <= max(5.0 * noise, 1e-4), (diff, noise)
-    assert diff <= 1e-3, (diff, noise)
+        updates.append((tr.flat.p - start).double())
+    # Two synchronised runs differ by the float atomics of the small-batch backward kernels, which Adam amplifies to a full
+    # +-lr per step on the few weights whose gradient is near zero: element-wise that noise can reach the size of an update,
+    # in the norm of the 24 steps' summed update it is ~1e-3.  A rewritten ring slot would apply lr * 0.9^8 = 0.43 lr in
+    # EVERY weight's step: the summed update would move by tens of per cent in that norm.
+    scale = updates[0].norm().item()
+    noise = (updates[0] - updates[1]).norm().item() / scale
+    diff = (updates[0] - updates[2]).norm().item() / scale
+    assert diff <= max(5.0 * noise, 2e-2), (diff, noise)
+    assert noise <= 2e-2, noise
 
 
 def test_graph_trainer_respects_train_eval_switch():

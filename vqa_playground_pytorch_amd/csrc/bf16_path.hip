@@ -206,10 +206,9 @@ static int tn_splits(int Kdim, int N1, int N2, BfTileChoice t) {
   // Workgroups a launch aims for.  The 128x128 transposed-read tile holds 80 KB of LDS: ONE workgroup per CU, so the split
   // count is the largest that keeps the grid within one round of the 256 CUs (measured at K = 12800, B = 128 x 100 regions:
   // [320 x 2048] 48.1 -> 41.4 us, [1024 x 320] 28.1 -> 21.8 us against the former "at least 512 workgroups", and the slab
-  // reduction behind it shrinks with the split count); the smaller tiles fit two or more per CU.  VQA_BF16_TN_ITEMS overrides.
-  const char* opt = vqa::option("VQA_BF16_TN_ITEMS");
+  // reduction behind it shrinks with the split count); the smaller tiles fit two or more per CU.
   const bool one_per_cu = t.bm == 128 && t.bn == 128;
-  const long want = opt != nullptr && std::atol(opt) > 0 ? std::atol(opt) : (one_per_cu ? 256 : 512);
+  const long want = one_per_cu ? 256 : 512;
   long s = one_per_cu ? want / tiles : (want + tiles - 1) / tiles;
   const long max_by_rows = (Kdim + 511) / 512;  // keep >= 512 rows (8 stages) per split
   if (s > max_by_rows) s = max_by_rows;
@@ -272,8 +271,7 @@ static int launch_tn(const char* who, const bf16* A, int lda, const bf16* B, int
   const int tiles_m = (N1 + t.bm - 1) / t.bm, tiles_n = (N2 + t.bn - 1) / t.bn;
   int rows_per_split = (Kdim + S - 1) / S;
   rows_per_split = (rows_per_split + kBfBK - 1) / kBfBK * kBfBK;
-  const char* order = vqa::option("VQA_BF16_TN_ORDER");    // "n": always walk the column tiles first (comparison knob)
-  const int m_fast = (tiles_m < tiles_n && !(order != nullptr && order[0] == 'n')) ? tiles_m : 0;
+  const int m_fast = tiles_m < tiles_n ? tiles_m : 0;    // (measured: [320 x 2048], K = 12800: 41 -> 38.5 us)
   const char* form = vqa::option("VQA_BF16_TN");           // "perm": the register-transpose staging (comparison knob)
   const bool tr = !(form != nullptr && form[0] == 'p');
 #define LAUNCH_T(BM_, BN_, XB_, TR_)                                                                                        \
@@ -840,8 +838,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_fwd_bf16(const vqa_bf16_t* x, const v
   VQA_REQUIRE(aligned(x, 16) && aligned(w1, 16), VQA_E_UNSUPPORTED, "lowrank_bilinear_fusion_fwd_bf16: x/w1 must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int M = B * N;
-  static const bool two_rank_off = vqa::option("VQA_K4_BF16_TWO_RANK") != nullptr && vqa::option("VQA_K4_BF16_TWO_RANK")[0] == '0';
-  if (R == 2 && N >= 2 && M > 64 && !two_rank_off) {
+  if (R == 2 && N >= 2 && M > 64) {
     const size_t lds = BfTile<128, 128>::kSmemBytes + 128 * sizeof(int);
     VQA_ENSURE_LDS(bilinear_fwd2_bf16_kernel, lds);
     const int tm_ = (M + 127) / 128, tn_ = H / 64;

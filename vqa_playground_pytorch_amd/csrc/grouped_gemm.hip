@@ -24,15 +24,14 @@
 // K split; a phase's products together can (a few hundred 64x64 tiles x 2-8 splits), and the 2-6 launch-floor kernels
 // that used to surround each library GEMM (dropout, bias + activation, activation gradient + column sums, slices, adds)
 // become arithmetic in the one epilogue launch.
-#include <cstring>
-
 #include "gemm_f32_mfma.hpp"
 
 namespace vqa {
 
 constexpr int kGMaxProbs = VQA_GROUPED_MAX;
 constexpr int kGMaxGemms = VQA_GROUPED_GEMM_MAX;
-constexpr int kGBN = 64;   // tile rows BM: 64 (default) or 128; K step BK x register sets PF: VQA_GROUPED_PIPE; one value per launch
+constexpr int kGBN = 64, kGBK = 16, kGPF = 2;   // 64-column tiles, 16-deep K steps, two register sets in flight; tile rows
+                                                // BM: 64 (default) or 128 (VQA_GROUPED_BM), one value per launch
 
 struct GProbs {
   VqaGemmProblem p[kGMaxGemms];
@@ -364,15 +363,7 @@ extern "C" int vqa_grouped_gemm(const VqaGemmProblem* problems, int n, vqa_strea
   int items = 0;
   const char* tile = vqa::option("VQA_GROUPED_BM");     // tile rows: 64 (default) or 128
   const int bm = (tile != nullptr && std::atoi(tile) == 128) ? 128 : 64;
-  // K step x register sets in flight ("16x2" default, "16x3", "32x2", "32x3"): a global load has PF stages of BK/2 MFMAs per
-  // wave to land; 64-row tiles only
-  const char* pipe = vqa::option("VQA_GROUPED_PIPE");
-  int bk = 16, pf = 2;
-  if (pipe != nullptr && bm == 64) {
-    if (std::strcmp(pipe, "16x3") == 0) pf = 3;
-    else if (std::strcmp(pipe, "32x2") == 0) bk = 32;
-    else if (std::strcmp(pipe, "32x3") == 0) bk = 32, pf = 3;
-  }
+  constexpr int bk = kGBK;
   for (int i = 0; i < n; ++i) {
     VqaGemmProblem p = problems[i];
     VQA_REQUIRE(p.A && p.B && (p.slab || p.out), VQA_E_BADARG, "grouped_gemm[%d]: null pointer", i);
@@ -414,14 +405,11 @@ extern "C" int vqa_grouped_gemm(const VqaGemmProblem* problems, int n, vqa_strea
   const auto launch = [&](auto kernel, size_t lds) {
     hipLaunchKernelGGL(kernel, dim3(items), dim3(kGemmThreads), lds, static_cast<hipStream_t>(stream), g, items);
   };
-  // LDS: the largest of the three operand forms (both operands K-contiguous; with the 16-deep step in their own orientation)
-#define VQA_GG_LDS(BM_, BK_) (2 * gemm_stage_floats<BM_, kGBN, BK_, true, true, BK_ == 16>() * sizeof(float))
-  if (bm == 128) launch(grouped_gemm_kernel<128, 16, 2>, VQA_GG_LDS(128, 16));
-  else if (bk == 16 && pf == 2) launch(grouped_gemm_kernel<64, 16, 2>, VQA_GG_LDS(64, 16));
-  else if (bk == 16) launch(grouped_gemm_kernel<64, 16, 3>, VQA_GG_LDS(64, 16));
-  else if (pf == 2) launch(grouped_gemm_kernel<64, 32, 2>, VQA_GG_LDS(64, 32));
-  else launch(grouped_gemm_kernel<64, 32, 3>, VQA_GG_LDS(64, 32));
-#undef VQA_GG_LDS
+  // LDS: the largest of the three operand forms (both operands K-contiguous, in their own orientation)
+  if (bm == 128)
+    launch(grouped_gemm_kernel<128, kGBK, kGPF>, 2 * gemm_stage_floats<128, kGBN, kGBK, true, true, true>() * sizeof(float));
+  else
+    launch(grouped_gemm_kernel<64, kGBK, kGPF>, 2 * gemm_stage_floats<64, kGBN, kGBK, true, true, true>() * sizeof(float));
   return check_launch("grouped_gemm");
 }
 

@@ -890,13 +890,7 @@ static int launch_fwd(const float* vl, const float* ql, const float* w, const fl
       // nine T_i loads and pipeline fill.  The kernel is VALU-issue bound: what helps is an even wave count per SIMD, not
       // more waves.
       int nw = nsets < 8 ? (nsets < 4 ? nsets : 4) : 8;
-      int jt = 1;
-      // VQA_K2_FWD_WAVES / VQA_K2_FWD_JT (measurement knobs): waves per sample (<= 8) and slices of the region axis j
-      if (const char* e = vqa::option("VQA_K2_FWD_WAVES")) nw = std::atoi(e) >= 1 && std::atoi(e) <= 8 ? std::atoi(e) : nw;
-      if (const char* e = vqa::option("VQA_K2_FWD_JT")) jt = std::atoi(e) >= 1 && std::atoi(e) <= 9 ? std::atoi(e) : jt;
-      const int nj = ((N + jt - 1) / jt + 3) / 4 * 4;
-      jt = (N + nj - 1) / nj;
-      if (nw > nsets * jt) nw = nsets * jt;
+      const int jt = 1, nj = (N + 3) / 4 * 4;   // (one slice of the region axis j: see the kernel's note on work units)
       const size_t lds_m = (size_t)nw * 4 * kOdaIG * 4 * sizeof(float);
       if (bits)
         hipLaunchKernelGGL(oda_fwd_mfma_kernel<true>, dim3(B), dim3(64 * nw), lds_m, s, vl, ql, w, bias, logits, dc, N, L, G, jt, nj);

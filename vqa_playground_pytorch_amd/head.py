@@ -93,13 +93,12 @@ class Phase:
     # fewer than MIN_ITEMS items the parts are shortened until it has (256 CUs x 4 resident workgroups want >= ~2 per CU).
     # A product that ends up in ONE part and is the only contribution to its result is finished inside the GEMM kernel
     # (direct output: bias / activation / gate / dropout on the accumulators) and needs neither slab nor epilogue job.
-    # VQA_GROUPED_ITEMS / VQA_GROUPED_PART / VQA_GROUPED_BM (tile rows 64 | 128) / VQA_GROUPED_PIPE (K step x register sets
-    # in flight, "16x2" | "16x3" | "32x2" | "32x3"; the last two read by the library as well): measurement knobs.
+    # VQA_GROUPED_ITEMS / VQA_GROUPED_PART / VQA_GROUPED_BM (tile rows 64 | 128, read by the library as well): measurement knobs.
     MIN_ITEMS = int(os.environ.get("VQA_GROUPED_ITEMS", "512"))
     MAX_PART = int(os.environ.get("VQA_GROUPED_PART", "640"))
     TILE_M = 128 if os.environ.get("VQA_GROUPED_BM") == "128" else 64
     DIRECT = os.environ.get("VQA_GROUPED_DIRECT", "1") == "1"
-    STEP_K = 32 if os.environ.get("VQA_GROUPED_PIPE", "").startswith("32") and TILE_M == 64 else 16
+    STEP_K = 16        # the kernel's K step: a contraction part is a whole number of steps
 
     def __init__(self, device, name):
         self.device, self.name = device, name
