@@ -482,6 +482,23 @@ def test_lowrank_bilinear_fusion_large_batch_against_torch_fp64(ops, monkeypatch
         assert err <= 2e-5, "%s: %.2e" % (name, err)
 
 
+def test_relation_gates_match_autograd(ops):
+    """ops.RelationGates: (t, c2) = (q1 * pooled, q2) handed out twice; both consumers' gradients are combined by ONE kernel.
+    Against plain autograd on the same expression, with two, one and no second consumer."""
+    B, D = 6, 72
+    q1, q2, po = (seeded.seeded_array((B, D), 431 + i).astype(np.float32) for i in range(3))
+    w = [seeded.seeded_array((B, D), 441 + i).astype(np.float32) for i in range(4)]
+    for use in ((1, 1, 1, 1), (1, 1, 0, 0), (0, 1, 1, 0)):
+        a, b, c = g(q1, True), g(q2, True), g(po, True)
+        outs = ops.relation_gates(a, b, c)
+        sum(u * (o * g(wi)).sum() for u, o, wi in zip(use, outs, w)).backward()
+        a2, b2, c2 = g(q1, True), g(q2, True), g(po, True)
+        t = a2 * c2
+        sum(u * (o * g(wi)).sum() for u, o, wi in zip(use, (t, b2, t, b2), w)).backward()
+        for name, x, y in (("d_q1", a, a2), ("d_q2", b, b2), ("d_pooled", c, c2)):
+            close(name, x.grad, y.grad.cpu().numpy().astype(np.float64))
+
+
 # ----------------------------------------------------------------------------------------------- K2
 @pytest.mark.parametrize("B,N,L,G", [(2, 4, 6, 3), (3, 36, 310, 4), (2, 13, 70, 2), (1, 1, 5, 1), (2, 37, 100, 8)])
 def test_object_difference_no_dropout(ops, B, N, L, G):

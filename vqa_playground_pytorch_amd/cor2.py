@@ -216,8 +216,13 @@ class Model(nn.Module):
             # reach the attention maps as a per-glimpse constant, which the softmax backward cancels exactly.)  v2 is
             # materialised once, already dropped out for compress_v2 (K1 apply kernel); the second attention pools v
             # itself and maps the result: sum_n alpha2[n] v2[n] = t + q2 * sum_n alpha2[n] v[n].
-            t = q_gate_1 * pooled1_first
-            c2 = q_gate_2
+            # (t, c2) for the relation / projection node and (t_b, c2_b) -- the same values -- for the pooled map of the second
+            # attention: two handles, so that both gradients meet in ONE backward kernel (ops.RelationGates)
+            if q_gate_1.is_cuda and q_gate_1.dtype == torch.float32 and q_gate_1.numel() % 4 == 0:
+                t, c2, t_b, c2_b = ops.relation_gates(q_gate_1, q_gate_2, pooled1_first)
+            else:
+                t = t_b = q_gate_1 * pooled1_first
+                c2 = c2_b = q_gate_2
             p = self.compress_v2.p if (self.training and self.compress_v2.p) else 0.0
             if fused_node:
                 # relation step + projection as one autograd node: backward reduces the projection's data gradient to
@@ -235,7 +240,7 @@ class Model(nn.Module):
                                     packed=shad.get("fusion_vq2"), h2=h2_2)
             v2_att, alpha2, _ = self.att2.attend(v_feature, self.att2.conv_att.pre_activation(fuse2),
                                                  lambda pooled, pd: ops.relation_apply(
-                                                     pooled, t, c2, pd, ops.next_dropout_seed() if pd else 0),
+                                                     pooled, t_b, c2_b, pd, ops.next_dropout_seed() if pd else 0),
                                                  grouped=grouped)
             # the reference's v2_feature[:, [0, 1], :] (visu.py:198-207 reads it after an eval forward).  Eval: computed here,
             # like the reference does.  Training: a step never looks at it, so it is computed when read, from copies of the

@@ -160,6 +160,39 @@ __global__ __launch_bounds__(256) void dropout_groups_bwd_kernel(const float* __
 
 using namespace vqa;
 
+namespace vqa {
+// backward of (t, c) = (a * b, c) handed to TWO consumers each: d_a = (g1 + g2) b, d_b = (g1 + g2) a, d_c = h1 + h2
+// (g2 / h2 may be NULL).  One launch for what autograd would do in two accumulations and two products.
+__global__ __launch_bounds__(256) void gate_product_bwd_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                               const float* __restrict__ h1, const float* __restrict__ h2,
+                                                               const float* __restrict__ a, const float* __restrict__ b,
+                                                               float* __restrict__ d_a, float* __restrict__ d_b,
+                                                               float* __restrict__ d_c, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 g = ld4(g1 + 4 * i);
+  if (g2 != nullptr) g = add4(g, ld4(g2 + 4 * i));
+  float4 h = ld4(h1 + 4 * i);
+  if (h2 != nullptr) h = add4(h, ld4(h2 + 4 * i));
+  st4(d_a + 4 * i, mul4(g, ld4(b + 4 * i)));
+  st4(d_b + 4 * i, mul4(g, ld4(a + 4 * i)));
+  st4(d_c + 4 * i, h);
+}
+}  // namespace vqa
+
+extern "C" int vqa_gate_product_bwd(const float* g1, const float* g2, const float* h1, const float* h2, const float* a,
+                                    const float* b, float* d_a, float* d_b, float* d_c, size_t n, vqa_stream_t stream) {
+  VQA_REQUIRE(g1 && h1 && a && b && d_a && d_b && d_c, VQA_E_BADARG, "gate_product_bwd: null pointer");
+  VQA_REQUIRE(n > 0 && n % 4 == 0, VQA_E_UNSUPPORTED, "gate_product_bwd: n = %zu must be a positive multiple of 4", n);
+  VQA_REQUIRE(vqa::aligned(g1, 16) && vqa::aligned(h1, 16) && vqa::aligned(a, 16) && vqa::aligned(b, 16) && vqa::aligned(d_a, 16) &&
+                  vqa::aligned(d_b, 16) && vqa::aligned(d_c, 16) && (g2 == nullptr || vqa::aligned(g2, 16)) &&
+                  (h2 == nullptr || vqa::aligned(h2, 16)),
+              VQA_E_UNSUPPORTED, "gate_product_bwd: tensors must be 16-byte aligned");
+  hipLaunchKernelGGL(vqa::gate_product_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), g1, g2, h1, h2, a, b, d_a, d_b, d_c, n / 4);
+  return vqa::check_launch("gate_product_bwd");
+}
+
 extern "C" int vqa_bias_act(const float* y, const float* bias, int bias_stride, float* out, int G, int B, int A, int act,
                             int group_first, vqa_stream_t stream) {
   VQA_REQUIRE(y && out, VQA_E_BADARG, "bias_act: null pointer");

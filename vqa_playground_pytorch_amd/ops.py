@@ -1258,6 +1258,46 @@ def rank_product(h1, h2):
     return RankProduct.apply(h1, h2)
 
 
+class RelationGates(torch.autograd.Function):
+    """(q1, q2, pooled) -> (t, c2, t', c2') with t = q1 * pooled, c2 = q2: the two operands of the closed-form relation step
+    (config/CoR2.py:191-199, :216), handed out TWICE -- once for the relation / projection node, once for the second
+    attention's pooled map -- so that both consumers' gradients reach THIS node's backward together: one kernel
+    (vqa_gate_product_bwd) forms d q1 = (g + g') * pooled, d pooled = (g + g') * q1, d q2 = h + h' instead of autograd's two
+    accumulations and two products.  All [B,D] fp32."""
+
+    @staticmethod
+    def forward(ctx, q1, q2, pooled):
+        q1, q2, pooled = _prep("q1", q1), _prep("q2", q2), _prep("pooled", pooled)
+        if q1.shape != pooled.shape or q2.shape != pooled.shape or pooled.numel() % 4:
+            raise ValueError("relation_gates: q1, q2, pooled must share one shape with a multiple of 4 elements")
+        t = q1 * pooled
+        ctx.save_for_backward(q1, pooled)
+        return t, q2.view_as(q2), t.view_as(t), q2.view_as(q2)
+
+    @staticmethod
+    def backward(ctx, g1, h1, g2, h2):
+        q1, pooled = ctx.saved_tensors
+        if g1 is None:
+            g1, g2 = g2, None
+        if h1 is None:
+            h1, h2 = h2, None
+        if g1 is None:
+            g1 = torch.zeros_like(q1)
+        if h1 is None:
+            h1 = torch.zeros_like(q1)
+        g1, h1 = _prep("d_t", g1), _prep("d_c2", h1)
+        g2 = _prep("d_t'", g2) if g2 is not None else None
+        h2 = _prep("d_c2'", h2) if h2 is not None else None
+        d_q1, d_pooled, d_q2 = torch.empty_like(q1), torch.empty_like(q1), torch.empty_like(q1)
+        _launch("gate_product_bwd", (q1.numel(),), _lib.lib().vqa_gate_product_bwd, _p(g1), _p(g2), _p(h1), _p(h2), _p(q1),
+                _p(pooled), _p(d_q1), _p(d_pooled), _p(d_q2), q1.numel())
+        return d_q1, d_q2, d_pooled
+
+
+def relation_gates(q1, q2, pooled):
+    return RelationGates.apply(q1, q2, pooled)
+
+
 class WithFirstGroup(torch.autograd.Function):
     """pooled [B,G,D] -> (pooled, pooled[:,0]) for the two consumers of the first attention's pooled features (its own
     glimpse projections; the relation step, which reads glimpse 0).  Backward adds the slice gradient into a copy of
