@@ -90,11 +90,11 @@ class Phase:
 
     # How a phase is cut into work items (64x64 tile x contraction part).  No item is longer than MAX_PART contraction
     # steps (a phase mixes K = 155 .. 2400: the longest items would otherwise set the launch time), and when the phase has
-    # fewer than MIN_ITEMS items the parts are shortened until it has (256 CUs x 4 resident workgroups want >= ~2 per CU).
+    # fewer items than the target (see _size) the parts are shortened until it has.
     # A product that ends up in ONE part and is the only contribution to its result is finished inside the GEMM kernel
     # (direct output: bias / activation / gate / dropout on the accumulators) and needs neither slab nor epilogue job.
     # VQA_GROUPED_ITEMS / VQA_GROUPED_PART / VQA_GROUPED_BM (tile rows 64 | 128, read by the library as well): measurement knobs.
-    MIN_ITEMS = int(os.environ.get("VQA_GROUPED_ITEMS", "512"))
+    MIN_ITEMS = int(os.environ.get("VQA_GROUPED_ITEMS", "0"))     # 0: by the phase's rows (below)
     MAX_PART = int(os.environ.get("VQA_GROUPED_PART", "640"))
     TILE_M = 128 if os.environ.get("VQA_GROUPED_BM") == "128" else 64
     DIRECT = os.environ.get("VQA_GROUPED_DIRECT", "1") == "1"
@@ -122,9 +122,14 @@ class Phase:
         probs = [(t, p) for t in self.targets for p in t.problems]
         tiles = lambda t: math.ceil(t.M / self.TILE_M) * math.ceil(t.N / 64)  # noqa: E731
         part = self.MAX_PART
+        # work items a launch aims for: 512 (two per CU) at the training batch; a phase whose products have <= 128 rows (one
+        # rank's share of BASELINE configs[4]: 128 samples) holds one or two row tiles per product and needs deeper splits to
+        # fill the chip -- measured at B = 128: 768 / 1024 / 1536 / 2048 items -> 0.158 / 0.151 / 0.151 / 0.151 ms of grouped
+        # GEMM per step (512: 0.172), at B = 512: 768 / 1024 are 0.5 / 1 % slower than 512
+        min_items = self.MIN_ITEMS or (1024 if min(t.M for t in self.targets) <= 128 else 512)
         while True:
             items = sum(tiles(t) * math.ceil(p["K"] / part) for t, p in probs)
-            if items >= self.MIN_ITEMS or part <= 128:
+            if items >= min_items or part <= 128:
                 break
             part = max(128, part - 64)
         for t, p in probs:
