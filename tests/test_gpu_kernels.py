@@ -518,7 +518,8 @@ def test_object_difference_no_dropout(ops, B, N, L, G):
     close("d_bias", bt.grad, db)
 
 
-@pytest.mark.parametrize("B,N,L,G,p", [(3, 36, 310, 4, 0.5), (2, 13, 70, 2, 0.25), (130, 5, 64, 4, 0.5)])
+@pytest.mark.parametrize("B,N,L,G,p", [(3, 36, 310, 4, 0.5), (2, 13, 70, 2, 0.25), (130, 5, 64, 4, 0.5),
+                                       (180, 13, 200, 2, 0.5), (140, 36, 310, 4, 0.5)])   # the last two: the chunk-split data gradient
 def test_object_difference_with_dropout(ops, B, N, L, G, p):
     """The fused kernels regenerate the mask from (seed, index); export it and hand it to the oracle."""
     seed = 1234567
@@ -544,7 +545,7 @@ def test_object_difference_with_dropout(ops, B, N, L, G, p):
     assert 0.4 < (other == mask).mean() < 0.6 + abs(0.5 - p), "a different seed must give a different mask"
 
 
-@pytest.mark.parametrize("B,N,L,G,p", [(3, 36, 310, 4, 0.5), (2, 13, 70, 2, 0.25), (2, 36, 310, 4, 0.0)])
+@pytest.mark.parametrize("B,N,L,G,p", [(3, 36, 310, 4, 0.5), (2, 13, 70, 2, 0.25), (2, 36, 310, 4, 0.0), (180, 13, 200, 2, 0.5)])
 def test_object_difference_gated_region_gradient(ops, B, N, L, G, p):
     """gate_dvl: vl is a relu output (zeros where the layer in front was inactive) and d_vl comes back multiplied by
     (vl > 0) -- the gradient with respect to that layer's pre-activation; every other output is unchanged."""

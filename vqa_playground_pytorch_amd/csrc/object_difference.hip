@@ -516,6 +516,107 @@ __global__ void oda_bwd_data_bits_kernel(const float* __restrict__ vl, const flo
   }
 }
 
+// The same with the region chunks of a sample spread over the waves of a workgroup: grid (ceil(L/64), B), wave c = chunk
+// i0 = c kIC of the regions i, lane = feature d of the block.  The kernel above runs 5 waves per sample (one feature per lane,
+// three chunks each in turn): a CU's 10 waves sit 3/3/2/2 on its SIMDs and the busiest SIMD sets the time (VALU-issue bound:
+// >= 65 % of the busy SIMD-cycles).  Here a wave is a third of that work and a CU holds 15 of them: the same instruction
+// stream in pieces that spread evenly.  Every wave writes its own plane of partial sums (no read-modify-write in the j loop);
+// the planes meet in LDS, and the N output rows are split over the waves again.
+template <int G>
+__global__ void oda_bwd_data_bits_split_kernel(const float* __restrict__ vl, const float* __restrict__ ql,
+                                               const float* __restrict__ w, const float* __restrict__ dS,
+                                               float* __restrict__ d_vl, float* __restrict__ d_ql, DropCfg dc, int N, int L,
+                                               int gate) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NC = blockDim.x >> 6;                       // chunk waves = ceil(N / kIC)
+  float* dT_s = reinterpret_cast<float*>(smem);         // [NC][N][64]
+  float* dq_s = dT_s + (size_t)NC * N * 64;             // [NC][64]
+  float* dS_s = dq_s + NC * 64;                         // [N + kIC][G]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int c = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y;
+  const int d_raw = blockIdx.x * 64 + lane;
+  const bool active = d_raw < L;
+  const int d = active ? d_raw : L - 1;
+  const int NI = (N + 31) >> 5;
+  const uint32_t key = drop_key(dc);
+  const uint32_t stride = (uint32_t)N * (uint32_t)L;
+  const float* vlb = vl + (size_t)b * N * L;
+  for (int t = tid; t < (N + kIC) * G; t += blockDim.x) dS_s[t] = t < N * G ? dS[(size_t)b * N * G + t] : 0.f;
+  __syncthreads();
+  float* mine = dT_s + (size_t)c * N * 64 + lane;       // this wave's plane: row n at mine[n * 64]
+  {
+    const int i0 = c * kIC;
+    const int sh = i0 & 31;
+    const bool straddle = ((min(i0 + kIC, N) - 1) >> 5) != (i0 >> 5);
+    const uint32_t base = ((uint32_t)b * NI + (uint32_t)(i0 >> 5)) * stride;
+    f32x2 ds[kIC / 2][G], dTi[kIC / 2];
+#pragma unroll
+    for (int ip = 0; ip < kIC / 2; ++ip) {
+      dTi[ip] = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < G; ++g) ds[ip][g] = f32x2{dS_s[(i0 + 2 * ip) * G + g], dS_s[(i0 + 2 * ip + 1) * G + g]};
+    }
+    auto load_w = [&](float (&wr)[G], int j) {
+      const int jc = min(j, N - 1);
+#pragma unroll
+      for (int g = 0; g < G; ++g) wr[g] = w[((size_t)g * N + jc) * L + d];
+    };
+    auto one_j = [&](int j, const float (&wv)[G]) {
+      const uint32_t bits = oda_bits(base + (uint32_t)(j * L + d), stride, sh, straddle, key);
+      f32x2 u[kIC / 2];
+#pragma unroll
+      for (int ip = 0; ip < kIC / 2; ++ip) u[ip] = ds[ip][0] * f32x2{wv[0], wv[0]};
+#pragma unroll
+      for (int g = 1; g < G; ++g)
+#pragma unroll
+        for (int ip = 0; ip < kIC / 2; ++ip) u[ip] = __builtin_elementwise_fma(ds[ip][g], f32x2{wv[g], wv[g]}, u[ip]);
+      f32x2 pj = f32x2{0.f, 0.f};
+      static_for<kIC / 2>([&](auto ip_) {
+        constexpr int ip = decltype(ip_)::value;
+        const f32x2 m = f32x2{keep_bit<2 * ip>(u[ip].x, bits), keep_bit<2 * ip + 1>(u[ip].y, bits)};
+        dTi[ip] += m;
+        pj += m;
+      });
+      mine[j * 64] = -(pj.x + pj.y);
+    };
+    float wa[G], wb[G], wc[G];
+    load_w(wa, 0);
+    load_w(wb, 1);
+    load_w(wc, 2);
+    for (int j = 0; j < N; j += 3) {
+      one_j(j, wa);
+      load_w(wa, j + 3);
+      if (j + 1 < N) one_j(j + 1, wb);
+      load_w(wb, j + 4);
+      if (j + 2 < N) one_j(j + 2, wc);
+      load_w(wc, j + 5);
+    }
+#pragma unroll
+    for (int ip = 0; ip < kIC / 2; ++ip) {      // (the wave's own column of its own plane: written above, by this lane)
+      if (i0 + 2 * ip < N) mine[(i0 + 2 * ip) * 64] += dTi[ip].x;
+      if (i0 + 2 * ip + 1 < N) mine[(i0 + 2 * ip + 1) * 64] += dTi[ip].y;
+    }
+  }
+  __syncthreads();
+  const float qd = ql[(size_t)b * L + d] * dc.scale;      // (the kept values' factor 2 rides on q here)
+  float dq = 0.f;
+  for (int n = c; n < N; n += NC) {                       // the output rows, dealt over the waves
+    float t = 0.f;
+    for (int q = 0; q < NC; ++q) t += dT_s[((size_t)q * N + n) * 64 + lane];    // fixed order
+    const float vn = vlb[(size_t)n * L + d];
+    if (active) d_vl[((size_t)b * N + n) * L + d] = (gate != 0 && !(vn > 0.f)) ? 0.f : t * qd;
+    dq = fmaf(t, vn, dq);
+  }
+  dq_s[c * 64 + lane] = dq;
+  __syncthreads();
+  if (c == 0 && active) {
+    float s = 0.f;
+    for (int q = 0; q < NC; ++q) s += dq_s[q * 64 + lane];
+    d_ql[(size_t)b * L + d] = s * dc.scale;
+  }
+}
+
 // backward d_w slabs, bit mask: as oda_bwd_weight_kernel; the hash words of the chunk's kIC regions j are drawn once per
 // 32 regions i
 template <int G>
@@ -921,7 +1022,14 @@ static int launch_bwd(const float* vl, const float* ql, const float* w, const fl
   {
     const size_t lds = ((size_t)N * nt + (size_t)(N + kIC) * G) * sizeof(float);   // (+ kIC zero rows of dS, bit-mask kernel)
     VQA_REQUIRE(lds <= 160 * 1024, VQA_E_UNSUPPORTED, "object_difference_attention_bwd: N=%d L=%d need %zu B of LDS", N, L, lds);
-    if (oda_bits_mode(dc, B, N, L)) {
+    static const bool split_off = vqa::option("VQA_K2_DATA_SPLIT") != nullptr && vqa::option("VQA_K2_DATA_SPLIT")[0] == '0';
+    const int nc = (N + kIC - 1) / kIC;
+    if (oda_bits_mode(dc, B, N, L) && nc <= 4 && !split_off && (long)B * ((L + 63) / 64) >= 512) {
+      const size_t lds_s = ((size_t)nc * N * 64 + (size_t)nc * 64 + (size_t)(N + kIC) * G) * sizeof(float);
+      VQA_ENSURE_LDS((oda_bwd_data_bits_split_kernel<G>), lds_s);
+      hipLaunchKernelGGL((oda_bwd_data_bits_split_kernel<G>), dim3((L + 63) / 64, B), dim3(64 * nc), lds_s, s, vl, ql, w, dS,
+                         d_vl, d_ql, dc, N, L, gate_dvl);
+    } else if (oda_bits_mode(dc, B, N, L)) {
       VQA_ENSURE_LDS((oda_bwd_data_bits_kernel<G>), lds);
       hipLaunchKernelGGL((oda_bwd_data_bits_kernel<G>), dim3(B), dim3(nt), lds, s, vl, ql, w, dS, d_vl, d_ql, dc, N, L, gate_dvl);
     } else if (dc.p8 > 0) {
