@@ -2,7 +2,7 @@
 """Per-kernel micro-benchmark of libvqa_mi355x.so at the BASELINE shapes (B=512, N=36, D=2048, L=310, H=510, G=4, R=2).
 Interleaved rounds in ONE process (guide rule 24); prints median / min per variant and the roofline fraction.
 
-    python tools/kbench.py [--only k4fwd,k4bwd,k1,k2,k3,k3a,k5] [--tiles 128x128,64x64] [--rounds 20]
+    python tools/kbench.py [--only k4fwd,k4bwd,k1,k2,k3,k3a,k5 | bf16 | head] [--tiles 128x128,64x64] [--rounds 20]
 """
 import argparse
 import os
@@ -79,6 +79,44 @@ def bf16_section(rounds):
             print("  %-22s median %7.1f us  %7.1f TF/s (%.1f%% of 2500)" % (key, med * 1e3, 2.0 * kd * n1 * n2 / med / 1e9, 2.0 * kd * n1 * n2 / med / 1e9 / 25))
 
 
+def head_section(rounds):
+    """Grouped phases of the [B,.] layers (head.py: one grouped GEMM launch + one grouped epilogue launch) against the same
+    layers on torch / library GEMMs, B = 512, forward only, GPU-side time (each batch of calls is queued behind a device-side
+    sleep: the Python cost of a phase is larger than its kernels)."""
+    from vqa_playground_pytorch_amd import head
+    Bh = 512
+    q = torch.randn(Bh, 2400, device=dev)
+    ws = [torch.randn(310, 2400, device=dev) / 49 for _ in range(4)]
+    bs = [torch.zeros(310, device=dev) for _ in range(4)]
+    x = torch.randn(Bh, 510, device=dev)
+    wc, bc = torch.randn(2000, 510, device=dev) / 22, torch.zeros(2000, device=dev)
+    wcat, bcat = torch.cat(ws), torch.cat(bs)
+
+    def gpu_time(f, n=30):
+        for _ in range(3):
+            f()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(48_000_000)
+        a.record()
+        for _ in range(n):
+            f()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n * 1e3
+
+    cases = {
+        "4 x [512,2400]->310 + bias + relu   grouped     ": lambda: head.QuestionProjections.apply(q, 0.0, 0, (), 0.0, 0, (), *ws, *bs),
+        "   (as ONE [512,2400]->1240 GEMM)    torch       ": lambda: torch.relu(torch.nn.functional.linear(q, wcat, bcat)),
+        "[512,510]->2000 + bias               grouped     ": lambda: head.Classifier.apply(x, wc, bc, 0.0, 0),
+        "                                     torch linear": lambda: torch.nn.functional.linear(x, wc, bc),
+    }
+    print("== grouped head phases vs library, B = %d (us per phase, median of %d rounds)" % (Bh, rounds))
+    with torch.no_grad():
+        for name, f in cases.items():
+            print("  %s %7.1f" % (name, statistics.median(gpu_time(f) for _ in range(rounds))))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -88,6 +126,8 @@ def main():
     only = set(filter(None, args.only.split(",")))
     if only == {"bf16"}:
         return bf16_section(args.rounds)
+    if only == {"head"}:
+        return head_section(min(args.rounds, 5))
     want = lambda k: not only or k in only  # noqa: E731
     tiles = args.tiles.split(",")
     torch.manual_seed(0)
