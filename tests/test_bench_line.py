@@ -1,0 +1,110 @@
+"""bench.py's stdout contract: ONE compact JSON line under 2000 bytes that still carries `roofline` and `cpu_baseline`
+(the round-3 line grew to 21 KB and the driver recorded `parsed: null`), and the (kernel, grid) look-up of the committed
+counter tables."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+
+def _canned(world=1):
+    entry = {"kernel": "linear_act_fwd", "shape": [18432, 2048, 310, True], "launches": 10, "mean_ms": 0.21901,
+             "bound": "mfma", "achieved": 106.83, "peak": 157.3, "unit": "TFLOP/s", "frac": 0.6791, "traffic": 196012345,
+             "ms_per_step": 0.21901, "mfma_busy_pct": 77.12,
+             "mfma_counters": {"SQ_BUSY_CYCLES": 1.0e7, "SQ_INSTS_MFMA": 5.0e6, "SQ_VALU_MFMA_BUSY_CYCLES": 3.0e8,
+                               "launches": 8, "key": "vqa::rt::gemm_nt_kernel<9, 5, 1, 2, 2, true, vqa::EpiBiasAct, 0>|grid=65536"},
+             "device_kernels": [["(rt::gemm_nt_kernel<9, 5, 1, 2, 2, true, EpiBiasAct>)", 65536]]}
+    sub = {"metric": "m" * 90, "value": 462553.0, "unit": "samples/s", "ms_per_step": 1.107, "dtype": "f32", "steps": 20,
+           "warmup": 5, "roofline": dict(entry, shapes=[[1] * 6] * 3), "step_coverage": {"timed_ops_ms": 1.0},
+           "workload": "w" * 200, "launch": "hipGraph replay (2 graphs + eager all-reduce)", "command": "bench.py --model oda",
+           "wall_s": 9.1}
+    full = {
+        "metric": "VQA samples/sec (fwd+bwd), CoR2 batch 512, 36x2048 regions", "value": 214712.3, "unit": "samples/s",
+        "n_gpus": world, "steps": 20, "warmup": 5, "ms_per_step": 2.385, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "CoR2 fwd+bwd fp32, batch 512/GPU, 36x2048 regions + 2400-d question, 2-step chain, 2000 "
+                               "answers (BASELINE configs[1]; configs[3] at 8 GPUs)", "global_batch": 512 * world,
+                   "step": "s" * 120, "parallelism": "dp%d" % world, "launch": "hipGraph replay (2 graphs + eager all-reduce)",
+                   "relation_mode": "factored", "library_gemms": "x" * 300,
+                   "inputs": "1 resident batch re-read every step; over 4 rotating batches (+1 device copy/step): -1.7%, see "
+                             "rotating_inputs", "inputs_note": "n" * 400},
+        "final_loss": 970.1, "final_grad_norm": 3.2,
+        "roofline": dict(entry, shapes=[[18432, 2048, 310, True], [18432, 2048, 310, False]],
+                         device_kernels=["vqa::rt::gemm_nt_kernel<9, 5, 1, 2, 2"]),
+        "traffic_source": "t" * 200, "step_coverage": {"timed_ops_ms": 2.6, "of_ms_per_step": 1.09},
+        "roofline_all": [dict(entry, kernel="op%d" % i) for i in range(70)],
+        "rotating_inputs": {"batches": 4, "value": 211096.7, "unit": "samples/s", "ms_per_step": 2.425, "note": "n" * 100},
+        "sub_records": {tag: dict(sub) for tag, _ in bench.SUB_RECORDS},
+        "cpu_baseline": {"value": 49.13, "unit": "samples/s", "cores": 16, "kind": "port", "host_cores": 256,
+                         "sample": "CoR2 fwd+bwd (KLD-sum loss, dropout on), batch 16 x 31 steps after 1 warm-up; "
+                                   "reference-faithful torch-CPU port; 16 threads of 256 host cores",
+                         "all_runs": [{"cores": 16, "value": 49.13, "sample": "s" * 200}] * 2},
+    }
+    if world > 1:
+        full["distributed"] = {"nranks": world, "backend": "nccl", "allreduce_payload_bytes": 47760976,
+                               "allreduce_ms_alone": 0.412, "allreduce_busbw_GBs": 202.9, "per_rank_samples_per_s": 200000.0,
+                               "overlap": False}
+    full["sub_records"]["oda_b512"] = {"error": "rc=1 " + "e" * 300}
+    return full
+
+
+def test_compact_line_is_small_and_complete(tmp_path, capsys):
+    for world in (1, 8):
+        full = _canned(world)
+        assert len(json.dumps(full)) > 20000                     # the record that used to be printed whole
+        bench.emit(full, str(tmp_path / "bench_detail.json"))
+        out, err = capsys.readouterr()
+        lines = [ln for ln in out.splitlines() if ln.strip()]
+        assert len(lines) == 1 and len(lines[0]) < bench.COMPACT_LIMIT
+        line = json.loads(lines[0])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                    "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert key in line, key
+        assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "mean_ms", "launches",
+                    "mfma_busy_pct")) <= set(line["roofline"])
+        assert set(("value", "unit", "cores", "kind", "sample", "host_cores")) <= set(line["cpu_baseline"])
+        assert line["config"]["workload"].startswith("CoR2 fwd+bwd fp32") and "relation_mode" in line["config"]
+        assert line["rotating_inputs"] == {"value": 211096.7, "ms_per_step": 2.425, "batches": 4}
+        assert set(line["sub_records"]) == {tag for tag, _ in bench.SUB_RECORDS}
+        assert set(line["sub_records"]["cor2_bf16_n100_b128"]) == {"value", "ms_per_step", "dtype", "kernel", "frac"}
+        assert "error" in line["sub_records"]["oda_b512"]
+        assert ("distributed" in line) == (world > 1)
+        # the full record went to the detail file and to stderr
+        detail = json.load(open(tmp_path / "bench_detail.json"))
+        assert len(detail["roofline_all"]) == 70 and detail["detail_file"] == "bench_detail.json"
+        assert json.loads(err.strip().splitlines()[-1])["roofline_all"]
+
+
+def test_compact_line_sheds_optional_parts_rather_than_overflowing():
+    full = _canned(8)
+    full["sub_records"] = {"tag_%03d" % i: {"value": 1.0, "ms_per_step": 1.0, "dtype": "f32",
+                                            "roofline": {"kernel": "k" * 40, "frac": 0.5}} for i in range(40)}
+    line = bench.compact_line(full)
+    assert len(json.dumps(line)) < bench.COMPACT_LIMIT
+    assert "roofline" in line and "cpu_baseline" in line and "sub_records" not in line
+
+
+def test_pmc_rows_are_matched_by_kernel_and_grid():
+    table = {
+        "vqa::relation_apply_fwd_kernel<float, 256>|grid=262144": {"FETCH_SIZE_KiB": 12315.0, "WRITE_SIZE_KiB": 16384.0, "launches": 8},
+        "vqa::relation_apply_fwd_kernel<float, 256>|grid=524288": {"FETCH_SIZE_KiB": 78073.0, "WRITE_SIZE_KiB": 147456.0, "launches": 8},
+        "vqa::rt::gemm_tn_kernel<5, 2, false, false>|grid=65536": {"FETCH_SIZE_KiB": 84976.0, "WRITE_SIZE_KiB": 39699.5, "launches": 8},
+        "vqa::rt::gemm_tn_kernel<5, 2, true, true>|grid=65536": {"FETCH_SIZE_KiB": 96178.0, "WRITE_SIZE_KiB": 39699.5, "launches": 8},
+        "vqa::attention_pool_bwd_fused_kernel<float, 256, 4, 2>|grid=131072": {"FETCH_SIZE_KiB": 83178.0, "WRITE_SIZE_KiB": 288.0, "launches": 16},
+    }
+    big = bench.pmc_row(table, "relation_apply_fwd", ((524288, "(relation_apply_fwd_kernel<T, 256>)"),))
+    small = bench.pmc_row(table, "relation_apply_fwd", ((262144, "(relation_apply_fwd_kernel<T, 256>)"),))
+    assert big["WRITE_SIZE_KiB"] == 147456.0 and small["WRITE_SIZE_KiB"] == 16384.0
+    assert bench.pmc_row(table, "relation_apply_fwd", ((1024, "x"),)) is None            # a grid the table never saw
+    assert bench.pmc_row(table, "relation_apply_fwd", ()) is None                           # no launch log: no guess
+    gated = bench.pmc_row(table, "linear_act_bwd", ((65536, "(rt::gemm_tn_kernel<5, 2, true, true>)"), (317440, "linear_dw_reduce_kernel")))
+    plain = bench.pmc_row(table, "linear_act_bwd", ((65536, "(rt::gemm_tn_kernel<5, 2, false, false>)"), (317440, "linear_dw_reduce_kernel")))
+    assert gated["FETCH_SIZE_KiB"] == 96178.0 and plain["FETCH_SIZE_KiB"] == 84976.0
+    # K3's backward is the fused kernel at B = 512 (the stream kernel's row is simply absent)
+    fused = bench.pmc_row(table, "softmax_attention_pool_drop_bwd", ((131072, "(attention_pool_bwd_fused_kernel<T, 256, 4, 2>)"),))
+    assert fused["key"].startswith("vqa::attention_pool_bwd_fused_kernel")

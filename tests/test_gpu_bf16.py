@@ -630,3 +630,35 @@ def test_cor2_bf16_train_steps():
     with torch.no_grad():
         after = RF.kld_sum_loss(model.eval()(batch), a).item()
     assert after < before, (before, after)
+
+
+@pytest.mark.parametrize("B,N", [(8, 100), (40, 36)])
+def test_cor2_bf16_pairwise_relation_trains(B, N):
+    """bf16 compute with the pairwise relation kernel (relation_mode=0) in TRAIN mode: compress_v2 then reads a tensor
+    that needs a gradient (through q_gate_1 / q_gate_2 / alpha1), so its input dropout cannot be the in-kernel mask of
+    ops.LinearBf16 (no data gradient there) -- the layer drops beforehand.  Regression of round 3 (the backward raised).
+    Every parameter receives a finite gradient, and in eval mode the step agrees with relation_mode=1's (same function)."""
+    from oracle import reference_faithful as RF
+    torch.manual_seed(11)
+    v, q, a = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(B, regions=N, answers=300, seed=17))
+    batch = {"v": v.to(torch.bfloat16), "q_idxes": q}
+    grads = {}
+    for mode in (0, 1):
+        model = _build_cor2(300, compute_dtype=torch.bfloat16, relation_mode=mode)
+        model.train()
+        RF.kld_sum_loss(model(batch), a).backward()
+        for n, p in model.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), (mode, n)
+            assert float(p.grad.abs().max()) > 0 or "conv_att.conv.bias" in n, (mode, n)
+        model.zero_grad(set_to_none=True)
+        model.eval()
+        logits = model(batch)
+        RF.kld_sum_loss(logits, a).backward()
+        grads[mode] = (npy(logits), {n: npy(p.grad) for n, p in model.named_parameters()})
+    np.testing.assert_allclose(grads[0][0], grads[1][0], rtol=0, atol=RTOL_MODEL * np.abs(grads[1][0]).max())
+    for n, g1 in grads[1][1].items():
+        g0 = grads[0][1][n]
+        if np.sqrt((g1 ** 2).sum()) < 1e-6:
+            continue
+        err = np.sqrt(((g0 - g1) ** 2).sum()) / np.sqrt((g1 ** 2).sum())
+        assert err <= GRAD_RELF, "%s: relation_mode 0 vs 1 relative Frobenius error %.3e" % (n, err)

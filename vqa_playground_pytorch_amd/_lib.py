@@ -9,7 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VQA_LIB_PATH", os.path.join(_HERE, "libvqa_mi355x.so"))  # env override: profiling builds
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _c_f = ctypes.c_void_p          # device pointer to fp32
 _c_pp = ctypes.c_void_p         # host array of device pointers
@@ -25,6 +25,9 @@ SIGNATURES = {
     "vqa_version": (_c_i, []),
     "vqa_last_error": (ctypes.c_char_p, []),
     "vqa_set_option": (_c_i, [ctypes.c_char_p, ctypes.c_char_p]),
+    "vqa_launch_log_reset": (None, []),
+    "vqa_launch_log": (_c_i, [ctypes.POINTER(ctypes.c_ulonglong), _c_i]),
+    "vqa_launch_log_kernel": (ctypes.c_char_p, [_c_i]),
     "vqa_pairwise_relation_reduce_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_pairwise_relation_reduce_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,
                                                 _c_i, _c_i, _c_i, _c_st]),

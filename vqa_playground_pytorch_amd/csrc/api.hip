@@ -3,6 +3,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 
 #include "common.hpp"
 
@@ -20,11 +21,22 @@ char* error_buffer() {
 namespace {
 struct OptionTable {
   std::mutex mu;
-  std::unordered_map<std::string, std::pair<bool, std::string>> values;  // name -> (is set, value)
+  std::unordered_set<std::string> interned;                     // node-stable storage: a value handed out is never touched again
+  std::unordered_map<std::string, const std::string*> values;   // name -> interned value, nullptr = unset
+  const std::string* intern(const char* v) { return v != nullptr ? &*interned.emplace(v).first : nullptr; }
 };
 OptionTable& options() {
   static OptionTable* t = new OptionTable();  // never destroyed: launches may outlive static destruction order
   return *t;
+}
+struct LaunchLog {
+  int n;
+  unsigned long long items[VQA_LAUNCH_LOG_CAP];
+  const char* kernel[VQA_LAUNCH_LOG_CAP];   // the kernel expression as written at the launch site (string literal)
+};
+LaunchLog& launch_log() {
+  static thread_local LaunchLog log = {0, {0}, {nullptr}};
+  return log;
 }
 }  // namespace
 
@@ -32,11 +44,17 @@ const char* option(const char* name) {
   OptionTable& t = options();
   std::lock_guard<std::mutex> lock(t.mu);
   auto it = t.values.find(name);
-  if (it == t.values.end()) {
-    const char* e = std::getenv(name);
-    it = t.values.emplace(name, std::make_pair(e != nullptr, std::string(e != nullptr ? e : ""))).first;
+  if (it == t.values.end()) it = t.values.emplace(name, t.intern(std::getenv(name))).first;
+  return it->second != nullptr ? it->second->c_str() : nullptr;
+}
+
+void note_launch(const char* kernel, dim3 grid, dim3 block) {
+  LaunchLog& log = launch_log();
+  if (log.n < VQA_LAUNCH_LOG_CAP) {
+    log.items[log.n] = (unsigned long long)grid.x * grid.y * grid.z * block.x * block.y * block.z;
+    log.kernel[log.n] = kernel;
   }
-  return it->second.first ? it->second.second.c_str() : nullptr;
+  ++log.n;
 }
 
 // Zero-fill as a plain kernel.  hipMemsetAsync must not be used in this library: captured into a hipGraph (memset
@@ -61,7 +79,7 @@ int zero_async(void* ptr, size_t bytes, hipStream_t s) {
   size_t blocks = (words + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, head, words, tail);
+  VQA_LAUNCH(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, head, words, tail);
   return check_launch("zero_fill");
 }
 }  // namespace vqa
@@ -71,7 +89,18 @@ extern "C" int vqa_set_option(const char* name, const char* value) {
   VQA_REQUIRE(name != nullptr && name[0] != 0, VQA_E_BADARG, "set_option: empty name");
   vqa::OptionTable& t = vqa::options();
   std::lock_guard<std::mutex> lock(t.mu);
-  t.values[name] = std::make_pair(value != nullptr, std::string(value != nullptr ? value : ""));
+  t.values[name] = t.intern(value);
   return VQA_OK;
+}
+extern "C" void vqa_launch_log_reset(void) { vqa::launch_log().n = 0; }
+extern "C" int vqa_launch_log(unsigned long long* items, int capacity) {
+  const vqa::LaunchLog& log = vqa::launch_log();
+  const int n = log.n < VQA_LAUNCH_LOG_CAP ? log.n : VQA_LAUNCH_LOG_CAP;
+  for (int i = 0; i < n && i < capacity; ++i) items[i] = log.items[i];
+  return log.n;
+}
+extern "C" const char* vqa_launch_log_kernel(int i) {
+  const vqa::LaunchLog& log = vqa::launch_log();
+  return (i >= 0 && i < log.n && i < VQA_LAUNCH_LOG_CAP) ? log.kernel[i] : nullptr;
 }
 extern "C" const char* vqa_last_error(void) { return vqa::error_buffer(); }

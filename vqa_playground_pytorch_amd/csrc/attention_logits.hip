@@ -399,7 +399,7 @@ static int al_fwd_impl(const char* who, const T* x, int ldx, const float* w, con
   if (blocks > 2048) blocks = 2048;
   const int mode = dc.p8 == 0 ? 0 : (dc.p8 == kDropHalf ? 1 : 2);
 #define CALL_M(G_, MODE_) \
-  hipLaunchKernelGGL((attention_logits_fwd_kernel<T, G_, MODE_>), dim3(blocks), dim3(kAlThreads), 0, s, x, ldx, w, bias, logits, M, K, dc)
+  VQA_LAUNCH((attention_logits_fwd_kernel<T, G_, MODE_>), dim3(blocks), dim3(kAlThreads), 0, s, x, ldx, w, bias, logits, M, K, dc)
 #define CALL(G_)                       \
   if (mode == 0) CALL_M(G_, 0);        \
   else if (mode == 1) CALL_M(G_, 1);   \
@@ -434,7 +434,7 @@ static int al_bwd_impl(const char* who, const T* x, int ldx, const float* w, con
   float* partb = part + (size_t)blocks * G * KPAD;
   const int mode = dc.p8 == 0 ? 0 : (dc.p8 == kDropHalf ? 1 : 2);
 #define CALL_M(G_, MODE_)                                                                                                        \
-  hipLaunchKernelGGL((attention_logits_bwd_kernel<T, G_, MODE_>), dim3(blocks), dim3(kAlThreads), 0, s, x, ldx, w, d_logits, d_x, \
+  VQA_LAUNCH((attention_logits_bwd_kernel<T, G_, MODE_>), dim3(blocks), dim3(kAlThreads), 0, s, x, ldx, w, d_logits, d_x, \
                      part, partb, M, K, dc)
 #define CALL(G_)                       \
   if (mode == 0) CALL_M(G_, 0);        \
@@ -443,7 +443,7 @@ static int al_bwd_impl(const char* who, const T* x, int ldx, const float* w, con
   VQA_AL_SWITCH_G(G, CALL);
 #undef CALL
 #undef CALL_M
-  hipLaunchKernelGGL(attention_logits_finish_kernel, dim3((G * K + G + 15) / 16), dim3(256), 0, s, part, partb, d_w, d_bias, K,
+  VQA_LAUNCH(attention_logits_finish_kernel, dim3((G * K + G + 15) / 16), dim3(256), 0, s, part, partb, d_w, d_bias, K,
                      G, KPAD, blocks);
   return check_launch(who);
 }

@@ -346,7 +346,7 @@ static int launch_fwd(const float* logits, const T* v, float* alpha, float* pool
   constexpr int NT = 256;
   const size_t lds = ((size_t)N * G + 2 * kMaxG) * sizeof(float);
   dim3 grid((D / 4 + NT - 1) / NT, B);
-  hipLaunchKernelGGL((attention_pool_fwd_kernel<T, NT, G>), grid, dim3(NT), lds, s, logits, v, alpha, pooled, first, N, D, dc);
+  VQA_LAUNCH((attention_pool_fwd_kernel<T, NT, G>), grid, dim3(NT), lds, s, logits, v, alpha, pooled, first, N, D, dc);
   return check_launch("softmax_attention_pool_fwd");
 }
 
@@ -361,7 +361,7 @@ static int launch_bwd(const float* alpha, const T* v, const float* d_pooled, con
     const int min_b = env != nullptr ? std::atoi(env) : 512;
     const size_t lds_f = ((size_t)2 * N * G + kMaxG) * sizeof(float);
     if (B >= min_b && D % 4 == 0 && D <= 4 * NT * 2 && D > 4 * NT) {
-      hipLaunchKernelGGL((attention_pool_bwd_fused_kernel<T, NT, G, 2>), dim3(B), dim3(NT), lds_f, s, alpha, v, d_pooled, d_first,
+      VQA_LAUNCH((attention_pool_bwd_fused_kernel<T, NT, G, 2>), dim3(B), dim3(NT), lds_f, s, alpha, v, d_pooled, d_first,
                          d_alpha_ext, d_logits, d_v, N, D, dc);
       return check_launch("softmax_attention_pool_bwd");
     }
@@ -373,13 +373,13 @@ static int launch_bwd(const float* alpha, const T* v, const float* d_pooled, con
   const size_t lds = 2 * (size_t)N * G * sizeof(float);
   if ((long)B * D / 4 < 4 * 65536) {  // fewer than 4 waves per CU worth of lanes: split the rows over the waves
     constexpr int RS = NT / 64;
-    hipLaunchKernelGGL((attention_pool_bwd_stream_kernel<T, NT, G, RS>), dim3((D / 4 + 63) / 64, B), dim3(NT), lds, s, alpha,
+    VQA_LAUNCH((attention_pool_bwd_stream_kernel<T, NT, G, RS>), dim3((D / 4 + 63) / 64, B), dim3(NT), lds, s, alpha,
                        v, d_pooled, d_first, d_logits, d_v, N, D, dc);
   } else {
-    hipLaunchKernelGGL((attention_pool_bwd_stream_kernel<T, NT, G, 1>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), lds, s, alpha,
+    VQA_LAUNCH((attention_pool_bwd_stream_kernel<T, NT, G, 1>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), lds, s, alpha,
                        v, d_pooled, d_first, d_logits, d_v, N, D, dc);
   }
-  hipLaunchKernelGGL(attention_softmax_bwd_kernel, dim3(B), dim3(256), lds + kMaxG * sizeof(float), s, alpha, d_logits,
+  VQA_LAUNCH(attention_softmax_bwd_kernel, dim3(B), dim3(256), lds + kMaxG * sizeof(float), s, alpha, d_logits,
                      d_alpha_ext, d_logits, N, G);
   return check_launch("softmax_attention_pool_bwd");
 }

@@ -235,7 +235,7 @@ static int launch_nt(const char* who, const bf16* A, int lda, const bf16* B, int
   {                                                                                                                        \
     const size_t lds = BfTile<BM_, BN_>::kSmemBytes;                                                                       \
     VQA_ENSURE_LDS((gemm_bf16_nt_kernel<BM_, BN_, XA_>), lds);                                                             \
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM_, BN_, XA_>), dim3(tiles_m * tiles_n), dim3(kBfThreads), lds, s, A, lda, B, \
+    VQA_LAUNCH((gemm_bf16_nt_kernel<BM_, BN_, XA_>), dim3(tiles_m * tiles_n), dim3(kBfThreads), lds, s, A, lda, B, \
                        ldb, bias, C, ldc, M, N, K, act, tiles_n, ex.scale, ex.gate, ex.ldg, ex.dc, ex.mask_ld);            \
   }
 #define LAUNCH(BM_, BN_)                   \
@@ -278,7 +278,7 @@ static int launch_tn(const char* who, const bf16* A, int lda, const bf16* B, int
   {                                                                                                                         \
     const size_t lds = TR_ ? (size_t)BfTileTr<BM_, BN_>::kSmemBytes : (size_t)BfTile<BM_, BN_>::kSmemBytes;                 \
     VQA_ENSURE_LDS((gemm_bf16_tn_kernel<BM_, BN_, XB_, TR_>), lds);                                                         \
-    hipLaunchKernelGGL((gemm_bf16_tn_kernel<BM_, BN_, XB_, TR_>), dim3(tiles_m * tiles_n, 1, S), dim3(kBfThreads), lds, s,  \
+    VQA_LAUNCH((gemm_bf16_tn_kernel<BM_, BN_, XB_, TR_>), dim3(tiles_m * tiles_n, 1, S), dim3(kBfThreads), lds, s,  \
                        A, lda, B, ldb, workspace, Kdim, N1, N2, rows_per_split, tiles_n, ex.dc, ex.mask_ld, m_fast);        \
   }
 #define LAUNCH_X(BM_, BN_, XB_)    \
@@ -298,7 +298,7 @@ static int launch_tn(const char* who, const bf16* A, int lda, const bf16* B, int
 #undef LAUNCH_X
 #undef LAUNCH_T
   (void)groups;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((out_cols + 511) / 512), (unsigned)N1), dim3(256), 0, s, workspace,
+  VQA_LAUNCH(slab_reduce_kernel, dim3((unsigned)((out_cols + 511) / 512), (unsigned)N1), dim3(256), 0, s, workspace,
                      outs, S, N1, N2, gp, out_rows, out_cols, out_ld, ex.scale);
   return check_launch(who);
 }
@@ -708,7 +708,7 @@ extern "C" int vqa_pack_bf16(const float* src, int batch, int rows, int cols, vq
     if (rc != VQA_OK) return rc;
   }
   const size_t count = (size_t)batch * rows * cols;
-  hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, src,
+  VQA_LAUNCH(pack_bf16_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, src,
                      reinterpret_cast<bf16*>(dst), rows, cols, dst_batch_stride, dst_row_stride, dst_col_stride, count);
   return check_launch("pack_bf16");
 }
@@ -716,7 +716,7 @@ extern "C" int vqa_pack_bf16(const float* src, int batch, int rows, int cols, vq
 extern "C" int vqa_pack_many(const void* table, int jobs, size_t total, vqa_stream_t stream) {
   VQA_REQUIRE(table != nullptr && jobs > 0 && total > 0, VQA_E_BADARG, "pack_many: empty job table");
   VQA_REQUIRE(aligned(table, 8), VQA_E_UNSUPPORTED, "pack_many: the table must be 8-byte aligned");
-  hipLaunchKernelGGL(pack_many_kernel, dim3((unsigned)((total + kPackBlock - 1) / kPackBlock)), dim3(256), 0, static_cast<hipStream_t>(stream),
+  VQA_LAUNCH(pack_many_kernel, dim3((unsigned)((total + kPackBlock - 1) / kPackBlock)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const PackJob*>(table), jobs, total);
   return check_launch("pack_many");
 }
@@ -842,7 +842,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_fwd_bf16(const vqa_bf16_t* x, const v
     const size_t lds = BfTile<128, 128>::kSmemBytes + 128 * sizeof(int);
     VQA_ENSURE_LDS(bilinear_fwd2_bf16_kernel, lds);
     const int tm_ = (M + 127) / 128, tn_ = H / 64;
-    hipLaunchKernelGGL(bilinear_fwd2_bf16_kernel, dim3(tm_ * tn_), dim3(kBfThreads), lds, s, reinterpret_cast<const bf16*>(x),
+    VQA_LAUNCH(bilinear_fwd2_bf16_kernel, dim3(tm_ * tn_), dim3(kBfThreads), lds, s, reinterpret_cast<const bf16*>(x),
                        reinterpret_cast<const bf16*>(w1), b1, h2, reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(h1), M, N,
                        L, H, tn_, H_in);
     return check_launch("lowrank_bilinear_fusion_fwd_bf16");
@@ -854,7 +854,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_fwd_bf16(const vqa_bf16_t* x, const v
   {                                                                                                                       \
     const size_t lds = BfTile<BM_, BN_>::kSmemBytes + BM_ * sizeof(int) + BfTileStore<BM_, BN_>::kBytes;                  \
     VQA_ENSURE_LDS((bilinear_fwd_bf16_kernel<BM_, BN_>), lds);                                                            \
-    hipLaunchKernelGGL((bilinear_fwd_bf16_kernel<BM_, BN_>), dim3(tiles_m * tiles_n), dim3(kBfThreads), lds, s,           \
+    VQA_LAUNCH((bilinear_fwd_bf16_kernel<BM_, BN_>), dim3(tiles_m * tiles_n), dim3(kBfThreads), lds, s,           \
                        reinterpret_cast<const bf16*>(x), reinterpret_cast<const bf16*>(w1), b1, h2,                       \
                        reinterpret_cast<bf16*>(out), reinterpret_cast<bf16*>(h1), M, N, L, H, R, tiles_n, H_in);         \
   }
@@ -903,7 +903,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd_bf16(const vqa_bf16_t* x, const v
   const bf16* gb = reinterpret_cast<const bf16*>(g);
   const bf16* h1b = reinterpret_cast<const bf16*>(h1);
 #define PREP8(RT_)                                                                                                        \
-  hipLaunchKernelGGL(bilinear_bwd_prep8_bf16_kernel<RT_>, dim3(H / 128, B), dim3(256), 0, s, gb, h1b, h2, gs, d_h2, gsum, \
+  VQA_LAUNCH(bilinear_bwd_prep8_bf16_kernel<RT_>, dim3(H / 128, B), dim3(256), 0, s, gb, h1b, h2, gs, d_h2, gsum, \
                      N, H, H_out)
   switch (R) {
     case 1: PREP8(1); break;
@@ -913,15 +913,15 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd_bf16(const vqa_bf16_t* x, const v
     case 5: PREP8(5); break;
     default:
       if ((long)B * H < 4 * 65536) {
-        hipLaunchKernelGGL(bilinear_bwd_prep_bf16_kernel<16>, dim3(H / 64, B), dim3(256), 0, s, gb, h1b, h2, gs, d_h2, gsum, N, H,
+        VQA_LAUNCH(bilinear_bwd_prep_bf16_kernel<16>, dim3(H / 64, B), dim3(256), 0, s, gb, h1b, h2, gs, d_h2, gsum, N, H,
                            R, H_out);
       } else {
-        hipLaunchKernelGGL(bilinear_bwd_prep_bf16_kernel<4>, dim3(H / 256, B), dim3(256), 0, s, gb, h1b, h2, gs, d_h2, gsum, N, H,
+        VQA_LAUNCH(bilinear_bwd_prep_bf16_kernel<4>, dim3(H / 256, B), dim3(256), 0, s, gb, h1b, h2, gs, d_h2, gsum, N, H,
                            R, H_out);
       }
   }
 #undef PREP8
-  hipLaunchKernelGGL(bilinear_db_bf16_kernel, dim3(RH / 64), dim3(256), 0, s, h2, gsum, db, B, H, R, H_out);
+  VQA_LAUNCH(bilinear_db_bf16_kernel, dim3(RH / 64), dim3(256), 0, s, h2, gsum, db, B, H, R, H_out);
   if (d_x != nullptr) {
     NtExtra ex;
     if (gate_dx) {   // x is the relu output of the layer in front: its gradient gate rides in this store

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(rt::kThreads, 1) void bilinear_dw_rt_kernel(DwRtArg
 }  // namespace
 
 bool dw_rt_supported(int B, int N, int L, int H, int R, int ldx) {
-  static const bool off = vqa::option("VQA_K4_DW_RT") != nullptr && vqa::option("VQA_K4_DW_RT")[0] == '0';
+  const bool off = vqa::option_is("VQA_K4_DW_RT", '0');
   return !off && (R == 1 || R == 2) && (N == 36 || N == 100) && L > 256 && L < kCols && ldx == L && L % 2 == 0 && H >= 16 &&
          B >= 64 && (size_t)B * N * H * 4 < (1ull << 32);
 }
@@ -351,7 +351,7 @@ int dw_rt_launch(const float* g, const float* x, const float* h2, const float* c
       static unsigned long long* st = nullptr;                                                                  \
       if (st == nullptr) (void)hipMalloc(&st, 1024 * 5 * 8);                                                    \
       a.stamps = st;                                                                                            \
-      hipLaunchKernelGGL((bilinear_dw_rt_kernel<2, 9, 9, 4>), grid, dim3(rt::kThreads), lds, s, a);             \
+      VQA_LAUNCH((bilinear_dw_rt_kernel<2, 9, 9, 4>), grid, dim3(rt::kThreads), lds, s, a);             \
       static int shown = 0;                                                                                     \
       if (++shown == 20) {                                                                                      \
         unsigned long long h[1024 * 5];                                                                         \
@@ -369,7 +369,7 @@ int dw_rt_launch(const float* g, const float* x, const float* h2, const float* c
       }                                                                                                         \
     }                                                                                                           \
     else                                                                                                        \
-      hipLaunchKernelGGL((bilinear_dw_rt_kernel<R_, NS_, D_>), grid, dim3(rt::kThreads), lds, s, a);            \
+      VQA_LAUNCH((bilinear_dw_rt_kernel<R_, NS_, D_>), grid, dim3(rt::kThreads), lds, s, a);            \
   }
   if (R == 1) {
     if (N == 36) LAUNCH(1, 9) else LAUNCH(1, 25)

@@ -291,7 +291,7 @@ static int launch_folded(const char* who, const float* in, int ld_in, const Fold
 #define LAUNCH_C(NB_, R_, W_, OB_)                                                                                           \
   {                                                                                                                          \
     VQA_ENSURE_LDS((bilinear_folded_kernel<NB_, R_, H2_ROWS, W_, OB_>), lds);                                                \
-    hipLaunchKernelGGL((bilinear_folded_kernel<NB_, R_, H2_ROWS, W_, OB_>), dim3(tiles_o * groups), dim3(64 * W_), lds, s,   \
+    VQA_LAUNCH((bilinear_folded_kernel<NB_, R_, H2_ROWS, W_, OB_>), dim3(tiles_o * groups), dim3(64 * W_), lds, s,   \
                        in, ld_in, wp, ldw, h2, h2_dim, out, ld_out, B, N, C, O, tiles_o, gate);                              \
   }
 #define LAUNCH_W(NB_, R_, OB_) \
@@ -359,7 +359,7 @@ bool folded_supported(int B, int N, int L, int H, int R) {
 int folded_transpose_weights(const float* const* w1, float* wt, int L, int H, int R, hipStream_t s) {
   FoldPtrs wp{};
   for (int r = 0; r < R; ++r) wp.w[r] = w1[r];
-  hipLaunchKernelGGL(fold_transpose_kernel, dim3((L + 31) / 32, (H + 31) / 32, R), dim3(256), 0, s, wp, wt, L, H);
+  VQA_LAUNCH(fold_transpose_kernel, dim3((L + 31) / 32, (H + 31) / 32, R), dim3(256), 0, s, wp, wt, L, H);
   return check_launch("lowrank_bilinear_fusion_folded_bwd (weight transpose)");
 }
 

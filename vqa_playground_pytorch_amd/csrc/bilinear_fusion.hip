@@ -620,7 +620,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_fwd(const float* x, int ldx, const fl
   {                                                                                                                   \
     const size_t lds = GemmTile<BM_, BN_, 16, true, true>::kSmemBytes + BM_ * sizeof(int);                                \
     VQA_ENSURE_LDS((bilinear_fwd_kernel<BM_, BN_, BK_>), lds);                                                        \
-    hipLaunchKernelGGL((bilinear_fwd_kernel<BM_, BN_, BK_>), dim3(tiles_m * tiles_n), dim3(kGemmThreads), lds, s, x, ldx,   \
+    VQA_LAUNCH((bilinear_fwd_kernel<BM_, BN_, BK_>), dim3(tiles_m * tiles_n), dim3(kGemmThreads), lds, s, x, ldx,   \
                        rp, h2, out, h1, M, N, L, H, R, tiles_n);                                                      \
   }
   VQA_TILE_SWITCH(t, LAUNCH);
@@ -664,7 +664,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd(const float* x, int ldx, const fl
   float* dbslab = slab + (size_t)S * R * H * L;
 
   // (1) dh2
-  hipLaunchKernelGGL(bilinear_dh2_kernel, dim3((H / 2 + 63) / 64, B), dim3(256), 0, s, g, h1, d_h2, N, H, R);
+  VQA_LAUNCH(bilinear_dh2_kernel, dim3((H / 2 + 63) / 64, B), dim3(256), 0, s, g, h1, d_h2, N, H, R);
   // (2) dx
   if (d_x != nullptr) {
     const TileChoice t = tile_override_or(choose_tile(M, L, 1));
@@ -673,7 +673,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd(const float* x, int ldx, const fl
   {                                                                                                                  \
     const size_t lds = GemmTile<BM_, BN_, 16, true, false>::kSmemBytes;                                                  \
     VQA_ENSURE_LDS((bilinear_dx_kernel<BM_, BN_, BK_>), lds);                                                        \
-    hipLaunchKernelGGL((bilinear_dx_kernel<BM_, BN_, BK_>), dim3(tiles_m * tiles_n), dim3(kGemmThreads), lds, s, g, rp, h2, \
+    VQA_LAUNCH((bilinear_dx_kernel<BM_, BN_, BK_>), dim3(tiles_m * tiles_n), dim3(kGemmThreads), lds, s, g, rp, h2, \
                        d_x, M, N, L, H, R, tiles_n, make_row_to_sample(N));                                                                 \
   }
     VQA_TILE_SWITCH(t, LAUNCH);
@@ -689,7 +689,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd(const float* x, int ldx, const fl
   {                                                                                                                        \
     const size_t lds = GemmTile<BM_, BN_, 16, false, false>::kSmemBytes + (size_t)spl * R_ * BM_ * sizeof(float);         \
     VQA_ENSURE_LDS((bilinear_dw_sample_kernel<BM_, BN_, PF_, R_>), lds);                                                   \
-    hipLaunchKernelGGL((bilinear_dw_sample_kernel<BM_, BN_, PF_, R_>), dim3(tiles_m * tiles_n * S), dim3(kGemmThreads), lds, \
+    VQA_LAUNCH((bilinear_dw_sample_kernel<BM_, BN_, PF_, R_>), dim3(tiles_m * tiles_n * S), dim3(kGemmThreads), lds, \
                        s, g, h2, x, ldx, slab, dbslab, B, N, L, H, tiles_m, tiles_n, spl, SP, inv);                        \
   }
 #define LAUNCH(BM_, BN_, PF_)                 \
@@ -712,14 +712,14 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd(const float* x, int ldx, const fl
   {                                                                                                                 \
     const size_t lds = GemmTile<BM_, BN_, 16, false, false>::kSmemBytes;                                                \
     VQA_ENSURE_LDS((bilinear_dw_kernel<BM_, BN_, BK_>), lds);                                                       \
-    hipLaunchKernelGGL((bilinear_dw_kernel<BM_, BN_, BK_>), dim3(tiles_m * tiles_n * R * S), dim3(kGemmThreads), lds, s, g,  \
+    VQA_LAUNCH((bilinear_dw_kernel<BM_, BN_, BK_>), dim3(tiles_m * tiles_n * R * S), dim3(kGemmThreads), lds, s, g,  \
                        h2, x, ldx, slab, dbslab, M, N, L, H, R, tiles_m, tiles_n, rows_per_split, make_row_to_sample(N));                          \
   }
     VQA_TILE_SWITCH(tw, LAUNCH);
 #undef LAUNCH
     }
     const int HL = H * L;
-    hipLaunchKernelGGL(bilinear_dw_reduce_kernel, dim3((HL / 2 + 255) / 256, R), dim3(256), 0, s, slab, dbslab, ro, HL, H, R, S);
+    VQA_LAUNCH(bilinear_dw_reduce_kernel, dim3((HL / 2 + 255) / 256, R), dim3(256), 0, s, slab, dbslab, ro, HL, H, R, S);
   }
   return check_launch("lowrank_bilinear_fusion_bwd");
 }
@@ -829,7 +829,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_folded_bwd_gated(const float* x, int 
     const int HL2 = H * L;
     const size_t n2 = (size_t)B * R * H;
     const int nb_dw = (HL2 / 2 + 255) / 256, nb_dh2 = (int)((n2 / 2 + 255) / 256);
-    hipLaunchKernelGGL(bilinear_dw_dh2_reduce_kernel, dim3(R * nb_dw + nb_dh2), dim3(256), 0, s, slab, dbslab, ro, HL2, H, R,
+    VQA_LAUNCH(bilinear_dw_dh2_reduce_kernel, dim3(R * nb_dw + nb_dh2), dim3(256), 0, s, slab, dbslab, ro, HL2, H, R,
                        kDwRtGroups, nb_dw, part, d_h2, n2, 2);
     return check_launch("lowrank_bilinear_fusion_folded_bwd");
   }
@@ -846,7 +846,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_folded_bwd_gated(const float* x, int 
   {                                                                                                                             \
     const size_t lds = GemmTile<64, 64, BK_, false, false>::kSmemBytes + (size_t)spl * R_ * 64 * sizeof(float);                 \
     VQA_ENSURE_LDS((bilinear_dw_dh2_kernel<64, 64, PF_, R_, BK_>), lds);                                                        \
-    hipLaunchKernelGGL((bilinear_dw_dh2_kernel<64, 64, PF_, R_, BK_>), dim3(tiles_m * tiles_n * S), dim3(kGemmThreads), lds, s, \
+    VQA_LAUNCH((bilinear_dw_dh2_kernel<64, 64, PF_, R_, BK_>), dim3(tiles_m * tiles_n * S), dim3(kGemmThreads), lds, s, \
                        g, h2, x, ldx, rp, slab, dbslab, part, B, N, L, H, tiles_m, tiles_n, spl, SP, inv);                      \
   }
 #define LAUNCH_PF(R_, PF_) \
@@ -866,7 +866,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_folded_bwd_gated(const float* x, int 
   const int HL = H * L;
   const size_t n = (size_t)B * R * H;
   const int nb_dw = (HL / 2 + 255) / 256, nb_dh2 = (int)((n / 2 + 255) / 256);
-  hipLaunchKernelGGL(bilinear_dw_dh2_reduce_kernel, dim3(R * nb_dw + nb_dh2), dim3(256), 0, s, slab, dbslab, ro, HL, H, R, S, nb_dw,
+  VQA_LAUNCH(bilinear_dw_dh2_reduce_kernel, dim3(R * nb_dw + nb_dh2), dim3(256), 0, s, slab, dbslab, ro, HL, H, R, S, nb_dw,
                      part, d_h2, n, 2 * tiles_n);
   return check_launch("lowrank_bilinear_fusion_folded_bwd");
 }

@@ -279,9 +279,9 @@ int launch(const FoldRtArgs& a0, int R, hipStream_t s) {
   a.tiles_o = (a.NO + 64 * IB - 1) / (64 * IB);
   const dim3 grid((unsigned)(((a.B + S - 1) / S) * a.tiles_o));
   if (R == 1)
-    hipLaunchKernelGGL((bilinear_fold_rt_kernel<FWD, S, IB, 1>), grid, dim3(rt::kThreads), 0, s, a);
+    VQA_LAUNCH((bilinear_fold_rt_kernel<FWD, S, IB, 1>), grid, dim3(rt::kThreads), 0, s, a);
   else
-    hipLaunchKernelGGL((bilinear_fold_rt_kernel<FWD, S, IB, 2>), grid, dim3(rt::kThreads), 0, s, a);
+    VQA_LAUNCH((bilinear_fold_rt_kernel<FWD, S, IB, 2>), grid, dim3(rt::kThreads), 0, s, a);
   return check_launch(FWD ? "lowrank_bilinear_fusion_folded_fwd (register-tile)" : "lowrank_bilinear_fusion_folded_bwd (dx, register-tile)");
 }
 
@@ -290,7 +290,7 @@ int launch(const FoldRtArgs& a0, int R, hipStream_t s) {
 // Shapes the register-tile kernels take: R <= 2, 17 .. 48 regions (three blocks of 16; fewer regions waste them), a batch
 // that fills the chip, 4-byte-addressable tensors below 4 GiB.  VQA_K4_RT=0 keeps the LDS-tile kernels.
 bool fold_rt_supported(int B, int N, int K, int NO, int R, int ldx, int ldw, int ldo) {
-  static const bool off = vqa::option("VQA_K4_RT") != nullptr && vqa::option("VQA_K4_RT")[0] == '0';
+  const bool off = vqa::option_is("VQA_K4_RT", '0');
   return !off && R >= 1 && R <= 2 && N > 16 && N <= 48 && B >= 256 && K >= 32 && NO >= 64 && ldx % 2 == 0 && ldw % 2 == 0 &&
          ldo % 2 == 0 && (size_t)B * N * (size_t)(ldx > ldo ? ldx : ldo) * 4 < (1ull << 32) && (size_t)NO * ldw * 4 < (1ull << 32);
 }

@@ -30,7 +30,21 @@ inline int check_launch(const char* what) {
 
 // api.hip: value of a tuning / diagnostic knob -- the environment variable of that name as it was at the FIRST query (or
 // what vqa_set_option() installed since), nullptr when unset.  Launchers never read the environment themselves.
+// The returned string is interned (never mutated or freed), so it stays valid across later vqa_set_option() calls.
 const char* option(const char* name);
+inline bool option_is(const char* name, char first) {   // knob set and starting with `first` (e.g. "0" = switched off)
+  const char* v = option(name);
+  return v != nullptr && v[0] == first;
+}
+
+// api.hip: per-thread log of the launches of the current C-ABI call (grid in work-items, as rocprofv3's Grid_Size reports
+// it) -- bench.py keys the committed PMC tables by (kernel, grid) with it.  A few stores per launch, always on.
+void note_launch(const char* kernel, dim3 grid, dim3 block);
+#define VQA_LAUNCH(kernel, grid, block, lds, stream, ...)                  \
+  do {                                                                      \
+    ::vqa::note_launch(#kernel, (grid), (block));                                   \
+    hipLaunchKernelGGL(kernel, (grid), (block), (lds), (stream), __VA_ARGS__); \
+  } while (0)
 
 int zero_async(void* ptr, size_t bytes, hipStream_t s);  // api.hip: zero-fill kernel (never hipMemsetAsync: see there)
 

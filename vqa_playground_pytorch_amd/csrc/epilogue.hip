@@ -188,7 +188,7 @@ extern "C" int vqa_gate_product_bwd(const float* g1, const float* g2, const floa
                   vqa::aligned(d_b, 16) && vqa::aligned(d_c, 16) && (g2 == nullptr || vqa::aligned(g2, 16)) &&
                   (h2 == nullptr || vqa::aligned(h2, 16)),
               VQA_E_UNSUPPORTED, "gate_product_bwd: tensors must be 16-byte aligned");
-  hipLaunchKernelGGL(vqa::gate_product_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0,
+  VQA_LAUNCH(vqa::gate_product_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), g1, g2, h1, h2, a, b, d_a, d_b, d_c, n / 4);
   return vqa::check_launch("gate_product_bwd");
 }
@@ -200,7 +200,7 @@ extern "C" int vqa_bias_act(const float* y, const float* bias, int bias_stride, 
               "bias_act: bad sizes G=%d B=%d A=%d bias_stride=%d", G, B, A, bias_stride);
   VQA_REQUIRE(act >= 0 && act <= 2, VQA_E_BADARG, "bias_act: act must be 0 (none), 1 (relu) or 2 (sigmoid), got %d", act);
   const size_t n = (size_t)G * B * A;
-  hipLaunchKernelGGL(bias_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), y, bias,
+  VQA_LAUNCH(bias_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), y, bias,
                      bias_stride, out, G, B, A, act, group_first);
   return check_launch("bias_act");
 }
@@ -211,7 +211,7 @@ extern "C" int vqa_act_bwd_colsum(const float* gy, const float* out, float* gz, 
   VQA_REQUIRE(d_bias == nullptr || d_bias_stride >= A, VQA_E_BADARG, "act_bwd_colsum: d_bias_stride %d < A = %d", d_bias_stride, A);
   VQA_REQUIRE(G > 0 && B > 0 && A > 0 && G <= 65535, VQA_E_BADARG, "act_bwd_colsum: bad sizes G=%d B=%d A=%d", G, B, A);
   VQA_REQUIRE(act >= 0 && act <= 2, VQA_E_BADARG, "act_bwd_colsum: act must be 0, 1 or 2, got %d", act);
-  hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3((A + 15) / 16, G), dim3(256), 0, static_cast<hipStream_t>(stream), gy, out, gz,
+  VQA_LAUNCH(act_bwd_colsum_kernel, dim3((A + 15) / 16, G), dim3(256), 0, static_cast<hipStream_t>(stream), gy, out, gz,
                      d_bias, d_bias_stride, G, B, A, act, group_first);
   return check_launch("act_bwd_colsum");
 }
@@ -221,7 +221,7 @@ extern "C" int vqa_rank_product_fwd(const float* h1, const float* h2, float* out
   VQA_REQUIRE(B > 0 && R > 0 && H > 0 && H % 2 == 0, VQA_E_BADARG, "rank_product_fwd: bad sizes B=%d R=%d H=%d (H even)", B, R, H);
   VQA_REQUIRE(aligned(h1, 8) && aligned(h2, 8) && aligned(out, 8), VQA_E_UNSUPPORTED, "rank_product_fwd: tensors must be 8-byte aligned");
   const size_t n = (size_t)B * H / 2;
-  hipLaunchKernelGGL(rank_product_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+  VQA_LAUNCH(rank_product_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      h1, h2, out, B, R, H);
   return check_launch("rank_product_fwd");
 }
@@ -233,7 +233,7 @@ extern "C" int vqa_rank_product_bwd(const float* g, const float* h1, const float
   VQA_REQUIRE(aligned(g, 8) && aligned(h1, 8) && aligned(h2, 8) && aligned(d_h1, 8) && aligned(d_h2, 8), VQA_E_UNSUPPORTED,
               "rank_product_bwd: tensors must be 8-byte aligned");
   const size_t n = (size_t)B * H / 2;
-  hipLaunchKernelGGL(rank_product_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+  VQA_LAUNCH(rank_product_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      g, h1, h2, d_h1, d_h2, B, R, H);
   return check_launch("rank_product_bwd");
 }
@@ -248,11 +248,11 @@ extern "C" int vqa_dropout_groups_fwd(const float* x, int ldx, float* out, float
   const size_t n = (size_t)G * M * K;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (K % 4 == 0)
-    hipLaunchKernelGGL(dropout_groups_fwd_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x, ldx, out, G, M, K, dc);
+    VQA_LAUNCH(dropout_groups_fwd_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x, ldx, out, G, M, K, dc);
   else if (K % 2 == 0)
-    hipLaunchKernelGGL(dropout_groups_fwd_kernel<2>, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, s, x, ldx, out, G, M, K, dc);
+    VQA_LAUNCH(dropout_groups_fwd_kernel<2>, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, s, x, ldx, out, G, M, K, dc);
   else
-    hipLaunchKernelGGL(dropout_groups_fwd_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, ldx, out, G, M, K, dc);
+    VQA_LAUNCH(dropout_groups_fwd_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, ldx, out, G, M, K, dc);
   return check_launch("dropout_groups_fwd");
 }
 
@@ -266,10 +266,10 @@ extern "C" int vqa_dropout_groups_bwd(const float* gy, float* d_x, float p_drop,
   const size_t n = (size_t)M * K;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (n % 4 == 0)
-    hipLaunchKernelGGL(dropout_groups_bwd_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, gy, d_x, G, M, K, dc);
+    VQA_LAUNCH(dropout_groups_bwd_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, gy, d_x, G, M, K, dc);
   else if (n % 2 == 0)
-    hipLaunchKernelGGL(dropout_groups_bwd_kernel<2>, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, s, gy, d_x, G, M, K, dc);
+    VQA_LAUNCH(dropout_groups_bwd_kernel<2>, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, s, gy, d_x, G, M, K, dc);
   else
-    hipLaunchKernelGGL(dropout_groups_bwd_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gy, d_x, G, M, K, dc);
+    VQA_LAUNCH(dropout_groups_bwd_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gy, d_x, G, M, K, dc);
   return check_launch("dropout_groups_bwd");
 }

@@ -403,7 +403,7 @@ extern "C" int vqa_grouped_gemm(const VqaGemmProblem* problems, int n, vqa_strea
   }
   g.first[n] = items;
   const auto launch = [&](auto kernel, size_t lds) {
-    hipLaunchKernelGGL(kernel, dim3(items), dim3(kGemmThreads), lds, static_cast<hipStream_t>(stream), g, items);
+    VQA_LAUNCH(kernel, dim3(items), dim3(kGemmThreads), lds, static_cast<hipStream_t>(stream), g, items);
   };
   // LDS: the largest of the three operand forms (both operands K-contiguous, in their own orientation)
   if (bm == 128)
@@ -446,7 +446,7 @@ extern "C" int vqa_grouped_epilogue(const VqaEpilogueJob* jobs, int n, vqa_strea
     VQA_REQUIRE(threads < (1L << 30), VQA_E_UNSUPPORTED, "grouped_epilogue: too many elements");
   }
   g.first[n] = (int)threads;
-  hipLaunchKernelGGL(grouped_epilogue_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+  VQA_LAUNCH(grouped_epilogue_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), g, (int)threads);
   return check_launch("grouped_epilogue");
 }

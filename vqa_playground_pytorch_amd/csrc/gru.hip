@@ -121,7 +121,7 @@ extern "C" int vqa_gru_gates_fwd(const float* gi, const float* a, const float* h
   int rc = gru_check("gru_gates_fwd", B, T, H, t, af);
   if (rc != VQA_OK) return rc;
   const size_t n4 = (size_t)B * H / 4;
-  hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), gi,
+  VQA_LAUNCH(gru_gates_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), gi,
                      a, h_prev, masks, h_new, hm_next, hist_group_stride, r_s, i_s, n_s, an_s, B, T, H, t, af);
   return check_launch("gru_gates_fwd");
 }
@@ -134,7 +134,7 @@ extern "C" int vqa_gru_gates_bwd(const float* d_out_t, const float* carry_in, co
   int rc = gru_check("gru_gates_bwd", B, T, H, t, af);
   if (rc != VQA_OK) return rc;
   const size_t n4 = (size_t)B * H / 4;
-  hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+  VQA_LAUNCH(gru_gates_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      d_out_t, carry_in, dhm, masks, r_s, i_s, n_s, an_s, h_prev, gz, hist_group_stride, d_gi, carry_out, B, T, H,
                      t, af);
   return check_launch("gru_gates_bwd");

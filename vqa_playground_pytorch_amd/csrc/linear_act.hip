@@ -319,11 +319,11 @@ extern "C" int vqa_linear_act_fwd(const float* x, int ldx, const float* w, const
     const EpiBiasAct epi{y, bias, N, act, dc.p8 > 0 ? dc.scale : 1.f};
     if (dc.p8 > 0) {
       VQA_ENSURE_LDS((rt::gemm_nt_kernel<9, 5, 1, 2, 2, true, EpiBiasAct>), S::kLdsBytes);
-      hipLaunchKernelGGL((rt::gemm_nt_kernel<9, 5, 1, 2, 2, true, EpiBiasAct>), dim3(tiles_m * tiles_n), dim3(rt::kThreads),
+      VQA_LAUNCH((rt::gemm_nt_kernel<9, 5, 1, 2, 2, true, EpiBiasAct>), dim3(tiles_m * tiles_n), dim3(rt::kThreads),
                          S::kLdsBytes, s, a, dc, epi);
     } else {
       VQA_ENSURE_LDS((rt::gemm_nt_kernel<9, 5, 1, 2, 2, false, EpiBiasAct>), S::kLdsBytes);
-      hipLaunchKernelGGL((rt::gemm_nt_kernel<9, 5, 1, 2, 2, false, EpiBiasAct>), dim3(tiles_m * tiles_n), dim3(rt::kThreads),
+      VQA_LAUNCH((rt::gemm_nt_kernel<9, 5, 1, 2, 2, false, EpiBiasAct>), dim3(tiles_m * tiles_n), dim3(rt::kThreads),
                          S::kLdsBytes, s, a, dc, epi);
     }
     return check_launch("linear_act_fwd");
@@ -335,11 +335,11 @@ extern "C" int vqa_linear_act_fwd(const float* x, int ldx, const float* w, const
     const size_t lds = GemmTile<BM_, BN_, 16, true, true>::kSmemBytes;                                                  \
     if (dc.p8 > 0) {                                                                                                    \
       VQA_ENSURE_LDS((linear_fwd_kernel<BM_, BN_, PF_, true>), lds);                                                    \
-      hipLaunchKernelGGL((linear_fwd_kernel<BM_, BN_, PF_, true>), dim3(tiles_m * tiles_n), dim3(kGemmThreads), lds, s,  \
+      VQA_LAUNCH((linear_fwd_kernel<BM_, BN_, PF_, true>), dim3(tiles_m * tiles_n), dim3(kGemmThreads), lds, s,  \
                          x, ldx, w, bias, y, M, K, N, act, dc, tiles_n);                                                \
     } else {                                                                                                            \
       VQA_ENSURE_LDS((linear_fwd_kernel<BM_, BN_, PF_, false>), lds);                                                   \
-      hipLaunchKernelGGL((linear_fwd_kernel<BM_, BN_, PF_, false>), dim3(tiles_m * tiles_n), dim3(kGemmThreads), lds, s, \
+      VQA_LAUNCH((linear_fwd_kernel<BM_, BN_, PF_, false>), dim3(tiles_m * tiles_n), dim3(kGemmThreads), lds, s, \
                          x, ldx, w, bias, y, M, K, N, act, dc, tiles_n);                                                \
     }                                                                                                                   \
   }
@@ -376,11 +376,11 @@ extern "C" int vqa_linear_act_bwd(const float* x, int ldx, const float* w, const
     const size_t lds = GemmTile<BM_, BN_, 16, true, false>::kSmemBytes;                                                \
     if (dc.p8 > 0) {                                                                                                   \
       VQA_ENSURE_LDS((linear_dx_kernel<BM_, BN_, PF_, true>), lds);                                                    \
-      hipLaunchKernelGGL((linear_dx_kernel<BM_, BN_, PF_, true>), dim3(tiles_m * tiles_n), dim3(kGemmThreads), lds, s,  \
+      VQA_LAUNCH((linear_dx_kernel<BM_, BN_, PF_, true>), dim3(tiles_m * tiles_n), dim3(kGemmThreads), lds, s,  \
                          gy, y, w, d_x, M, K, N, act, dc, tiles_n);                                                    \
     } else {                                                                                                           \
       VQA_ENSURE_LDS((linear_dx_kernel<BM_, BN_, PF_, false>), lds);                                                   \
-      hipLaunchKernelGGL((linear_dx_kernel<BM_, BN_, PF_, false>), dim3(tiles_m * tiles_n), dim3(kGemmThreads), lds, s, \
+      VQA_LAUNCH((linear_dx_kernel<BM_, BN_, PF_, false>), dim3(tiles_m * tiles_n), dim3(kGemmThreads), lds, s, \
                          gy, y, w, d_x, M, K, N, act, dc, tiles_n);                                                    \
     }                                                                                                                  \
   }
@@ -400,15 +400,15 @@ extern "C" int vqa_linear_act_bwd(const float* x, int ldx, const float* w, const
     const dim3 grid(a.tiles1 * a.tiles2 * S);
     const bool gate = act == 1, drop = dc.p8 > 0;
     if (gate && drop)
-      hipLaunchKernelGGL((rt::gemm_tn_kernel<5, 2, true, true>), grid, dim3(rt::kThreads), 0, s, a, dc);
+      VQA_LAUNCH((rt::gemm_tn_kernel<5, 2, true, true>), grid, dim3(rt::kThreads), 0, s, a, dc);
     else if (gate)
-      hipLaunchKernelGGL((rt::gemm_tn_kernel<5, 2, true, false>), grid, dim3(rt::kThreads), 0, s, a, dc);
+      VQA_LAUNCH((rt::gemm_tn_kernel<5, 2, true, false>), grid, dim3(rt::kThreads), 0, s, a, dc);
     else if (drop)
-      hipLaunchKernelGGL((rt::gemm_tn_kernel<5, 2, false, true>), grid, dim3(rt::kThreads), 0, s, a, dc);
+      VQA_LAUNCH((rt::gemm_tn_kernel<5, 2, false, true>), grid, dim3(rt::kThreads), 0, s, a, dc);
     else
-      hipLaunchKernelGGL((rt::gemm_tn_kernel<5, 2, false, false>), grid, dim3(rt::kThreads), 0, s, a, dc);
+      VQA_LAUNCH((rt::gemm_tn_kernel<5, 2, false, false>), grid, dim3(rt::kThreads), 0, s, a, dc);
     const int NK = N * K;
-    hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3((NK / 2 + 255) / 256), dim3(256), 0, s, slab, dbslab, d_w, d_b, NK, N, S);
+    VQA_LAUNCH(linear_dw_reduce_kernel, dim3((NK / 2 + 255) / 256), dim3(256), 0, s, slab, dbslab, d_w, d_b, NK, N, S);
   } else {
     const TileChoice t = linear_dw_tile();
     const int S = splits_for_linear_dw(M, K, N, t);
@@ -422,18 +422,18 @@ extern "C" int vqa_linear_act_bwd(const float* x, int ldx, const float* w, const
     const size_t lds = GemmTile<BM_, BN_, 16, false, false>::kSmemBytes;                                                 \
     if (dc.p8 > 0) {                                                                                                     \
       VQA_ENSURE_LDS((linear_dw_kernel<BM_, BN_, PF_, true>), lds);                                                      \
-      hipLaunchKernelGGL((linear_dw_kernel<BM_, BN_, PF_, true>), dim3(tiles_m * tiles_n * S), dim3(kGemmThreads), lds, s, \
+      VQA_LAUNCH((linear_dw_kernel<BM_, BN_, PF_, true>), dim3(tiles_m * tiles_n * S), dim3(kGemmThreads), lds, s, \
                          gy, y, x, ldx, slab, dbslab, M, K, N, act, dc, tiles_m, tiles_n, rows_per_split);                \
     } else {                                                                                                             \
       VQA_ENSURE_LDS((linear_dw_kernel<BM_, BN_, PF_, false>), lds);                                                     \
-      hipLaunchKernelGGL((linear_dw_kernel<BM_, BN_, PF_, false>), dim3(tiles_m * tiles_n * S), dim3(kGemmThreads), lds, s, \
+      VQA_LAUNCH((linear_dw_kernel<BM_, BN_, PF_, false>), dim3(tiles_m * tiles_n * S), dim3(kGemmThreads), lds, s, \
                          gy, y, x, ldx, slab, dbslab, M, K, N, act, dc, tiles_m, tiles_n, rows_per_split);                \
     }                                                                                                                    \
   }
     VQA_TILE_SWITCH(t, LAUNCH);
 #undef LAUNCH
     const int NK = N * K;
-    hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3((NK / 2 + 255) / 256), dim3(256), 0, s, slab, dbslab, d_w, d_b, NK, N, S);
+    VQA_LAUNCH(linear_dw_reduce_kernel, dim3((NK / 2 + 255) / 256), dim3(256), 0, s, slab, dbslab, d_w, d_b, NK, N, S);
   }
   return check_launch("linear_act_bwd");
 }
@@ -452,7 +452,7 @@ extern "C" int vqa_linear_dropout_mask(float* mask, float p_drop, uint64_t seed,
   VQA_REQUIRE(mask && M > 0 && K > 0 && K % 2 == 0, VQA_E_BADARG, "linear_dropout_mask: bad arguments");
   VQA_REQUIRE(p_drop >= 0.f && p_drop < 1.f, VQA_E_BADARG, "linear_dropout_mask: p_drop=%f outside [0,1)", (double)p_drop);
   const size_t n = (size_t)M * K;
-  hipLaunchKernelGGL(linear_mask_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+  VQA_LAUNCH(linear_mask_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      mask, n, make_drop(p_drop, seed, seed_ptr));
   return check_launch("linear_dropout_mask");
 }

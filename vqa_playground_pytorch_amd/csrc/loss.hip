@@ -104,7 +104,7 @@ extern "C" int vqa_kld_sum_loss(const float* logits, const float* target, float*
               "kld_sum_loss: workspace of %zu B is too small", workspace_bytes);
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* row_loss = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(kld_rows_kernel, dim3(B), dim3(kLossThreads), 0, s, logits, target, row_loss, d_logits, C);
-  hipLaunchKernelGGL(kld_total_kernel, dim3(1), dim3(256), 0, s, row_loss, loss, B);
+  VQA_LAUNCH(kld_rows_kernel, dim3(B), dim3(kLossThreads), 0, s, logits, target, row_loss, d_logits, C);
+  VQA_LAUNCH(kld_total_kernel, dim3(1), dim3(256), 0, s, row_loss, loss, B);
   return check_launch("kld_sum_loss");
 }

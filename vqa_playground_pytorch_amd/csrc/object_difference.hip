@@ -970,7 +970,7 @@ static int oda_threads(int L) {
 static int oda_groups(int B) { return B < 128 ? B : 128; }
 // the 4x4-MFMA kernels (forward, weight gradient): G <= 4 glimpses, N <= 36 regions, no dropout or the one-bit p = 0.5 mask
 static bool oda_mfma_ok(const DropCfg& dc, int B, int N, int L, int G) {
-  static const bool off = vqa::option("VQA_K2_MFMA") != nullptr && vqa::option("VQA_K2_MFMA")[0] == '0';
+  const bool off = vqa::option_is("VQA_K2_MFMA", '0');
   return !off && G <= 4 && N <= 4 * kOdaIG && (dc.p8 == 0 || oda_bits_mode(dc, B, N, L)) && (size_t)B * N * L * 4 < (1ull << 32);
 }
 static int oda_mfma_groups(int B) { return B < 256 ? B : 256; }   // sample groups of the MFMA weight gradient: one workgroup per CU
@@ -994,24 +994,24 @@ static int launch_fwd(const float* vl, const float* ql, const float* w, const fl
       const int jt = 1, nj = (N + 3) / 4 * 4;   // (one slice of the region axis j: see the kernel's note on work units)
       const size_t lds_m = (size_t)nw * 4 * kOdaIG * 4 * sizeof(float);
       if (bits)
-        hipLaunchKernelGGL(oda_fwd_mfma_kernel<true>, dim3(B), dim3(64 * nw), lds_m, s, vl, ql, w, bias, logits, dc, N, L, G, jt, nj);
+        VQA_LAUNCH(oda_fwd_mfma_kernel<true>, dim3(B), dim3(64 * nw), lds_m, s, vl, ql, w, bias, logits, dc, N, L, G, jt, nj);
       else
-        hipLaunchKernelGGL(oda_fwd_mfma_kernel<false>, dim3(B), dim3(64 * nw), lds_m, s, vl, ql, w, bias, logits, dc, N, L, G, jt, nj);
+        VQA_LAUNCH(oda_fwd_mfma_kernel<false>, dim3(B), dim3(64 * nw), lds_m, s, vl, ql, w, bias, logits, dc, N, L, G, jt, nj);
       return check_launch("object_difference_attention_fwd");
     }
   }
   if (oda_bits_mode(dc, B, N, L)) {
     const size_t lds_b = (size_t)(nt / 64) * kIB * G * sizeof(float);
-    hipLaunchKernelGGL((oda_fwd_bits_kernel<G>), dim3((N + kIB - 1) / kIB, B), dim3(nt), lds_b, s, vl, ql, w, bias, logits, dc, N,
+    VQA_LAUNCH((oda_fwd_bits_kernel<G>), dim3((N + kIB - 1) / kIB, B), dim3(nt), lds_b, s, vl, ql, w, bias, logits, dc, N,
                        L);
     return check_launch("object_difference_attention_fwd");
   }
   const size_t lds = (size_t)(nt / 64) * kIC * G * sizeof(float);
   dim3 grid((N + kIC - 1) / kIC, B);
   if (dc.p8 > 0)
-    hipLaunchKernelGGL((oda_fwd_kernel<G, true>), grid, dim3(nt), lds, s, vl, ql, w, bias, logits, dc, N, L);
+    VQA_LAUNCH((oda_fwd_kernel<G, true>), grid, dim3(nt), lds, s, vl, ql, w, bias, logits, dc, N, L);
   else
-    hipLaunchKernelGGL((oda_fwd_kernel<G, false>), grid, dim3(nt), lds, s, vl, ql, w, bias, logits, dc, N, L);
+    VQA_LAUNCH((oda_fwd_kernel<G, false>), grid, dim3(nt), lds, s, vl, ql, w, bias, logits, dc, N, L);
   return check_launch("object_difference_attention_fwd");
 }
 
@@ -1022,22 +1022,22 @@ static int launch_bwd(const float* vl, const float* ql, const float* w, const fl
   {
     const size_t lds = ((size_t)N * nt + (size_t)(N + kIC) * G) * sizeof(float);   // (+ kIC zero rows of dS, bit-mask kernel)
     VQA_REQUIRE(lds <= 160 * 1024, VQA_E_UNSUPPORTED, "object_difference_attention_bwd: N=%d L=%d need %zu B of LDS", N, L, lds);
-    static const bool split_off = vqa::option("VQA_K2_DATA_SPLIT") != nullptr && vqa::option("VQA_K2_DATA_SPLIT")[0] == '0';
+    const bool split_off = vqa::option_is("VQA_K2_DATA_SPLIT", '0');
     const int nc = (N + kIC - 1) / kIC;
     if (oda_bits_mode(dc, B, N, L) && nc <= 4 && !split_off && (long)B * ((L + 63) / 64) >= 512) {
       const size_t lds_s = ((size_t)nc * N * 64 + (size_t)nc * 64 + (size_t)(N + kIC) * G) * sizeof(float);
       VQA_ENSURE_LDS((oda_bwd_data_bits_split_kernel<G>), lds_s);
-      hipLaunchKernelGGL((oda_bwd_data_bits_split_kernel<G>), dim3((L + 63) / 64, B), dim3(64 * nc), lds_s, s, vl, ql, w, dS,
+      VQA_LAUNCH((oda_bwd_data_bits_split_kernel<G>), dim3((L + 63) / 64, B), dim3(64 * nc), lds_s, s, vl, ql, w, dS,
                          d_vl, d_ql, dc, N, L, gate_dvl);
     } else if (oda_bits_mode(dc, B, N, L)) {
       VQA_ENSURE_LDS((oda_bwd_data_bits_kernel<G>), lds);
-      hipLaunchKernelGGL((oda_bwd_data_bits_kernel<G>), dim3(B), dim3(nt), lds, s, vl, ql, w, dS, d_vl, d_ql, dc, N, L, gate_dvl);
+      VQA_LAUNCH((oda_bwd_data_bits_kernel<G>), dim3(B), dim3(nt), lds, s, vl, ql, w, dS, d_vl, d_ql, dc, N, L, gate_dvl);
     } else if (dc.p8 > 0) {
       VQA_ENSURE_LDS((oda_bwd_data_kernel<G, true>), lds);
-      hipLaunchKernelGGL((oda_bwd_data_kernel<G, true>), dim3(B), dim3(nt), lds, s, vl, ql, w, dS, d_vl, d_ql, dc, N, L, gate_dvl);
+      VQA_LAUNCH((oda_bwd_data_kernel<G, true>), dim3(B), dim3(nt), lds, s, vl, ql, w, dS, d_vl, d_ql, dc, N, L, gate_dvl);
     } else {
       VQA_ENSURE_LDS((oda_bwd_data_kernel<G, false>), lds);
-      hipLaunchKernelGGL((oda_bwd_data_kernel<G, false>), dim3(B), dim3(nt), lds, s, vl, ql, w, dS, d_vl, d_ql, dc, N, L, gate_dvl);
+      VQA_LAUNCH((oda_bwd_data_kernel<G, false>), dim3(B), dim3(nt), lds, s, vl, ql, w, dS, d_vl, d_ql, dc, N, L, gate_dvl);
     }
   }
   {
@@ -1052,19 +1052,19 @@ static int launch_bwd(const float* vl, const float* ql, const float* w, const fl
       const int nsets = (L + 15) / 16, nw = nsets < 4 ? nsets : 4;
       const size_t lds_m = (size_t)nw * 4 * kOdaIG * 64 * sizeof(float);
       if (dc.p8 > 0)
-        hipLaunchKernelGGL(oda_bwd_weight_mfma_kernel<true>, dim3(SG), dim3(128 * nw), lds_m, s, vl, ql, dS, slab, dc, B, N, L, G, spg);
+        VQA_LAUNCH(oda_bwd_weight_mfma_kernel<true>, dim3(SG), dim3(128 * nw), lds_m, s, vl, ql, dS, slab, dc, B, N, L, G, spg);
       else
-        hipLaunchKernelGGL(oda_bwd_weight_mfma_kernel<false>, dim3(SG), dim3(128 * nw), lds_m, s, vl, ql, dS, slab, dc, B, N, L, G, spg);
+        VQA_LAUNCH(oda_bwd_weight_mfma_kernel<false>, dim3(SG), dim3(128 * nw), lds_m, s, vl, ql, dS, slab, dc, B, N, L, G, spg);
     } else if (oda_bits_mode(dc, B, N, L))
-      hipLaunchKernelGGL((oda_bwd_weight_bits_kernel<G>), grid, dim3(nt), lds, s, vl, ql, dS, slab, dc, B, N, L, spg);
+      VQA_LAUNCH((oda_bwd_weight_bits_kernel<G>), grid, dim3(nt), lds, s, vl, ql, dS, slab, dc, B, N, L, spg);
     else if (dc.p8 > 0)
-      hipLaunchKernelGGL((oda_bwd_weight_kernel<G, true>), grid, dim3(nt), lds, s, vl, ql, dS, slab, dc, B, N, L, spg);
+      VQA_LAUNCH((oda_bwd_weight_kernel<G, true>), grid, dim3(nt), lds, s, vl, ql, dS, slab, dc, B, N, L, spg);
     else
-      hipLaunchKernelGGL((oda_bwd_weight_kernel<G, false>), grid, dim3(nt), lds, s, vl, ql, dS, slab, dc, B, N, L, spg);
+      VQA_LAUNCH((oda_bwd_weight_kernel<G, false>), grid, dim3(nt), lds, s, vl, ql, dS, slab, dc, B, N, L, spg);
     const size_t n = (size_t)G * N * L;
-    hipLaunchKernelGGL(oda_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, slab, d_w, n, SG);
+    VQA_LAUNCH(oda_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, slab, d_w, n, SG);
   }
-  hipLaunchKernelGGL(oda_dbias_kernel<G>, dim3(1), dim3(1024), 0, s, dS, d_bias, B * N);
+  VQA_LAUNCH(oda_dbias_kernel<G>, dim3(1), dim3(1024), 0, s, dS, d_bias, B * N);
   return check_launch("object_difference_attention_bwd");
 }
 
@@ -1137,7 +1137,7 @@ extern "C" int vqa_object_difference_dropout_mask(float* mask, float p_drop, uin
   int rc = oda_check("object_difference_dropout_mask", B, N, L, 1, p_drop);
   if (rc != VQA_OK) return rc;
   const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
-  hipLaunchKernelGGL(oda_mask_kernel, dim3((N * L + 255) / 256, N, B), dim3(256), 0, static_cast<hipStream_t>(stream), mask,
+  VQA_LAUNCH(oda_mask_kernel, dim3((N * L + 255) / 256, N, B), dim3(256), 0, static_cast<hipStream_t>(stream), mask,
                      dc, N, L, oda_bits_mode(dc, B, N, L));
   return check_launch("object_difference_dropout_mask");
 }

@@ -113,8 +113,8 @@ extern "C" int vqa_grad_norm_clip_coef(const float* g, size_t n, float max_norm,
   const size_t need = (n / 4 + 255) / 256;
   const int blocks = (int)(need < (size_t)kNormBlocks ? (need ? need : 1) : (size_t)kNormBlocks);
   double* partial = static_cast<double*>(workspace);
-  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, s, g, n, partial);
-  hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(256), 0, s, partial, blocks, max_norm, norm_and_coef);
+  VQA_LAUNCH(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, s, g, n, partial);
+  VQA_LAUNCH(norm_finish_kernel, dim3(1), dim3(256), 0, s, partial, blocks, max_norm, norm_and_coef);
   return check_launch("grad_norm_clip_coef");
 }
 
@@ -126,7 +126,7 @@ extern "C" int vqa_adam_step(float* p, const float* g, float* m, float* v, size_
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   const float step_size = (float)(lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   const size_t blocks = (n / 4 + 256) / 256;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n,
+  VQA_LAUNCH(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n,
                      norm_and_coef, static_cast<const float*>(nullptr), beta1, beta2, eps, step_size, inv_sqrt_bc2);
   return check_launch("adam_step");
 }
@@ -137,7 +137,7 @@ extern "C" int vqa_adam_step_dyn(float* p, const float* g, float* m, float* v, s
   VQA_REQUIRE(aligned(p, 16) && aligned(g, 16) && aligned(m, 16) && aligned(v, 16), VQA_E_UNSUPPORTED,
               "adam_step_dyn: buffers must be 16-byte aligned");
   const size_t blocks = (n / 4 + 256) / 256;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n,
+  VQA_LAUNCH(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n,
                      norm_and_coef, step_scalars, beta1, beta2, eps, 0.f, 1.f);
   return check_launch("adam_step_dyn");
 }

@@ -500,14 +500,14 @@ static int pairwise_fwd_impl(const char* who, const T* v, const float* q1, const
   VQA_REQUIRE(B <= 65535, VQA_E_UNSUPPORTED, "%s: B=%d exceeds 65535", who, B);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (mode == 1 && N <= kRegN) {
-    hipLaunchKernelGGL(pairwise_fwd_reg_kernel<T>, dim3((D / 4 + 63) / 64, B), dim3(64), 0, s, v, q1, q2, alpha, alpha_stride,
+    VQA_LAUNCH(pairwise_fwd_reg_kernel<T>, dim3((D / 4 + 63) / 64, B), dim3(64), 0, s, v, q1, q2, alpha, alpha_stride,
                        v2, N, D);
     return check_launch(who);
   }
   if (mode == 1) {
     VQA_REQUIRE(N <= 4096, VQA_E_UNSUPPORTED, "%s: N=%d exceeds 4096", who, N);
     constexpr int NT = 256;
-    hipLaunchKernelGGL((pairwise_fwd_stream_kernel<T, NT>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), (size_t)N * 4, s, v, q1, q2,
+    VQA_LAUNCH((pairwise_fwd_stream_kernel<T, NT>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), (size_t)N * 4, s, v, q1, q2,
                        alpha, alpha_stride, v2, N, D);
     return check_launch(who);
   }
@@ -515,12 +515,12 @@ static int pairwise_fwd_impl(const char* who, const T* v, const float* q1, const
     const int tiles_d = (D / 4 + 63) / 64;
     if constexpr (sizeof(T) == 4) {
       if ((long)B * D >= (1L << 19) && vqa::option("VQA_K1_PAIRWISE_REG4") == nullptr) {   // enough columns for half-sized waves
-        hipLaunchKernelGGL(pairwise_fwd_pairs_reg2_kernel, dim3((D / 2 + 63) / 64, B), dim3(64), 0, s, v, q1, q2, alpha,
+        VQA_LAUNCH(pairwise_fwd_pairs_reg2_kernel, dim3((D / 2 + 63) / 64, B), dim3(64), 0, s, v, q1, q2, alpha,
                            alpha_stride, v2, N, D, make_drop(0.f, 0));
         return check_launch(who);
       }
     }
-    hipLaunchKernelGGL(pairwise_fwd_pairs_reg_kernel<T>, dim3(tiles_d, B), dim3(64), 0, s, v, q1, q2, alpha, alpha_stride, v2,
+    VQA_LAUNCH(pairwise_fwd_pairs_reg_kernel<T>, dim3(tiles_d, B), dim3(64), 0, s, v, q1, q2, alpha, alpha_stride, v2,
                        N, D);
     return check_launch(who);
   }
@@ -530,10 +530,10 @@ static int pairwise_fwd_impl(const char* who, const T* v, const float* q1, const
   dim3 grid((D / 4 + nt - 1) / nt, B);
   if (nt == 128) {
     VQA_ENSURE_LDS((pairwise_fwd_kernel<T, 128>), lds);
-    hipLaunchKernelGGL((pairwise_fwd_kernel<T, 128>), grid, dim3(128), lds, s, v, q1, q2, alpha, alpha_stride, v2, N, D, mode);
+    VQA_LAUNCH((pairwise_fwd_kernel<T, 128>), grid, dim3(128), lds, s, v, q1, q2, alpha, alpha_stride, v2, N, D, mode);
   } else {
     VQA_ENSURE_LDS((pairwise_fwd_kernel<T, 64>), lds);
-    hipLaunchKernelGGL((pairwise_fwd_kernel<T, 64>), grid, dim3(64), lds, s, v, q1, q2, alpha, alpha_stride, v2, N, D, mode);
+    VQA_LAUNCH((pairwise_fwd_kernel<T, 64>), grid, dim3(64), lds, s, v, q1, q2, alpha, alpha_stride, v2, N, D, mode);
   }
   return check_launch(who);
 }
@@ -562,19 +562,19 @@ static int pairwise_bwd_impl(const char* who, const T* v, const float* q1, const
     const size_t lds = (((size_t)N * 8 + 15) / 16) * 16 + (size_t)RS * 3 * (NT / RS) * sizeof(float4);
     const dim3 grid((D / 4 + 63) / 64, B);
     if (g_v2_b != nullptr) {
-      hipLaunchKernelGGL((pairwise_bwd_stream_kernel<T, NT, true, RS>), grid, dim3(NT), lds, s, v, q1, q2, alpha, alpha_stride,
+      VQA_LAUNCH((pairwise_bwd_stream_kernel<T, NT, true, RS>), grid, dim3(NT), lds, s, v, q1, q2, alpha, alpha_stride,
                          g_v2, g_v2_b, d_alpha, d_q1, d_q2, d_v, N, D);
     } else {
-      hipLaunchKernelGGL((pairwise_bwd_stream_kernel<T, NT, false, RS>), grid, dim3(NT), lds, s, v, q1, q2, alpha, alpha_stride,
+      VQA_LAUNCH((pairwise_bwd_stream_kernel<T, NT, false, RS>), grid, dim3(NT), lds, s, v, q1, q2, alpha, alpha_stride,
                          g_v2, g_v2_b, d_alpha, d_q1, d_q2, d_v, N, D);
     }
     return check_launch(who);
   }
   if (g_v2_b != nullptr) {
-    hipLaunchKernelGGL((pairwise_bwd_stream_kernel<T, NT, true, 1>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), (size_t)N * 8, s,
+    VQA_LAUNCH((pairwise_bwd_stream_kernel<T, NT, true, 1>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), (size_t)N * 8, s,
                        v, q1, q2, alpha, alpha_stride, g_v2, g_v2_b, d_alpha, d_q1, d_q2, d_v, N, D);
   } else {
-    hipLaunchKernelGGL((pairwise_bwd_stream_kernel<T, NT, false, 1>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), (size_t)N * 8, s,
+    VQA_LAUNCH((pairwise_bwd_stream_kernel<T, NT, false, 1>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), (size_t)N * 8, s,
                        v, q1, q2, alpha, alpha_stride, g_v2, g_v2_b, d_alpha, d_q1, d_q2, d_v, N, D);
   }
   return check_launch(who);
@@ -604,7 +604,7 @@ static int relation_apply_fwd_impl(const char* who, const T* v, const float* t, 
   if (zsplit > (N + 3) / 4) zsplit = (N + 3) / 4;
   if (zsplit < 1) zsplit = 1;
   const int rows_per_block = (N + zsplit - 1) / zsplit;
-  hipLaunchKernelGGL((relation_apply_fwd_kernel<T, NT>), dim3(col_blocks, B, (N + rows_per_block - 1) / rows_per_block), dim3(NT),
+  VQA_LAUNCH((relation_apply_fwd_kernel<T, NT>), dim3(col_blocks, B, (N + rows_per_block - 1) / rows_per_block), dim3(NT),
                      0, static_cast<hipStream_t>(stream), v, t, c2, out, N, D, rows_per_block, make_drop(p_drop, seed, seed_ptr));
   return check_launch(who);
 }
@@ -626,17 +626,17 @@ static int relation_apply_bwd_impl(const char* who, const T* v, const float* c2,
     if (d_v == nullptr && D % 8 == 0 && aligned(v, 16) && aligned(g, 16) && (long)B * N * D < (1L << 32) &&
         (long)B * D / 4 < 4 * 65536) {
       constexpr int RS = 8;
-      hipLaunchKernelGGL(relation_apply_bwd8_bf16_kernel<RS>, dim3((D / 8 + 256 / RS - 1) / (256 / RS), B), dim3(256), 0, s,
+      VQA_LAUNCH(relation_apply_bwd8_bf16_kernel<RS>, dim3((D / 8 + 256 / RS - 1) / (256 / RS), B), dim3(256), 0, s,
                          reinterpret_cast<const bf16*>(v), reinterpret_cast<const bf16*>(g), d_t, d_c2, N, D, dc);
       return check_launch(who);
     }
   }
   if ((long)B * D / 4 < 4 * 65536) {  // small batch: the 4 waves of a workgroup share 256 columns and split the rows
     constexpr int RS = NT / 64;
-    hipLaunchKernelGGL((relation_apply_bwd_kernel<T, NT, RS>), dim3((D / 4 + 63) / 64, B), dim3(NT),
+    VQA_LAUNCH((relation_apply_bwd_kernel<T, NT, RS>), dim3((D / 4 + 63) / 64, B), dim3(NT),
                        (size_t)RS * 2 * (NT / RS) * sizeof(float4), s, v, c2, g, d_t, d_c2, d_v, N, D, dc);
   } else {
-    hipLaunchKernelGGL((relation_apply_bwd_kernel<T, NT, 1>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), 0, s, v, c2, g, d_t,
+    VQA_LAUNCH((relation_apply_bwd_kernel<T, NT, 1>), dim3((D / 4 + NT - 1) / NT, B), dim3(NT), 0, s, v, c2, g, d_t,
                        d_c2, d_v, N, D, dc);
   }
   return check_launch(who);
@@ -713,7 +713,7 @@ extern "C" int vqa_pairwise_relation_reduce_drop_fwd(const float* v, const float
   VQA_REQUIRE(vqa_pairwise_relation_reduce_drop_supported(B, N, D) && aligned(v, 16) && aligned(q1, 16) && aligned(q2, 16) &&
                   aligned(v2, 16),
               VQA_E_UNSUPPORTED, "pairwise_relation_reduce_drop_fwd: needs N <= %d, D %% 4 == 0, B*D >= 2^19, aligned tensors", kRegN);
-  hipLaunchKernelGGL(pairwise_fwd_pairs_reg2_kernel, dim3((D / 2 + 63) / 64, B), dim3(64), 0, static_cast<hipStream_t>(stream), v, q1,
+  VQA_LAUNCH(pairwise_fwd_pairs_reg2_kernel, dim3((D / 2 + 63) / 64, B), dim3(64), 0, static_cast<hipStream_t>(stream), v, q1,
                      q2, alpha, alpha_stride, v2, N, D, make_drop(p_drop, seed, seed_ptr));
   return check_launch("pairwise_relation_reduce_drop_fwd");
 }

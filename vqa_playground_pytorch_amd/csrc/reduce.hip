@@ -176,7 +176,7 @@ static int column_sum_impl(const char* who, const T* x, int ld, float* out, void
   VQA_REQUIRE(x && out, VQA_E_BADARG, "%s: null pointer", who);
   VQA_REQUIRE(M > 0 && N > 0 && ld >= N, VQA_E_BADARG, "%s: bad sizes M=%d N=%d ld=%d", who, M, N, ld);
   if (M <= kColShortM) {
-    hipLaunchKernelGGL(column_sum_short_kernel<T>, dim3((N + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), x, ld,
+    VQA_LAUNCH(column_sum_short_kernel<T>, dim3((N + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), x, ld,
                        out, M, N);
     return check_launch(who);
   }
@@ -190,14 +190,14 @@ static int column_sum_impl(const char* who, const T* x, int ld, float* out, void
   float* dst = S > 1 ? static_cast<float*>(workspace) : out;
   const dim3 grid((N + 64 * vec - 1) / (64 * vec), S);
   if (vec == 4) {
-    hipLaunchKernelGGL((column_sum_kernel<T, 4>), grid, dim3(kColThreads), 0, s, x, ld, dst, M, N, rows_per_slab);
+    VQA_LAUNCH((column_sum_kernel<T, 4>), grid, dim3(kColThreads), 0, s, x, ld, dst, M, N, rows_per_slab);
   } else if (vec == 2) {
-    hipLaunchKernelGGL((column_sum_kernel<T, 2>), grid, dim3(kColThreads), 0, s, x, ld, dst, M, N, rows_per_slab);
+    VQA_LAUNCH((column_sum_kernel<T, 2>), grid, dim3(kColThreads), 0, s, x, ld, dst, M, N, rows_per_slab);
   } else {
-    hipLaunchKernelGGL((column_sum_kernel<T, 1>), grid, dim3(kColThreads), 0, s, x, ld, dst, M, N, rows_per_slab);
+    VQA_LAUNCH((column_sum_kernel<T, 1>), grid, dim3(kColThreads), 0, s, x, ld, dst, M, N, rows_per_slab);
   }
   if (S > 1)
-    hipLaunchKernelGGL(column_sum_finish_kernel, dim3((N + 63) / 64), dim3(256), 0, s, static_cast<const float*>(workspace),
+    VQA_LAUNCH(column_sum_finish_kernel, dim3((N + 63) / 64), dim3(256), 0, s, static_cast<const float*>(workspace),
                        out, N, S);
   return check_launch(who);
 }

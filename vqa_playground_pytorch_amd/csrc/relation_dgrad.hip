@@ -323,7 +323,7 @@ using namespace vqa;
 
 // include/vqa_mi355x.h
 extern "C" int vqa_relation_projection_dgrad_supported(int B, int N, int D, int L) {
-  static const bool off = vqa::option("VQA_FUSE_RELATION_DGRAD") != nullptr && vqa::option("VQA_FUSE_RELATION_DGRAD")[0] == '0';
+  const bool off = vqa::option_is("VQA_FUSE_RELATION_DGRAD", '0');
   return !off && N == kRegions && B >= 1 && D % 64 == 0 && D >= 64 && L >= 32 && L % 2 == 0 && (size_t)B * N * D * 4 < (1ull << 32) &&
          (size_t)L * D * 4 < (1ull << 32);
 }
@@ -360,12 +360,12 @@ extern "C" int vqa_relation_projection_dgrad(const float* gz, const float* w, co
 #define VQA_RD_LAUNCH(T_)                                                                \
   {                                                                                      \
     VQA_ENSURE_LDS(relation_dgrad_kernel<T_>, lds);                                      \
-    hipLaunchKernelGGL(relation_dgrad_kernel<T_>, grid, dim3(rt::kThreads), lds, s, a, dc); \
+    VQA_LAUNCH(relation_dgrad_kernel<T_>, grid, dim3(rt::kThreads), lds, s, a, dc); \
   }
   if (tune == 1) VQA_RD_LAUNCH(1)
   else if (tune == 2) VQA_RD_LAUNCH(2)
   else if (tune == 3) VQA_RD_LAUNCH(3)
-  else if (tune == 4) hipLaunchKernelGGL(relation_dgrad_kernel<4>, grid, dim3(rt::kThreads), 0, s, a, dc);
+  else if (tune == 4) VQA_LAUNCH(relation_dgrad_kernel<4>, grid, dim3(rt::kThreads), 0, s, a, dc);
   else VQA_RD_LAUNCH(0)
 #undef VQA_RD_LAUNCH
   return check_launch("relation_projection_dgrad");

@@ -193,7 +193,9 @@ class MyConv1d(nn.Module):
         kernels (ops.LinearBf16).  packed: the layer's shadows from the model's ShadowPlan, or None."""
         w = self.conv.weight.squeeze(-1)
         if self.out_channels >= 32 and self.bf16_gemm == "engine" and af in (None, "", "relu"):
-            if p and p != 0.5:
+            if p and (p != 0.5 or x.requires_grad):
+                # the in-kernel mask exists at p = 0.5 and has no data gradient (compress_v reads the model input); an x
+                # that needs one (compress_v2 behind the pairwise relation, relation_mode=0) is dropped beforehand
                 x, p = F.dropout(x, p=p, training=True), 0.0
             return ops.linear_bf16(x, w, self.conv.bias, af, p, ops.next_dropout_seed() if p else 0,
                                    pregated=self.grad_pregated, packed=packed)

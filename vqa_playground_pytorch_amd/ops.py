@@ -26,6 +26,7 @@ class KernelTimer:
     def __init__(self, names=None):
         self.names = set(names) if names else None
         self.events = {}
+        self.grids = {}       # (name, shape) -> ((grid in work-items, kernel expression), ...) of the kernels the call launched
 
     def wants(self, name):
         return self.names is None or name in self.names
@@ -52,10 +53,17 @@ def _launch(name, shape, fn, *args):
     t = _timer
     if t is not None and t.wants(name):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        handle = _lib.lib()
+        handle.vqa_launch_log_reset()
         a.record()
         rc = fn(*args, _stream())
         b.record()
         t.events.setdefault((name, shape), []).append((a, b))
+        if (name, shape) not in t.grids:      # the device kernels behind this call: grid sizes in work-items, launch order
+            buf = (ctypes.c_ulonglong * 16)()
+            n = handle.vqa_launch_log(buf, 16)
+            t.grids[(name, shape)] = tuple((int(buf[i]), (handle.vqa_launch_log_kernel(i) or b"").decode())
+                                           for i in range(min(n, 16)))
     else:
         rc = fn(*args, _stream())
     _lib.check(rc, name)
