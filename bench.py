@@ -726,7 +726,7 @@ def main():
                         "traffic": lead["traffic"], "kernel": name, "mean_ms": round(total_ms / launches, 5),
                         "launches": launches, "ms_per_step": round(sum(e["ms_per_step"] for e in group), 5),
                         "shapes": [e["shape"] for e in group],
-                        "device_kernels": [k for k, _ in PMC_KERNELS.get(name, [])]}
+                        "device_kernels": lead.get("device_kernels", PMC_KERNELS.get(name, []))}
             if "mfma_busy_pct" in lead:
                 dominant["mfma_busy_pct"] = lead["mfma_busy_pct"]
         else:

@@ -658,7 +658,11 @@ def test_cor2_bf16_pairwise_relation_trains(B, N):
     np.testing.assert_allclose(grads[0][0], grads[1][0], rtol=0, atol=RTOL_MODEL * np.abs(grads[1][0]).max())
     for n, g1 in grads[1][1].items():
         g0 = grads[0][1][n]
-        if np.sqrt((g1 ** 2).sum()) < 1e-6:
+        # mathematically zero in eval mode (a per-glimpse constant in front of the softmax over regions): rounding noise on
+        # both sides
+        zero = n.endswith("conv_att.conv.bias") or (n.startswith(("fusion_vq1.list_linear1", "fusion_vq2.list_linear1"))
+                                                    and n.endswith(".bias"))
+        if zero or np.sqrt((g1 ** 2).sum()) < 1e-6:
             continue
         err = np.sqrt(((g0 - g1) ** 2).sum()) / np.sqrt((g1 ** 2).sum())
         assert err <= GRAD_RELF, "%s: relation_mode 0 vs 1 relative Frobenius error %.3e" % (n, err)
