@@ -97,7 +97,7 @@ def main():
             if not info:
                 sized = ph._size()
                 info["parts"] = sorted({(p["ksplit"], p["splits"]) for _, p in sized})
-                info["items"] = sum(-(-t.M // head.Phase.tile(p["form"])[0]) * -(-t.N // head.Phase.tile(p["form"])[1]) * p["splits"] for t, p in sized)
+                info["items"] = sum(-(-t.M // head.Phase.TILE_M) * -(-t.N // 64) * p["splits"] for t, p in sized)
             ph.run()
 
         def lib():

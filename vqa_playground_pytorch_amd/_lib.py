@@ -105,7 +105,6 @@ SIGNATURES = {
                                                     _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_gate_product_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_st]),
     "vqa_grouped_gemm": (_c_i, [ctypes.c_void_p, _c_i, _c_st]),
-    "vqa_grouped_tile": (_c_i, [_c_i, ctypes.POINTER(_c_i), ctypes.POINTER(_c_i), ctypes.POINTER(_c_i)]),
     "vqa_grouped_epilogue": (_c_i, [ctypes.c_void_p, _c_i, _c_st]),
     "vqa_gru_gates_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_f, _c_f, _c_f, _c_f,
                                  _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),

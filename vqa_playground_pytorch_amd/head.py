@@ -88,30 +88,17 @@ class Phase:
     """Collects the GEMM problems and epilogue jobs of one phase, sizes the contraction splits so that the phase's tiles
     fill the chip, allocates the slabs and launches the two kernels."""
 
-    # How a phase is cut into work items (output tile x contraction part; the tile of a form is the library's:
-    # vqa_grouped_tile -- 128 x 64 for NT / NN, 128 x 128 for TN, 32-deep stages).  No item is longer than MAX_PART contraction
+    # How a phase is cut into work items (64x64 tile x contraction part).  No item is longer than MAX_PART contraction
     # steps (a phase mixes K = 155 .. 2400: the longest items would otherwise set the launch time), and when the phase has
     # fewer items than the target (see _size) the parts are shortened until it has.
     # A product that ends up in ONE part and is the only contribution to its result is finished inside the GEMM kernel
     # (direct output: bias / activation / gate / dropout on the accumulators) and needs neither slab nor epilogue job.
-    # VQA_GROUPED_PART (a fixed part length): measurement knob.
-    FIXED_PART = int(os.environ.get("VQA_GROUPED_PART", "0"))     # 0: by the estimate in _size
-    MAX_PART = 1280
+    # VQA_GROUPED_ITEMS / VQA_GROUPED_PART / VQA_GROUPED_BM (tile rows 64 | 128, read by the library as well): measurement knobs.
+    MIN_ITEMS = int(os.environ.get("VQA_GROUPED_ITEMS", "0"))     # 0: by the phase's rows (below)
+    MAX_PART = int(os.environ.get("VQA_GROUPED_PART", "640"))
+    TILE_M = 128 if os.environ.get("VQA_GROUPED_BM") == "128" else 64
     DIRECT = os.environ.get("VQA_GROUPED_DIRECT", "1") == "1"
-    SLOTS = 512           # workgroups the chip runs at once: 256 CUs x 2 (the kernel's launch bounds)
-    LONE = float(os.environ.get("VQA_GG_LONE", "1.15"))            # constants of the estimate in _size (sweep knobs)
-    SLAB_US_PER_MB = float(os.environ.get("VQA_GG_SLAB", "0.15"))
-    SPLIT_US = float(os.environ.get("VQA_GG_SPLIT", "0"))
-    _tiles = {}
-
-    @classmethod
-    def tile(cls, form):
-        """(rows, cols, stage depth) of the work-item tile of a GEMM form, asked of the library once."""
-        if form not in cls._tiles:
-            r, c, d = _c.c_int(), _c.c_int(), _c.c_int()
-            _lib.check(_lib.lib().vqa_grouped_tile(int(form), _c.byref(r), _c.byref(c), _c.byref(d)), "grouped_tile")
-            cls._tiles[form] = (r.value, c.value, d.value)
-        return cls._tiles[form]
+    STEP_K = 16        # the kernel's K step: a contraction part is a whole number of steps
 
     def __init__(self, device, name):
         self.device, self.name = device, name
@@ -133,53 +120,21 @@ class Phase:
 
     def _size(self):
         probs = [(t, p) for t in self.targets for p in t.problems]
-        def tiles(t, p):
-            rows, cols, _ = self.tile(p["form"])
-            return math.ceil(t.M / rows) * math.ceil(t.N / cols)
-
-        # Work items run two per CU.  A CU's MFMA rate is what it is whether one workgroup or two share it, so a launch takes
-        # about max(all stage work / 256 CUs, the longest item alone on its CU) + an item's fixed cost, and every extra part of
-        # a product is one more slab written and read back.  Stage work: 64 MFMAs per wave for the 128 x 64 tiles (NT, NN), 128
-        # for the 128 x 128 TN tile -- TN parts are therefore half as long.  All products of a phase share the part length (a
-        # multiple of the stage depth); the candidate that minimises the estimate wins.
-        step = max(self.tile(p["form"])[2] for _, p in probs)
-        kmax = max(p["K"] for _, p in probs)
-        weight = lambda p: 2 if p["form"] in (TN, TN_A4) else 1        # noqa: E731
-        tn_mode = os.environ.get("VQA_GG_TN", "half")     # sweep knob: how the TN (weight-gradient) products are cut
-        def part_of(p, part):
-            if weight(p) == 2 and tn_mode == "whole":
-                return math.ceil(p["K"] / step) * step
-            if weight(p) == 2 and tn_mode == "same":
-                return part
-            return max(step, part // weight(p) // step * step)
-
-        best = None
-        for part in range(step, min(self.MAX_PART, math.ceil(kmax / step) * step) + 1, step):
-            items = work = longest = slabs = 0
-            for t, p in probs:
-                n = math.ceil(p["K"] / part_of(p, part))
-                stages = math.ceil(math.ceil(p["K"] / n) / step) * weight(p)
-                items += tiles(t, p) * n
-                work += tiles(t, p) * n * (stages + 1.5)          # + prologue / epilogue of an item, in stages
-                longest = max(longest, stages + 1.5)
-                slabs += (t.M * t.N * n) if n > 1 else 0
-            if self.FIXED_PART:     # measurement knob
-                best = (0.0, self.FIXED_PART)
+        tiles = lambda t: math.ceil(t.M / self.TILE_M) * math.ceil(t.N / 64)  # noqa: E731
+        part = self.MAX_PART
+        # work items a launch aims for: 512 (two per CU) at the training batch; a phase whose products have <= 128 rows (one
+        # rank's share of BASELINE configs[4]: 128 samples) holds one or two row tiles per product and needs deeper splits to
+        # fill the chip -- measured at B = 128: 768 / 1024 / 1536 / 2048 items -> 0.158 / 0.151 / 0.151 / 0.151 ms of grouped
+        # GEMM per step (512: 0.172), at B = 512: 768 / 1024 are 0.5 / 1 % slower than 512
+        min_items = self.MIN_ITEMS or (1024 if min(t.M for t in self.targets) <= 128 else 512)
+        while True:
+            items = sum(tiles(t) * math.ceil(p["K"] / part) for t, p in probs)
+            if items >= min_items or part <= 128:
                 break
-            # workgroups are dealt to the CUs in turn, two per CU at most: up to 256 items every item runs alone on its CU
-            # (and pays its barrier / DMA waits in full: + 15 %, measured), above that a CU's two share its MFMA rate.
-            # A stage of a lone workgroup ~ 1 us (64 MFMAs x 32 cycles); a slab costs ~0.15 us per MB written and read back
-            lone = items <= self.SLOTS // 2
-            cost = max(work / (self.SLOTS / 2), longest * (1 if lone else 2)) * (self.LONE if lone else 1.0)
-            cost += longest if items > self.SLOTS else 0.0
-            # a split product needs an epilogue job: a launch the phase may otherwise not have + its slabs read back
-            cost += (self.SPLIT_US if slabs else 0.0) + self.SLAB_US_PER_MB * 1e-6 * 4.0 * slabs
-            if best is None or cost < best[0] - 1e-9:
-                best = (cost, part)
-        part = best[1]
+            part = max(128, part - 64)
         for t, p in probs:
-            splits = math.ceil(p["K"] / part_of(p, part))
-            p["ksplit"] = math.ceil(p["K"] / splits / step) * step
+            splits = math.ceil(p["K"] / part)
+            p["ksplit"] = math.ceil(p["K"] / splits / self.STEP_K) * self.STEP_K
             p["splits"] = math.ceil(p["K"] / p["ksplit"])
         return probs
 
