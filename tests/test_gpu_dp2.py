@@ -1,7 +1,8 @@
 """The multi-rank step on hardware that has ONE GPU: two ranks (gloo, device tensors) share cuda:0 and must reproduce the
 single-process step on the whole batch -- kernel by kernel and replayed from hipGraphs, with the single flat all-reduce and
 with the two-half backward whose first all-reduce runs under the second half (trainer.DataParallelTrainer; train.py:517's
-DataParallel replaced by one process per GPU).  The RCCL path itself needs >= 2 GPUs and is the driver's scaling run."""
+DataParallel replaced by one process per GPU).  backend = "nccl" puts rank r on cuda:r and the collectives on RCCL across
+the devices -- BASELINE configs[3]'s transport; it needs >= 2 GPUs and is skipped on the one-GPU test box."""
 import json
 import os
 import socket
@@ -9,6 +10,7 @@ import subprocess
 import sys
 
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,15 +37,18 @@ def _run(world, env):
     return json.loads(lines[-1])
 
 
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
 @pytest.mark.parametrize("model", ["cor2", "oda"])
-def test_two_ranks_on_one_gpu_match_one_process(model):
+def test_two_ranks_match_one_process(model, backend):
+    if backend == "nccl" and torch.cuda.device_count() < 2:       # (counting devices does not initialise the GPU)
+        pytest.skip("RCCL across devices needs >= 2 GPUs; this box has %d" % torch.cuda.device_count())
     want = _run(1, {"G": "0", "MODEL": model})
     assert want["world"] == 1 and len(want["losses"]) == 7
     for graph in ("0", "1"):
         for overlap in ("0", "1"):
-            got = _run(2, {"G": graph, "VQA_DP_OVERLAP": overlap, "MODEL": model})
-            tag = (model, graph, overlap)
-            assert got["world"] == 2, tag
+            got = _run(2, {"G": graph, "VQA_DP_OVERLAP": overlap, "MODEL": model, "BACKEND": backend})
+            tag = (model, backend, graph, overlap)
+            assert got["world"] == 2 and got["backend"] == backend, tag
             assert got["graph"] == (graph == "1"), tag           # the step really was captured / really was not
             assert got["overlap"] == (overlap == "1"), tag
             for a, b in zip(got["losses"], want["losses"]):

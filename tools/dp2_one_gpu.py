@@ -4,6 +4,7 @@ flat-gradient SUM all-reduce between the replayed hipGraphs, the two-half backwa
 second half -- on a single-GPU box.  Rank 0 prints ONE JSON line with the global losses / gradient norms of 7 steps.
 
     python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/dp2_one_gpu.py
+    BACKEND=nccl python -m torch.distributed.run --nproc-per-node 2 ... tools/dp2_one_gpu.py    # rank r on cuda:r, RCCL across them
     python tools/dp2_one_gpu.py            # the same steps in one process on the whole batch (the expected record)
     NCCL1=1 python tools/dp2_one_gpu.py    # one process, a ONE-rank "nccl" (= RCCL) group, the all-reduce forced
   env: G=1|0 graph replay or kernel by kernel;  VQA_DP_OVERLAP=1: backward in two halves (forced at world size 1);  MODEL=cor2|oda
@@ -26,12 +27,20 @@ from vqa_playground_pytorch_amd import CoR2Model, ODAModel  # noqa: E402
 from vqa_playground_pytorch_amd.trainer import DataParallelTrainer  # noqa: E402
 
 multi = "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1
+# BACKEND=gloo (default): every rank on cuda:0, the collectives on gloo -- runs on a one-GPU box;
+# BACKEND=nccl: rank r on cuda:r, the collectives on RCCL across the devices (needs >= world GPUs: the xGMI path itself)
+backend = os.environ.get("BACKEND", "gloo")
+local = int(os.environ.get("LOCAL_RANK", "0")) if (multi and backend == "nccl") else 0
+dev = torch.device("cuda", local)
+torch.cuda.set_device(local)
 if multi:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("gloo")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
 rank = dist.get_rank() if multi else 0
-dev = torch.device("cuda:0")
-torch.cuda.set_device(0)
 nccl1 = not multi and os.environ.get("NCCL1") == "1"
 if nccl1:
     import socket
