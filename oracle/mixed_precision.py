@@ -72,7 +72,9 @@ class CoR2MixedOracle(RF.CoR2Oracle):
     comparison with the product's exported masks: the caller switches the DropLinear modules' own F.dropout off and masks their
     inputs by forward pre-hooks (as tests/test_gpu_models.py does for the float64 restatement), and hands the masks of the four
     1x1-convolution sites -- which this forward evaluates without calling the modules -- in sample["site_masks"] =
-    {"compress_v", "compress_v2": [b,N,2048]; "att1.conv_att", "att2.conv_att": [b,N,510]} (keep / (1 - p) values: 0 or 2)."""
+    {"compress_v", "compress_v2": [b,N,2048]; "att1.conv_att", "att2.conv_att": [b,N,510]} (keep / (1 - p) values: 0 or 2).
+    sample["forced_gates"] (eval mode, optional) = {"compress_v", "compress_v2": bool [b,N,310]; "att1.glimpses",
+    "att2.glimpses": bool [b,620]}: the product's relu decisions at the sites a bf16 rounding can flip (see _gate)."""
 
     def __init__(self, *args, rounding=True, **kw):
         super().__init__(*args, **kw)
@@ -81,13 +83,29 @@ class CoR2MixedOracle(RF.CoR2Oracle):
     def _r(self, x, both=False):
         return _Round.apply(x, both) if self.rounding else x
 
-    def _region_linear(self, mod, x, mask=None):
+    def _gate(self, site, pre, forced):
+        """relu(pre) -- or, with the product's own gates handed in (sample["forced_gates"][site], a bool tensor: "the
+        product's output of this relu is > 0"), pre * gate.  The units where the two sides decide differently are counted in
+        self.gate_flips[site] = (units that differ, units, largest |pre| among them / rms(pre)): a test that forces the gates
+        asserts with these numbers that only knife-edge units (|pre| within rounding of 0) ever differ."""
+        if forced is None:
+            return F.relu(pre)
+        own = pre.detach() > 0
+        diff = own != forced
+        rms = float(pre.detach().pow(2).mean().sqrt())
+        n, edge = self.gate_flips.get(site, (0, 0, 0.0))[0], self.gate_flips.get(site, (0, 0, 0.0))[2]
+        units = self.gate_flips.get(site, (0, 0, 0.0))[1]
+        worst = float(pre.detach()[diff].abs().max()) / max(rms, 1e-30) if bool(diff.any()) else 0.0
+        self.gate_flips[site] = (n + int(diff.sum()), units + diff.numel(), max(edge, worst))
+        return pre * forced.to(pre.dtype)
+
+    def _region_linear(self, mod, x, mask=None, site=None, forced=None):
         """relu(drop(x) W^T + b) with the bf16 shadow of W; the output and its gradient are bf16.  (The product zeroes the
         dropped elements of the bf16 operand and applies the factor 2 to the accumulator: the same numbers, 2 is exact.)"""
         w = self._r(mod.conv.weight.squeeze(-1))
         if mask is not None:
             x = x * mask
-        return self._r(F.relu(F.linear(x, w, mod.conv.bias)), both=True)
+        return self._r(self._gate(site, F.linear(x, w, mod.conv.bias), forced), both=True)
 
     def _fusion(self, mf, x_low, q_low):
         h2 = torch.stack([lin(q_low) for lin in mf.list_linear2], 1)                                     # [B,R,H] fp32
@@ -102,15 +120,23 @@ class CoR2MixedOracle(RF.CoR2Oracle):
         alpha = F.softmax(logits, dim=1)
         return alpha, torch.matmul(alpha.transpose(1, 2), v)                                              # pooled [B,G,D]
 
-    @staticmethod
-    def _glimpses(att, pooled):
-        return torch.cat([att.list_linear_v_fusion[g](pooled[:, g, :]) for g in range(att.glimpses)], dim=1)
+    def _glimpses(self, att, pooled, site=None, forced=None):
+        if forced is None:
+            return torch.cat([att.list_linear_v_fusion[g](pooled[:, g, :]) for g in range(att.glimpses)], dim=1)
+        if self.training:
+            raise NotImplementedError("forced gates are an eval-mode comparison (the glimpse layers' dropout is not restated here)")
+        pre = torch.cat([F.linear(pooled[:, g, :], att.list_linear_v_fusion[g].linear.weight, att.list_linear_v_fusion[g].linear.bias)
+                         for g in range(att.glimpses)], dim=1)
+        return self._gate(site, pre, forced)
 
     def forward(self, sample):
         sm = sample.get("site_masks")
         if self.training and sm is None:
             raise NotImplementedError("CoR2MixedOracle in training mode needs the product's masks (see the class docstring)")
         sm = sm or {}
+        fg = sample.get("forced_gates") or {}      # the product's relu gates (bool, "output > 0"): see _gate
+        if not hasattr(self, "gate_flips") or sample.get("reset_gate_flips", True):
+            self.gate_flips = {}
         v = sample["v"]
         q = sample["q"] if "q" in sample else sample["q_idxes"]
         b, n = v.size(0), v.size(1)
@@ -118,17 +144,17 @@ class CoR2MixedOracle(RF.CoR2Oracle):
         q_low = self.compress_q(q)
         q1 = self.expand_q_1(self.compress_q_1(q))
         q2 = self.expand_q_2(self.compress_q_2(q))
-        v_low = self._region_linear(self.compress_v, v, sm.get("compress_v"))
+        v_low = self._region_linear(self.compress_v, v, sm.get("compress_v"), "compress_v", fg.get("compress_v"))
         fuse1 = self._fusion(self.fusion_vq1, v_low, q_low)
         alpha1, pooled1 = self._attend(self.att1, fuse1, v, sm.get("att1.conv_att"))
-        v1_att = self._glimpses(self.att1, pooled1)
+        v1_att = self._glimpses(self.att1, pooled1, "att1.glimpses", fg.get("att1.glimpses"))
         t = q1 * pooled1[:, 0, :]
         v2 = self._r(t.unsqueeze(1) + q2.unsqueeze(1) * v, both=True)                                     # relation tensor
-        v2_low = self._region_linear(self.compress_v2, v2, sm.get("compress_v2"))
+        v2_low = self._region_linear(self.compress_v2, v2, sm.get("compress_v2"), "compress_v2", fg.get("compress_v2"))
         fuse2 = self._fusion(self.fusion_vq2, v2_low, q_low)
         alpha2, pooled2_v = self._attend(self.att2, fuse2, v, sm.get("att2.conv_att"))
         pooled2 = t.unsqueeze(1) + q2.unsqueeze(1) * pooled2_v               # = alpha2^T v2 for a softmax alpha2
-        v2_att = self._glimpses(self.att2, pooled2)
+        v2_att = self._glimpses(self.att2, pooled2, "att2.glimpses", fg.get("att2.glimpses"))
         self.alpha_dict = {"alpha1": torch.split(alpha1, 1, dim=2), "alpha2": torch.split(alpha2, 1, dim=2),
                            "feature": v2[:, [0, 1], :]}
         self.taps = {"v2_feature": v2, "fusion_vq1": fuse1, "fusion_vq2": fuse2, "compress_v": v_low, "compress_v2": v2_low}

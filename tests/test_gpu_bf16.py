@@ -480,6 +480,86 @@ def test_cor2_bf16_at_size_against_bf16_aware_oracle(B, N):
           % (B, N, np.abs(npy(got) - want).max() / np.abs(want).max(), worst[2], worst[0], worst[1]))
 
 
+RTOL_FORCED = 1e-2       # with the product's relu gates handed to the oracle: relative Frobenius error of EVERY parameter
+RTOL_FORCED_MAX = 2e-2   # gradient, whole tensor, nothing set aside / its largest element on the tensor's scale
+#                          (measured on the MI355X at B = 128, N = 100: 3.1e-3 / 3.6e-3 at the worst tensor, logits 1.3e-4)
+FLIP_FRACTION = 5e-4     # units per site where the oracle's own gate differs from the product's (measured: <= 6.3e-5: 123 of
+FLIP_EDGE = 5e-3         # 3 968 000 compress_v2 units), and how far from zero the oracle's pre-activation may be at such a
+#                          unit, in rms of the layer's pre-activations (measured: <= 4.8e-4)
+
+
+@pytest.mark.parametrize("B,N", [(128, 100), (16, 36)])
+def test_cor2_bf16_at_size_with_the_products_gates(B, N):
+    """The same comparison with the ONE chaotic ingredient taken out.  What separates the two sides beyond rounding is the
+    relu gate of units whose pre-activation sits within a bf16 rounding of zero: which way such a unit falls
+    depends on the fp32 summation order of kernels upstream, and each flipped unit moves a whole row of a gradient.  Here the
+    product's own decisions at the four sites a bf16 rounding reaches -- compress_v, compress_v2 (bf16 outputs) and the two
+    glimpse projections (fed by attention maps that moved with them) -- are recorded in the forward and handed to the
+    bf16-aware oracle (oracle/mixed_precision.py: forced_gates), which reports where its own gates differ.  Asserted:
+      * the two sides differ at <= FLIP_FRACTION of a site's units, and only at knife-edge units (the oracle's |pre-activation|
+        <= FLIP_EDGE of the layer's rms) -- a wrong gate in the product (a mis-cropped pad row, a wrong tile) would show here;
+      * with the gates equal, logits and EVERY parameter gradient agree as whole tensors at RTOL_FORCED (relative Frobenius)
+        and RTOL_FORCED_MAX (largest element), NO rows set aside."""
+    from oracle import mixed_precision as MP
+    from oracle import reference_faithful as RF
+    nans = 2000
+    model = _build_cor2(nans, compute_dtype=torch.bfloat16)
+    aware = seeded.load_state(MP.CoR2MixedOracle(nans), 0).eval().double()
+    v, q, a = seeded.seeded_inputs(B, regions=N, answers=nans, seed=1024)
+    gates = {}
+    hooks = [getattr(model, site).register_forward_hook(
+        lambda mod, args, out, site=site: gates.__setitem__(site, (out[..., :mod.out_channels] > 0).cpu()))
+        for site in ("compress_v", "compress_v2")]
+    for site in ("att1", "att2"):      # the glimpse projections run inside attend(): wrap it
+        att = getattr(model, site)
+        inner = att.attend
+
+        def attend(*args, _inner=inner, _site=site, **kw):
+            res = _inner(*args, **kw)
+            gates[_site + ".glimpses"] = (res[0] > 0).cpu()
+            return res
+        att.attend = attend
+    try:
+        got = model({"v": torch.from_numpy(v).to(dev()), "q_idxes": torch.from_numpy(q).to(dev())})
+    finally:
+        for h in hooks:
+            h.remove()
+        for site in ("att1", "att2"):
+            del getattr(model, site).attend
+    assert set(gates) == {"compress_v", "compress_v2", "att1.glimpses", "att2.glimpses"}
+    RF.kld_sum_loss(got, torch.from_numpy(a).to(dev())).backward()
+    want, flips = [], {}
+    for lo in range(0, B, 32):                 # float64 on the CPU, 32 samples at a time; the loss is a sum over samples
+        w = aware({"v": torch.from_numpy(v[lo:lo + 32]).double(), "q": torch.from_numpy(q[lo:lo + 32]).double(),
+                   "forced_gates": {k: g[lo:lo + 32] for k, g in gates.items()}})
+        RF.kld_sum_loss(w, torch.from_numpy(a[lo:lo + 32]).double()).backward()
+        want.append(w.detach())
+        for site, (n, units, edge) in aware.gate_flips.items():
+            f = flips.get(site, (0, 0, 0.0))
+            flips[site] = (f[0] + n, f[1] + units, max(f[2], edge))
+    for site, (n, units, edge) in flips.items():
+        print("  gates %-14s differ at %d of %d units (%.1e), largest |pre| / rms there %.1e" % (site, n, units, n / units, edge))
+        assert n <= FLIP_FRACTION * units and edge <= FLIP_EDGE, (site, n, units, edge)
+    want = torch.cat(want).numpy()
+    close_f32("logits", got, want, RTOL_FORCED)
+    zero_grads = {"%s.list_linear1.%d.linear.bias" % (f, r) for f in ("fusion_vq1", "fusion_vq2") for r in range(2)} | \
+        {"att1.conv_att.conv.bias", "att2.conv_att.conv.bias"}
+    worst = (0.0, 0.0, "")
+    for (n, p), (_, po) in zip(model.named_parameters(), aware.named_parameters()):
+        if n in zero_grads:       # (mathematically zero: held to their weight's scale by the test above)
+            continue
+        ref, g = po.grad.numpy().astype(np.float64), npy(p.grad).astype(np.float64)
+        e_fro = np.sqrt(((g - ref) ** 2).sum()) / np.sqrt((ref ** 2).sum())
+        e_max = np.abs(g - ref).max() / np.abs(ref).max()
+        if os.environ.get("VQA_TEST_VERBOSE"):
+            print("  %-45s max-abs %.2e  Frobenius %.2e" % (n, e_max, e_fro))
+        assert e_fro <= RTOL_FORCED and e_max <= RTOL_FORCED_MAX, "%s: Frobenius %.3e, max-abs %.3e of scale" % (n, e_fro, e_max)
+        if e_fro > worst[1]:
+            worst = (e_max, e_fro, n)
+    print("[cor2 bf16 B=%d N=%d, gates forced] logits rel err %.2e; worst gradient: %s Frobenius %.2e, max-abs %.2e"
+          % (B, N, np.abs(npy(got) - want).max() / np.abs(want).max(), worst[2], worst[1], worst[0]))
+
+
 def _compare_gradients(model, aware, tag, dropout=False, rtol_fro=None, rtol_max=None):
     """Every parameter gradient of `model` against `aware`'s at RTOL_AWARE (relative Frobenius) / RTOL_AWARE_MAX (largest
     element on the tensor's scale); the mathematically-zero bias gradients on their weight's scale.  -> worst (max, fro, name)
