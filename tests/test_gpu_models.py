@@ -935,3 +935,37 @@ def test_trainer_switches_the_tuned_gemm_table_on():
         theirs = {k: v for k, v in tn.get_validators()}
         assert all(theirs.get(k) == v for k, v in mine.items()), (mine, theirs)
         assert len(tn.get_results()) >= 50
+
+
+@pytest.mark.parametrize("cls,nans,head_mode", [("cor2", 300, "auto"), ("cor2", 300, "grouped"), ("oda", 300, "grouped")])
+def test_pregated_gradients_have_a_single_consumer(cls, nans, head_mode, monkeypatch):
+    """head.py's phases hand gradients over ALREADY multiplied by the producer's activation / dropout gate (the consumer holds
+    the producer's stored output): QuestionProjections -> GatesAndRankFactors, GlimpseProjections -> VectorFusion,
+    VectorFusion -> Classifier.  That is only sound while the handed-over tensor has no second consumer -- autograd would sum
+    a gated and an ungated gradient.  The contract is checked on the graph the models really build: every output of those
+    phase nodes is referenced by at most ONE next-function edge, and that edge comes from the phase that gates for it."""
+    from vqa_playground_pytorch_amd import head
+    monkeypatch.setattr(head, "MODE", head_mode)
+    model = build(cls, nans).train()
+    v, q, a = seeded.seeded_inputs(4, answers=nans, seed=21)
+    logits = model({"v": torch.from_numpy(v).to(dev()), "q_idxes": torch.from_numpy(q).to(dev())})
+    consumers = {}                       # (producer node name, output index) -> [consumer node names]
+    seen, stack = set(), [logits.grad_fn]
+    while stack:
+        node = stack.pop()
+        if node is None or node in seen:
+            continue
+        seen.add(node)
+        for nxt, idx in node.next_functions:
+            if nxt is not None:
+                consumers.setdefault((nxt.name(), id(nxt), idx), []).append(node.name())
+                stack.append(nxt)
+    allowed = {"QuestionProjectionsBackward": {"GatesAndRankFactorsBackward"},
+               "GlimpseProjectionsBackward": {"VectorFusionBackward"},
+               "VectorFusionBackward": {"ClassifierBackward"}}
+    checked = 0
+    for (name, _, idx), users in consumers.items():
+        if name in allowed:
+            assert len(users) == 1 and users[0] in allowed[name], (name, idx, users)
+            checked += 1
+    assert checked >= (3 if cls == "cor2" else 2), (checked, sorted({k[0] for k in consumers}))

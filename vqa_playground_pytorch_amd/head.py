@@ -158,6 +158,10 @@ class Phase:
                 else:
                     t.slab = torch.empty(t.S, t.M, t.N, device=self.device, dtype=torch.float32)
                     if any(p["colsum"] for p in t.problems):
+                        # the colsum job sums all S slabs of the target, and only problems with colsum=True write theirs:
+                        # a target that mixed the two kinds would add uninitialised rows into a bias gradient
+                        if not all(p["colsum"] for p in t.problems):
+                            raise _lib.VqaLibraryError("phase %s: the products of one target must agree on colsum" % self.name)
                         t.colsum = torch.empty(t.S, t.M, device=self.device, dtype=torch.float32)
                 base = 0
                 for p in t.problems:

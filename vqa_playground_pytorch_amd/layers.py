@@ -7,10 +7,14 @@ behaviour as the reference, so its checkpoints load and its call sites read the 
   MyConv1d, MyLinear, MyATT            <- config/CoR2.py:56-157 (identical copies in config/ODA.py:73-174)
 
 What differs is underneath: the python per-sample loops are gone; MutanFusion's region side, the
-attention softmax+pooling and (in the models) the pairwise relation / object-difference tensors run
-in hand-written HIP kernels through libvqa_mi355x.so (ops.py).  Plain dense GEMMs that the north
-star does not name (MyLinear / MyConv1d projections) go to rocBLAS/hipBLASLt through F.linear.
-There is no CPU path: GPU tensors only.
+attention softmax+pooling, the region projections (MyConv1d: K5, dropout + GEMM + bias + relu in one
+kernel) and (in the models) the pairwise relation / object-difference tensors run in hand-written
+HIP kernels through libvqa_mi355x.so (ops.py); the [B,.]-sized MyLinear layers run as grouped
+phases (head.py, K6) -- except, under VQA_HEAD=auto, CoR2's glimpse projections and ODA's [B,.]
+layers, which are one batched library GEMM each with HIP epilogues (my_linears below).
+On GPU tensors every layer takes the HIP path and raises if the library is missing; the plain torch
+expressions in this file (bmul, bmatmul, _activation, the non-CUDA branches) exist for CPU tensors
+only -- shape checks and the state_dict tests -- and are never part of a measured step.
 """
 import os
 
