@@ -949,7 +949,7 @@ def test_pregated_gradients_have_a_single_consumer(cls, nans, head_mode, monkeyp
     model = build(cls, nans).train()
     v, q, a = seeded.seeded_inputs(4, answers=nans, seed=21)
     logits = model({"v": torch.from_numpy(v).to(dev()), "q_idxes": torch.from_numpy(q).to(dev())})
-    consumers = {}                       # (producer node name, output index) -> [consumer node names]
+    consumers, nodes = {}, {}            # (producer node name, its id, output index) -> [consumer node names]
     seen, stack = set(), [logits.grad_fn]
     while stack:
         node = stack.pop()
@@ -959,13 +959,19 @@ def test_pregated_gradients_have_a_single_consumer(cls, nans, head_mode, monkeyp
         for nxt, idx in node.next_functions:
             if nxt is not None:
                 consumers.setdefault((nxt.name(), id(nxt), idx), []).append(node.name())
+                nodes[id(nxt)] = nxt
                 stack.append(nxt)
     allowed = {"QuestionProjectionsBackward": {"GatesAndRankFactorsBackward"},
                "GlimpseProjectionsBackward": {"VectorFusionBackward"},
                "VectorFusionBackward": {"ClassifierBackward"}}
     checked = 0
-    for (name, _, idx), users in consumers.items():
+    for (name, nid, idx), users in consumers.items():
         if name in allowed:
+            # a group the producer was told is `ungated` (ODA's q_low, which the object-difference kernel reads as well)
+            # receives plain gradients and gates them itself: any number of consumers
+            ungated = nodes[nid].cfg[5] if name == "QuestionProjectionsBackward" else ()
+            if idx in ungated:
+                continue
             assert len(users) == 1 and users[0] in allowed[name], (name, idx, users)
             checked += 1
     assert checked >= (3 if cls == "cor2" else 2), (checked, sorted({k[0] for k in consumers}))
