@@ -623,7 +623,7 @@ def main():
             print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
     t_start = time.perf_counter()
-    warm = max(args.warmup, 4) if not args.no_graph else args.warmup   # 3 eager steps precede the capture
+    warm = max(args.warmup, 3) if not args.no_graph else args.warmup   # 2 eager steps precede the capture
     for i in range(warm):
         trainer.step(sample, a)
         if i == 0:

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates the measured evidence of a round on the MI355X box (run through gpurun from the repo root):
-#   bash tools/refresh_evidence.sh r03_a
+#   bash tools/refresh_evidence.sh r04_f
 # Writes everything under gpurun_out/<tag>/ ; copy what is to be judged into profiles/.
 set -u
-TAG=${1:-r03_x}
+TAG=${1:-r04_x}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -12,27 +12,29 @@ cd /tmp && export TMPDIR=/tmp
 # 1. HBM traffic counters: two separate --pmc passes (never combined with trace domains), kernel by kernel
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records > "$OUT/pmc_$c.log" 2>&1
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records --detail-file /tmp/pmc_detail.json > "$OUT/pmc_$c.log" 2>&1
 done
 python3 "$ROOT/tools/pmc_table.py" /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE "$OUT/pmc_traffic.json" > "$OUT/pmc_table.log" 2>&1
 # 1b. matrix-pipe occupancy counters (their own pass), CoR2 and ODA steps
 rm -rf /tmp/pmc_mfma /tmp/pmc_mfma_oda
 MFMA_CTRS="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
-timeout 600 rocprofv3 --pmc $MFMA_CTRS --output-format csv -d /tmp/pmc_mfma -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records > "$OUT/pmc_mfma.log" 2>&1
+timeout 600 rocprofv3 --pmc $MFMA_CTRS --output-format csv -d /tmp/pmc_mfma -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records --detail-file /tmp/pmc_detail.json > "$OUT/pmc_mfma.log" 2>&1
 python3 "$ROOT/tools/pmc_mfma.py" /tmp/pmc_mfma "$OUT/pmc_mfma.json" > "$OUT/pmc_mfma_table.log" 2>&1
 
 # 1c. the bf16 / 100-region step (configs[4], one rank's share): matrix-pipe counters of its kernels
 rm -rf /tmp/pmc_mfma_bf16
-timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma_bf16 -- python3 "$ROOT/bench.py" --dtype bf16 --regions 100 --batch 128 --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records > "$OUT/pmc_mfma_bf16.log" 2>&1
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma_bf16 -- python3 "$ROOT/bench.py" --dtype bf16 --regions 100 --batch 128 --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records --detail-file /tmp/pmc_detail.json > "$OUT/pmc_mfma_bf16.log" 2>&1
 python3 "$ROOT/tools/pmc_mfma.py" /tmp/pmc_mfma_bf16 "$OUT/pmc_mfma_bf16_n100_b128.json" > "$OUT/pmc_mfma_bf16_table.log" 2>&1
 # 1d. K2 (the ODA attention op): VALU issue counters of its kernels
 rm -rf /tmp/pmc_valu_oda
-timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_valu_oda -- python3 "$ROOT/bench.py" --model oda-attention --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records > "$OUT/pmc_valu_oda.log" 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_valu_oda -- python3 "$ROOT/bench.py" --model oda-attention --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records --detail-file /tmp/pmc_detail.json > "$OUT/pmc_valu_oda.log" 2>&1
 python3 "$ROOT/tools/pmc_mfma.py" /tmp/pmc_valu_oda "$OUT/pmc_valu_oda_attention.json" > "$OUT/pmc_valu_oda_table.log" 2>&1
 
 # 2. bench lines
 cd "$ROOT"
-run() { name=$1; shift; timeout 900 python3 bench.py "$@" > "$OUT/$name.log" 2>&1; tail -1 "$OUT/$name.log" > "$OUT/$name.json"; }
+# (bench.py prints its compact line on stdout and the full record on stderr + --detail-file)
+run() { name=$1; shift; timeout 900 python3 bench.py --detail-file "$OUT/${name}_detail.json" "$@" > "$OUT/$name.json" 2> "$OUT/$name.log"; }
+run bench_default
 run bench_b512 --steps 20 --warmup 5
 VQA_HEAD=legacy run bench_b512_legacy_head --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records
 VQA_HEAD=grouped run bench_b512_grouped_head --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records
@@ -51,7 +53,7 @@ cd /tmp
 for mode in graph eager; do
   extra=""; [ $mode = eager ] && extra="--no-graph"
   rm -rf /tmp/kt_$mode
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$mode -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records $extra > "$OUT/kt_$mode.log" 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$mode -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records --detail-file /tmp/kt_detail.json $extra > "$OUT/kt_$mode.log" 2>&1
   f=$(find /tmp/kt_$mode -name "*kernel_stats.csv" | sort | sed -n 1p)
   [ -n "$f" ] && cp "$f" "$OUT/bench_b512_${mode}_kernel_stats.csv"
   python3 "$ROOT/tools/by_grid.py" /tmp/kt_$mode 1 "hand-written kernels, per-dispatch durations by (kernel, grid work-items); rocprofv3 --kernel-trace of bench.py --steps 20 --warmup 5 --no-cpu-baseline $extra (the last column is the total over the run)" > "$OUT/vqa_kernels_by_grid_$mode.txt" 2>&1
@@ -60,7 +62,7 @@ done
 for cfg in "oda_b512|--model oda" "bf16_n100_b128|--dtype bf16 --regions 100 --batch 128"; do
   name=${cfg%%|*}; args=${cfg#*|}
   rm -rf /tmp/kt_$name
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$name -- python3 "$ROOT/bench.py" $args --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records > "$OUT/kt_$name.log" 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$name -- python3 "$ROOT/bench.py" $args --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records --detail-file /tmp/kt_detail.json > "$OUT/kt_$name.log" 2>&1
   f=$(find /tmp/kt_$name -name "*kernel_stats.csv" | sort | sed -n 1p)
   [ -n "$f" ] && cp "$f" "$OUT/bench_${name}_kernel_stats.csv"
   python3 "$ROOT/tools/by_grid.py" /tmp/kt_$name 1 "hand-written kernels, per-dispatch durations by (kernel, grid work-items); rocprofv3 --kernel-trace of bench.py $args --steps 20 --warmup 5 --no-cpu-baseline (the last column is the total over the run)" > "$OUT/vqa_kernels_by_grid_$name.txt" 2>&1

@@ -203,6 +203,11 @@ class FlatState:
 class DataParallelTrainer:
     """Replicated model + flat-gradient sum-all-reduce + the reference's clip/Adam/ExponentialLR."""
 
+    # graph=True: steps launched kernel by kernel before the step is captured (the capture itself runs one more forward +
+    # backward on a side stream first, torch's recipe).  Two suffice for the allocator, the kernels' LDS attributes and the
+    # recorded GEMM solutions; every further step of a short warm-up is then already a replay at its steady clock.
+    EAGER_STEPS_BEFORE_CAPTURE = 2
+
     def __init__(self, model, lr=1e-4, clip=0.25, gamma=0.5 ** (1 / 50000), broadcast=True, group=None,
                  fused_adam=None, graph=False, adopt_inputs=False, overlap=None):
         self.model = model
@@ -425,7 +430,7 @@ class DataParallelTrainer:
             self._eager_steps += 1
             if ops.host_seed_draws != seeds_before:
                 self.want_graph = False       # host-seeded dropout mask in the forward: replay would freeze it
-            elif self._eager_steps >= 3:      # warmed up (allocator, LDS attributes, autotuned GEMMs): capture
+            elif self._eager_steps >= self.EAGER_STEPS_BEFORE_CAPTURE:   # warmed up (allocator, LDS attributes, GEMM table): capture
                 try:
                     self._capture(sample, target)
                 except Exception as e:        # noqa: BLE001 -- any capture failure: keep training, kernel by kernel
@@ -576,7 +581,7 @@ class DataParallelTrainer:
             self._eager_steps += 1
             if ops.host_seed_draws != seeds_before:
                 self.want_graph = False
-            elif self._eager_steps >= 3:
+            elif self._eager_steps >= self.EAGER_STEPS_BEFORE_CAPTURE:
                 try:
                     self._capture_split(sample, target)
                 except Exception as e:        # noqa: BLE001 -- any capture failure: keep training, kernel by kernel
