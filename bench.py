@@ -39,7 +39,7 @@ LOW, HID, GLIMPSES, RANK = 310, 510, 4, 2
 
 
 K4_FOLDED = os.environ.get("VQA_K4_FORM", "auto") != "engine"
-EVIDENCE_TAG = "r03"      # profiles/<tag>_pmc_traffic.json / <tag>_pmc_mfma.json: rocprofv3 --pmc passes of this command
+EVIDENCE_TAG = "r04"      # profiles/<tag>_pmc_traffic.json / <tag>_pmc_mfma.json: rocprofv3 --pmc passes of this command
 
 
 def work_of(name, shape):
