@@ -215,6 +215,13 @@ int main(int argc, char** argv) {
         RT_TIME("dropout, VALU 1 per MFMA (TUNE 32)", (launch_nt<9, 5, 1, 2, 2, true, 32>(A, K, B, K, bias, y, M, N, K, 1, dch)));
         RT_TIME("no dropout (TUNE 0)", (launch_nt<9, 5, 1, 2, 2, false, 0>(A, K, B, K, bias, y, M, N, K, 1, dc0)));
         RT_TIME("dropout, VALU unpinned (TUNE 0) again", (launch_nt<9, 5, 1, 2, 2, true, 0>(A, K, B, K, bias, y, M, N, K, 1, dch)));
+        // round 4: hash words shared across the four lane groups by ds_bpermute (TUNE 0) vs hashed per lane (64); the chunk's
+        // masks in one burst in front of its MFMAs (0, 64: the default) vs staggered over its row blocks (128, 192: round 2)
+        RT_TIME("dropout, per-lane hashes, one burst (TUNE 64)", (launch_nt<9, 5, 1, 2, 2, true, 64>(A, K, B, K, bias, y, M, N, K, 1, dch)));
+        RT_TIME("dropout, shared hashes, staggered (TUNE 128)", (launch_nt<9, 5, 1, 2, 2, true, 128>(A, K, B, K, bias, y, M, N, K, 1, dch)));
+        RT_TIME("dropout, per-lane hashes, staggered (192)", (launch_nt<9, 5, 1, 2, 2, true, 192>(A, K, B, K, bias, y, M, N, K, 1, dch)));
+        RT_TIME("dropout, shared hashes, one burst (TUNE 0) again", (launch_nt<9, 5, 1, 2, 2, true, 0>(A, K, B, K, bias, y, M, N, K, 1, dch)));
+        RT_TIME("no dropout (TUNE 0) again", (launch_nt<9, 5, 1, 2, 2, false, 0>(A, K, B, K, bias, y, M, N, K, 1, dc0)));
       }
       RT_TIME("stamped (TUNE 16)", (launch_nt<9, 5, 1, 2, 2, false, 16>(A, K, B, K, bias, y, M, N, K, 1, dc0, stamps)));
       clock_report("real kernel");
@@ -351,6 +358,19 @@ int main(int argc, char** argv) {
         CK(hipGetLastError());
         compare(gated ? "dW 5x8, relu gate + dropout" : "dW 5x8", dw, dwref, (size_t)N1 * N2, N2);
         compare(gated ? "db (gated)" : "db", db, dbref, N1, N1);
+        if (gated) {   // round 4: hash words shared by groups of eight lanes (SHARE), the chunk's VALU side in one burst (TUNE 1)
+          auto t = [&](const char* what, auto kern) {
+            float ms_ = time_ms([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(rt::kThreads), 0, 0, p, dc); }, iters);
+            printf("  exp dW %-44s %.1f us\n", what, ms_ * 1e3);
+          };
+          t("per-lane hashes, staggered", rt::gemm_tn_kernel<5, 2, true, true, false, 0>);
+          t("shared hashes, staggered", rt::gemm_tn_kernel<5, 2, true, true, true, 0>);
+          t("per-lane hashes, one burst", rt::gemm_tn_kernel<5, 2, true, true, false, 1>);
+          t("shared hashes, one burst", rt::gemm_tn_kernel<5, 2, true, true, true, 1>);
+          t("shared hashes, no gate, staggered", rt::gemm_tn_kernel<5, 2, false, true, true, 0>);
+          t("shared hashes, no gate, one burst", rt::gemm_tn_kernel<5, 2, false, true, true, 1>);
+          t("no dropout, no gate", rt::gemm_tn_kernel<5, 2, false, false, false, 0>);
+        }
         float ms = time_ms(run, iters);
         printf("  -> %.1f us  %.1f TF/s (%.1f%% of 157.3)   [+ slab reduce %.1f us]\n", ms * 1e3, flop / ms / 1e9,
                flop / ms / 1e9 / 1.573,

@@ -88,7 +88,8 @@ struct NtShape {
 };
 
 // TUNE (experiments, tools/rt_probe.hip; 0 in the library): bit 0 = no loads inside the loop (MFMA-stream ceiling),
-// bits 1-3 = MFMAs between two loads (0 = default spacing), bit 4 = stamp the main loop's clocks into p.stamps.
+// bits 1-3 = MFMAs between two loads (0 = default spacing), bit 4 = stamp the main loop's clocks into p.stamps,
+// bit 6 = the dropout hash words per lane instead of shared by ds_bpermute, bit 7 = the masks staggered over the row blocks.
 template <int RB, int CB, int WM, int WN, int WK, bool DROP, class Epi, int TUNE = 0>
 __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg dc, Epi epi) {
   using S = NtShape<RB, CB, WM, WN, WK>;
@@ -110,6 +111,18 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg 
     wordA[i] = ((uint32_t)row * (uint32_t)p.K) >> 5;
     hw[i] = 0u;
   }
+  // DROP, shared hashes (round 4).  The four lanes (r, g = 0..3) of a row need the SAME hash word per pair of chunks and used
+  // to compute it four times.  Now lane (r, g) hashes for the row blocks g, g + 4, g + 8 only and the words travel across the
+  // lane groups by ds_bpermute (the LDS crossbar: no VALU slot, no LDS memory): 3 hashes + RB permutes per pair instead of RB
+  // hashes.  (TUNE & 64 keeps the per-lane form for the A/B probe.)
+  constexpr bool SHARE = DROP && (TUNE & 64) == 0;
+  constexpr int NSEL = (RB + 3) / 4;
+  uint32_t wordSel[NSEL];
+  int permAddr[4];
+#pragma unroll
+  for (int k = 0; k < NSEL; ++k) wordSel[k] = ((uint32_t)min(m0 + 16 * min(g + 4 * k, RB - 1) + r, p.M - 1) * (uint32_t)p.K) >> 5;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) permAddr[q] = 4 * (r + 16 * q);
 #pragma unroll
   for (int j = 0; j < CB; ++j) {
     const int col = min(n0 + 16 * j + r, p.N - 1);
@@ -147,8 +160,20 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg 
   };
   // DROP: chunk c covers the elements k = 16 c + 4 g .. + 3 of the lane's row: bits 16 (c & 1) + 4 g .. + 3 of the hash word
   // of counter (row K + 16 c) >> 5.  FRESH (c even): the word is computed; c odd: the one of c - 1 is reused.
+  auto hash_pair = [&](int pair) {      // SHARE: the words of all RB row blocks for the pair of chunks 2 pair, 2 pair + 1
+    uint32_t h[NSEL];
+#pragma unroll
+    for (int k = 0; k < NSEL; ++k) h[k] = mask_word32(wordSel[k] + (uint32_t)pair, key);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) hw[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(permAddr[i & 3], (int)h[i >> 2]);
+  };
   auto mask_row = [&](f32x4& ai, int i, int c, bool fresh) {
-    if (fresh) hw[i] = mask_word32(wordA[i] + (uint32_t)(c >> 1), key);
+    if constexpr (SHARE) {
+      // row block 0 of a pair is masked first (under the previous chunk's last MFMAs): that is where the pair's words are made
+      if (fresh && i == 0) hash_pair(c >> 1);
+    } else {
+      if (fresh) hw[i] = mask_word32(wordA[i] + (uint32_t)(c >> 1), key);
+    }
     keep4_bits(ai, hw[i] >> (4u * g + 16u * (uint32_t)(c & 1)));
   };
   auto compute = [&](f32x4(&a)[RB], f32x4(&b)[CB], int c) {   // one chunk on its own (c even)
@@ -171,18 +196,29 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg 
   auto step = [&](f32x4(&an)[RB], f32x4(&bn)[CB], int cn, f32x4(&a)[RB], f32x4(&b)[CB], int c, auto even) {
     constexpr bool EVEN = decltype(even)::value;
     if constexpr ((TUNE & 1) == 0) load(an, bn, cn);
+    // Round 4: the masks of the chunk's row blocks 1 .. RB - 1 in ONE burst in front of its MFMAs (block 0 was masked under the
+    // previous chunk's last block).  Staggered one row block ahead of its MFMAs -- the round-2 form, TUNE & 128 -- the same
+    // instructions interrupt the MFMA stream RB times per chunk instead of once: 205.1 us against 194.6 at M = 18432, K = 2048,
+    // N = 310 (no dropout: 177.5; tools/rt_probe.hip).
+    constexpr bool BURST = DROP && (TUNE & 128) == 0;
+    if constexpr (BURST) {
+#pragma unroll
+      for (int i = 1; i < RB; ++i) mask_row(a[i], i, c, EVEN);
+    }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       if constexpr (DROP) {
-        if (i + 1 < RB)
-          mask_row(a[i + 1], i + 1, c, EVEN);
-        else
+        if (i + 1 < RB) {
+          if constexpr (!BURST) mask_row(a[i + 1], i + 1, c, EVEN);
+        } else {
           mask_row(an[0], 0, cn, !EVEN);
+        }
       }
       mfma_row(a[i], b, i);
     }
     constexpr int NL = (TUNE & 1) == 0 ? RB + CB : 0, NM = 4 * RB * CB;
     constexpr int PER = ((TUNE >> 1) & 7) != 0 ? ((TUNE >> 1) & 7) : (NM / (2 * (RB + CB)) > 0 ? NM / (2 * (RB + CB)) : 1);
+    if constexpr (BURST) __builtin_amdgcn_sched_group_barrier(0x002, 8 * (RB - 1), 0);
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // MFMA
@@ -314,8 +350,13 @@ struct TnArgs {
   int rows_per_split;       // multiple of 16
 };
 
-template <int RB, int SP, bool MASK, bool DROP>
+// SHARE (with DROP; needs N2 % 64 == 0 and SP <= 2): a hash word covers 32 columns of a row, i.e. the 8 lanes r & ~7 .. + 7 of a
+// lane group need the same word for each of the 4 SP (contraction step, span) pairs of a chunk -- each of the 8 lanes hashes
+// ONE of them and the words travel by ds_bpermute: 1 hash + 4 SP permutes per chunk instead of 4 SP hashes.
+// TUNE (experiments): 1 = the VALU side of a chunk's steps 1..3 in ONE burst in front of its MFMAs instead of one per step.
+template <int RB, int SP, bool MASK, bool DROP, bool SHARE = false, int TUNE = 0>
 __global__ __launch_bounds__(kThreads, 1) void gemm_tn_kernel(TnArgs p, DropCfg dc) {
+  static_assert(!SHARE || (DROP && 4 * SP <= 8), "SHARE: dropout on, at most two 64-column spans");
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -355,6 +396,23 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_kernel(TnArgs p, DropCfg 
     float a[4][RB];
     float y[4][MASK ? RB : 1];
     f32x4 q[4][SP];
+    uint32_t hw[SHARE ? 4 : 1][SHARE ? SP : 1];   // SHARE: the hash words of the chunk's (step, span) pairs
+  };
+  // SHARE: lane t = r & 7 of its group of eight hashes for step t / SP, span t % SP; its 4 columns sit at bit 4 (r & 7)
+  const int t8 = r & 7;
+  const uint32_t share_col = (uint32_t)n2_0 + 64u * (uint32_t)(t8 % SP) + 32u * (uint32_t)(r >> 3);
+  const uint32_t share_row = (uint32_t)(4 * g + t8 / SP);
+  const uint32_t share_shift = 4u * (uint32_t)t8;
+  const int share_addr = 4 * (lane & ~7);
+  auto share_words = [&](Set& st, int m_c) {
+    if constexpr (SHARE) {
+      const uint32_t e = ((uint32_t)m_c + share_row) * (uint32_t)p.N2 + share_col;
+      const int h = (int)mask_word32(e >> 5, key);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int q = 0; q < SP; ++q) st.hw[kb][q] = (uint32_t)__builtin_amdgcn_ds_bpermute(share_addr + 4 * (kb * SP + q), h);
+    }
   };
   // rows m_c + 4 g + kb of the chunk that starts at row m_c (all < m_hi: whole chunks only)
   auto load = [&](Set& st, int m_c) {
@@ -378,7 +436,10 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_kernel(TnArgs p, DropCfg 
 #pragma unroll
       for (int i = 0; i < RB; ++i) st.a[kb][i] = st.y[kb][i] > 0.f ? st.a[kb][i] : 0.f;
     }
-    if constexpr (DROP) {     // p = 0.5 bit mask of the four columns (unscaled: the factor 2 is the epilogue's)
+    if constexpr (SHARE) {
+#pragma unroll
+      for (int q = 0; q < SP; ++q) keep4_bits(st.q[kb][q], st.hw[kb][q] >> share_shift);
+    } else if constexpr (DROP) {     // p = 0.5 bit mask of the four columns (unscaled: the factor 2 is the epilogue's)
       const uint32_t erow = (uint32_t)(m_c + kb) * (uint32_t)p.N2;
 #pragma unroll
       for (int q = 0; q < SP; ++q) {
@@ -399,6 +460,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_kernel(TnArgs p, DropCfg 
           acc[i][q][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.a[kb][i], st.q[kb][q][e], acc[i][q][e], 0, 0, 0);
   };
   auto compute = [&](Set& st, int m_c) {   // one chunk on its own
+    share_words(st, m_c);
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       prep(st, kb, m_c);
@@ -410,12 +472,19 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_kernel(TnArgs p, DropCfg 
   // entry step 0 of `st` is prepared already.
   auto step = [&](Set& sn, int m_n, Set& st, int m_c) {
     load(sn, m_n);
+    constexpr bool BURST = (TUNE & 1) != 0 && (MASK || DROP);
+    if constexpr (BURST) {
+#pragma unroll
+      for (int kb = 1; kb < 4; ++kb) prep(st, kb, m_c);
+    }
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-      if (kb + 1 < 4)
-        prep(st, kb + 1, m_c);
-      else
+      if (kb + 1 < 4) {
+        if constexpr (!BURST) prep(st, kb + 1, m_c);
+      } else {
+        share_words(sn, m_n);
         prep(sn, 0, m_n);
+      }
       mfmas(st, kb);
     }
     constexpr int NL = 4 * (RB * (MASK ? 2 : 1) + SP), NM = 16 * RB * SP;
@@ -439,6 +508,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_kernel(TnArgs p, DropCfg 
     }
     if (c < nfull) {
       load(s0, m_lo + 16 * c);
+      share_words(s0, m_lo + 16 * c);
       prep(s0, 0, m_lo + 16 * c);
       __builtin_amdgcn_sched_barrier(0);
       for (; c < nfull; c += 2) {

@@ -399,7 +399,13 @@ extern "C" int vqa_linear_act_bwd(const float* x, int ldx, const float* w, const
                        rows_per_split};
     const dim3 grid(a.tiles1 * a.tiles2 * S);
     const bool gate = act == 1, drop = dc.p8 > 0;
-    if (gate && drop)
+    // (the dropout mask's hash words shared within groups of eight lanes when the rows are whole 64-column spans)
+    const bool share = drop && K % 64 == 0 && !vqa::option_is("VQA_RT_SHARE_HASH", '0');
+    if (gate && drop && share)      // (with the gate the VALU side of a chunk goes in one burst: 195.0 -> 192.9 us, tools/rt_probe.hip)
+      VQA_LAUNCH((rt::gemm_tn_kernel<5, 2, true, true, true, 1>), grid, dim3(rt::kThreads), 0, s, a, dc);
+    else if (drop && share)
+      VQA_LAUNCH((rt::gemm_tn_kernel<5, 2, false, true, true>), grid, dim3(rt::kThreads), 0, s, a, dc);
+    else if (gate && drop)
       VQA_LAUNCH((rt::gemm_tn_kernel<5, 2, true, true>), grid, dim3(rt::kThreads), 0, s, a, dc);
     else if (gate)
       VQA_LAUNCH((rt::gemm_tn_kernel<5, 2, true, false>), grid, dim3(rt::kThreads), 0, s, a, dc);
