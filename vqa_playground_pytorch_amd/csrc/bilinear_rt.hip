@@ -49,7 +49,8 @@ struct FoldRtArgs {
 
 constexpr int kNB = 3;     // region blocks of 16 (N <= 48)
 
-template <bool FWD, int S, int IB, int R>
+// FG: (sample, row block) pairs whose weight fragments are folded in ONE burst of VALU instructions, ahead of their 12 FG MFMAs
+template <bool FWD, int S, int IB, int R, int FG = 1>
 __global__ __launch_bounds__(rt::kThreads, 1) void bilinear_fold_rt_kernel(FoldRtArgs p) {
   using rt::f32x4;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
@@ -150,33 +151,46 @@ __global__ __launch_bounds__(rt::kThreads, 1) void bilinear_fold_rt_kernel(FoldR
     constexpr int NL = decltype(nloads)::value;
     constexpr int NQ = S * IB;                 // (sample, row block) pairs, q = s IB + i
     constexpr int NV = R == 2 ? 4 : 2;         // VALU instructions of one fold
-    f32x4 we = fold(f, 0, 0);
-    if constexpr (PIN) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+    f32x4 we[FG], wn[FG];
+#pragma unroll
+    for (int t = 0; t < FG; ++t) we[t] = fold(f, min(t, NQ - 1) / IB, min(t, NQ - 1) % IB);
+    if constexpr (PIN) __builtin_amdgcn_sched_group_barrier(0x002, NV * FG, 0);
     int issued = 0;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int s = q / IB, i = q % IB;
-      f32x4 wn = we;
-      if (q + 1 < NQ) {
-        wn = fold(f, (q + 1) / IB, (q + 1) % IB);
-        if constexpr (PIN) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+    for (int q0 = 0; q0 < NQ; q0 += FG) {
+#pragma unroll
+      for (int t = 0; t < FG; ++t) wn[t] = we[t];
+      if (q0 + FG < NQ) {
+#pragma unroll
+        for (int t = 0; t < FG; ++t)
+          if (q0 + FG + t < NQ) {
+            wn[t] = fold(f, (q0 + FG + t) / IB, (q0 + FG + t) % IB);
+            if constexpr (PIN) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);     // (consecutive groups: one burst)
+          }
       }
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
+      for (int t = 0; t < FG; ++t) {
+        const int q = q0 + t;
+        if (q >= NQ) break;
+        const int s = q / IB, i = q % IB;
 #pragma unroll
-        for (int j = 0; j < kNB; ++j) {
-          acc[s][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(we[kb], f.x[s][j][kb], acc[s][i][j], 0, 0, 0);
-          if constexpr (PIN) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            // loads spread evenly over the chunk's MFMAs
-            const int m = q * 4 * kNB + kb * kNB + j;
-            if (issued < NL && (m + 1) * NL / (NQ * 4 * kNB) > issued) {
-              __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-              ++issued;
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int j = 0; j < kNB; ++j) {
+            acc[s][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(we[t][kb], f.x[s][j][kb], acc[s][i][j], 0, 0, 0);
+            if constexpr (PIN) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              // loads spread evenly over the chunk's MFMAs
+              const int m = q * 4 * kNB + kb * kNB + j;
+              if (issued < NL && (m + 1) * NL / (NQ * 4 * kNB) > issued) {
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                ++issued;
+              }
             }
           }
-        }
-      we = wn;
+      }
+#pragma unroll
+      for (int t = 0; t < FG; ++t) we[t] = wn[t];
     }
   };
   // one pipeline step (gemm_nt_kernel): chunk cn is requested in the shadow of chunk c's MFMAs
@@ -278,8 +292,18 @@ int launch(const FoldRtArgs& a0, int R, hipStream_t s) {
   constexpr int S = FWD ? 4 : 2, IB = FWD ? 4 : 5;
   a.tiles_o = (a.NO + 64 * IB - 1) / (64 * IB);
   const dim3 grid((unsigned)(((a.B + S - 1) / S) * a.tiles_o));
+  // fold-burst size: the folds of FG (sample, row block) pairs issued together, ahead of their 12 FG MFMAs -- fewer, longer
+  // interruptions of the MFMA stream (the K5 mask finding of round 4).  Measured in the step at B = 512 (us per launch,
+  // FG = 1 / 2 / 4): forward 91.2 / 91.0 / 88.9, data gradient + weight side 193.7 / 189.6 / 196.6 (more live fragments than
+  // its 120 accumulators leave room for).  VQA_K4_FG overrides (measurement knob).
+  const char* fg_opt = vqa::option("VQA_K4_FG");
+  const int fg = fg_opt != nullptr ? std::atoi(fg_opt) : (FWD ? 4 : 2);
   if (R == 1)
     VQA_LAUNCH((bilinear_fold_rt_kernel<FWD, S, IB, 1>), grid, dim3(rt::kThreads), 0, s, a);
+  else if (fg == 2)
+    VQA_LAUNCH((bilinear_fold_rt_kernel<FWD, S, IB, 2, 2>), grid, dim3(rt::kThreads), 0, s, a);
+  else if (fg == 4)
+    VQA_LAUNCH((bilinear_fold_rt_kernel<FWD, S, IB, 2, 4>), grid, dim3(rt::kThreads), 0, s, a);
   else
     VQA_LAUNCH((bilinear_fold_rt_kernel<FWD, S, IB, 2>), grid, dim3(rt::kThreads), 0, s, a);
   return check_launch(FWD ? "lowrank_bilinear_fusion_folded_fwd (register-tile)" : "lowrank_bilinear_fusion_folded_bwd (dx, register-tile)");
