@@ -157,7 +157,7 @@ __device__ __forceinline__ uint32_t dpp_u32(uint32_t x) {
 
 // Work units: (feature set, slice of the regions j) -- the logits are sums over both, so any split is exact.  JT slices of NJ
 // regions each (NJ a multiple of 4); wave w of the workgroup takes units w, w + nwaves, ...
-template <bool MASK>
+template <bool MASK, bool PK = false>
 __global__ __launch_bounds__(512) void oda_fwd_mfma_kernel(const float* __restrict__ vl, const float* __restrict__ ql,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
                                                            float* __restrict__ logits, DropCfg dc, int N, int L, int G,
@@ -251,9 +251,19 @@ __global__ __launch_bounds__(512) void oda_fwd_mfma_kernel(const float* __restri
         // the nine masked differences of this j in one burst, then nine independent MFMAs back to back: an MFMA that reads
         // a register the VALU has just written stalls on it (two wait states each in the interleaved order)
         float x[kOdaIG];
+        if constexpr (PK) {      // the nine differences as four v_pk_add_f32 + one v_sub_f32 (fewer issue slots)
+          const f32x2 tj2 = f32x2{Tj, Tj};
+#pragma unroll
+          for (int h = 0; h < kOdaIG / 2; ++h) {
+            const f32x2 d2 = f32x2{Ti[2 * h], Ti[2 * h + 1]} - tj2;
+            x[2 * h] = d2[0];
+            x[2 * h + 1] = d2[1];
+          }
+          x[kOdaIG - 1] = Ti[kOdaIG - 1] - Tj;
+        }
         static_for<kOdaIG>([&](auto ig_) {
           constexpr int ig = decltype(ig_)::value;
-          x[ig] = Ti[ig] - Tj;
+          if constexpr (!PK) x[ig] = Ti[ig] - Tj;
           if constexpr (MASK) x[ig] = ig < 8 ? keep_bit<(4 * ig) & 31>(x[ig], b0) : keep_bit<0>(x[ig], b1);
         });
         __builtin_amdgcn_sched_group_barrier(0x002, MASK ? 3 * kOdaIG + 6 : kOdaIG + 2, 0);
@@ -298,7 +308,7 @@ __global__ __launch_bounds__(512) void oda_fwd_mfma_kernel(const float* __restri
 // bits of all regions i of one (j, d): hashed once per sample, the bit picked per i with a register offset).
 // Workgroup = 4 waves = one group of samples, the 20 feature sets of L = 310 split 5 per wave: 256 groups of 2 samples at
 // B = 512 = one workgroup per CU, the same work for every wave.  slab[sg][g][j][d], summed by oda_reduce_kernel.
-template <bool MASK>
+template <bool MASK, bool PK = false>
 __global__ __launch_bounds__(512) void oda_bwd_weight_mfma_kernel(const float* __restrict__ vl, const float* __restrict__ ql,
                                                                   const float* __restrict__ dS, float* __restrict__ slab,
                                                                   DropCfg dc, int B, int N, int L, int G,
@@ -379,9 +389,19 @@ __global__ __launch_bounds__(512) void oda_bwd_weight_mfma_kernel(const float* _
           asm("" : "+v"(Ti));
           const float av = (r < G && dok && i0 + ii < N) ? sa[ii] : 0.f;   // (zero beyond N, G, L: such terms add nothing)
           float x[kOdaIG];
+          if constexpr (PK) {     // the nine differences as four v_pk_add_f32 + one v_sub_f32 (see the forward kernel)
+            const f32x2 ti2 = f32x2{Ti, Ti};
+#pragma unroll
+            for (int h = 0; h < kOdaIG / 2; ++h) {
+              const f32x2 d2 = ti2 - f32x2{Tj[2 * h], Tj[2 * h + 1]};
+              x[2 * h] = d2[0];
+              x[2 * h + 1] = d2[1];
+            }
+            x[kOdaIG - 1] = Ti - Tj[kOdaIG - 1];
+          }
           static_for<kOdaIG>([&](auto jg_) {
             constexpr int jg = decltype(jg_)::value;
-            x[jg] = Ti - Tj[jg];
+            if constexpr (!PK) x[jg] = Ti - Tj[jg];
             if constexpr (MASK) x[jg] = keep_bit<ii>(x[jg], ws[jg]);
           });
           __builtin_amdgcn_sched_group_barrier(0x002, MASK ? 3 * kOdaIG + 2 : kOdaIG + 2, 0);
@@ -993,10 +1013,15 @@ static int launch_fwd(const float* vl, const float* ql, const float* w, const fl
       int nw = nsets < 8 ? (nsets < 4 ? nsets : 4) : 8;
       const int jt = 1, nj = (N + 3) / 4 * 4;   // (one slice of the region axis j: see the kernel's note on work units)
       const size_t lds_m = (size_t)nw * 4 * kOdaIG * 4 * sizeof(float);
-      if (bits)
+      // packed subtracts (round 4): the nine differences of a region j as four v_pk_add_f32 + one v_sub_f32 -- the kernel is
+      // VALU-issue bound, 52.1 -> 50.5 us at B = 512 (the weight gradient likewise); VQA_K2_PK=0 keeps the scalar form for A/B
+      if (bits && !vqa::option_is("VQA_K2_PK", '0')) {
+        VQA_LAUNCH((oda_fwd_mfma_kernel<true, true>), dim3(B), dim3(64 * nw), lds_m, s, vl, ql, w, bias, logits, dc, N, L, G, jt, nj);
+      } else if (bits) {
         VQA_LAUNCH(oda_fwd_mfma_kernel<true>, dim3(B), dim3(64 * nw), lds_m, s, vl, ql, w, bias, logits, dc, N, L, G, jt, nj);
-      else
+      } else {
         VQA_LAUNCH(oda_fwd_mfma_kernel<false>, dim3(B), dim3(64 * nw), lds_m, s, vl, ql, w, bias, logits, dc, N, L, G, jt, nj);
+      }
       return check_launch("object_difference_attention_fwd");
     }
   }
@@ -1051,10 +1076,14 @@ static int launch_bwd(const float* vl, const float* ql, const float* w, const fl
       SG = (B + spg - 1) / spg;
       const int nsets = (L + 15) / 16, nw = nsets < 4 ? nsets : 4;
       const size_t lds_m = (size_t)nw * 4 * kOdaIG * 64 * sizeof(float);
-      if (dc.p8 > 0)
+      const bool pk = !vqa::option_is("VQA_K2_PK", '0');     // packed subtracts (round 4; "0" = the scalar form, for A/B)
+      if (dc.p8 > 0 && pk) {
+        VQA_LAUNCH((oda_bwd_weight_mfma_kernel<true, true>), dim3(SG), dim3(128 * nw), lds_m, s, vl, ql, dS, slab, dc, B, N, L, G, spg);
+      } else if (dc.p8 > 0) {
         VQA_LAUNCH(oda_bwd_weight_mfma_kernel<true>, dim3(SG), dim3(128 * nw), lds_m, s, vl, ql, dS, slab, dc, B, N, L, G, spg);
-      else
+      } else {
         VQA_LAUNCH(oda_bwd_weight_mfma_kernel<false>, dim3(SG), dim3(128 * nw), lds_m, s, vl, ql, dS, slab, dc, B, N, L, G, spg);
+      }
     } else if (oda_bits_mode(dc, B, N, L))
       VQA_LAUNCH((oda_bwd_weight_bits_kernel<G>), grid, dim3(nt), lds, s, vl, ql, dS, slab, dc, B, N, L, spg);
     else if (dc.p8 > 0)
