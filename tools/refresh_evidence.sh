@@ -1,14 +1,18 @@
 #!/bin/bash
 # Regenerates the measured evidence of a round on the MI355X box (run through gpurun from the repo root):
-#   bash tools/refresh_evidence.sh r04_f
-# Writes everything under gpurun_out/<tag>/ ; copy what is to be judged into profiles/.
+#   bash tools/refresh_evidence.sh r04_f [pmc,bench,trace,conv]      (second argument: which parts; default all)
+# Writes everything under gpurun_out/<tag>/ ; copy what is to be judged into profiles/.  The counter tables of part `pmc` are
+# also installed as profiles/<round>_pmc_{traffic,mfma}.json on the box, so that the bench lines of the same call read them.
 set -u
 TAG=${1:-r04_x}
+PARTS=${2:-pmc,bench,trace,conv}
+want() { case ",$PARTS," in *",$1,"*) return 0;; *) return 1;; esac; }
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 
+if want pmc; then
 # 1. HBM traffic counters: two separate --pmc passes (never combined with trace domains), kernel by kernel
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
@@ -29,7 +33,11 @@ python3 "$ROOT/tools/pmc_mfma.py" /tmp/pmc_mfma_bf16 "$OUT/pmc_mfma_bf16_n100_b1
 rm -rf /tmp/pmc_valu_oda
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_valu_oda -- python3 "$ROOT/bench.py" --model oda-attention --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records --detail-file /tmp/pmc_detail.json > "$OUT/pmc_valu_oda.log" 2>&1
 python3 "$ROOT/tools/pmc_mfma.py" /tmp/pmc_valu_oda "$OUT/pmc_valu_oda_attention.json" > "$OUT/pmc_valu_oda_table.log" 2>&1
+cp "$OUT/pmc_traffic.json" "$ROOT/profiles/${TAG%%_*}_pmc_traffic.json"
+cp "$OUT/pmc_mfma.json" "$ROOT/profiles/${TAG%%_*}_pmc_mfma.json"
+fi
 
+if want bench; then
 # 2. bench lines
 cd "$ROOT"
 # (bench.py prints its compact line on stdout and the full record on stderr + --detail-file)
@@ -47,7 +55,9 @@ run bench_b512_encoder --no-sub-records --encoder --steps 10 --warmup 5 --no-cpu
 run bench_oda_b512 --no-sub-records --model oda --steps 20 --warmup 5 --no-cpu-baseline
 run bench_oda_attention_b512 --model oda-attention --steps 20 --warmup 5
 VQA_K4_FORM=engine run bench_b512_k4_engine --no-sub-records --steps 20 --warmup 5 --no-cpu-baseline
+fi
 
+if want trace; then
 # 3. rocprofv3 kernel traces of the same commands (graph replay and kernel by kernel)
 cd /tmp
 for mode in graph eager; do
@@ -67,7 +77,10 @@ for cfg in "oda_b512|--model oda" "bf16_n100_b128|--dtype bf16 --regions 100 --b
   [ -n "$f" ] && cp "$f" "$OUT/bench_${name}_kernel_stats.csv"
   python3 "$ROOT/tools/by_grid.py" /tmp/kt_$name 1 "hand-written kernels, per-dispatch durations by (kernel, grid work-items); rocprofv3 --kernel-trace of bench.py $args --steps 20 --warmup 5 --no-cpu-baseline (the last column is the total over the run)" > "$OUT/vqa_kernels_by_grid_$name.txt" 2>&1
 done
+fi
+if want conv; then
 # 5. does the replayed step still train on this build?  (student vs a fixed teacher, the reference's recipe)
 timeout 600 python3 "$ROOT/tools/convergence.py" --steps 3000 --model cor2 --out "$OUT/convergence_cor2.json" > "$OUT/convergence_cor2.log" 2>&1
 timeout 600 python3 "$ROOT/tools/convergence.py" --steps 3000 --model oda --out "$OUT/convergence_oda.json" > "$OUT/convergence_oda.log" 2>&1
+fi
 ls -la "$OUT"
