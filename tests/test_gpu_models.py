@@ -975,3 +975,127 @@ def test_pregated_gradients_have_a_single_consumer(cls, nans, head_mode, monkeyp
             assert len(users) == 1 and users[0] in allowed[name], (name, idx, users)
             checked += 1
     assert checked >= (3 if cls == "cor2" else 2), (checked, sorted({k[0] for k in consumers}))
+
+
+# ---- the same comparison with the product's relu decisions handed to the restatement: ALL 512 samples at RTOL -------------------
+FLIP_FRACTION_F32 = 5e-6   # units per site where the float64 restatement's own gate differs from the product's (measured on the
+#                            MI355X: 2 of 5 713 920 compress_v2 units = 3.5e-7, none anywhere else, CoR2 and ODA) ...
+FLIP_EDGE_F32 = 1e-5       # ... and how far from zero its pre-activation may be there, in rms of the site's pre-activations
+#                            (measured 3.8e-7: float32 rounding of a sum of 2048 products)
+RTOL_FORCED_F32 = 2e-4     # with the gates equal: every gradient of the loss over all 512 samples (measured: 2.0e-5 CoR2, 5.5e-5 ODA)
+
+
+@pytest.mark.parametrize("cls,nans", [("cor2", 2000), ("oda", 3000)])
+def test_baseline_batch_with_the_products_gates(cls, nans, monkeypatch):
+    """test_baseline_batch_against_oracle splits off the samples that own a relu unit within float32 rounding of zero (more
+    than half of a CoR2 batch) and holds them to a looser bar, because a unit that falls on the other side of zero moves a
+    whole row of a gradient.  Here that ONE ingredient is taken out instead: the product's own relu decisions at every relu
+    site of the head (compress_v, compress_v2, the question projections, the glimpse projections) are recorded in the
+    forward -- module hooks and wrappers around the calls that produce them -- and the float64 restatement multiplies its
+    pre-activations by them instead of applying relu (its activation function is swapped for the duration of the run, in
+    call order).  Asserted: the two sides decide differently at <= FLIP_FRACTION_F32 of a site's units and only where the
+    restatement's |pre-activation| <= FLIP_EDGE_F32 rms (a wrong gate in the product would show here); and then logits and
+    EVERY parameter gradient of the loss over ALL 512 samples agree at RTOL_FORCED_F32 = 2e-4 -- five times inside north_star's
+    1e-3, no sample set aside."""
+    from vqa_playground_pytorch_amd import cor2 as cor2_mod
+    from vqa_playground_pytorch_amd import head
+    from vqa_playground_pytorch_amd import oda as oda_mod
+    B = 512
+    model = build(cls, nans)
+    v, q, a = seeded.seeded_inputs(B, answers=nans, seed=512)
+    rec = {}
+    hooks = [model.compress_v.register_forward_hook(lambda m, args, out: rec.__setitem__("compress_v", (out > 0).cpu()))]
+    for name in (("att1", "att2") if cls == "cor2" else ("att",)):
+        att = getattr(model, name)
+
+        def attend(*args, _inner=att.attend, _name=name, **kw):
+            res = _inner(*args, **kw)
+            rec[_name + ".glimpses"] = (res[0] > 0).cpu()
+            return res
+        att.attend = attend
+    if cls == "cor2":
+        assert head.MODE == "auto"
+        inner_q = head.QuestionProjections.apply
+
+        def question_projections(*args, **kw):
+            lows = inner_q(*args, **kw)
+            rec["q_proj"] = [(t > 0).cpu() for t in lows]     # compress_q, linear_q, compress_q_1, compress_q_2
+            return lows
+        monkeypatch.setattr(head.QuestionProjections, "apply", question_projections)
+        inner_rp = cor2_mod.ops.relation_projection
+
+        def relation_projection(*args, **kw):
+            out = inner_rp(*args, **kw)
+            rec["compress_v2"] = (out > 0).cpu()
+            return out
+        monkeypatch.setattr(cor2_mod.ops, "relation_projection", relation_projection)
+    else:
+        inner_ml = oda_mod.my_linears
+
+        def my_linears(mods, x, **kw):
+            out = inner_ml(mods, x, **kw)
+            if len(mods) == 2 and mods[0] is model.compress_q:
+                rec["q_proj"] = [(out[0] > 0).cpu(), (out[1] > 0).cpu()]      # compress_q, linear_q
+            return out
+        monkeypatch.setattr(oda_mod, "my_linears", my_linears)
+    try:
+        got = model({"v": torch.from_numpy(v).to(dev()), "q_idxes": torch.from_numpy(q).to(dev())})
+    finally:
+        for h in hooks:
+            h.remove()
+        for name in (("att1", "att2") if cls == "cor2" else ("att",)):
+            del getattr(model, name).attend
+    RF.kld_sum_loss(got, torch.from_numpy(a).to(dev())).backward()
+    # the restatement's relu sites in call order (oracle/reference_faithful.py: CoR2Oracle.forward / ODAOracle.forward)
+    if cls == "cor2":
+        assert set(rec) == {"compress_v", "compress_v2", "q_proj", "att1.glimpses", "att2.glimpses"}
+        A = rec["att1.glimpses"].shape[1] // 4
+        order = [("compress_q", rec["q_proj"][0]), ("compress_v", rec["compress_v"])] + \
+            [("att1.glimpses", rec["att1.glimpses"][:, g * A:(g + 1) * A]) for g in range(4)] + \
+            [("compress_q_1", rec["q_proj"][2]), ("compress_q_2", rec["q_proj"][3]), ("compress_v2", rec["compress_v2"])] + \
+            [("att2.glimpses", rec["att2.glimpses"][:, g * A:(g + 1) * A]) for g in range(4)] + [("linear_q", rec["q_proj"][1])]
+    else:
+        assert set(rec) == {"compress_v", "q_proj", "att.glimpses"}
+        A = rec["att.glimpses"].shape[1] // 4
+        order = [("compress_v", rec["compress_v"]), ("compress_q", rec["q_proj"][0])] + \
+            [("att.glimpses", rec["att.glimpses"][:, g * A:(g + 1) * A]) for g in range(4)] + [("linear_q", rec["q_proj"][1])]
+    o64 = seeded.load_state({"cor2": RF.CoR2Oracle, "oda": RF.ODAOracle}[cls](nans), 0).eval().double()
+    flips, cursor, rng = {}, [0], [0, 0]
+    activate = RF._activate
+
+    def forced(x, af, dim):
+        if af != "relu":
+            return activate(x, af, dim)
+        site, gate = order[cursor[0]]
+        cursor[0] += 1
+        gate = gate[rng[0]:rng[1]].reshape(x.shape)
+        xd = x.detach()
+        diff = (xd > 0) != gate
+        rms = float(xd.pow(2).mean().sqrt())
+        n, units, edge = flips.get(site, (0, 0, 0.0))
+        flips[site] = (n + int(diff.sum()), units + diff.numel(),
+                       max(edge, float(xd[diff].abs().max()) / rms if bool(diff.any()) else 0.0))
+        return x * gate.to(x.dtype)
+
+    params = [p for _, p in o64.named_parameters()]
+    want = []
+    RF._activate = forced
+    try:
+        for lo in range(0, B, 64):
+            rng[0], rng[1], cursor[0] = lo, lo + 64, 0
+            w64 = o64({"v": torch.from_numpy(v[lo:lo + 64]).double(), "q": torch.from_numpy(q[lo:lo + 64]).double()})
+            assert cursor[0] == len(order)
+            RF.kld_sum_loss(w64, torch.from_numpy(a[lo:lo + 64]).double()).backward()
+            want.append(w64.detach())
+    finally:
+        RF._activate = activate
+    for site, (n, units, edge) in sorted(flips.items()):
+        print("  [%s] gates %-14s differ at %d of %d units (%.1e), largest |pre| / rms there %.1e" % (cls, site, n, units, n / units, edge))
+        assert n <= max(1, FLIP_FRACTION_F32 * units) and edge <= FLIP_EDGE_F32, (site, n, units, edge)
+    assert rel(got, torch.cat(want).numpy()) <= RTOL
+    worst = (0.0, "")
+    for (n, p), po in zip(model.named_parameters(), params):
+        e = grad_err(p.grad, po.grad.numpy(), ATOL_512) * RTOL          # (error on the tensor's scale)
+        assert e <= RTOL_FORCED_F32, (cls, n, e)
+        worst = max(worst, (e, n))
+    print("[%s B=512, gates forced] all %d samples: worst gradient error %.2e of its tensor's scale (%s)" % (cls, B, worst[0], worst[1]))
