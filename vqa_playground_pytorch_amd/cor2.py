@@ -247,11 +247,13 @@ class Model(nn.Module):
             # two region rows and of t / c2 rows that belong to THIS forward only when it ran eagerly -- under graph replay
             # t and c2 are the graph's own buffers and hold the latest replay's values (documented on SideOutputs).  Only
             # the [:, 0:2] slice of v is kept alive, not the [B,N,2048] input.
-            t_d, c2_d, v_d = t.detach(), c2.detach(), v_feature.detach()[:, 0:2, :].float()
+            # (the slice keeps its storage dtype until it is read: for bf16 regions .float() is a conversion kernel, and a
+            #  training step never reads the feature)
+            t_d, c2_d, v_d = t.detach(), c2.detach(), v_feature.detach()[:, 0:2, :]
             if self.training:
-                feature = lambda: torch.addcmul(t_d.unsqueeze(1), c2_d.unsqueeze(1), v_d)  # noqa: E731
+                feature = lambda: torch.addcmul(t_d.unsqueeze(1), c2_d.unsqueeze(1), v_d.float())  # noqa: E731
             else:
-                feature = torch.addcmul(t_d.unsqueeze(1), c2_d.unsqueeze(1), v_d)
+                feature = torch.addcmul(t_d.unsqueeze(1), c2_d.unsqueeze(1), v_d.float())
         else:
             # pairwise form: every (i, j) term of the relation tensor summed in the kernel, as the reference structures it;
             # v2 has two consumers, each gets its own alias (see ops.pairwise_relation_reduce)
