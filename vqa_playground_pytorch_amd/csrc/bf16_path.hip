@@ -183,8 +183,50 @@ __global__ __launch_bounds__(kBfThreads) void gemm_bf16_tn_kernel(const bf16* __
 struct BfOuts {
   float* p[kBfMaxR];
 };
+// An optional second job of the slab-reduction launch (K4's weight gradient): the bias gradients of the R rank layers,
+// db1[r][h] = sum_b h2[b,r,h] * gsum[b,h] -- 256 lanes = 64 columns x 4 sample slices (a serial loop over B per column is a
+// chain of B dependent L2 round trips: 36 us at B = 128); the slices meet in LDS, fixed order.  Until round 4 a launch of
+// its own (4.8 us at the launch floor, twice per step); now the blocks behind the reduction's own rows.  (The plain layers'
+// bias gradient -- column sums of a [12800, 320] bf16 tensor -- was tried as such a job too: its 40 blocks walk 50 rows per
+// lane and take 24 us, longer than the two launches they replace; it keeps its column_sum kernels.)
+struct BfDbJob {
+  const float* h2 = nullptr;     // [B, R, Hout] (unpadded); nullptr: no job
+  const float* gsum = nullptr;   // [B, H]
+  BfOuts db1{};                  // R vectors of Hout values: the nn.Linear bias gradients themselves
+  int B = 0, H = 0, R = 0, Hout = 0;
+  int blocks = 0;                // R * H / 64
+};
+__device__ __forceinline__ void bilinear_db_block(const BfDbJob& j, int block) {
+  __shared__ float part[3][64];
+  const float* __restrict__ h2 = j.h2;
+  const float* __restrict__ gsum = j.gsum;
+  const int B = j.B, H = j.H, R = j.R, Hout = j.Hout;
+  const int c = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int e = block * 64 + c;  // < R*H: H % 256 == 0
+  const int h = e % H;
+  const int eo = (e / H) * Hout + min(h, Hout - 1);   // (pad columns: a clamped read, not stored)
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int b = slice;
+  for (; b + 12 < B; b += 16) {
+    a0 = fmaf(h2[(size_t)b * R * Hout + eo], gsum[(size_t)b * H + h], a0);
+    a1 = fmaf(h2[(size_t)(b + 4) * R * Hout + eo], gsum[(size_t)(b + 4) * H + h], a1);
+    a2 = fmaf(h2[(size_t)(b + 8) * R * Hout + eo], gsum[(size_t)(b + 8) * H + h], a2);
+    a3 = fmaf(h2[(size_t)(b + 12) * R * Hout + eo], gsum[(size_t)(b + 12) * H + h], a3);
+  }
+  for (; b < B; b += 4) a0 = fmaf(h2[(size_t)b * R * Hout + eo], gsum[(size_t)b * H + h], a0);
+  const float a = (a0 + a1) + (a2 + a3);
+  if (slice > 0) part[slice - 1][c] = a;
+  __syncthreads();
+  if (slice == 0 && h < Hout) j.db1.p[e / H][h] = a + part[0][c] + part[1][c] + part[2][c];
+}
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, BfOuts outs, int S, int N1, int N2,
-                                                          int gp, int out_rows, int out_cols, int out_ld, float scale) {
+                                                          int gp, int out_rows, int out_cols, int out_ld, float scale,
+                                                          BfDbJob dbjob) {
+  if ((int)blockIdx.y >= N1) {            // (block-uniform) the rows behind the reduction's own: the bias-gradient job
+    const int block = ((int)blockIdx.y - N1) * (int)gridDim.x + (int)blockIdx.x;
+    if (block < dbjob.blocks) bilinear_db_block(dbjob, block);
+    return;
+  }
   const int c = (blockIdx.x * 256 + threadIdx.x) * 2;
   const int n1 = blockIdx.y;
   const int g = n1 / gp, r = n1 - g * gp;
@@ -265,7 +307,7 @@ struct TnExtra {
 // outs: `groups` output matrices [out_rows, out_cols] (row stride out_ld); row n1 of the product belongs to group n1 / gp.
 static int launch_tn(const char* who, const bf16* A, int lda, const bf16* B, int ldb, const BfOuts& outs, int groups, int gp,
                      int out_rows, int out_cols, int out_ld, float* workspace, int Kdim, int N1, int N2, hipStream_t s,
-                     const TnExtra& ex = TnExtra()) {
+                     const TnExtra& ex = TnExtra(), const BfDbJob& dbjob = BfDbJob()) {
   const BfTileChoice t = tn_tile(N1, N2);
   const int S = tn_splits(Kdim, N1, N2, t);
   const int tiles_m = (N1 + t.bm - 1) / t.bm, tiles_n = (N2 + t.bn - 1) / t.bn;
@@ -298,8 +340,10 @@ static int launch_tn(const char* who, const bf16* A, int lda, const bf16* B, int
 #undef LAUNCH_X
 #undef LAUNCH_T
   (void)groups;
-  VQA_LAUNCH(slab_reduce_kernel, dim3((unsigned)((out_cols + 511) / 512), (unsigned)N1), dim3(256), 0, s, workspace,
-                     outs, S, N1, N2, gp, out_rows, out_cols, out_ld, ex.scale);
+  const unsigned gx = (unsigned)((out_cols + 511) / 512);
+  const unsigned extra = dbjob.h2 != nullptr ? ((unsigned)dbjob.blocks + gx - 1) / gx : 0u;
+  VQA_LAUNCH(slab_reduce_kernel, dim3(gx, (unsigned)N1 + extra), dim3(256), 0, s, workspace, outs, S, N1, N2, gp, out_rows,
+             out_cols, out_ld, ex.scale, dbjob);
   return check_launch(who);
 }
 
@@ -561,31 +605,6 @@ __global__ __launch_bounds__(256) void bilinear_bwd_prep8_bf16_kernel(const bf16
       gsum[(size_t)b * H + h + j] = t;
     }
   }
-}
-
-// db1[r][h] = sum_b h2[b,r,h] * gsum[b,h].  256 lanes = 64 columns x 4 sample slices (a serial loop over B per
-// column is a chain of B dependent L2 round trips: 36 us at B = 128); slices meet in LDS, fixed order.
-// (db1: one output vector per rank, Hout <= H values each -- the nn.Linear bias gradients themselves)
-__global__ __launch_bounds__(256) void bilinear_db_bf16_kernel(const float* __restrict__ h2, const float* __restrict__ gsum,
-                                                               BfOuts db1, int B, int H, int R, int Hout) {
-  __shared__ float part[3][64];
-  const int c = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + c;  // < R*H: H % 256 == 0
-  const int h = e % H;
-  const int eo = (e / H) * Hout + min(h, Hout - 1);   // h2 is the unpadded [B,R,Hout] (pad columns: a clamped read, not stored)
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int b = slice;
-  for (; b + 12 < B; b += 16) {
-    a0 = fmaf(h2[(size_t)b * R * Hout + eo], gsum[(size_t)b * H + h], a0);
-    a1 = fmaf(h2[(size_t)(b + 4) * R * Hout + eo], gsum[(size_t)(b + 4) * H + h], a1);
-    a2 = fmaf(h2[(size_t)(b + 8) * R * Hout + eo], gsum[(size_t)(b + 8) * H + h], a2);
-    a3 = fmaf(h2[(size_t)(b + 12) * R * Hout + eo], gsum[(size_t)(b + 12) * H + h], a3);
-  }
-  for (; b < B; b += 4) a0 = fmaf(h2[(size_t)b * R * Hout + eo], gsum[(size_t)b * H + h], a0);
-  const float a = (a0 + a1) + (a2 + a3);
-  if (slice > 0) part[slice - 1][c] = a;
-  __syncthreads();
-  if (slice == 0 && h < Hout) db1.p[e / H][h] = a + part[0][c] + part[1][c] + part[2][c];
 }
 
 // fp32 [batch, rows, cols] -> bf16 at dst[b*sb + r*sr + c*sc]  (dst zero-filled beforehand: the pads)
@@ -921,7 +940,6 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd_bf16(const vqa_bf16_t* x, const v
       }
   }
 #undef PREP8
-  VQA_LAUNCH(bilinear_db_bf16_kernel, dim3(RH / 64), dim3(256), 0, s, h2, gsum, db, B, H, R, H_out);
   if (d_x != nullptr) {
     NtExtra ex;
     if (gate_dx) {   // x is the relu output of the layer in front: its gradient gate rides in this store
@@ -932,6 +950,15 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd_bf16(const vqa_bf16_t* x, const v
                    reinterpret_cast<bf16*>(d_x), L, M, L, RH, 0, s, ex);
     if (rc != VQA_OK) return rc;
   }
+  BfDbJob dbjob;        // the bias gradients ride in the weight gradient's slab-reduction launch
+  dbjob.h2 = h2;
+  dbjob.gsum = gsum;
+  dbjob.db1 = db;
+  dbjob.B = B;
+  dbjob.H = H;
+  dbjob.R = R;
+  dbjob.Hout = H_out;
+  dbjob.blocks = RH / 64;
   return launch_tn("lowrank_bilinear_fusion_bwd_bf16(dw)", gs, RH, reinterpret_cast<const bf16*>(x), L, dw, R, H, H_out, L_out,
-                   L_out, slabs, M, RH, L, s);
+                   L_out, slabs, M, RH, L, s, TnExtra(), dbjob);
 }
