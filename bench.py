@@ -270,7 +270,7 @@ def compact_line(full):
     line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                         "vs_baseline", "dtype", "data"))
     cfg = full.get("config", {})
-    line["config"] = _pick(cfg, ("workload", "global_batch", "parallelism", "launch", "relation_mode", "inputs"))
+    line["config"] = _pick(cfg, ("workload", "global_batch", "parallelism", "launch", "relation_mode", "f32_products", "inputs"))
     line["config"]["workload"] = str(line["config"].get("workload", ""))[:200]
     line["roofline"] = _pick(full.get("roofline"), ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "mean_ms",
                                                     "launches", "mfma_busy_pct"))
@@ -293,7 +293,15 @@ def compact_line(full):
                 subs[tag] = dict(_pick(rec, ("value", "ms_per_step", "dtype")), kernel=roof.get("kernel"), frac=roof.get("frac"))
         line["sub_records"] = subs
     line["detail"] = full.get("detail_file")
-    for optional in ("detail", "sub_records", "rotating_inputs", "distributed"):   # never needed today: a hard guarantee
+    if len(json.dumps(line)) >= COMPACT_LIMIT:           # first the long texts, then whole optional parts (a hard guarantee)
+        line["config"]["workload"] = line["config"]["workload"][:120]
+        if "cpu_baseline" in line:
+            line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:100]
+    if len(json.dumps(line)) >= COMPACT_LIMIT:
+        for rec in line.get("sub_records", {}).values():
+            if rec.get("kernel"):
+                rec["kernel"] = str(rec["kernel"])[:24]
+    for optional in ("detail", "sub_records", "rotating_inputs", "distributed"):
         if len(json.dumps(line)) < COMPACT_LIMIT:
             break
         line.pop(optional, None)
@@ -396,6 +404,9 @@ SUB_RECORDS = [
     ("oda_attention_b512", ["--model", "oda-attention"]),
     ("cor2_pairwise_b512", ["--relation-mode", "0"]),
     ("cor2_bf16_n100_b128", ["--dtype", "bf16", "--regions", "100", "--batch", "128"]),
+    # the headline config with K5's fp32 products formed from exact three-way bf16 splits on the bf16 matrix pipe (opt-in; fp32
+    # in, fp32 accumulate, fp32 out; error against float64 of the size of the fp32 MFMA engine's: tests/test_gpu_split.py)
+    ("cor2_split_products_b512", ["--f32-products", "split"]),
 ]
 
 
@@ -539,6 +550,9 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="f32 = the reference's arithmetic (headline); "
                     "bf16 = BASELINE configs[4]: bf16 storage + bf16 MFMA on the region side, fp32 accumulate, fp32 "
                     "master weights (use with --regions 100 --batch 128)")
+    ap.add_argument("--f32-products", default=os.environ.get("VQA_F32_PRODUCTS", "mfma"), choices=["mfma", "split"],
+                    help="how K5's fp32 products are formed: mfma = v_mfma_f32_16x16x4_f32 (default, the headline); split = "
+                         "three-way bf16 splits of both operands, six partial products on v_mfma_f32_16x16x32_bf16, fp32 accumulation")
     ap.add_argument("--regions", type=int, default=REGIONS, help="regions per image (36; configs[4]: 100 dense regions)")
     ap.add_argument("--encoder", action="store_true", help="include the question encoder (SURVEY 8f row 3): SkipThoughts = "
                     "embedding(620) + 26-step BayesianGRU(2400), randomly initialised, fed int64 token ids [B,26] instead of "
@@ -553,6 +567,7 @@ def main():
     ap.add_argument("--no-sub-records", action="store_true", help="headline only: do not attach the other single-GPU "
                     "BASELINE configs (ODA, the ODA attention op, CoR2 pairwise, CoR2 bf16 N=100) as sub-records")
     args = ap.parse_args()
+    os.environ["VQA_F32_PRODUCTS"] = args.f32_products     # (read per call by ops.split_products; children inherit it)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)          # no launcher around us: start the ranks ourselves (never measure 1 GPU silently)
@@ -762,6 +777,8 @@ def main():
                        "launch": ("hipGraph replay (3 graphs: backward in two halves, the first all-reduce under the second)"
                                   if trainer.overlap else "hipGraph replay (2 graphs + eager all-reduce)") if graphed else "eager",
                        "relation_mode": "factored" if args.relation_mode == 1 else "pairwise",
+                       "f32_products": ("fp32 MFMA" if args.f32_products == "mfma" else
+                                        "split: 3-way bf16 splits, 6 partial products on the bf16 MFMA, fp32 accumulate"),
                        "library_gemms": __import__("vqa_playground_pytorch_amd.tuned_gemms", fromlist=["describe"]).describe(),
                        "inputs": ("1 resident batch%s"
                                   % ("; %d rotating batches (+1 device copy/step): %+.1f%%"

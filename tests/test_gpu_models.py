@@ -154,7 +154,8 @@ RTOL_EDGE_MAX = 1e-1   # ... and its max-abs error on the tensor's own scale: a 
 #                        row of a glimpse layer's gradient by that sample's whole contribution (measured: 1.8e-2 of the scale
 #                        for a single sample, 3.9e-2 over ODA's 149 knife-edge samples of this batch)
 VARIANTS = [("cor2", 2000, "default"), ("cor2", 2000, "pairwise"), ("cor2", 2000, "k4_engine"), ("cor2", 2000, "legacy_head"),
-            ("cor2", 2000, "grouped_head"), ("oda", 3000, "default"), ("oda", 3000, "grouped_head")]
+            ("cor2", 2000, "grouped_head"), ("oda", 3000, "default"), ("oda", 3000, "grouped_head"),
+            ("cor2", 2000, "split_products"), ("oda", 3000, "split_products")]
 _oracle_cache = {}
 
 
@@ -162,8 +163,12 @@ def build_variant(cls, nans, variant, monkeypatch):
     """default = what bench.py times; pairwise = relation_mode 0 (the relation tensor built from every (i,j) term);
     k4_engine = the Mutan fusion in its R-GEMM form on the LDS tile engine (VQA_K4_FORM=engine); legacy_head / grouped_head =
     the [B,.]-sized layers all on library GEMMs + epilogue kernels / all as grouped phases (VQA_HEAD=legacy / grouped; the
-    default, auto, groups CoR2's phases except the glimpse projections and keeps ODA on the library)."""
+    default, auto, groups CoR2's phases except the glimpse projections and keeps ODA on the library); split_products = the region
+    projections' forward and weight gradient on the split engine (VQA_F32_PRODUCTS=split: fp32 products from three-way bf16
+    splits on the bf16 matrix pipe, csrc/gemm_f32_split.hpp) -- held to the SAME bars as the fp32 MFMA engine."""
     from vqa_playground_pytorch_amd import head, ops
+    if variant == "split_products":
+        monkeypatch.setenv("VQA_F32_PRODUCTS", "split")
     if variant == "k4_engine":
         monkeypatch.setattr(ops, "_K4_FORM", "engine")
     if variant in ("legacy_head", "grouped_head"):

@@ -9,7 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VQA_LIB_PATH", os.path.join(_HERE, "libvqa_mi355x.so"))  # env override: profiling builds
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _c_f = ctypes.c_void_p          # device pointer to fp32
 _c_pp = ctypes.c_void_p         # host array of device pointers
@@ -76,6 +76,12 @@ SIGNATURES = {
     "vqa_linear_act_bwd": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz,
                                   _c_i, _c_i, _c_i, _c_i, _c_fl, _c_u64, _c_f, _c_st]),
     "vqa_linear_dropout_mask": (_c_i, [_c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_st]),
+    "vqa_linear_split_supported": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_fl]),
+    "vqa_linear_act_fwd_split_workspace_bytes": (_c_sz, [_c_i, _c_i]),
+    "vqa_linear_act_fwd_split": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_i, _c_i, _c_i, _c_i, _c_fl, _c_u64, _c_f, _c_st]),
+    "vqa_linear_act_dw_split_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i]),
+    "vqa_linear_act_dw_split": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_i, _c_i, _c_i, _c_i, _c_fl, _c_u64,
+                                       _c_f, _c_st]),
     # bf16 (mixed-precision) side
     "vqa_pairwise_relation_reduce_fwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_pairwise_relation_reduce_bwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f,

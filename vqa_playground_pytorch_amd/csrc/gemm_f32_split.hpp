@@ -1,0 +1,616 @@
+// fp32 GEMM on the bf16 matrix pipe: every fp32 operand is split EXACTLY into three bf16 terms x = x0 + x1 + x2 (8 + 8 + 8
+// significant bits, round-to-nearest at each level, so the residuals are zero-mean) and a product a b is formed from the six
+// partial products whose weight is >= 2^-16 of it:  a0 b0 + (a0 b1 + a1 b0) + (a1 b1 + a0 b2 + a2 b0), each exact in the
+// MFMA's fp32 accumulator arithmetic (a product of two 8-bit significands has 16 bits).  What is dropped -- a1 b2 + a2 b1 +
+// a2 b2 -- is bounded by 2^-24 |a b| (|x1| <= 2^-8 |x|, |x2| <= 2^-17 |x|): below half an ulp of the fp32 product itself.
+// The accumulation is the MFMA's fp32 accumulation, as in gemm_f32_rt.hpp.  So the result carries the rounding of an fp32
+// GEMM (tests/test_gpu_split.py holds both engines against float64 at M = 18432, K = 2048: rms error 4-6e-7 of the result's
+// rms on either, largest error equal), but the multiplies run on v_mfma_f32_16x16x32_bf16 (1024 FLOP/clk/SIMD) instead of
+// v_mfma_f32_16x16x4_f32 (64): six bf16 MFMAs replace eight fp32 ones of twice the issue time per 16x16x32 block step,
+// 2.67 x fewer matrix-pipe cycles.  (The chip clocks bf16 MFMA loops lower -- 1.5-1.7 GHz against 1.9-2.1 -- so what arrives is
+// about 1.7 x: tools/split_probe.hip.)
+//
+// Engine shape = gemm_f32_rt.hpp's: ONE wave per SIMD, RB x CB accumulator blocks of 16x16 per wave, fragments straight from
+// L2 by buffer loads, no LDS in the main loop, a K split over two waves reduced through LDS at the end.
+//   A [M,K] fp32 (the activations: split in registers, 9 VALU instructions per pair of elements, issued in the shadow of the
+//     previous row block's MFMAs -- a v_mfma_f32_16x16x32_bf16 holds the vector issue port for 8 of its 16 cycles);
+//   B [N,K] pre-split ONCE per step into a packed plane image (`split_pack_kernel`): the weights are small and every
+//     workgroup re-reads them, so splitting them in every wave would double the VALU work for nothing.
+//
+// Contraction order inside a 32-deep chunk: lane group g = lane >> 4 supplies the 8 values k = 4 g .. 4 g + 3 and
+// 16 + 4 g .. 16 + 4 g + 3 (two 16-byte loads of a K-contiguous fp32 row; each load instruction covers a contiguous 64 bytes
+// per row).  The packed B image stores exactly those 8 values of a plane as one 16-byte group, in the order the lanes of a wave
+// read them, so that a fragment load is ONE contiguous KiB (8 whole cache lines instead of 16-32 partly used ones):
+//   Bp[n / 16][chunk][plane][lane = (n % 16) + 16 g][8 bf16]      (rows padded to a multiple of 16 with zeros)
+#pragma once
+#include <type_traits>
+
+#include "gemm_f32_rt.hpp"
+
+namespace vqa {
+namespace sp {
+
+using rt::f32x4;
+using rt::ldg16;
+using rt::make_rsrc;
+using rt::rsrc_t;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int kChunk = 32;            // contraction depth of one v_mfma_f32_16x16x32_bf16
+constexpr int kPackedChunkBytes = 3 * 1024;   // one 16-row block's chunk in the packed image: 3 planes x 64 lanes x 16 bytes
+
+// x0, x1 -> the three bf16 planes of both, packed (x0 in the low half): 9 VALU instructions.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t opaque(uint32_t v) {   // (keeps hipcc from re-deriving the halves of a pack by a second convert)
+  asm("" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ uint32_t pack2(f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2)); }
+// x - (the bf16 pair p widened): v_dot2c_f32_bf16 with the constant pairs (-1, 0) and (0, -1) -- one instruction per element
+// (x + p.lo * -1 + p.hi * 0), against shift / and / packed subtract = three per pair.  The difference is exact (it is
+// representable: p is x rounded to 8 significant bits), tools/split_probe.hip checks the instruction delivers it bit for bit.
+template <bool DOT>
+__device__ __forceinline__ f32x2 residual(f32x2 x, uint32_t p) {
+  if constexpr (DOT) {
+    const bf16x2 pv = __builtin_bit_cast(bf16x2, p);
+    const bf16x2 m0 = {(__bf16)-1.0f, (__bf16)0.0f}, m1 = {(__bf16)0.0f, (__bf16)-1.0f};
+    return f32x2{__builtin_amdgcn_fdot2_f32_bf16(pv, m0, x[0], false), __builtin_amdgcn_fdot2_f32_bf16(pv, m1, x[1], false)};
+  } else {
+    const f32x2 w = {bf16_lo(p), bf16_hi(p)};
+    return x - w;
+  }
+}
+// a pair of fp32 -> its three bf16 planes, packed (element 0 in the low half): 7 VALU instructions (9 without the dot form)
+template <bool DOT>
+__device__ __forceinline__ void split_pair(f32x2 x, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+  p0 = opaque(pack2(x));
+  const f32x2 r = residual<DOT>(x, p0);   // |r| <= 2^-9 |x|
+  p1 = opaque(pack2(r));
+  const f32x2 t = residual<DOT>(r, p1);   // |t| <= 2^-18 |x|: at most 8 significant bits remain, the last pack is exact
+  p2 = pack2(t);
+}
+struct Planes {
+  u32x4 p[3];
+};
+template <bool DOT = true>
+__device__ __forceinline__ void split8(const f32x4& lo, const f32x4& hi, Planes& o) {
+  uint32_t w[3][4];
+  split_pair<DOT>(__builtin_shufflevector(lo, lo, 0, 1), w[0][0], w[1][0], w[2][0]);
+  split_pair<DOT>(__builtin_shufflevector(lo, lo, 2, 3), w[0][1], w[1][1], w[2][1]);
+  split_pair<DOT>(__builtin_shufflevector(hi, hi, 0, 1), w[0][2], w[1][2], w[2][2]);
+  split_pair<DOT>(__builtin_shufflevector(hi, hi, 2, 3), w[0][3], w[1][3], w[2][3]);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) o.p[q] = u32x4{w[q][0], w[q][1], w[q][2], w[q][3]};
+}
+__device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// ---- the packed plane image of a [N, K] fp32 matrix (K % 32 == 0) -------------------------------------------------
+// one thread per (row block, chunk, lane): 8 fp32 in, 3 x 16 bytes out
+template <bool DOT = false>
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ w, int ldw, int N, int K,
+                                                         u32x4* __restrict__ out) {
+  const int chunks = K / kChunk;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int nblocks = (N + 15) / 16;
+  if (t >= (long)nblocks * chunks * 64) return;
+  const int lane = (int)(t & 63), r = lane & 15, g = lane >> 4;
+  const long bc = t >> 6;
+  const int c = (int)(bc % chunks), n = (int)(bc / chunks) * 16 + r;
+  f32x4 lo = f32x4{0.f, 0.f, 0.f, 0.f}, hi = lo;
+  if (n < N) {
+    const float* src = w + (size_t)n * ldw + c * kChunk + 4 * g;
+    lo = *reinterpret_cast<const f32x4*>(src);
+    hi = *reinterpret_cast<const f32x4*>(src + 16);
+  }
+  Planes pl;
+  split8<DOT>(lo, hi, pl);
+  u32x4* dst = out + (size_t)bc * 192 + lane;
+  dst[0] = pl.p[0];
+  dst[64] = pl.p[1];
+  dst[128] = pl.p[2];
+}
+__host__ __device__ inline size_t packed_bytes(int N, int K) { return (size_t)((N + 15) / 16) * (K / kChunk) * kPackedChunkBytes; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// NT form:  C[m][n] = sum_k A[m][k] * B[n][k]     A [M,K] fp32 row stride lda; B as the packed plane image of [N,K]
+// Workgroup tile (16 RB WM) x (16 CB WN), WK waves split the contraction range (WM WN WK = 4).  K % 64 == 0.
+// DROP: A masked by the p = 0.5 dropout of element (m, k) before it is split (one hash word per row and chunk: 32 elements).
+// ------------------------------------------------------------------------------------------------------------------
+struct NtArgs {
+  const float* A;
+  const u32x4* Bp;
+  int lda;
+  int M, N, K;
+  int tiles_n;
+};
+
+// NR = raw A row blocks in flight per wave (a ring: the load of row block n + NR goes out when n has been split; 2 RB % NR == 0).
+// TUNE (tools/split_probe.hip): bit 0 = no A split (the planes are the raw registers: MFMA + load ceiling, wrong results),
+// bit 1 = no A loads in the loop, bits 2-3 = VALU instructions pinned per MFMA (0 = the default 2), bit 4 = row-major tile
+// order (an XCD then works on every column tile and needs all of B in its L2), bit 5 = no B loads in the loop,
+// bit 6 = residuals by v_dot2c_f32_bf16 (WRONG results as written: kept for the probe), bit 7 = nt policy on the A loads
+template <int RB, int CB, int WM, int WN, int WK, bool DROP, class Epi, int TUNE = 0, int NR = RB>
+__global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg dc, Epi epi) {
+  using S = rt::NtShape<RB, CB, WM, WN, WK>;
+  static_assert((2 * RB) % NR == 0 && NR >= 2 && NR <= 2 * RB, "the ring must divide a pair of chunks");
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wk = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
+  // Column-major tile order: xcd_remap gives an XCD a contiguous range of tiles, so it works on ONE column tile (or few) and only
+  // that part of the packed B image has to live in its 4 MiB L2; the A rows are then read by tiles_n XCDs (Infinity Cache).
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles_m = gridDim.x / p.tiles_n;
+  const int tm = (TUNE & 16) ? tile / p.tiles_n : tile % tiles_m, tn = (TUNE & 16) ? tile % p.tiles_n : tile / tiles_m;
+  const int m0 = tm * S::BM + wm * (16 * RB);
+  const int n0 = tn * S::BN + wn * (16 * CB);
+  const int chunks = p.K / kChunk;
+
+  uint32_t offA[RB], offB[CB], wordA[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    const int row = min(m0 + 16 * i + r, p.M - 1);
+    offA[i] = ((uint32_t)row * (uint32_t)p.lda + 4u * g) * 4u;
+    wordA[i] = ((uint32_t)row * (uint32_t)p.K) >> 5;
+  }
+#pragma unroll
+  for (int j = 0; j < CB; ++j) {
+    const int blk = min((n0 >> 4) + j, (p.N + 15) / 16 - 1);     // (n0 is a multiple of 16; rows past N are zeros in the image)
+    offB[j] = (uint32_t)blk * (uint32_t)chunks * (uint32_t)kPackedChunkBytes + 16u * lane;
+  }
+  const rsrc_t Ab = make_rsrc(p.A, ((size_t)(p.M - 1) * p.lda + p.K) * 4);
+  const rsrc_t Bb = make_rsrc(p.Bp, packed_bytes(p.N, p.K));
+  const uint32_t key = DROP ? drop_key(dc) : 0u;
+
+  f32x4 acc[RB][CB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i)
+#pragma unroll
+    for (int j = 0; j < CB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int per = ((chunks + WK - 1) / WK + 1) & ~1;   // per wave: an even number of chunks
+  const int c_lo = min(chunks, wk * per), c_hi = min(chunks, c_lo + per);
+
+  struct ARaw {
+    f32x4 lo, hi;
+  };
+  auto loadA = [&](ARaw& a, int i, int c) {
+    const uint32_t so = (uint32_t)c * 128u;
+    constexpr int AUX = (TUNE & 128) ? 2 : 0;   // (experiment: nt = streaming policy for the activations)
+    a.lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(Ab, (int)offA[i], (int)so, AUX));
+    a.hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(Ab, (int)(offA[i] + 64u), (int)so, AUX));
+  };
+  auto loadB = [&](Planes(&b)[CB], int c) {
+    const uint32_t so = (uint32_t)c * (uint32_t)kPackedChunkBytes;
+#pragma unroll
+    for (int j = 0; j < CB; ++j)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        b[j].p[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(Bb, (int)(offB[j] + 1024u * q), (int)so, 0));
+  };
+  // the planes of row block i of chunk c from its raw registers (DROP: masked first -- lane (r, g) holds the elements
+  // k = 32 c + 4 g .. + 3 and 32 c + 16 + 4 g .. + 3 of its row: bits 4 g .. and 16 + 4 g .. of the row's hash word of the chunk)
+  auto prepare = [&](const ARaw& a, Planes& pl, int i, int c) {
+    if constexpr ((TUNE & 1) != 0) {
+      pl.p[0] = __builtin_bit_cast(u32x4, a.lo);
+      pl.p[1] = __builtin_bit_cast(u32x4, a.hi);
+      pl.p[2] = __builtin_bit_cast(u32x4, a.lo);
+    } else {
+      ARaw m = a;
+      if constexpr (DROP) {
+        const uint32_t w = mask_word32(wordA[i] + (uint32_t)c, key);
+        rt::keep4_bits(m.lo, w >> (4u * g));
+        rt::keep4_bits(m.hi, w >> (4u * g + 16u));
+      }
+      split8<(TUNE & 64) != 0>(m.lo, m.hi, pl);
+    }
+  };
+  // 6 CB MFMAs of a row block; an accumulator is revisited every CB MFMAs
+  auto mfma_row = [&](const Planes& a, const Planes(&b)[CB], int i) {
+    constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int j = 0; j < CB; ++j) acc[i][j] = mfma_bf16(a.p[PA[q]], b[j].p[PB[q]], acc[i][j]);
+  };
+
+  // Row blocks are numbered n = P RB + i over a PAIR of chunks (P = parity of the chunk inside the pair); raw row block n lives in
+  // ring slot n % NR and its planes in plane set n & 1.  Step n: split row block n + 1 (under the MFMAs of n), send the load of
+  // n + 1 + NR into the slot just freed, issue the 6 CB MFMAs of n.  B: the planes of the next chunk load at the start of a chunk.
+  ARaw a[NR];
+  Planes b0[CB], b1[CB], pl[2];
+  auto fetch = [&](int n, int c_pair) {   // raw row block n (may run past the pair: n >= 2 RB wraps into the next pairs)
+    const int c = min(c_pair + n / RB, c_hi - 1);
+    loadA(a[n % NR], n % RB, c);
+  };
+  auto loadB1 = [&](Planes(&b)[CB], int idx, int c) {   // plane idx % 3 of column block idx / 3
+    b[idx / 3].p[idx % 3] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+        Bb, (int)(offB[idx / 3] + 1024u * (idx % 3)), (int)((uint32_t)c * (uint32_t)kPackedChunkBytes), 0));
+  };
+  // Every row block is its own scheduling region: its loads are consumed in LATER regions, so hipcc cannot sink them down to
+  // their first use (where it puts a load it believes costs tens of cycles) -- they go out where the group barriers place them.
+  auto chunk = [&](Planes(&b)[CB], Planes(&bn)[CB], int c_pair, auto parity) {
+    constexpr int P = decltype(parity)::value;
+    constexpr int LB = (3 * CB + RB - 1) / RB;   // B plane loads per row block
+    const int cb = min(c_pair + P + 1, c_hi - 1);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int n = P * RB + i;
+      prepare(a[(n + 1) % NR], pl[(n + 1) & 1], (n + 1) % RB, min(c_pair + (n + 1) / RB, c_hi - 1));
+      if constexpr ((TUNE & 2) == 0) fetch(n + 1 + NR, c_pair);
+      int nb = 0;
+      if constexpr ((TUNE & 32) == 0) {
+#pragma unroll
+        for (int idx = i * LB; idx < (i + 1) * LB && idx < 3 * CB; ++idx, ++nb) loadB1(bn, idx, cb);
+      }
+      mfma_row(pl[n & 1], b, i);
+      constexpr int NM = 6 * CB;
+      constexpr int VPM = ((TUNE >> 2) & 3) != 0 ? ((TUNE >> 2) & 3) : 2;
+      const int nl = nb + ((TUNE & 2) == 0 ? 2 : 0);
+      const int per = nl > 0 ? NM / nl : NM;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);   // VALU
+        if (nl > 0 && m % per == per - 1 && m / per < nl) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (c_lo < c_hi) {
+    loadB(b0, c_lo);
+#pragma unroll
+    for (int n = 0; n < NR; ++n) fetch(n, c_lo);
+    prepare(a[0], pl[0], 0, c_lo);
+    fetch(NR, c_lo);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c = c_lo; c < c_hi; c += 2) {
+      chunk(b0, b1, c, std::integral_constant<int, 0>{});
+      chunk(b1, b0, c, std::integral_constant<int, 1>{});
+    }
+  }
+
+  auto finish = [&](int blk, f32x4 v) {
+    const int i = blk / CB, j = blk % CB;
+    const int col = n0 + 16 * j + r;
+    if (col < p.N) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = m0 + 16 * i + 4 * g + t;
+        if (row < p.M) epi(row, col, v[t]);
+      }
+    }
+  };
+  if constexpr (WK == 2) {
+    extern __shared__ __attribute__((aligned(16))) char sp_smem[];
+    f32x4* red = reinterpret_cast<f32x4*>(sp_smem);
+    f32x4* out_box = red + (size_t)((wmn * 2 + wk) * S::HALF) * 64 + lane;
+    const f32x4* in_box = red + (size_t)((wmn * 2 + (wk ^ 1)) * S::HALF) * 64 + lane;
+    if (wk == 0) {
+#pragma unroll
+      for (int blk = S::HALF; blk < S::NB; ++blk) out_box[(blk - S::HALF) * 64] = acc[blk / CB][blk % CB];
+    } else {
+#pragma unroll
+      for (int blk = 0; blk < S::HALF; ++blk) out_box[blk * 64] = acc[blk / CB][blk % CB];
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int blk = 0; blk < S::HALF; ++blk) finish(blk, acc[blk / CB][blk % CB] + in_box[blk * 64]);
+    } else {
+#pragma unroll
+      for (int blk = S::HALF; blk < S::NB; ++blk) finish(blk, acc[blk / CB][blk % CB] + in_box[(blk - S::HALF) * 64]);
+    }
+  } else {
+#pragma unroll
+    for (int blk = 0; blk < S::NB; ++blk) finish(blk, acc[blk / CB][blk % CB]);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// TN form (weight gradient):  slab[s][n1][n2] = sum_{m in slab s} G[m][n1] * X[m][n2]
+//   G [M,N1] (the gated output gradient) comes as a packed plane image written by `pack_tn_kernel` (gate, split, column sums
+//   for the bias gradient -- one small pass over 23 MB, so that only ONE operand is split inside the GEMM: with both split in
+//   the loop a wave would issue 2.25 VALU instructions per MFMA, more than the 8 free issue cycles of a 16-cycle MFMA take);
+//   X [M,N2] fp32 row stride ldx (the layer input; DROP: times its p = 0.5 mask), split in registers.
+// Contraction = rows.  Chunk c = rows 32 c .. 32 c + 31; lane (r, g) supplies the rows 32 c + 8 g + j, j = 0..7.
+//   G image: Gp[chunk][n1 / 16][plane][lane = (n1 % 16) + 16 g][8 bf16 = rows j]
+//   X: the OUTPUT column index is permuted as in gemm_f32_rt.hpp's TN form -- lane r loads the 4 consecutive columns
+//   4 r .. 4 r + 3 of a 64-column span as one 16-byte load per row, component cc feeds accumulator block cc (columns
+//   {4 r + cc}), and the four blocks of a span come back together as 16-byte stores.
+// Workgroup = 4 waves = 4 x NA consecutive 16-row blocks of n1 (all of N1 = 310 for NA = 5) x one group of SPN spans of n2 x
+// one row slab; loop order per chunk: the 4 SPN column blocks outermost (a block's planes are made under the MFMAs of the
+// one before), the NA row blocks x 6 products inside.
+// ------------------------------------------------------------------------------------------------------------------
+struct TnArgs {
+  const u32x4* Gp;
+  const float* X;
+  float* slab;
+  int ldx;
+  int M, N1, N2;
+  int nblocks;          // (N1 + 15) / 16
+  int cps;              // chunks per slab (even)
+  int tiles1, tiles2;   // workgroup tiles along n1 (4 NA blocks each) and n2 (64 SPN columns each)
+};
+struct TnPlan {
+  int slabs, cps;
+};
+inline TnPlan tn_plan(int M, int want_slabs) {
+  const int chunks = (M + kChunk - 1) / kChunk;
+  int S = want_slabs < 1 ? 1 : want_slabs;
+  if (S > (chunks + 1) / 2) S = (chunks + 1) / 2;
+  int cps = ((chunks + S - 1) / S + 1) & ~1;
+  S = (chunks + cps - 1) / cps;
+  return {S, cps};
+}
+__host__ __device__ inline size_t packed_tn_bytes(int slabs, int cps, int N1) {
+  return (size_t)slabs * cps * ((N1 + 15) / 16) * kPackedChunkBytes;
+}
+
+// gate + split + pack of G, and the column sums of the gated G (the bias gradient's partial sums, fixed order).
+// One wave per (slab, quarter of the slab's chunks, n1 block): kPackParts x slabs partial column sums per column; three chunks
+// (24 or 48 row loads) in flight per wave.
+constexpr int kPackParts = 4;
+template <bool GATE>
+__global__ __launch_bounds__(64) void pack_tn_kernel(const float* __restrict__ gy, const float* __restrict__ y, int ld, int M,
+                                                     int N1, int nblocks, int cps, u32x4* __restrict__ out,
+                                                     float* __restrict__ dbslab) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int blk = blockIdx.x % nblocks, sp_ = blockIdx.x / nblocks;   // sp_ = slab * kPackParts + part
+  const int slab = sp_ / kPackParts, part = sp_ % kPackParts;
+  const int per = (cps + kPackParts - 1) / kPackParts;
+  const int lo = part * per, hi = min(cps, lo + per);
+  const int n1 = 16 * blk + r;
+  const bool col_ok = n1 < N1;
+  const float* gcol = gy + n1;
+  const float* ycol = y + n1;
+  float colsum = 0.f;
+  constexpr int U = 3;
+  for (int cc = lo; cc < hi; cc += U) {
+    float v[U][8], yv[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int m = (slab * cps + cc + u) * kChunk + 8 * g + j;
+        const bool ok = col_ok && cc + u < hi && m < M;
+        v[u][j] = ok ? gcol[(size_t)m * ld] : 0.f;
+        if constexpr (GATE) yv[u][j] = ok ? ycol[(size_t)m * ld] : 0.f;
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (cc + u >= hi) break;
+      const int c = slab * cps + cc + u;
+      uint32_t w[3][4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        float a0 = v[u][2 * jj], a1 = v[u][2 * jj + 1];
+        if constexpr (GATE) {
+          a0 = yv[u][2 * jj] > 0.f ? a0 : 0.f;
+          a1 = yv[u][2 * jj + 1] > 0.f ? a1 : 0.f;
+        }
+        split_pair<false>(f32x2{a0, a1}, w[0][jj], w[1][jj], w[2][jj]);
+        colsum += a0 + a1;
+      }
+      u32x4* dst = out + ((size_t)c * nblocks + blk) * 192 + lane;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) dst[64 * q] = u32x4{w[q][0], w[q][1], w[q][2], w[q][3]};
+    }
+  }
+  if (dbslab != nullptr) {
+    colsum += __shfl_xor(colsum, 16);
+    colsum += __shfl_xor(colsum, 32);
+    if (g == 0 && col_ok) dbslab[(size_t)sp_ * N1 + n1] = colsum;
+  }
+}
+
+// TUNE: bit 0 = no X split (wrong results: ceiling), bit 1 = no X loads in the loop, bit 5 = no G loads in the loop
+template <int NA, int SPN, bool DROP, int TUNE = 0>
+__global__ __launch_bounds__(kThreads, 1) void gemm_tn_kernel(TnArgs p, DropCfg dc) {
+  constexpr int NBX = 4 * SPN;   // X column blocks per chunk
+  static_assert(NBX % 2 == 0, "plane sets alternate per block");
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles = p.tiles1 * p.tiles2;
+  const int slab = bid / tiles, tile = bid % tiles;
+  const int t2 = tile % p.tiles2, t1 = tile / p.tiles2;
+  const int b1 = (t1 * 4 + wave) * NA;       // first n1 block of this wave
+  const int n2_0 = t2 * (64 * SPN);
+  const int c_lo = slab * p.cps, c_hi = c_lo + p.cps;
+
+  uint32_t offX[8], offG[NA];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    offX[j] = ((uint32_t)(8 * g + j) * (uint32_t)p.ldx + (uint32_t)min(n2_0 + 4 * r, p.N2 - 4)) * 4u;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) offG[i] = (uint32_t)min(b1 + i, p.nblocks - 1) * (uint32_t)kPackedChunkBytes + 16u * lane;
+  // rows past M read as zeros (the buffer's range check); columns past N2 are clamped and never stored
+  const rsrc_t Xb = make_rsrc(p.X, ((size_t)(p.M - 1) * p.ldx + p.N2) * 4);
+  const rsrc_t Gb = make_rsrc(p.Gp, (size_t)gridDim.x / tiles * p.cps * p.nblocks * kPackedChunkBytes);
+  const uint32_t key = DROP ? drop_key(dc) : 0u;
+  const uint32_t chunk_stride_x = 32u * (uint32_t)p.ldx * 4u, chunk_stride_g = (uint32_t)p.nblocks * (uint32_t)kPackedChunkBytes;
+
+  f32x4 acc[NA][NBX];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int b = 0; b < NBX; ++b) acc[i][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  f32x4 xr[SPN][8];
+  Planes g0[NA], g1[NA], pl[2];
+  auto loadX = [&](int q, int c) {
+    const uint32_t so = (uint32_t)c * chunk_stride_x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      xr[q][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(Xb, (int)(offX[j] + 256u * q), (int)so, 0));
+  };
+  auto loadG1 = [&](Planes(&gp)[NA], int idx, int c) {
+    gp[idx / 3].p[idx % 3] = __builtin_bit_cast(
+        u32x4, __builtin_amdgcn_raw_buffer_load_b128(Gb, (int)(offG[idx / 3] + 1024u * (idx % 3)), (int)((uint32_t)c * chunk_stride_g), 0));
+  };
+  // DROP: element (row m, column n2) keeps iff bit (m N2 + n2) & 31 of the hash word of counter (m N2 + n2) >> 5 is set.  A lane's
+  // four columns 4 r .. 4 r + 3 of span q sit at bits 4 (r & 7) .. + 3 of the word of (row, 32-column group 2 q + (r >> 3)).  The 8 lanes
+  // r & ~7 .. + 7 of a lane group need the same 8 SPN words per chunk (8 rows x SPN spans): lane t = r & 7 hashes the words of
+  // row j = t (every span) and they travel by ds_bpermute -- SPN hashes + 8 SPN permutes per chunk instead of 8 SPN hashes.
+  uint32_t hw[SPN][8];
+  const int t8 = r & 7;
+  auto hash_chunk = [&](int q, int c) {
+    const uint32_t row = (uint32_t)c * 32u + 8u * (uint32_t)g + (uint32_t)t8;
+    const uint32_t e = row * (uint32_t)p.N2 + (uint32_t)n2_0 + 64u * (uint32_t)q + 32u * (uint32_t)(r >> 3);
+    const int h = (int)mask_word32(e >> 5, key);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) hw[q][j] = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ((lane & ~7) + j), h);
+  };
+  // planes of X block (q, cc) of the chunk whose raw rows are in xr[q]
+  auto prepare = [&](Planes& o, int q, int cc) {
+    if constexpr ((TUNE & 1) != 0) {
+      o.p[0] = __builtin_bit_cast(u32x4, xr[q][cc]);
+      o.p[1] = __builtin_bit_cast(u32x4, xr[q][cc + 4]);
+      o.p[2] = __builtin_bit_cast(u32x4, xr[q][cc]);
+    } else {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = xr[q][j][cc];
+        if constexpr (DROP) {
+          const uint32_t m = 0u - ((hw[q][j] >> (4u * (uint32_t)t8 + (uint32_t)cc)) & 1u);
+          v[j] = __uint_as_float(__float_as_uint(x) & m);
+        } else {
+          v[j] = x;
+        }
+      }
+      uint32_t w[3][4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) split_pair<false>(f32x2{v[2 * jj], v[2 * jj + 1]}, w[0][jj], w[1][jj], w[2][jj]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) o.p[k] = u32x4{w[k][0], w[k][1], w[k][2], w[k][3]};
+    }
+  };
+  auto mfma_block = [&](const Planes& x, const Planes(&gp)[NA], int b) {
+    constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int i = 0; i < NA; ++i) acc[i][b] = mfma_bf16(gp[i].p[PA[k]], x.p[PB[k]], acc[i][b]);
+  };
+  // One chunk.  On entry pl[0] holds the planes of block 0 of chunk c, xr the raw rows of chunk c (span 0's of chunk c + 1 once
+  // its last block has been split).  Region of block b: planes of block b + 1, loads, 6 NA MFMAs.
+  auto chunk = [&](Planes(&gp)[NA], Planes(&gn)[NA], int c) {
+    const int cn = min(c + 1, c_hi - 1);
+    constexpr int LG = (3 * NA + NBX - SPN - 1) / (NBX - SPN);   // G plane loads per region that carries no X loads
+    int gidx = 0;
+#pragma unroll
+    for (int b = 0; b < NBX; ++b) {
+      const int q = b / 4, cc = b % 4;
+      int nl = 0;
+      if (b + 1 < NBX) {
+        if constexpr (DROP) {
+          if ((b + 1) % 4 == 0) hash_chunk((b + 1) / 4, c);
+        }
+        prepare(pl[(b + 1) & 1], (b + 1) / 4, (b + 1) % 4);
+      } else {
+        if constexpr (DROP) hash_chunk(0, cn);
+        prepare(pl[0], 0, 0);      // next chunk's block 0: its span was reloaded in region 3
+      }
+      if (cc == 3) {
+        // span q's last block was split in the previous region: its registers take the next chunk's rows
+        if constexpr ((TUNE & 2) == 0) {
+          loadX(q, cn);
+          nl = 8;
+        }
+      } else if constexpr ((TUNE & 32) == 0) {
+#pragma unroll
+        for (int k = 0; k < LG; ++k)
+          if (gidx < 3 * NA) {
+            loadG1(gn, gidx, cn);
+            ++gidx;
+            ++nl;
+          }
+      }
+      mfma_block(pl[b & 1], gp, b);
+      constexpr int NM = 6 * NA;
+      const int per = nl > 0 ? NM / nl : NM;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+        if (nl > 0 && m % per == per - 1 && m / per < nl) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  {
+#pragma unroll
+    for (int idx = 0; idx < 3 * NA; ++idx) loadG1(g0, idx, c_lo);
+#pragma unroll
+    for (int q = 0; q < SPN; ++q) loadX(q, c_lo);
+    if constexpr (DROP) hash_chunk(0, c_lo);
+    prepare(pl[0], 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c = c_lo; c < c_hi; c += 2) {
+      chunk(g0, g1, c);
+      chunk(g1, g0, c + 1);
+    }
+  }
+
+  // D[row = n1 % 16 = 4 g + t][col r] of block (i, b = 4 q + cc) is column n2_0 + 64 q + 4 r + cc: the four cc of a span = one store
+  float* out = p.slab + (size_t)slab * p.N1 * p.N2;
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int q = 0; q < SPN; ++q) {
+      const int col = n2_0 + 64 * q + 4 * r;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int n1 = 16 * (b1 + i) + 4 * g + t;
+        if (b1 + i < p.nblocks && n1 < p.N1 && col + 3 < p.N2)
+          *reinterpret_cast<f32x4*>(out + (size_t)n1 * p.N2 + col) =
+              f32x4{acc[i][4 * q][t], acc[i][4 * q + 1][t], acc[i][4 * q + 2][t], acc[i][4 * q + 3][t]};
+      }
+    }
+}
+
+// d_w[e] = scale * (fixed-order sum of the S slabs), float4 lanes, four slabs' loads in flight;  d_b[n] = sum of the Sb rows
+// of partial column sums (the blocks past the d_w range: one thread per column, eight rows in flight)
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slab, const float* __restrict__ dbslab,
+                                                       float* __restrict__ d_w, float* __restrict__ d_b, int NK, int N, int S,
+                                                       int Sb, float scale) {
+  const int wblocks = (NK / 4 + 255) / 256;
+  if ((int)blockIdx.x >= wblocks) {
+    const int n = ((int)blockIdx.x - wblocks) * 256 + threadIdx.x;
+    if (d_b == nullptr || n >= N) return;
+    float a = 0.f;
+    int s = 0;
+    for (; s + 8 <= Sb; s += 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = dbslab[(size_t)(s + k) * N + n];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a += v[k];
+    }
+    for (; s < Sb; ++s) a += dbslab[(size_t)s * N + n];
+    d_b[n] = a;
+    return;
+  }
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= NK) return;
+  const float* src = slab + e;
+  f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 4 <= S; s += 4) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + (size_t)s * NK), v1 = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 1) * NK),
+                v2 = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 2) * NK), v3 = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 3) * NK);
+    a = (((a + v0) + v1) + v2) + v3;
+  }
+  for (; s < S; ++s) a += *reinterpret_cast<const f32x4*>(src + (size_t)s * NK);
+  *reinterpret_cast<f32x4*>(d_w + e) = a * scale;
+}
+inline int slab_sum_blocks(int NK, int N) { return (NK / 4 + 255) / 256 + (N + 255) / 256; }
+
+}  // namespace sp
+}  // namespace vqa

@@ -1,0 +1,125 @@
+// K5 on the split engine (gemm_f32_split.hpp): the tall region projections of CoR2 / ODA (config/CoR2.py:72-88 at :168-169,
+// :213,:218; M = B*36 rows, K = 2048, N = 310) with every fp32 product formed from exact three-way bf16 splits of its
+// operands on the bf16 matrix pipe.  Same contract as vqa_linear_act_fwd / the weight-gradient half of vqa_linear_act_bwd
+// (same dropout mask, same epilogues, fp32 in and out); selected by the host when the option VQA_F32_PRODUCTS is "split".
+#include "common.hpp"
+#include "gemm_f32_split.hpp"
+
+namespace vqa {
+
+struct SplitEpiBiasAct {
+  float* y;
+  const float* bias;
+  int ldy, act;
+  float scale;
+  __device__ __forceinline__ void operator()(int row, int col, float v) const {
+    v = fmaf(v, scale, bias != nullptr ? bias[col] : 0.f);      // scale: 2 when the operand was masked unscaled (p = 0.5)
+    if (act == 1) v = fmaxf(v, 0.f);
+    y[(size_t)row * ldy + col] = v;
+  }
+};
+
+static size_t round256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+static bool split_shape_ok(int M, int K, int N, int ldx, float p_drop) {
+  const DropCfg dc = make_drop(p_drop, 0);
+  return M >= 1152 && K >= 128 && K % 64 == 0 && N >= 16 && N % 2 == 0 && ldx % 4 == 0 && ldx >= K &&
+         (size_t)M * ldx * 4 < (1ull << 32) && (size_t)M * N * 4 < (1ull << 32) && sp::packed_bytes(N, K) < (1ull << 32) &&
+         (dc.p8 == 0 || dc.p8 == kDropHalf);
+}
+static int tn_slabs() {
+  int s = 16;   // 16 n2 tiles x 16 row slabs = 256 workgroups at 310 x 2048
+  if (const char* e = vqa::option("VQA_SPLIT_DW_SLABS")) s = std::atoi(e);
+  return s < 1 ? 1 : (s > 64 ? 64 : s);
+}
+
+}  // namespace vqa
+
+using namespace vqa;
+
+extern "C" int vqa_linear_split_supported(int M, int K, int N, int ldx, float p_drop) {
+  return split_shape_ok(M, K, N, ldx, p_drop) ? 1 : 0;
+}
+
+extern "C" size_t vqa_linear_act_fwd_split_workspace_bytes(int K, int N) { return round256(sp::packed_bytes(N, K)); }
+
+extern "C" int vqa_linear_act_fwd_split(const float* x, int ldx, const float* w, const float* bias, float* y, void* workspace,
+                                        size_t workspace_bytes, int M, int K, int N, int act, float p_drop, uint64_t seed,
+                                        const uint64_t* seed_ptr, vqa_stream_t stream) {
+  VQA_REQUIRE(x && w && y && workspace, VQA_E_BADARG, "linear_act_fwd_split: null pointer");
+  VQA_REQUIRE(act == 0 || act == 1, VQA_E_BADARG, "linear_act_fwd_split: act must be 0 (none) or 1 (relu), got %d", act);
+  VQA_REQUIRE(split_shape_ok(M, K, N, ldx, p_drop), VQA_E_UNSUPPORTED,
+              "linear_act_fwd_split: shape outside the split engine (M=%d K=%d N=%d ldx=%d p=%f); see vqa_linear_split_supported",
+              M, K, N, ldx, (double)p_drop);
+  VQA_REQUIRE(aligned(x, 16) && aligned(w, 16) && aligned(y, 8) && aligned(workspace, 16), VQA_E_UNSUPPORTED,
+              "linear_act_fwd_split: x, w, workspace must be 16-byte aligned");
+  VQA_REQUIRE(workspace_bytes >= vqa_linear_act_fwd_split_workspace_bytes(K, N), VQA_E_BADARG,
+              "linear_act_fwd_split: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
+  sp::u32x4* wp = static_cast<sp::u32x4*>(workspace);
+  {
+    const long threads = (long)((N + 15) / 16) * (K / sp::kChunk) * 64;
+    VQA_LAUNCH((sp::split_pack_kernel<false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, w, K, N, K, wp);
+  }
+  // 144 x 160 workgroup tiles, each wave 9 x 5 accumulator blocks over half of K (M = 18432, N = 310: 256 workgroups)
+  using S = rt::NtShape<9, 5, 1, 2, 2>;
+  const int tiles_m = (M + S::BM - 1) / S::BM, tiles_n = (N + S::BN - 1) / S::BN;
+  const sp::NtArgs a{x, wp, ldx, M, N, K, tiles_n};
+  const SplitEpiBiasAct epi{y, bias, N, act, dc.p8 > 0 ? dc.scale : 1.f};
+  if (dc.p8 > 0) {
+    VQA_ENSURE_LDS((sp::gemm_nt_kernel<9, 5, 1, 2, 2, true, SplitEpiBiasAct, 0, 3>), S::kLdsBytes);
+    VQA_LAUNCH((sp::gemm_nt_kernel<9, 5, 1, 2, 2, true, SplitEpiBiasAct, 0, 3>), dim3(tiles_m * tiles_n), dim3(sp::kThreads),
+               S::kLdsBytes, s, a, dc, epi);
+  } else {
+    VQA_ENSURE_LDS((sp::gemm_nt_kernel<9, 5, 1, 2, 2, false, SplitEpiBiasAct, 0, 3>), S::kLdsBytes);
+    VQA_LAUNCH((sp::gemm_nt_kernel<9, 5, 1, 2, 2, false, SplitEpiBiasAct, 0, 3>), dim3(tiles_m * tiles_n), dim3(sp::kThreads),
+               S::kLdsBytes, s, a, dc, epi);
+  }
+  return check_launch("linear_act_fwd_split");
+}
+
+extern "C" size_t vqa_linear_act_dw_split_workspace_bytes(int M, int K, int N) {
+  const sp::TnPlan pl = sp::tn_plan(M, tn_slabs());
+  return round256(sp::packed_tn_bytes(pl.slabs, pl.cps, N)) + round256((size_t)pl.slabs * N * K * 4) +
+         round256((size_t)pl.slabs * sp::kPackParts * N * 4);
+}
+
+extern "C" int vqa_linear_act_dw_split(const float* x, int ldx, const float* y, const float* gy, float* d_w, float* d_b,
+                                       void* workspace, size_t workspace_bytes, int M, int K, int N, int act, float p_drop,
+                                       uint64_t seed, const uint64_t* seed_ptr, vqa_stream_t stream) {
+  VQA_REQUIRE(x && gy && d_w && workspace, VQA_E_BADARG, "linear_act_dw_split: null pointer");
+  VQA_REQUIRE(act == 0 || (act == 1 && y != nullptr), VQA_E_BADARG, "linear_act_dw_split: act = 1 needs the forward output y");
+  VQA_REQUIRE(split_shape_ok(M, K, N, ldx, p_drop) && K % 128 == 0, VQA_E_UNSUPPORTED,
+              "linear_act_dw_split: shape outside the split engine (M=%d K=%d N=%d ldx=%d p=%f)", M, K, N, ldx, (double)p_drop);
+  VQA_REQUIRE(aligned(x, 16) && aligned(d_w, 16) && aligned(workspace, 16), VQA_E_UNSUPPORTED,
+              "linear_act_dw_split: x, d_w, workspace must be 16-byte aligned");
+  VQA_REQUIRE(workspace_bytes >= vqa_linear_act_dw_split_workspace_bytes(M, K, N), VQA_E_BADARG,
+              "linear_act_dw_split: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
+  const sp::TnPlan pl = sp::tn_plan(M, tn_slabs());
+  const int nblocks = (N + 15) / 16;
+  char* base = static_cast<char*>(workspace);
+  sp::u32x4* gp = reinterpret_cast<sp::u32x4*>(base);
+  float* slab = reinterpret_cast<float*>(base + round256(sp::packed_tn_bytes(pl.slabs, pl.cps, N)));
+  float* dbslab = slab + round256((size_t)pl.slabs * N * K * 4) / 4;
+  if (act == 1)
+    VQA_LAUNCH((sp::pack_tn_kernel<true>), dim3(pl.slabs * sp::kPackParts * nblocks), dim3(64), 0, s, gy, y, N, M, N, nblocks, pl.cps,
+               gp, dbslab);
+  else
+    VQA_LAUNCH((sp::pack_tn_kernel<false>), dim3(pl.slabs * sp::kPackParts * nblocks), dim3(64), 0, s, gy, y, N, M, N, nblocks, pl.cps,
+               gp, dbslab);
+  constexpr int NA = 5, SPN = 2;
+  const int tiles1 = (nblocks + 4 * NA - 1) / (4 * NA), tiles2 = (K + 64 * SPN - 1) / (64 * SPN);
+  const sp::TnArgs a{gp, x, slab, ldx, M, N, K, nblocks, pl.cps, tiles1, tiles2};
+  const dim3 grid(tiles1 * tiles2 * pl.slabs);
+  if (dc.p8 > 0)
+    VQA_LAUNCH((sp::gemm_tn_kernel<NA, SPN, true>), grid, dim3(sp::kThreads), 0, s, a, dc);
+  else
+    VQA_LAUNCH((sp::gemm_tn_kernel<NA, SPN, false>), grid, dim3(sp::kThreads), 0, s, a, dc);
+  const int NK = N * K;
+  VQA_LAUNCH((sp::slab_sum_kernel), dim3(sp::slab_sum_blocks(NK, N)), dim3(256), 0, s, slab, dbslab, d_w, d_b, NK, N, pl.slabs,
+             pl.slabs * sp::kPackParts, dc.p8 > 0 ? dc.scale : 1.f);
+  return check_launch("linear_act_dw_split");
+}

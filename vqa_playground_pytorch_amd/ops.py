@@ -871,6 +871,46 @@ class ObjectDifferenceAttention(torch.autograd.Function):
         return d_vl, d_ql, d_w, d_bias, None, None, None
 
 
+def split_products(M, K, N, ldx, p_drop, weight_gradient=False):
+    """True when this tall projection runs on the split engine (csrc/gemm_f32_split.hpp: fp32 products from exact three-way
+    bf16 splits on the bf16 matrix pipe, fp32 accumulation) -- opt-in by VQA_F32_PRODUCTS=split, default the fp32 MFMA engine."""
+    if os.environ.get("VQA_F32_PRODUCTS", "mfma") != "split":
+        return False
+    if weight_gradient and K % 128 != 0:
+        return False
+    return _lib.lib().vqa_linear_split_supported(M, K, N, ldx, float(p_drop)) == 1
+
+
+def _linear_fwd(x, w, bias, y, M, K, N, act, p_drop, seed):
+    """y = act(dropout(x) W^T + b), on the engine split_products() selects."""
+    L_ = _lib.lib()
+    sv, sp = _seed_args(seed)
+    if split_products(M, K, N, K, p_drop):
+        ws_bytes = L_.vqa_linear_act_fwd_split_workspace_bytes(K, N)
+        ws = torch.empty((ws_bytes + 3) // 4, device=x.device, dtype=torch.float32)
+        _launch("linear_act_fwd_split", (M, K, N, float(p_drop) > 0), L_.vqa_linear_act_fwd_split, _p(x), K, _p(w), _p(bias),
+                _p(y), _p(ws), ws_bytes, M, K, N, int(act), float(p_drop), sv, sp)
+    else:
+        _launch("linear_act_fwd", (M, K, N, float(p_drop) > 0), L_.vqa_linear_act_fwd,
+                _p(x), K, _p(w), _p(bias), _p(y), M, K, N, int(act), float(p_drop), sv, sp)
+
+
+def _linear_dw(x, w, y, gy, d_w, d_b, M, K, N, act, p_drop, seed):
+    """d_w, d_b of y = act(dropout(x) W^T + b) (no data gradient), on the engine split_products() selects."""
+    L_ = _lib.lib()
+    sv, sp = _seed_args(seed)
+    if split_products(M, K, N, K, p_drop, weight_gradient=True):
+        ws_bytes = L_.vqa_linear_act_dw_split_workspace_bytes(M, K, N)
+        ws = torch.empty((ws_bytes + 3) // 4, device=x.device, dtype=torch.float32)
+        _launch("linear_act_dw_split", (M, K, N, p_drop > 0, act), L_.vqa_linear_act_dw_split, _p(x), K,
+                _p(y) if act == 1 else None, _p(gy), _p(d_w), _p(d_b), _p(ws), ws_bytes, M, K, N, act, p_drop, sv, sp)
+    else:
+        ws_bytes = L_.vqa_linear_act_bwd_workspace_bytes(M, K, N)
+        ws = torch.empty((ws_bytes + 3) // 4, device=x.device, dtype=torch.float32)
+        _launch("linear_act_bwd", (M, K, N, p_drop > 0, False), L_.vqa_linear_act_bwd,
+                _p(x), K, _p(w), _p(y), _p(gy), None, _p(d_w), _p(d_b), _p(ws), ws_bytes, M, K, N, act, p_drop, sv, sp)
+
+
 class LinearAct(torch.autograd.Function):
     """K5.  y = act(dropout_p(x) W^T + b) on the fp32 MFMA tile engine; act in {None, 'relu'}.
     Replaces MyConv1d(k=1).forward (config/CoR2.py:72-88) / MyLinear.forward (config/CoR2.py:106-121)."""
@@ -888,9 +928,7 @@ class LinearAct(torch.autograd.Function):
         if w.shape != (N, K) or (bias is not None and bias.shape != (N,)):
             raise ValueError("linear_act: weight must be [N,K] = [%d,%d], bias [N]" % (N, K))
         y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
-        sv, sp = _seed_args(seed)
-        _launch("linear_act_fwd", (M, K, N, float(p_drop) > 0), _lib.lib().vqa_linear_act_fwd,
-                _p(x), K, _p(w), _p(bias), _p(y), M, K, N, int(act), float(p_drop), sv, sp)
+        _linear_fwd(x, w, bias, y, M, K, N, int(act), float(p_drop), seed)
         ctx.save_for_backward(x, w, y)
         ctx.bias = bias
         ctx.cfg = (M, K, N, int(act), float(p_drop), seed, bias is not None)
@@ -918,12 +956,15 @@ class LinearAct(torch.autograd.Function):
         in_kernel_dx = d_x is not None and not (p_drop == 0 and M >= 4096 and LinearAct.library_dgrad)
         d_w = _grad_like(w)
         d_b = _grad_like(ctx.bias) if has_bias else None
+        if not in_kernel_dx:
+            _linear_dw(x, w, y, gy, d_w, d_b, M, K, N, act, p_drop, seed)
+            return d_x, d_w, d_b, None, None, None, None
         L_ = _lib.lib()
         ws_bytes = L_.vqa_linear_act_bwd_workspace_bytes(M, K, N)
         ws = torch.empty((ws_bytes + 3) // 4, device=x.device, dtype=torch.float32)
         sv, sp = _seed_args(seed)
         _launch("linear_act_bwd", (M, K, N, p_drop > 0, in_kernel_dx), L_.vqa_linear_act_bwd,
-                _p(x), K, _p(w), _p(y), _p(gy), _p(d_x) if in_kernel_dx else None, _p(d_w), _p(d_b), _p(ws), ws_bytes,
+                _p(x), K, _p(w), _p(y), _p(gy), _p(d_x), _p(d_w), _p(d_b), _p(ws), ws_bytes,
                 M, K, N, act, p_drop, sv, sp)
         return d_x, d_w, d_b, None, None, None, None
 
@@ -969,7 +1010,7 @@ class RelationProjection(torch.autograd.Function):
                     float(p_drop), sv, sp, B, N, D)
         M = B * N
         y = torch.empty(B, N, L, device=v.device, dtype=torch.float32)
-        _launch("linear_act_fwd", (M, D, L, False), L_.vqa_linear_act_fwd, _p(x), D, _p(w), _p(bias), _p(y), M, D, L, 1, 0.0, 0, None)
+        _linear_fwd(x, w, bias, y, M, D, L, 1, 0.0, 0)
         ctx.save_for_backward(v, x, w, y)
         ctx.bias = bias
         ctx.cfg = (float(p_drop), seed, bool(pregated))
@@ -987,10 +1028,7 @@ class RelationProjection(torch.autograd.Function):
         L_ = _lib.lib()
         d_w = _grad_like(w)
         d_b = _grad_like(ctx.bias) if ctx.bias is not None else None
-        ws_bytes = L_.vqa_linear_act_bwd_workspace_bytes(M, D, L)
-        ws = torch.empty((ws_bytes + 3) // 4, device=v.device, dtype=torch.float32)
-        _launch("linear_act_bwd", (M, D, L, False, False), L_.vqa_linear_act_bwd, _p(x), D, _p(w), _p(y), _p(gz), None, _p(d_w),
-                _p(d_b), _p(ws), ws_bytes, M, D, L, 0, 0.0, 0, None)
+        _linear_dw(x, w, y, gz, d_w, d_b, M, D, L, 0, 0.0, 0)
         d_t = torch.empty(B, D, device=v.device, dtype=torch.float32)
         d_c2 = torch.empty(B, D, device=v.device, dtype=torch.float32)
         sv, sp = _seed_args(seed)
