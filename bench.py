@@ -32,6 +32,8 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TF = 157.3   # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
 MFMA_BF16_PEAK_TF = 2500.0 # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16), no sparsity
+MFMA_SPLIT_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0   # an fp32 product on the split engine = six bf16 partial products: 416.7 TFLOP/s of
+                                               # fp32 GEMM FLOPs is what the bf16 pipe can deliver (csrc/gemm_f32_split.hpp)
 
 BATCH, REGIONS, FEAT, QDIM, ANSWERS = 512, 36, 2048, 2400, 2000
 ROTATE = 4                 # resident batches of the `rotating_inputs` pass (4 x 151 MB > the 256 MB Infinity Cache)
@@ -56,7 +58,10 @@ def work_of(name, shape):
     if base == "lowrank_bilinear_fusion_bwd":
         B, N, L, H, R, dx = s[:6]
         return "mfma", B * (2 * R * N * L * H) * (2 if dx else 1)                    # dW1 (+ dx) contractions
-    if base == "linear_act_fwd":
+    if base in ("linear_act_fwd", "linear_act_fwd_split"):
+        M, K, N = s[:3]
+        return "mfma", 2 * M * K * N                                                  # the fp32 GEMM's FLOPs on either engine
+    if base == "linear_act_dw_split":
         M, K, N = s[:3]
         return "mfma", 2 * M * K * N
     if base == "linear_act_bwd":
@@ -137,6 +142,8 @@ PMC_KERNELS = {  # C-ABI entry -> kernel-name prefixes of its dominant device ke
     "lowrank_bilinear_fusion_fwd": ["vqa::bilinear_fold_rt_kernel<true", "vqa::bilinear_fold_kernel<true"],
     "linear_act_fwd": ["vqa::rt::gemm_nt_kernel<9, 5, 1, 2, 2"],
     "linear_act_bwd": ["vqa::rt::gemm_tn_kernel<5, 2"],
+    "linear_act_fwd_split": ["vqa::sp::gemm_nt_kernel<9, 5, 1, 2, 2"],
+    "linear_act_dw_split": ["vqa::sp::gemm_tn_kernel<5, 2"],
     "lowrank_bilinear_fusion_bwd": ["vqa::bilinear_dw_rt_kernel"],
     "relation_projection_dgrad": ["vqa::relation_dgrad_kernel"],
     "attention_logits_fwd": ["vqa::attention_logits_fwd_kernel"],
@@ -222,6 +229,8 @@ def roofline_entry(name, shape, launches, mean_ms, B, regions=REGIONS, bf16=Fals
         achieved, peak, unit = work / sec / 1e9, HBM_PEAK_GBS, "GB/s"
     elif name.endswith("_bf16") or name.startswith("gemm_bf16"):
         achieved, peak, unit = work / sec / 1e12, MFMA_BF16_PEAK_TF, "TFLOP/s"
+    elif name.endswith("_split"):
+        achieved, peak, unit = work / sec / 1e12, round(MFMA_SPLIT_PEAK_TF, 1), "TFLOP/s"
     else:  # "mfma" and "valu" share the fp32 peak on gfx950 (157.3 TFLOP/s for both pipes)
         achieved, peak, unit = work / sec / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
     entry.update({"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,

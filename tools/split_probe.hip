@@ -207,10 +207,11 @@ static void launch_sp_tn(const float* G, const float* Yg, const float* X, void* 
   float* slab = (float*)((char*)ws + ((sp::packed_tn_bytes(pl.slabs, pl.cps, N1) + 255) & ~(size_t)255));
   float* dbslab = slab + (size_t)pl.slabs * N1 * N2;
   if (!gemm_only) {
+    const size_t lds = sp::pack_tn_lds_bytes(nblocks);
     if (Yg)
-      hipLaunchKernelGGL((sp::pack_tn_kernel<true>), dim3(pl.slabs * sp::kPackParts * nblocks), dim3(64), 0, 0, G, Yg, N1, M, N1, nblocks, pl.cps, gp, dbslab);
+      hipLaunchKernelGGL((sp::pack_tn_kernel<true, false>), dim3(pl.slabs * sp::kPackParts), dim3(256), lds, 0, G, Yg, N1, M, N1, nblocks, pl.cps, gp, dbslab, (float*)nullptr);
     else
-      hipLaunchKernelGGL((sp::pack_tn_kernel<false>), dim3(pl.slabs * sp::kPackParts * nblocks), dim3(64), 0, 0, G, Yg, N1, M, N1, nblocks, pl.cps, gp, dbslab);
+      hipLaunchKernelGGL((sp::pack_tn_kernel<false, false>), dim3(pl.slabs * sp::kPackParts), dim3(256), lds, 0, G, Yg, N1, M, N1, nblocks, pl.cps, gp, dbslab, (float*)nullptr);
   }
   if (pack_only) return;
   const int tiles1 = (nblocks + 19) / 20, tiles2 = (N2 + 127) / 128;

@@ -80,7 +80,7 @@ SIGNATURES = {
     "vqa_linear_act_fwd_split_workspace_bytes": (_c_sz, [_c_i, _c_i]),
     "vqa_linear_act_fwd_split": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_i, _c_i, _c_i, _c_i, _c_fl, _c_u64, _c_f, _c_st]),
     "vqa_linear_act_dw_split_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i]),
-    "vqa_linear_act_dw_split": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_i, _c_i, _c_i, _c_i, _c_fl, _c_u64,
+    "vqa_linear_act_dw_split": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_i, _c_i, _c_i, _c_i, _c_fl, _c_u64,
                                        _c_f, _c_st]),
     # bf16 (mixed-precision) side
     "vqa_pairwise_relation_reduce_fwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_i, _c_i, _c_i, _c_i, _c_st]),

@@ -351,62 +351,81 @@ __host__ __device__ inline size_t packed_tn_bytes(int slabs, int cps, int N1) {
   return (size_t)slabs * cps * ((N1 + 15) / 16) * kPackedChunkBytes;
 }
 
-// gate + split + pack of G, and the column sums of the gated G (the bias gradient's partial sums, fixed order).
-// One wave per (slab, quarter of the slab's chunks, n1 block): kPackParts x slabs partial column sums per column; three chunks
-// (24 or 48 row loads) in flight per wave.
-constexpr int kPackParts = 4;
-template <bool GATE>
-__global__ __launch_bounds__(64) void pack_tn_kernel(const float* __restrict__ gy, const float* __restrict__ y, int ld, int M,
-                                                     int N1, int nblocks, int cps, u32x4* __restrict__ out,
-                                                     float* __restrict__ dbslab) {
-  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  const int blk = blockIdx.x % nblocks, sp_ = blockIdx.x / nblocks;   // sp_ = slab * kPackParts + part
-  const int slab = sp_ / kPackParts, part = sp_ % kPackParts;
+// gate + split + pack of G, and the column sums of the gated G (the bias gradient's partial sums, fixed order); optionally the
+// gated G itself in fp32 (what torch's threshold_backward would have written for the data gradient's kernel).
+// One workgroup per (slab, quarter of the slab's chunks): whole rows come in by coalesced 16-byte loads (a row is N1 floats,
+// 8-byte aligned at least), are gated, and cross an LDS tile of 32 rows x (N1 padded) floats to reach the lanes that pack
+// them: lane (r, g) of wave w packs column 16 blk + r, rows 8 g .. 8 g + 7, for the blocks blk = w, w + 4, ...
+constexpr int kPackParts = 18;   // 16 slabs x 18 = 288 workgroups of two chunks at M = 18432
+template <bool GATE, bool WRITE_GZ>
+__global__ __launch_bounds__(256) void pack_tn_kernel(const float* __restrict__ gy, const float* __restrict__ y, int ld, int M,
+                                                      int N1, int nblocks, int cps, u32x4* __restrict__ out,
+                                                      float* __restrict__ dbslab, float* __restrict__ gz) {
+  extern __shared__ __attribute__((aligned(16))) float pk_tile[];   // [32][pitch], pitch = 16 nblocks + 1 (odd: the 4 lane groups'
+  const int pitch = 16 * nblocks + 1;                               //  rows 8 g land on different banks)
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+  const int slab = blockIdx.x / kPackParts, part = blockIdx.x % kPackParts;
   const int per = (cps + kPackParts - 1) / kPackParts;
   const int lo = part * per, hi = min(cps, lo + per);
-  const int n1 = 16 * blk + r;
-  const bool col_ok = n1 < N1;
-  const float* gcol = gy + n1;
-  const float* ycol = y + n1;
-  float colsum = 0.f;
-  constexpr int U = 3;
-  for (int cc = lo; cc < hi; cc += U) {
-    float v[U][8], yv[U][8];
+  const int pairs = N1 / 2;                   // (N1 is even: rows are float2-aligned)
+  float colsum[8];                            // per block this wave owns (blk = wave + 4 k), column r, rows of lane group g
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int m = (slab * cps + cc + u) * kChunk + 8 * g + j;
-        const bool ok = col_ok && cc + u < hi && m < M;
-        v[u][j] = ok ? gcol[(size_t)m * ld] : 0.f;
-        if constexpr (GATE) yv[u][j] = ok ? ycol[(size_t)m * ld] : 0.f;
-      }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (cc + u >= hi) break;
-      const int c = slab * cps + cc + u;
-      uint32_t w[3][4];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        float a0 = v[u][2 * jj], a1 = v[u][2 * jj + 1];
+  for (int k = 0; k < 8; ++k) colsum[k] = 0.f;
+  for (int cc = lo; cc < hi; ++cc) {
+    const int c = slab * cps + cc;
+    const int m0 = c * kChunk;
+    // 32 rows x N1 floats, float2 per thread and step
+    for (int idx = threadIdx.x; idx < 32 * pairs; idx += 256) {
+      const int row = idx / pairs, cp = idx % pairs;
+      const int m = m0 + row;
+      float2 v = make_float2(0.f, 0.f);
+      if (m < M) {
+        v = *reinterpret_cast<const float2*>(gy + (size_t)m * ld + 2 * cp);
         if constexpr (GATE) {
-          a0 = yv[u][2 * jj] > 0.f ? a0 : 0.f;
-          a1 = yv[u][2 * jj + 1] > 0.f ? a1 : 0.f;
+          const float2 yy = *reinterpret_cast<const float2*>(y + (size_t)m * ld + 2 * cp);
+          v.x = yy.x > 0.f ? v.x : 0.f;
+          v.y = yy.y > 0.f ? v.y : 0.f;
         }
-        split_pair<false>(f32x2{a0, a1}, w[0][jj], w[1][jj], w[2][jj]);
-        colsum += a0 + a1;
+        if constexpr (WRITE_GZ) *reinterpret_cast<float2*>(gz + (size_t)m * ld + 2 * cp) = v;
       }
-      u32x4* dst = out + ((size_t)c * nblocks + blk) * 192 + lane;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) dst[64 * q] = u32x4{w[q][0], w[q][1], w[q][2], w[q][3]};
+      pk_tile[row * pitch + 2 * cp] = v.x;
+      pk_tile[row * pitch + 2 * cp + 1] = v.y;
     }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int blk = wave + 4 * k;
+      if (blk < nblocks) {
+        const int col = 16 * blk + r;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = col < N1 ? pk_tile[(8 * g + j) * pitch + col] : 0.f;
+        uint32_t w[3][4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          split_pair<false>(f32x2{v[2 * jj], v[2 * jj + 1]}, w[0][jj], w[1][jj], w[2][jj]);
+          colsum[k] += v[2 * jj] + v[2 * jj + 1];
+        }
+        u32x4* dst = out + ((size_t)c * nblocks + blk) * 192 + lane;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) dst[64 * q] = u32x4{w[q][0], w[q][1], w[q][2], w[q][3]};
+      }
+    }
+    __syncthreads();
   }
   if (dbslab != nullptr) {
-    colsum += __shfl_xor(colsum, 16);
-    colsum += __shfl_xor(colsum, 32);
-    if (g == 0 && col_ok) dbslab[(size_t)sp_ * N1 + n1] = colsum;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float sum = colsum[k];
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      const int col = 16 * (wave + 4 * k) + r;
+      if (g == 0 && wave + 4 * k < nblocks && col < N1) dbslab[(size_t)blockIdx.x * N1 + col] = sum;
+    }
   }
 }
+inline size_t pack_tn_lds_bytes(int nblocks) { return (size_t)32 * (16 * nblocks + 1) * sizeof(float); }
+constexpr int kPackMaxBlocks = 30;   // (8 blocks per wave; the tile stays under the 64 KiB default LDS cap)
 
 // TUNE: bit 0 = no X split (wrong results: ceiling), bit 1 = no X loads in the loop, bit 5 = no G loads in the loop
 template <int NA, int SPN, bool DROP, int TUNE = 0>
@@ -576,25 +595,27 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_kernel(TnArgs p, DropCfg 
 }
 
 // d_w[e] = scale * (fixed-order sum of the S slabs), float4 lanes, four slabs' loads in flight;  d_b[n] = sum of the Sb rows
-// of partial column sums (the blocks past the d_w range: one thread per column, eight rows in flight)
+// of partial column sums (the blocks past the d_w range)
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slab, const float* __restrict__ dbslab,
                                                        float* __restrict__ d_w, float* __restrict__ d_b, int NK, int N, int S,
                                                        int Sb, float scale) {
   const int wblocks = (NK / 4 + 255) / 256;
   if ((int)blockIdx.x >= wblocks) {
-    const int n = ((int)blockIdx.x - wblocks) * 256 + threadIdx.x;
-    if (d_b == nullptr || n >= N) return;
+    // 16 columns per block: thread (column tid & 15, row group tid >> 4) adds the rows s = group, group + 16, ... in order,
+    // then the 16 groups' partial sums are added in order
+    __shared__ float part[16][17];
+    const int n = ((int)blockIdx.x - wblocks) * 16 + (threadIdx.x & 15), grp = threadIdx.x >> 4;
     float a = 0.f;
-    int s = 0;
-    for (; s + 8 <= Sb; s += 8) {
-      float v[8];
+    if (d_b != nullptr && n < N)
+      for (int s = grp; s < Sb; s += 16) a += dbslab[(size_t)s * N + n];
+    part[grp][threadIdx.x & 15] = a;
+    __syncthreads();
+    if (d_b != nullptr && threadIdx.x < 16 && n < N) {
+      float t = 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = dbslab[(size_t)(s + k) * N + n];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) a += v[k];
+      for (int k = 0; k < 16; ++k) t += part[k][threadIdx.x];
+      d_b[n] = t;
     }
-    for (; s < Sb; ++s) a += dbslab[(size_t)s * N + n];
-    d_b[n] = a;
     return;
   }
   const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -610,7 +631,7 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
   for (; s < S; ++s) a += *reinterpret_cast<const f32x4*>(src + (size_t)s * NK);
   *reinterpret_cast<f32x4*>(d_w + e) = a * scale;
 }
-inline int slab_sum_blocks(int NK, int N) { return (NK / 4 + 255) / 256 + (N + 255) / 256; }
+inline int slab_sum_blocks(int NK, int N) { return (NK / 4 + 255) / 256 + (N + 15) / 16; }
 
 }  // namespace sp
 }  // namespace vqa

@@ -23,7 +23,7 @@ static size_t round256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 static bool split_shape_ok(int M, int K, int N, int ldx, float p_drop) {
   const DropCfg dc = make_drop(p_drop, 0);
-  return M >= 1152 && K >= 128 && K % 64 == 0 && N >= 16 && N % 2 == 0 && ldx % 4 == 0 && ldx >= K &&
+  return M >= 1152 && K >= 128 && K % 64 == 0 && N >= 16 && N % 2 == 0 && (N + 15) / 16 <= sp::kPackMaxBlocks && ldx % 4 == 0 && ldx >= K &&
          (size_t)M * ldx * 4 < (1ull << 32) && (size_t)M * N * 4 < (1ull << 32) && sp::packed_bytes(N, K) < (1ull << 32) &&
          (dc.p8 == 0 || dc.p8 == kDropHalf);
 }
@@ -86,10 +86,12 @@ extern "C" size_t vqa_linear_act_dw_split_workspace_bytes(int M, int K, int N) {
 }
 
 extern "C" int vqa_linear_act_dw_split(const float* x, int ldx, const float* y, const float* gy, float* d_w, float* d_b,
-                                       void* workspace, size_t workspace_bytes, int M, int K, int N, int act, float p_drop,
+                                       float* gz_out, void* workspace, size_t workspace_bytes, int M, int K, int N, int act, float p_drop,
                                        uint64_t seed, const uint64_t* seed_ptr, vqa_stream_t stream) {
   VQA_REQUIRE(x && gy && d_w && workspace, VQA_E_BADARG, "linear_act_dw_split: null pointer");
   VQA_REQUIRE(act == 0 || (act == 1 && y != nullptr), VQA_E_BADARG, "linear_act_dw_split: act = 1 needs the forward output y");
+  VQA_REQUIRE(gz_out == nullptr || (act == 1 && aligned(gz_out, 8)), VQA_E_BADARG,
+              "linear_act_dw_split: gz_out (the gated gradient) only with act = 1, 8-byte aligned");
   VQA_REQUIRE(split_shape_ok(M, K, N, ldx, p_drop) && K % 128 == 0, VQA_E_UNSUPPORTED,
               "linear_act_dw_split: shape outside the split engine (M=%d K=%d N=%d ldx=%d p=%f)", M, K, N, ldx, (double)p_drop);
   VQA_REQUIRE(aligned(x, 16) && aligned(d_w, 16) && aligned(workspace, 16), VQA_E_UNSUPPORTED,
@@ -104,12 +106,16 @@ extern "C" int vqa_linear_act_dw_split(const float* x, int ldx, const float* y, 
   sp::u32x4* gp = reinterpret_cast<sp::u32x4*>(base);
   float* slab = reinterpret_cast<float*>(base + round256(sp::packed_tn_bytes(pl.slabs, pl.cps, N)));
   float* dbslab = slab + round256((size_t)pl.slabs * N * K * 4) / 4;
-  if (act == 1)
-    VQA_LAUNCH((sp::pack_tn_kernel<true>), dim3(pl.slabs * sp::kPackParts * nblocks), dim3(64), 0, s, gy, y, N, M, N, nblocks, pl.cps,
-               gp, dbslab);
-  else
-    VQA_LAUNCH((sp::pack_tn_kernel<false>), dim3(pl.slabs * sp::kPackParts * nblocks), dim3(64), 0, s, gy, y, N, M, N, nblocks, pl.cps,
-               gp, dbslab);
+  {
+    const dim3 pgrid(pl.slabs * sp::kPackParts);
+    const size_t lds = sp::pack_tn_lds_bytes(nblocks);
+    if (act == 1 && gz_out != nullptr)
+      VQA_LAUNCH((sp::pack_tn_kernel<true, true>), pgrid, dim3(256), lds, s, gy, y, N, M, N, nblocks, pl.cps, gp, dbslab, gz_out);
+    else if (act == 1)
+      VQA_LAUNCH((sp::pack_tn_kernel<true, false>), pgrid, dim3(256), lds, s, gy, y, N, M, N, nblocks, pl.cps, gp, dbslab, (float*)nullptr);
+    else
+      VQA_LAUNCH((sp::pack_tn_kernel<false, false>), pgrid, dim3(256), lds, s, gy, y, N, M, N, nblocks, pl.cps, gp, dbslab, (float*)nullptr);
+  }
   constexpr int NA = 5, SPN = 2;
   const int tiles1 = (nblocks + 4 * NA - 1) / (4 * NA), tiles2 = (K + 64 * SPN - 1) / (64 * SPN);
   const sp::TnArgs a{gp, x, slab, ldx, M, N, K, nblocks, pl.cps, tiles1, tiles2};

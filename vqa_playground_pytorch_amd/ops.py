@@ -895,16 +895,19 @@ def _linear_fwd(x, w, bias, y, M, K, N, act, p_drop, seed):
                 _p(x), K, _p(w), _p(bias), _p(y), M, K, N, int(act), float(p_drop), sv, sp)
 
 
-def _linear_dw(x, w, y, gy, d_w, d_b, M, K, N, act, p_drop, seed):
-    """d_w, d_b of y = act(dropout(x) W^T + b) (no data gradient), on the engine split_products() selects."""
+def _linear_dw(x, w, y, gy, d_w, d_b, M, K, N, act, p_drop, seed, gz_out=None):
+    """d_w, d_b of y = act(dropout(x) W^T + b) (no data gradient), on the engine split_products() selects.  gz_out (split engine,
+    act = relu only): receives gy * (y > 0), which the pass that packs the gradient for the GEMM has in hand."""
     L_ = _lib.lib()
     sv, sp = _seed_args(seed)
     if split_products(M, K, N, K, p_drop, weight_gradient=True):
         ws_bytes = L_.vqa_linear_act_dw_split_workspace_bytes(M, K, N)
         ws = torch.empty((ws_bytes + 3) // 4, device=x.device, dtype=torch.float32)
         _launch("linear_act_dw_split", (M, K, N, p_drop > 0, act), L_.vqa_linear_act_dw_split, _p(x), K,
-                _p(y) if act == 1 else None, _p(gy), _p(d_w), _p(d_b), _p(ws), ws_bytes, M, K, N, act, p_drop, sv, sp)
+                _p(y) if act == 1 else None, _p(gy), _p(d_w), _p(d_b), _p(gz_out) if gz_out is not None else None, _p(ws), ws_bytes,
+                M, K, N, act, p_drop, sv, sp)
     else:
+        assert gz_out is None
         ws_bytes = L_.vqa_linear_act_bwd_workspace_bytes(M, K, N)
         ws = torch.empty((ws_bytes + 3) // 4, device=x.device, dtype=torch.float32)
         _launch("linear_act_bwd", (M, K, N, p_drop > 0, False), L_.vqa_linear_act_bwd,
@@ -1024,11 +1027,15 @@ class RelationProjection(torch.autograd.Function):
         L = w.shape[0]
         M = B * N
         gy = _prep("grad_y", gy)
-        gz = gy if pregated else torch.ops.aten.threshold_backward(gy, y, 0)     # one gated tensor for both gradients
         L_ = _lib.lib()
         d_w = _grad_like(w)
         d_b = _grad_like(ctx.bias) if ctx.bias is not None else None
-        _linear_dw(x, w, y, gz, d_w, d_b, M, D, L, 0, 0.0, 0)
+        if not pregated and split_products(M, D, L, D, 0.0, weight_gradient=True):
+            gz = torch.empty_like(gy)                 # the split engine's packing pass gates the gradient and writes it out as well
+            _linear_dw(x, w, y, gy, d_w, d_b, M, D, L, 1, 0.0, 0, gz_out=gz)
+        else:
+            gz = gy if pregated else torch.ops.aten.threshold_backward(gy, y, 0)     # one gated tensor for both gradients
+            _linear_dw(x, w, y, gz, d_w, d_b, M, D, L, 0, 0.0, 0)
         d_t = torch.empty(B, D, device=v.device, dtype=torch.float32)
         d_c2 = torch.empty(B, D, device=v.device, dtype=torch.float32)
         sv, sp = _seed_args(seed)
