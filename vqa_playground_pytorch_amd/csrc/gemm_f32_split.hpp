@@ -130,8 +130,8 @@ struct NtArgs {
 
 // NR = raw A row blocks in flight per wave (a ring: the load of row block n + NR goes out when n has been split; 2 RB % NR == 0).
 // TUNE (tools/split_probe.hip): bit 0 = no A split (the planes are the raw registers: MFMA + load ceiling, wrong results),
-// bit 1 = no A loads in the loop, bits 2-3 = VALU instructions pinned per MFMA (0 = the default 2), bit 4 = row-major tile
-// order (an XCD then works on every column tile and needs all of B in its L2), bit 5 = no B loads in the loop,
+// bit 1 = no A loads in the loop, bits 2-3 = VALU instructions pinned per MFMA (0 = the default 2), bit 4 = column-major tile
+// order (an XCD then works on one column tile, but A is fetched once per column tile), bit 5 = no B loads in the loop,
 // bit 6 = residuals by v_dot2c_f32_bf16 (WRONG results as written: kept for the probe), bit 7 = nt policy on the A loads
 template <int RB, int CB, int WM, int WN, int WK, bool DROP, class Epi, int TUNE = 0, int NR = RB>
 __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg dc, Epi epi) {
@@ -140,11 +140,12 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg 
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wk = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
-  // Column-major tile order: xcd_remap gives an XCD a contiguous range of tiles, so it works on ONE column tile (or few) and only
-  // that part of the packed B image has to live in its 4 MiB L2; the A rows are then read by tiles_n XCDs (Infinity Cache).
+  // Row-major tile order: xcd_remap gives an XCD a contiguous range of tiles, so the tiles_n column tiles of a row tile run on ONE
+  // XCD and its A rows come from HBM once (column-major -- TUNE & 16 -- runs as fast but fetches A once per column tile: 311 MB
+  // counted per launch against 177 algorithmic at N = 310); the packed B image (3.8 MB) is then wanted whole in every L2.
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tiles_m = gridDim.x / p.tiles_n;
-  const int tm = (TUNE & 16) ? tile / p.tiles_n : tile % tiles_m, tn = (TUNE & 16) ? tile % p.tiles_n : tile / tiles_m;
+  const int tm = (TUNE & 16) ? tile % tiles_m : tile / p.tiles_n, tn = (TUNE & 16) ? tile / tiles_m : tile % p.tiles_n;
   const int m0 = tm * S::BM + wm * (16 * RB);
   const int n0 = tn * S::BN + wn * (16 * CB);
   const int chunks = p.K / kChunk;
