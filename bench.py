@@ -67,7 +67,7 @@ def work_of(name, shape):
     if base == "linear_act_bwd":
         M, K, N, _drop, dx = s[:5]
         return "mfma", 2 * M * K * N * (2 if dx else 1)                              # dW (+ dx)
-    if base == "relation_projection_dgrad":
+    if base in ("relation_projection_dgrad", "relation_projection_dgrad_split"):
         B, N, D, L = s[:4]
         return "mfma", 2 * B * N * D * L                                              # the data-gradient contraction
     if base == "grouped_gemm":                                                            # K6: every GEMM of a phase of the
@@ -144,6 +144,7 @@ PMC_KERNELS = {  # C-ABI entry -> kernel-name prefixes of its dominant device ke
     "linear_act_bwd": ["vqa::rt::gemm_tn_kernel<5, 2"],
     "linear_act_fwd_split": ["vqa::sp::gemm_nt_kernel<9, 5, 1, 2, 2"],
     "linear_act_dw_split": ["vqa::sp::gemm_tn_kernel<5, 2"],
+    "relation_projection_dgrad_split": ["vqa::relation_dgrad_split_kernel"],
     "lowrank_bilinear_fusion_bwd": ["vqa::bilinear_dw_rt_kernel"],
     "relation_projection_dgrad": ["vqa::relation_dgrad_kernel"],
     "attention_logits_fwd": ["vqa::attention_logits_fwd_kernel"],

@@ -889,16 +889,19 @@ def test_relation_apply(ops, B, N, D, p, dtype):
     close("d_v", vt.grad.float(), c2[:, None, :].astype(np.float64) * gm, tol)
 
 
-@pytest.mark.parametrize("form", ["two workgroups per CU", "one workgroup per CU"])
+@pytest.mark.parametrize("form", ["two workgroups per CU", "one workgroup per CU", "split engine"])
 @pytest.mark.parametrize("p", [0.0, 0.5, 0.25])
 @pytest.mark.parametrize("B,D,L", [(4, 2048, 310), (5, 256, 310), (33, 128, 34), (1, 64, 32), (8, 320, 48)])
-def test_relation_projection_fused_backward(ops, B, D, L, p, form, lib_option):
+def test_relation_projection_fused_backward(ops, B, D, L, p, form, lib_option, monkeypatch):
     """relation step + second region projection as one node (K1 -> K5): the output equals relation_apply followed by
     linear_act, and d_t / d_c2 / dW / db equal the gradients of that composition (fp64 closed form of the data gradient:
     the masked grad_x summed over the 36 regions) -- without the [B,36,D] data gradient ever being written.  Both forms of
-    the data-gradient kernel (csrc/relation_dgrad.hip: the default, and VQA_RELDG_TUNE=0)."""
+    the data-gradient kernel (csrc/relation_dgrad.hip: the default, and VQA_RELDG_TUNE=0), and the one on the split engine
+    (csrc/relation_dgrad_split.hip, VQA_F32_PRODUCTS=split; the projection itself then runs there too where its shape allows)."""
     if form == "one workgroup per CU":
         lib_option("VQA_RELDG_TUNE", 0)
+    if form == "split engine":
+        monkeypatch.setenv("VQA_F32_PRODUCTS", "split")
     N = 36
     v = seeded.seeded_array((B, N, D), 411)
     t = seeded.seeded_array((B, D), 412)

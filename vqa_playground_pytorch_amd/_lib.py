@@ -77,6 +77,10 @@ SIGNATURES = {
                                   _c_i, _c_i, _c_i, _c_i, _c_fl, _c_u64, _c_f, _c_st]),
     "vqa_linear_dropout_mask": (_c_i, [_c_f, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_st]),
     "vqa_linear_split_supported": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_fl]),
+    "vqa_relation_projection_dgrad_split_supported": (_c_i, [_c_i, _c_i, _c_i, _c_i]),
+    "vqa_relation_projection_dgrad_split_workspace_bytes": (_c_sz, [_c_i, _c_i]),
+    "vqa_relation_projection_dgrad_split": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_fl, _c_u64, _c_f, _c_i, _c_i, _c_i,
+                                                   _c_i, _c_st]),
     "vqa_linear_act_fwd_split_workspace_bytes": (_c_sz, [_c_i, _c_i]),
     "vqa_linear_act_fwd_split": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_i, _c_i, _c_i, _c_i, _c_fl, _c_u64, _c_f, _c_st]),
     "vqa_linear_act_dw_split_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i]),

@@ -133,23 +133,16 @@ struct NtArgs {
 // bit 1 = no A loads in the loop, bits 2-3 = VALU instructions pinned per MFMA (0 = the default 2), bit 4 = column-major tile
 // order (an XCD then works on one column tile, but A is fetched once per column tile), bit 5 = no B loads in the loop,
 // bit 6 = residuals by v_dot2c_f32_bf16 (WRONG results as written: kept for the probe), bit 7 = nt policy on the A loads
-template <int RB, int CB, int WM, int WN, int WK, bool DROP, class Epi, int TUNE = 0, int NR = RB>
-__global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg dc, Epi epi) {
-  using S = rt::NtShape<RB, CB, WM, WN, WK>;
+// The main loop of the NT form as a device function: acc[i][j] += the contraction over the chunks [c_lo, c_hi) (an even count) of
+// rows m0 + 16 i .. of A against the column blocks (n0 >> 4) + j of the packed image.  a_bytes = the extent of A the loads may
+// touch (beyond it they read zeros: a contraction padded past the row end -- K = 320 over rows of 310 -- leans on that and on
+// the image's zero planes there).
+template <int RB, int CB, bool DROP, int TUNE, int NR>
+__device__ __forceinline__ void nt_accumulate(const NtArgs& p, const DropCfg& dc, size_t a_bytes, int m0, int n0, int c_lo, int c_hi,
+                                              f32x4 (&acc)[RB][CB]) {
   static_assert((2 * RB) % NR == 0 && NR >= 2 && NR <= 2 * RB, "the ring must divide a pair of chunks");
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wk = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
-  // Row-major tile order: xcd_remap gives an XCD a contiguous range of tiles, so the tiles_n column tiles of a row tile run on ONE
-  // XCD and its A rows come from HBM once (column-major -- TUNE & 16 -- runs as fast but fetches A once per column tile: 311 MB
-  // counted per launch against 177 algorithmic at N = 310); the packed B image (3.8 MB) is then wanted whole in every L2.
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int tiles_m = gridDim.x / p.tiles_n;
-  const int tm = (TUNE & 16) ? tile % tiles_m : tile / p.tiles_n, tn = (TUNE & 16) ? tile / tiles_m : tile % p.tiles_n;
-  const int m0 = tm * S::BM + wm * (16 * RB);
-  const int n0 = tn * S::BN + wn * (16 * CB);
   const int chunks = p.K / kChunk;
-
   uint32_t offA[RB], offB[CB], wordA[RB];
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
@@ -162,18 +155,9 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg 
     const int blk = min((n0 >> 4) + j, (p.N + 15) / 16 - 1);     // (n0 is a multiple of 16; rows past N are zeros in the image)
     offB[j] = (uint32_t)blk * (uint32_t)chunks * (uint32_t)kPackedChunkBytes + 16u * lane;
   }
-  const rsrc_t Ab = make_rsrc(p.A, ((size_t)(p.M - 1) * p.lda + p.K) * 4);
+  const rsrc_t Ab = make_rsrc(p.A, a_bytes);
   const rsrc_t Bb = make_rsrc(p.Bp, packed_bytes(p.N, p.K));
   const uint32_t key = DROP ? drop_key(dc) : 0u;
-
-  f32x4 acc[RB][CB];
-#pragma unroll
-  for (int i = 0; i < RB; ++i)
-#pragma unroll
-    for (int j = 0; j < CB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int per = ((chunks + WK - 1) / WK + 1) & ~1;   // per wave: an even number of chunks
-  const int c_lo = min(chunks, wk * per), c_hi = min(chunks, c_lo + per);
 
   struct ARaw {
     f32x4 lo, hi;
@@ -273,6 +257,34 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg 
       chunk(b1, b0, c, std::integral_constant<int, 1>{});
     }
   }
+
+}
+
+template <int RB, int CB, int WM, int WN, int WK, bool DROP, class Epi, int TUNE = 0, int NR = RB>
+__global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg dc, Epi epi) {
+  using S = rt::NtShape<RB, CB, WM, WN, WK>;
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wk = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
+  // Row-major tile order: xcd_remap gives an XCD a contiguous range of tiles, so the tiles_n column tiles of a row tile run on ONE
+  // XCD and its A rows come from HBM once (column-major -- TUNE & 16 -- runs as fast but fetches A once per column tile: 311 MB
+  // counted per launch against 177 algorithmic at N = 310); the packed B image (3.8 MB) is then wanted whole in every L2.
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles_m = gridDim.x / p.tiles_n;
+  const int tm = (TUNE & 16) ? tile % tiles_m : tile / p.tiles_n, tn = (TUNE & 16) ? tile / tiles_m : tile % p.tiles_n;
+  const int m0 = tm * S::BM + wm * (16 * RB);
+  const int n0 = tn * S::BN + wn * (16 * CB);
+  const int chunks = p.K / kChunk;
+
+  f32x4 acc[RB][CB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i)
+#pragma unroll
+    for (int j = 0; j < CB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int per = ((chunks + WK - 1) / WK + 1) & ~1;   // per wave: an even number of chunks
+  const int c_lo = min(chunks, wk * per), c_hi = min(chunks, c_lo + per);
+
+  nt_accumulate<RB, CB, DROP, TUNE, NR>(p, dc, ((size_t)(p.M - 1) * p.lda + p.K) * 4, m0, n0, c_lo, c_hi, acc);
 
   auto finish = [&](int blk, f32x4 v) {
     const int i = blk / CB, j = blk % CB;
@@ -597,7 +609,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_kernel(TnArgs p, DropCfg 
 
 // d_w[e] = scale * (fixed-order sum of the S slabs), float4 lanes, four slabs' loads in flight;  d_b[n] = sum of the Sb rows
 // of partial column sums (the blocks past the d_w range)
-__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slab, const float* __restrict__ dbslab,
+static __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slab, const float* __restrict__ dbslab,
                                                        float* __restrict__ d_w, float* __restrict__ d_b, int NK, int N, int S,
                                                        int Sb, float scale) {
   const int wblocks = (NK / 4 + 255) / 256;

@@ -1039,8 +1039,14 @@ class RelationProjection(torch.autograd.Function):
         d_t = torch.empty(B, D, device=v.device, dtype=torch.float32)
         d_c2 = torch.empty(B, D, device=v.device, dtype=torch.float32)
         sv, sp = _seed_args(seed)
-        _launch("relation_projection_dgrad", (B, N, D, L, p_drop > 0), L_.vqa_relation_projection_dgrad, _p(gz), _p(w), _p(v),
-                _p(d_t), _p(d_c2), p_drop, sv, sp, B, N, D, L)
+        if os.environ.get("VQA_F32_PRODUCTS", "mfma") == "split" and L_.vqa_relation_projection_dgrad_split_supported(B, N, D, L) == 1:
+            ws_bytes = L_.vqa_relation_projection_dgrad_split_workspace_bytes(D, L)
+            ws = torch.empty((ws_bytes + 3) // 4, device=v.device, dtype=torch.float32)
+            _launch("relation_projection_dgrad_split", (B, N, D, L, p_drop > 0), L_.vqa_relation_projection_dgrad_split, _p(gz), _p(w),
+                    _p(v), _p(d_t), _p(d_c2), _p(ws), ws_bytes, p_drop, sv, sp, B, N, D, L)
+        else:
+            _launch("relation_projection_dgrad", (B, N, D, L, p_drop > 0), L_.vqa_relation_projection_dgrad, _p(gz), _p(w), _p(v),
+                    _p(d_t), _p(d_c2), p_drop, sv, sp, B, N, D, L)
         return None, d_t, d_c2, d_w, d_b, None, None, None, None
 
 
