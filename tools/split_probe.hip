@@ -293,6 +293,10 @@ int main(int argc, char** argv) {
   T("split 9x5 ring 3", (launch_sp<9, 5, 1, 2, 2, false, 0, 3>(A, K, Bp, bias, y, M, N, K, 1, dc0)));
   T("split 9x5 ring 6, no split no loads (TUNE 35)", (launch_sp<9, 5, 1, 2, 2, false, 35, 6>(A, K, Bp, bias, y, M, N, K, 1, dc0)));
   T("split 9x5 ring 3 dropout", (launch_sp<9, 5, 1, 2, 2, true, 0, 3>(A, K, Bp, bias, y, M, N, K, 1, dch)));
+  T("split 9x5 ring 3, dot residuals (TUNE 64)", (launch_sp<9, 5, 1, 2, 2, false, 64, 3>(A, K, Bp, bias, y, M, N, K, 1, dc0)));
+  T("split 9x5 ring 3, dot residuals, dropout", (launch_sp<9, 5, 1, 2, 2, true, 64, 3>(A, K, Bp, bias, y, M, N, K, 1, dch)));
+  T("split 9x5 ring 3 (plain residuals)", (launch_sp<9, 5, 1, 2, 2, false, 0, 3>(A, K, Bp, bias, y, M, N, K, 1, dc0)));
+  T("split 9x5 ring 3 dropout (plain residuals)", (launch_sp<9, 5, 1, 2, 2, true, 0, 3>(A, K, Bp, bias, y, M, N, K, 1, dch)));
   T("split 9x5 ring 6 again", (launch_sp<9, 5, 1, 2, 2, false, 0, 6>(A, K, Bp, bias, y, M, N, K, 1, dc0)));
   // ---------------------------------------------------------------- TN: weight gradient dW = gate(G)^T drop(X)
   {

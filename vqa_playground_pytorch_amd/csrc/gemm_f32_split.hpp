@@ -48,14 +48,17 @@ __device__ __forceinline__ uint32_t opaque(uint32_t v) {   // (keeps hipcc from 
   return v;
 }
 __device__ __forceinline__ uint32_t pack2(f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2)); }
-// x - (the bf16 pair p widened): v_dot2c_f32_bf16 with the constant pairs (-1, 0) and (0, -1) -- one instruction per element
-// (x + p.lo * -1 + p.hi * 0), against shift / and / packed subtract = three per pair.  The difference is exact (it is
-// representable: p is x rounded to 8 significant bits), tools/split_probe.hip checks the instruction delivers it bit for bit.
+// x - (the bf16 pair p widened).  Default: shift / and / packed subtract, three instructions per pair.  DOT: v_dot2c_f32_bf16 with
+// the constant pairs (-1, 0) and (0, -1), one instruction per element (x + p.lo * -1 + p.hi * 0); the difference is exact (it is
+// representable: p is x rounded to 8 significant bits) and tools/split_probe.hip checks the planes come out bit for bit the
+// same -- but the kernel runs 8 % slower with it (the dot instruction is not a full-rate one), so it stays a probe option.
 template <bool DOT>
 __device__ __forceinline__ f32x2 residual(f32x2 x, uint32_t p) {
   if constexpr (DOT) {
+    // (the constant pairs come through registers: written as literals hipcc folds (-1, 0) into the INLINE constant -1.0, which
+    //  the instruction reads as the f32 pattern 0xBF800000 = the pair (0, -1))
     const bf16x2 pv = __builtin_bit_cast(bf16x2, p);
-    const bf16x2 m0 = {(__bf16)-1.0f, (__bf16)0.0f}, m1 = {(__bf16)0.0f, (__bf16)-1.0f};
+    const bf16x2 m0 = __builtin_bit_cast(bf16x2, opaque(0x0000BF80u)), m1 = __builtin_bit_cast(bf16x2, opaque(0xBF800000u));
     return f32x2{__builtin_amdgcn_fdot2_f32_bf16(pv, m0, x[0], false), __builtin_amdgcn_fdot2_f32_bf16(pv, m1, x[1], false)};
   } else {
     const f32x2 w = {bf16_lo(p), bf16_hi(p)};
@@ -132,7 +135,8 @@ struct NtArgs {
 // TUNE (tools/split_probe.hip): bit 0 = no A split (the planes are the raw registers: MFMA + load ceiling, wrong results),
 // bit 1 = no A loads in the loop, bits 2-3 = VALU instructions pinned per MFMA (0 = the default 2), bit 4 = column-major tile
 // order (an XCD then works on one column tile, but A is fetched once per column tile), bit 5 = no B loads in the loop,
-// bit 6 = residuals by v_dot2c_f32_bf16 (WRONG results as written: kept for the probe), bit 7 = nt policy on the A loads
+// bit 6 = residuals by v_dot2c_f32_bf16 (bit-identical planes, 7 instead of 9 VALU instructions per pair -- and 8 % SLOWER:
+// 129.7 against 119.5 us, tools/split_probe.hip), bit 7 = nt policy on the A loads (162 against 117 us)
 // The main loop of the NT form as a device function: acc[i][j] += the contraction over the chunks [c_lo, c_hi) (an even count) of
 // rows m0 + 16 i .. of A against the column blocks (n0 >> 4) + j of the packed image.  a_bytes = the extent of A the loads may
 // touch (beyond it they read zeros: a contraction padded past the row end -- K = 320 over rows of 310 -- leans on that and on
