@@ -56,7 +56,7 @@ for kind in ("traffic", "mfma"):
     src = os.path.join(out, "pmc_%s_split.json" % kind)
     if not os.path.exists(src):
         continue
-    rows = {k: v for k, v in json.load(open(src)).items() if "sp::" in k or "sp14" in k or "sp15" in k}
+    rows = {k: v for k, v in json.load(open(src)).items() if "sp::" in k or "_split_kernel" in k or "pack_wt_kernel" in k}
     for dst in (os.path.join(out, "pmc_%s.json" % kind), "%s_pmc_%s.json" % (prof, kind)):
         if os.path.exists(dst):
             table = json.load(open(dst))
