@@ -297,6 +297,11 @@ int main(int argc, char** argv) {
   T("split 9x5 ring 3, dot residuals, dropout", (launch_sp<9, 5, 1, 2, 2, true, 64, 3>(A, K, Bp, bias, y, M, N, K, 1, dch)));
   T("split 9x5 ring 3 (plain residuals)", (launch_sp<9, 5, 1, 2, 2, false, 0, 3>(A, K, Bp, bias, y, M, N, K, 1, dc0)));
   T("split 9x5 ring 3 dropout (plain residuals)", (launch_sp<9, 5, 1, 2, 2, true, 0, 3>(A, K, Bp, bias, y, M, N, K, 1, dch)));
+  T("split 9x5 ring 3, 1 VALU per MFMA (TUNE 4)", (launch_sp<9, 5, 1, 2, 2, false, 4, 3>(A, K, Bp, bias, y, M, N, K, 1, dc0)));
+  T("split 9x5 ring 3, 1 VALU per MFMA, dropout", (launch_sp<9, 5, 1, 2, 2, true, 4, 3>(A, K, Bp, bias, y, M, N, K, 1, dch)));
+  T("split 9x5 ring 3, 3 VALU per MFMA (TUNE 12)", (launch_sp<9, 5, 1, 2, 2, false, 12, 3>(A, K, Bp, bias, y, M, N, K, 1, dc0)));
+  T("split 9x5 ring 3 (2 VALU per MFMA)", (launch_sp<9, 5, 1, 2, 2, false, 0, 3>(A, K, Bp, bias, y, M, N, K, 1, dc0)));
+  T("split 9x5 ring 3 dropout (2 VALU per MFMA)", (launch_sp<9, 5, 1, 2, 2, true, 0, 3>(A, K, Bp, bias, y, M, N, K, 1, dch)));
   T("split 9x5 ring 6 again", (launch_sp<9, 5, 1, 2, 2, false, 0, 6>(A, K, Bp, bias, y, M, N, K, 1, dc0)));
   // ---------------------------------------------------------------- TN: weight gradient dW = gate(G)^T drop(X)
   {
@@ -366,6 +371,11 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL(sp::slab_sum_kernel, dim3(sp::slab_sum_blocks(N1 * N2, N1)), dim3(256), 0, 0, slab_rt, dbslab_rt, dw, db, N1 * N2, N1, S, S, 1.f);
     };
     T2("  slab sum only", slab_sum_only());
+    T2("  gemm only, 1 VALU per MFMA (TUNE 4)", (launch_sp_tn<false, 4>(G, nullptr, A, ws, dw, db, M, N1, N2, S, dcz, false, true)));
+    T2("  gemm only, 1 VALU per MFMA, dropout", (launch_sp_tn<true, 4>(G, nullptr, A, ws, dw, db, M, N1, N2, S, dch2, false, true)));
+    T2("  gemm only, 3 VALU per MFMA (TUNE 12)", (launch_sp_tn<false, 12>(G, nullptr, A, ws, dw, db, M, N1, N2, S, dcz, false, true)));
+    T2("  gemm only again", (launch_sp_tn<false>(G, nullptr, A, ws, dw, db, M, N1, N2, S, dcz, false, true)));
+    T2("  gemm only, dropout again", (launch_sp_tn<true>(G, nullptr, A, ws, dw, db, M, N1, N2, S, dch2, false, true)));
     T2("  gemm only, no X split (TUNE 1)", (launch_sp_tn<false, 1>(G, nullptr, A, ws, dw, db, M, N1, N2, S, dcz, false, true)));
     T2("  gemm only, no X loads (TUNE 2)", (launch_sp_tn<false, 2>(G, nullptr, A, ws, dw, db, M, N1, N2, S, dcz, false, true)));
     T2("  gemm only, no G loads (TUNE 32)", (launch_sp_tn<false, 32>(G, nullptr, A, ws, dw, db, M, N1, N2, S, dcz, false, true)));

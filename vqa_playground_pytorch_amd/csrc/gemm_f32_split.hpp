@@ -574,7 +574,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_kernel(TnArgs p, DropCfg 
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+        __builtin_amdgcn_sched_group_barrier(0x002, ((TUNE >> 2) & 3) != 0 ? ((TUNE >> 2) & 3) : 2, 0);   // VALU
         if (nl > 0 && m % per == per - 1 && m / per < nl) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
       }
       __builtin_amdgcn_sched_barrier(0);
