@@ -143,7 +143,7 @@ PMC_KERNELS = {  # C-ABI entry -> kernel-name prefixes of its dominant device ke
     "linear_act_fwd": ["vqa::rt::gemm_nt_kernel<9, 5, 1, 2, 2"],
     "linear_act_bwd": ["vqa::rt::gemm_tn_kernel<5, 2"],
     "linear_act_fwd_split": ["vqa::sp::gemm_nt_kernel<9, 5, 1, 2, 2"],
-    "linear_act_dw_split": ["vqa::sp::gemm_tn_kernel<5, 2"],
+    "linear_act_dw_split": ["vqa::sp::gemm_tn_shared_kernel<5", "vqa::sp::gemm_tn_kernel<5, 2"],
     "relation_projection_dgrad_split": ["vqa::relation_dgrad_split_kernel"],
     "lowrank_bilinear_fusion_bwd": ["vqa::bilinear_dw_rt_kernel"],
     "relation_projection_dgrad": ["vqa::relation_dgrad_kernel"],

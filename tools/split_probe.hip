@@ -216,7 +216,10 @@ static void launch_sp_tn(const float* G, const float* Yg, const float* X, void* 
   if (pack_only) return;
   const int tiles1 = (nblocks + 19) / 20, tiles2 = (N2 + 127) / 128;
   sp::TnArgs a{gp, X, slab, N2, M, N1, N2, nblocks, pl.cps, tiles1, tiles2};
-  hipLaunchKernelGGL((sp::gemm_tn_kernel<5, 2, DROP, TUNE>), dim3(tiles1 * tiles2 * pl.slabs), dim3(sp::kThreads), 0, 0, a, dc);
+  if constexpr ((TUNE & 256) != 0)
+    hipLaunchKernelGGL((sp::gemm_tn_shared_kernel<5, DROP, (TUNE & 255)>), dim3(tiles1 * tiles2 * pl.slabs), dim3(sp::kThreads), sp::kTnSharedLds, 0, a, dc);
+  else
+    hipLaunchKernelGGL((sp::gemm_tn_kernel<5, 2, DROP, TUNE>), dim3(tiles1 * tiles2 * pl.slabs), dim3(sp::kThreads), 0, 0, a, dc);
   if (gemm_only) return;
   const int NK = N1 * N2;
   hipLaunchKernelGGL(sp::slab_sum_kernel, dim3(sp::slab_sum_blocks(NK, N1)), dim3(256), 0, 0, slab, dbslab, dw, db, NK, N1, pl.slabs,
@@ -350,6 +353,14 @@ int main(int argc, char** argv) {
         CK(hipGetLastError());
         compare(mode ? "dW split, gate + dropout" : "dW split", dw, dwref, (size_t)N1 * N2, N2);
         compare(mode ? "db split, gate" : "db split", db, dbref, N1, N1);
+        CK(hipMemset(dw, 0xff, (size_t)N1 * N2 * 4));
+        if (mode)
+          launch_sp_tn<true, 256>(G, Yg, A, ws, dw, db, M, N1, N2, S, dc);
+        else
+          launch_sp_tn<false, 256>(G, nullptr, A, ws, dw, db, M, N1, N2, S, dc);
+        CK(hipDeviceSynchronize());
+        CK(hipGetLastError());
+        compare(mode ? "dW split SHARED, gate + dropout" : "dW split SHARED", dw, dwref, (size_t)N1 * N2, N2);
       }
     }
     const double flop2 = 2.0 * M * N1 * N2;
@@ -371,6 +382,12 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL(sp::slab_sum_kernel, dim3(sp::slab_sum_blocks(N1 * N2, N1)), dim3(256), 0, 0, slab_rt, dbslab_rt, dw, db, N1 * N2, N1, S, S, 1.f);
     };
     T2("  slab sum only", slab_sum_only());
+    T2("  gemm only, X split shared through LDS", (launch_sp_tn<false, 256>(G, nullptr, A, ws, dw, db, M, N1, N2, S, dcz, false, true)));
+    T2("  gemm only, shared, dropout", (launch_sp_tn<true, 256>(G, nullptr, A, ws, dw, db, M, N1, N2, S, dch2, false, true)));
+    T2("  gemm only, shared, unpinned (TUNE 64)", (launch_sp_tn<false, 256 + 64>(G, nullptr, A, ws, dw, db, M, N1, N2, S, dcz, false, true)));
+    T2("  gemm only, shared, unpinned, dropout", (launch_sp_tn<true, 256 + 64>(G, nullptr, A, ws, dw, db, M, N1, N2, S, dch2, false, true)));
+    T2("  gemm only, shared, no X loads", (launch_sp_tn<false, 258>(G, nullptr, A, ws, dw, db, M, N1, N2, S, dcz, false, true)));
+    T2("  gemm only, shared, no G loads", (launch_sp_tn<false, 288>(G, nullptr, A, ws, dw, db, M, N1, N2, S, dcz, false, true)));
     T2("  gemm only, 1 VALU per MFMA (TUNE 4)", (launch_sp_tn<false, 4>(G, nullptr, A, ws, dw, db, M, N1, N2, S, dcz, false, true)));
     T2("  gemm only, 1 VALU per MFMA, dropout", (launch_sp_tn<true, 4>(G, nullptr, A, ws, dw, db, M, N1, N2, S, dch2, false, true)));
     T2("  gemm only, 3 VALU per MFMA (TUNE 12)", (launch_sp_tn<false, 12>(G, nullptr, A, ws, dw, db, M, N1, N2, S, dcz, false, true)));

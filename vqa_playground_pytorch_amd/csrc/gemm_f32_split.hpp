@@ -611,6 +611,179 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_kernel(TnArgs p, DropCfg 
     }
 }
 
+// The TN form with the split of X shared by the workgroup.  The four waves of a workgroup work on the SAME rows and columns of X
+// (they differ in n1), so in gemm_tn_kernel each of them loads and splits all of it: 4 x the loads, 4 x the VALU work (a quarter
+// of that kernel's time: 104 us against 80 with the split switched off).  Here wave w loads only the two columns of each
+// 4-column group that make X blocks 2 w and 2 w + 1 (8-byte loads), splits those two blocks of the NEXT chunk under this chunk's
+// MFMAs and writes their planes into LDS (2 x 24 KiB, double-buffered); all four waves read every block's planes back (three
+// ds_read_b128 per block, one block ahead).  One workgroup barrier per chunk, placed in front of the last block so that the next
+// chunk's block 0 is prefetched under it.  SPN = 2 (8 blocks: two per wave).
+constexpr int kTnSharedLds = 2 * 8 * 3 * 1024;
+template <int NA, bool DROP, int TUNE = 0>
+__global__ __launch_bounds__(kThreads, 1) void gemm_tn_shared_kernel(TnArgs p, DropCfg dc) {
+  constexpr int SPN = 2, NBX = 8;
+  extern __shared__ __attribute__((aligned(16))) char tn_smem[];
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles = p.tiles1 * p.tiles2;
+  const int slab = bid / tiles, tile = bid % tiles;
+  const int t2 = tile % p.tiles2, t1 = tile / p.tiles2;
+  const int b1 = (t1 * 4 + wave) * NA;       // first n1 block of this wave
+  const int n2_0 = t2 * (64 * SPN);
+  const int c_lo = slab * p.cps, c_hi = c_lo + p.cps;
+  const int pq = wave >> 1, pc = 2 * (wave & 1);   // this wave produces the X blocks 4 pq + pc, 4 pq + pc + 1
+
+  uint32_t offX[8], offG[NA];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    offX[j] = ((uint32_t)(8 * g + j) * (uint32_t)p.ldx + (uint32_t)min(n2_0 + 64 * pq + 4 * r + pc, p.N2 - 2)) * 4u;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) offG[i] = (uint32_t)min(b1 + i, p.nblocks - 1) * (uint32_t)kPackedChunkBytes + 16u * lane;
+  const rsrc_t Xb = make_rsrc(p.X, ((size_t)(p.M - 1) * p.ldx + p.N2) * 4);
+  const rsrc_t Gb = make_rsrc(p.Gp, (size_t)gridDim.x / tiles * p.cps * p.nblocks * kPackedChunkBytes);
+  const uint32_t key = DROP ? drop_key(dc) : 0u;
+  const uint32_t chunk_stride_x = 32u * (uint32_t)p.ldx * 4u, chunk_stride_g = (uint32_t)p.nblocks * (uint32_t)kPackedChunkBytes;
+  u32x4* const lds = reinterpret_cast<u32x4*>(tn_smem);     // [buffer][block][plane][lane]
+
+  f32x4 acc[NA][NBX];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int b = 0; b < NBX; ++b) acc[i][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  f32x2 raw0[8], raw1[8];
+  Planes g0[NA], g1[NA], xp[2];
+  uint32_t hw[8];
+  const int t8 = r & 7;
+  auto loadX = [&](f32x2(&raw)[8], int c) {
+    const uint32_t so = (uint32_t)min(c, c_hi - 1) * chunk_stride_x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+      raw[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(Xb, (int)offX[j], (int)so, 0));
+    }
+  };
+  auto loadG1 = [&](Planes(&gp)[NA], int idx, int c) {
+    gp[idx / 3].p[idx % 3] = __builtin_bit_cast(
+        u32x4, __builtin_amdgcn_raw_buffer_load_b128(Gb, (int)(offG[idx / 3] + 1024u * (idx % 3)), (int)((uint32_t)min(c, c_hi - 1) * chunk_stride_g), 0));
+  };
+  // the hash words of this wave's span for the 8 rows of chunk c (gemm_tn_kernel's sharing: lane t = r & 7 hashes row t)
+  auto hash_chunk = [&](int c) {
+    const uint32_t row = (uint32_t)min(c, c_hi - 1) * 32u + 8u * (uint32_t)g + (uint32_t)t8;
+    const uint32_t e = row * (uint32_t)p.N2 + (uint32_t)n2_0 + 64u * (uint32_t)pq + 32u * (uint32_t)(r >> 3);
+    const int h = (int)mask_word32(e >> 5, key);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) hw[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ((lane & ~7) + j), h);
+  };
+  // split column k (0 / 1) of the raw rows into the planes of X block 4 pq + pc + k and write them to LDS buffer `buf`
+  auto produce = [&](const f32x2(&raw)[8], int k, int buf) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = raw[j][k];
+      if constexpr (DROP) {
+        const uint32_t m = 0u - ((hw[j] >> (4u * (uint32_t)t8 + (uint32_t)(pc + k))) & 1u);
+        v[j] = __uint_as_float(__float_as_uint(x) & m);
+      } else {
+        v[j] = x;
+      }
+    }
+    uint32_t w[3][4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) split_pair<false>(f32x2{v[2 * jj], v[2 * jj + 1]}, w[0][jj], w[1][jj], w[2][jj]);
+    u32x4* dst = lds + ((size_t)(buf * NBX + 4 * pq + pc + k) * 3) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) dst[64 * q] = u32x4{w[q][0], w[q][1], w[q][2], w[q][3]};
+  };
+  auto fetch = [&](Planes& o, int b, int buf) {
+    const u32x4* src = lds + ((size_t)(buf * NBX + b) * 3) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) o.p[q] = src[64 * q];
+  };
+  auto mfma_block = [&](const Planes& x, const Planes(&gp)[NA], int b) {
+    constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int i = 0; i < NA; ++i) acc[i][b] = mfma_bf16(gp[i].p[PA[k]], x.p[PB[k]], acc[i][b]);
+  };
+  // One chunk (parity P inside a pair).  On entry: the planes of chunk c are in LDS buffer P (published by the last barrier) and
+  // block 0's are in xp[0]; `rn` holds the raw rows of chunk c + 1, `rf` is free for chunk c + 2's.
+  auto chunk = [&](Planes(&gp)[NA], Planes(&gn)[NA], f32x2(&rn)[8], f32x2(&rf)[8], int c, auto parity) {
+    constexpr int P = decltype(parity)::value;
+    int gidx = 0;
+#pragma unroll
+    for (int b = 0; b < NBX; ++b) {
+      if (b == 7) __syncthreads();            // every wave's planes of chunk c + 1 are in buffer P ^ 1; buffer P's last block was read in region 6
+      if (b + 1 < NBX) fetch(xp[(b + 1) & 1], b + 1, P);
+      else fetch(xp[0], 0, P ^ 1);
+      if (b == 0) {
+        if constexpr ((TUNE & 2) == 0) loadX(rf, c + 2);
+        if constexpr (DROP) hash_chunk(c + 1);
+      }
+      if (b == 1) produce(rn, 0, P ^ 1);
+      if (b == 4) produce(rn, 1, P ^ 1);
+      if constexpr ((TUNE & 32) == 0) {
+        if (b == 2 || b == 3 || b == 5 || b == 6) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (gidx < 3 * NA) {
+              loadG1(gn, gidx, c + 1);
+              ++gidx;
+            }
+        }
+      }
+      mfma_block(xp[b & 1], gp, b);
+      if constexpr ((TUNE & 64) == 0) {
+        // the block's 6 NA MFMAs with the region's other work pinned between them: the three LDS reads of the next block first,
+        // then the split's VALU instructions (two per MFMA), the loads spread over the middle, the LDS writes at the end
+        constexpr int NM = 6 * NA;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // MFMA
+          if (m < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                        // DS read
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                   // VALU
+          if (m >= 6 && m < 22 && (m & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (<= 8 per region)
+          if (m >= NM - 6 && (m & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write (<= 3 per region)
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  {
+#pragma unroll
+    for (int idx = 0; idx < 3 * NA; ++idx) loadG1(g0, idx, c_lo);
+    loadX(raw0, c_lo);
+    loadX(raw1, c_lo + 1);
+    if constexpr (DROP) hash_chunk(c_lo);
+    produce(raw0, 0, 0);
+    produce(raw0, 1, 0);
+    __syncthreads();
+    fetch(xp[0], 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c = c_lo; c < c_hi; c += 2) {
+      chunk(g0, g1, raw1, raw0, c, std::integral_constant<int, 0>{});
+      chunk(g1, g0, raw0, raw1, c + 1, std::integral_constant<int, 1>{});
+    }
+  }
+
+  float* out = p.slab + (size_t)slab * p.N1 * p.N2;
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int q = 0; q < SPN; ++q) {
+      const int col = n2_0 + 64 * q + 4 * r;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int n1 = 16 * (b1 + i) + 4 * g + t;
+        if (b1 + i < p.nblocks && n1 < p.N1 && col + 3 < p.N2)
+          *reinterpret_cast<f32x4*>(out + (size_t)n1 * p.N2 + col) =
+              f32x4{acc[i][4 * q][t], acc[i][4 * q + 1][t], acc[i][4 * q + 2][t], acc[i][4 * q + 3][t]};
+      }
+    }
+}
+
 // d_w[e] = scale * (fixed-order sum of the S slabs), float4 lanes, four slabs' loads in flight;  d_b[n] = sum of the Sb rows
 // of partial column sums (the blocks past the d_w range)
 static __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slab, const float* __restrict__ dbslab,

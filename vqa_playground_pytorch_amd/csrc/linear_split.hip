@@ -120,10 +120,19 @@ extern "C" int vqa_linear_act_dw_split(const float* x, int ldx, const float* y, 
   const int tiles1 = (nblocks + 4 * NA - 1) / (4 * NA), tiles2 = (K + 64 * SPN - 1) / (64 * SPN);
   const sp::TnArgs a{gp, x, slab, ldx, M, N, K, nblocks, pl.cps, tiles1, tiles2};
   const dim3 grid(tiles1 * tiles2 * pl.slabs);
-  if (dc.p8 > 0)
-    VQA_LAUNCH((sp::gemm_tn_kernel<NA, SPN, true>), grid, dim3(sp::kThreads), 0, s, a, dc);
-  else
-    VQA_LAUNCH((sp::gemm_tn_kernel<NA, SPN, false>), grid, dim3(sp::kThreads), 0, s, a, dc);
+  // the split of x shared by the workgroup's four waves through LDS (91.9 / 94.0 us against 99 / 107 with every wave splitting
+  // all of it, tools/split_probe.hip); VQA_SPLIT_TN_SHARED=0 keeps the per-wave form
+  if (vqa::option_is("VQA_SPLIT_TN_SHARED", '0')) {
+    if (dc.p8 > 0)
+      VQA_LAUNCH((sp::gemm_tn_kernel<NA, SPN, true>), grid, dim3(sp::kThreads), 0, s, a, dc);
+    else
+      VQA_LAUNCH((sp::gemm_tn_kernel<NA, SPN, false>), grid, dim3(sp::kThreads), 0, s, a, dc);
+  } else {
+    if (dc.p8 > 0)
+      VQA_LAUNCH((sp::gemm_tn_shared_kernel<NA, true>), grid, dim3(sp::kThreads), sp::kTnSharedLds, s, a, dc);
+    else
+      VQA_LAUNCH((sp::gemm_tn_shared_kernel<NA, false>), grid, dim3(sp::kThreads), sp::kTnSharedLds, s, a, dc);
+  }
   const int NK = N * K;
   VQA_LAUNCH((sp::slab_sum_kernel), dim3(sp::slab_sum_blocks(NK, N)), dim3(256), 0, s, slab, dbslab, d_w, d_b, NK, N, pl.slabs,
              pl.slabs * sp::kPackParts, dc.p8 > 0 ? dc.scale : 1.f);
