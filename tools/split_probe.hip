@@ -171,19 +171,20 @@ static void check_dot_form(const float* X, int N, int K, const char* what) {
   CK(hipFree(p1));
 }
 
-template <int RB, int CB, int WM, int WN, int WK, bool DROP, int TUNE = 0, int NR = RB>
+template <int RB, int CB, int WM, int WN, int WK, bool DROP, int TUNE = 0, int NR = RB, bool SHARE_A = false>
 static void launch_sp(const float* A, int lda, const sp::u32x4* Bp, const float* bias, float* y, int M, int N, int K, int act,
                       DropCfg dc) {
   using S = rt::NtShape<RB, CB, WM, WN, WK>;
   const int tiles_m = (M + S::BM - 1) / S::BM, tiles_n = (N + S::BN - 1) / S::BN;
   sp::NtArgs p{A, Bp, lda, M, N, K, tiles_n};
-  auto kern = sp::gemm_nt_kernel<RB, CB, WM, WN, WK, DROP, EpiBiasRelu, TUNE, NR>;
+  auto kern = sp::gemm_nt_kernel<RB, CB, WM, WN, WK, DROP, EpiBiasRelu, TUNE, NR, SHARE_A>;
+  constexpr size_t lds = sp::nt_lds_bytes<RB, WN, WK, SHARE_A>(S::kLdsBytes);
   static bool once = false;
-  if (!once && S::kLdsBytes > 65536) {
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::kLdsBytes));
+  if (!once && lds > 65536) {
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     once = true;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(sp::kThreads), S::kLdsBytes, 0, p, dc,
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(sp::kThreads), lds, 0, p, dc,
                      EpiBiasRelu{y, bias, N, act, (DROP && dc.p8 > 0) ? dc.scale : 1.f});
 }
 
@@ -278,6 +279,14 @@ int main(int argc, char** argv) {
       CK(hipDeviceSynchronize());
       CK(hipGetLastError());
       compare(drop ? "split bf16 9x5 ring 6, dropout" : "split bf16 9x5 ring 6", y, yref, (size_t)M * N, N);
+      CK(hipMemset(y, 0xff, (size_t)M * N * 4));
+      if (drop)
+        launch_sp<9, 5, 1, 2, 2, true, 0, 3, true>(A, K, Bp, bias, y, M, N, K, 0, dc);
+      else
+        launch_sp<9, 5, 1, 2, 2, false, 0, 3, true>(A, K, Bp, bias, y, M, N, K, 0, dc);
+      CK(hipDeviceSynchronize());
+      CK(hipGetLastError());
+      compare(drop ? "split bf16 9x5 SHARED A, dropout" : "split bf16 9x5 SHARED A", y, yref, (size_t)M * N, N);
     }
   }
   const DropCfg dc0 = make_drop(0.f, 0), dch = make_drop(0.5f, 777);
@@ -305,6 +314,10 @@ int main(int argc, char** argv) {
   T("split 9x5 ring 3, 3 VALU per MFMA (TUNE 12)", (launch_sp<9, 5, 1, 2, 2, false, 12, 3>(A, K, Bp, bias, y, M, N, K, 1, dc0)));
   T("split 9x5 ring 3 (2 VALU per MFMA)", (launch_sp<9, 5, 1, 2, 2, false, 0, 3>(A, K, Bp, bias, y, M, N, K, 1, dc0)));
   T("split 9x5 ring 3 dropout (2 VALU per MFMA)", (launch_sp<9, 5, 1, 2, 2, true, 0, 3>(A, K, Bp, bias, y, M, N, K, 1, dch)));
+  T("split 9x5, A split shared by the wave pair", (launch_sp<9, 5, 1, 2, 2, false, 0, 3, true>(A, K, Bp, bias, y, M, N, K, 1, dc0)));
+  T("split 9x5, shared, dropout", (launch_sp<9, 5, 1, 2, 2, true, 0, 3, true>(A, K, Bp, bias, y, M, N, K, 1, dch)));
+  T("split 9x5 ring 3 once more", (launch_sp<9, 5, 1, 2, 2, false, 0, 3>(A, K, Bp, bias, y, M, N, K, 1, dc0)));
+  T("split 9x5 ring 3 dropout once more", (launch_sp<9, 5, 1, 2, 2, true, 0, 3>(A, K, Bp, bias, y, M, N, K, 1, dch)));
   T("split 9x5 ring 6 again", (launch_sp<9, 5, 1, 2, 2, false, 0, 6>(A, K, Bp, bias, y, M, N, K, 1, dc0)));
   // ---------------------------------------------------------------- TN: weight gradient dW = gate(G)^T drop(X)
   {

@@ -264,9 +264,149 @@ __device__ __forceinline__ void nt_accumulate(const NtArgs& p, const DropCfg& dc
 
 }
 
-template <int RB, int CB, int WM, int WN, int WK, bool DROP, class Epi, int TUNE = 0, int NR = RB>
+// nt_accumulate for a workgroup whose NW waves work on the SAME rows of A (different column blocks, the whole contraction each):
+// instead of every wave loading and splitting all RB row blocks, wave w loads and splits the row blocks w, w + NW, ... of the
+// NEXT chunk under this chunk's MFMAs and writes their planes into LDS (2 buffers x RB x 3 KiB); all waves read every row
+// block's planes back, one row block ahead of its MFMAs.  One workgroup barrier per chunk, in front of the last row block.
+// `lds`: 2 * RB * 3 * 1024 bytes.  Chunks [c_lo, c_hi), an even count.
+// DROP: A masked by the p = 0.5 dropout of element (m, k) before it is split, as in nt_accumulate.  All waves that meet at the
+// barrier must run the same number of chunks.
+template <int RB, int CB, int NW, bool DROP, int TUNE>
+__device__ __forceinline__ void nt_accumulate_shared(const NtArgs& p, const DropCfg& dc, size_t a_bytes, int m0, int n0, int c_lo,
+                                                     int c_hi, int wave, char* lds_bytes, f32x4 (&acc)[RB][CB]) {
+  constexpr int MINE = (RB + NW - 1) / NW;     // row blocks a wave produces at most
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int chunks = p.K / kChunk;
+  u32x4* const lds = reinterpret_cast<u32x4*>(lds_bytes);   // [buffer][row block][plane][lane]
+  uint32_t offA[MINE], offB[CB], wordA[MINE];
+#pragma unroll
+  for (int k = 0; k < MINE; ++k) {
+    const int i = min(wave + NW * k, RB - 1);
+    const int row = min(m0 + 16 * i + r, p.M - 1);
+    offA[k] = ((uint32_t)row * (uint32_t)p.lda + 4u * g) * 4u;
+    wordA[k] = ((uint32_t)row * (uint32_t)p.K) >> 5;
+  }
+  const uint32_t key = DROP ? drop_key(dc) : 0u;
+#pragma unroll
+  for (int j = 0; j < CB; ++j) {
+    const int blk = min((n0 >> 4) + j, (p.N + 15) / 16 - 1);
+    offB[j] = (uint32_t)blk * (uint32_t)chunks * (uint32_t)kPackedChunkBytes + 16u * lane;
+  }
+  const rsrc_t Ab = make_rsrc(p.A, a_bytes);
+  const rsrc_t Bb = make_rsrc(p.Bp, packed_bytes(p.N, p.K));
+  struct ARaw {
+    f32x4 lo, hi;
+  };
+  ARaw raw0[MINE], raw1[MINE];
+  Planes b0[CB], b1[CB], xp[2];
+  auto loadA = [&](ARaw(&raw)[MINE], int c) {
+    const uint32_t so = (uint32_t)min(c, c_hi - 1) * 128u;
+#pragma unroll
+    for (int k = 0; k < MINE; ++k) {
+      raw[k].lo = ldg16(Ab, offA[k], so);
+      raw[k].hi = ldg16(Ab, offA[k] + 64u, so);
+    }
+  };
+  auto loadB1 = [&](Planes(&b)[CB], int idx, int c) {
+    b[idx / 3].p[idx % 3] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+        Bb, (int)(offB[idx / 3] + 1024u * (idx % 3)), (int)((uint32_t)min(c, c_hi - 1) * (uint32_t)kPackedChunkBytes), 0));
+  };
+  auto produce = [&](const ARaw& a, int k, int buf, int c) {     // row block wave + NW k of chunk c (uniform guard)
+    if (wave + NW * k < RB) {
+      Planes pl;
+      ARaw m = a;
+      if constexpr (DROP) {
+        const uint32_t w = mask_word32(wordA[k] + (uint32_t)min(c, c_hi - 1), key);
+        rt::keep4_bits(m.lo, w >> (4u * g));
+        rt::keep4_bits(m.hi, w >> (4u * g + 16u));
+      }
+      split8<false>(m.lo, m.hi, pl);
+      u32x4* dst = lds + ((size_t)(buf * RB + wave + NW * k) * 3) * 64 + lane;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) dst[64 * q] = pl.p[q];
+    }
+  };
+  auto fetch = [&](Planes& o, int i, int buf) {
+    const u32x4* src = lds + ((size_t)(buf * RB + i) * 3) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) o.p[q] = src[64 * q];
+  };
+  auto mfma_row = [&](const Planes& a, const Planes(&b)[CB], int i) {
+    constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int j = 0; j < CB; ++j) acc[i][j] = mfma_bf16(a.p[PA[q]], b[j].p[PB[q]], acc[i][j]);
+  };
+  // parity P: the planes of chunk c are in LDS buffer P, row block 0's in xp[RB P & 1]...: row blocks are numbered n = P RB + i
+  // over a pair of chunks so that the plane sets alternate across the chunk boundary (RB odd)
+  auto chunk = [&](Planes(&b)[CB], Planes(&bn)[CB], ARaw(&rn)[MINE], ARaw(&rf)[MINE], int c, auto parity) {
+    constexpr int P = decltype(parity)::value;
+    constexpr int LB = (3 * CB + RB - 2) / (RB - 1);   // B plane loads per row block (none in the last)
+    int bidx = 0, pk = 0;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int n = P * RB + i;
+      if (i == RB - 1) __syncthreads();     // chunk c + 1's planes are all in buffer P ^ 1
+      if (i + 1 < RB) fetch(xp[(n + 1) & 1], i + 1, P);
+      else fetch(xp[(n + 1) & 1], 0, P ^ 1);
+      if (i == 0) loadA(rf, c + 2);
+      // this wave's row blocks of chunk c + 1: one per region, from region 1 on
+      if (i >= 1 && pk < MINE && i < RB - 1) {
+        produce(rn[pk], pk, P ^ 1, c + 1);
+        ++pk;
+      }
+      int nl = 0;
+      if (i < RB - 1) {
+#pragma unroll
+        for (int k = 0; k < LB; ++k)
+          if (bidx < 3 * CB) {
+            loadB1(bn, bidx, c + 1);
+            ++bidx;
+            ++nl;
+          }
+      }
+      mfma_row(xp[n & 1], b, i);
+      constexpr int NM = 6 * CB;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // MFMA
+        if (m < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                        // DS read
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                   // VALU
+        if (m >= 4 && m < 4 + 2 * (2 * MINE + LB) && (m & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+        if (m >= NM - 6 && (m & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  static_assert(MINE <= RB - 2, "a wave's row blocks are produced in the regions 1 .. RB - 2");
+  if (c_lo < c_hi) {
+#pragma unroll
+    for (int idx = 0; idx < 3 * CB; ++idx) loadB1(b0, idx, c_lo);
+    loadA(raw0, c_lo);
+    loadA(raw1, c_lo + 1);
+#pragma unroll
+    for (int k = 0; k < MINE; ++k) produce(raw0[k], k, 0, c_lo);
+    __syncthreads();
+    fetch(xp[0], 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c = c_lo; c < c_hi; c += 2) {
+      chunk(b0, b1, raw1, raw0, c, std::integral_constant<int, 0>{});
+      chunk(b1, b0, raw0, raw1, c + 1, std::integral_constant<int, 1>{});
+    }
+  }
+}
+
+// SHARE_A (WM == 1): the WN waves of a K range work on the same rows of A and share its split through LDS (nt_accumulate_shared);
+// needs the K ranges of the WK groups to be equally long (the host checks K % (64 WK) == 0).  Dynamic LDS: nt_lds_bytes().
+template <int RB, int WN, int WK, bool SHARE_A>
+constexpr size_t nt_lds_bytes(size_t reduction_bytes) {
+  return SHARE_A ? (reduction_bytes > (size_t)WK * 2 * RB * 3 * 1024 ? reduction_bytes : (size_t)WK * 2 * RB * 3 * 1024) : reduction_bytes;
+}
+template <int RB, int CB, int WM, int WN, int WK, bool DROP, class Epi, int TUNE = 0, int NR = RB, bool SHARE_A = false>
 __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg dc, Epi epi) {
   using S = rt::NtShape<RB, CB, WM, WN, WK>;
+  static_assert(!SHARE_A || WM == 1, "SHARE_A: the waves of a K range share their rows");
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wk = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
@@ -288,7 +428,14 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg 
   const int per = ((chunks + WK - 1) / WK + 1) & ~1;   // per wave: an even number of chunks
   const int c_lo = min(chunks, wk * per), c_hi = min(chunks, c_lo + per);
 
-  nt_accumulate<RB, CB, DROP, TUNE, NR>(p, dc, ((size_t)(p.M - 1) * p.lda + p.K) * 4, m0, n0, c_lo, c_hi, acc);
+  if constexpr (SHARE_A) {
+    extern __shared__ __attribute__((aligned(16))) char sp_smem[];
+    nt_accumulate_shared<RB, CB, WN, DROP, TUNE>(p, dc, ((size_t)(p.M - 1) * p.lda + p.K) * 4, m0, n0, c_lo, c_hi, wn,
+                                                 sp_smem + (size_t)wk * 2 * RB * 3 * 1024, acc);
+    __syncthreads();   // the K-split reduction below reuses the plane buffers
+  } else {
+    nt_accumulate<RB, CB, DROP, TUNE, NR>(p, dc, ((size_t)(p.M - 1) * p.lda + p.K) * 4, m0, n0, c_lo, c_hi, acc);
+  }
 
   auto finish = [&](int blk, f32x4 v) {
     const int i = blk / CB, j = blk % CB;
@@ -391,22 +538,25 @@ __global__ __launch_bounds__(256) void pack_tn_kernel(const float* __restrict__ 
   for (int cc = lo; cc < hi; ++cc) {
     const int c = slab * cps + cc;
     const int m0 = c * kChunk;
-    // 32 rows x N1 floats, float2 per thread and step
-    for (int idx = threadIdx.x; idx < 32 * pairs; idx += 256) {
-      const int row = idx / pairs, cp = idx % pairs;
+    // 32 rows x N1 floats: wave w takes the rows w, w + 4, ..., its lanes the float2 pairs of a row (no index division; a row
+    // is one contiguous run of N1 / 2 eight-byte loads)
+#pragma unroll 2
+    for (int row = wave; row < 32; row += 4) {
       const int m = m0 + row;
-      float2 v = make_float2(0.f, 0.f);
-      if (m < M) {
-        v = *reinterpret_cast<const float2*>(gy + (size_t)m * ld + 2 * cp);
-        if constexpr (GATE) {
-          const float2 yy = *reinterpret_cast<const float2*>(y + (size_t)m * ld + 2 * cp);
-          v.x = yy.x > 0.f ? v.x : 0.f;
-          v.y = yy.y > 0.f ? v.y : 0.f;
+      for (int cp = lane; cp < pairs; cp += 64) {
+        float2 v = make_float2(0.f, 0.f);
+        if (m < M) {
+          v = *reinterpret_cast<const float2*>(gy + (size_t)m * ld + 2 * cp);
+          if constexpr (GATE) {
+            const float2 yy = *reinterpret_cast<const float2*>(y + (size_t)m * ld + 2 * cp);
+            v.x = yy.x > 0.f ? v.x : 0.f;
+            v.y = yy.y > 0.f ? v.y : 0.f;
+          }
+          if constexpr (WRITE_GZ) *reinterpret_cast<float2*>(gz + (size_t)m * ld + 2 * cp) = v;
         }
-        if constexpr (WRITE_GZ) *reinterpret_cast<float2*>(gz + (size_t)m * ld + 2 * cp) = v;
+        pk_tile[row * pitch + 2 * cp] = v.x;
+        pk_tile[row * pitch + 2 * cp + 1] = v.y;
       }
-      pk_tile[row * pitch + 2 * cp] = v.x;
-      pk_tile[row * pitch + 2 * cp + 1] = v.y;
     }
     __syncthreads();
 #pragma unroll
@@ -660,7 +810,6 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_shared_kernel(TnArgs p, D
     const uint32_t so = (uint32_t)min(c, c_hi - 1) * chunk_stride_x;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
       raw[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(Xb, (int)offX[j], (int)so, 0));
     }
   };

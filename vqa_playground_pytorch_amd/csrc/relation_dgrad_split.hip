@@ -55,6 +55,8 @@ __global__ __launch_bounds__(256) void pack_wt_kernel(const float* __restrict__ 
   for (int q = 0; q < 3; ++q) dst[64 * q] = sp::u32x4{pw[q][0], pw[q][1], pw[q][2], pw[q][3]};
 }
 
+constexpr int kSharedLds = 2 * kRB * 3 * 1024;
+template <bool SHARED>
 __global__ __launch_bounds__(sp::kThreads, 1) void relation_dgrad_split_kernel(RelSplitArgs p, DropCfg dc) {
   using rt::f32x4;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(sp::kThreads, 1) void relation_dgrad_split_kernel(R
   const int tile = xcd_remap(blockIdx.x, gridDim.x);   // the column tiles of a row tile are neighbours: gz rows come from L2
   const int m0 = (tile / p.tiles_n) * kBM;
   const int n0 = (tile % p.tiles_n) * 256 + 64 * wave;
-  if (n0 >= p.D) return;                     // (no barrier in this kernel)
+  if (!SHARED && n0 >= p.D) return;          // (SHARED: D % 256 == 0 is required, every wave takes part in the barriers)
   const int M = p.M, D = p.D;
 
   f32x4 acc[kRB][4];   // [row block][column class e]: rows 16 i + 4 g + t (register t), column n0 + 4 r + e
@@ -72,7 +74,13 @@ __global__ __launch_bounds__(sp::kThreads, 1) void relation_dgrad_split_kernel(R
     for (int e = 0; e < 4; ++e) acc[i][e] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
     const sp::NtArgs a{p.gz, p.wp, p.L, M, D, p.Kp, p.tiles_n};
-    sp::nt_accumulate<kRB, 4, false, 0, 3>(a, dc, (size_t)M * p.L * 4, m0, n0, 0, p.Kp / sp::kChunk, acc);
+    if constexpr (SHARED) {
+      // the four waves work on the same rows of gz: its split is shared through LDS (every wave splits a quarter of the row blocks)
+      extern __shared__ __attribute__((aligned(16))) char rd_smem[];
+      sp::nt_accumulate_shared<kRB, 4, 4, false, 0>(a, dc, (size_t)M * p.L * 4, m0, n0, 0, p.Kp / sp::kChunk, wave, rd_smem, acc);
+    } else {
+      sp::nt_accumulate<kRB, 4, false, 0, 3>(a, dc, (size_t)M * p.L * 4, m0, n0, 0, p.Kp / sp::kChunk, acc);
+    }
   }
 
   // ---- epilogue (relation_dgrad.hip's): mask, multiply by v, add the rows of each sample up ----
@@ -208,6 +216,10 @@ extern "C" int vqa_relation_projection_dgrad_split(const float* gz, const float*
   a.tiles_n = (D + 255) / 256;
   const int tiles_m = (a.M + kBM - 1) / kBM;
   const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
-  VQA_LAUNCH(relation_dgrad_split_kernel, dim3((unsigned)(tiles_m * a.tiles_n)), dim3(sp::kThreads), 0, s, a, dc);
+  // D % 256 == 0: gz's split shared by the workgroup's four waves through LDS (VQA_SPLIT_DGRAD_SHARED=0: every wave splits all of it)
+  if (D % 256 == 0 && !vqa::option_is("VQA_SPLIT_DGRAD_SHARED", '0'))
+    VQA_LAUNCH(relation_dgrad_split_kernel<true>, dim3((unsigned)(tiles_m * a.tiles_n)), dim3(sp::kThreads), kSharedLds, s, a, dc);
+  else
+    VQA_LAUNCH(relation_dgrad_split_kernel<false>, dim3((unsigned)(tiles_m * a.tiles_n)), dim3(sp::kThreads), 0, s, a, dc);
   return check_launch("relation_projection_dgrad_split");
 }
