@@ -871,12 +871,15 @@ class ObjectDifferenceAttention(torch.autograd.Function):
         return d_vl, d_ql, d_w, d_bias, None, None, None
 
 
-def split_products(M, K, N, ldx, p_drop, weight_gradient=False):
+def split_products(M, K, N, ldx, p_drop, weight_gradient=False, tensors=()):
     """True when this tall projection runs on the split engine (csrc/gemm_f32_split.hpp: fp32 products from exact three-way
-    bf16 splits on the bf16 matrix pipe, fp32 accumulation) -- opt-in by VQA_F32_PRODUCTS=split, default the fp32 MFMA engine."""
+    bf16 splits on the bf16 matrix pipe, fp32 accumulation) -- opt-in by VQA_F32_PRODUCTS=split, default the fp32 MFMA engine.
+    `tensors`: the operands the engine reads with 16-byte loads (a view at an odd offset stays on the fp32 MFMA engine)."""
     if os.environ.get("VQA_F32_PRODUCTS", "mfma") != "split":
         return False
     if weight_gradient and K % 128 != 0:
+        return False
+    if any(t is not None and t.data_ptr() % 16 != 0 for t in tensors):
         return False
     return _lib.lib().vqa_linear_split_supported(M, K, N, ldx, float(p_drop)) == 1
 
@@ -885,7 +888,7 @@ def _linear_fwd(x, w, bias, y, M, K, N, act, p_drop, seed):
     """y = act(dropout(x) W^T + b), on the engine split_products() selects."""
     L_ = _lib.lib()
     sv, sp = _seed_args(seed)
-    if split_products(M, K, N, K, p_drop):
+    if split_products(M, K, N, K, p_drop, tensors=(x, w)):
         ws_bytes = L_.vqa_linear_act_fwd_split_workspace_bytes(K, N)
         ws = torch.empty((ws_bytes + 3) // 4, device=x.device, dtype=torch.float32)
         _launch("linear_act_fwd_split", (M, K, N, float(p_drop) > 0), L_.vqa_linear_act_fwd_split, _p(x), K, _p(w), _p(bias),
@@ -900,7 +903,7 @@ def _linear_dw(x, w, y, gy, d_w, d_b, M, K, N, act, p_drop, seed, gz_out=None):
     act = relu only): receives gy * (y > 0), which the pass that packs the gradient for the GEMM has in hand."""
     L_ = _lib.lib()
     sv, sp = _seed_args(seed)
-    if split_products(M, K, N, K, p_drop, weight_gradient=True):
+    if split_products(M, K, N, K, p_drop, weight_gradient=True, tensors=(x, d_w)):
         ws_bytes = L_.vqa_linear_act_dw_split_workspace_bytes(M, K, N)
         ws = torch.empty((ws_bytes + 3) // 4, device=x.device, dtype=torch.float32)
         _launch("linear_act_dw_split", (M, K, N, p_drop > 0, act), L_.vqa_linear_act_dw_split, _p(x), K,
@@ -1030,7 +1033,7 @@ class RelationProjection(torch.autograd.Function):
         L_ = _lib.lib()
         d_w = _grad_like(w)
         d_b = _grad_like(ctx.bias) if ctx.bias is not None else None
-        if not pregated and split_products(M, D, L, D, 0.0, weight_gradient=True):
+        if not pregated and split_products(M, D, L, D, 0.0, weight_gradient=True, tensors=(x, d_w)):
             gz = torch.empty_like(gy)                 # the split engine's packing pass gates the gradient and writes it out as well
             _linear_dw(x, w, y, gy, d_w, d_b, M, D, L, 1, 0.0, 0, gz_out=gz)
         else:
