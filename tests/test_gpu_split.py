@@ -118,3 +118,41 @@ def test_split_engine_refuses_what_it_cannot_run(ops):
     rc = L.vqa_linear_act_fwd_split(x.data_ptr(), 2000, x.data_ptr(), None, y.data_ptr(), ws.data_ptr(), ws.numel() * 4, 18432, 2000,
                                     310, 1, 0.0, 0, None, None)
     assert rc != 0
+
+
+@pytest.mark.parametrize("p", [0.0, 0.5])
+def test_split_relation_projection_gradients_at_size(ops, monkeypatch, p):
+    """The fused relation + projection node (K1 -> K5) at B = 512 on both engines against float64: d_t, d_c2 (the data gradient
+    reduced in the GEMM tile, csrc/relation_dgrad{,_split}.hip), d_w, d_b.  Each engine's gradients are compared with the float64
+    closed form gated by ITS OWN forward's relu gates; the split engine's error has to be of the fp32 MFMA engine's size."""
+    B, N, D, L, seed = 512, 36, 2048, 310, 4711
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    v = torch.randn(B, N, D, generator=gen).to(dev())
+    t = torch.randn(B, D, generator=gen).to(dev())
+    c2 = torch.sigmoid(torch.randn(B, D, generator=gen)).to(dev())
+    w = (torch.randn(L, D, generator=gen) / D ** 0.5).to(dev())
+    b = (0.1 * torch.randn(L, generator=gen)).to(dev())
+    gy = (torch.randn(B, N, L, generator=gen) / 64).to(dev())
+    mask = ops.linear_dropout_mask(B * N, D, p, seed, dev()).view(B, N, D).double() if p > 0 else None
+    x64 = t.double()[:, None, :] + c2.double()[:, None, :] * v.double()
+    if mask is not None:
+        x64 = x64 * mask
+    errs = {}
+    for engine in ("mfma", "split"):
+        monkeypatch.setenv("VQA_F32_PRODUCTS", engine)
+        tt, ct, wt, bt = (z.clone().requires_grad_(True) for z in (t, c2, w, b))
+        y = ops.relation_projection(v, tt, ct, wt, bt, p, seed)
+        y.backward(gy)
+        gz = gy.double() * (y.detach() > 0)
+        dx = gz.reshape(B * N, L) @ w.double()
+        dx = dx.view(B, N, D) * (mask if mask is not None else 1.0)
+        ref = {"d_t": dx.sum(1), "d_c2": (dx * v.double()).sum(1), "d_w": gz.reshape(B * N, L).t() @ x64.reshape(B * N, D),
+               "d_b": gz.sum((0, 1))}
+        got = {"d_t": tt.grad, "d_c2": ct.grad, "d_w": wt.grad, "d_b": bt.grad}
+        errs[engine] = {k: err(got[k], ref[k]) for k in ref}
+        print("[%s p=%.1f] " % (engine, p) + "  ".join("%s max %.2e rms %.2e" % (k, *e) for k, e in errs[engine].items()))
+        for k, (mx, rm) in errs[engine].items():
+            assert mx <= 2e-5 and rm <= 2e-6, (engine, k, mx, rm)
+    for k in errs["split"]:
+        assert errs["split"][k][1] <= 2.0 * errs["mfma"][k][1] + 1e-8, (k, errs["split"][k], errs["mfma"][k])
+        assert errs["split"][k][0] <= 2.0 * errs["mfma"][k][0] + 1e-7, (k, errs["split"][k], errs["mfma"][k])
