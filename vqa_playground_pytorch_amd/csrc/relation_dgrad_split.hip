@@ -56,7 +56,9 @@ __global__ __launch_bounds__(256) void pack_wt_kernel(const float* __restrict__ 
 }
 
 constexpr int kSharedLds = 2 * kRB * 3 * 1024;
-template <bool SHARED>
+// TUNE (ablations, VQA_SPLIT_DGRAD_TUNE, tools/dgrad_split_ablate.py; wrong results): 1 = no main loop, 2 = v read as ones (no v
+// loads), 4 = no mask / no multiply / no per-sample sums (the accumulators are added up and stored)
+template <bool SHARED, int TUNE = 0>
 __global__ __launch_bounds__(sp::kThreads, 1) void relation_dgrad_split_kernel(RelSplitArgs p, DropCfg dc) {
   using rt::f32x4;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
@@ -74,7 +76,9 @@ __global__ __launch_bounds__(sp::kThreads, 1) void relation_dgrad_split_kernel(R
     for (int e = 0; e < 4; ++e) acc[i][e] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
     const sp::NtArgs a{p.gz, p.wp, p.L, M, D, p.Kp, p.tiles_n};
-    if constexpr (SHARED) {
+    if constexpr ((TUNE & 1) != 0) {
+      acc[0][0] = f32x4{(float)m0, (float)n0, 1.f, 2.f};
+    } else if constexpr (SHARED) {
       // the four waves work on the same rows of gz: its split is shared through LDS (every wave splits a quarter of the row blocks)
       extern __shared__ __attribute__((aligned(16))) char rd_smem[];
       sp::nt_accumulate_shared<kRB, 4, 4, false, 0>(a, dc, (size_t)M * p.L * 4, m0, n0, 0, p.Kp / sp::kChunk, wave, rd_smem, acc);
@@ -85,7 +89,17 @@ __global__ __launch_bounds__(sp::kThreads, 1) void relation_dgrad_split_kernel(R
 
   // ---- epilogue (relation_dgrad.hip's): mask, multiply by v, add the rows of each sample up ----
   const rt::rsrc_t Vb = rt::make_rsrc(p.v, (size_t)M * D * 4);
+  if constexpr ((TUNE & 4) != 0) {
+    f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < kRB; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum += acc[i][e];
+    if (g == 0) *reinterpret_cast<f32x4*>(p.d_t + (size_t)(m0 / kRegions) * D + n0 + 4 * r) = sum;
+    return;
+  }
   auto vt = [&](int i, int t) -> f32x4 {
+    if constexpr ((TUNE & 2) != 0) return f32x4{1.f, 1.f, 1.f, 1.f};
     const int row = min(m0 + 16 * i + 4 * g + t, M - 1);
     return rt::ldg16(Vb, (uint32_t)(n0 + 4 * r) * 4u + (uint32_t)row * (uint32_t)D * 4u, 0u);
   };
@@ -217,7 +231,13 @@ extern "C" int vqa_relation_projection_dgrad_split(const float* gz, const float*
   const int tiles_m = (a.M + kBM - 1) / kBM;
   const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
   // D % 256 == 0: gz's split shared by the workgroup's four waves through LDS (VQA_SPLIT_DGRAD_SHARED=0: every wave splits all of it)
-  if (D % 256 == 0 && !vqa::option_is("VQA_SPLIT_DGRAD_SHARED", '0'))
+  const int tune = vqa::option("VQA_SPLIT_DGRAD_TUNE") ? std::atoi(vqa::option("VQA_SPLIT_DGRAD_TUNE")) : 0;
+  const dim3 grid_((unsigned)(tiles_m * a.tiles_n));
+  if (tune == 1 && D % 256 == 0) VQA_LAUNCH((relation_dgrad_split_kernel<true, 1>), grid_, dim3(sp::kThreads), kSharedLds, s, a, dc);
+  else if (tune == 2 && D % 256 == 0) VQA_LAUNCH((relation_dgrad_split_kernel<true, 2>), grid_, dim3(sp::kThreads), kSharedLds, s, a, dc);
+  else if (tune == 4 && D % 256 == 0) VQA_LAUNCH((relation_dgrad_split_kernel<true, 4>), grid_, dim3(sp::kThreads), kSharedLds, s, a, dc);
+  else if (tune == 5 && D % 256 == 0) VQA_LAUNCH((relation_dgrad_split_kernel<true, 5>), grid_, dim3(sp::kThreads), kSharedLds, s, a, dc);
+  else if (D % 256 == 0 && !vqa::option_is("VQA_SPLIT_DGRAD_SHARED", '0'))
     VQA_LAUNCH(relation_dgrad_split_kernel<true>, dim3((unsigned)(tiles_m * a.tiles_n)), dim3(sp::kThreads), kSharedLds, s, a, dc);
   else
     VQA_LAUNCH(relation_dgrad_split_kernel<false>, dim3((unsigned)(tiles_m * a.tiles_n)), dim3(sp::kThreads), 0, s, a, dc);
