@@ -257,3 +257,30 @@ def test_head_mode_selects_the_grouped_phases_per_model(monkeypatch):
         assert head.glimpses_grouped() is glimpses
     monkeypatch.setattr(head, "MODE", "grouped")
     assert head.supported("cor2", 2400, 311) is False
+
+
+def test_split_engine_is_opt_in_and_refuses_what_it_cannot_run(monkeypatch):
+    """ops.split_products: off unless VQA_F32_PRODUCTS=split; with it, only the shapes the split engine runs (queried from the
+    library, no GPU needed), the weight gradient only with K % 128 == 0, and never an operand at an offset that is not 16-byte
+    aligned -- everything else stays on the fp32 MFMA engine.  The workspace queries need no GPU either."""
+    L_ = _lib.lib()
+    monkeypatch.delenv("VQA_F32_PRODUCTS", raising=False)
+    assert not ops.split_products(18432, 2048, 310, 2048, 0.5)
+    monkeypatch.setenv("VQA_F32_PRODUCTS", "mfma")
+    assert not ops.split_products(18432, 2048, 310, 2048, 0.5)
+    monkeypatch.setenv("VQA_F32_PRODUCTS", "split")
+    assert ops.split_products(18432, 2048, 310, 2048, 0.5) and ops.split_products(18432, 2048, 310, 2048, 0.0)
+    assert not ops.split_products(18432, 2048, 310, 2048, 0.3)            # one-bit masks only
+    assert not ops.split_products(144, 2048, 310, 2048, 0.0)              # short matrices stay on the LDS-tile engine
+    assert not ops.split_products(18432, 2000, 310, 2000, 0.0)            # K % 64
+    assert ops.split_products(18432, 192, 310, 192, 0.0) and not ops.split_products(18432, 192, 310, 192, 0.0, weight_gradient=True)
+    buf = torch.zeros(64)
+    aligned = buf[(-buf.data_ptr() // 4) % 4:]
+    assert aligned.data_ptr() % 16 == 0
+    assert ops.split_products(18432, 2048, 310, 2048, 0.0, tensors=(aligned, None))
+    assert not ops.split_products(18432, 2048, 310, 2048, 0.0, tensors=(aligned[1:],))
+    assert L_.vqa_linear_act_fwd_split_workspace_bytes(2048, 310) >= 20 * 64 * 3072
+    assert L_.vqa_linear_act_dw_split_workspace_bytes(18432, 2048, 310) >= 16 * 310 * 2048 * 4
+    assert L_.vqa_relation_projection_dgrad_split_supported(512, 36, 2048, 310) == 1
+    assert L_.vqa_relation_projection_dgrad_split_supported(512, 35, 2048, 310) == 0
+    assert L_.vqa_relation_projection_dgrad_split_workspace_bytes(2048, 310) >= 128 * 10 * 3072
