@@ -5,10 +5,10 @@ import ctypes, os, sys, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-def run(tune, shared):
+def run(tune, shared, L=310):
     from vqa_playground_pytorch_amd import _lib
     L_ = _lib.lib()
-    B, N, D, L = 512, 36, 2048, 310
+    B, N, D = 512, 36, 2048
     dev = torch.device("cuda:0")
     gz = torch.randn(B * N, L, device=dev) / 64
     w = torch.randn(L, D, device=dev) / 45
@@ -30,12 +30,15 @@ def run(tune, shared):
         for _ in range(30): call(p)
         e1.record(); torch.cuda.synchronize()
         out.append(e0.elapsed_time(e1) / 30 * 1e3)
-    print("tune %s shared %s: %.1f us (no mask)  %.1f us (p = 0.5)   [incl. the 5 us W^T pack launch]" % (tune, shared, out[0], out[1]))
+    print("L %d tune %s shared %s: %.1f us (no mask)  %.1f us (p = 0.5)   [incl. the 5 us W^T pack launch]" % (L, tune, shared, out[0], out[1]))
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
-        run(sys.argv[1], sys.argv[2])
+        run(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 310)
     else:
         for tune, shared in (("0", "1"), ("0", "0"), ("2", "1"), ("4", "1"), ("1", "1"), ("5", "1")):
             env = dict(os.environ, VQA_SPLIT_DGRAD_TUNE=tune, VQA_SPLIT_DGRAD_SHARED=shared)
             subprocess.run([sys.executable, os.path.abspath(__file__), tune, shared], env=env, check=True)
+        # rows of 320 floats (64-byte aligned) instead of 310 (8-byte aligned): the same ten chunks
+        for L in (320, 310, 320):
+            subprocess.run([sys.executable, os.path.abspath(__file__), "0", "1", str(L)], env=dict(os.environ, VQA_SPLIT_DGRAD_TUNE="0"), check=True)
