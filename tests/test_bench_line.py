@@ -20,7 +20,7 @@ def _canned(world=1):
                                "launches": 8, "key": "vqa::rt::gemm_nt_kernel<9, 5, 1, 2, 2, true, vqa::EpiBiasAct, 0>|grid=65536"},
              "device_kernels": [["(rt::gemm_nt_kernel<9, 5, 1, 2, 2, true, EpiBiasAct>)", 65536]]}
     sub = {"metric": "m" * 90, "value": 462553.0, "unit": "samples/s", "ms_per_step": 1.107, "dtype": "f32", "steps": 20,
-           "warmup": 5, "roofline": dict(entry, shapes=[[1] * 6] * 3), "step_coverage": {"timed_ops_ms": 1.0},
+           "warmup": 5, "roofline": dict(entry, kernel="lowrank_bilinear_fusion_bwd_bf16", shapes=[[1] * 6] * 3), "step_coverage": {"timed_ops_ms": 1.0},
            "workload": "w" * 200, "launch": "hipGraph replay (2 graphs + eager all-reduce)", "command": "bench.py --model oda",
            "wall_s": 9.1}
     full = {
@@ -31,25 +31,31 @@ def _canned(world=1):
                                "answers (BASELINE configs[1]; configs[3] at 8 GPUs)", "global_batch": 512 * world,
                    "step": "s" * 120, "parallelism": "dp%d" % world, "launch": "hipGraph replay (2 graphs + eager all-reduce)",
                    "relation_mode": "factored", "library_gemms": "x" * 300,
-                   "inputs": "1 resident batch re-read every step; over 4 rotating batches (+1 device copy/step): -1.7%, see "
-                             "rotating_inputs", "inputs_note": "n" * 400},
+                   "f32_products": "3xbf16 split, 6 partial products, fp32 accumulate",
+                   "inputs": "4 rotating resident batches (+1 device copy/step); 1 resident batch: 254000.1 (+2.1%)",
+                   "inputs_note": "n" * 400},
         "final_loss": 970.1, "final_grad_norm": 3.2,
         "roofline": dict(entry, shapes=[[18432, 2048, 310, True], [18432, 2048, 310, False]],
                          device_kernels=["vqa::rt::gemm_nt_kernel<9, 5, 1, 2, 2"]),
         "traffic_source": "t" * 200, "step_coverage": {"timed_ops_ms": 2.6, "of_ms_per_step": 1.09},
         "roofline_all": [dict(entry, kernel="op%d" % i) for i in range(70)],
-        "rotating_inputs": {"batches": 4, "value": 211096.7, "unit": "samples/s", "ms_per_step": 2.425, "note": "n" * 100},
+        "resident_inputs": {"batches": 1, "value": 254000.1, "unit": "samples/s", "ms_per_step": 2.016, "note": "n" * 100},
         "sub_records": {tag: dict(sub) for tag, _ in bench.SUB_RECORDS},
         "cpu_baseline": {"value": 49.13, "unit": "samples/s", "cores": 16, "kind": "port", "host_cores": 256,
                          "sample": "CoR2 fwd+bwd (KLD-sum loss, dropout on), batch 16 x 31 steps after 1 warm-up; "
                                    "reference-faithful torch-CPU port; 16 threads of 256 host cores",
-                         "all_runs": [{"cores": 16, "value": 49.13, "sample": "s" * 200}] * 2},
+                         "sweep": {"16": 49.13, "32": 41.0, "64": 30.2},
+                         "all_runs": [{"cores": 16, "value": 49.13, "sample": "s" * 200}] * 3},
     }
-    if world > 1:
+    if world > 1:       # (a multi-GPU run carries no sub-records and no CPU baseline: bench.py attaches those at N = 1 only)
+        del full["sub_records"]
         full["distributed"] = {"nranks": world, "backend": "nccl", "allreduce_payload_bytes": 47760976,
                                "allreduce_ms_alone": 0.412, "allreduce_busbw_GBs": 202.9, "per_rank_samples_per_s": 200000.0,
-                               "overlap": False}
-    full["sub_records"]["oda_b512"] = {"error": "rc=1 " + "e" * 300}
+                               "overlap": False,
+                               "schedules": {"single": {"value": 1600000.0, "ms_per_step": 2.56},
+                                             "overlap": {"value": 1500000.0, "ms_per_step": 2.73}}}
+    if world == 1:
+        full["sub_records"]["oda_b512"] = {"error": "rc=1 " + "e" * 300}
     return full
 
 
@@ -69,11 +75,16 @@ def test_compact_line_is_small_and_complete(tmp_path, capsys):
                     "mfma_busy_pct")) <= set(line["roofline"])
         assert set(("value", "unit", "cores", "kind", "sample", "host_cores")) <= set(line["cpu_baseline"])
         assert line["config"]["workload"].startswith("CoR2 fwd+bwd fp32") and "relation_mode" in line["config"]
-        assert line["rotating_inputs"] == {"value": 211096.7, "ms_per_step": 2.425, "batches": 4}
-        assert set(line["sub_records"]) == {tag for tag, _ in bench.SUB_RECORDS}
-        assert set(line["sub_records"]["cor2_bf16_n100_b128"]) == {"value", "ms_per_step", "dtype", "kernel", "frac"}
-        assert "error" in line["sub_records"]["oda_b512"]
+        assert line["resident_inputs"] == {"value": 254000.1, "ms_per_step": 2.016, "batches": 1}
+        assert line["config"]["f32_products"].startswith("3xbf16 split") and line["cpu_baseline"]["sweep"]["32"] == 41.0
+        if world == 1:
+            assert set(line["sub_records"]) == {tag for tag, _ in bench.SUB_RECORDS}
+            assert set(line["sub_records"]["cor2_bf16_n100_b128"]) == {"value", "ms_per_step", "kernel", "frac"}
+            assert "error" in line["sub_records"]["oda_b512"]
+            assert len(lines[0]) < bench.COMPACT_LIMIT - 60          # headroom for longer numbers and kernel names
         assert ("distributed" in line) == (world > 1)
+        if world > 1:
+            assert set(line["distributed"]["schedules"]) == {"single", "overlap"}
         # the full record went to the detail file and to stderr
         detail = json.load(open(tmp_path / "bench_detail.json"))
         assert len(detail["roofline_all"]) == 70 and detail["detail_file"] == "bench_detail.json"

@@ -58,3 +58,32 @@ def test_two_ranks_match_one_process(model, backend):
             # (a sum over a few thousand weights after 7 Adam steps: the two ranks add their gradient halves in another
             #  order than one process does, and Adam's normalisation amplifies rounding where a gradient is near zero)
             assert abs(got["weight_digest"] - want["weight_digest"]) <= 1e-4 * abs(want["weight_digest"]) + 1e-5, tag
+
+
+def test_bench_two_rank_rehearsal_prints_a_valid_record(tmp_path):
+    """`bench.py --gpus 2` as the driver's scaling run starts it, rehearsed on ONE GPU: VQA_ONE_GPU_REHEARSAL=1 lets both ranks
+    share cuda:0, gloo carries the collectives.  The first 8-GPU run must produce a valid record without a second try
+    (VERDICT r04 item 6): the compact line parses, stays under 2 KB WITH the `distributed` block, says n_gpus = 2 and a global
+    batch of 2 per-rank batches, and the block holds BOTH reduction schedules (single all-reduce / two-half backward with
+    the first all-reduce under the second half), `value` being the faster one."""
+    detail = tmp_path / "bench_detail.json"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VQA_ONE_GPU_REHEARSAL="1", VQA_DIST_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "3", "--batch", "64",
+           "--detail-file", str(detail)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    assert len(lines[0]) < 2000
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 3 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 128 and line["config"]["parallelism"] == "dp2"
+    assert line["dtype"] == "f32" and line["config"]["f32_products"].startswith("3xbf16 split")
+    d = line["distributed"]
+    assert d["nranks"] == 2 and d["backend"] == "gloo" and d["allreduce_payload_bytes"] >= 4 * 11940244
+    assert set(d["schedules"]) == {"single", "overlap"}
+    rates = [s["value"] for s in d["schedules"].values()]
+    assert all(v > 0 for v in rates) and abs(line["value"] - max(rates)) <= 1e-6 * max(rates)
+    assert "roofline" in line and line["roofline"]["frac"] is not None and 0 < line["roofline"]["frac"] < 1
+    assert "cpu_baseline" not in line and "sub_records" not in line          # N = 1 only
+    full = json.load(open(detail))
+    assert full["distributed"]["schedules"].keys() == d["schedules"].keys() and len(full["roofline_all"]) > 10

@@ -623,8 +623,11 @@ def test_linear_act_3d_no_bias_no_dx(ops):
     close("d_w", wt.grad, dw)
 
 
-def test_linear_act_full_size_vs_fp64(ops):
-    """compress_v at B=512: [18432,2048] x [2048,310] against an fp64 matmul on the GPU."""
+@pytest.mark.parametrize("engine", ["split", "mfma"])
+def test_linear_act_full_size_vs_fp64(ops, engine, monkeypatch):
+    """compress_v at B=512: [18432,2048] x [2048,310] against an fp64 matmul on the GPU, on both fp32 engines (split = the default:
+    csrc/gemm_f32_split.hpp; mfma = v_mfma_f32_16x16x4_f32, csrc/gemm_f32_rt.hpp)."""
+    monkeypatch.setenv("VQA_F32_PRODUCTS", engine)
     gen = torch.Generator(device="cpu").manual_seed(5)
     x = torch.randn(512 * 36, 2048, generator=gen).to(dev())
     w = (torch.randn(310, 2048, generator=gen) / 2048 ** 0.5).to(dev())
@@ -897,11 +900,10 @@ def test_relation_projection_fused_backward(ops, B, D, L, p, form, lib_option, m
     linear_act, and d_t / d_c2 / dW / db equal the gradients of that composition (fp64 closed form of the data gradient:
     the masked grad_x summed over the 36 regions) -- without the [B,36,D] data gradient ever being written.  Both forms of
     the data-gradient kernel (csrc/relation_dgrad.hip: the default, and VQA_RELDG_TUNE=0), and the one on the split engine
-    (csrc/relation_dgrad_split.hip, VQA_F32_PRODUCTS=split; the projection itself then runs there too where its shape allows)."""
+    (csrc/relation_dgrad_split.hip, VQA_F32_PRODUCTS=split, the default; the projection itself then runs there too where its shape allows)."""
     if form == "one workgroup per CU":
         lib_option("VQA_RELDG_TUNE", 0)
-    if form == "split engine":
-        monkeypatch.setenv("VQA_F32_PRODUCTS", "split")
+    monkeypatch.setenv("VQA_F32_PRODUCTS", "split" if form == "split engine" else "mfma")
     N = 36
     v = seeded.seeded_array((B, N, D), 411)
     t = seeded.seeded_array((B, D), 412)

@@ -155,7 +155,7 @@ RTOL_EDGE_MAX = 1e-1   # ... and its max-abs error on the tensor's own scale: a 
 #                        for a single sample, 3.9e-2 over ODA's 149 knife-edge samples of this batch)
 VARIANTS = [("cor2", 2000, "default"), ("cor2", 2000, "pairwise"), ("cor2", 2000, "k4_engine"), ("cor2", 2000, "legacy_head"),
             ("cor2", 2000, "grouped_head"), ("oda", 3000, "default"), ("oda", 3000, "grouped_head"),
-            ("cor2", 2000, "split_products"), ("oda", 3000, "split_products")]
+            ("cor2", 2000, "fp32_mfma"), ("oda", 3000, "fp32_mfma")]
 _oracle_cache = {}
 
 
@@ -163,12 +163,12 @@ def build_variant(cls, nans, variant, monkeypatch):
     """default = what bench.py times; pairwise = relation_mode 0 (the relation tensor built from every (i,j) term);
     k4_engine = the Mutan fusion in its R-GEMM form on the LDS tile engine (VQA_K4_FORM=engine); legacy_head / grouped_head =
     the [B,.]-sized layers all on library GEMMs + epilogue kernels / all as grouped phases (VQA_HEAD=legacy / grouped; the
-    default, auto, groups CoR2's phases except the glimpse projections and keeps ODA on the library); split_products = the region
-    projections' forward and weight gradient on the split engine (VQA_F32_PRODUCTS=split: fp32 products from three-way bf16
-    splits on the bf16 matrix pipe, csrc/gemm_f32_split.hpp) -- held to the SAME bars as the fp32 MFMA engine."""
+    default, auto, groups CoR2's phases except the glimpse projections and keeps ODA on the library).  Every variant but the last
+    runs the region projections on the split engine (the default since round 5: fp32 products from three-way bf16 splits on the
+    bf16 matrix pipe, csrc/gemm_f32_split.hpp); fp32_mfma = the same on the fp32 MFMA engine (VQA_F32_PRODUCTS=mfma) -- both
+    engines are held to the SAME bars."""
     from vqa_playground_pytorch_amd import head, ops
-    if variant == "split_products":
-        monkeypatch.setenv("VQA_F32_PRODUCTS", "split")
+    monkeypatch.setenv("VQA_F32_PRODUCTS", "mfma" if variant == "fp32_mfma" else "split")
     if variant == "k4_engine":
         monkeypatch.setattr(ops, "_K4_FORM", "engine")
     if variant in ("legacy_head", "grouped_head"):
@@ -287,20 +287,13 @@ def test_baseline_batch_against_oracle(cls, nans, variant, monkeypatch):
     compare_at_512(cls, model, got, a, want, keep, g_keep, g_edge, "%s/%s/eval" % (cls, variant))
 
 
-@pytest.mark.parametrize("cls,nans,variant", VARIANTS)
-def test_training_step_with_shared_masks_against_oracle(cls, nans, variant, monkeypatch):
-    """The configuration the benchmark times -- CoR2 / ODA, 512 x 36 x 2048, TRAINING mode, dropout 0.5 at every site --
-    against the float64 restatement of the reference fed the SAME masks.  Every mask of the HIP path is a pure function of
-    (seed, element index) (`vqa_linear_dropout_mask` writes it for any [M,K] site), so the seeds the forward drew are
-    enough to rebuild them: the restatement's own F.dropout is switched off and each Drop* layer's input is multiplied by the
-    mask of the corresponding site instead.  Checks the wiring the per-kernel masked tests cannot: one seed per site, the
-    site-to-mask layouts (four question projections sharing one draw, the gates' [2,B,310] draw, the pooled glimpses masked
-    inside K3 / inside the relation map, K2's one-bit mask over [B,N,N*L]), backward regenerating the forward's masks.  Knife-edge
-    relu samples are compared separately, as in test_baseline_batch_against_oracle; the variants are the same as there."""
+def forward_recording_masks(model, cls, v, q):
+    """One training-mode forward of the product with every dropout mask it applies rebuilt from the seeds it drew (each mask of
+    the HIP path is a pure function of (seed, element index)): -> logits, {restatement site: mask}, the seeds.  Also asserts the
+    wiring -- one seed per site, the site-to-mask layouts of both head forms."""
     from vqa_playground_pytorch_amd import ops
-    B, N = 512, 36
-    model = build_variant(cls, nans, variant, monkeypatch).train()
-    v, q, a = seeded.seeded_inputs(B, answers=nans, seed=513)
+    B, N = v.shape[0], v.shape[1]
+    assert N == 36
     seeds, rec, orig = [], [], {}
     for name in ("next_dropout_seed", "dropout", "linear_act", "attention_logits", "softmax_attention_pool_drop",
                  "relation_projection", "relation_apply", "object_difference_attention"):
@@ -394,6 +387,23 @@ def test_training_step_with_shared_masks_against_oracle(cls, nans, variant, monk
         for g in range(4):
             masks["att.list_linear_v_fusion.%d" % g] = m[3][:, g]
 
+    return got, masks, seeds
+
+
+@pytest.mark.parametrize("cls,nans,variant", VARIANTS)
+def test_training_step_with_shared_masks_against_oracle(cls, nans, variant, monkeypatch):
+    """The configuration the benchmark times -- CoR2 / ODA, 512 x 36 x 2048, TRAINING mode, dropout 0.5 at every site --
+    against the float64 restatement of the reference fed the SAME masks.  Every mask of the HIP path is a pure function of
+    (seed, element index) (`vqa_linear_dropout_mask` writes it for any [M,K] site), so the seeds the forward drew are
+    enough to rebuild them: the restatement's own F.dropout is switched off and each Drop* layer's input is multiplied by the
+    mask of the corresponding site instead.  Checks the wiring the per-kernel masked tests cannot: one seed per site, the
+    site-to-mask layouts (four question projections sharing one draw, the gates' [2,B,310] draw, the pooled glimpses masked
+    inside K3 / inside the relation map, K2's one-bit mask over [B,N,N*L]), backward regenerating the forward's masks.  Knife-edge
+    relu samples are compared separately, as in test_baseline_batch_against_oracle; the variants are the same as there."""
+    B = 512
+    model = build_variant(cls, nans, variant, monkeypatch).train()
+    v, q, a = seeded.seeded_inputs(B, answers=nans, seed=513)
+    got, masks, seeds = forward_recording_masks(model, cls, v, q)
     want, keep, g_keep, g_edge = oracle_at_512(cls, nans, v, q, a, (cls, "train", tuple(str(x) for x in seeds)), masks)
     compare_at_512(cls, model, got, a, want, keep, g_keep, g_edge, "%s/%s/train" % (cls, variant))
 
@@ -990,8 +1000,10 @@ FLIP_EDGE_F32 = 1e-5       # ... and how far from zero its pre-activation may be
 RTOL_FORCED_F32 = 2e-4     # with the gates equal: every gradient of the loss over all 512 samples (measured: 2.0e-5 CoR2, 5.5e-5 ODA)
 
 
+@pytest.mark.parametrize("engine", ["split", "mfma"])
+@pytest.mark.parametrize("mode", ["eval", "train"])
 @pytest.mark.parametrize("cls,nans", [("cor2", 2000), ("oda", 3000)])
-def test_baseline_batch_with_the_products_gates(cls, nans, monkeypatch):
+def test_baseline_batch_with_the_products_gates(cls, nans, mode, engine, monkeypatch):
     """test_baseline_batch_against_oracle splits off the samples that own a relu unit within float32 rounding of zero (more
     than half of a CoR2 batch) and holds them to a looser bar, because a unit that falls on the other side of zero moves a
     whole row of a gradient.  Here that ONE ingredient is taken out instead: the product's own relu decisions at every relu
@@ -1001,14 +1013,20 @@ def test_baseline_batch_with_the_products_gates(cls, nans, monkeypatch):
     call order).  Asserted: the two sides decide differently at <= FLIP_FRACTION_F32 of a site's units and only where the
     restatement's |pre-activation| <= FLIP_EDGE_F32 rms (a wrong gate in the product would show here); and then logits and
     EVERY parameter gradient of the loss over ALL 512 samples agree at RTOL_FORCED_F32 = 2e-4 -- five times inside north_star's
-    1e-3, no sample set aside."""
+    1e-3, no sample set aside.
+    engine: the region projections on the split engine (the default, what bench.py's headline runs) and on the fp32 MFMA
+    engine.  mode = train: the configuration the benchmark times -- dropout 0.5 at every site -- with the product's masks
+    rebuilt from its seeds and handed to the restatement (forward_recording_masks), gates forced on top of that."""
     from vqa_playground_pytorch_amd import cor2 as cor2_mod
     from vqa_playground_pytorch_amd import head
     from vqa_playground_pytorch_amd import oda as oda_mod
     B = 512
+    monkeypatch.setenv("VQA_F32_PRODUCTS", engine)
     model = build(cls, nans)
-    v, q, a = seeded.seeded_inputs(B, answers=nans, seed=512)
-    rec = {}
+    if mode == "train":
+        model.train()
+    v, q, a = seeded.seeded_inputs(B, answers=nans, seed=512 if mode == "eval" else 514)
+    rec, masks = {}, None
     hooks = [model.compress_v.register_forward_hook(lambda m, args, out: rec.__setitem__("compress_v", (out > 0).cpu()))]
     for name in (("att1", "att2") if cls == "cor2" else ("att",)):
         att = getattr(model, name)
@@ -1044,7 +1062,10 @@ def test_baseline_batch_with_the_products_gates(cls, nans, monkeypatch):
             return out
         monkeypatch.setattr(oda_mod, "my_linears", my_linears)
     try:
-        got = model({"v": torch.from_numpy(v).to(dev()), "q_idxes": torch.from_numpy(q).to(dev())})
+        if mode == "train":
+            got, masks, _ = forward_recording_masks(model, cls, v, q)
+        else:
+            got = model({"v": torch.from_numpy(v).to(dev()), "q_idxes": torch.from_numpy(q).to(dev())})
     finally:
         for h in hooks:
             h.remove()
@@ -1064,8 +1085,18 @@ def test_baseline_batch_with_the_products_gates(cls, nans, monkeypatch):
         A = rec["att.glimpses"].shape[1] // 4
         order = [("compress_v", rec["compress_v"]), ("compress_q", rec["q_proj"][0])] + \
             [("att.glimpses", rec["att.glimpses"][:, g * A:(g + 1) * A]) for g in range(4)] + [("linear_q", rec["q_proj"][1])]
-    o64 = seeded.load_state({"cor2": RF.CoR2Oracle, "oda": RF.ODAOracle}[cls](nans), 0).eval().double()
+    o64 = seeded.load_state({"cor2": RF.CoR2Oracle, "oda": RF.ODAOracle}[cls](nans), 0)
+    o64 = (o64.train() if masks is not None else o64.eval()).double()
     flips, cursor, rng = {}, [0], [0, 0]
+    if masks is not None:     # the restatement's own F.dropout off; every Drop* layer's input times the product's mask of that site
+        sites = 0
+        for name, mod in o64.named_modules():
+            if isinstance(mod, (RF.DropLinear, RF.DropConv1x1)):
+                assert mod.p == 0.5 and name in masks, name
+                mod.p = None
+                mod.register_forward_pre_hook(lambda _m, args, name=name: (args[0] * masks[name][rng[0]:rng[1]].double(),))
+                sites += 1
+        assert sites == len(masks) == {"cor2": 19, "oda": 9}[cls]
     activate = RF._activate
 
     def forced(x, af, dim):
@@ -1103,4 +1134,5 @@ def test_baseline_batch_with_the_products_gates(cls, nans, monkeypatch):
         e = grad_err(p.grad, po.grad.numpy(), ATOL_512) * RTOL          # (error on the tensor's scale)
         assert e <= RTOL_FORCED_F32, (cls, n, e)
         worst = max(worst, (e, n))
-    print("[%s B=512, gates forced] all %d samples: worst gradient error %.2e of its tensor's scale (%s)" % (cls, B, worst[0], worst[1]))
+    print("[%s B=512 %s, %s engine, gates forced] all %d samples: worst gradient error %.2e of its tensor's scale (%s)"
+          % (cls, mode, engine, B, worst[0], worst[1]))

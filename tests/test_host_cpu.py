@@ -259,15 +259,19 @@ def test_head_mode_selects_the_grouped_phases_per_model(monkeypatch):
     assert head.supported("cor2", 2400, 311) is False
 
 
-def test_split_engine_is_opt_in_and_refuses_what_it_cannot_run(monkeypatch):
-    """ops.split_products: off unless VQA_F32_PRODUCTS=split; with it, only the shapes the split engine runs (queried from the
-    library, no GPU needed), the weight gradient only with K % 128 == 0, and never an operand at an offset that is not 16-byte
-    aligned -- everything else stays on the fp32 MFMA engine.  The workspace queries need no GPU either."""
+def test_split_engine_is_the_default_and_refuses_what_it_cannot_run(monkeypatch):
+    """ops.split_products: on by default (round 5) and with VQA_F32_PRODUCTS=split, off with VQA_F32_PRODUCTS=mfma, anything else
+    is an error; on, it takes only the shapes the split engine runs (queried from the library, no GPU needed), the weight
+    gradient only with K % 128 == 0, and never an operand at an offset that is not 16-byte aligned -- everything else stays on
+    the fp32 MFMA engine.  The workspace queries need no GPU either."""
     L_ = _lib.lib()
     monkeypatch.delenv("VQA_F32_PRODUCTS", raising=False)
-    assert not ops.split_products(18432, 2048, 310, 2048, 0.5)
+    assert ops.f32_products() == "split" and ops.split_products(18432, 2048, 310, 2048, 0.5)
     monkeypatch.setenv("VQA_F32_PRODUCTS", "mfma")
     assert not ops.split_products(18432, 2048, 310, 2048, 0.5)
+    monkeypatch.setenv("VQA_F32_PRODUCTS", "bf16")
+    with pytest.raises(ValueError):
+        ops.split_products(18432, 2048, 310, 2048, 0.5)
     monkeypatch.setenv("VQA_F32_PRODUCTS", "split")
     assert ops.split_products(18432, 2048, 310, 2048, 0.5) and ops.split_products(18432, 2048, 310, 2048, 0.0)
     assert not ops.split_products(18432, 2048, 310, 2048, 0.3)            # one-bit masks only

@@ -5,6 +5,8 @@
 #include <unordered_map>
 #include <unordered_set>
 
+#include <climits>
+
 #include "common.hpp"
 
 namespace vqa {
@@ -53,8 +55,10 @@ void note_launch(const char* kernel, dim3 grid, dim3 block) {
   if (log.n < VQA_LAUNCH_LOG_CAP) {
     log.items[log.n] = (unsigned long long)grid.x * grid.y * grid.z * block.x * block.y * block.z;
     log.kernel[log.n] = kernel;
+    ++log.n;
+  } else if (log.n < INT_MAX) {   // the count saturates: a long-lived process that never resets the log launches > 2^31 kernels
+    ++log.n;                      // in a few hours, and a wrapped counter would pass the bound check above with a negative index
   }
-  ++log.n;
 }
 
 // Zero-fill as a plain kernel.  hipMemsetAsync must not be used in this library: captured into a hipGraph (memset
@@ -95,9 +99,9 @@ extern "C" int vqa_set_option(const char* name, const char* value) {
 extern "C" void vqa_launch_log_reset(void) { vqa::launch_log().n = 0; }
 extern "C" int vqa_launch_log(unsigned long long* items, int capacity) {
   const vqa::LaunchLog& log = vqa::launch_log();
-  const int n = log.n < VQA_LAUNCH_LOG_CAP ? log.n : VQA_LAUNCH_LOG_CAP;
+  const int n = log.n < 0 ? 0 : (log.n < VQA_LAUNCH_LOG_CAP ? log.n : VQA_LAUNCH_LOG_CAP);
   for (int i = 0; i < n && i < capacity; ++i) items[i] = log.items[i];
-  return log.n;
+  return log.n < 0 ? 0 : log.n;   // (saturates at INT_MAX)
 }
 extern "C" const char* vqa_launch_log_kernel(int i) {
   const vqa::LaunchLog& log = vqa::launch_log();

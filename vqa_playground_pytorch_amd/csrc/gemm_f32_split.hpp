@@ -91,6 +91,22 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// ---- the engine's domain is ALL of fp32: the repair path ------------------------------------------------------------------
+// The three-way split is exact for every finite x whose leading plane is finite.  Outside of that -- x = +-Inf or NaN, or
+// |x| within half a bf16 ulp of FLT_MAX (plane 0 rounds to Inf) -- plane 1 is Inf - Inf = NaN, and a zero plane of the other
+// operand meeting an Inf plane is NaN as well (this includes the zero padding of a contraction: K = 320 over rows of 310).  In
+// every such case the affected ACCUMULATORS come out non-finite (NaN and Inf survive any further accumulation), so the
+// epilogues test their outputs (7 VALU instructions per four) and recompute a non-finite one as a plain fp32 dot product of
+// the ORIGINAL operands: an fp32 GEMM's answer -- finite where the fp32 MFMA engine's is finite (inputs next to FLT_MAX),
+// +-Inf / NaN where the data says so.  The path is never taken on finite well-scaled data (one execz branch per four outputs);
+// on a tensor full of NaNs it makes the kernel slow, not wrong.  tests/test_gpu_split.py::test_split_engine_edge_values.
+__device__ __forceinline__ uint32_t abs_bits_max(const f32x4& v) {
+  const u32x4 b = __builtin_bit_cast(u32x4, v) & 0x7FFFFFFFu;
+  return max(max(b[0], b[1]), max(b[2], b[3]));
+}
+__device__ __forceinline__ bool any_nonfinite(const f32x4& v) { return abs_bits_max(v) >= 0x7F800000u; }
+__device__ __forceinline__ bool nonfinite(float v) { return (__float_as_uint(v) & 0x7FFFFFFFu) >= 0x7F800000u; }
+
 // ---- the packed plane image of a [N, K] fp32 matrix (K % 32 == 0) -------------------------------------------------
 // one thread per (row block, chunk, lane): 8 fp32 in, 3 x 16 bytes out
 template <bool DOT = false>
@@ -129,7 +145,25 @@ struct NtArgs {
   int lda;
   int M, N, K;
   int tiles_n;
+  const float* Bf = nullptr;   // the fp32 original of the packed image, [N, K] row stride ldb: operand of the repair path
+  int ldb = 0;                 // (nullptr: the kernel's caller repairs in its own epilogue, or not at all)
 };
+// the repair path of the NT form: C[row][col] as an fp32 dot product of the original operands (DROP: the same mask bits)
+template <bool DROP>
+__device__ __forceinline__ float nt_repair(const float* A, int lda, const float* Bf, int ldb, int K, int row, int col, uint32_t key) {
+  const float* a = A + (size_t)row * lda;
+  const float* b = Bf + (size_t)col * ldb;
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) {
+    float x = a[k];
+    if constexpr (DROP) {
+      const uint32_t e = (uint32_t)row * (uint32_t)K + (uint32_t)k;
+      x = ((mask_word32(e >> 5, key) >> (e & 31u)) & 1u) != 0u ? x : 0.f;
+    }
+    s = fmaf(x, b[k], s);
+  }
+  return s;
+}
 
 // NR = raw A row blocks in flight per wave (a ring: the load of row block n + NR goes out when n has been split; 2 RB % NR == 0).
 // TUNE (tools/split_probe.hip): bit 0 = no A split (the planes are the raw registers: MFMA + load ceiling, wrong results),
@@ -437,9 +471,11 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg 
     nt_accumulate<RB, CB, DROP, TUNE, NR>(p, dc, ((size_t)(p.M - 1) * p.lda + p.K) * 4, m0, n0, c_lo, c_hi, acc);
   }
 
+  uint64_t bad = 0;      // blocks of this lane that hold a non-finite output: recomputed below (any_nonfinite)
   auto finish = [&](int blk, f32x4 v) {
     const int i = blk / CB, j = blk % CB;
     const int col = n0 + 16 * j + r;
+    if (any_nonfinite(v)) bad |= 1ull << blk;
     if (col < p.N) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -472,6 +508,19 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg 
 #pragma unroll
     for (int blk = 0; blk < S::NB; ++blk) finish(blk, acc[blk / CB][blk % CB]);
   }
+  static_assert(S::NB <= 64, "one bit per accumulator block");
+  if (p.Bf != nullptr && bad != 0) {     // the repair path: the flagged blocks' outputs again, as fp32 dot products
+    const uint32_t key = DROP ? drop_key(dc) : 0u;
+    for (int blk = 0; blk < S::NB; ++blk) {
+      if (((bad >> blk) & 1ull) == 0) continue;
+      const int col = n0 + 16 * (blk % CB) + r;
+      if (col >= p.N) continue;
+      for (int t = 0; t < 4; ++t) {
+        const int row = m0 + 16 * (blk / CB) + 4 * g + t;
+        if (row < p.M) epi(row, col, nt_repair<DROP>(p.A, p.lda, p.Bf, p.ldb, p.K, row, col, key));
+      }
+    }
+  }
 }
 
 
@@ -499,7 +548,59 @@ struct TnArgs {
   int nblocks;          // (N1 + 15) / 16
   int cps;              // chunks per slab (even)
   int tiles1, tiles2;   // workgroup tiles along n1 (4 NA blocks each) and n2 (64 SPN columns each)
+  const float* Gf = nullptr;   // the fp32 original of the packed image ([M, N1], row stride ldg) and, when it was gated, the
+  const float* Yf = nullptr;   // forward output whose sign gates it: operands of the repair path (any_nonfinite); Gf == nullptr:
+  int ldg = 0;                 // no repair
 };
+// The epilogue of both TN kernels: D[row = n1 % 16 = 4 g + t][col r] of block (i, b = 4 q + cc) is column n2_0 + 64 q + 4 r + cc,
+// so the four cc of a span leave as one 16-byte store.  A group of four that holds a non-finite value is stored again from the
+// repair path: the slab's rows contracted as fp32 dot products of the original operands (same gate, same mask bits).
+template <int NA, int SPN, bool DROP>
+__device__ __forceinline__ void tn_store(const TnArgs& p, const DropCfg& dc, const f32x4 (&acc)[NA][4 * SPN], int slab, int b1, int n2_0,
+                                         int r, int g) {
+  float* out = p.slab + (size_t)slab * p.N1 * p.N2;
+  uint64_t bad = 0;
+  static_assert(NA * SPN * 4 <= 64, "one bit per 16-byte store");
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int q = 0; q < SPN; ++q) {
+      const int col = n2_0 + 64 * q + 4 * r;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int n1 = 16 * (b1 + i) + 4 * g + t;
+        const f32x4 v = f32x4{acc[i][4 * q][t], acc[i][4 * q + 1][t], acc[i][4 * q + 2][t], acc[i][4 * q + 3][t]};
+        if (b1 + i < p.nblocks && n1 < p.N1 && col + 3 < p.N2) {
+          *reinterpret_cast<f32x4*>(out + (size_t)n1 * p.N2 + col) = v;
+          if (any_nonfinite(v)) bad |= 1ull << ((i * SPN + q) * 4 + t);
+        }
+      }
+    }
+  if (p.Gf != nullptr && bad != 0) {
+    const uint32_t key = DROP ? drop_key(dc) : 0u;
+    const int m_lo = slab * p.cps * kChunk, m_hi = min(p.M, m_lo + p.cps * kChunk);
+    for (int k = 0; k < NA * SPN * 4; ++k) {
+      if (((bad >> k) & 1ull) == 0) continue;
+      const int t = k & 3, q = (k >> 2) % SPN, i = (k >> 2) / SPN;
+      const int n1 = 16 * (b1 + i) + 4 * g + t, col = n2_0 + 64 * q + 4 * r;
+      f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int m = m_lo; m < m_hi; ++m) {
+        float gv = p.Gf[(size_t)m * p.ldg + n1];
+        if (p.Yf != nullptr) gv = p.Yf[(size_t)m * p.ldg + n1] > 0.f ? gv : 0.f;
+        f32x4 x = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * p.ldx + col);
+        if constexpr (DROP) {
+          const uint32_t e = (uint32_t)m * (uint32_t)p.N2 + (uint32_t)col;     // a multiple of 4
+          const uint32_t w = mask_word32(e >> 5, key) >> (e & 31u);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) x[c] = ((w >> c) & 1u) != 0u ? x[c] : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sum[c] = fmaf(gv, x[c], sum[c]);
+      }
+      *reinterpret_cast<f32x4*>(out + (size_t)n1 * p.N2 + col) = sum;
+    }
+  }
+}
 struct TnPlan {
   int slabs, cps;
 };
@@ -744,21 +845,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_kernel(TnArgs p, DropCfg 
     }
   }
 
-  // D[row = n1 % 16 = 4 g + t][col r] of block (i, b = 4 q + cc) is column n2_0 + 64 q + 4 r + cc: the four cc of a span = one store
-  float* out = p.slab + (size_t)slab * p.N1 * p.N2;
-#pragma unroll
-  for (int i = 0; i < NA; ++i)
-#pragma unroll
-    for (int q = 0; q < SPN; ++q) {
-      const int col = n2_0 + 64 * q + 4 * r;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int n1 = 16 * (b1 + i) + 4 * g + t;
-        if (b1 + i < p.nblocks && n1 < p.N1 && col + 3 < p.N2)
-          *reinterpret_cast<f32x4*>(out + (size_t)n1 * p.N2 + col) =
-              f32x4{acc[i][4 * q][t], acc[i][4 * q + 1][t], acc[i][4 * q + 2][t], acc[i][4 * q + 3][t]};
-      }
-    }
+  tn_store<NA, SPN, DROP>(p, dc, acc, slab, b1, n2_0, r, g);
 }
 
 // The TN form with the split of X shared by the workgroup.  The four waves of a workgroup work on the SAME rows and columns of X
@@ -917,20 +1004,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_shared_kernel(TnArgs p, D
     }
   }
 
-  float* out = p.slab + (size_t)slab * p.N1 * p.N2;
-#pragma unroll
-  for (int i = 0; i < NA; ++i)
-#pragma unroll
-    for (int q = 0; q < SPN; ++q) {
-      const int col = n2_0 + 64 * q + 4 * r;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int n1 = 16 * (b1 + i) + 4 * g + t;
-        if (b1 + i < p.nblocks && n1 < p.N1 && col + 3 < p.N2)
-          *reinterpret_cast<f32x4*>(out + (size_t)n1 * p.N2 + col) =
-              f32x4{acc[i][4 * q][t], acc[i][4 * q + 1][t], acc[i][4 * q + 2][t], acc[i][4 * q + 3][t]};
-      }
-    }
+  tn_store<NA, SPN, DROP>(p, dc, acc, slab, b1, n2_0, r, g);
 }
 
 // d_w[e] = scale * (fixed-order sum of the S slabs), float4 lanes, four slabs' loads in flight;  d_b[n] = sum of the Sb rows

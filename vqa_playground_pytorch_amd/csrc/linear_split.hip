@@ -65,7 +65,7 @@ extern "C" int vqa_linear_act_fwd_split(const float* x, int ldx, const float* w,
   // 144 x 160 workgroup tiles, each wave 9 x 5 accumulator blocks over half of K (M = 18432, N = 310: 256 workgroups)
   using S = rt::NtShape<9, 5, 1, 2, 2>;
   const int tiles_m = (M + S::BM - 1) / S::BM, tiles_n = (N + S::BN - 1) / S::BN;
-  const sp::NtArgs a{x, wp, ldx, M, N, K, tiles_n};
+  const sp::NtArgs a{x, wp, ldx, M, N, K, tiles_n, w, K};      // (w, K: the repair path's operand)
   const SplitEpiBiasAct epi{y, bias, N, act, dc.p8 > 0 ? dc.scale : 1.f};
   if (dc.p8 > 0) {
     VQA_ENSURE_LDS((sp::gemm_nt_kernel<9, 5, 1, 2, 2, true, SplitEpiBiasAct, 0, 3>), S::kLdsBytes);
@@ -94,8 +94,8 @@ extern "C" int vqa_linear_act_dw_split(const float* x, int ldx, const float* y, 
               "linear_act_dw_split: gz_out (the gated gradient) only with act = 1, 8-byte aligned");
   VQA_REQUIRE(split_shape_ok(M, K, N, ldx, p_drop) && K % 128 == 0, VQA_E_UNSUPPORTED,
               "linear_act_dw_split: shape outside the split engine (M=%d K=%d N=%d ldx=%d p=%f)", M, K, N, ldx, (double)p_drop);
-  VQA_REQUIRE(aligned(x, 16) && aligned(d_w, 16) && aligned(workspace, 16), VQA_E_UNSUPPORTED,
-              "linear_act_dw_split: x, d_w, workspace must be 16-byte aligned");
+  VQA_REQUIRE(aligned(x, 16) && aligned(d_w, 16) && aligned(workspace, 16) && aligned(gy, 8) && (y == nullptr || aligned(y, 8)),
+              VQA_E_UNSUPPORTED, "linear_act_dw_split: x, d_w, workspace must be 16-byte aligned, gy and y 8-byte");
   VQA_REQUIRE(workspace_bytes >= vqa_linear_act_dw_split_workspace_bytes(M, K, N), VQA_E_BADARG,
               "linear_act_dw_split: workspace too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -118,7 +118,7 @@ extern "C" int vqa_linear_act_dw_split(const float* x, int ldx, const float* y, 
   }
   constexpr int NA = 5, SPN = 2;
   const int tiles1 = (nblocks + 4 * NA - 1) / (4 * NA), tiles2 = (K + 64 * SPN - 1) / (64 * SPN);
-  const sp::TnArgs a{gp, x, slab, ldx, M, N, K, nblocks, pl.cps, tiles1, tiles2};
+  const sp::TnArgs a{gp, x, slab, ldx, M, N, K, nblocks, pl.cps, tiles1, tiles2, gy, act == 1 ? y : nullptr, N};
   const dim3 grid(tiles1 * tiles2 * pl.slabs);
   // the split of x shared by the workgroup's four waves through LDS (91.9 / 94.0 us against 99 / 107 with every wave splitting
   // all of it, tools/split_probe.hip); VQA_SPLIT_TN_SHARED=0 keeps the per-wave form

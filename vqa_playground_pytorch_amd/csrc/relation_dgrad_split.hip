@@ -29,6 +29,7 @@ struct RelSplitArgs {
   int B, M, L, D;
   int Kp;               // L rounded up to an even number of 32-deep chunks
   int tiles_n;          // workgroup tiles of 256 columns
+  const float* wf;      // W [L, D] itself: operand of the repair path (gemm_f32_split.hpp, any_nonfinite)
 };
 
 // W [L, D] -> the plane image of W^T.  Image row block cb = 4 (d / 64) + e, lane (r, g)  <->  column d = 64 (cb / 4) + 4 r + e,
@@ -84,6 +85,37 @@ __global__ __launch_bounds__(sp::kThreads, 1) void relation_dgrad_split_kernel(R
       sp::nt_accumulate_shared<kRB, 4, 4, false, 0>(a, dc, (size_t)M * p.L * 4, m0, n0, 0, p.Kp / sp::kChunk, wave, rd_smem, acc);
     } else {
       sp::nt_accumulate<kRB, 4, false, 0, 3>(a, dc, (size_t)M * p.L * 4, m0, n0, 0, p.Kp / sp::kChunk, acc);
+    }
+  }
+
+  // ---- outside the split's domain (a non-finite accumulator: gemm_f32_split.hpp, any_nonfinite): the lane's 144 values of dx
+  // again as fp32 dot products of the original operands (this also undoes what a non-finite value in the NEXT row's first
+  // Kp - L elements did through the contraction's padding)
+  if constexpr (TUNE == 0) {
+    uint32_t top = 0;     // the largest |bits| among the lane's accumulators (straight-line code: no short-circuit branches)
+#pragma unroll
+    for (int i = 0; i < kRB; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) top = max(top, sp::abs_bits_max(acc[i][e]));
+    if (top >= 0x7F800000u) {
+#pragma unroll 1
+      for (int it = 0; it < 4 * kRB; ++it) {       // (one rolled loop; the results go home through a select chain: cold code, kept small)
+        const float* grow = p.gz + (size_t)min(m0 + 16 * (it >> 2) + 4 * g + (it & 3), M - 1) * p.L;
+        const float* wcol = p.wf + n0 + 4 * r;
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int l = 0; l < p.L; ++l) {
+          const float gv = grow[l];
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wcol + (size_t)l * D);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[e] = fmaf(gv, wv[e], s[e]);
+        }
+#pragma unroll
+        for (int i = 0; i < kRB; ++i)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][e][t] = it == 4 * i + t ? s[e] : acc[i][e][t];
+      }
     }
   }
 
@@ -205,8 +237,8 @@ extern "C" int vqa_relation_projection_dgrad_split(const float* gz, const float*
   VQA_REQUIRE(B > 0 && N > 0 && D > 0 && L > 0, VQA_E_BADARG, "relation_projection_dgrad_split: bad sizes B=%d N=%d D=%d L=%d", B, N, D, L);
   VQA_REQUIRE(vqa_relation_projection_dgrad_split_supported(B, N, D, L), VQA_E_UNSUPPORTED,
               "relation_projection_dgrad_split: needs N = 36 regions, D %% 64 == 0, even L >= 32 (N=%d D=%d L=%d)", N, D, L);
-  VQA_REQUIRE(aligned(w, 4) && aligned(v, 16) && aligned(d_t, 16) && aligned(d_c2, 16) && aligned(gz, 8) && aligned(workspace, 16),
-              VQA_E_UNSUPPORTED, "relation_projection_dgrad_split: v, d_t, d_c2, workspace must be 16-byte aligned, gz 8-byte");
+  VQA_REQUIRE(aligned(w, 16) && aligned(v, 16) && aligned(d_t, 16) && aligned(d_c2, 16) && aligned(gz, 8) && aligned(workspace, 16),
+              VQA_E_UNSUPPORTED, "relation_projection_dgrad_split: w, v, d_t, d_c2, workspace must be 16-byte aligned, gz 8-byte");
   VQA_REQUIRE(workspace_bytes >= vqa_relation_projection_dgrad_split_workspace_bytes(D, L), VQA_E_BADARG,
               "relation_projection_dgrad_split: workspace too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -228,6 +260,7 @@ extern "C" int vqa_relation_projection_dgrad_split(const float* gz, const float*
   a.D = D;
   a.Kp = Kp;
   a.tiles_n = (D + 255) / 256;
+  a.wf = w;
   const int tiles_m = (a.M + kBM - 1) / kBM;
   const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
   // D % 256 == 0: gz's split shared by the workgroup's four waves through LDS (VQA_SPLIT_DGRAD_SHARED=0: every wave splits all of it)

@@ -871,11 +871,23 @@ class ObjectDifferenceAttention(torch.autograd.Function):
         return d_vl, d_ql, d_w, d_bias, None, None, None
 
 
+def f32_products():
+    """How the tall fp32 projections form their products: "split" (the default since round 5: exact three-way bf16 splits of both
+    operands, six partial products on v_mfma_f32_16x16x32_bf16, fp32 accumulation -- csrc/gemm_f32_split.hpp; an fp32 GEMM in
+    error and in domain, tests/test_gpu_split.py) or "mfma" (v_mfma_f32_16x16x4_f32).  Host-side selection, read per call from the
+    environment variable VQA_F32_PRODUCTS -- not a library option (vqa_set_option has no say in it)."""
+    mode = os.environ.get("VQA_F32_PRODUCTS", "split")
+    if mode not in ("split", "mfma"):
+        raise ValueError("VQA_F32_PRODUCTS must be 'split' or 'mfma', got %r" % (mode,))
+    return mode
+
+
 def split_products(M, K, N, ldx, p_drop, weight_gradient=False, tensors=()):
     """True when this tall projection runs on the split engine (csrc/gemm_f32_split.hpp: fp32 products from exact three-way
-    bf16 splits on the bf16 matrix pipe, fp32 accumulation) -- opt-in by VQA_F32_PRODUCTS=split, default the fp32 MFMA engine.
+    bf16 splits on the bf16 matrix pipe, fp32 accumulation): f32_products() says "split" (the default) and the library takes the
+    shape (vqa_linear_split_supported); everything else runs on the fp32 MFMA engine.
     `tensors`: the operands the engine reads with 16-byte loads (a view at an odd offset stays on the fp32 MFMA engine)."""
-    if os.environ.get("VQA_F32_PRODUCTS", "mfma") != "split":
+    if f32_products() != "split":
         return False
     if weight_gradient and K % 128 != 0:
         return False
@@ -903,7 +915,7 @@ def _linear_dw(x, w, y, gy, d_w, d_b, M, K, N, act, p_drop, seed, gz_out=None):
     act = relu only): receives gy * (y > 0), which the pass that packs the gradient for the GEMM has in hand."""
     L_ = _lib.lib()
     sv, sp = _seed_args(seed)
-    if split_products(M, K, N, K, p_drop, weight_gradient=True, tensors=(x, d_w)):
+    if split_products(M, K, N, K, p_drop, weight_gradient=True, tensors=(x, d_w, gy, y if act == 1 else None)):
         ws_bytes = L_.vqa_linear_act_dw_split_workspace_bytes(M, K, N)
         ws = torch.empty((ws_bytes + 3) // 4, device=x.device, dtype=torch.float32)
         _launch("linear_act_dw_split", (M, K, N, p_drop > 0, act), L_.vqa_linear_act_dw_split, _p(x), K,
@@ -1042,7 +1054,8 @@ class RelationProjection(torch.autograd.Function):
         d_t = torch.empty(B, D, device=v.device, dtype=torch.float32)
         d_c2 = torch.empty(B, D, device=v.device, dtype=torch.float32)
         sv, sp = _seed_args(seed)
-        if os.environ.get("VQA_F32_PRODUCTS", "mfma") == "split" and L_.vqa_relation_projection_dgrad_split_supported(B, N, D, L) == 1:
+        if (f32_products() == "split" and L_.vqa_relation_projection_dgrad_split_supported(B, N, D, L) == 1
+                and all(t.data_ptr() % 16 == 0 for t in (v, gz, w))):
             ws_bytes = L_.vqa_relation_projection_dgrad_split_workspace_bytes(D, L)
             ws = torch.empty((ws_bytes + 3) // 4, device=v.device, dtype=torch.float32)
             _launch("relation_projection_dgrad_split", (B, N, D, L, p_drop > 0), L_.vqa_relation_projection_dgrad_split, _p(gz), _p(w),
