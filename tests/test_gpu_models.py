@@ -1078,7 +1078,8 @@ def test_baseline_batch_with_the_products_gates(cls, nans, mode, engine, monkeyp
         A = rec["att1.glimpses"].shape[1] // 4
         order = [("compress_q", rec["q_proj"][0]), ("compress_v", rec["compress_v"])] + \
             [("att1.glimpses", rec["att1.glimpses"][:, g * A:(g + 1) * A]) for g in range(4)] + \
-            [("compress_q_1", rec["q_proj"][2]), ("compress_q_2", rec["q_proj"][3]), ("compress_v2", rec["compress_v2"])] + \
+            [("compress_q_1", rec["q_proj"][2], "expand_q_1"), ("compress_q_2", rec["q_proj"][3], "expand_q_2"),
+             ("compress_v2", rec["compress_v2"])] + \
             [("att2.glimpses", rec["att2.glimpses"][:, g * A:(g + 1) * A]) for g in range(4)] + [("linear_q", rec["q_proj"][1])]
     else:
         assert set(rec) == {"compress_v", "q_proj", "att.glimpses"}
@@ -1102,10 +1103,17 @@ def test_baseline_batch_with_the_products_gates(cls, nans, mode, engine, monkeyp
     def forced(x, af, dim):
         if af != "relu":
             return activate(x, af, dim)
-        site, gate = order[cursor[0]]
+        site, gate = order[cursor[0]][:2]
+        consumer = order[cursor[0]][2] if len(order[cursor[0]]) > 2 else None
         cursor[0] += 1
         gate = gate[rng[0]:rng[1]].reshape(x.shape)
         xd = x.detach()
+        if masks is not None and consumer is not None:
+            # training mode: the grouped head hands these two projections over with the NEXT layer's input dropout already applied
+            # (head.QuestionProjections), so the recorded sign is gate AND keep; where the unit was dropped its gate reaches
+            # nothing (the restatement multiplies by the same mask right behind) -- the restatement's own decision stands there
+            keep = masks[consumer][rng[0]:rng[1]].reshape(x.shape) > 0
+            gate = torch.where(keep, gate, xd > 0)
         diff = (xd > 0) != gate
         rms = float(xd.pow(2).mean().sqrt())
         n, units, edge = flips.get(site, (0, 0, 0.0))
@@ -1131,8 +1139,14 @@ def test_baseline_batch_with_the_products_gates(cls, nans, mode, engine, monkeyp
     assert rel(got, torch.cat(want).numpy()) <= RTOL
     worst = (0.0, "")
     for (n, p), po in zip(model.named_parameters(), params):
-        e = grad_err(p.grad, po.grad.numpy(), ATOL_512) * RTOL          # (error on the tensor's scale)
-        assert e <= RTOL_FORCED_F32, (cls, n, e)
+        g64, w64 = p.grad.detach().cpu().numpy().astype(np.float64), po.grad.numpy()
+        assert np.isfinite(g64).all()
+        err, scale = np.abs(g64 - w64).max(), np.abs(w64).max()
+        # 2e-4 of the tensor's scale; the absolute floor ATOL_512 is for the gradients that are mathematically ZERO (a bias in
+        # front of a softmax over regions: conv_att's, the region-side Mutan biases), where both sides hold rounding noise of a
+        # sum over 512 x 36 rows -- a few 1e-7 in eval mode, up to 1e-6 with the dropout factors 2 of training mode
+        assert err <= RTOL_FORCED_F32 * scale + ATOL_512, (cls, n, err, scale)
+        e = err / (scale + ATOL_512 / RTOL_FORCED_F32)                  # (error on the tensor's scale)
         worst = max(worst, (e, n))
     print("[%s B=512 %s, %s engine, gates forced] all %d samples: worst gradient error %.2e of its tensor's scale (%s)"
           % (cls, mode, engine, B, worst[0], worst[1]))

@@ -70,6 +70,9 @@ __global__ __launch_bounds__(sp::kThreads, 1) void relation_dgrad_split_kernel(R
   if (!SHARED && n0 >= p.D) return;          // (SHARED: D % 256 == 0 is required, every wave takes part in the barriers)
   const int M = p.M, D = p.D;
 
+  // (the descriptor of v is made HERE, ahead of every divergent region: made behind the repair branch below it became a PHI of
+  //  a divergent region, lived in VGPRs, and each of the epilogue's 36 loads of v ran inside a waterfall loop: +50 us)
+  const rt::rsrc_t Vb = rt::make_rsrc(p.v, (size_t)M * D * 4);
   f32x4 acc[kRB][4];   // [row block][column class e]: rows 16 i + 4 g + t (register t), column n0 + 4 r + e
 #pragma unroll
   for (int i = 0; i < kRB; ++i)
@@ -120,7 +123,6 @@ __global__ __launch_bounds__(sp::kThreads, 1) void relation_dgrad_split_kernel(R
   }
 
   // ---- epilogue (relation_dgrad.hip's): mask, multiply by v, add the rows of each sample up ----
-  const rt::rsrc_t Vb = rt::make_rsrc(p.v, (size_t)M * D * 4);
   if constexpr ((TUNE & 4) != 0) {
     f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
