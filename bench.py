@@ -594,6 +594,9 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="CoR2: backward in two halves, the second reasoning step's "
                     "gradients all-reduced under the second half (trainer overlap; at one GPU it only splits the backward)")
     ap.add_argument("--no-rotate", action="store_true", help="time the steps on ONE resident batch instead of %d rotating ones" % ROTATE)
+    ap.add_argument("--copy-inputs", action="store_true", help="rotating batches are COPIED into one pair of graph input buffers "
+                    "(one device-to-device copy per step inside the timed region) instead of the step being captured once per "
+                    "resident batch (trainer input_slots)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying "
                     "the captured hipGraphs of the step")
     ap.add_argument("--detail-file", default=os.path.join(os.getcwd(), "bench_detail.json"), help="where the full record "
@@ -657,10 +660,11 @@ def main():
 
     t_start = time.perf_counter()
     # `value` is measured over ROTATE different resident batches, visited in turn: every step's 151 MB of regions then comes from
-    # HBM and not from the 256 MB Infinity Cache (one batch re-read every step would).  The replayed graphs read fixed input
-    # buffers, so each step starts with one device-to-device copy of its batch into them (read + written inside the timed
-    # region: an upper bound on what cold inputs cost).  The resident-batch figure is reported beside it (`config.inputs`,
-    # `resident_inputs`).  --no-rotate: the resident batch only (profiling passes).
+    # HBM and not from the 256 MB Infinity Cache (one batch re-read every step would).  The batches are the slots of a feeder's
+    # ring: the trainer captures the forward + backward graph once per slot (input_slots), each reading its slot in place, so no
+    # step copies its batch (--copy-inputs: one pair of graph input buffers and a device-to-device copy per step, rounds 1-4's
+    # rotating pass).  The resident-batch figure is reported beside it (`config.inputs`, `resident_inputs`).  --no-rotate: the
+    # resident batch only (profiling passes).
     rotate = not args.no_rotate and not args.encoder
 
     def run_schedule(overlap):
@@ -678,7 +682,8 @@ def main():
         # adopt_inputs: the synthetic batches are resident; the first one's tensors become the replayed graphs' input buffers
         # (a real feeder goes through the trainer's private input buffers: tools/feed_bench.py)
         trainer = DataParallelTrainer(model, lr=1e-4, clip=0.25, graph=not args.no_graph, adopt_inputs=True,
-                                      overlap=("force" if world == 1 else True) if overlap else False)
+                                      overlap=("force" if world == 1 else True) if overlap else False,
+                                      input_slots=1 if (not rotate or args.copy_inputs) else ROTATE)
         torch.manual_seed(100 + rank)  # per-rank dropout streams and data shards differ
         v = torch.randn(B, args.regions, FEAT, device=dev)
         if bf16:
@@ -693,7 +698,8 @@ def main():
             for _ in range(ROTATE - 1):
                 batches.append(({"v": torch.randn_like(v.float()).to(v.dtype), "q_idxes": torch.randn_like(q)},
                                 torch.softmax(2.0 * torch.randn(B, answers, device=dev), dim=1)))
-        warm = max(args.warmup, 3) if not args.no_graph else args.warmup   # 2 eager steps precede the capture
+        # 2 eager steps precede the first capture; each further input slot is captured by the first step that lands in it
+        warm = max(args.warmup, 2 + (1 if (not rotate or args.copy_inputs) else ROTATE)) if not args.no_graph else args.warmup
         for i in range(warm):
             trainer.step(*batches[i % len(batches)])
             if i == 0:
@@ -865,13 +871,17 @@ def main():
                        "f32_products": ("fp32 MFMA (v_mfma_f32_16x16x4_f32)" if args.f32_products == "mfma" else
                                         "3xbf16 split, 6 partial products, fp32 accumulate"),
                        "library_gemms": __import__("vqa_playground_pytorch_amd.tuned_gemms", fromlist=["describe"]).describe(),
-                       "inputs": ("%d rotating batches (+1 device copy/step); 1 resident batch: %.1f (%+.1f%%)"
-                                  % (ROTATE, resident["value"], 100.0 * (resident["value"] / (world * B * args.steps / elapsed) - 1.0))
+                       "inputs": ("%d rotating batches (%s); 1 resident batch: %.1f (%+.1f%%)"
+                                  % (ROTATE, "+1 device copy/step" if args.copy_inputs else "a step graph per batch slot, no copy",
+                                     resident["value"], 100.0 * (resident["value"] / (world * B * args.steps / elapsed) - 1.0))
                                   if resident is not None else "1 resident batch"),
                        "inputs_note": ("`value` visits %d different resident batches in turn (%.0f MB of regions each: together "
-                                       "beyond the 256 MB Infinity Cache), one device-to-device copy into the replayed graphs' "
-                                       "input buffers per step inside the timed region; `resident_inputs` re-reads ONE batch "
-                                       "(cache-resident, no copy)" % (ROTATE, v.numel() * v.element_size() / 1e6))
+                                       "beyond the 256 MB Infinity Cache); %s; `resident_inputs` re-reads ONE batch "
+                                       "(cache-resident)" % (ROTATE, v.numel() * v.element_size() / 1e6,
+                                                             "one device-to-device copy into the replayed graphs' input buffers "
+                                                             "per step inside the timed region" if args.copy_inputs else
+                                                             "the forward + backward graph is captured once per batch slot and "
+                                                             "reads its slot in place (trainer input_slots), no copy"))
                        if resident is not None else "ONE resident batch re-read every step"},
             "final_loss": round(final_loss, 3), "final_grad_norm": round(final_gnorm, 3),
             "roofline": dominant,

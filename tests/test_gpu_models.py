@@ -637,6 +637,41 @@ def test_graph_trainer_fed_by_prefetcher_matches_eager():
         assert abs(l0 - l1) <= 1e-4 * abs(l0), (out[False], out[True])
 
 
+@pytest.mark.parametrize("overlap", [False, "force"])
+def test_graph_per_input_slot_reads_batches_in_place(overlap):
+    """input_slots (bench.py's rotating batches; a feeder's ring of resident buffers): the forward + backward graph is captured
+    once per slot and reads the slot's tensors in place.  Same batches, same seeds as a trainer with ONE pair of graph input
+    buffers that every batch is copied into: the loss sequences are identical -- and the slotted trainer's replays issue no copy
+    of a batch (its graphs' input tensors ARE the callers'), also with the backward in two halves."""
+    from vqa_playground_pytorch_amd.trainer import DataParallelTrainer
+    ring = []
+    for i in range(3):
+        v, q, a = (torch.from_numpy(x).to(dev()) for x in seeded.seeded_inputs(64, answers=300, seed=80 + i))
+        ring.append(({"v": v, "q_idxes": q}, a))
+    keep = [(s["v"].clone(), s["q_idxes"].clone(), a.clone()) for s, a in ring]
+    out = {}
+    for slots in (1, 3):
+        torch.manual_seed(21)
+        tr = DataParallelTrainer(build("cor2", 300).train(), lr=2e-5, clip=0.25, graph=True, adopt_inputs=slots > 1,
+                                 overlap=overlap, input_slots=slots)
+        losses = []
+        for i in range(14):
+            loss, norm = tr.step(*ring[i % 3])
+            losses.append((loss.clone(), norm.clone()))
+        torch.cuda.synchronize()
+        out[slots] = [(x.item(), n.item()) for x, n in losses]
+        assert tr._graph is not None, "step was not captured"
+        assert len(tr._slots) == slots
+        if slots > 1:
+            ptrs = {slot["sample"]["v"].data_ptr() for slot in tr._slots}
+            assert ptrs == {s["v"].data_ptr() for s, _ in ring}           # every slot graph reads its batch in place
+            assert bool(tr.overlap) == bool(overlap)
+    for (s, a), (v0, q0, a0) in zip(ring, keep):                          # and nobody wrote the callers' tensors
+        assert torch.equal(s["v"], v0) and torch.equal(s["q_idxes"], q0) and torch.equal(a, a0)
+    for (l1, n1), (l3, n3) in zip(out[1], out[3]):
+        assert abs(l1 - l3) <= 1e-5 * abs(l1) and abs(n1 - n3) <= 1e-4 * abs(n1), (out[1], out[3])
+
+
 def test_graph_replays_queued_without_host_sync():
     """bench.py's flow: replays queued back to back with no host read in between, at the headline batch.  The loss and
     gradient norm read once at the end must equal those of the same steps launched kernel by kernel.  (Regression: a

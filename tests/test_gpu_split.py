@@ -165,7 +165,7 @@ def test_split_relation_projection_gradients_at_size(ops, monkeypatch, p):
 # to their accumulators (non-finite) and recompute those outputs as fp32 dot products of the original operands
 # (gemm_f32_split.hpp, any_nonfinite).  Checked here against the fp32 MFMA engine and float64, through the C ABI.
 
-EDGE_M, EDGE_K, EDGE_N = 2304, 256, 310
+EDGE_M, EDGE_K, EDGE_N = 4608, 256, 310      # (M >= 4096: both engines run their tall-matrix kernels, forward and weight gradient)
 
 
 def _classes(t):
@@ -181,10 +181,10 @@ def _edge_operands(kind, gen):
     fmax = torch.finfo(torch.float32).max
     if kind == "flt_max":
         # values whose bf16 rounding is Inf (> 3.3961e38) next to partners small enough that every sum stays finite in fp32
-        for i, (m, k) in enumerate([(0, 0), (5, 17), (143, 255), (144, 31), (1000, 100), (2303, 128), (2303, 129)]):
+        for i, (m, k) in enumerate([(0, 0), (5, 17), (143, 255), (144, 31), (1000, 100), (4607, 128), (4607, 129)]):
             x[m, k] = fmax * (1.0 if i % 2 == 0 else -1.0) * (1.0 - 2.0 ** -(9 + i))
             w[:, k] *= 2.0 ** -30
-            gy[m, :] *= 2.0 ** -60                 # (the weight gradient multiplies x[m, k] with gy[m, :]; 2304 rows are added up)
+            gy[m, :] *= 2.0 ** -60                 # (the weight gradient multiplies x[m, k] with gy[m, :]; 4608 rows are added up)
         for (n, k) in [(3, 40), (309, 200)]:
             w[n, k] = -fmax * (1.0 - 2.0 ** -12)
             x[:, k] *= 2.0 ** -40
@@ -193,11 +193,11 @@ def _edge_operands(kind, gen):
             x[m, :] *= 2.0 ** -40
     elif kind == "nonfinite":
         inf, nan = float("inf"), float("nan")
-        x[1, 3], x[150, 200], x[151, 200], x[2000, 0], x[2303, 255] = inf, -inf, nan, inf, nan
+        x[1, 3], x[150, 200], x[151, 200], x[2000, 0], x[4607, 255] = inf, -inf, nan, inf, nan
         x[700, 10], x[700, 11] = inf, -inf          # Inf - Inf in one row
         w[5, 9], w[300, 100], w[17, 255] = inf, nan, -inf
         w[40, 3] = 0.0                               # x[1, 3] = Inf meets an exact zero: NaN on any engine
-        gy[9, 9], gy[1500, 309], gy[1501, 0], gy[2303, 150] = inf, nan, -inf, inf
+        gy[9, 9], gy[1500, 309], gy[1501, 0], gy[4607, 150] = inf, nan, -inf, inf
     elif kind == "tiny":
         x = torch.exp2(-126.0 + 26.0 * torch.rand(M, Kd, generator=gen)) * torch.sign(torch.randn(M, Kd, generator=gen))
         w = torch.randn(N, Kd, generator=gen)

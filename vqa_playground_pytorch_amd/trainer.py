@@ -209,7 +209,7 @@ class DataParallelTrainer:
     EAGER_STEPS_BEFORE_CAPTURE = 2
 
     def __init__(self, model, lr=1e-4, clip=0.25, gamma=0.5 ** (1 / 50000), broadcast=True, group=None,
-                 fused_adam=None, graph=False, adopt_inputs=False, overlap=None):
+                 fused_adam=None, graph=False, adopt_inputs=False, overlap=None, input_slots=1):
         self.model = model
         self.group = group
         self.clip = clip
@@ -246,6 +246,13 @@ class DataParallelTrainer:
         # tensors every step (resident synthetic data), but later batches OVERWRITE those tensors -- never combine it
         # with a feeder that recycles its own buffers (feed.DevicePrefetcher).
         self.adopt_inputs = bool(adopt_inputs)
+        # input_slots > 1 (with adopt_inputs): the feeder hands over batches in a RING of that many resident buffers (a DMA
+        # target per slot).  The forward + backward graph is then captured once PER SLOT, reading that slot's tensors in
+        # place -- the first step that sees a new slot runs kernel by kernel and captures it -- so no step pays a
+        # device-to-device copy of its batch into a private input buffer; clip + Adam (which read no inputs) stay one graph.
+        # The graphs share one memory pool: they never run concurrently.  A batch in none of the slots is copied into slot 0.
+        self.input_slots = max(1, int(input_slots)) if self.adopt_inputs else 1
+        self._slots = []
         self._graph = None
         self._eager_steps = 0
         # overlap (GPU path, models that offer late_parameters() / forward_with_cut(): CoR2, ODA): backward runs in two halves;
@@ -448,30 +455,65 @@ class DataParallelTrainer:
             # the capture (dropout is baked into the graph): this step is launched kernel by kernel; the captured graphs
             # stay valid for the regular steps that follow
             return self.step_eager(sample, target)
-        for k, t in g["sample"].items():
-            if sample[k].data_ptr() != t.data_ptr():
-                t.copy_(sample[k], non_blocking=True)
-        if target.data_ptr() != g["target"].data_ptr():
-            g["target"].copy_(target, non_blocking=True)
+        slot = self._slot_of(sample, target)
+        if slot is None and len(self._slots) < self.input_slots:
+            # a slot of the feeder's ring the step has not been captured on yet: this step runs kernel by kernel (the same
+            # launches, device-side seed and step scalars as a replay), then the front graph is captured on the slot's tensors
+            self._set_step_scalars()
+            loss = self._front(sample, target)
+            if self.reduce:
+                dist.all_reduce(f.g, op=dist.ReduceOp.SUM, group=self.group)
+            self._tail()
+            try:
+                self._slots.append(self._capture_front(sample, target, g["pool"], ("front",)))
+            except Exception as e:        # noqa: BLE001 -- keep training: further batches of this slot are copied into slot 0
+                import sys
+                print("[vqa trainer] capture of input slot %d failed (%s: %s); its batches will be copied into slot 0"
+                      % (len(self._slots), type(e).__name__, str(e).splitlines()[0] if str(e) else ""), file=sys.stderr)
+                self.input_slots = len(self._slots)
+                torch.cuda.synchronize()
+            return loss, f.norm_and_coef[0]
+        if slot is None:
+            slot = g
+            for k, t in g["sample"].items():
+                if sample[k].data_ptr() != t.data_ptr():
+                    t.copy_(sample[k], non_blocking=True)
+            if target.data_ptr() != g["target"].data_ptr():
+                g["target"].copy_(target, non_blocking=True)
         self._set_step_scalars()
-        g["front"].replay()
+        slot["front"].replay()
         if self.reduce:
             dist.all_reduce(f.g, op=dist.ReduceOp.SUM, group=self.group)
         g["tail"].replay()
-        return g["loss"], f.norm_and_coef[0]
+        return slot["loss"], f.norm_and_coef[0]
 
-    def _capture(self, sample, target):
+    def _slot_of(self, sample, target):
+        """The captured input slot whose tensors ARE this batch's (same addresses), or None."""
+        for slot in self._slots:
+            if target.data_ptr() == slot["target"].data_ptr() and all(
+                    sample[k].data_ptr() == t.data_ptr() for k, t in slot["sample"].items()):
+                return slot
+        return None
+
+    def _capture_front(self, sample, target, pool, names):
+        """Capture forward + loss + backward + gather (names = ("front",)) or its two halves (("front_a", "front_b")) reading
+        `sample` / `target` -- the caller's tensors with adopt_inputs, private copies otherwise.  -> the slot record."""
         static_sample = {k: (v if self.adopt_inputs else v.clone()) for k, v in sample.items()
                          if isinstance(v, torch.Tensor) and k in self._model_keys(sample)}
         if not self.adopt_inputs:
             target = target.clone()
+        split = len(names) == 2
         # torch's capture recipe: one forward+backward on a side stream first, so the parameters' AccumulateGrad
         # nodes belong to a capturable stream (nodes created on the default stream would run there and abort the
         # capture).  It only refills the gradient buffer; no parameter is updated.
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            self._front(static_sample, target)
+            if split:
+                self._front_a(static_sample, target)
+                self._front_b()
+            else:
+                self._front(static_sample, target)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         mode = "global"
@@ -483,28 +525,45 @@ class DataParallelTrainer:
             torch.cuda.synchronize()
             time.sleep(1.0)
             mode = "thread_local"
-        front, tail = torch.cuda.CUDAGraph(keep_graph=True), torch.cuda.CUDAGraph(keep_graph=True)
-        pool = torch.cuda.graph_pool_handle()
-        with torch.cuda.graph(front, pool=pool, capture_error_mode=mode):
-            loss = self._front(static_sample, target)
-        with torch.cuda.graph(tail, pool=pool, capture_error_mode=mode):
-            self._tail()
+        graphs = {k: torch.cuda.CUDAGraph(keep_graph=True) for k in names}
+        if split:
+            with torch.cuda.graph(graphs["front_a"], pool=pool, capture_error_mode=mode):
+                loss = self._front_a(static_sample, target)
+            with torch.cuda.graph(graphs["front_b"], pool=pool, capture_error_mode=mode):
+                self._front_b()
+        else:
+            with torch.cuda.graph(graphs["front"], pool=pool, capture_error_mode=mode):
+                loss = self._front(static_sample, target)
+        self._audit_and_instantiate(graphs)
+        return dict(graphs, loss=loss, sample=static_sample, target=target, mode=mode)
+
+    def _audit_and_instantiate(self, graphs):
         # Audit before instantiating: a memset node (hipMemsetAsync under capture) is replayed correctly once and then
         # writes garbage on ROCm 7.2 (tools/graph_memset_check.py).  The library and the model issue none -- zero fills
         # are kernels, the loss and the bias gradients avoid torch's semaphore-based reductions -- and a step that
         # contains one anyway (a user-supplied seq2vec, a new torch op) must not be replayed.
-        self.graph_nodes = {"front": graph_node_types(front), "tail": graph_node_types(tail)}
-        if any("kernel" not in c for c in self.graph_nodes.values()):
+        nodes = {k: graph_node_types(v) for k, v in graphs.items()}
+        self.graph_nodes = dict(getattr(self, "graph_nodes", None) or {}, **nodes)
+        if any("kernel" not in c for c in nodes.values()):
             # the audit could not read the graphs (runtime library not queryable): unknown is not "clean" -- stay eager
             raise RuntimeError("cannot audit the captured graphs for memset nodes (hipGraphGetNodes unavailable)")
-        memsets = sum(c.get("memset", 0) for c in self.graph_nodes.values())
+        memsets = sum(c.get("memset", 0) for c in nodes.values())
         if memsets:
             raise RuntimeError("captured step holds %d memset node(s), which do not replay reliably" % memsets)
-        front.instantiate()
-        tail.instantiate()
+        for v in graphs.values():
+            v.instantiate()
         torch.cuda.synchronize()
-        self._graph = {"front": front, "tail": tail, "loss": loss, "sample": static_sample, "target": target,
-                       "training": self.model.training}
+
+    def _capture(self, sample, target):
+        pool = torch.cuda.graph_pool_handle()
+        self.graph_nodes = {}
+        slot = self._capture_front(sample, target, pool, ("front",))
+        tail = torch.cuda.CUDAGraph(keep_graph=True)
+        with torch.cuda.graph(tail, pool=pool, capture_error_mode=slot["mode"]):
+            self._tail()
+        self._audit_and_instantiate({"tail": tail})
+        self._slots = [slot]
+        self._graph = dict(slot, tail=tail, pool=pool, training=self.model.training)
 
     # ---- backward in two halves, the first all-reduce under the second (overlap=True) ---------------------------------
     def _front_a(self, sample, target, device_seed=True):
@@ -596,57 +655,48 @@ class DataParallelTrainer:
         if self.model.training != g["training"] or target.shape != g["target"].shape or any(
                 k not in sample or sample[k].shape != t.shape or sample[k].dtype != t.dtype for k, t in g["sample"].items()):
             return self.step_eager(sample, target)
-        for k, t in g["sample"].items():
-            if sample[k].data_ptr() != t.data_ptr():
-                t.copy_(sample[k], non_blocking=True)
-        if target.data_ptr() != g["target"].data_ptr():
-            g["target"].copy_(target, non_blocking=True)
+        slot = self._slot_of(sample, target)
+        if slot is None and len(self._slots) < self.input_slots:      # a new slot of the feeder's ring: see _graph_step
+            self._set_step_scalars()
+            loss = self._front_a(sample, target)
+            pending = self._reduce_late_async()
+            self._front_b()
+            self._reduce_early(pending)
+            self._tail()
+            try:
+                self._slots.append(self._capture_front(sample, target, g["pool"], ("front_a", "front_b")))
+            except Exception as e:        # noqa: BLE001
+                import sys
+                print("[vqa trainer] capture of input slot %d failed (%s: %s); its batches will be copied into slot 0"
+                      % (len(self._slots), type(e).__name__, str(e).splitlines()[0] if str(e) else ""), file=sys.stderr)
+                self.input_slots = len(self._slots)
+                torch.cuda.synchronize()
+            return loss, f.norm_and_coef[0]
+        if slot is None:
+            slot = g
+            for k, t in g["sample"].items():
+                if sample[k].data_ptr() != t.data_ptr():
+                    t.copy_(sample[k], non_blocking=True)
+            if target.data_ptr() != g["target"].data_ptr():
+                g["target"].copy_(target, non_blocking=True)
         self._set_step_scalars()
-        g["front_a"].replay()
+        slot["front_a"].replay()
         pending = self._reduce_late_async()
-        g["front_b"].replay()
+        slot["front_b"].replay()
         self._reduce_early(pending)
         g["tail"].replay()
-        return g["loss"], f.norm_and_coef[0]
+        return slot["loss"], f.norm_and_coef[0]
 
     def _capture_split(self, sample, target):
-        static_sample = {k: (v if self.adopt_inputs else v.clone()) for k, v in sample.items()
-                         if isinstance(v, torch.Tensor) and k in self._model_keys(sample)}
-        if not self.adopt_inputs:
-            target = target.clone()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            self._front_a(static_sample, target)
-            self._front_b()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        mode = "global"
-        if self.reduce:
-            import time
-            dist.barrier(group=self.group)
-            torch.cuda.synchronize()
-            time.sleep(1.0)
-            mode = "thread_local"
-        graphs = {k: torch.cuda.CUDAGraph(keep_graph=True) for k in ("front_a", "front_b", "tail")}
         pool = torch.cuda.graph_pool_handle()
-        with torch.cuda.graph(graphs["front_a"], pool=pool, capture_error_mode=mode):
-            loss = self._front_a(static_sample, target)
-        with torch.cuda.graph(graphs["front_b"], pool=pool, capture_error_mode=mode):
-            self._front_b()
-        with torch.cuda.graph(graphs["tail"], pool=pool, capture_error_mode=mode):
+        self.graph_nodes = {}
+        slot = self._capture_front(sample, target, pool, ("front_a", "front_b"))
+        tail = torch.cuda.CUDAGraph(keep_graph=True)
+        with torch.cuda.graph(tail, pool=pool, capture_error_mode=slot["mode"]):
             self._tail()
-        self.graph_nodes = {k: graph_node_types(v) for k, v in graphs.items()}
-        if any("kernel" not in c for c in self.graph_nodes.values()):
-            # the audit could not read the graphs (runtime library not queryable): unknown is not "clean" -- stay eager
-            raise RuntimeError("cannot audit the captured graphs for memset nodes (hipGraphGetNodes unavailable)")
-        memsets = sum(c.get("memset", 0) for c in self.graph_nodes.values())
-        if memsets:
-            raise RuntimeError("captured step holds %d memset node(s), which do not replay reliably" % memsets)
-        for v in graphs.values():
-            v.instantiate()
-        torch.cuda.synchronize()
-        self._graph = dict(graphs, loss=loss, sample=static_sample, target=target, training=self.model.training)
+        self._audit_and_instantiate({"tail": tail})
+        self._slots = [slot]
+        self._graph = dict(slot, tail=tail, pool=pool, training=self.model.training)
 
     @property
     def lr(self):
