@@ -895,9 +895,10 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd_bf16(const vqa_bf16_t* x, const v
                                                     const vqa_bf16_t* h1, const vqa_bf16_t* g, vqa_bf16_t* d_x,
                                                     float* const* d_w1, float* const* d_b1, float* d_h2, void* workspace,
                                                     size_t workspace_bytes, int B, int N, int L, int H, int R, int H_out,
-                                                    int L_out, int gate_dx, vqa_stream_t stream) {
+                                                    int L_out, int gate_dx, int phases, vqa_stream_t stream) {
   VQA_REQUIRE(x && h2 && h1 && g && d_w1 && d_b1 && d_h2 && workspace, VQA_E_BADARG,
               "lowrank_bilinear_fusion_bwd_bf16: null pointer");
+  VQA_REQUIRE(phases >= 1 && phases <= 3, VQA_E_BADARG, "lowrank_bilinear_fusion_bwd_bf16: phases must be 1, 2 or 3, got %d", phases);
   VQA_REQUIRE(d_x == nullptr || w1t != nullptr, VQA_E_BADARG, "lowrank_bilinear_fusion_bwd_bf16: d_x needs w1t");
   int rc = check_k4("lowrank_bilinear_fusion_bwd_bf16", B, N, L, H, R);
   if (rc != VQA_OK) return rc;
@@ -924,7 +925,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd_bf16(const vqa_bf16_t* x, const v
 #define PREP8(RT_)                                                                                                        \
   VQA_LAUNCH(bilinear_bwd_prep8_bf16_kernel<RT_>, dim3(H / 128, B), dim3(256), 0, s, gb, h1b, h2, gs, d_h2, gsum, \
                      N, H, H_out)
-  switch (R) {
+  if (phases & 1) switch (R) {
     case 1: PREP8(1); break;
     case 2: PREP8(2); break;
     case 3: PREP8(3); break;
@@ -940,7 +941,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd_bf16(const vqa_bf16_t* x, const v
       }
   }
 #undef PREP8
-  if (d_x != nullptr) {
+  if ((phases & 1) && d_x != nullptr) {
     NtExtra ex;
     if (gate_dx) {   // x is the relu output of the layer in front: its gradient gate rides in this store
       ex.gate = reinterpret_cast<const bf16*>(x);
@@ -950,6 +951,7 @@ extern "C" int vqa_lowrank_bilinear_fusion_bwd_bf16(const vqa_bf16_t* x, const v
                    reinterpret_cast<bf16*>(d_x), L, M, L, RH, 0, s, ex);
     if (rc != VQA_OK) return rc;
   }
+  if (!(phases & 2)) return check_launch("lowrank_bilinear_fusion_bwd_bf16");
   BfDbJob dbjob;        // the bias gradients ride in the weight gradient's slab-reduction launch
   dbjob.h2 = h2;
   dbjob.gsum = gsum;

@@ -252,6 +252,11 @@ class DataParallelTrainer:
         # device-to-device copy of its batch into a private input buffer; clip + Adam (which read no inputs) stay one graph.
         # The graphs share one memory pool: they never run concurrently.  A batch in none of the slots is copied into slot 0.
         self.input_slots = max(1, int(input_slots)) if self.adopt_inputs else 1
+        # weight gradients beside the data-gradient chain (ops.side_branches): on for the bf16 configuration, whose kernels are
+        # too small to fill the chip (BASELINE configs[4]: 128 samples per GPU); VQA_SIDE_BRANCH=1 forces it on, =0 off
+        import os as _os2
+        self._side = (getattr(model, "compute_dtype", None) == torch.bfloat16 or _os2.environ.get("VQA_SIDE_BRANCH") == "1") \
+            and _os2.environ.get("VQA_SIDE_BRANCH") != "0"
         self._slots = []
         self._graph = None
         self._eager_steps = 0
@@ -358,7 +363,8 @@ class DataParallelTrainer:
             f = self.flat
             f.begin_backward()
             try:
-                loss.backward()
+                with ops.side_branches(self._side):
+                    loss.backward()
             finally:
                 f.end_backward()
             f.gather_grads()
@@ -390,7 +396,8 @@ class DataParallelTrainer:
             ops.set_device_seed(None)
         f.begin_backward()
         try:
-            torch.autograd.backward(logits, d_logits)
+            with ops.side_branches(self._side):
+                torch.autograd.backward(logits, d_logits)
         finally:
             f.end_backward()
         f.gather_grads()
@@ -581,7 +588,8 @@ class DataParallelTrainer:
         live = [(o, i) for o, i in zip(outs, ins) if i.requires_grad]
         ops.set_grad_slots(self.flat.p, self.flat.g)
         try:
-            grads = torch.autograd.grad(logits, self._late + [i for _, i in live], grad_outputs=d_logits, allow_unused=True)
+            with ops.side_branches(self._side):
+                grads = torch.autograd.grad(logits, self._late + [i for _, i in live], grad_outputs=d_logits, allow_unused=True)
         finally:
             ops.set_grad_slots(self.flat.p, None)
         self.flat.store_grads(self._late, grads[:len(self._late)])
@@ -596,7 +604,8 @@ class DataParallelTrainer:
         from . import ops
         ops.set_grad_slots(self.flat.p, self.flat.g)
         try:
-            grads = torch.autograd.grad(tensors, self._early, grad_outputs=grads_in, allow_unused=True)
+            with ops.side_branches(self._side):
+                grads = torch.autograd.grad(tensors, self._early, grad_outputs=grads_in, allow_unused=True)
         finally:
             ops.set_grad_slots(self.flat.p, None)
         self.flat.store_grads(self._early, grads)
