@@ -252,11 +252,11 @@ class DataParallelTrainer:
         # device-to-device copy of its batch into a private input buffer; clip + Adam (which read no inputs) stay one graph.
         # The graphs share one memory pool: they never run concurrently.  A batch in none of the slots is copied into slot 0.
         self.input_slots = max(1, int(input_slots)) if self.adopt_inputs else 1
-        # weight gradients beside the data-gradient chain (ops.side_branches): on for the bf16 configuration, whose kernels are
-        # too small to fill the chip (BASELINE configs[4]: 128 samples per GPU); VQA_SIDE_BRANCH=1 forces it on, =0 off
+        # weight gradients beside the data-gradient chain (ops.side_branches): OFF unless VQA_SIDE_BRANCH=1 -- measured on the
+        # bf16 configuration (BASELINE configs[4], 128 samples per GPU, the case it was built for): 1.008 ms against 0.958, the
+        # concurrent kernels slow each other by more than the chain saves (docs/measured_negatives_r05.md)
         import os as _os2
-        self._side = (getattr(model, "compute_dtype", None) == torch.bfloat16 or _os2.environ.get("VQA_SIDE_BRANCH") == "1") \
-            and _os2.environ.get("VQA_SIDE_BRANCH") != "0"
+        self._side = _os2.environ.get("VQA_SIDE_BRANCH") == "1"
         self._slots = []
         self._graph = None
         self._eager_steps = 0
