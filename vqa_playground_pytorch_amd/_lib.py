@@ -9,7 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VQA_LIB_PATH", os.path.join(_HERE, "libvqa_mi355x.so"))  # env override: profiling builds
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _c_f = ctypes.c_void_p          # device pointer to fp32
 _c_pp = ctypes.c_void_p         # host array of device pointers
@@ -113,6 +113,11 @@ SIGNATURES = {
     "vqa_lowrank_bilinear_fusion_bwd_bf16_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i, _c_i, _c_i]),
     "vqa_lowrank_bilinear_fusion_bwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_pp, _c_pp, _c_f, _c_f, _c_sz,
                                                     _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_bilinear_fold_bf16_supported": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_i]),
+    "vqa_bilinear_fold_fwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_bilinear_fold_bwd_bf16_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i, _c_i, _c_i]),
+    "vqa_bilinear_fold_bwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_pp, _c_pp, _c_f, _c_f, _c_sz,
+                                          _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
     "vqa_gate_product_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_st]),
     "vqa_grouped_gemm": (_c_i, [ctypes.c_void_p, _c_i, _c_st]),
     "vqa_grouped_epilogue": (_c_i, [ctypes.c_void_p, _c_i, _c_st]),

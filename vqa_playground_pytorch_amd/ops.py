@@ -846,6 +846,9 @@ def linear_bf16(x, w, bias=None, act=None, p_drop=0.0, seed=0, pregated=False, p
     return LinearBf16.apply(x, w, bias, act or None, float(p_drop or 0.0), seed, pregated, packed)
 
 
+K4_BF16_FORM = os.environ.get("VQA_K4_BF16_FORM", "fold")     # "fold" (default) | "rgemm"
+
+
 class LowRankBilinearFusionBf16(torch.autograd.Function):
     """K4 on the bf16 MFMA engine.  x bf16 [B,(N,)Lp] with Lp >= L zero-padded to a multiple of 64; h2 fp32 [B,R,H];
     master weights / biases fp32 ([H,L] / [H] per rank).  Returns bf16 [B,(N,)Hp], Hp = H padded to 256 (pad = 0).
@@ -885,14 +888,23 @@ class LowRankBilinearFusionBf16(torch.autograd.Function):
             w1t = None
         need_bwd = any(ctx.needs_input_grad)
         out = torch.empty(*lead, Hp, device=dev, dtype=torch.bfloat16)
-        h1 = torch.empty(B * N, R, Hp, device=dev, dtype=torch.bfloat16) if need_bwd else None
-        _launch("lowrank_bilinear_fusion_fwd_bf16", (B, N, Lp, Hp, R, need_bwd),
-                _lib.lib().vqa_lowrank_bilinear_fusion_fwd_bf16, _p(x), _p(w1p), _p(b1p), _p(h2), _p(out), _p(h1),
-                B, N, Lp, Hp, R, H)
+        # rank-folded (csrc/bilinear_fold_bf16.hip: one product per sample with the weight sum_r diag(h2_r[b]) W1_r built in
+        # registers; no h1 saved) wherever the library offers it -- R = 2, N <= 128; VQA_K4_BF16_FORM=rgemm keeps the R-GEMM form
+        fold = K4_BF16_FORM != "rgemm" and _lib.lib().vqa_bilinear_fold_bf16_supported(B, N, Lp, Hp, R) == 1
+        h1 = None
+        if fold:
+            _launch("lowrank_bilinear_fusion_fwd_bf16", (B, N, Lp, Hp, R, need_bwd), _lib.lib().vqa_bilinear_fold_fwd_bf16,
+                    _p(x), _p(w1p), _p(b1p), _p(h2), _p(out), B, N, Lp, Hp, R, H)
+        else:
+            h1 = torch.empty(B * N, R, Hp, device=dev, dtype=torch.bfloat16) if need_bwd else None
+            _launch("lowrank_bilinear_fusion_fwd_bf16", (B, N, Lp, Hp, R, need_bwd),
+                    _lib.lib().vqa_lowrank_bilinear_fusion_fwd_bf16, _p(x), _p(w1p), _p(b1p), _p(h2), _p(out), _p(h1),
+                    B, N, Lp, Hp, R, H)
         if need_bwd:
             ctx.save_for_backward(x, h2, h1, *w1)
             ctx.b1 = b1
             ctx.w1t = w1t
+            ctx.fold = (w1p, b1p) if fold else None
         ctx.dims = (B, N, L, Lp, H, Hp, R, bool(gate_dx))
         return out
 
@@ -916,6 +928,14 @@ class LowRankBilinearFusionBf16(torch.autograd.Function):
         d_b1 = [_grad_like(b) for b in ctx.b1]
         d_h2 = torch.empty(B, R, H, device=dev, dtype=torch.float32)
         L_ = _lib.lib()
+        if ctx.fold is not None:
+            w1p, b1p = ctx.fold
+            ws_bytes = L_.vqa_bilinear_fold_bwd_bf16_workspace_bytes(B, N, Lp, Hp, R)
+            ws = torch.empty((ws_bytes + 3) // 4, device=dev, dtype=torch.float32)
+            _launch("lowrank_bilinear_fusion_bwd_bf16", (B, N, Lp, Hp, R, d_x is not None), L_.vqa_bilinear_fold_bwd_bf16,
+                    _p(x), _p(w1p), _p(w1t), _p(b1p), _p(h2), _p(g), _p(d_x), _ptr_array(d_w1), _ptr_array(d_b1), _p(d_h2),
+                    _p(ws), ws_bytes, B, N, Lp, Hp, R, H, L, int(gate_dx and d_x is not None))
+            return (d_x, d_h2, None, None, *d_w1, *d_b1)
         ws_bytes = L_.vqa_lowrank_bilinear_fusion_bwd_bf16_workspace_bytes(B, N, Lp, Hp, R)
         ws = torch.empty((ws_bytes + 3) // 4, device=dev, dtype=torch.float32)
         args = (_p(x), _p(w1t), _p(h2), _p(h1), _p(g), _p(d_x), _ptr_array(d_w1), _ptr_array(d_b1), _p(d_h2), _p(ws), ws_bytes,
