@@ -497,6 +497,17 @@ def test_relation_gates_match_autograd(ops):
         sum(u * (o * g(wi)).sum() for u, o, wi in zip(use, (t, b2, t, b2), w)).backward()
         for name, x, y in (("d_q1", a, a2), ("d_q2", b, b2), ("d_pooled", c, c2)):
             close(name, x.grad, y.grad.cpu().numpy().astype(np.float64))
+    # pooled = glimpse 0 of a [B,G,D] tensor read IN PLACE (rows G * D floats apart): no contiguous copy, same numbers
+    full = g(seeded.seeded_array((B, 4, D), 451).astype(np.float32), True)
+    a, b = g(q1, True), g(q2, True)
+    outs = ops.relation_gates(a, b, full[:, 0])
+    sum((o * g(wi)).sum() for o, wi in zip(outs, w)).backward()
+    full2, a2, b2 = full.detach().clone().requires_grad_(), g(q1, True), g(q2, True)
+    t = a2 * full2[:, 0]
+    sum((o * g(wi)).sum() for o, wi in zip((t, b2, t, b2), w)).backward()
+    close("t (strided pooled)", outs[0], t.detach().cpu().numpy().astype(np.float64))
+    for name, x, y in (("d_q1", a, a2), ("d_q2", b, b2), ("d_pooled", full, full2)):
+        close(name + " (strided pooled)", x.grad, y.grad.cpu().numpy().astype(np.float64))
 
 
 # ----------------------------------------------------------------------------------------------- K2

@@ -118,7 +118,8 @@ SIGNATURES = {
     "vqa_bilinear_fold_bwd_bf16_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i, _c_i, _c_i]),
     "vqa_bilinear_fold_bwd_bf16": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_pp, _c_pp, _c_f, _c_f, _c_sz,
                                           _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),
-    "vqa_gate_product_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_st]),
+    "vqa_gate_product_fwd": (_c_i, [_c_f, _c_f, ctypes.c_long, _c_f, _c_i, _c_i, _c_st]),
+    "vqa_gate_product_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_long, _c_f, _c_f, _c_f, _c_i, _c_i, _c_st]),
     "vqa_grouped_gemm": (_c_i, [ctypes.c_void_p, _c_i, _c_st]),
     "vqa_grouped_epilogue": (_c_i, [ctypes.c_void_p, _c_i, _c_st]),
     "vqa_gru_gates_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_f, _c_f, _c_f, _c_f,

@@ -161,35 +161,60 @@ __global__ __launch_bounds__(256) void dropout_groups_bwd_kernel(const float* __
 using namespace vqa;
 
 namespace vqa {
-// backward of (t, c) = (a * b, c) handed to TWO consumers each: d_a = (g1 + g2) b, d_b = (g1 + g2) a, d_c = h1 + h2
-// (g2 / h2 may be NULL).  One launch for what autograd would do in two accumulations and two products.
-__global__ __launch_bounds__(256) void gate_product_bwd_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
-                                                               const float* __restrict__ h1, const float* __restrict__ h2,
-                                                               const float* __restrict__ a, const float* __restrict__ b,
-                                                               float* __restrict__ d_a, float* __restrict__ d_b,
-                                                               float* __restrict__ d_c, size_t n4) {
+// t = a * b with b a strided-row view (rows of `cols` floats, ldb apart): the relation step's t = q1 * pooled[:, 0] read straight
+// from the [B,G,D] pooled tensor (no contiguous copy of the slice, no torch multiply)
+__global__ __launch_bounds__(256) void gate_product_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, long ldb,
+                                                               float* __restrict__ t, int cols4, size_t n4) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
+  const size_t row = i / (size_t)cols4, c4 = i - row * (size_t)cols4;
+  st4(t + 4 * i, mul4(ld4(a + 4 * i), ld4(b + row * ldb + 4 * c4)));
+}
+// backward of (t, c) = (a * b, c) handed to TWO consumers each: d_a = (g1 + g2) b, d_b = (g1 + g2) a, d_c = h1 + h2
+// (g2 / h2 may be NULL).  One launch for what autograd would do in two accumulations and two products.  b: rows ldb apart.
+__global__ __launch_bounds__(256) void gate_product_bwd_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                               const float* __restrict__ h1, const float* __restrict__ h2,
+                                                               const float* __restrict__ a, const float* __restrict__ b, long ldb,
+                                                               float* __restrict__ d_a, float* __restrict__ d_b,
+                                                               float* __restrict__ d_c, int cols4, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const size_t row = i / (size_t)cols4, c4 = i - row * (size_t)cols4;
   float4 g = ld4(g1 + 4 * i);
   if (g2 != nullptr) g = add4(g, ld4(g2 + 4 * i));
   float4 h = ld4(h1 + 4 * i);
   if (h2 != nullptr) h = add4(h, ld4(h2 + 4 * i));
-  st4(d_a + 4 * i, mul4(g, ld4(b + 4 * i)));
+  st4(d_a + 4 * i, mul4(g, ld4(b + row * ldb + 4 * c4)));
   st4(d_b + 4 * i, mul4(g, ld4(a + 4 * i)));
   st4(d_c + 4 * i, h);
 }
 }  // namespace vqa
 
+extern "C" int vqa_gate_product_fwd(const float* a, const float* b, long ldb, float* t, int rows, int cols, vqa_stream_t stream) {
+  VQA_REQUIRE(a && b && t, VQA_E_BADARG, "gate_product_fwd: null pointer");
+  VQA_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && ldb >= cols && ldb % 4 == 0, VQA_E_UNSUPPORTED,
+              "gate_product_fwd: cols = %d and ldb = %ld must be positive multiples of 4, ldb >= cols", cols, ldb);
+  VQA_REQUIRE(vqa::aligned(a, 16) && vqa::aligned(b, 16) && vqa::aligned(t, 16), VQA_E_UNSUPPORTED,
+              "gate_product_fwd: tensors must be 16-byte aligned");
+  const size_t n4 = (size_t)rows * cols / 4;
+  VQA_LAUNCH(vqa::gate_product_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a, b,
+             ldb, t, cols / 4, n4);
+  return vqa::check_launch("gate_product_fwd");
+}
+
 extern "C" int vqa_gate_product_bwd(const float* g1, const float* g2, const float* h1, const float* h2, const float* a,
-                                    const float* b, float* d_a, float* d_b, float* d_c, size_t n, vqa_stream_t stream) {
+                                    const float* b, long ldb, float* d_a, float* d_b, float* d_c, int rows, int cols,
+                                    vqa_stream_t stream) {
   VQA_REQUIRE(g1 && h1 && a && b && d_a && d_b && d_c, VQA_E_BADARG, "gate_product_bwd: null pointer");
-  VQA_REQUIRE(n > 0 && n % 4 == 0, VQA_E_UNSUPPORTED, "gate_product_bwd: n = %zu must be a positive multiple of 4", n);
+  VQA_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && ldb >= cols && ldb % 4 == 0, VQA_E_UNSUPPORTED,
+              "gate_product_bwd: cols = %d and ldb = %ld must be positive multiples of 4, ldb >= cols", cols, ldb);
   VQA_REQUIRE(vqa::aligned(g1, 16) && vqa::aligned(h1, 16) && vqa::aligned(a, 16) && vqa::aligned(b, 16) && vqa::aligned(d_a, 16) &&
                   vqa::aligned(d_b, 16) && vqa::aligned(d_c, 16) && (g2 == nullptr || vqa::aligned(g2, 16)) &&
                   (h2 == nullptr || vqa::aligned(h2, 16)),
               VQA_E_UNSUPPORTED, "gate_product_bwd: tensors must be 16-byte aligned");
-  VQA_LAUNCH(vqa::gate_product_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), g1, g2, h1, h2, a, b, d_a, d_b, d_c, n / 4);
+  const size_t n4 = (size_t)rows * cols / 4;
+  VQA_LAUNCH(vqa::gate_product_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), g1, g2, h1, h2, a, b, ldb, d_a, d_b, d_c, cols / 4, n4);
   return vqa::check_launch("gate_product_bwd");
 }
 

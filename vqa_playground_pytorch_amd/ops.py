@@ -1466,10 +1466,17 @@ class RelationGates(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q1, q2, pooled):
-        q1, q2, pooled = _prep("q1", q1), _prep("q2", q2), _prep("pooled", pooled)
-        if q1.shape != pooled.shape or q2.shape != pooled.shape or pooled.numel() % 4:
-            raise ValueError("relation_gates: q1, q2, pooled must share one shape with a multiple of 4 elements")
-        t = q1 * pooled
+        q1, q2 = _prep("q1", q1), _prep("q2", q2)
+        # pooled: [B,D] dense, or glimpse 0 of the [B,G,D] pooled tensor read in place (rows D floats wide, G * D apart)
+        if pooled.dim() != 2 or pooled.stride(1) != 1 or pooled.dtype != torch.float32 or not pooled.is_cuda or \
+                pooled.stride(0) % 4 or pooled.data_ptr() % 16:
+            pooled = _prep("pooled", pooled)
+        if q1.shape != pooled.shape or q2.shape != pooled.shape or pooled.shape[1] % 4:
+            raise ValueError("relation_gates: q1, q2, pooled must share one [B,D] shape with D a multiple of 4")
+        rows, cols = pooled.shape
+        t = torch.empty_like(q1)
+        _launch("gate_product_fwd", (q1.numel(),), _lib.lib().vqa_gate_product_fwd, _p(q1), _p(pooled), pooled.stride(0), _p(t),
+                rows, cols)
         ctx.save_for_backward(q1, pooled)
         return t, q2.view_as(q2), t.view_as(t), q2.view_as(q2)
 
@@ -1488,8 +1495,9 @@ class RelationGates(torch.autograd.Function):
         g2 = _prep("d_t'", g2) if g2 is not None else None
         h2 = _prep("d_c2'", h2) if h2 is not None else None
         d_q1, d_pooled, d_q2 = torch.empty_like(q1), torch.empty_like(q1), torch.empty_like(q1)
+        rows, cols = pooled.shape
         _launch("gate_product_bwd", (q1.numel(),), _lib.lib().vqa_gate_product_bwd, _p(g1), _p(g2), _p(h1), _p(h2), _p(q1),
-                _p(pooled), _p(d_q1), _p(d_pooled), _p(d_q2), q1.numel())
+                _p(pooled), pooled.stride(0), _p(d_q1), _p(d_pooled), _p(d_q2), rows, cols)
         return d_q1, d_q2, d_pooled
 
 
@@ -1512,7 +1520,14 @@ class WithFirstGroup(torch.autograd.Function):
         if g_full is None and g_first is None:
             return None
         ref = g_full if g_full is not None else g_first
-        g = g_full.clone() if g_full is not None else torch.zeros(ctx.shape, device=ref.device, dtype=ref.dtype)
+        # (the full gradient is the fresh output of the glimpse projections' backward and has no other reader: the slice is
+        #  added IN PLACE -- a clone first was a 16.8 MB device copy per step)
+        if g_full is None:
+            g = torch.zeros(ctx.shape, device=ref.device, dtype=ref.dtype)
+        elif g_first is not None and not g_full.is_contiguous():      # (an expanded gradient -- sum().backward() -- is not writable)
+            g = g_full.clone()
+        else:
+            g = g_full
         if g_first is not None:
             g[:, 0].add_(g_first)
         return g
