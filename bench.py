@@ -57,12 +57,7 @@ def work_of(name, shape):
         return "mfma", B * (2 * R * N * L * H + 2 * R * N * H)
     if base == "lowrank_bilinear_fusion_bwd":
         B, N, L, H, R, dx = s[:6]
-        if len(s) > 6 and s[6]:                                                       # the data path alone (the weight gradients
-            return "mfma", B * (2 * R * N * L * H) * (1 if dx else 0) or None         # are their own launch on the side branch)
         return "mfma", B * (2 * R * N * L * H) * (2 if dx else 1)                    # dW1 (+ dx) contractions
-    if base == "lowrank_bilinear_fusion_dw":
-        B, N, L, H, R = s[:5]
-        return "mfma", B * (2 * R * N * L * H)
     if base in ("linear_act_fwd", "linear_act_fwd_split"):
         M, K, N = s[:3]
         return "mfma", 2 * M * K * N                                                  # the fp32 GEMM's FLOPs on either engine

@@ -73,28 +73,43 @@ __global__ __launch_bounds__(256) void fold_fwd_kernel(const bf16* __restrict__ 
   for (int hb = 0; hb < 4; ++hb)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[hb][nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  const int chunks = L / 32;
-  for (int c = 0; c < chunks; ++c) {
-    u32x4 raw[kR][4], bx[NB], a[4];
+  // One wave per SIMD and operands straight from L2: nothing hides a load but the loop itself -- the raw fragments of chunk c + 1
+  // are requested before chunk c is folded and multiplied (two register sets, L / 32 is even)
+  struct Raw {
+    u32x4 w[kR][4], x[NB];
+  };
+  auto load = [&](Raw& o, int c) {
 #pragma unroll
     for (int hb = 0; hb < 4; ++hb)
 #pragma unroll
-      for (int r = 0; r < kR; ++r) raw[r][hb] = ldg16(wa[r][hb] + 32 * c);
+      for (int r = 0; r < kR; ++r) o.w[r][hb] = ldg16(wa[r][hb] + 32 * c);
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) bx[nb] = ldg16(xb[nb] + 32 * c);
+    for (int nb = 0; nb < NB; ++nb) o.x[nb] = ldg16(xb[nb] + 32 * c);
+  };
+  auto compute = [&](const Raw& in) {
+    u32x4 a[4];
 #pragma unroll
     for (int hb = 0; hb < 4; ++hb)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        f32x2 s = unpack2(raw[0][hb][e]) * q[0][hb];
+        f32x2 s = unpack2(in.w[0][hb][e]) * q[0][hb];
 #pragma unroll
-        for (int r = 1; r < kR; ++r) s += unpack2(raw[r][hb][e]) * q[r][hb];
+        for (int r = 1; r < kR; ++r) s += unpack2(in.w[r][hb][e]) * q[r][hb];
         a[hb][e] = pack2(s);
       }
 #pragma unroll
     for (int hb = 0; hb < 4; ++hb)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc[hb][nb] = mfma(a[hb], bx[nb], acc[hb][nb]);
+      for (int nb = 0; nb < NB; ++nb) acc[hb][nb] = mfma(a[hb], in.x[nb], acc[hb][nb]);
+  };
+  const int chunks = L / 32;
+  Raw r0, r1;
+  load(r0, 0);
+  for (int c = 0; c < chunks; c += 2) {
+    load(r1, c + 1);
+    compute(r0);
+    load(r0, min(c + 2, chunks - 1));
+    compute(r1);
   }
   // D of block (hb, nb): rows = features h0 + 16 hb + 4 g + i, column = region 16 nb + r16
 #pragma unroll
@@ -152,15 +167,19 @@ __global__ __launch_bounds__(256) void fold_dx_kernel(const bf16* __restrict__ g
   for (int lb = 0; lb < 4; ++lb)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[lb][nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  const int chunks = H / 32;
-  for (int c = 0; c < chunks; ++c) {
-    u32x4 raw[kR][4], bx[NB], a[4];
+  struct Raw {
+    u32x4 w[kR][4], x[NB];
+  };
+  auto load = [&](Raw& o, int c) {
 #pragma unroll
     for (int lb = 0; lb < 4; ++lb)
 #pragma unroll
-      for (int r = 0; r < kR; ++r) raw[r][lb] = ldg16(wa[lb] + (size_t)r * H + 32 * c);
+      for (int r = 0; r < kR; ++r) o.w[r][lb] = ldg16(wa[lb] + (size_t)r * H + 32 * c);
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) bx[nb] = ldg16(gb[nb] + 32 * c);
+    for (int nb = 0; nb < NB; ++nb) o.x[nb] = ldg16(gb[nb] + 32 * c);
+  };
+  auto compute = [&](const Raw& in, int c) {
+    u32x4 a[4];
     f32x2 qv[kR][4];      // h2_r[b, 32 c + 8 g + 2 e .. + 1]
 #pragma unroll
     for (int r = 0; r < kR; ++r) {
@@ -175,15 +194,24 @@ __global__ __launch_bounds__(256) void fold_dx_kernel(const bf16* __restrict__ g
     for (int lb = 0; lb < 4; ++lb)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        f32x2 s = unpack2(raw[0][lb][e]) * qv[0][e];
+        f32x2 s = unpack2(in.w[0][lb][e]) * qv[0][e];
 #pragma unroll
-        for (int r = 1; r < kR; ++r) s += unpack2(raw[r][lb][e]) * qv[r][e];
+        for (int r = 1; r < kR; ++r) s += unpack2(in.w[r][lb][e]) * qv[r][e];
         a[lb][e] = pack2(s);
       }
 #pragma unroll
     for (int lb = 0; lb < 4; ++lb)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc[lb][nb] = mfma(a[lb], bx[nb], acc[lb][nb]);
+      for (int nb = 0; nb < NB; ++nb) acc[lb][nb] = mfma(a[lb], in.x[nb], acc[lb][nb]);
+  };
+  const int chunks = H / 32;      // (even: H % 64 == 0)
+  Raw r0, r1;
+  load(r0, 0);
+  for (int c = 0; c < chunks; c += 2) {
+    load(r1, c + 1);
+    compute(r0, c);
+    load(r0, min(c + 2, chunks - 1));
+    compute(r1, c + 1);
   }
 #pragma unroll
   for (int lb = 0; lb < 4; ++lb) {
@@ -258,22 +286,44 @@ __global__ __launch_bounds__(256, 1) void fold_dw_kernel(DwArgs p) {
   // transposing reads: lane 4 q + p of a 16-lane group addresses row q, columns 4 p .. 4 p + 3 of a 4 x 16 block
   const int tq = r16 >> 2, tp = r16 & 3;
   const int b_lo = slab * p.sps, b_hi = min(p.B, b_lo + p.sps);
+  // staging: 16-byte pieces, rows = regions (zero past N); the next sample's pieces are requested while this one is multiplied
+  constexpr int XP = (ROWS * (LBW * 4) + 255) / 256, GP = ROWS * 8 / 256;      // pieces per thread (Lh / 8 = 4 LBW per row)
+  u32x4 sx[XP], sg[GP];
+  auto fetch = [&](int b) {
+#pragma unroll
+    for (int k = 0; k < XP; ++k) {
+      const int t = threadIdx.x + 256 * k;
+      const int row = t / (LBW * 4), pc = t - row * (LBW * 4);
+      sx[k] = u32x4{0u, 0u, 0u, 0u};
+      if (row < N) sx[k] = ldg16(p.x + ((size_t)b * N + row) * L + lbase + 8 * pc);
+    }
+#pragma unroll
+    for (int k = 0; k < GP; ++k) {
+      const int t = threadIdx.x + 256 * k;
+      const int row = t >> 3, pc = t & 7;
+      sg[k] = u32x4{0u, 0u, 0u, 0u};
+      if (row < N) sg[k] = ldg16(p.g + ((size_t)b * N + row) * H + h0 + 8 * pc);
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int k = 0; k < XP; ++k) {
+      const int t = threadIdx.x + 256 * k;
+      const int row = t / (LBW * 4), pc = t - row * (LBW * 4);
+      if (row < ROWS) *reinterpret_cast<u32x4*>(xs + (size_t)row * pitch_x + 16 * pc) = sx[k];
+    }
+#pragma unroll
+    for (int k = 0; k < GP; ++k) {
+      const int t = threadIdx.x + 256 * k;
+      *reinterpret_cast<u32x4*>(gs + (size_t)(t >> 3) * pitch_g + 16 * (t & 7)) = sg[k];
+    }
+  };
+  if (b_lo < b_hi) fetch(b_lo);
   for (int b = b_lo; b < b_hi; ++b) {
     __syncthreads();      // the previous sample's fragments have been read
-    // stage: 16-byte pieces, rows = regions (zero past N)
-    for (int t = threadIdx.x; t < ROWS * (Lh / 8); t += 256) {
-      const int row = t / (Lh / 8), pc = t - row * (Lh / 8);
-      u32x4 v = u32x4{0u, 0u, 0u, 0u};
-      if (row < N) v = ldg16(p.x + ((size_t)b * N + row) * L + lbase + 8 * pc);
-      *reinterpret_cast<u32x4*>(xs + (size_t)row * pitch_x + 16 * pc) = v;
-    }
-    for (int t = threadIdx.x; t < ROWS * 8; t += 256) {
-      const int row = t >> 3, pc = t & 7;
-      u32x4 v = u32x4{0u, 0u, 0u, 0u};
-      if (row < N) v = ldg16(p.g + ((size_t)b * N + row) * H + h0 + 8 * pc);
-      *reinterpret_cast<u32x4*>(gs + (size_t)row * pitch_g + 16 * pc) = v;
-    }
+    stage();
     __syncthreads();
+    if (b + 1 < b_hi) fetch(b + 1);
     f32x4v P[2][LBW];
 #pragma unroll
     for (int j = 0; j < 2; ++j)

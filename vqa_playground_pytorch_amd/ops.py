@@ -69,98 +69,6 @@ def _launch(name, shape, fn, *args):
     _lib.check(rc, name)
 
 
-# ---- side branch -----------------------------------------------------------------------------------------------------
-# Weight and bias gradients feed nothing but the optimizer.  In a step whose kernels are too small to fill 256 CUs (the bf16
-# configuration at 128 samples per GPU: 89-240 workgroups per GEMM, two dozen launch-floor kernels in the data-gradient chain)
-# they can run BESIDE that chain instead of inside it: forked onto a second stream where their operands exist, joined once
-# backward has returned.  Captured into the step's hipGraph this is a second branch of the graph.  The trainer scopes it
-# (`side_branches()` around its backward; a caller that reads gradients right after autograd.backward() without the join would
-# race), and it is off where it was measured to lose: the fp32 register-tile / split kernels hold a whole CU each (one wave per
-# SIMD, ~450 registers), a second such kernel interleaves with the chain's instead of co-residing (CoR2 B = 512: +6 %,
-# docs/measured_negatives_r04.md).  VQA_SIDE_BRANCH=0 switches it off everywhere, =1 on for every op that offers it.
-_side = {"on": False, "stream": {}, "pending": set()}
-_SIDE_ENV = os.environ.get("VQA_SIDE_BRANCH", "auto")
-
-
-class side_branches:
-    """`with ops.side_branches(): backward` -- ops may fork weight-gradient work onto the side stream; joined on exit."""
-
-    def __init__(self, enabled=True):
-        self.enabled = bool(enabled) and _SIDE_ENV != "0"
-
-    def __enter__(self):
-        self.was = _side["on"]
-        _side["on"] = self.enabled
-        return self
-
-    def __exit__(self, *exc):
-        _side["on"] = self.was
-        join_side_branch()
-        return False
-
-
-def side_branch_active():
-    return _side["on"]
-
-
-class _SideBranch:
-    """Everything launched inside runs on the device's side stream, ordered behind what the current stream has enqueued so far.
-    `tensors`: operands allocated on the main stream that the side work reads or writes -- the allocator must not hand their
-    memory to a later main-stream kernel before the side work is done (under capture: not at all inside this graph)."""
-
-    def __init__(self, tensors):
-        self.tensors = [t for t in tensors if t is not None]
-
-    def __enter__(self):
-        cur = torch.cuda.current_stream()
-        dev = cur.device_index
-        side = _side["stream"].get(dev)
-        if side is None:
-            side = _side["stream"][dev] = torch.cuda.Stream(device=dev)
-        side.wait_stream(cur)
-        for t in self.tensors:
-            t.record_stream(side)
-        _side["pending"].add(dev)
-        self.ctx = torch.cuda.stream(side)
-        self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        return self.ctx.__exit__(*exc)
-
-
-class _NoBranch:
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        return False
-
-
-def _slot_views(grads):
-    """Are these gradient tensors all views of the trainer's flat gradient buffer (ops._grad_like found their slots)?  Only then
-    may the kernels that write them leave the chain: autograd adopts such a tensor as .grad without launching anything, while
-    a fresh tensor would be accumulated by a main-stream kernel that must not overtake the side stream's writes."""
-    return all(t is None or t._base is not None for t in grads)
-
-
-def side_branch(*tensors, want=True):
-    """Context for work that may leave the main chain (see above); a no-op unless a side_branches() scope is open."""
-    if _side["on"] and want:
-        return _SideBranch(tensors)
-    return _NoBranch()
-
-
-def join_side_branch():
-    """The current stream waits for everything forked so far (the end of backward; before the gradients are read)."""
-    if _side["pending"]:
-        cur = torch.cuda.current_stream()
-        dev = cur.device_index
-        if dev in _side["pending"]:
-            cur.wait_stream(_side["stream"][dev])
-            _side["pending"].discard(dev)
-
-
 class _Timed:
     """Event pair around library (torch / hipBLASLt) ops on the current stream, so that bench.py's per-kernel table covers
     the whole step and not only the C-ABI launches.  A no-op unless a KernelTimer is installed."""
@@ -830,11 +738,9 @@ class LinearBf16(torch.autograd.Function):
             d_x = gemm_bf16_nt(gz, wpt).view(*gy.shape[:-1], Kp)
         d_w = _grad_like(w)
         d_b = _grad_like(ctx.bias) if ctx.bias is not None else None
-        # (feeds the optimizer only: beside the data-gradient chain where a scope is open)
-        with side_branch(gz, x2, want=_slot_views([d_w, d_b])):
-            gemm_bf16_tn(gz, x2, outs=[d_w], out_rows=out_f, out_cols=in_f, p_drop=p_drop, seed=seed)
-            if d_b is not None:
-                column_sum(gz, out=d_b, cols=out_f)
+        gemm_bf16_tn(gz, x2, outs=[d_w], out_rows=out_f, out_cols=in_f, p_drop=p_drop, seed=seed)
+        if d_b is not None:
+            column_sum(gz, out=d_b, cols=out_f)
         return d_x, d_w, d_b, None, None, None, None, None
 
 
@@ -940,17 +846,8 @@ class LowRankBilinearFusionBf16(torch.autograd.Function):
         ws = torch.empty((ws_bytes + 3) // 4, device=dev, dtype=torch.float32)
         args = (_p(x), _p(w1t), _p(h2), _p(h1), _p(g), _p(d_x), _ptr_array(d_w1), _ptr_array(d_b1), _p(d_h2), _p(ws), ws_bytes,
                 B, N, Lp, Hp, R, H, L, int(gate_dx and d_x is not None))
-        branch = side_branch(ws, x, *d_w1, *d_b1, want=_slot_views(d_w1 + d_b1))
-        if isinstance(branch, _NoBranch):
-            _launch("lowrank_bilinear_fusion_bwd_bf16", (B, N, Lp, Hp, R, d_x is not None),
-                    L_.vqa_lowrank_bilinear_fusion_bwd_bf16, *args, 3)
-        else:
-            # the data path (g * h2 and d_h2, then d_x) on the chain; the weight / bias gradients -- which read the workspace the
-            # first phase filled and feed the optimizer only -- beside it
-            _launch("lowrank_bilinear_fusion_bwd_bf16", (B, N, Lp, Hp, R, d_x is not None, 1),
-                    L_.vqa_lowrank_bilinear_fusion_bwd_bf16, *args, 1)
-            with branch:
-                _launch("lowrank_bilinear_fusion_dw_bf16", (B, N, Lp, Hp, R), L_.vqa_lowrank_bilinear_fusion_bwd_bf16, *args, 2)
+        _launch("lowrank_bilinear_fusion_bwd_bf16", (B, N, Lp, Hp, R, d_x is not None),
+                L_.vqa_lowrank_bilinear_fusion_bwd_bf16, *args, 3)
         return (d_x, d_h2, None, None, *d_w1, *d_b1)
 
 

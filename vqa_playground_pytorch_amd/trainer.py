@@ -252,11 +252,6 @@ class DataParallelTrainer:
         # device-to-device copy of its batch into a private input buffer; clip + Adam (which read no inputs) stay one graph.
         # The graphs share one memory pool: they never run concurrently.  A batch in none of the slots is copied into slot 0.
         self.input_slots = max(1, int(input_slots)) if self.adopt_inputs else 1
-        # weight gradients beside the data-gradient chain (ops.side_branches): OFF unless VQA_SIDE_BRANCH=1 -- measured on the
-        # bf16 configuration (BASELINE configs[4], 128 samples per GPU, the case it was built for): 1.008 ms against 0.958, the
-        # concurrent kernels slow each other by more than the chain saves (docs/measured_negatives_r05.md)
-        import os as _os2
-        self._side = _os2.environ.get("VQA_SIDE_BRANCH") == "1"
         self._slots = []
         self._graph = None
         self._eager_steps = 0
@@ -363,8 +358,7 @@ class DataParallelTrainer:
             f = self.flat
             f.begin_backward()
             try:
-                with ops.side_branches(self._side):
-                    loss.backward()
+                loss.backward()
             finally:
                 f.end_backward()
             f.gather_grads()
@@ -396,8 +390,7 @@ class DataParallelTrainer:
             ops.set_device_seed(None)
         f.begin_backward()
         try:
-            with ops.side_branches(self._side):
-                torch.autograd.backward(logits, d_logits)
+            torch.autograd.backward(logits, d_logits)
         finally:
             f.end_backward()
         f.gather_grads()
@@ -588,8 +581,7 @@ class DataParallelTrainer:
         live = [(o, i) for o, i in zip(outs, ins) if i.requires_grad]
         ops.set_grad_slots(self.flat.p, self.flat.g)
         try:
-            with ops.side_branches(self._side):
-                grads = torch.autograd.grad(logits, self._late + [i for _, i in live], grad_outputs=d_logits, allow_unused=True)
+            grads = torch.autograd.grad(logits, self._late + [i for _, i in live], grad_outputs=d_logits, allow_unused=True)
         finally:
             ops.set_grad_slots(self.flat.p, None)
         self.flat.store_grads(self._late, grads[:len(self._late)])
@@ -604,8 +596,7 @@ class DataParallelTrainer:
         from . import ops
         ops.set_grad_slots(self.flat.p, self.flat.g)
         try:
-            with ops.side_branches(self._side):
-                grads = torch.autograd.grad(tensors, self._early, grad_outputs=grads_in, allow_unused=True)
+            grads = torch.autograd.grad(tensors, self._early, grad_outputs=grads_in, allow_unused=True)
         finally:
             ops.set_grad_slots(self.flat.p, None)
         self.flat.store_grads(self._early, grads)
