@@ -8,9 +8,9 @@ STORES in bf16 rounded to bf16 at the same point, forward and backward -- everyt
   forward   v; the packed shadows of compress_v / compress_v2 / fusion_vq{1,2}.list_linear1 weights; the outputs of
             compress_v, compress_v2 (after relu), fusion_vq1, fusion_vq2; the relation tensor v2 handed to compress_v2
   backward  the gradients of those same activations (d fuse from the attention-logit kernel, d x from K4's data-gradient
-            GEMM, d v2 from compress_v2's); K4 in its rank-folded form (the product's default, round 5): the per-sample
-            folded weight sum_r diag(h2_r) W1_r, which is the bf16 operand of its forward and data-gradient products; in
-            its R-GEMM form (k4_form="rgemm"): the rank-scaled gradient g * h2_r and the saved h1 that d h2 is contracted against
+            GEMM, d v2 from compress_v2's); K4 in its R-GEMM form (the product's default): the rank-scaled gradient g * h2_r (its
+            GEMM operand) and the saved h1 that d h2 is contracted against; in its rank-folded form (k4_form="fold", round 5): the
+            per-sample folded weight sum_r diag(h2_r) W1_r, the bf16 operand of its forward and data-gradient products
 
 With ``rounding=False`` the class computes the reference's function exactly (closed form of the relation step, see
 below) and tests/test_oracle_golden.py checks it against reference_faithful.CoR2Oracle -- that anchors this file to the
@@ -77,10 +77,10 @@ class CoR2MixedOracle(RF.CoR2Oracle):
     sample["forced_gates"] (eval mode, optional) = {"compress_v", "compress_v2": bool [b,N,310]; "att1.glimpses",
     "att2.glimpses": bool [b,620]}: the product's relu decisions at the sites a bf16 rounding can flip (see _gate)."""
 
-    def __init__(self, *args, rounding=True, k4_form="fold", **kw):
+    def __init__(self, *args, rounding=True, k4_form="rgemm", **kw):
         super().__init__(*args, **kw)
         self.rounding = rounding
-        self.k4_form = k4_form          # which of the product's two K4 forms is restated ("fold" = its default, "rgemm")
+        self.k4_form = k4_form          # which of the product's two K4 forms is restated ("rgemm" = its default, "fold")
 
     def _r(self, x, both=False):
         return _Round.apply(x, both) if self.rounding else x
@@ -111,10 +111,10 @@ class CoR2MixedOracle(RF.CoR2Oracle):
 
     def _fusion(self, mf, x_low, q_low):
         h2 = torch.stack([lin(q_low) for lin in mf.list_linear2], 1)                                     # [B,R,H] fp32
-        if self.k4_form == "rgemm":      # the product's R-GEMM form (csrc/bf16_path.hip; VQA_K4_BF16_FORM=rgemm)
+        if self.k4_form == "rgemm":      # the product's R-GEMM form (csrc/bf16_path.hip, its default)
             h1 = torch.stack([F.linear(x_low, self._r(lin.linear.weight), lin.linear.bias) for lin in mf.list_linear1], 2)
             return self._r(_RankProduct.apply(h1, h2, self.rounding), both=True)                          # [B,N,H] bf16
-        # the product's rank-folded form (csrc/bilinear_fold_bf16.hip, the default): the same sum reassociated --
+        # the product's rank-folded form (csrc/bilinear_fold_bf16.hip, VQA_K4_BF16_FORM=fold): the same sum reassociated --
         #   sum_r (x W1_r^T + b1_r) h2_r  =  x Wb^T + sum_r h2_r b1_r,   Wb = sum_r diag(h2_r[b]) W1_r  per sample --
         # with Wb folded from the bf16 shadows of W1_r in fp32 and ROUNDED to bf16 (it is the MFMA operand of the forward and of
         # the data gradient; the rounding is a straight-through step for the gradients of W1_r and h2, which the product forms

@@ -434,8 +434,8 @@ def _gradient_error(g, ref):
     return np.abs(kept).max() / np.abs(ref).max(), np.sqrt((kept ** 2).sum()) / norm, np.sqrt(rows.sum()) / norm
 
 
-@pytest.mark.parametrize("B,N", [(128, 100), (16, 36)])
-def test_cor2_bf16_at_size_against_bf16_aware_oracle(B, N):
+@pytest.mark.parametrize("B,N,k4_form", [(128, 100, "rgemm"), (16, 36, "rgemm"), (128, 100, "fold")])
+def test_cor2_bf16_at_size_against_bf16_aware_oracle(B, N, k4_form, monkeypatch):
     """BASELINE configs[4] at the size it is benchmarked at -- one rank's share of batch 1024: B = 128 samples of 100 x 2048
     regions, bf16 compute -- eval mode: logits, attention maps and EVERY parameter gradient against the bf16-aware
     restatement at RTOL_AWARE (relative Frobenius; RTOL_AWARE_MAX bounds the largest single element).  The comparison with
@@ -443,9 +443,13 @@ def test_cor2_bf16_at_size_against_bf16_aware_oracle(B, N):
     there every relu gate a bf16 rounding flips counts as error."""
     from oracle import mixed_precision as MP
     from oracle import reference_faithful as RF
+    from vqa_playground_pytorch_amd import ops as ops_mod
+    # k4_form: the product's K4 in its default R-GEMM form, and rank-folded (VQA_K4_BF16_FORM=fold; the restatement rounds the
+    # per-sample folded weight where that form does)
+    monkeypatch.setattr(ops_mod, "K4_BF16_FORM", k4_form)
     nans = 2000
     model = _build_cor2(nans, compute_dtype=torch.bfloat16)
-    aware = seeded.load_state(MP.CoR2MixedOracle(nans), 0).eval().double()
+    aware = seeded.load_state(MP.CoR2MixedOracle(nans, k4_form=k4_form), 0).eval().double()
     v, q, a = seeded.seeded_inputs(B, regions=N, answers=nans, seed=1024)
     got = model({"v": torch.from_numpy(v).to(dev()), "q_idxes": torch.from_numpy(q).to(dev())})
     assert got.dtype == torch.float32 and got.shape == (B, nans)

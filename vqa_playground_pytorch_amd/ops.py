@@ -752,7 +752,10 @@ def linear_bf16(x, w, bias=None, act=None, p_drop=0.0, seed=0, pregated=False, p
     return LinearBf16.apply(x, w, bias, act or None, float(p_drop or 0.0), seed, pregated, packed)
 
 
-K4_BF16_FORM = os.environ.get("VQA_K4_BF16_FORM", "fold")     # "fold" (default) | "rgemm"
+# "rgemm" (default: R products on the LDS-tile engine, csrc/bf16_path.hip) | "fold" (csrc/bilinear_fold_bf16.hip: one product per
+# sample with the rank-folded weight -- half the MFMA work, but a per-sample weight has no reuse across samples and the kernels are
+# L2-bound at the config's size: 139 us per fusion against 108, docs/measured_negatives_r05.md; kept as a tested alternative)
+K4_BF16_FORM = os.environ.get("VQA_K4_BF16_FORM", "rgemm")
 
 
 class LowRankBilinearFusionBf16(torch.autograd.Function):
@@ -794,9 +797,9 @@ class LowRankBilinearFusionBf16(torch.autograd.Function):
             w1t = None
         need_bwd = any(ctx.needs_input_grad)
         out = torch.empty(*lead, Hp, device=dev, dtype=torch.bfloat16)
-        # rank-folded (csrc/bilinear_fold_bf16.hip: one product per sample with the weight sum_r diag(h2_r[b]) W1_r built in
-        # registers; no h1 saved) wherever the library offers it -- R = 2, N <= 128; VQA_K4_BF16_FORM=rgemm keeps the R-GEMM form
-        fold = K4_BF16_FORM != "rgemm" and _lib.lib().vqa_bilinear_fold_bf16_supported(B, N, Lp, Hp, R) == 1
+        # VQA_K4_BF16_FORM=fold: rank-folded (csrc/bilinear_fold_bf16.hip: one product per sample with the weight
+        # sum_r diag(h2_r[b]) W1_r built in registers; no h1 saved) where the library offers it -- R = 2, N <= 128
+        fold = K4_BF16_FORM == "fold" and _lib.lib().vqa_bilinear_fold_bf16_supported(B, N, Lp, Hp, R) == 1
         h1 = None
         if fold:
             _launch("lowrank_bilinear_fusion_fwd_bf16", (B, N, Lp, Hp, R, need_bwd), _lib.lib().vqa_bilinear_fold_fwd_bf16,
