@@ -252,9 +252,11 @@ def roofline_entry(name, shape, launches, mean_ms, B, regions=REGIONS, bf16=Fals
         achieved, peak, unit = work / sec / 1e12, round(MFMA_SPLIT_PEAK_TF, 1), "TFLOP/s"
     else:  # "mfma" and "valu" share the fp32 peak on gfx950 (157.3 TFLOP/s for both pipes)
         achieved, peak, unit = work / sec / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
+    # (the ODA head at B = 512 runs K2 / K3 at the shapes of the attention-op benchmark: their rows live in that table)
+    cfgs = [] if cfg is None else [cfg] + (["oda_attention"] if model_name == "oda" and cfg == "" else [])
+    traffic = next((t for t in (pmc_traffic(name, grids, c) for c in cfgs) if t is not None), None)
     entry.update({"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
-                  "frac": round(achieved / peak, 4),
-                  "traffic": pmc_traffic(name, grids, cfg) if cfg is not None else None})
+                  "frac": round(achieved / peak, 4), "traffic": traffic})
     if name == "lowrank_bilinear_fusion_fwd" and K4_FOLDED and regions <= 112 and len(shape) >= 5 and shape[1] > 1:
         # `achieved` prices the kernel at SURVEY 8d's algorithmic FLOPs (R GEMMs per fusion).  The rank-folded kernel
         # executes 1/R of them on the matrix core, plus the padding of a sample to whole 16-region blocks and of L / H to
@@ -264,7 +266,7 @@ def roofline_entry(name, shape, launches, mean_ms, B, regions=REGIONS, bf16=Fals
         entry["form"] = "rank-folded (csrc/bilinear_folded.hip)"
         entry["mfma_flops_executed"] = int(executed)
         entry["mfma_executed_tflops"] = round(executed / sec / 1e12, 2)
-    busy = pmc_mfma(name, grids, cfg) if cfg is not None else None
+    busy = next((t for t in (pmc_mfma(name, grids, c) for c in cfgs) if t is not None), None)
     if busy is not None:
         if busy.get("mfma_busy_pct") is not None:
             entry["mfma_busy_pct"] = busy.get("mfma_busy_pct")

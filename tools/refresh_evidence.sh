@@ -1,11 +1,11 @@
 #!/bin/bash
 # Regenerates the measured evidence of a round on the MI355X box (run through gpurun from the repo root):
-#   bash tools/refresh_evidence.sh r04_f [pmc,split,bench,trace,conv]      (second argument: which parts; default all)
+#   bash tools/refresh_evidence.sh r05_f [pmc,mfma,bench,trace,conv]      (second argument: which parts; default all)
 # Writes everything under gpurun_out/<tag>/ ; copy what is to be judged into profiles/.  The counter tables of part `pmc` are
 # also installed as profiles/<round>_pmc_{traffic,mfma}.json on the box, so that the bench lines of the same call read them.
 set -u
-TAG=${1:-r04_x}
-PARTS=${2:-pmc,split,bench,trace,conv}
+TAG=${1:-r05_x}
+PARTS=${2:-pmc,mfma,bench,trace,conv}
 want() { case ",$PARTS," in *",$1,"*) return 0;; *) return 1;; esac; }
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
@@ -25,55 +25,69 @@ MFMA_CTRS="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYC
 timeout 600 rocprofv3 --pmc $MFMA_CTRS --output-format csv -d /tmp/pmc_mfma -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records --detail-file /tmp/pmc_detail.json > "$OUT/pmc_mfma.log" 2>&1
 python3 "$ROOT/tools/pmc_mfma.py" /tmp/pmc_mfma "$OUT/pmc_mfma.json" > "$OUT/pmc_mfma_table.log" 2>&1
 
-# 1c. the bf16 / 100-region step (configs[4], one rank's share): matrix-pipe counters of its kernels
+# 1c. the bf16 / 100-region step (configs[4], one rank's share): matrix-pipe counters and HBM traffic of its kernels
 rm -rf /tmp/pmc_mfma_bf16
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma_bf16 -- python3 "$ROOT/bench.py" --dtype bf16 --regions 100 --batch 128 --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records --detail-file /tmp/pmc_detail.json > "$OUT/pmc_mfma_bf16.log" 2>&1
 python3 "$ROOT/tools/pmc_mfma.py" /tmp/pmc_mfma_bf16 "$OUT/pmc_mfma_bf16_n100_b128.json" > "$OUT/pmc_mfma_bf16_table.log" 2>&1
-# 1d. K2 (the ODA attention op): VALU issue counters of its kernels
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_bf16_$c
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_bf16_$c -- python3 "$ROOT/bench.py" --dtype bf16 --regions 100 --batch 128 --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records --detail-file /tmp/pmc_detail.json > "$OUT/pmc_bf16_$c.log" 2>&1
+done
+python3 "$ROOT/tools/pmc_table.py" /tmp/pmc_bf16_FETCH_SIZE /tmp/pmc_bf16_WRITE_SIZE "$OUT/pmc_traffic_bf16_n100_b128.json" > "$OUT/pmc_table_bf16.log" 2>&1
+# 1d. K2 (the ODA attention op): VALU issue counters and HBM traffic of its kernels
 rm -rf /tmp/pmc_valu_oda
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_valu_oda -- python3 "$ROOT/bench.py" --model oda-attention --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records --detail-file /tmp/pmc_detail.json > "$OUT/pmc_valu_oda.log" 2>&1
-python3 "$ROOT/tools/pmc_mfma.py" /tmp/pmc_valu_oda "$OUT/pmc_valu_oda_attention.json" > "$OUT/pmc_valu_oda_table.log" 2>&1
+python3 "$ROOT/tools/pmc_mfma.py" /tmp/pmc_valu_oda "$OUT/pmc_mfma_oda_attention.json" > "$OUT/pmc_valu_oda_table.log" 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_oda_$c
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_oda_$c -- python3 "$ROOT/bench.py" --model oda-attention --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records --detail-file /tmp/pmc_detail.json > "$OUT/pmc_oda_$c.log" 2>&1
+done
+python3 "$ROOT/tools/pmc_table.py" /tmp/pmc_oda_FETCH_SIZE /tmp/pmc_oda_WRITE_SIZE "$OUT/pmc_traffic_oda_attention.json" > "$OUT/pmc_table_oda.log" 2>&1
+for f in pmc_mfma_bf16_n100_b128 pmc_traffic_bf16_n100_b128 pmc_mfma_oda_attention pmc_traffic_oda_attention; do
+  [ -f "$OUT/$f.json" ] && cp "$OUT/$f.json" "$ROOT/profiles/${TAG%%_*}_$f.json"
+done
 cp "$OUT/pmc_traffic.json" "$ROOT/profiles/${TAG%%_*}_pmc_traffic.json"
 cp "$OUT/pmc_mfma.json" "$ROOT/profiles/${TAG%%_*}_pmc_mfma.json"
 fi
 
-if want split; then
-# 1e. the opt-in split engine (bench.py --f32-products split): counters of its kernels, merged into the round's tables (their
-#     kernel names -- vqa::sp::* -- do not occur in the default run), its bench line, its kernel trace, its convergence run
+if want mfma; then
+# 1e. the fp32 MFMA engine (bench.py --f32-products mfma; the default runs the split engine): counters of its kernels, merged into
+#     the round's tables (their names -- vqa::rt::gemm_*, relation_dgrad_kernel -- do not occur in the default run), its bench
+#     line, its kernel trace, its convergence run
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc_split_$c
-  timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_split_$c -- python3 "$ROOT/bench.py" --f32-products split --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records --detail-file /tmp/pmc_detail.json > "$OUT/pmc_split_$c.log" 2>&1
+  rm -rf /tmp/pmc_mfmaeng_$c
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_mfmaeng_$c -- python3 "$ROOT/bench.py" --f32-products mfma --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records --detail-file /tmp/pmc_detail.json > "$OUT/pmc_mfmaeng_$c.log" 2>&1
 done
-python3 "$ROOT/tools/pmc_table.py" /tmp/pmc_split_FETCH_SIZE /tmp/pmc_split_WRITE_SIZE "$OUT/pmc_traffic_split.json" > "$OUT/pmc_table_split.log" 2>&1
-rm -rf /tmp/pmc_mfma_split
-timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma_split -- python3 "$ROOT/bench.py" --f32-products split --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records --detail-file /tmp/pmc_detail.json > "$OUT/pmc_mfma_split.log" 2>&1
-python3 "$ROOT/tools/pmc_mfma.py" /tmp/pmc_mfma_split "$OUT/pmc_mfma_split.json" > "$OUT/pmc_mfma_split_table.log" 2>&1
+python3 "$ROOT/tools/pmc_table.py" /tmp/pmc_mfmaeng_FETCH_SIZE /tmp/pmc_mfmaeng_WRITE_SIZE "$OUT/pmc_traffic_mfmaeng.json" > "$OUT/pmc_table_mfmaeng.log" 2>&1
+rm -rf /tmp/pmc_mfma_mfmaeng
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma_mfmaeng -- python3 "$ROOT/bench.py" --f32-products mfma --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-rotate --no-sub-records --detail-file /tmp/pmc_detail.json > "$OUT/pmc_mfma_mfmaeng.log" 2>&1
+python3 "$ROOT/tools/pmc_mfma.py" /tmp/pmc_mfma_mfmaeng "$OUT/pmc_mfma_mfmaeng.json" > "$OUT/pmc_mfma_mfmaeng_table.log" 2>&1
 python3 - "$OUT" "$ROOT/profiles/${TAG%%_*}" <<'PY'
 import json, os, sys
 out, prof = sys.argv[1], sys.argv[2]
 for kind in ("traffic", "mfma"):
-    src = os.path.join(out, "pmc_%s_split.json" % kind)
+    src = os.path.join(out, "pmc_%s_mfmaeng.json" % kind)
     if not os.path.exists(src):
         continue
-    rows = {k: v for k, v in json.load(open(src)).items() if "sp::" in k or "_split_kernel" in k or "pack_wt_kernel" in k}
+    rows = {k: v for k, v in json.load(open(src)).items() if "rt::gemm_" in k or "relation_dgrad_kernel" in k or "linear_dw_reduce" in k}
     for dst in (os.path.join(out, "pmc_%s.json" % kind), "%s_pmc_%s.json" % (prof, kind)):
         if os.path.exists(dst):
             table = json.load(open(dst))
-            table.update(rows)
+            table.update({k: v for k, v in rows.items() if k not in table})
             json.dump(table, open(dst, "w"), indent=1, sort_keys=True)
-    print(kind, "split rows merged:", sorted(rows))
+    print(kind, "fp32 MFMA engine rows merged:", sorted(rows))
 PY
 cd "$ROOT"
-timeout 900 python3 bench.py --detail-file "$OUT/bench_b512_split_detail.json" --f32-products split --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records > "$OUT/bench_b512_split.json" 2> "$OUT/bench_b512_split.log"
-timeout 900 python3 bench.py --detail-file "$OUT/bench_oda_b512_split_detail.json" --model oda --f32-products split --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records > "$OUT/bench_oda_b512_split.json" 2> "$OUT/bench_oda_b512_split.log"
+timeout 900 python3 bench.py --detail-file "$OUT/bench_b512_mfma_detail.json" --f32-products mfma --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records > "$OUT/bench_b512_mfma.json" 2> "$OUT/bench_b512_mfma.log"
+timeout 900 python3 bench.py --detail-file "$OUT/bench_oda_b512_mfma_detail.json" --model oda --f32-products mfma --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records > "$OUT/bench_oda_b512_mfma.json" 2> "$OUT/bench_oda_b512_mfma.log"
 cd /tmp
-rm -rf /tmp/kt_split
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_split -- python3 "$ROOT/bench.py" --f32-products split --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records --detail-file /tmp/kt_detail.json > "$OUT/kt_split.log" 2>&1
-f=$(find /tmp/kt_split -name "*kernel_stats.csv" | sort | sed -n 1p)
-[ -n "$f" ] && cp "$f" "$OUT/bench_b512_split_kernel_stats.csv"
-python3 "$ROOT/tools/by_grid.py" /tmp/kt_split 1 "hand-written kernels, per-dispatch durations by (kernel, grid work-items); rocprofv3 --kernel-trace of bench.py --f32-products split --steps 20 --warmup 5 --no-cpu-baseline (the last column is the total over the run)" > "$OUT/vqa_kernels_by_grid_split.txt" 2>&1
-VQA_F32_PRODUCTS=split timeout 600 python3 "$ROOT/tools/convergence.py" --steps 3000 --model cor2 --out "$OUT/convergence_cor2_split.json" > "$OUT/convergence_cor2_split.log" 2>&1
+rm -rf /tmp/kt_mfmaeng
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_mfmaeng -- python3 "$ROOT/bench.py" --f32-products mfma --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records --detail-file /tmp/kt_detail.json > "$OUT/kt_mfmaeng.log" 2>&1
+f=$(find /tmp/kt_mfmaeng -name "*kernel_stats.csv" | sort | sed -n 1p)
+[ -n "$f" ] && cp "$f" "$OUT/bench_b512_mfma_kernel_stats.csv"
+python3 "$ROOT/tools/by_grid.py" /tmp/kt_mfmaeng 1 "hand-written kernels, per-dispatch durations by (kernel, grid work-items); rocprofv3 --kernel-trace of bench.py --f32-products mfma --steps 20 --warmup 5 --no-cpu-baseline (the last column is the total over the run)" > "$OUT/vqa_kernels_by_grid_mfma.txt" 2>&1
+VQA_F32_PRODUCTS=mfma timeout 600 python3 "$ROOT/tools/convergence.py" --steps 3000 --model cor2 --out "$OUT/convergence_cor2_mfma.json" > "$OUT/convergence_cor2_mfma.log" 2>&1
 cd "$ROOT"
 fi
 
@@ -88,6 +102,8 @@ VQA_HEAD=legacy run bench_b512_legacy_head --steps 20 --warmup 5 --no-cpu-baseli
 VQA_HEAD=grouped run bench_b512_grouped_head --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records
 VQA_HEAD=grouped run bench_oda_b512_grouped_head --model oda --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records
 run bench_b512_eager --steps 20 --warmup 5 --no-graph --no-cpu-baseline --no-rotate --no-sub-records
+run bench_b512_copy_inputs --steps 20 --warmup 5 --copy-inputs --no-cpu-baseline --no-sub-records
+VQA_K4_BF16_FORM=fold run bench_bf16_n100_b128_k4fold --no-sub-records --dtype bf16 --regions 100 --batch 128 --steps 20 --warmup 5 --no-cpu-baseline
 run bench_b512_pairwise --no-sub-records --steps 20 --warmup 5 --relation-mode 0 --no-cpu-baseline
 run bench_f32_n100_b128 --no-sub-records --regions 100 --batch 128 --steps 20 --warmup 5 --no-cpu-baseline
 run bench_bf16_n100_b128 --no-sub-records --dtype bf16 --regions 100 --batch 128 --steps 20 --warmup 5 --no-cpu-baseline
