@@ -33,3 +33,19 @@ def test_one_rank_rccl_allreduce_is_the_identity(model):
             for a, b in zip(got["norms"], want["norms"]):
                 assert abs(a - b) <= 1e-5 * abs(b), (tag, got["norms"], want["norms"])
             assert abs(got["weight_digest"] - want["weight_digest"]) <= 1e-4 * abs(want["weight_digest"]) + 1e-5, tag
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_one_rank_rccl_with_a_graph_per_input_slot(overlap):
+    """bench.py's form of the multi-GPU step: rotating resident batches, one forward + backward graph per input slot (trainer
+    input_slots), the all-reduce (a one-rank RCCL group, forced) between / beside the replayed graphs of whichever slot is up.
+    Three resident copies of one batch visited in turn must give the numbers of the single-buffer step."""
+    env = {"G": "1", "VQA_DP_OVERLAP": overlap, "MODEL": "cor2"}
+    want = _run(1, env)
+    got = _run(1, dict(env, NCCL1="1", SLOTS="3"))
+    assert got["reduce"] and got["backend"] == "nccl" and got["graph"] and got["slots"] == 3, got
+    assert got["overlap"] == (overlap == "1")
+    for a, b in zip(got["losses"], want["losses"]):
+        assert abs(a - b) <= 1e-6 * abs(b), (got["losses"], want["losses"])
+    for a, b in zip(got["norms"], want["norms"]):
+        assert abs(a - b) <= 1e-5 * abs(b), (got["norms"], want["norms"])

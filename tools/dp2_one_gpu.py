@@ -7,7 +7,9 @@ second half -- on a single-GPU box.  Rank 0 prints ONE JSON line with the global
     BACKEND=nccl python -m torch.distributed.run --nproc-per-node 2 ... tools/dp2_one_gpu.py    # rank r on cuda:r, RCCL across them
     python tools/dp2_one_gpu.py            # the same steps in one process on the whole batch (the expected record)
     NCCL1=1 python tools/dp2_one_gpu.py    # one process, a ONE-rank "nccl" (= RCCL) group, the all-reduce forced
-  env: G=1|0 graph replay or kernel by kernel;  VQA_DP_OVERLAP=1: backward in two halves (forced at world size 1);  MODEL=cor2|oda
+  env: G=1|0 graph replay or kernel by kernel;  VQA_DP_OVERLAP=1: backward in two halves (forced at world size 1);  MODEL=cor2|oda;
+       SLOTS=k: the batch lives in k resident copies visited in turn, the trainer captures one forward + backward graph per copy
+       (input_slots, bench.py's rotating batches) -- same numbers as SLOTS=1
 (tests/test_gpu_dp2.py runs all combinations and compares them with the single-process record; tests/test_gpu_nccl1.py
 runs the single-process steps with the all-reduce issued through a one-rank RCCL communicator and demands bit-identical
 results: RCCL init, the collective between the replayed graphs, the async work handle beside the second backward graph.)"""
@@ -56,14 +58,16 @@ if rank == 0:
     torch.manual_seed(100)
 model = cls(["PAD"], 300).to(dev).eval()    # eval mode: no dropout, so N ranks on shards == 1 process on the batch
 split = os.environ.get("VQA_DP_OVERLAP", "0") == "1"
+slots = int(os.environ.get("SLOTS", "1"))
 tr = DataParallelTrainer(model, lr=1e-4, graph=os.environ.get("G", "1") == "1",
-                         overlap=("force" if not multi else True) if split else False)
+                         overlap=("force" if not multi else True) if split else False, adopt_inputs=slots > 1, input_slots=slots)
 torch.manual_seed(5)
 v, q = torch.randn(8, 36, 2048, device=dev), torch.randn(8, 2400, device=dev)
 a = torch.softmax(torch.randn(8, 300, device=dev), 1)
+ring = [({"v": tr.shard(v).clone(), "q_idxes": tr.shard(q).clone()}, tr.shard(a).clone()) for _ in range(slots)]
 losses, norms = [], []
-for _ in range(7):
-    loss, norm = tr.step({"v": tr.shard(v), "q_idxes": tr.shard(q)}, tr.shard(a))
+for i in range(7):
+    loss, norm = tr.step(*ring[i % slots])
     t = loss.clone()
     if multi:
         dist.all_reduce(t)
@@ -78,6 +82,7 @@ if rank == 0:
     print(json.dumps({"world": dist.get_world_size() if multi else 1, "graph": tr._graph is not None, "overlap": bool(tr.overlap),
                       "reduce": bool(tr.reduce), "backend": dist.get_backend() if dist.is_initialized() else None,
                       "graphs": sorted(k for k in (tr._graph or {}) if k in ("front", "front_a", "front_b", "tail")),
+                      "slots": len(getattr(tr, "_slots", [])),
                       "losses": losses, "norms": norms, "weight_digest": float(w.double().sum().item())}), flush=True)
 if multi or nccl1:
     dist.barrier()

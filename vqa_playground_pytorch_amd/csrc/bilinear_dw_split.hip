@@ -1,0 +1,280 @@
+// K4's weight gradient on the SPLIT engine: the per-sample product of the rank-folded backward,
+//
+//     P_b = g_b^T [x_b | 1]   [H, L + 1]     dW1_r += diag(h2_r[b]) P_b[:, :L]     db1_r += h2_r[b] * P_b[:, L]
+//                                             dh2_r[b,h] = sum_l P_b[h,l] W1_r[h,l] + P_b[h,L] b1_r[h]
+//
+// (putils/__init__.py:232-238 backward; same outputs and workspace layout as bilinear_dw_rt.hip, whose fp32-MFMA form ran at
+// 50 % matrix-pipe occupancy and 1.43 x its algorithmic traffic for two rounds) with every fp32 product formed from exact
+// three-way bf16 splits of BOTH operands -- six partial products on v_mfma_f32_16x16x16_bf16, fp32 accumulation: an fp32
+// product, csrc/gemm_f32_split.hpp.  The contraction runs over the 36 regions of ONE sample (three 16-deep steps, rows 36..47
+// zero), which is the ROW index of g and x in memory: both tiles are split while they are staged -- as they lie in memory, one
+// bf16 image per plane -- and come back as MFMA fragments through gfx950's transposing LDS read (ds_read_b64_tr_b16: four
+// consecutive rows of one column per lane, exactly the 16x16x16 operand).  No operand is split twice inside a workgroup; across
+// workgroups x_b is split once per 64-row tile of H (8 x) and g_b once per column half (2 x): 8.7 us of VALU per launch at
+// B = 512 against 29 us of matrix pipe.
+//
+// Workgroup = 64 features h x half of the (padded) columns x one slab of samples; 4 waves = 2 (h halves: 2 blocks of 16) x 2
+// (column quarters: LBW blocks of 16).  Per sample: stage + split (the next sample's loads are in flight under this one's
+// products), 3 x 6 x 2 x LBW MFMAs, fold P into the slab's dW accumulators (fp32 registers), contract it against W1_r (registers,
+// in the accumulator layout) for dh2.  Column L of the x tile is the constant 1: the bias gradient and dh2's bias term ride along.
+#include "bilinear_folded.hpp"
+#include "gemm_f32_split.hpp"
+
+namespace vqa {
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int kR = 2, kRows = 48;
+
+struct DwSplitArgs {
+  const float* g;        // [B N, H]
+  const float* x;        // [B N, L]
+  const float* h2;       // [B, R, H]
+  const float* w[kR];    // [H, L]
+  const float* b[kR];    // [H]
+  float* slab;           // [kDwSplitSlabs][R][H L]
+  float* dbslab;         // [kDwSplitSlabs][R][H]
+  float* part;           // [2][B R H]: dh2's partial sums over the two column halves
+  int B, N, L, H, sps;
+};
+
+__device__ __forceinline__ f32x4v mfma16(s16x4 a, s16x4 b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+
+template <int LBW>
+__global__ __launch_bounds__(256, 1) void bilinear_dw_split_kernel(DwSplitArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char dws_smem[];
+  constexpr int LH = 32 * LBW;                     // columns of this workgroup's half (2 waves x LBW blocks x 16)
+  constexpr int PG = 64 * 2 + 16, PX = LH * 2 + 16;   // row pitches of the plane images (bytes)
+  constexpr int GPAIRS = 36 * 32, XPAIRS_ROW = LH / 2;
+  char* gim = dws_smem;                            // [3 planes][kRows][PG]
+  char* xim = gim + 3 * kRows * PG;                // [3 planes][kRows][PX]
+  float* red = reinterpret_cast<float*>(xim + 3 * kRows * PX);   // [2 column waves][R][64]
+  const int L = p.L, H = p.H, N = p.N;
+  const int lane = threadIdx.x & 63, r16 = lane & 15, gq = lane >> 4, wave = threadIdx.x >> 6;
+  const int wh = wave >> 1, wl = wave & 1;
+  const int ht = blockIdx.x % ((H + 63) / 64), lh = (blockIdx.x / ((H + 63) / 64)) & 1, slab = blockIdx.x / (2 * ((H + 63) / 64));
+  const int h0 = ht * 64, lbase = lh * LH;
+  // zero both images once: the rows N .. 47 stay zero, everything else is rewritten per sample
+  for (int t = threadIdx.x; t < (3 * kRows * (PG + PX)) / 16; t += 256) reinterpret_cast<uint4*>(dws_smem)[t] = make_uint4(0u, 0u, 0u, 0u);
+  // W1_r in the accumulator layout: block (j, lb): rows h0 + 16 (2 wh + j) + 4 gq + i, column lbase + 16 (LBW wl + lb) + r16;
+  // column L holds b1_r (it meets P's column of region sums), columns past it and rows past H are zero
+  float w1f[kR][2][LBW][4];
+#pragma unroll
+  for (int r = 0; r < kR; ++r)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int lb = 0; lb < LBW; ++lb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int h = h0 + 16 * (2 * wh + j) + 4 * gq + i, l = lbase + 16 * (LBW * wl + lb) + r16;
+          float v = 0.f;
+          if (h < H) v = l < L ? p.w[r][(size_t)h * L + l] : (l == L ? p.b[r][h] : 0.f);
+          w1f[r][j][lb][i] = v;
+        }
+  f32x4v dw[kR][2][LBW];
+#pragma unroll
+  for (int r = 0; r < kR; ++r)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int lb = 0; lb < LBW; ++lb) dw[r][j][lb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging: float2 pieces (rows of g / x are 8-byte aligned: H and L are even); the next sample's pieces are requested
+  // before this sample's products
+  constexpr int GP = (GPAIRS + 255) / 256;                 // pieces per thread
+  constexpr int XP = (36 * XPAIRS_ROW + 255) / 256;
+  sp::f32x2 sg[GP], sx[XP];
+  auto fetch = [&](int b) {
+#pragma unroll
+    for (int k = 0; k < GP; ++k) {
+      const int t = threadIdx.x + 256 * k;
+      const int row = t >> 5, c = t & 31, h = h0 + 2 * c;
+      sg[k] = sp::f32x2{0.f, 0.f};
+      if (row < N && h < H) sg[k] = *reinterpret_cast<const sp::f32x2*>(p.g + ((size_t)b * N + row) * H + h);
+    }
+#pragma unroll
+    for (int k = 0; k < XP; ++k) {
+      const int t = threadIdx.x + 256 * k;
+      const int row = t / XPAIRS_ROW, c = t - row * XPAIRS_ROW, l = lbase + 2 * c;
+      sx[k] = sp::f32x2{0.f, 0.f};
+      if (row < N) {
+        if (l < L) sx[k] = *reinterpret_cast<const sp::f32x2*>(p.x + ((size_t)b * N + row) * L + l);
+        else if (l == L) sx[k] = sp::f32x2{1.f, 0.f};
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int k = 0; k < GP; ++k) {
+      const int t = threadIdx.x + 256 * k;
+      const int row = t >> 5, c = t & 31;
+      if (row < 36 && row < N) {
+        uint32_t q0, q1, q2;
+        sp::split_pair<false>(sg[k], q0, q1, q2);
+        char* dst = gim + (size_t)row * PG + 4 * c;
+        *reinterpret_cast<uint32_t*>(dst) = q0;
+        *reinterpret_cast<uint32_t*>(dst + kRows * PG) = q1;
+        *reinterpret_cast<uint32_t*>(dst + 2 * kRows * PG) = q2;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < XP; ++k) {
+      const int t = threadIdx.x + 256 * k;
+      const int row = t / XPAIRS_ROW, c = t - row * XPAIRS_ROW;
+      if (row < 36 && row < N) {
+        uint32_t q0, q1, q2;
+        sp::split_pair<false>(sx[k], q0, q1, q2);
+        char* dst = xim + (size_t)row * PX + 4 * c;
+        *reinterpret_cast<uint32_t*>(dst) = q0;
+        *reinterpret_cast<uint32_t*>(dst + kRows * PX) = q1;
+        *reinterpret_cast<uint32_t*>(dst + 2 * kRows * PX) = q2;
+      }
+    }
+  };
+  // transposing reads: lane 4 q + p of a 16-lane group addresses row q, columns 4 p .. 4 p + 3 of a 4 x 16 block and receives
+  // column (lane & 15), rows 0..3 -- the four contraction indices 4 gq .. 4 gq + 3 of a 16-deep step
+  const int tq = r16 >> 2, tp = r16 & 3;
+  auto frag = [&](const char* image, int pitch, int plane, int step, int colblock) -> s16x4 {
+    const char* src = image + ((size_t)plane * kRows + 16 * step + 4 * gq + tq) * pitch + (16 * colblock + 4 * tp) * 2;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(src));
+  };
+  const int b_lo = slab * p.sps, b_hi = min(p.B, b_lo + p.sps);
+  if (b_lo < b_hi) fetch(b_lo);
+  for (int b = b_lo; b < b_hi; ++b) {
+    __syncthreads();      // the previous sample's fragments have been read (and, first time round, the images are zeroed)
+    stage();
+    __syncthreads();
+    if (b + 1 < b_hi) fetch(b + 1);
+    f32x4v P[2][LBW];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int lb = 0; lb < LBW; ++lb) P[j][lb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      s16x4 a[3][2], bx[3][LBW];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) a[pl][j] = frag(gim, PG, pl, s, 2 * wh + j);
+#pragma unroll
+        for (int lb = 0; lb < LBW; ++lb) bx[pl][lb] = frag(xim, PX, pl, s, LBW * wl + lb);
+      }
+      constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};      // the six partial products of weight >= 2^-16
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int lb = 0; lb < LBW; ++lb) P[j][lb] = mfma16(a[PA[k]][j], bx[PB[k]][lb], P[j][lb]);
+    }
+    // fold into the slab's gradients; contract against W1_r (and b1_r in column L) for dh2
+    float part[kR][2][4];
+#pragma unroll
+    for (int r = 0; r < kR; ++r)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x4v qh;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int h = h0 + 16 * (2 * wh + j) + 4 * gq + i;
+          qh[i] = h < H ? p.h2[((size_t)b * kR + r) * H + h] : 0.f;
+          part[r][j][i] = 0.f;
+        }
+#pragma unroll
+        for (int lb = 0; lb < LBW; ++lb) {
+          dw[r][j][lb] += qh * P[j][lb];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) part[r][j][i] = fmaf(P[j][lb][i], w1f[r][j][lb][i], part[r][j][i]);
+        }
+      }
+#pragma unroll
+    for (int r = 0; r < kR; ++r)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float s = part[r][j][i];
+          s += __shfl_xor(s, 1);
+          s += __shfl_xor(s, 2);
+          s += __shfl_xor(s, 4);
+          s += __shfl_xor(s, 8);
+          if (r16 == 0) red[(wl * kR + r) * 64 + 16 * (2 * wh + j) + 4 * gq + i] = s;
+        }
+    __syncthreads();
+    if (threadIdx.x < kR * 64) {
+      const int r = threadIdx.x >> 6, h = threadIdx.x & 63;
+      if (h0 + h < H)
+        p.part[(size_t)lh * p.B * kR * H + ((size_t)b * kR + r) * H + h0 + h] = red[(0 * kR + r) * 64 + h] + red[(1 * kR + r) * 64 + h];
+    }
+  }
+  // slab[slab][r][h][l] (l < L) and dbslab[slab][r][h] (column L)
+#pragma unroll
+  for (int r = 0; r < kR; ++r) {
+    float* dst = p.slab + ((size_t)slab * kR + r) * H * L;
+    float* dbd = p.dbslab + ((size_t)slab * kR + r) * H;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int lb = 0; lb < LBW; ++lb) {
+        const int l = lbase + 16 * (LBW * wl + lb) + r16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int h = h0 + 16 * (2 * wh + j) + 4 * gq + i;
+          if (h >= H) continue;
+          if (l < L) dst[(size_t)h * L + l] = dw[r][j][lb][i];
+          else if (l == L) dbd[h] = dw[r][j][lb][i];
+        }
+      }
+  }
+}
+
+}  // namespace
+
+bool dw_split_supported(int B, int N, int L, int H, int R, int ldx) {
+  if (vqa::option_is("VQA_K4_DW_SPLIT", '0')) return false;
+  const int lbw = (L + 1 + 63) / 64;
+  return R == kR && N >= 1 && N <= 36 && ldx == L && L % 2 == 0 && H % 2 == 0 && lbw >= 1 && lbw <= 5 && H >= 16 && B >= 64 &&
+         (size_t)B * N * H * 4 < (1ull << 32) && (size_t)B * N * L * 4 < (1ull << 32);
+}
+
+int dw_split_launch(const float* g, const float* x, const float* h2, const float* const* w1, const float* const* b1, float* slab,
+                    float* dbslab, float* part, int B, int N, int L, int H, int R, hipStream_t s) {
+  DwSplitArgs a{};
+  a.g = g;
+  a.x = x;
+  a.h2 = h2;
+  for (int r = 0; r < kR; ++r) {
+    a.w[r] = w1[r];
+    a.b[r] = b1[r];
+  }
+  a.slab = slab;
+  a.dbslab = dbslab;
+  a.part = part;
+  a.B = B;
+  a.N = N;
+  a.L = L;
+  a.H = H;
+  a.sps = (B + kDwSplitSlabs - 1) / kDwSplitSlabs;
+  const int lbw = (L + 1 + 63) / 64;
+  const dim3 grid(kDwSplitSlabs * 2 * ((H + 63) / 64));
+#define LAUNCH(LBW_)                                                                                                   \
+  {                                                                                                                    \
+    const size_t lds = (size_t)3 * kRows * (64 * 2 + 16) + (size_t)3 * kRows * (32 * LBW_ * 2 + 16) + 2 * kR * 64 * 4; \
+    VQA_ENSURE_LDS((bilinear_dw_split_kernel<LBW_>), lds);                                                             \
+    VQA_LAUNCH((bilinear_dw_split_kernel<LBW_>), grid, dim3(256), lds, s, a);                                          \
+  }
+  switch (lbw) {
+    case 1: LAUNCH(1) break;
+    case 2: LAUNCH(2) break;
+    case 3: LAUNCH(3) break;
+    case 4: LAUNCH(4) break;
+    default: LAUNCH(5) break;
+  }
+#undef LAUNCH
+  return check_launch("lowrank_bilinear_fusion_folded_bwd (dW, split engine)");
+}
+
+}  // namespace vqa

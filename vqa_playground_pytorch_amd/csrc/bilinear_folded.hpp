@@ -26,6 +26,14 @@ bool dw_rt_supported(int B, int N, int L, int H, int R, int ldx);
 int dw_rt_launch(const float* g, const float* x, const float* h2, const float* const* w1, const float* const* b1, float* slab,
                  float* dbslab, float* part, int B, int N, int L, int H, int R, hipStream_t s);
 
+// The same product on the split engine (bilinear_dw_split.hip: six bf16 partial products per fp32 product, both operands split
+// while they are staged): same outputs, kDwSplitSlabs sample slabs.  The default where it applies; VQA_K4_DW_SPLIT=0 keeps the
+// fp32 MFMA form.
+constexpr int kDwSplitSlabs = 16;
+bool dw_split_supported(int B, int N, int L, int H, int R, int ldx);
+int dw_split_launch(const float* g, const float* x, const float* h2, const float* const* w1, const float* const* b1, float* slab,
+                    float* dbslab, float* part, int B, int N, int L, int H, int R, hipStream_t s);
+
 // Register-tile forms of the folded forward and data gradient (bilinear_rt.hip); K = contraction length, NO = output rows
 bool fold_rt_supported(int B, int N, int K, int NO, int R, int ldx, int ldw, int ldo);
 int fold_rt_forward(const float* x, int ldx, const float* const* w1, const float* const* b1, const float* h2, float* out, int B,

@@ -751,7 +751,9 @@ static int dw_fold_splits(int B, int N, int H, int L, int R) {
 }
 static size_t folded_bwd_floats(int B, int N, int L, int H, int R, size_t* wt_off, size_t* slab_off, size_t* db_off,
                                 size_t* part_off) {
-  const int S = dw_fold_splits(B, N, H, L, R), tiles_n = (L + 63) / 64;
+  int S = dw_fold_splits(B, N, H, L, R);
+  if (dw_split_supported(B, N, L, H, R, L) && S < kDwSplitSlabs) S = kDwSplitSlabs;      // (the split form's slab count)
+  const int tiles_n = (L + 63) / 64;
   size_t off = 0;
   *wt_off = off;
   off += (size_t)R * L * H;
@@ -822,6 +824,17 @@ extern "C" int vqa_lowrank_bilinear_fusion_folded_bwd_gated(const float* x, int 
     if (rc != VQA_OK) return rc;
   }
   // (2) P_b = g_b^T x_b once per sample: dW1_r, db1_r slabs and dh2
+  if (dw_split_supported(B, N, L, H, R, ldx)) {
+    // split engine (bilinear_dw_split.hip): 16 slabs, dh2 in two partial sums
+    rc = dw_split_launch(g, x, h2, w1, b1, slab, dbslab, part, B, N, L, H, R, s);
+    if (rc != VQA_OK) return rc;
+    const int HL2 = H * L;
+    const size_t n2 = (size_t)B * R * H;
+    const int nb_dw = (HL2 / 2 + 255) / 256, nb_dh2 = (int)((n2 / 2 + 255) / 256);
+    VQA_LAUNCH(bilinear_dw_dh2_reduce_kernel, dim3(R * nb_dw + nb_dh2), dim3(256), 0, s, slab, dbslab, ro, HL2, H, R,
+                       kDwSplitSlabs, nb_dw, part, d_h2, n2, 2);
+    return check_launch("lowrank_bilinear_fusion_folded_bwd");
+  }
   if (dw_rt_supported(B, N, L, H, R, ldx) && dw_fold_splits(B, N, H, L, R) >= kDwRtGroups) {
     // register-tile form (bilinear_dw_rt.hip): 8 slabs, dh2 in two partial sums (the workspace holds >= 2 of them)
     rc = dw_rt_launch(g, x, h2, w1, b1, slab, dbslab, part, B, N, L, H, R, s);
