@@ -5,17 +5,17 @@
 //
 // (putils/__init__.py:232-238 backward; same outputs and workspace layout as bilinear_dw_rt.hip, whose fp32-MFMA form ran at
 // 50 % matrix-pipe occupancy and 1.43 x its algorithmic traffic for two rounds) with every fp32 product formed from exact
-// three-way bf16 splits of BOTH operands -- six partial products on v_mfma_f32_16x16x16_bf16, fp32 accumulation: an fp32
-// product, csrc/gemm_f32_split.hpp.  The contraction runs over the 36 regions of ONE sample (three 16-deep steps, rows 36..47
+// three-way bf16 splits of BOTH operands -- six partial products on v_mfma_f32_16x16x32_bf16, fp32 accumulation: an fp32
+// product, csrc/gemm_f32_split.hpp.  The contraction runs over the 36 regions of ONE sample (two 32-deep steps, rows past 36
 // zero), which is the ROW index of g and x in memory: both tiles are split while they are staged -- as they lie in memory, one
 // bf16 image per plane -- and come back as MFMA fragments through gfx950's transposing LDS read (ds_read_b64_tr_b16: four
-// consecutive rows of one column per lane, exactly the 16x16x16 operand).  No operand is split twice inside a workgroup; across
+// consecutive rows of one column per lane; two of them are a lane's eight contraction indices).  No operand is split twice inside a workgroup; across
 // workgroups x_b is split once per 64-row tile of H (8 x) and g_b once per column half (2 x): 8.7 us of VALU per launch at
 // B = 512 against 29 us of matrix pipe.
 //
 // Workgroup = 64 features h x half of the (padded) columns x one slab of samples; 4 waves = 2 (h halves: 2 blocks of 16) x 2
-// (column quarters: LBW blocks of 16).  Per sample: stage + split (the next sample's loads are in flight under this one's
-// products), 3 x 6 x 2 x LBW MFMAs, fold P into the slab's dW accumulators (fp32 registers), contract it against W1_r (registers,
+// (column quarters: LBW blocks of 16).  Per sample: 2 x 6 x 2 x LBW MFMAs out of one LDS buffer while the next sample is split into
+// the other (one barrier per sample), fold P into the slab's dW accumulators (fp32 registers), contract it against W1_r (registers,
 // in the accumulator layout) for dh2.  Column L of the x tile is the constant 1: the bias gradient and dh2's bias term ride along.
 #include "bilinear_folded.hpp"
 #include "gemm_f32_split.hpp"
@@ -35,11 +35,14 @@ struct DwSplitArgs {
   const float* b[kR];    // [H]
   float* slab;           // [kDwSplitSlabs][R][H L]
   float* dbslab;         // [kDwSplitSlabs][R][H]
-  float* part;           // [2][B R H]: dh2's partial sums over the two column halves
+  float* part;           // [4][B R H]: dh2's partial sums over the four column quarters (2 workgroup halves x 2 waves)
   int B, N, L, H, sps;
 };
 
-__device__ __forceinline__ f32x4v mfma16(s16x4 a, s16x4 b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4v mfma32(const u32x4v& a, const u32x4v& b, const f32x4v& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 template <int LBW>
 __global__ __launch_bounds__(256, 1) void bilinear_dw_split_kernel(DwSplitArgs p) {
@@ -47,16 +50,20 @@ __global__ __launch_bounds__(256, 1) void bilinear_dw_split_kernel(DwSplitArgs p
   constexpr int LH = 32 * LBW;                     // columns of this workgroup's half (2 waves x LBW blocks x 16)
   constexpr int PG = 64 * 2 + 16, PX = LH * 2 + 16;   // row pitches of the plane images (bytes)
   constexpr int GPAIRS = 36 * 32, XPAIRS_ROW = LH / 2;
-  char* gim = dws_smem;                            // [3 planes][kRows][PG]
-  char* xim = gim + 3 * kRows * PG;                // [3 planes][kRows][PX]
-  float* red = reinterpret_cast<float*>(xim + 3 * kRows * PX);   // [2 column waves][R][64]
+  constexpr int IMG = 3 * kRows * (PG + PX);       // one buffer: [3 planes][kRows][PG] then [3 planes][kRows][PX]
+  float* h2s = reinterpret_cast<float*>(dws_smem + 2 * IMG);     // [sps][R][64]: the slab's question-side factors of this h tile
   const int L = p.L, H = p.H, N = p.N;
   const int lane = threadIdx.x & 63, r16 = lane & 15, gq = lane >> 4, wave = threadIdx.x >> 6;
   const int wh = wave >> 1, wl = wave & 1;
   const int ht = blockIdx.x % ((H + 63) / 64), lh = (blockIdx.x / ((H + 63) / 64)) & 1, slab = blockIdx.x / (2 * ((H + 63) / 64));
   const int h0 = ht * 64, lbase = lh * LH;
-  // zero both images once: the rows N .. 47 stay zero, everything else is rewritten per sample
-  for (int t = threadIdx.x; t < (3 * kRows * (PG + PX)) / 16; t += 256) reinterpret_cast<uint4*>(dws_smem)[t] = make_uint4(0u, 0u, 0u, 0u);
+  const int b_lo = slab * p.sps, b_hi = min(p.B, b_lo + p.sps);
+  // zero both image buffers once: the rows N .. 47 stay zero, everything else is rewritten per sample
+  for (int t = threadIdx.x; t < 2 * IMG / 16; t += 256) reinterpret_cast<uint4*>(dws_smem)[t] = make_uint4(0u, 0u, 0u, 0u);
+  for (int t = threadIdx.x; t < (b_hi - b_lo) * kR * 64; t += 256) {
+    const int bb = t / (kR * 64), u = t - bb * (kR * 64), r = u >> 6, h = h0 + (u & 63);
+    h2s[t] = h < H ? p.h2[((size_t)(b_lo + bb) * kR + r) * H + h] : 0.f;
+  }
   // W1_r in the accumulator layout: block (j, lb): rows h0 + 16 (2 wh + j) + 4 gq + i, column lbase + 16 (LBW wl + lb) + r16;
   // column L holds b1_r (it meets P's column of region sums), columns past it and rows past H are zero
   float w1f[kR][2][LBW][4];
@@ -81,8 +88,7 @@ __global__ __launch_bounds__(256, 1) void bilinear_dw_split_kernel(DwSplitArgs p
 #pragma unroll
       for (int lb = 0; lb < LBW; ++lb) dw[r][j][lb] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-  // ---- staging: float2 pieces (rows of g / x are 8-byte aligned: H and L are even); the next sample's pieces are requested
-  // before this sample's products
+  // ---- staging: float2 pieces (rows of g / x are 8-byte aligned: H and L are even), split into the three plane images
   constexpr int GP = (GPAIRS + 255) / 256;                 // pieces per thread
   constexpr int XP = (36 * XPAIRS_ROW + 255) / 256;
   sp::f32x2 sg[GP], sx[XP];
@@ -105,7 +111,9 @@ __global__ __launch_bounds__(256, 1) void bilinear_dw_split_kernel(DwSplitArgs p
       }
     }
   };
-  auto stage = [&]() {
+  auto stage = [&](char* buf) {
+    char* gim = buf;
+    char* xim = buf + 3 * kRows * PG;
 #pragma unroll
     for (int k = 0; k < GP; ++k) {
       const int t = threadIdx.x + 256 * k;
@@ -133,28 +141,41 @@ __global__ __launch_bounds__(256, 1) void bilinear_dw_split_kernel(DwSplitArgs p
       }
     }
   };
-  // transposing reads: lane 4 q + p of a 16-lane group addresses row q, columns 4 p .. 4 p + 3 of a 4 x 16 block and receives
-  // column (lane & 15), rows 0..3 -- the four contraction indices 4 gq .. 4 gq + 3 of a 16-deep step
+  // Fragments of v_mfma_f32_16x16x32_bf16 by the transposing read: lane 4 q + p of a 16-lane group addresses row q, columns
+  // 4 p .. 4 p + 3 of a 4 x 16 block and receives column (lane & 15), rows 0..3; a lane's eight contraction indices 8 gq .. 8 gq + 7
+  // are two such reads.  The 36 regions are two 32-deep steps: step 1 holds rows 32..35, the lane groups past them read zero rows.
   const int tq = r16 >> 2, tp = r16 & 3;
-  auto frag = [&](const char* image, int pitch, int plane, int step, int colblock) -> s16x4 {
-    const char* src = image + ((size_t)plane * kRows + 16 * step + 4 * gq + tq) * pitch + (16 * colblock + 4 * tp) * 2;
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(src));
+  const int row_s[2] = {8 * gq + tq, 32 + 8 * min(gq, 1) + tq};
+  auto frag = [&](const char* image, int pitch, int plane, int step, int colblock) -> u32x4v {
+    const char* src = image + ((size_t)plane * kRows + row_s[step]) * pitch + (16 * colblock + 4 * tp) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(src));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(src + 4 * pitch));
+    const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+    return u32x4v{a.x, a.y, b.x, b.y};
   };
-  const int b_lo = slab * p.sps, b_hi = min(p.B, b_lo + p.sps);
+  // One barrier per sample: while sample b is multiplied out of buffer `cur`, sample b + 1 is split into the other buffer (its
+  // loads went out one sample earlier) and sample b + 2's loads are requested.
   if (b_lo < b_hi) fetch(b_lo);
-  for (int b = b_lo; b < b_hi; ++b) {
-    __syncthreads();      // the previous sample's fragments have been read (and, first time round, the images are zeroed)
-    stage();
-    __syncthreads();
-    if (b + 1 < b_hi) fetch(b + 1);
+  __syncthreads();                 // the buffers are zeroed, h2s is in place
+  if (b_lo < b_hi) stage(dws_smem);
+  if (b_lo + 1 < b_hi) fetch(b_lo + 1);
+  __syncthreads();
+  int cur = 0;
+  for (int b = b_lo; b < b_hi; ++b, cur ^= 1) {
+    const char* gim = dws_smem + cur * IMG;
+    const char* xim = gim + 3 * kRows * PG;
+    if (b + 1 < b_hi) {
+      stage(dws_smem + (cur ^ 1) * IMG);
+      if (b + 2 < b_hi) fetch(b + 2);
+    }
     f32x4v P[2][LBW];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int lb = 0; lb < LBW; ++lb) P[j][lb] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      s16x4 a[3][2], bx[3][LBW];
+    for (int s = 0; s < 2; ++s) {
+      u32x4v a[3][2], bx[3][LBW];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
@@ -168,47 +189,41 @@ __global__ __launch_bounds__(256, 1) void bilinear_dw_split_kernel(DwSplitArgs p
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int lb = 0; lb < LBW; ++lb) P[j][lb] = mfma16(a[PA[k]][j], bx[PB[k]][lb], P[j][lb]);
+          for (int lb = 0; lb < LBW; ++lb) P[j][lb] = mfma32(a[PA[k]][j], bx[PB[k]][lb], P[j][lb]);
     }
     // fold into the slab's gradients; contract against W1_r (and b1_r in column L) for dh2
-    float part[kR][2][4];
+    const float* hq = h2s + (size_t)(b - b_lo) * kR * 64;
 #pragma unroll
     for (int r = 0; r < kR; ++r)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        f32x4v qh;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int h = h0 + 16 * (2 * wh + j) + 4 * gq + i;
-          qh[i] = h < H ? p.h2[((size_t)b * kR + r) * H + h] : 0.f;
-          part[r][j][i] = 0.f;
-        }
+        const f32x4v qh = *reinterpret_cast<const f32x4v*>(hq + r * 64 + 16 * (2 * wh + j) + 4 * gq);
+        f32x4v part = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int lb = 0; lb < LBW; ++lb) {
           dw[r][j][lb] += qh * P[j][lb];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) part[r][j][i] = fmaf(P[j][lb][i], w1f[r][j][lb][i], part[r][j][i]);
+          for (int i = 0; i < 4; ++i) part[i] = fmaf(P[j][lb][i], w1f[r][j][lb][i], part[i]);
         }
-      }
-#pragma unroll
-    for (int r = 0; r < kR; ++r)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
+        // sum over the 16 columns of a block (the lanes r16); each column wave writes its own partial sum (4 parts in all)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float s = part[r][j][i];
+          float s = part[i];
           s += __shfl_xor(s, 1);
           s += __shfl_xor(s, 2);
           s += __shfl_xor(s, 4);
           s += __shfl_xor(s, 8);
-          if (r16 == 0) red[(wl * kR + r) * 64 + 16 * (2 * wh + j) + 4 * gq + i] = s;
+          part[i] = s;
         }
+        const int h = h0 + 16 * (2 * wh + j) + 4 * gq;
+        if (r16 == 0) {
+          float* dst = p.part + (size_t)(2 * lh + wl) * p.B * kR * H + ((size_t)b * kR + r) * H + h;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (h + i < H) dst[i] = part[i];
+        }
+      }
     __syncthreads();
-    if (threadIdx.x < kR * 64) {
-      const int r = threadIdx.x >> 6, h = threadIdx.x & 63;
-      if (h0 + h < H)
-        p.part[(size_t)lh * p.B * kR * H + ((size_t)b * kR + r) * H + h0 + h] = red[(0 * kR + r) * 64 + h] + red[(1 * kR + r) * 64 + h];
-    }
   }
   // slab[slab][r][h][l] (l < L) and dbslab[slab][r][h] (column L)
 #pragma unroll
@@ -262,7 +277,8 @@ int dw_split_launch(const float* g, const float* x, const float* h2, const float
   const dim3 grid(kDwSplitSlabs * 2 * ((H + 63) / 64));
 #define LAUNCH(LBW_)                                                                                                   \
   {                                                                                                                    \
-    const size_t lds = (size_t)3 * kRows * (64 * 2 + 16) + (size_t)3 * kRows * (32 * LBW_ * 2 + 16) + 2 * kR * 64 * 4; \
+    const size_t lds = 2 * ((size_t)3 * kRows * (64 * 2 + 16) + (size_t)3 * kRows * (32 * LBW_ * 2 + 16)) +          \
+                       (size_t)a.sps * kR * 64 * 4;                                                                    \
     VQA_ENSURE_LDS((bilinear_dw_split_kernel<LBW_>), lds);                                                             \
     VQA_LAUNCH((bilinear_dw_split_kernel<LBW_>), grid, dim3(256), lds, s, a);                                          \
   }

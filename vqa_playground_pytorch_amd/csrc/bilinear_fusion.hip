@@ -825,14 +825,14 @@ extern "C" int vqa_lowrank_bilinear_fusion_folded_bwd_gated(const float* x, int 
   }
   // (2) P_b = g_b^T x_b once per sample: dW1_r, db1_r slabs and dh2
   if (dw_split_supported(B, N, L, H, R, ldx)) {
-    // split engine (bilinear_dw_split.hip): 16 slabs, dh2 in two partial sums
+    // split engine (bilinear_dw_split.hip): 16 slabs, dh2 in four partial sums (the workspace holds 2 * tiles_n >= 4 of them)
     rc = dw_split_launch(g, x, h2, w1, b1, slab, dbslab, part, B, N, L, H, R, s);
     if (rc != VQA_OK) return rc;
     const int HL2 = H * L;
     const size_t n2 = (size_t)B * R * H;
     const int nb_dw = (HL2 / 2 + 255) / 256, nb_dh2 = (int)((n2 / 2 + 255) / 256);
     VQA_LAUNCH(bilinear_dw_dh2_reduce_kernel, dim3(R * nb_dw + nb_dh2), dim3(256), 0, s, slab, dbslab, ro, HL2, H, R,
-                       kDwSplitSlabs, nb_dw, part, d_h2, n2, 2);
+                       kDwSplitSlabs, nb_dw, part, d_h2, n2, 4);
     return check_launch("lowrank_bilinear_fusion_folded_bwd");
   }
   if (dw_rt_supported(B, N, L, H, R, ldx) && dw_fold_splits(B, N, H, L, R) >= kDwRtGroups) {
