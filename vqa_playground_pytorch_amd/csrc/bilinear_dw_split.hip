@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, 1) void bilinear_dw_split_kernel(DwSplitArgs p
   extern __shared__ __attribute__((aligned(16))) char dws_smem[];
   constexpr int LH = 32 * LBW;                     // columns of this workgroup's half (2 waves x LBW blocks x 16)
   constexpr int PG = 64 * 2 + 16, PX = LH * 2 + 16;   // row pitches of the plane images (bytes)
-  constexpr int GPAIRS = 36 * 32, XPAIRS_ROW = LH / 2;
+  constexpr int XPAIRS_ROW = LH / 2;
   constexpr int IMG = 3 * kRows * (PG + PX);       // one buffer: [3 planes][kRows][PG] then [3 planes][kRows][PX]
   float* h2s = reinterpret_cast<float*>(dws_smem + 2 * IMG);     // [sps][R][64]: the slab's question-side factors of this h tile
   const int L = p.L, H = p.H, N = p.N;
@@ -88,56 +88,56 @@ __global__ __launch_bounds__(256, 1) void bilinear_dw_split_kernel(DwSplitArgs p
 #pragma unroll
       for (int lb = 0; lb < LBW; ++lb) dw[r][j][lb] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-  // ---- staging: float2 pieces (rows of g / x are 8-byte aligned: H and L are even), split into the three plane images
-  constexpr int GP = (GPAIRS + 255) / 256;                 // pieces per thread
-  constexpr int XP = (36 * XPAIRS_ROW + 255) / 256;
+  // ---- staging: float2 pieces (rows of g / x are 8-byte aligned: H and L are even), split into the three plane images.
+  // Everything about a piece but the sample is fixed per thread and hoisted: g tile -- thread (row t >> 5, pair t & 31), pieces 8
+  // rows apart; x tile -- threads 0..239 as (row t / XPAIRS_ROW', pair), pieces 3 rows apart (N = 36 = 12 x 3); a sample only
+  // moves the base pointer.  (Recomputed per piece and sample the addressing was 600 of the kernel's 970 VALU instructions per
+  // sample and wave: rocprofv3 SQ_INSTS_VALU, tools/k4_dw_counters.sh.)
+  constexpr int GP = 5, XP = 12;
+  static_assert(XPAIRS_ROW * 3 <= 256, "three rows of x pairs per pass");
+  const int gc = threadIdx.x & 31, gr = threadIdx.x >> 5;
+  const bool g_ok = h0 + 2 * gc < H;                         // (only the last h tile has pairs past H)
+  const uint32_t goff = (uint32_t)(gr * H + min(h0 + 2 * gc, H - 2));
+  const uint32_t glds = (uint32_t)(gr * PG + 4 * gc);
+  const sp::f32x2 gmask = g_ok ? sp::f32x2{1.f, 1.f} : sp::f32x2{0.f, 0.f};
+  const bool x_thread = threadIdx.x < 3 * XPAIRS_ROW;
+  const int xr = threadIdx.x / XPAIRS_ROW, xc = threadIdx.x - xr * XPAIRS_ROW, xl = lbase + 2 * xc;
+  const uint32_t xoff = (uint32_t)(xr * L + min(xl, L - 2));
+  const uint32_t xlds = (uint32_t)(xr * PX + 4 * xc);
+  const sp::f32x2 xmask = xl < L ? sp::f32x2{1.f, 1.f} : sp::f32x2{0.f, 0.f};
+  const sp::f32x2 xone = xl == L ? sp::f32x2{1.f, 0.f} : sp::f32x2{0.f, 0.f};     // column L: the constant 1
   sp::f32x2 sg[GP], sx[XP];
   auto fetch = [&](int b) {
+    const float* gb = p.g + (size_t)b * N * H + goff;
+    const float* xb = p.x + (size_t)b * N * L + xoff;
 #pragma unroll
-    for (int k = 0; k < GP; ++k) {
-      const int t = threadIdx.x + 256 * k;
-      const int row = t >> 5, c = t & 31, h = h0 + 2 * c;
-      sg[k] = sp::f32x2{0.f, 0.f};
-      if (row < N && h < H) sg[k] = *reinterpret_cast<const sp::f32x2*>(p.g + ((size_t)b * N + row) * H + h);
-    }
+    for (int k = 0; k < GP; ++k)
+      if (k < 4 || wave < 2) sg[k] = *reinterpret_cast<const sp::f32x2*>(gb + (size_t)k * 8 * H);     // rows 32..35: waves 0, 1
+    if (x_thread) {
 #pragma unroll
-    for (int k = 0; k < XP; ++k) {
-      const int t = threadIdx.x + 256 * k;
-      const int row = t / XPAIRS_ROW, c = t - row * XPAIRS_ROW, l = lbase + 2 * c;
-      sx[k] = sp::f32x2{0.f, 0.f};
-      if (row < N) {
-        if (l < L) sx[k] = *reinterpret_cast<const sp::f32x2*>(p.x + ((size_t)b * N + row) * L + l);
-        else if (l == L) sx[k] = sp::f32x2{1.f, 0.f};
-      }
+      for (int k = 0; k < XP; ++k) sx[k] = *reinterpret_cast<const sp::f32x2*>(xb + (size_t)k * 3 * L);
     }
   };
   auto stage = [&](char* buf) {
-    char* gim = buf;
-    char* xim = buf + 3 * kRows * PG;
+    char* gdst = buf + glds;
+    char* xdst = buf + 3 * kRows * PG + xlds;
 #pragma unroll
-    for (int k = 0; k < GP; ++k) {
-      const int t = threadIdx.x + 256 * k;
-      const int row = t >> 5, c = t & 31;
-      if (row < 36 && row < N) {
+    for (int k = 0; k < GP; ++k)
+      if (k < 4 || wave < 2) {
         uint32_t q0, q1, q2;
-        sp::split_pair<false>(sg[k], q0, q1, q2);
-        char* dst = gim + (size_t)row * PG + 4 * c;
-        *reinterpret_cast<uint32_t*>(dst) = q0;
-        *reinterpret_cast<uint32_t*>(dst + kRows * PG) = q1;
-        *reinterpret_cast<uint32_t*>(dst + 2 * kRows * PG) = q2;
+        sp::split_pair<false>(sg[k] * gmask, q0, q1, q2);
+        *reinterpret_cast<uint32_t*>(gdst + k * 8 * PG) = q0;
+        *reinterpret_cast<uint32_t*>(gdst + k * 8 * PG + kRows * PG) = q1;
+        *reinterpret_cast<uint32_t*>(gdst + k * 8 * PG + 2 * kRows * PG) = q2;
       }
-    }
+    if (x_thread) {
 #pragma unroll
-    for (int k = 0; k < XP; ++k) {
-      const int t = threadIdx.x + 256 * k;
-      const int row = t / XPAIRS_ROW, c = t - row * XPAIRS_ROW;
-      if (row < 36 && row < N) {
+      for (int k = 0; k < XP; ++k) {
         uint32_t q0, q1, q2;
-        sp::split_pair<false>(sx[k], q0, q1, q2);
-        char* dst = xim + (size_t)row * PX + 4 * c;
-        *reinterpret_cast<uint32_t*>(dst) = q0;
-        *reinterpret_cast<uint32_t*>(dst + kRows * PX) = q1;
-        *reinterpret_cast<uint32_t*>(dst + 2 * kRows * PX) = q2;
+        sp::split_pair<false>(sx[k] * xmask + xone, q0, q1, q2);
+        *reinterpret_cast<uint32_t*>(xdst + k * 3 * PX) = q0;
+        *reinterpret_cast<uint32_t*>(xdst + k * 3 * PX + kRows * PX) = q1;
+        *reinterpret_cast<uint32_t*>(xdst + k * 3 * PX + 2 * kRows * PX) = q2;
       }
     }
   };
@@ -251,8 +251,9 @@ __global__ __launch_bounds__(256, 1) void bilinear_dw_split_kernel(DwSplitArgs p
 bool dw_split_supported(int B, int N, int L, int H, int R, int ldx) {
   if (vqa::option_is("VQA_K4_DW_SPLIT", '0')) return false;
   const int lbw = (L + 1 + 63) / 64;
-  return R == kR && N >= 1 && N <= 36 && ldx == L && L % 2 == 0 && H % 2 == 0 && lbw >= 1 && lbw <= 5 && H >= 16 && B >= 64 &&
-         (size_t)B * N * H * 4 < (1ull << 32) && (size_t)B * N * L * 4 < (1ull << 32);
+  // (N = 36: the staging's piece maps are built for it; B <= 512: the slab's question-side factors wait in LDS, 32 samples' worth)
+  return R == kR && N == 36 && ldx == L && L % 2 == 0 && L >= 2 && H % 2 == 0 && lbw >= 1 && lbw <= 5 && H >= 16 && B >= 64 &&
+         (B + kDwSplitSlabs - 1) / kDwSplitSlabs <= 32 && (size_t)B * N * H * 4 < (1ull << 32) && (size_t)B * N * L * 4 < (1ull << 32);
 }
 
 int dw_split_launch(const float* g, const float* x, const float* h2, const float* const* w1, const float* const* b1, float* slab,
