@@ -456,12 +456,17 @@ def test_lowrank_bilinear_fusion_full_size_properties(ops, monkeypatch, form):
     assert (out2 - 3.0 * out).abs().max().item() <= 1e-5 * scale * 3
 
 
-@pytest.mark.parametrize("form", ["folded", "engine"])
-@pytest.mark.parametrize("B,N", [(1501, 36), (203, 100), (4099, 36)])
-def test_lowrank_bilinear_fusion_large_batch_against_torch_fp64(ops, monkeypatch, form, B, N):
+@pytest.mark.parametrize("form", ["folded", "engine", "folded+dw_split"])
+@pytest.mark.parametrize("B,N", [(1501, 36), (203, 100), (4099, 36), (512, 36), (333, 36)])
+def test_lowrank_bilinear_fusion_large_batch_against_torch_fp64(ops, monkeypatch, lib_option, form, B, N):
     """Folded K4, forward and every gradient, at batches that are no multiple of its 8- / 4-sample groups and give the
     weight-gradient kernel uneven sample slabs -- 4099 samples also exceed what one slab can keep of the question-side
-    factors in LDS (regression: the slab count must grow with the batch); reference = torch autograd in fp64 on the GPU."""
+    factors in LDS (regression: the slab count must grow with the batch); reference = torch autograd in fp64 on the GPU.
+    folded+dw_split: the weight gradient on the split engine (csrc/bilinear_dw_split.hip, VQA_K4_DW_SPLIT=1; it serves N = 36 and
+    B <= 512, every other shape stays on the fp32 kernels) -- same bars."""
+    if form == "folded+dw_split":
+        lib_option("VQA_K4_DW_SPLIT", "1")
+        form = "folded"
     monkeypatch.setattr(ops, "_K4_FORM", form)
     L, H, R = 310, 510, 2
     gen = torch.Generator(device="cpu").manual_seed(11)

@@ -248,8 +248,11 @@ __global__ __launch_bounds__(256, 1) void bilinear_dw_split_kernel(DwSplitArgs p
 
 }  // namespace
 
+// OPT-IN (VQA_K4_DW_SPLIT=1): measured at B = 512 the kernel takes ~150 us against the fp32 register-tile form's 86
+// (docs/measured_negatives_r05.md: 730 VALU instructions per sample and wave -- the fold's accumulators live in AGPRs next to
+// 80 registers of W1 and every FMA on them is three instructions -- and 185 LDS instructions for 120 MFMAs).
 bool dw_split_supported(int B, int N, int L, int H, int R, int ldx) {
-  if (vqa::option_is("VQA_K4_DW_SPLIT", '0')) return false;
+  if (!vqa::option_is("VQA_K4_DW_SPLIT", '1')) return false;
   const int lbw = (L + 1 + 63) / 64;
   // (N = 36: the staging's piece maps are built for it; B <= 512: the slab's question-side factors wait in LDS, 32 samples' worth)
   return R == kR && N == 36 && ldx == L && L % 2 == 0 && L >= 2 && H % 2 == 0 && lbw >= 1 && lbw <= 5 && H >= 16 && B >= 64 &&

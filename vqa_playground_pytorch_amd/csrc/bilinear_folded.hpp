@@ -27,8 +27,8 @@ int dw_rt_launch(const float* g, const float* x, const float* h2, const float* c
                  float* dbslab, float* part, int B, int N, int L, int H, int R, hipStream_t s);
 
 // The same product on the split engine (bilinear_dw_split.hip: six bf16 partial products per fp32 product, both operands split
-// while they are staged): same outputs, kDwSplitSlabs sample slabs.  The default where it applies; VQA_K4_DW_SPLIT=0 keeps the
-// fp32 MFMA form.
+// while they are staged): same outputs, kDwSplitSlabs sample slabs.  Opt-in (VQA_K4_DW_SPLIT=1): measured slower than the fp32
+// register-tile form (150 against 86 us at B = 512).
 constexpr int kDwSplitSlabs = 16;
 bool dw_split_supported(int B, int N, int L, int H, int R, int ldx);
 int dw_split_launch(const float* g, const float* x, const float* h2, const float* const* w1, const float* const* b1, float* slab,
