@@ -306,7 +306,7 @@ def compact_line(full):
     line["config"] = _pick(cfg, ("workload", "global_batch", "parallelism", "launch", "relation_mode", "f32_products", "inputs"))
     line["config"]["workload"] = str(line["config"].get("workload", ""))[:130]
     line["roofline"] = _pick(full.get("roofline"), ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "mean_ms",
-                                                    "launches", "mfma_busy_pct"))
+                                                    "launches", "mfma_busy_pct", "valu_issue_pct_min"))
     if full.get("cpu_baseline") is not None:
         cb = full["cpu_baseline"]
         line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "host_cores", "sweep"))
@@ -837,8 +837,9 @@ def main():
                         "launches": launches, "ms_per_step": round(sum(e["ms_per_step"] for e in group), 5),
                         "shapes": [e["shape"] for e in group],
                         "device_kernels": lead.get("device_kernels", PMC_KERNELS.get(name, []))}
-            if "mfma_busy_pct" in lead:
-                dominant["mfma_busy_pct"] = lead["mfma_busy_pct"]
+            for k in ("mfma_busy_pct", "valu_issue_pct_min"):
+                if k in lead:
+                    dominant[k] = lead[k]
         else:
             dominant = dict(entries[0])
         kernel_ms = sum(e["ms_per_step"] for e in entries)
