@@ -70,7 +70,7 @@ def work_of(name, shape):
     if base in ("relation_projection_dgrad", "relation_projection_dgrad_split"):
         B, N, D, L = s[:4]
         return "mfma", 2 * B * N * D * L                                              # the data-gradient contraction
-    if base == "grouped_gemm":                                                            # K6: every GEMM of a phase of the
+    if base in ("grouped_gemm", "grouped_gemm_split"):                                    # K6: every GEMM of a phase of the
         return "mfma", s[2]                                                               # [B,.] layers (head.py), FLOPs summed
     if base == "grouped_epilogue":
         return "hbm", s[2] * f                                                            # slabs read + outputs written
@@ -158,6 +158,7 @@ PMC_KERNELS = {  # C-ABI entry -> kernel-name prefixes of its dominant device ke
     "softmax_attention_pool_drop_fwd": ["vqa::attention_pool_fwd_kernel"],
     "softmax_attention_pool_drop_bwd": ["vqa::attention_pool_bwd_fused_kernel", "vqa::attention_pool_bwd_stream_kernel"],
     "grouped_gemm": ["vqa::grouped_gemm_kernel"],
+    "grouped_gemm_split": ["vqa::grouped_gemm_split_kernel"],
     "grouped_epilogue": ["vqa::grouped_epilogue_kernel"],
     "object_difference_attention_fwd": ["vqa::oda_fwd"],
     "object_difference_attention_bwd": ["vqa::oda_bwd_data", "vqa::oda_bwd_weight"],

@@ -32,10 +32,15 @@ def close(name, got, want, rtol=RTOL):
     assert err <= rtol, "%s: rel err %.3e" % (name, err)
 
 
-@pytest.fixture(scope="module")
-def head():
+@pytest.fixture(scope="module", params=["split", "mfma"])
+def head(request):
+    """The module with the phases' GEMM launch pinned to one engine: csrc/grouped_gemm_split.hip (the default with the split
+    products) or csrc/grouped_gemm.hip (fp32 MFMA)."""
     from vqa_playground_pytorch_amd import head as h
-    return h
+    before = h.Phase.ENGINE
+    h.Phase.ENGINE = request.param
+    yield h
+    h.Phase.ENGINE = before
 
 
 @pytest.mark.parametrize("M,N,K", [(512, 310, 2400), (3, 155, 2048), (64, 64, 16), (130, 2000, 510), (1, 310, 310), (77, 620, 1240)])

@@ -1,6 +1,7 @@
 """CPU-side checks of the product package: the C-ABI library loads and exports every symbol the
 header declares, the nn.Module surface matches the reference's (names, shapes, errors), and the
 product path refuses to run without a GPU instead of falling back."""
+import math
 import os
 import re
 
@@ -257,6 +258,32 @@ def test_head_mode_selects_the_grouped_phases_per_model(monkeypatch):
         assert head.glimpses_grouped() is glimpses
     monkeypatch.setattr(head, "MODE", "grouped")
     assert head.supported("cor2", 2400, 311) is False
+
+
+def test_grouped_phases_follow_the_products_engine_and_size_their_parts(monkeypatch):
+    """head.Phase: the phases' GEMM launch runs on the engine of the step's other fp32 products unless VQA_GROUPED_ENGINE pins
+    it; the Python tile rule is the library's (vqa_grouped_gemm_split_tile_cols); the part planner cuts a phase so that its
+    in-order schedule over 256 units is no longer than the uncut one's."""
+    from vqa_playground_pytorch_amd import head
+    L_ = _lib.lib()
+    for n in list(range(1, 700)) + [1020, 1240, 2048, 2400, 3000]:
+        assert head.Phase.split_tile_cols(n) == L_.vqa_grouped_gemm_split_tile_cols(n), n
+    assert [head.Phase.split_tile_cols(n) for n in (310, 2048, 2400, 510)] == [160, 128, 160, 128]
+    monkeypatch.setattr(head.Phase, "ENGINE", "auto")
+    monkeypatch.delenv("VQA_F32_PRODUCTS", raising=False)
+    assert head.Phase.engine() == "split"
+    monkeypatch.setenv("VQA_F32_PRODUCTS", "mfma")
+    assert head.Phase.engine() == "mfma"
+    monkeypatch.setattr(head.Phase, "ENGINE", "split")
+    assert head.Phase.engine() == "split"
+    monkeypatch.setattr(head.Phase, "ENGINE", "fp64")
+    with pytest.raises(ValueError):
+        head.Phase.engine()
+    # the four question projections at B = 512: 4 x (4 x 2 tiles) x 75 steps -> 8 parts each = 256 items, one per CU
+    part = head.Phase._plan_split([(8, 75)] * 4)
+    assert math.ceil(75 / part) == 8
+    # a phase that already holds a chip's worth of short items is left uncut
+    assert head.Phase._plan_split([(64, 10)] * 2 + [(32, 10)] * 3) >= 10
 
 
 def test_split_engine_is_the_default_and_refuses_what_it_cannot_run(monkeypatch):

@@ -2,7 +2,7 @@
 """Grouped-GEMM phases of the CoR2 step (B = 512) as raw problem tables -- no autograd, no epilogue fusion: one
 vqa_grouped_gemm + one vqa_grouped_epilogue (plain slab sums) per phase -- against the library on the same products.
 
-    python tools/gg_bench.py [--rounds 5] [--batch 512] [--check]
+    [VQA_GROUPED_ENGINE=split|mfma] python tools/gg_bench.py [--rounds 5] [--batch 512] [--check] [--gemm-only]
     rocprofv3 --kernel-trace --output-format csv -d /tmp/gg -o gg -- python3 tools/gg_bench.py --rounds 2 ; python tools/by_grid.py /tmp/gg 1
 
 GPU-side time: each batch of calls is queued behind a device-side sleep (the Python cost of a phase exceeds its kernels)."""
@@ -97,7 +97,10 @@ def main():
             if not info:
                 sized = ph._size()
                 info["parts"] = sorted({(p["ksplit"], p["splits"]) for _, p in sized})
-                info["items"] = sum(-(-t.M // head.Phase.TILE_M) * -(-t.N // 64) * p["splits"] for t, p in sized)
+                if head.Phase.engine() == "split":
+                    info["items"] = sum(-(-t.M // 128) * -(-t.N // head.Phase.split_tile_cols(t.N)) * p["splits"] for t, p in sized)
+                else:
+                    info["items"] = sum(-(-t.M // head.Phase.TILE_M) * -(-t.N // 64) * p["splits"] for t, p in sized)
             ph.run()
 
         def lib():

@@ -9,7 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VQA_LIB_PATH", os.path.join(_HERE, "libvqa_mi355x.so"))  # env override: profiling builds
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _c_f = ctypes.c_void_p          # device pointer to fp32
 _c_pp = ctypes.c_void_p         # host array of device pointers
@@ -121,6 +121,8 @@ SIGNATURES = {
     "vqa_gate_product_fwd": (_c_i, [_c_f, _c_f, ctypes.c_long, _c_f, _c_i, _c_i, _c_st]),
     "vqa_gate_product_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_long, _c_f, _c_f, _c_f, _c_i, _c_i, _c_st]),
     "vqa_grouped_gemm": (_c_i, [ctypes.c_void_p, _c_i, _c_st]),
+    "vqa_grouped_gemm_split": (_c_i, [ctypes.c_void_p, _c_i, _c_st]),
+    "vqa_grouped_gemm_split_tile_cols": (_c_i, [_c_i]),
     "vqa_grouped_epilogue": (_c_i, [ctypes.c_void_p, _c_i, _c_st]),
     "vqa_gru_gates_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_f, _c_f, _c_f, _c_f,
                                  _c_i, _c_i, _c_i, _c_i, _c_i, _c_st]),

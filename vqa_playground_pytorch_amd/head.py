@@ -17,6 +17,7 @@ so the producer's backward starts at its GEMMs.  Activations that feed a dropout
 x/(1-p)), like K3 stores the pooled glimpses: "stored value > 0" is then "kept and active".
 """
 import ctypes
+import heapq
 import math
 import os
 
@@ -99,6 +100,13 @@ class Phase:
     TILE_M = 128 if os.environ.get("VQA_GROUPED_BM") == "128" else 64
     DIRECT = os.environ.get("VQA_GROUPED_DIRECT", "1") == "1"
     STEP_K = 16        # the kernel's K step: a contraction part is a whole number of steps
+    # Which matrix engine runs the phase's GEMM launch: "mfma" = csrc/grouped_gemm.hip on the fp32 MFMA (the default while the
+    # split form measures within 4 % of it); "split" = csrc/grouped_gemm_split.hip (128 x 128|160 tiles, 32-deep steps);
+    # "auto" = the engine of the step's other fp32 products (ops.f32_products()).
+    ENGINE = os.environ.get("VQA_GROUPED_ENGINE", "mfma")
+    SPLIT_UNITS = int(os.environ.get("VQA_GROUPED_SPLIT_UNITS", "256"))   # workgroups the chip runs at once (one per CU)
+    SPLIT_OVERHEAD = float(os.environ.get("VQA_GROUPED_SPLIT_OVERHEAD", "3"))   # an item's fixed cost, in contraction steps
+    _split_plans = {}
 
     def __init__(self, device, name):
         self.device, self.name = device, name
@@ -118,7 +126,62 @@ class Phase:
         """source: a _Target (its reduced slabs) or a tensor [M,N] (S = 1: an elementwise job on existing data)."""
         (self.pre_jobs if pre else self.jobs).append(dict(kind=kind, source=source, out=out, ldo=int(ldo), out_off=out_off, **kw))
 
+    @classmethod
+    def engine(cls):
+        if cls.ENGINE not in ("auto", "split", "mfma"):
+            raise ValueError("VQA_GROUPED_ENGINE must be auto, split or mfma (got %r)" % cls.ENGINE)
+        return ops.f32_products() if cls.ENGINE == "auto" else cls.ENGINE
+
+    @classmethod
+    def _plan_split(cls, shapes):
+        """Contraction steps per part for a launch on the split engine.  shapes: (tiles, steps) per problem -- 128 x BN tiles,
+        32-deep steps.  One workgroup per CU, items dispatched in order: the part length p (every problem is cut into
+        ceil(steps / p) equal parts) is the one whose in-order schedule over SPLIT_UNITS units finishes first, an item
+        costing its steps + SPLIT_OVERHEAD (prologue, the store of a 128 x BN slab)."""
+        key = tuple(shapes)
+        plan = cls._split_plans.get(key)
+        if plan is not None:
+            return plan
+        best = None
+        for part in range(2, max(st for _, st in shapes) + 1):
+            lens = []
+            for tiles, st in shapes:
+                n = math.ceil(st / part)
+                lens += [math.ceil(st / n) + cls.SPLIT_OVERHEAD] * (tiles * n)
+            if len(lens) > (1 << 14):
+                continue
+            units = [0.0] * cls.SPLIT_UNITS
+            # (in-order dispatch: the next item goes to the unit that frees first)
+            heapq.heapify(units)
+            for ln in lens:
+                heapq.heappush(units, heapq.heappop(units) + ln)
+            span = max(units)
+            if best is None or span < best[0] - 1e-9:
+                best = (span, part)
+        plan = best[1] if best is not None else 2
+        cls._split_plans[key] = plan
+        return plan
+
+    @staticmethod
+    def split_tile_cols(N):
+        """Tile width of csrc/grouped_gemm_split.hip for an N-wide output (vqa_grouped_gemm_split_tile_cols): 128 or 160,
+        whichever pads N less; ties go to the wider tile."""
+        w128, w160 = math.ceil(N / 128) * 128, math.ceil(N / 160) * 160
+        return 160 if w160 <= w128 else 128
+
+    def _size_split(self):
+        probs = [(t, p) for t in self.targets for p in t.problems]
+        shapes = [(math.ceil(t.M / 128) * math.ceil(t.N / self.split_tile_cols(t.N)), math.ceil(p["K"] / 32)) for t, p in probs]
+        part = self._plan_split(shapes)
+        for (t, p), (_, st) in zip(probs, shapes):
+            n = math.ceil(st / part)
+            p["ksplit"] = math.ceil(st / n) * 32
+            p["splits"] = math.ceil(p["K"] / p["ksplit"])
+        return probs
+
     def _size(self):
+        if self.engine() == "split":
+            return self._size_split()
         probs = [(t, p) for t in self.targets for p in t.problems]
         tiles = lambda t: math.ceil(t.M / self.TILE_M) * math.ceil(t.N / 64)  # noqa: E731
         part = self.MAX_PART
@@ -196,7 +259,11 @@ class Phase:
                             gp.seed, gp.seed_ptr = sv, (sp.value if sp is not None else None)
                             gp.drop_base, gp.drop_ld = int(j.get("drop_base", 0)), int(j.get("drop_ld", 0))
                     arr[i] = gp
-                ops._launch("grouped_gemm", (self.name, len(probs), flops if lo == 0 else 0), L_.vqa_grouped_gemm, arr, len(chunk))
+                if self.engine() == "split":
+                    ops._launch("grouped_gemm_split", (self.name, len(probs), flops if lo == 0 else 0), L_.vqa_grouped_gemm_split,
+                                arr, len(chunk))
+                else:
+                    ops._launch("grouped_gemm", (self.name, len(probs), flops if lo == 0 else 0), L_.vqa_grouped_gemm, arr, len(chunk))
         if jobs:
             for lo in range(0, len(jobs), MAX_GROUP):
                 self._epilogue(L_, jobs[lo:lo + MAX_GROUP], "post")
