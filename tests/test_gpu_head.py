@@ -198,3 +198,90 @@ def test_head_phases_match_plain_layers(head, B, train):
     if p:
         for site, m in masks.items():
             assert set(torch.unique(m).tolist()) == {0.0, 2.0}, site
+
+
+def _classes(t):
+    """0 finite, 1 +Inf, 2 -Inf, 3 NaN"""
+    return torch.where(torch.isnan(t), 3, torch.where(torch.isposinf(t), 1, torch.where(torch.isneginf(t), 2, 0)))
+
+
+@pytest.mark.parametrize("kind", ["flt_max", "nonfinite", "spread"])
+def test_grouped_split_engine_edge_values(kind):
+    """csrc/grouped_gemm_split.hip at the edges of fp32, all three forms in one launch, against csrc/grouped_gemm.hip (fp32
+    MFMA) and float64: operands next to FLT_MAX (their leading bf16 plane rounds to Inf), +-Inf / NaN, exponents spread over
+    2^-40 .. 2^40.  Same class (finite / +Inf / -Inf / NaN) at every output on both engines -- the split kernel recomputes a
+    non-finite accumulator as an fp32 dot product of the original operands -- and, where finite, an error on the scale of
+    sum |a| |b| within 2 x the fp32 MFMA kernel's."""
+    from vqa_playground_pytorch_amd import head as h
+    M, K, N = 256, 384, 310
+    gen = torch.Generator(device="cpu").manual_seed(2718)
+    x = torch.randn(M, K, generator=gen)
+    w = torch.randn(N, K, generator=gen) / K ** 0.5
+    gy = torch.randn(M, N, generator=gen) / 16
+    fmax = torch.finfo(torch.float32).max
+    if kind == "flt_max":
+        for i, (m, k) in enumerate([(0, 0), (5, 17), (127, 383), (128, 31), (255, 200)]):
+            x[m, k] = fmax * (1.0 if i % 2 == 0 else -1.0) * (1.0 - 2.0 ** -(9 + i))
+            w[:, k] *= 2.0 ** -30
+            gy[m, :] *= 2.0 ** -60
+        w[3, 40] = -fmax * (1.0 - 2.0 ** -12)
+        x[:, 40] *= 2.0 ** -40
+        gy[7, 7] = fmax * (1.0 - 2.0 ** -10)
+        x[7, :] *= 2.0 ** -40
+        w[7, :] *= 2.0 ** -40
+    elif kind == "nonfinite":
+        inf, nan = float("inf"), float("nan")
+        x[1, 3], x[150, 200], x[151, 200], x[255, 383] = inf, -inf, nan, inf
+        x[70, 10], x[70, 11] = inf, -inf
+        w[5, 9], w[300, 100], w[17, 383] = inf, nan, -inf
+        w[40, 3] = 0.0
+        gy[9, 9], gy[100, 309], gy[101, 0] = inf, nan, -inf
+    else:
+        x = x * torch.exp2(torch.randint(-40, 41, x.shape, generator=gen).float())
+        w = w * torch.exp2(torch.randint(-40, 41, w.shape, generator=gen).float())
+        gy = gy * torch.exp2(torch.randint(-40, 41, gy.shape, generator=gen).float())
+    xt, wt, gt = x.to(dev()), w.to(dev()), gy.to(dev())
+
+    def run(engine):
+        before = h.Phase.ENGINE
+        h.Phase.ENGINE = engine
+        try:
+            ph = h.Phase(dev(), "edge")
+            outs = {"y": torch.empty(M, N, device=dev()), "dx": torch.empty(M, K, device=dev()),
+                    "dw": torch.empty(N, K, device=dev()), "db": torch.empty(N, device=dev())}
+            t1 = ph.target(M, N)
+            ph.gemm(t1, h.NT, xt, K, wt, K, K)
+            ph.job(h.EPI_SUM, t1, outs["y"], N)
+            t2 = ph.target(M, K)
+            ph.gemm(t2, h.NN, gt, N, wt, K, N)
+            ph.job(h.EPI_SUM, t2, outs["dx"], K)
+            t3 = ph.target(N, K)
+            ph.gemm(t3, h.TN, gt, N, xt, K, M, colsum=True)
+            ph.job(h.EPI_SUM, t3, outs["dw"], K)
+            ph.job(h.EPI_SUM, t3, outs["db"], N, colsum=True)
+            ph.run()
+            torch.cuda.synchronize()
+            return outs
+        finally:
+            h.Phase.ENGINE = before
+
+    got_s, got_m = run("split"), run("mfma")
+    x64, w64, g64 = xt.double(), wt.double(), gt.double()
+    refs = {"y": (x64 @ w64.t(), x64.abs() @ w64.abs().t()), "dx": (g64 @ w64, g64.abs() @ w64.abs()),
+            "dw": (g64.t() @ x64, g64.abs().t() @ x64.abs()), "db": (g64.sum(0), g64.abs().sum(0))}
+    touched = 0
+    for name, (ref, scale) in refs.items():
+        cs, cm = _classes(got_s[name]), _classes(got_m[name])
+        assert torch.equal(cs, cm), "%s: %d outputs differ in class between the engines" % (name, int((cs != cm).sum()))
+        touched += int((cm != 0).sum())
+        fin = (cm == 0) & torch.isfinite(ref) & torch.isfinite(scale)
+        if kind != "nonfinite":
+            assert bool((cm == 0).all()), "%s: the fp32 MFMA kernel itself is not finite here -- the case is mis-built" % name
+        unit = scale.clamp_min(1e-300)
+        es = ((got_s[name].double() - ref).abs() / unit)[fin]
+        em = ((got_m[name].double() - ref).abs() / unit)[fin]
+        rs, rm = es.pow(2).mean().sqrt().item(), em.pow(2).mean().sqrt().item()
+        assert es.max().item() <= 4e-6, (name, es.max().item())
+        assert rs <= 2.0 * rm + 1e-9, (name, rs, rm)
+    if kind == "nonfinite":
+        assert touched > 0

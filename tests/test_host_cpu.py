@@ -261,8 +261,8 @@ def test_head_mode_selects_the_grouped_phases_per_model(monkeypatch):
 
 
 def test_grouped_phases_follow_the_products_engine_and_size_their_parts(monkeypatch):
-    """head.Phase: the phases' GEMM launch runs on the engine of the step's other fp32 products unless VQA_GROUPED_ENGINE pins
-    it; the Python tile rule is the library's (vqa_grouped_gemm_split_tile_cols); the part planner cuts a phase so that its
+    """head.Phase: with the split products (the default) the phases that measured faster on the split engine run there, the
+    others on the fp32 MFMA; VQA_GROUPED_ENGINE pins one engine for all; the Python tile rule is the library's (vqa_grouped_gemm_split_tile_cols); the part planner cuts a phase so that its
     in-order schedule over 256 units is no longer than the uncut one's."""
     from vqa_playground_pytorch_amd import head
     L_ = _lib.lib()
@@ -271,11 +271,13 @@ def test_grouped_phases_follow_the_products_engine_and_size_their_parts(monkeypa
     assert [head.Phase.split_tile_cols(n) for n in (310, 2048, 2400, 510)] == [160, 128, 160, 128]
     monkeypatch.setattr(head.Phase, "ENGINE", "auto")
     monkeypatch.delenv("VQA_F32_PRODUCTS", raising=False)
-    assert head.Phase.engine() == "split"
+    assert head.Phase.engine("q_proj_fwd") == "split" and head.Phase.engine("q_proj_bwd") == "mfma" and head.Phase.engine() == "mfma"
     monkeypatch.setenv("VQA_F32_PRODUCTS", "mfma")
-    assert head.Phase.engine() == "mfma"
+    assert head.Phase.engine("q_proj_fwd") == "mfma"
     monkeypatch.setattr(head.Phase, "ENGINE", "split")
-    assert head.Phase.engine() == "split"
+    assert head.Phase.engine("q_proj_bwd") == "split" and head.Phase.engine() == "split"
+    monkeypatch.setattr(head.Phase, "ENGINE", "mixed")
+    assert [head.Phase.engine(n) for n in ("classifier_bwd", "classifier_fwd")] == ["split", "mfma"]
     monkeypatch.setattr(head.Phase, "ENGINE", "fp64")
     with pytest.raises(ValueError):
         head.Phase.engine()

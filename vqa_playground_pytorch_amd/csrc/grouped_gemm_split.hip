@@ -7,17 +7,29 @@
 // M = 512 rows leave no room for the 144 x 80 register tiles of the region-sized split kernels, and the three operand
 // orientations (forward NT, data gradient NN, weight gradient TN) rule out one pre-packed plane image per weight.  So both
 // operands are split WHILE THEY ARE STAGED into LDS, once per workgroup tile:
-//   workgroup = 128 x BN outputs (BN = 128 or 160 per problem: whichever pads its N less -- 310 = 2 x 160, 2048 = 16 x 128),
-//               4 waves = 2 (64-row halves: 4 blocks of 16) x 2 (BN / 2 columns: CB = 4 or 5 blocks), 16 CB accumulators each;
-//   per 32-deep contraction step: 256 threads fetch (128 + BN) x 32 fp32 (the loads went out one step earlier), split them
-//               (7 VALU instructions per pair) and write the three bf16 planes of the NEXT step into the other LDS buffer; every
-//               wave reads 3 x (4 + CB) fragments back and issues 24 CB MFMAs; one barrier per step.
+//   workgroup = 128 x BN outputs (BN = 128 or 160 per problem: whichever pads its N less -- 310 = 2 x 160, 2048 = 16 x 128) of one
+//               contraction part, 8 waves of two kinds, one of each per SIMD:
+//     waves 4..7 stage: per 32-deep step 256 threads fetch (128 + BN) x 32 fp32 (buffer loads: out-of-range rows, columns and k
+//               come back as zeros; the loads of step s + 2 go out when step s + 1 has been staged), split them (9 VALU
+//               instructions per pair of elements) and write the three bf16 planes of step s + 1 into the LDS stage that is not
+//               being read;
+//     waves 0..3 multiply: 2 (64-row halves: 4 blocks of 16) x 2 (BN / 2 columns: CB = 4 or 5 blocks), 16 CB accumulators each;
+//               per step 3 (4 + CB) fragment reads and 24 CB MFMAs out of the other stage.  One barrier per step.
 //   K-contiguous operands (A of NT / NN, B of NT) are stored in fragment order -- [16-row block][plane][lane][8 bf16] -- so a
 //               fragment is one contiguous KiB (ds_read_b128); operands whose contraction index is the ROW in memory (B of NN,
 //               both of TN) are stored as they lie -- [plane][k][mn] bf16 -- and come back as fragments through gfx950's
 //               transposing read (ds_read_b64_tr_b16: four consecutive k of one column per lane), as in bilinear_dw_split.hip.
 // LDS traffic per step is (128 + BN) x 32 x 6 bytes written + 4 x (4 + CB) x 3 KiB read = 163 KiB for 1920 matrix-pipe
 // cycles (BN = 160): two thirds of the LDS rate, which is what bounds the tile from below -- a 64 x 64 tile would need 1.5 x it.
+//
+// Measured (tools/gs_probe.py, 256 tiles, one per CU): 2.3 us per step = 135-145 TFLOP/s at K = 2560 against 88-90 on the fp32
+// MFMA kernel, and 9-12 us per work item that do not depend on K (launch, two memory latencies, 80 KiB of slab per item).  The
+// step costs 1.47 us without the staging work and the difference is the staging's VALU instructions at their full issue time --
+// whether they run in the multiplying waves' own instruction stream, interleaved MFMA by MFMA (the first form of this kernel:
+// 2.23 us), or in other waves (this form): with every CU multiplying the chip runs at its power limit and work adds up.  With
+// ~10-step parts (what fills 256 CUs from M = 512 rows) the fixed cost weighs as much as the loop: the phases of the CoR2 head
+// come out between 0.77 and 1.36 x the fp32 MFMA launch's time, and head.py runs on this kernel the ones that win
+// (Phase.SPLIT_PHASES: -15 us per step).
 //
 // Domain: all of fp32, by the repair path of gemm_f32_split.hpp -- an accumulator that comes out non-finite (an operand was
 // Inf / NaN or within half a bf16 ulp of FLT_MAX) is recomputed as a plain fp32 dot product of the original operands.
@@ -31,7 +43,7 @@ using sp::f32x4;
 using sp::u32x4;
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kGsThreads = 256;
+constexpr int kGsThreads = 512;   // 4 multiplying + 4 staging waves
 constexpr int kGsBM = 128;
 constexpr int kGsMaxGemms = VQA_GROUPED_GEMM_MAX;
 // one LDS stage: A region (K-contiguous: 8 blocks x 3 KiB = 24576; row-contraction: 96 rows x 288) + B region (10 x 3 KiB = 30720;
@@ -126,11 +138,7 @@ struct Operand {
   // wait in `keep` for the odd item that completes the 8-byte slot.
   __device__ __forceinline__ void stage_item(f32x2 v, int q, char* dst, int t, uint32_t (&keep)[3]) const {
     uint32_t w[3];
-#if defined(GS_TUNE) && (GS_TUNE & 8)
-    w[0] = (__float_as_uint(v[0]) >> 16) | (__float_as_uint(v[1]) & 0xFFFF0000u), w[1] = 0, w[2] = 0;
-#else
     sp::split_pair<false>(v, w[0], w[1], w[2]);
-#endif
     if constexpr (KC) {
       if ((q & 1) == 0) {
 #pragma unroll
@@ -178,63 +186,88 @@ __device__ __forceinline__ float gs_elem(const float* p, int ld, int mn_valid, i
 template <int CB, bool A_KC, bool B_KC, bool A_SCALAR>
 __device__ __forceinline__ void gs_tile(const VqaGemmProblem& pr, const int m0, const int n0, const int split, char* smem) {
   constexpr int BN = 32 * CB;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1, r16 = lane & 15, gq = lane >> 4;
   const int k_begin = split * pr.ksplit, k_end = min(pr.K, k_begin + pr.ksplit);
   const int lim_a = min(k_end, pr.Ka), lim_b = min(k_end, pr.Kb);
   const int steps = (k_end - k_begin + 31) >> 5;
   const int mn_a = A_KC ? pr.M : pr.Ma, mn_b = B_KC ? pr.N : pr.Nb;
-  Operand<A_KC, kGsBM, A_SCALAR> oa;
-  Operand<B_KC, BN, false> ob;
-  oa.init(pr.A, pr.lda, mn_a, pr.Ka, m0, t);     // (the descriptors are made here, ahead of every divergent region: SGPR quads)
-  ob.init(pr.B, pr.ldb, mn_b, pr.Kb, n0, t);
   const bool want_colsum = !A_KC && (pr.colsum != nullptr || pr.colsum_out != nullptr) && n0 == 0;   // (wave-uniform)
-  const float colsum_on = want_colsum ? 1.f : 0.f;
-  f32x2 colsum = f32x2{0.f, 0.f};
+  // Two kinds of waves, one of each on every SIMD (the role is a scalar: no divergence, the buffer descriptors stay SGPR quads):
+  //   waves 4..7 STAGE: fetch (128 + BN) x 32 fp32 per step, split them, write the bf16 planes of step s + 1 into the LDS stage
+  //              the MFMA waves are not reading, request step s + 2 -- ~240 VALU instructions per step and wave;
+  //   waves 0..3 MULTIPLY: 3 (4 + CB) fragment reads and 24 CB MFMAs per step out of the other stage.
+  // A wave's own VALU work does not hide behind its own MFMAs (measured: every split instruction added its issue time to the
+  // step -- 2.23 us per step against 1.47 without the staging); another wave's does.  One barrier per step.
+  const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+  if (role != 0) {
+    const int t = (int)threadIdx.x - 256, lane = t & 63, wave = t >> 6;
+    Operand<A_KC, kGsBM, A_SCALAR> oa;
+    Operand<B_KC, BN, false> ob;
+    oa.init(pr.A, pr.lda, mn_a, pr.Ka, m0, t);
+    ob.init(pr.B, pr.ldb, mn_b, pr.Kb, n0, t);
+    constexpr int IA = Operand<A_KC, kGsBM, A_SCALAR>::ITEMS, IB = Operand<B_KC, BN, false>::ITEMS;
+    const float colsum_on = want_colsum ? 1.f : 0.f;
+    f32x2 colsum = f32x2{0.f, 0.f};
+    {
+      // the first two steps are requested together (one memory latency instead of two ahead of the first MFMA)
+      f32x2 first_a[IA], first_b[IB];
+      oa.fetch(first_a, k_begin, lim_a, t);
+      ob.fetch(first_b, k_begin, lim_b, t);
+      oa.fetch(oa.raw, k_begin + 32, lim_a, t);
+      ob.fetch(ob.raw, k_begin + 32, lim_b, t);
+      if constexpr (!A_KC) {
+#pragma unroll
+        for (int q = 0; q < IA; ++q) colsum += first_a[q] * colsum_on;
+      }
+      oa.stage(first_a, smem, t);
+      ob.stage(first_b, smem + kGsRegionA, t);
+    }
+    __syncthreads();
+    // Past the last step the loads are out of range (zeros) and the stage written is never read: no branch in the loop.
+    for (int s = 0; s < steps; ++s) {
+      char* nxt = smem + ((s + 1) & 1) * kGsStage;
+      const int kc2 = k_begin + 32 * (s + 2);
+      const uint32_t soff_a = (uint32_t)kc2 * oa.step_bytes, soff_b = (uint32_t)kc2 * ob.step_bytes;
+      uint32_t keep[3];
+#pragma unroll
+      for (int q = 0; q < IA; ++q) {
+        if constexpr (!A_KC) colsum += oa.raw[q] * colsum_on;
+        oa.stage_item(oa.raw[q], q, nxt, t, keep);
+        oa.fetch_item(oa.raw[q], q, soff_a, lim_a - kc2, t);
+      }
+#pragma unroll
+      for (int q = 0; q < IB; ++q) {
+        ob.stage_item(ob.raw[q], q, nxt + kGsRegionA, t, keep);
+        ob.fetch_item(ob.raw[q], q, soff_b, lim_b - kc2, t);
+      }
+      __syncthreads();
+    }
+    // a thread summed the elements A[k][m0 + 2 (t % 64) + {0, 1}] over the k rows 4 q + wave of every step: add the four waves
+    float* red = reinterpret_cast<float*>(smem);   // (the last step's barrier has passed: the stages are free)
+    if (want_colsum) {
+      red[wave * 128 + 2 * lane] = colsum[0];
+      red[wave * 128 + 2 * lane + 1] = colsum[1];
+    }
+    __syncthreads();
+    if (want_colsum && t < 128) {
+      const float total = (red[t] + red[128 + t]) + (red[256 + t] + red[384 + t]);
+      float* cs = pr.colsum_out != nullptr ? pr.colsum_out : pr.colsum + (size_t)(pr.slab_base + split) * pr.M;
+      if (m0 + t < pr.M) cs[m0 + t] = total;
+    }
+    return;
+  }
 
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1, r16 = lane & 15, gq = lane >> 4;
+  const Operand<A_KC, kGsBM, A_SCALAR> oa{};   // (fragment addressing only)
+  const Operand<B_KC, BN, false> ob{};
   f32x4 acc[4][CB];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < CB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // One basic block per step (no branch: a branch would keep the scheduler from moving anything between the MFMAs).  All
-  // 3 (4 + CB) fragment reads come first, in the order the MFMAs want them (the compiler cannot tell the two LDS stages apart: a
-  // read left further down would pin every LDS write of the staging behind it).  Then 6 CB slices of 4 independent MFMAs (one
-  // partial product of one column block, the four row blocks); slice u also stages item u of the NEXT step -- split (VALU), LDS
-  // write -- and requests the same item of the step after it, its registers being free again: every load has a whole step to
-  // land.  A v_mfma_f32_16x16x32_bf16 holds the vector issue port for half of its 16 cycles, so inside a slice the groups put
-  // three VALU instructions behind each MFMA; the slices are fenced (sched_barrier), which keeps the MFMA order -- consecutive
-  // products into one accumulator stay four MFMAs apart -- and the accumulators where they are.
-  // Past the last step the loads are out of range (zeros) and the stage written is never read.
-  constexpr int IA = Operand<A_KC, kGsBM, A_SCALAR>::ITEMS, IB = Operand<B_KC, BN, false>::ITEMS;
-  static_assert(IA + IB <= 6 * CB, "at most one item per slice");
-  // the first two steps are requested together (one memory latency instead of two ahead of the first MFMA)
-  {
-    f32x2 first_a[IA], first_b[IB];
-    oa.fetch(first_a, k_begin, lim_a, t);
-    ob.fetch(first_b, k_begin, lim_b, t);
-    oa.fetch(oa.raw, k_begin + 32, lim_a, t);
-    ob.fetch(ob.raw, k_begin + 32, lim_b, t);
-    if constexpr (!A_KC) {
-#pragma unroll
-      for (int q = 0; q < IA; ++q) colsum += first_a[q] * colsum_on;
-    }
-    oa.stage(first_a, smem, t);
-    ob.stage(first_b, smem + kGsRegionA, t);
-  }
-  auto add_colsum = [&](int q) {
-    if constexpr (!A_KC) colsum += oa.raw[q] * colsum_on;
-  };
   __syncthreads();
   for (int s = 0; s < steps; ++s) {
     const char* cur = smem + (s & 1) * kGsStage;
-    char* nxt = smem + ((s + 1) & 1) * kGsStage;
-    const int kc2 = k_begin + 32 * (s + 2);
-    const uint32_t soff_a = (uint32_t)kc2 * oa.step_bytes, soff_b = (uint32_t)kc2 * ob.step_bytes;
     u32x4 a[3][4], b[3][CB];
-#ifdef GS_TUNE
-    if ((GS_TUNE & 2) != 0) cur = smem;
-#endif
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
@@ -245,45 +278,17 @@ __device__ __forceinline__ void gs_tile(const VqaGemmProblem& pr, const int m0, 
     for (int j = 1; j < CB; ++j)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) b[pl][j] = ob.frag(cur + kGsRegionA, pl, CB * wn + j, lane);
-    __builtin_amdgcn_sched_barrier(0);
     constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};      // the six partial products of weight >= 2^-16
-    uint32_t keep_a[3], keep_b[3];
+    // (j, product, i): consecutive products into one accumulator stay four MFMAs apart
 #pragma unroll
     for (int j = 0; j < CB; ++j)
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        // slice 6 j + k; the IA + IB items are spread evenly over the 6 CB slices: item n goes with the first slice u that has
-        // n * slices <= u * items
-        constexpr int SLICES = 6 * CB, ITEMS = IA + IB;
-        const int u = 6 * j + k;
-        const int n = (u * ITEMS + SLICES - 1) / SLICES;              // first item not before this slice
-        const bool has = n < ITEMS && n * SLICES / ITEMS == u;   // (item n rides on slice floor(n SLICES / ITEMS); compile-time)
+      for (int k = 0; k < 6; ++k)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i][j] = sp::mfma_bf16(b[PB[k]][j], a[PA[k]][i], acc[i][j]);   // D^T: a lane holds 4 columns of a row
-#ifdef GS_TUNE
-        if ((GS_TUNE & 1) != 0) {
-        } else
-#endif
-        if (has && n < IA) {
-          add_colsum(n);
-          oa.stage_item(oa.raw[n], n, nxt, t, keep_a);
-          oa.fetch_item(oa.raw[n], n, soff_a, lim_a - kc2, t);
-        } else if (has) {
-          ob.stage_item(ob.raw[n - IA], n - IA, nxt + kGsRegionA, t, keep_b);
-          ob.fetch_item(ob.raw[n - IA], n - IA, soff_b, lim_b - kc2, t);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // VALU
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#ifdef GS_TUNE
-    if ((GS_TUNE & 4) == 0)
-#endif
     __syncthreads();
   }
+  __syncthreads();   // (the staging waves' column-sum exchange)
 
   // ---- outputs: lane (r16, gq) holds C[m0 + 64 wm + 16 i + r16][n0 + 16 (CB wn + j) + 4 gq + 0..3]
   uint32_t top = 0;
@@ -388,18 +393,6 @@ __device__ __forceinline__ void gs_tile(const VqaGemmProblem& pr, const int m0, 
       }
     }
   }
-  if (want_colsum) {
-    // a thread summed the elements A[k][m0 + 2 (t % 64) + {0, 1}] over the k rows 4 q + wave of every step: add the four waves
-    float* red = reinterpret_cast<float*>(smem);   // (the last step's barrier has passed: the stages are free)
-    red[wave * 128 + 2 * lane] = colsum[0];
-    red[wave * 128 + 2 * lane + 1] = colsum[1];
-    __syncthreads();
-    if (t < 128) {
-      const float total = (red[t] + red[128 + t]) + (red[256 + t] + red[384 + t]);
-      float* cs = pr.colsum_out != nullptr ? pr.colsum_out : pr.colsum + (size_t)(pr.slab_base + split) * pr.M;
-      if (m0 + t < pr.M) cs[m0 + t] = total;
-    }
-  }
 }
 
 __host__ __device__ inline int gs_tile_cols(int N) {   // the tile width that pads N less (ties: the wider tile, fewer items)
@@ -409,17 +402,11 @@ __host__ __device__ inline int gs_tile_cols(int N) {   // the tile width that pa
 
 template <int CB>
 __device__ __forceinline__ void gs_forms(const VqaGemmProblem& pr, int m0, int n0, int split, char* smem) {
-#ifdef GS_PROBE_ONE   // (compile-time probe: one instantiation, for looking at its schedule: -DGS_PROBE_ONE=0..4)
-  if (GS_PROBE_ONE == 0) gs_tile<CB, true, true, false>(pr, m0, n0, split, smem);
-  if (GS_PROBE_ONE == 1) gs_tile<CB, true, false, false>(pr, m0, n0, split, smem);
-  if (GS_PROBE_ONE == 2) gs_tile<CB, false, false, false>(pr, m0, n0, split, smem);
-#else
   if (pr.form == 0) gs_tile<CB, true, true, false>(pr, m0, n0, split, smem);          // NT
   else if (pr.form == 1) gs_tile<CB, true, false, false>(pr, m0, n0, split, smem);    // NN
   else if (pr.form == 2) gs_tile<CB, false, false, false>(pr, m0, n0, split, smem);   // TN
   else if (pr.form == 3) gs_tile<CB, true, false, true>(pr, m0, n0, split, smem);     // NN, A 4-byte aligned / odd extents
   else gs_tile<CB, false, false, true>(pr, m0, n0, split, smem);                      // TN, A 4-byte aligned / odd extents
-#endif
 }
 
 __global__ __launch_bounds__(kGsThreads, 1) void grouped_gemm_split_kernel(GsProbs g_arg, int items) {
@@ -435,12 +422,8 @@ __global__ __launch_bounds__(kGsThreads, 1) void grouped_gemm_split_kernel(GsPro
   const int tiles_n = (pr.N + bn - 1) / bn, tiles_m = (pr.M + kGsBM - 1) / kGsBM;
   const int split = local / (tiles_m * tiles_n), tl = local % (tiles_m * tiles_n);
   const int m0 = (tl / tiles_n) * kGsBM, n0 = (tl % tiles_n) * bn;
-#ifdef GS_PROBE_ONE
-  gs_forms<5>(pr, m0, n0, split, gs_smem);
-#else
   if (bn == 160) gs_forms<5>(pr, m0, n0, split, gs_smem);
   else gs_forms<4>(pr, m0, n0, split, gs_smem);
-#endif
 }
 
 }  // namespace

@@ -100,10 +100,12 @@ class Phase:
     TILE_M = 128 if os.environ.get("VQA_GROUPED_BM") == "128" else 64
     DIRECT = os.environ.get("VQA_GROUPED_DIRECT", "1") == "1"
     STEP_K = 16        # the kernel's K step: a contraction part is a whole number of steps
-    # Which matrix engine runs the phase's GEMM launch: "mfma" = csrc/grouped_gemm.hip on the fp32 MFMA (the default while the
-    # split form measures within 4 % of it); "split" = csrc/grouped_gemm_split.hip (128 x 128|160 tiles, 32-deep steps);
-    # "auto" = the engine of the step's other fp32 products (ops.f32_products()).
-    ENGINE = os.environ.get("VQA_GROUPED_ENGINE", "mfma")
+    # Which matrix engine runs a phase's GEMM launch.  "mfma" = csrc/grouped_gemm.hip on the fp32 MFMA; "split" =
+    # csrc/grouped_gemm_split.hip (128 x 128|160 tiles, 32-deep steps); "mixed" = per phase, whichever measured faster at
+    # B = 512 (tools/gg_bench.py: SPLIT_PHASES run on the split engine); "auto" (default) = mixed when the step's other fp32
+    # products run on the split engine (ops.f32_products()), else mfma.
+    ENGINE = os.environ.get("VQA_GROUPED_ENGINE", "auto")
+    SPLIT_PHASES = ("q_proj_fwd", "gates_h2_bwd", "vector_fusion_bwd", "classifier_bwd")
     SPLIT_UNITS = int(os.environ.get("VQA_GROUPED_SPLIT_UNITS", "256"))   # workgroups the chip runs at once (one per CU)
     SPLIT_OVERHEAD = float(os.environ.get("VQA_GROUPED_SPLIT_OVERHEAD", "3"))   # an item's fixed cost, in contraction steps
     _split_plans = {}
@@ -127,10 +129,16 @@ class Phase:
         (self.pre_jobs if pre else self.jobs).append(dict(kind=kind, source=source, out=out, ldo=int(ldo), out_off=out_off, **kw))
 
     @classmethod
-    def engine(cls):
-        if cls.ENGINE not in ("auto", "split", "mfma"):
-            raise ValueError("VQA_GROUPED_ENGINE must be auto, split or mfma (got %r)" % cls.ENGINE)
-        return ops.f32_products() if cls.ENGINE == "auto" else cls.ENGINE
+    def engine(cls, name=None):
+        """The engine of the phase called `name` (None: of a phase outside SPLIT_PHASES)."""
+        mode = cls.ENGINE
+        if mode not in ("auto", "mixed", "split", "mfma"):
+            raise ValueError("VQA_GROUPED_ENGINE must be auto, mixed, split or mfma (got %r)" % mode)
+        if mode == "auto":
+            mode = "mixed" if ops.f32_products() == "split" else "mfma"
+        if mode == "mixed":
+            return "split" if name in cls.SPLIT_PHASES else "mfma"
+        return mode
 
     @classmethod
     def _plan_split(cls, shapes):
@@ -180,7 +188,7 @@ class Phase:
         return probs
 
     def _size(self):
-        if self.engine() == "split":
+        if self.engine(self.name) == "split":
             return self._size_split()
         probs = [(t, p) for t in self.targets for p in t.problems]
         tiles = lambda t: math.ceil(t.M / self.TILE_M) * math.ceil(t.N / 64)  # noqa: E731
@@ -259,7 +267,7 @@ class Phase:
                             gp.seed, gp.seed_ptr = sv, (sp.value if sp is not None else None)
                             gp.drop_base, gp.drop_ld = int(j.get("drop_base", 0)), int(j.get("drop_ld", 0))
                     arr[i] = gp
-                if self.engine() == "split":
+                if self.engine(self.name) == "split":
                     ops._launch("grouped_gemm_split", (self.name, len(probs), flops if lo == 0 else 0), L_.vqa_grouped_gemm_split,
                                 arr, len(chunk))
                 else:
