@@ -271,13 +271,14 @@ def test_grouped_phases_follow_the_products_engine_and_size_their_parts(monkeypa
     assert [head.Phase.split_tile_cols(n) for n in (310, 2048, 2400, 510)] == [160, 128, 160, 128]
     monkeypatch.setattr(head.Phase, "ENGINE", "auto")
     monkeypatch.delenv("VQA_F32_PRODUCTS", raising=False)
-    assert head.Phase.engine("q_proj_fwd") == "split" and head.Phase.engine("q_proj_bwd") == "mfma" and head.Phase.engine() == "mfma"
+    assert head.Phase.engine("q_proj_fwd", 512) == "split" and head.Phase.engine("q_proj_bwd", 512) == "mfma"
+    assert head.Phase.engine("q_proj_fwd", 128) == "mfma" and head.Phase.engine() == "mfma"      # small batches stay on the fp32 MFMA
     monkeypatch.setenv("VQA_F32_PRODUCTS", "mfma")
-    assert head.Phase.engine("q_proj_fwd") == "mfma"
+    assert head.Phase.engine("q_proj_fwd", 512) == "mfma"
     monkeypatch.setattr(head.Phase, "ENGINE", "split")
-    assert head.Phase.engine("q_proj_bwd") == "split" and head.Phase.engine() == "split"
+    assert head.Phase.engine("q_proj_bwd", 5) == "split" and head.Phase.engine() == "split"
     monkeypatch.setattr(head.Phase, "ENGINE", "mixed")
-    assert [head.Phase.engine(n) for n in ("classifier_bwd", "classifier_fwd")] == ["split", "mfma"]
+    assert [head.Phase.engine(n, 512) for n in ("classifier_bwd", "classifier_fwd")] == ["split", "mfma"]
     monkeypatch.setattr(head.Phase, "ENGINE", "fp64")
     with pytest.raises(ValueError):
         head.Phase.engine()

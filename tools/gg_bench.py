@@ -97,7 +97,7 @@ def main():
             if not info:
                 sized = ph._size()
                 info["parts"] = sorted({(p["ksplit"], p["splits"]) for _, p in sized})
-                if head.Phase.engine(name) == "split":
+                if ph._engine() == "split":
                     info["items"] = sum(-(-t.M // 128) * -(-t.N // head.Phase.split_tile_cols(t.N)) * p["splits"] for t, p in sized)
                 else:
                     info["items"] = sum(-(-t.M // head.Phase.TILE_M) * -(-t.N // 64) * p["splits"] for t, p in sized)

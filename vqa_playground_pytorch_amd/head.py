@@ -106,6 +106,8 @@ class Phase:
     # products run on the split engine (ops.f32_products()), else mfma.
     ENGINE = os.environ.get("VQA_GROUPED_ENGINE", "auto")
     SPLIT_PHASES = ("q_proj_fwd", "gates_h2_bwd", "vector_fusion_bwd", "classifier_bwd")
+    SPLIT_MIN_ROWS = 384     # mixed: only at the training batch -- at 128 rows (one rank's share of BASELINE configs[4]) a phase is
+                             # a chip's worth of 2-3-step items and the split kernel's fixed cost per item loses: 0.997 vs 0.955 ms
     SPLIT_UNITS = int(os.environ.get("VQA_GROUPED_SPLIT_UNITS", "256"))   # workgroups the chip runs at once (one per CU)
     SPLIT_OVERHEAD = float(os.environ.get("VQA_GROUPED_SPLIT_OVERHEAD", "3"))   # an item's fixed cost, in contraction steps
     _split_plans = {}
@@ -129,16 +131,20 @@ class Phase:
         (self.pre_jobs if pre else self.jobs).append(dict(kind=kind, source=source, out=out, ldo=int(ldo), out_off=out_off, **kw))
 
     @classmethod
-    def engine(cls, name=None):
-        """The engine of the phase called `name` (None: of a phase outside SPLIT_PHASES)."""
+    def engine(cls, name=None, rows=None):
+        """The engine of the phase called `name` whose products have `rows` batch rows (None: a phase outside the table)."""
         mode = cls.ENGINE
         if mode not in ("auto", "mixed", "split", "mfma"):
             raise ValueError("VQA_GROUPED_ENGINE must be auto, mixed, split or mfma (got %r)" % mode)
         if mode == "auto":
             mode = "mixed" if ops.f32_products() == "split" else "mfma"
         if mode == "mixed":
-            return "split" if name in cls.SPLIT_PHASES else "mfma"
+            return "split" if (name in cls.SPLIT_PHASES and rows is not None and rows >= cls.SPLIT_MIN_ROWS) else "mfma"
         return mode
+
+    def _engine(self):
+        rows = [p["K"] if p["form"] in (TN, TN_A4) else t.M for t in self.targets for p in t.problems]
+        return self.engine(self.name, min(rows) if rows else None)
 
     @classmethod
     def _plan_split(cls, shapes):
@@ -188,7 +194,7 @@ class Phase:
         return probs
 
     def _size(self):
-        if self.engine(self.name) == "split":
+        if self._engine() == "split":
             return self._size_split()
         probs = [(t, p) for t in self.targets for p in t.problems]
         tiles = lambda t: math.ceil(t.M / self.TILE_M) * math.ceil(t.N / 64)  # noqa: E731
@@ -215,6 +221,7 @@ class Phase:
             self._epilogue(L_, self.pre_jobs, "pre")
         jobs = list(self.jobs)
         if self.targets:
+            engine = self._engine()
             probs = self._size()
             flops = 0
             for t in self.targets:
@@ -267,7 +274,7 @@ class Phase:
                             gp.seed, gp.seed_ptr = sv, (sp.value if sp is not None else None)
                             gp.drop_base, gp.drop_ld = int(j.get("drop_base", 0)), int(j.get("drop_ld", 0))
                     arr[i] = gp
-                if self.engine(self.name) == "split":
+                if engine == "split":
                     ops._launch("grouped_gemm_split", (self.name, len(probs), flops if lo == 0 else 0), L_.vqa_grouped_gemm_split,
                                 arr, len(chunk))
                 else:
