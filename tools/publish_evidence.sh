@@ -13,7 +13,7 @@ for f in bench_default bench_b512 bench_b512_mfma; do
 done
 for f in bench_b512_legacy_head bench_b512_grouped_head bench_oda_b512 bench_oda_b512_grouped_head bench_oda_attention_b512 \
          bench_bf16_n100_b128 bench_f32_n100_b128 bench_b512_pairwise bench_b512_encoder bench_b512_k4_engine bench_b512_eager bench_oda_b512_mfma \
-         bench_b512_copy_inputs bench_bf16_n100_b128_k4fold; do
+         bench_b512_copy_inputs bench_bf16_n100_b128_k4fold bench_b512_grouped_mfma bench_b512_grouped_split; do
   cp "$SRC/$f.json" "$DST/${TAG}_$f.json"
 done
 for f in bench_b512_graph_kernel_stats.csv bench_b512_eager_kernel_stats.csv bench_oda_b512_kernel_stats.csv \

@@ -103,6 +103,8 @@ VQA_HEAD=grouped run bench_b512_grouped_head --steps 20 --warmup 5 --no-cpu-base
 VQA_HEAD=grouped run bench_oda_b512_grouped_head --model oda --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records
 run bench_b512_eager --steps 20 --warmup 5 --no-graph --no-cpu-baseline --no-rotate --no-sub-records
 run bench_b512_copy_inputs --steps 20 --warmup 5 --copy-inputs --no-cpu-baseline --no-sub-records
+VQA_GROUPED_ENGINE=mfma run bench_b512_grouped_mfma --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records
+VQA_GROUPED_ENGINE=split run bench_b512_grouped_split --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records
 VQA_K4_BF16_FORM=fold run bench_bf16_n100_b128_k4fold --no-sub-records --dtype bf16 --regions 100 --batch 128 --steps 20 --warmup 5 --no-cpu-baseline
 run bench_b512_pairwise --no-sub-records --steps 20 --warmup 5 --relation-mode 0 --no-cpu-baseline
 run bench_f32_n100_b128 --no-sub-records --regions 100 --batch 128 --steps 20 --warmup 5 --no-cpu-baseline
