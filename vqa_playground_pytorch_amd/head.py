@@ -105,7 +105,8 @@ class Phase:
     # B = 512 (tools/gg_bench.py: SPLIT_PHASES run on the split engine); "auto" (default) = mixed when the step's other fp32
     # products run on the split engine (ops.f32_products()), else mfma.
     ENGINE = os.environ.get("VQA_GROUPED_ENGINE", "auto")
-    SPLIT_PHASES = ("q_proj_fwd", "gates_h2_bwd", "vector_fusion_bwd", "classifier_bwd")
+    SPLIT_PHASES = tuple(x for x in os.environ.get(
+        "VQA_GROUPED_SPLIT_PHASES", "q_proj_fwd,gates_h2_bwd,vector_fusion_bwd,classifier_bwd").split(",") if x)   # (a measurement knob)
     SPLIT_MIN_ROWS = 384     # mixed: only at the training batch -- at 128 rows (one rank's share of BASELINE configs[4]) a phase is
                              # a chip's worth of 2-3-step items and the split kernel's fixed cost per item loses: 0.997 vs 0.955 ms
     SPLIT_UNITS = int(os.environ.get("VQA_GROUPED_SPLIT_UNITS", "256"))   # workgroups the chip runs at once (one per CU)
