@@ -155,7 +155,7 @@ RTOL_EDGE_MAX = 1e-1   # ... and its max-abs error on the tensor's own scale: a 
 #                        for a single sample, 3.9e-2 over ODA's 149 knife-edge samples of this batch)
 VARIANTS = [("cor2", 2000, "default"), ("cor2", 2000, "pairwise"), ("cor2", 2000, "k4_engine"), ("cor2", 2000, "legacy_head"),
             ("cor2", 2000, "grouped_head"), ("oda", 3000, "default"), ("oda", 3000, "grouped_head"),
-            ("cor2", 2000, "fp32_mfma"), ("oda", 3000, "fp32_mfma")]
+            ("cor2", 2000, "fp32_mfma"), ("oda", 3000, "fp32_mfma"), ("cor2", 2000, "grouped_split")]
 _oracle_cache = {}
 
 
@@ -163,8 +163,9 @@ def build_variant(cls, nans, variant, monkeypatch):
     """default = what bench.py times; pairwise = relation_mode 0 (the relation tensor built from every (i,j) term);
     k4_engine = the Mutan fusion in its R-GEMM form on the LDS tile engine (VQA_K4_FORM=engine); legacy_head / grouped_head =
     the [B,.]-sized layers all on library GEMMs + epilogue kernels / all as grouped phases (VQA_HEAD=legacy / grouped; the
-    default, auto, groups CoR2's phases except the glimpse projections and keeps ODA on the library).  Every variant but the last
-    runs the region projections on the split engine (the default since round 5: fp32 products from three-way bf16 splits on the
+    default, auto, groups CoR2's phases except the glimpse projections and keeps ODA on the library); grouped_split = EVERY grouped
+    phase's GEMM launch on the split kernel (csrc/grouped_gemm_split.hip; the default runs four of the eight there).  Every
+    variant but fp32_mfma runs the region projections on the split engine (the default since round 5: fp32 products from three-way bf16 splits on the
     bf16 matrix pipe, csrc/gemm_f32_split.hpp); fp32_mfma = the same on the fp32 MFMA engine (VQA_F32_PRODUCTS=mfma) -- both
     engines are held to the SAME bars."""
     from vqa_playground_pytorch_amd import head, ops
@@ -173,6 +174,8 @@ def build_variant(cls, nans, variant, monkeypatch):
         monkeypatch.setattr(ops, "_K4_FORM", "engine")
     if variant in ("legacy_head", "grouped_head"):
         monkeypatch.setattr(head, "MODE", variant.split("_")[0])
+    if variant == "grouped_split":
+        monkeypatch.setattr(head.Phase, "ENGINE", "split")
     return build(cls, nans, **({"relation_mode": 0} if variant == "pairwise" else {}))
 
 
