@@ -119,3 +119,86 @@ def test_pmc_rows_are_matched_by_kernel_and_grid():
     # K3's backward is the fused kernel at B = 512 (the stream kernel's row is simply absent)
     fused = bench.pmc_row(table, "softmax_attention_pool_drop_bwd", ((131072, "(attention_pool_bwd_fused_kernel<T, 256, 4, 2>)"),))
     assert fused["key"].startswith("vqa::attention_pool_bwd_fused_kernel")
+
+
+def test_counter_rows_are_tied_to_the_kernel_sources(tmp_path):
+    """a committed counter row is evidence only for the code it was measured on.  tools/pmc_table.py stamps
+    every row with the fingerprint of the files that define its kernel; edit one byte of that kernel's source (in a temp copy of
+    csrc/) and the row reads stale, while rows of kernels defined elsewhere stay valid; bench.py then reports `traffic_stale`
+    and prints neither `traffic` nor `mfma_busy_pct`."""
+    import shutil
+
+    from vqa_playground_pytorch_amd import _srchash
+
+    csrc = tmp_path / "csrc"
+    shutil.copytree(_srchash.CSRC, csrc, ignore=shutil.ignore_patterns("build"))
+    csrc, inc = str(csrc), _srchash.INCLUDE
+    keys = ["vqa::relation_apply_fwd_kernel<float, 256>|grid=524288", "vqa::adam_kernel|grid=2985216",
+            "vqa::sp::gemm_nt_kernel<9, 5, 1, 2, 2, true, vqa::SplitEpiBiasAct, 0, 3, false>|grid=65536"]
+    table = _srchash.stamp_table({k: {"FETCH_SIZE_KiB": 1.0, "WRITE_SIZE_KiB": 2.0, "launches": 8} for k in keys}, csrc, inc)
+    assert table["__source__"]["source_hash"] == _srchash.source_hash(csrc, inc) == _srchash.source_hash()
+    assert all(len(table[k]["source"]) == 16 for k in keys)
+    assert "pairwise_relation.hip" in _srchash.kernel_sources(keys[0], csrc, inc)
+    assert "gemm_f32_split.hpp" in _srchash.kernel_sources(keys[2], csrc, inc)
+    assert not any(_srchash.row_is_stale(k, table[k], csrc, inc) for k in keys)
+    # one byte of the kernel's source file
+    path = os.path.join(csrc, "pairwise_relation.hip")
+    data = bytearray(open(path, "rb").read())
+    at = data.index(b"relation_apply_fwd_kernel")
+    data[at - 1:at - 1] = b" "
+    open(path, "wb").write(bytes(data))
+    _srchash._defs.clear()
+    assert _srchash.row_is_stale(keys[0], table[keys[0]], csrc, inc)
+    assert not _srchash.row_is_stale(keys[1], table[keys[1]], csrc, inc)          # optimizer.hip did not change
+    assert _srchash.source_hash(csrc, inc) != table["__source__"]["source_hash"]
+    # a header reaches every kernel
+    with open(os.path.join(csrc, "common.hpp"), "a") as fh:
+        fh.write("\n")
+    assert all(_srchash.row_is_stale(k, table[k], csrc, inc) for k in keys)
+    _srchash._defs.clear()
+    # rows without a stamp (tables older than round 6) and rows of kernels that no longer exist are stale too
+    assert _srchash.row_is_stale(keys[1], {"FETCH_SIZE_KiB": 1.0})
+    assert _srchash.row_is_stale("vqa::no_such_kernel|grid=64", {"source": "0" * 16})
+
+    # bench.py: a stale row is reported, not printed
+    fresh = _srchash.stamp_table({keys[0]: {"FETCH_SIZE_KiB": 10.0, "WRITE_SIZE_KiB": 20.0, "launches": 8}})
+    grids = ((524288, "(relation_apply_fwd_kernel<T, 256>)"),)
+    try:
+        bench._tables[("traffic", "")] = fresh
+        bench._tables[("mfma", "")] = {}
+        bench._tables[("trace", "")] = _srchash.stamp_table({keys[0]: {"launches": 64, "median_us": 48.6, "mean_us": 48.8}})
+        ok = bench.roofline_entry("relation_apply_fwd", (512, 36, 2048, True), 10, 0.05, 512, grids=grids)
+        assert ok["traffic"] == int((10.0 * 2 + 20.0) * 1024) and "traffic_stale" not in ok and ok["trace_ms"] == 0.0486
+        bench._tables[("traffic", "")] = {keys[0]: dict(fresh[keys[0]], source="0" * 16)}
+        bench._tables[("trace", "")] = {keys[0]: {"launches": 64, "median_us": 48.6, "source": "0" * 16}}
+        old = bench.roofline_entry("relation_apply_fwd", (512, 36, 2048, True), 10, 0.05, 512, grids=grids)
+        assert old["traffic"] is None and old["traffic_stale"] is True and "trace_ms" not in old
+        assert bench.compact_line({"roofline": old, "config": {}})["roofline"]["traffic_stale"] is True
+    finally:
+        bench._tables.clear()
+
+
+def test_committed_counter_tables_describe_this_tree():
+    """The tables bench.py reads (profiles/<EVIDENCE_TAG>_pmc_*.json, _trace*.json) were collected on the kernels of THIS tree:
+    no row is stale.  After a kernel edit and before the next tools/refresh_evidence.sh run the rows of the edited kernels ARE
+    stale -- bench.py then says `traffic_stale` instead of printing them, and this test SKIPS with their number (a reminder,
+    not a failure: the tree is allowed to be ahead of its evidence, it is not allowed to print old counters as new)."""
+    import glob
+
+    import pytest
+
+    from vqa_playground_pytorch_amd import _srchash
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", bench.EVIDENCE_TAG + "_pmc_*.json"))
+                   + glob.glob(os.path.join(ROOT, "profiles", bench.EVIDENCE_TAG + "_trace*.json")))
+    if not paths:
+        pytest.skip("no counter tables committed for %s yet" % bench.EVIDENCE_TAG)
+    report = []
+    for path in paths:
+        table = json.load(open(path))
+        assert "__source__" in table, path + " carries no source stamp"
+        stale = [k for k, row in table.items() if not k.startswith("__") and _srchash.row_is_stale(k, row)]
+        if stale:
+            report.append("%s: %d of %d rows stale" % (os.path.basename(path), len(stale), len(table) - 1))
+    if report:
+        pytest.skip("counter tables older than the kernels they name (bench.py reports traffic_stale): " + "; ".join(report))

@@ -25,6 +25,13 @@ def test_library_loads_and_exports_header_symbols():
         assert hasattr(handle, name), name
 
 
+def test_library_was_built_from_this_tree():
+    """vqa_source_hash() (written into the binary by csrc/Makefile) equals the hash of csrc/ + include/ as they are: the .so
+    that travels to the GPU box is not older than the sources beside it (VERDICT r05 weak #11)."""
+    built, tree = _lib.built_from_this_tree()
+    assert len(tree) == 64 and built == tree, "libvqa_mi355x.so is stale: rebuild with `python __graft_entry__.py build`"
+
+
 def test_workspace_queries_need_no_gpu():
     handle = _lib.lib()
     n = handle.vqa_lowrank_bilinear_fusion_bwd_workspace_bytes(512, 36, 310, 510, 2)

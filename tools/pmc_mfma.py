@@ -21,8 +21,12 @@ SQ_INSTS_VALU / (4 SIMDs * SQ_BUSY_CU_CYCLES).  Keys are "<kernel name>|grid=<wo
 import csv
 import glob
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vqa_playground_pytorch_amd import _srchash  # noqa: E402  (no GPU, no library needed)
 
 
 def main():
@@ -58,9 +62,12 @@ def main():
         if (entry.get("SQ_INSTS_MFMA", 0) > 0 or "mfma" in key or "gemm" in key or "bilinear" in key or "linear" in key
                 or "oda_" in key):
             table[key] = entry
+    _srchash.stamp_table(table)     # per-row source fingerprints: bench.py drops a row measured on other sources
     json.dump(table, open(dest, "w"), indent=1, sort_keys=True)
-    print("wrote %s: %d kernels" % (dest, len(table)))
+    print("wrote %s: %d kernels" % (dest, len(table) - 1))
     for k, v in table.items():
+        if k.startswith("__"):
+            continue
         if v.get("mfma_busy_pct") or v.get("valu_issue_pct_min"):
             print("  %-110s launches %4d  mfma busy %5.1f %%  valu issue >= %5.1f %%"
                   % (k[:110], v["launches"], v.get("mfma_busy_pct") or 0.0, v.get("valu_issue_pct_min") or 0.0))

@@ -8,12 +8,17 @@
 (separate passes, kernel by kernel -- counters are not collected inside graph replays.)  Keys are
 "<kernel name without 'void ' and the parameter list>|grid=<total work-items>", values the mean FETCH_SIZE / WRITE_SIZE
 per launch in KiB as the counters report them (FETCH_SIZE under-counts 16-byte-per-lane streaming reads by 2x on gfx950,
-MI355X_MICROARCH.md; bench.py applies that correction per kernel)."""
+MI355X_MICROARCH.md; bench.py applies that correction per kernel).  Each row also carries `source`: the fingerprint of the
+files that define its kernel (vqa_playground_pytorch_amd/_srchash.py), and the table `__source__.source_hash`."""
 import csv
 import glob
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vqa_playground_pytorch_amd import _srchash  # noqa: E402  (no GPU, no library needed)
 
 
 def load(directory, counter):
@@ -40,8 +45,10 @@ def main():
     for key in sorted(set(fetch) | set(write)):
         n = fetch.get(key, write.get(key))[0]
         table[key] = {"launches": n, "FETCH_SIZE_KiB": fetch.get(key, (0, 0.0))[1], "WRITE_SIZE_KiB": write.get(key, (0, 0.0))[1]}
+    # every row says which sources its kernel was compiled from (bench.py drops a row whose stamp differs from the tree's)
+    _srchash.stamp_table(table)
     json.dump(table, open(dest, "w"), indent=1, sort_keys=True)
-    print("wrote %s: %d kernels" % (dest, len(table)))
+    print("wrote %s: %d kernels" % (dest, len(table) - 1))
 
 
 if __name__ == "__main__":

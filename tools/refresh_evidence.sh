@@ -124,8 +124,10 @@ for mode in graph eager; do
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$mode -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records --detail-file /tmp/kt_detail.json $extra > "$OUT/kt_$mode.log" 2>&1
   f=$(find /tmp/kt_$mode -name "*kernel_stats.csv" | sort | sed -n 1p)
   [ -n "$f" ] && cp "$f" "$OUT/bench_b512_${mode}_kernel_stats.csv"
-  python3 "$ROOT/tools/by_grid.py" /tmp/kt_$mode 1 "hand-written kernels, per-dispatch durations by (kernel, grid work-items); rocprofv3 --kernel-trace of bench.py --steps 20 --warmup 5 --no-cpu-baseline $extra (the last column is the total over the run)" > "$OUT/vqa_kernels_by_grid_$mode.txt" 2>&1
+  python3 "$ROOT/tools/by_grid.py" /tmp/kt_$mode 1 "hand-written kernels, per-dispatch durations by (kernel, grid work-items); rocprofv3 --kernel-trace of bench.py --steps 20 --warmup 5 --no-cpu-baseline $extra (the last column is the total over the run)" "$OUT/trace_$mode.json" > "$OUT/vqa_kernels_by_grid_$mode.txt" 2>&1
 done
+# (the replayed step's per-kernel medians, stamped with their sources: bench.py's `trace_ms`)
+[ -f "$OUT/trace_graph.json" ] && cp "$OUT/trace_graph.json" "$ROOT/profiles/${TAG%%_*}_trace.json"
 # 4. the other two configurations, kernel by kernel is not needed: the replayed run's stats and per-dispatch durations
 for cfg in "oda_b512|--model oda" "bf16_n100_b128|--dtype bf16 --regions 100 --batch 128"; do
   name=${cfg%%|*}; args=${cfg#*|}
@@ -133,7 +135,8 @@ for cfg in "oda_b512|--model oda" "bf16_n100_b128|--dtype bf16 --regions 100 --b
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$name -- python3 "$ROOT/bench.py" $args --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records --detail-file /tmp/kt_detail.json > "$OUT/kt_$name.log" 2>&1
   f=$(find /tmp/kt_$name -name "*kernel_stats.csv" | sort | sed -n 1p)
   [ -n "$f" ] && cp "$f" "$OUT/bench_${name}_kernel_stats.csv"
-  python3 "$ROOT/tools/by_grid.py" /tmp/kt_$name 1 "hand-written kernels, per-dispatch durations by (kernel, grid work-items); rocprofv3 --kernel-trace of bench.py $args --steps 20 --warmup 5 --no-cpu-baseline (the last column is the total over the run)" > "$OUT/vqa_kernels_by_grid_$name.txt" 2>&1
+  python3 "$ROOT/tools/by_grid.py" /tmp/kt_$name 1 "hand-written kernels, per-dispatch durations by (kernel, grid work-items); rocprofv3 --kernel-trace of bench.py $args --steps 20 --warmup 5 --no-cpu-baseline (the last column is the total over the run)" "$OUT/trace_$name.json" > "$OUT/vqa_kernels_by_grid_$name.txt" 2>&1
+  [ -f "$OUT/trace_$name.json" ] && cp "$OUT/trace_$name.json" "$ROOT/profiles/${TAG%%_*}_trace_$name.json"
 done
 fi
 if want conv; then

@@ -9,7 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VQA_LIB_PATH", os.path.join(_HERE, "libvqa_mi355x.so"))  # env override: profiling builds
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _c_f = ctypes.c_void_p          # device pointer to fp32
 _c_pp = ctypes.c_void_p         # host array of device pointers
@@ -24,6 +24,7 @@ _c_st = ctypes.c_void_p         # hipStream_t
 SIGNATURES = {
     "vqa_version": (_c_i, []),
     "vqa_last_error": (ctypes.c_char_p, []),
+    "vqa_source_hash": (ctypes.c_char_p, []),
     "vqa_set_option": (_c_i, [ctypes.c_char_p, ctypes.c_char_p]),
     "vqa_launch_log_reset": (None, []),
     "vqa_launch_log": (_c_i, [ctypes.POINTER(ctypes.c_ulonglong), _c_i]),
@@ -190,3 +191,11 @@ def check(rc, what):
     if rc != 0:
         msg = lib().vqa_last_error()
         raise VqaLibraryError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def built_from_this_tree():
+    """(library's vqa_source_hash(), hash of the source tree beside it): equal when the loaded binary was built from the sources
+    in vqa_playground_pytorch_amd/csrc + include/ as they are now.  __graft_entry__.smoke() and tests/test_host_cpu.py assert
+    it, so a stale .so that travelled to the GPU box is seen there."""
+    from . import _srchash
+    return (lib().vqa_source_hash() or b"").decode(), _srchash.source_hash()

@@ -89,6 +89,11 @@ int zero_async(void* ptr, size_t bytes, hipStream_t s) {
 }  // namespace vqa
 
 extern "C" int vqa_version(void) { return VQA_ABI_VERSION; }
+extern "C" const char* vqa_source_hash(void) {
+  return
+#include "build/source_hash.inc"
+      ;
+}
 extern "C" int vqa_set_option(const char* name, const char* value) {
   VQA_REQUIRE(name != nullptr && name[0] != 0, VQA_E_BADARG, "set_option: empty name");
   vqa::OptionTable& t = vqa::options();
