@@ -68,3 +68,75 @@ def test_prefetcher_gpu_short_final_batch(last):
             assert g[k].shape == b[k].shape and torch.equal(g[k].cpu(), b[k]), k
         n += 1
     assert n == 5
+
+
+def _store(tmp_path, n_img=11, N=4, D=8, seed=3):
+    rs = np.random.RandomState(seed)
+    feats = rs.standard_normal((n_img, N, D)).astype(np.float32)
+    np.save(tmp_path / "size,rcnn_arch,224.npy", feats)
+    names = ["COCO_train2014_%012d.jpg" % (7 * i + 1) for i in range(n_img)]
+    (tmp_path / "size,rcnn_arch,224.txt").write_text("".join(n + "\n" for n in names), encoding="utf-8")
+    return feats, names
+
+
+def test_feature_store_reads_the_on_disk_layout(tmp_path):
+    """SURVEY 8f row 4 / VERDICT r05 missing #4: the store is the reference's 'att' array [n_img,N,D] fp32 + the one-name-per-row
+    text file (datasets.py:367,405-412,570-571; utils.py:452-454), memory-mapped; a sample's regions are
+    feature[name_to_idx[img_filename]] (datasets.py:912-913)."""
+    feats, names = _store(tmp_path)
+    for workers in (1, 3):
+        st = feed.FeatureStore(tmp_path / "size,rcnn_arch,224.npy", tmp_path / "size,rcnn_arch,224.txt", workers=workers)
+        assert len(st) == 11 and st.sample_shape == (4, 8) and st.index(names[5]) == 5
+        out = torch.empty(9, 4, 8)
+        got = st.gather([10, 0, 5, 5, 3, 9, 1], out)
+        assert got.shape == (7, 4, 8) and np.array_equal(got.numpy(), feats[[10, 0, 5, 5, 3, 9, 1]])
+        half = st.gather([2, 8], torch.empty(2, 4, 8, dtype=torch.bfloat16))
+        assert torch.equal(half, torch.from_numpy(feats[[2, 8]]).to(torch.bfloat16))
+        with pytest.raises(KeyError):
+            st.index("no_such_image.jpg")
+        with pytest.raises(IndexError):
+            st.gather([11], out)
+        with pytest.raises(ValueError):
+            st.gather([0], torch.empty(1, 4, 9))
+    # the same bytes inside another container (a contiguous HDF5 dataset is such a block): opened in place at its offset
+    raw = tmp_path / "container.bin"
+    raw.write_bytes(b"\x89HDF" + b"\0" * 92 + feats.tobytes())
+    st = feed.FeatureStore(raw, names, shape=feats.shape, offset=96)
+    assert np.array_equal(st.gather([4], torch.empty(1, 4, 8)).numpy(), feats[[4]])
+    with pytest.raises(ValueError):
+        feed.FeatureStore(tmp_path / "size,rcnn_arch,224.npy", names[:-1])
+
+
+def test_store_batches_equal_the_reference_items_collated(tmp_path):
+    """store_batches == collate() of the items the reference's Inner.__getitem__ would build (datasets.py:906-969), batch by
+    batch, shuffled or not, the short last batch included (no drop_last, datasets.py:975)."""
+    feats, names = _store(tmp_path)
+    st = feed.FeatureStore(tmp_path / "size,rcnn_arch,224.npy", names, workers=2)
+    rs = np.random.RandomState(1)
+    qa = []
+    for i in range(13):
+        ids = rs.choice(20, size=3, replace=False)
+        p = rs.dirichlet(np.ones(3))
+        qa.append({"img_filename": names[int(rs.randint(11))], "q_idxes": [1 + i, 2, 3, 0, 0, 0], "q_id": 500 + i,
+                   "a_10_idx": [(int(c), float(x)) for c, x in zip(ids, p)]})
+    for shuffle in (False, True):
+        order = np.arange(13)
+        if shuffle:
+            np.random.RandomState(9).shuffle(order)
+        got = [{k: t.clone() for k, t in b.items()} for b in feed.store_batches(st, qa, 5, 20, shuffle=shuffle, seed=9, pin=False)]
+        assert [b["v"].shape[0] for b in got] == [5, 5, 3]
+        for k, b in enumerate(got):
+            its = [dict(qa[i], v=feats[st.index(qa[i]["img_filename"])]) for i in order[5 * k:5 * k + 5]]
+            want = feed.collate(its, 20)
+            for key in ("v", "q_idxes", "q_id", "a"):
+                assert torch.equal(b[key], want[key]), (shuffle, k, key)
+    # test split: no answers; bf16 transport; the ring reuses its staging tensors
+    test_items = [{"v_idx": i % 11, "q_idxes": [1, 0, 0], "q_id": i} for i in range(8)]
+    seen = []
+    for b in feed.store_batches(st, test_items, 4, 20, pin=False, region_dtype=torch.bfloat16, ring=2):
+        assert set(b) == {"v", "q_idxes", "q_id"} and b["v"].dtype == torch.bfloat16
+        seen.append(b["v"].data_ptr())
+    assert len(seen) == 2 and seen[0] != seen[1]
+    # through the prefetcher (CPU pass-through here; tests/test_gpu_models.py feeds a trainer from it on the GPU)
+    out = list(feed.DevicePrefetcher(feed.store_batches(st, qa, 5, 20, pin=False, ring=4), "cpu", depth=2))
+    assert len(out) == 3 and torch.equal(out[2]["q_id"], torch.tensor([510, 511, 512]))

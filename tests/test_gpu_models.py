@@ -1041,7 +1041,7 @@ RTOL_FORCED_F32 = 2e-4     # with the gates equal: every gradient of the loss ov
 @pytest.mark.parametrize("engine", ["split", "mfma"])
 @pytest.mark.parametrize("mode", ["eval", "train"])
 @pytest.mark.parametrize("cls,nans", [("cor2", 2000), ("oda", 3000)])
-def test_baseline_batch_with_the_products_gates(cls, nans, mode, engine, monkeypatch):
+def test_baseline_batch_with_the_products_gates(cls, nans, mode, engine, monkeypatch, measured):
     """test_baseline_batch_against_oracle splits off the samples that own a relu unit within float32 rounding of zero (more
     than half of a CoR2 batch) and holds them to a looser bar, because a unit that falls on the other side of zero moves a
     whole row of a gradient.  Here that ONE ingredient is taken out instead: the product's own relu decisions at every relu
@@ -1174,7 +1174,9 @@ def test_baseline_batch_with_the_products_gates(cls, nans, mode, engine, monkeyp
     for site, (n, units, edge) in sorted(flips.items()):
         print("  [%s] gates %-14s differ at %d of %d units (%.1e), largest |pre| / rms there %.1e" % (cls, site, n, units, n / units, edge))
         assert n <= max(1, FLIP_FRACTION_F32 * units) and edge <= FLIP_EDGE_F32, (site, n, units, edge)
-    assert rel(got, torch.cat(want).numpy()) <= RTOL
+    e_logits = rel(got, torch.cat(want).numpy())
+    measured("logits rel err", e_logits, RTOL)
+    assert e_logits <= RTOL
     worst = (0.0, "")
     for (n, p), po in zip(model.named_parameters(), params):
         g64, w64 = p.grad.detach().cpu().numpy().astype(np.float64), po.grad.numpy()
@@ -1188,3 +1190,4 @@ def test_baseline_batch_with_the_products_gates(cls, nans, mode, engine, monkeyp
         worst = max(worst, (e, n))
     print("[%s B=512 %s, %s engine, gates forced] all %d samples: worst gradient error %.2e of its tensor's scale (%s)"
           % (cls, mode, engine, B, worst[0], worst[1]))
+    measured("worst gradient err / scale", worst[0], RTOL_FORCED_F32, worst[1])
