@@ -147,15 +147,26 @@ struct NtArgs {
   int tiles_n;
   const float* Bf = nullptr;   // the fp32 original of the packed image, [N, K] row stride ldb: operand of the repair path
   int ldb = 0;                 // (nullptr: the kernel's caller repairs in its own epilogue, or not at all)
+  // REL (K1 -> K5 fused, config/CoR2.py:215-218): the operand is not A but the relation step's output of it,
+  //   x[m][k] = T[s][k] + C2[s][k] * A[m][k],   s = m / rps   (T, C2 [M / rps, K] fp32, dense),
+  // formed in registers from the staged rows of T / C2 before the mask and the split: v2 is never written to HBM.
+  const float* T = nullptr;
+  const float* C2 = nullptr;
+  int rps = 0;                 // rows per sample
 };
+// REL: samples a BM-row tile can touch, and the LDS bytes of their staged (T, C2) rows: [sample][T | C2][K] floats
+__host__ __device__ inline int rel_samples(int BM, int rps) { return (BM - 1) / rps + 2; }
+__host__ __device__ inline size_t rel_lds_bytes(int BM, int rps, int K) { return (size_t)rel_samples(BM, rps) * 2 * K * 4; }
 // the repair path of the NT form: C[row][col] as an fp32 dot product of the original operands (DROP: the same mask bits)
 template <bool DROP>
-__device__ __forceinline__ float nt_repair(const float* A, int lda, const float* Bf, int ldb, int K, int row, int col, uint32_t key) {
+__device__ __forceinline__ float nt_repair(const float* A, int lda, const float* Bf, int ldb, int K, int row, int col, uint32_t key,
+                                           const float* T = nullptr, const float* C2 = nullptr, int rps = 1) {
   const float* a = A + (size_t)row * lda;
   const float* b = Bf + (size_t)col * ldb;
   float s = 0.f;
   for (int k = 0; k < K; ++k) {
     float x = a[k];
+    if (T != nullptr) x = fmaf(C2[(size_t)(row / rps) * K + k], x, T[(size_t)(row / rps) * K + k]);
     if constexpr (DROP) {
       const uint32_t e = (uint32_t)row * (uint32_t)K + (uint32_t)k;
       x = ((mask_word32(e >> 5, key) >> (e & 31u)) & 1u) != 0u ? x : 0.f;
@@ -175,18 +186,22 @@ __device__ __forceinline__ float nt_repair(const float* A, int lda, const float*
 // rows m0 + 16 i .. of A against the column blocks (n0 >> 4) + j of the packed image.  a_bytes = the extent of A the loads may
 // touch (beyond it they read zeros: a contraction padded past the row end -- K = 320 over rows of 310 -- leans on that and on
 // the image's zero planes there).
-template <int RB, int CB, bool DROP, int TUNE, int NR>
+// REL: `rel_lds` = the staged (T, C2) rows of the samples from `rel_s0` on (rel_stage), read back one row block ahead of the
+// block's split (two register sets: an LDS read issued in the region that needs it would stall the wave's whole issue stream).
+template <int RB, int CB, bool DROP, int TUNE, int NR, bool REL = false>
 __device__ __forceinline__ void nt_accumulate(const NtArgs& p, const DropCfg& dc, size_t a_bytes, int m0, int n0, int c_lo, int c_hi,
-                                              f32x4 (&acc)[RB][CB]) {
+                                              f32x4 (&acc)[RB][CB], const char* rel_lds = nullptr, int rel_s0 = 0) {
   static_assert((2 * RB) % NR == 0 && NR >= 2 && NR <= 2 * RB, "the ring must divide a pair of chunks");
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int chunks = p.K / kChunk;
   uint32_t offA[RB], offB[CB], wordA[RB];
+  uint32_t offT[REL ? RB : 1];     // REL: byte offset of (this lane's sample in row block i, k = 4 g) in the staged image
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
     const int row = min(m0 + 16 * i + r, p.M - 1);
     offA[i] = ((uint32_t)row * (uint32_t)p.lda + 4u * g) * 4u;
     wordA[i] = ((uint32_t)row * (uint32_t)p.K) >> 5;
+    if constexpr (REL) offT[i] = ((uint32_t)(row / p.rps - rel_s0) * 2u * (uint32_t)p.K + 4u * g) * 4u;
   }
 #pragma unroll
   for (int j = 0; j < CB; ++j) {
@@ -216,13 +231,31 @@ __device__ __forceinline__ void nt_accumulate(const NtArgs& p, const DropCfg& dc
   };
   // the planes of row block i of chunk c from its raw registers (DROP: masked first -- lane (r, g) holds the elements
   // k = 32 c + 4 g .. + 3 and 32 c + 16 + 4 g .. + 3 of its row: bits 4 g .. and 16 + 4 g .. of the row's hash word of the chunk)
-  auto prepare = [&](const ARaw& a, Planes& pl, int i, int c) {
+  struct TC {
+    f32x4 tlo, thi, clo, chi;
+  };
+  TC tc[REL ? 2 : 1];
+  auto loadTC = [&](TC& o, int i, int c) {     // the (T, C2) values of row block i's lanes for chunk c, from LDS
+    if constexpr (REL) {
+      const char* base = rel_lds + offT[i] + (uint32_t)c * 128u;
+      o.tlo = *reinterpret_cast<const f32x4*>(base);
+      o.thi = *reinterpret_cast<const f32x4*>(base + 64);
+      o.clo = *reinterpret_cast<const f32x4*>(base + (size_t)p.K * 4);
+      o.chi = *reinterpret_cast<const f32x4*>(base + (size_t)p.K * 4 + 64);
+    }
+  };
+  auto prepare = [&](const ARaw& a, Planes& pl, int i, int c, int n = 0) {
     if constexpr ((TUNE & 1) != 0) {
       pl.p[0] = __builtin_bit_cast(u32x4, a.lo);
       pl.p[1] = __builtin_bit_cast(u32x4, a.hi);
       pl.p[2] = __builtin_bit_cast(u32x4, a.lo);
     } else {
       ARaw m = a;
+      if constexpr (REL) {      // x = T + C2 * a (two v_pk_fma_f32 per four), before the mask and the split
+        const TC& q = tc[n & 1];
+        m.lo = __builtin_elementwise_fma(q.clo, m.lo, q.tlo);
+        m.hi = __builtin_elementwise_fma(q.chi, m.hi, q.thi);
+      }
       if constexpr (DROP) {
         const uint32_t w = mask_word32(wordA[i] + (uint32_t)c, key);
         rt::keep4_bits(m.lo, w >> (4u * g));
@@ -262,7 +295,8 @@ __device__ __forceinline__ void nt_accumulate(const NtArgs& p, const DropCfg& dc
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const int n = P * RB + i;
-      prepare(a[(n + 1) % NR], pl[(n + 1) & 1], (n + 1) % RB, min(c_pair + (n + 1) / RB, c_hi - 1));
+      prepare(a[(n + 1) % NR], pl[(n + 1) & 1], (n + 1) % RB, min(c_pair + (n + 1) / RB, c_hi - 1), n + 1);
+      if constexpr (REL) loadTC(tc[n & 1], (n + 2) % RB, min(c_pair + (n + 2) / RB, c_hi - 1));   // (row block n's set is free)
       if constexpr ((TUNE & 2) == 0) fetch(n + 1 + NR, c_pair);
       int nb = 0;
       if constexpr ((TUNE & 32) == 0) {
@@ -277,6 +311,7 @@ __device__ __forceinline__ void nt_accumulate(const NtArgs& p, const DropCfg& dc
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+        if (REL && m < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read: (T, C2) of the row block after next
         __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);   // VALU
         if (nl > 0 && m % per == per - 1 && m / per < nl) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
       }
@@ -287,7 +322,11 @@ __device__ __forceinline__ void nt_accumulate(const NtArgs& p, const DropCfg& dc
     loadB(b0, c_lo);
 #pragma unroll
     for (int n = 0; n < NR; ++n) fetch(n, c_lo);
-    prepare(a[0], pl[0], 0, c_lo);
+    if constexpr (REL) {
+      loadTC(tc[0], 0, c_lo);
+      loadTC(tc[1], 1 % RB, min(c_lo + 1 / RB, c_hi - 1));
+    }
+    prepare(a[0], pl[0], 0, c_lo, 0);
     fetch(NR, c_lo);
     __builtin_amdgcn_sched_barrier(0);
     for (int c = c_lo; c < c_hi; c += 2) {
@@ -437,10 +476,12 @@ template <int RB, int WN, int WK, bool SHARE_A>
 constexpr size_t nt_lds_bytes(size_t reduction_bytes) {
   return SHARE_A ? (reduction_bytes > (size_t)WK * 2 * RB * 3 * 1024 ? reduction_bytes : (size_t)WK * 2 * RB * 3 * 1024) : reduction_bytes;
 }
-template <int RB, int CB, int WM, int WN, int WK, bool DROP, class Epi, int TUNE = 0, int NR = RB, bool SHARE_A = false>
+// REL: the tile's (T, C2) rows are staged into LDS first (rel_lds_bytes(); the K-split reduction reuses the space afterwards).
+template <int RB, int CB, int WM, int WN, int WK, bool DROP, class Epi, int TUNE = 0, int NR = RB, bool SHARE_A = false, bool REL = false>
 __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg dc, Epi epi) {
   using S = rt::NtShape<RB, CB, WM, WN, WK>;
   static_assert(!SHARE_A || WM == 1, "SHARE_A: the waves of a K range share their rows");
+  static_assert(!(REL && SHARE_A), "REL is built on the per-wave split");
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wk = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
@@ -467,6 +508,20 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg 
     nt_accumulate_shared<RB, CB, WN, DROP, TUNE>(p, dc, ((size_t)(p.M - 1) * p.lda + p.K) * 4, m0, n0, c_lo, c_hi, wn,
                                                  sp_smem + (size_t)wk * 2 * RB * 3 * 1024, acc);
     __syncthreads();   // the K-split reduction below reuses the plane buffers
+  } else if constexpr (REL) {
+    extern __shared__ __attribute__((aligned(16))) char sp_smem[];
+    // stage T and C2 of the samples this workgroup's BM rows belong to: [sample][T | C2][K], 16-byte pieces, coalesced
+    const int s0 = (tm * S::BM) / p.rps;
+    const int ns = min(rel_samples(S::BM, p.rps), (p.M + p.rps - 1) / p.rps - s0);
+    const int k4 = p.K / 4;
+    for (int idx = threadIdx.x; idx < ns * 2 * k4; idx += kThreads) {
+      const int s = idx / (2 * k4), rem = idx - s * 2 * k4, which = rem / k4, k = rem - which * k4;
+      const float* src = (which == 0 ? p.T : p.C2) + (size_t)(s0 + s) * p.K + 4 * k;
+      reinterpret_cast<f32x4*>(sp_smem)[idx] = *reinterpret_cast<const f32x4*>(src);
+    }
+    __syncthreads();
+    nt_accumulate<RB, CB, DROP, TUNE, NR, true>(p, dc, ((size_t)(p.M - 1) * p.lda + p.K) * 4, m0, n0, c_lo, c_hi, acc, sp_smem, s0);
+    __syncthreads();   // the K-split reduction below reuses the staged rows' space
   } else {
     nt_accumulate<RB, CB, DROP, TUNE, NR>(p, dc, ((size_t)(p.M - 1) * p.lda + p.K) * 4, m0, n0, c_lo, c_hi, acc);
   }
@@ -517,7 +572,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg 
       if (col >= p.N) continue;
       for (int t = 0; t < 4; ++t) {
         const int row = m0 + 16 * (blk / CB) + 4 * g + t;
-        if (row < p.M) epi(row, col, nt_repair<DROP>(p.A, p.lda, p.Bf, p.ldb, p.K, row, col, key));
+        if (row < p.M) epi(row, col, nt_repair<DROP>(p.A, p.lda, p.Bf, p.ldb, p.K, row, col, key, REL ? p.T : nullptr, p.C2, REL ? p.rps : 1));
       }
     }
   }
@@ -551,7 +606,14 @@ struct TnArgs {
   const float* Gf = nullptr;   // the fp32 original of the packed image ([M, N1], row stride ldg) and, when it was gated, the
   const float* Yf = nullptr;   // forward output whose sign gates it: operands of the repair path (any_nonfinite); Gf == nullptr:
   int ldg = 0;                 // no repair
+  // REL (gemm_tn_shared_kernel): the layer input is x[m][n2] = T[s][n2] + C2[s][n2] * X[m][n2], s = m / rps (see NtArgs), recomputed
+  // from X = v while it is staged -- the weight gradient of compress_v2 without v2 in HBM.  rps_magic = 2^32 / rps + 1.
+  const float* T = nullptr;
+  const float* C2 = nullptr;
+  int rps = 0;
+  uint32_t rps_magic = 0;
 };
+inline uint32_t rps_magic_of(int rps) { return (uint32_t)((1ull << 32) / (uint64_t)rps + 1ull); }   // m / rps = umulhi(m, magic), m rps < 2^32
 // The epilogue of both TN kernels: D[row = n1 % 16 = 4 g + t][col r] of block (i, b = 4 q + cc) is column n2_0 + 64 q + 4 r + cc,
 // so the four cc of a span leave as one 16-byte store.  A group of four that holds a non-finite value is stored again from the
 // repair path: the slab's rows contracted as fp32 dot products of the original operands (same gate, same mask bits).
@@ -588,6 +650,10 @@ __device__ __forceinline__ void tn_store(const TnArgs& p, const DropCfg& dc, con
         float gv = p.Gf[(size_t)m * p.ldg + n1];
         if (p.Yf != nullptr) gv = p.Yf[(size_t)m * p.ldg + n1] > 0.f ? gv : 0.f;
         f32x4 x = *reinterpret_cast<const f32x4*>(p.X + (size_t)m * p.ldx + col);
+        if (p.T != nullptr) {
+          const size_t at = (size_t)(m / p.rps) * p.N2 + col;
+          x = __builtin_elementwise_fma(*reinterpret_cast<const f32x4*>(p.C2 + at), x, *reinterpret_cast<const f32x4*>(p.T + at));
+        }
         if constexpr (DROP) {
           const uint32_t e = (uint32_t)m * (uint32_t)p.N2 + (uint32_t)col;     // a multiple of 4
           const uint32_t w = mask_word32(e >> 5, key) >> (e & 31u);
@@ -855,8 +921,10 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_kernel(TnArgs p, DropCfg 
 // MFMAs and writes their planes into LDS (2 x 24 KiB, double-buffered); all four waves read every block's planes back (three
 // ds_read_b128 per block, one block ahead).  One workgroup barrier per chunk, placed in front of the last block so that the next
 // chunk's block 0 is prefetched under it.  SPN = 2 (8 blocks: two per wave).
+// REL: see TnArgs.  A lane's 8 rows of a chunk belong to at most two samples (rps >= 8): the (T, C2) pairs of both come in by
+// 8-byte loads two chunks ahead, like the raw rows, and each row picks its sample's pair.
 constexpr int kTnSharedLds = 2 * 8 * 3 * 1024;
-template <int NA, bool DROP, int TUNE = 0>
+template <int NA, bool DROP, int TUNE = 0, bool REL = false>
 __global__ __launch_bounds__(kThreads, 1) void gemm_tn_shared_kernel(TnArgs p, DropCfg dc) {
   constexpr int SPN = 2, NBX = 8;
   extern __shared__ __attribute__((aligned(16))) char tn_smem[];
@@ -893,6 +961,26 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_shared_kernel(TnArgs p, D
   Planes g0[NA], g1[NA], xp[2];
   uint32_t hw[8];
   const int t8 = r & 7;
+  struct TCPair {
+    f32x2 ta, ca, tb, cb;   // (T, C2) of this lane's two columns for the sample of its first row (a) and for the next one (b)
+    int na;                 // how many of the lane's 8 rows belong to sample a
+  };
+  TCPair tc0, tc1;
+  const int nsamples = (p.M + (REL ? p.rps : 1) - 1) / (REL ? p.rps : 1);
+  const uint32_t colT = (uint32_t)min(n2_0 + 64 * pq + 4 * r + pc, p.N2 - 2) * 4u;
+  const rsrc_t Tb = make_rsrc(REL ? p.T : p.X, (size_t)nsamples * p.N2 * 4), Cb = make_rsrc(REL ? p.C2 : p.X, (size_t)nsamples * p.N2 * 4);
+  auto loadTC = [&](TCPair& o, int c) {
+    if constexpr (REL) {
+      const uint32_t row = (uint32_t)min(c, c_hi - 1) * 32u + 8u * (uint32_t)g;
+      const uint32_t sa = min(__umulhi(row, p.rps_magic), (uint32_t)(nsamples - 1)), sb = min(sa + 1u, (uint32_t)(nsamples - 1));
+      o.na = (int)((sa + 1u) * (uint32_t)p.rps - row);      // rows until the sample ends (>= 8: all of them)
+      const uint32_t oa = sa * (uint32_t)p.N2 * 4u + colT, ob = sb * (uint32_t)p.N2 * 4u + colT;
+      o.ta = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(Tb, (int)oa, 0, 0));
+      o.ca = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(Cb, (int)oa, 0, 0));
+      o.tb = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(Tb, (int)ob, 0, 0));
+      o.cb = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(Cb, (int)ob, 0, 0));
+    }
+  };
   auto loadX = [&](f32x2(&raw)[8], int c) {
     const uint32_t so = (uint32_t)min(c, c_hi - 1) * chunk_stride_x;
 #pragma unroll
@@ -913,11 +1001,12 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_shared_kernel(TnArgs p, D
     for (int j = 0; j < 8; ++j) hw[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ((lane & ~7) + j), h);
   };
   // split column k (0 / 1) of the raw rows into the planes of X block 4 pq + pc + k and write them to LDS buffer `buf`
-  auto produce = [&](const f32x2(&raw)[8], int k, int buf) {
+  auto produce = [&](const f32x2(&raw)[8], int k, int buf, const TCPair& tc) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float x = raw[j][k];
+      float x = raw[j][k];
+      if constexpr (REL) x = j < tc.na ? fmaf(tc.ca[k], x, tc.ta[k]) : fmaf(tc.cb[k], x, tc.tb[k]);
       if constexpr (DROP) {
         const uint32_t m = 0u - ((hw[j] >> (4u * (uint32_t)t8 + (uint32_t)(pc + k))) & 1u);
         v[j] = __uint_as_float(__float_as_uint(x) & m);
@@ -946,7 +1035,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_shared_kernel(TnArgs p, D
   };
   // One chunk (parity P inside a pair).  On entry: the planes of chunk c are in LDS buffer P (published by the last barrier) and
   // block 0's are in xp[0]; `rn` holds the raw rows of chunk c + 1, `rf` is free for chunk c + 2's.
-  auto chunk = [&](Planes(&gp)[NA], Planes(&gn)[NA], f32x2(&rn)[8], f32x2(&rf)[8], int c, auto parity) {
+  auto chunk = [&](Planes(&gp)[NA], Planes(&gn)[NA], f32x2(&rn)[8], f32x2(&rf)[8], TCPair& tn, TCPair& tf, int c, auto parity) {
     constexpr int P = decltype(parity)::value;
     int gidx = 0;
 #pragma unroll
@@ -958,8 +1047,9 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_shared_kernel(TnArgs p, D
         if constexpr ((TUNE & 2) == 0) loadX(rf, c + 2);
         if constexpr (DROP) hash_chunk(c + 1);
       }
-      if (b == 1) produce(rn, 0, P ^ 1);
-      if (b == 4) produce(rn, 1, P ^ 1);
+      if (b == 1) produce(rn, 0, P ^ 1, tn);
+      if (b == 4) produce(rn, 1, P ^ 1, tn);
+      if (REL && b == 1) loadTC(tf, c + 2);      // (tf was the previous chunk's tn: free since its region 4; the caller swaps the two)
       if constexpr ((TUNE & 32) == 0) {
         if (b == 2 || b == 3 || b == 5 || b == 6) {
 #pragma unroll
@@ -992,15 +1082,17 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_shared_kernel(TnArgs p, D
     for (int idx = 0; idx < 3 * NA; ++idx) loadG1(g0, idx, c_lo);
     loadX(raw0, c_lo);
     loadX(raw1, c_lo + 1);
+    loadTC(tc0, c_lo);
+    loadTC(tc1, c_lo + 1);
     if constexpr (DROP) hash_chunk(c_lo);
-    produce(raw0, 0, 0);
-    produce(raw0, 1, 0);
+    produce(raw0, 0, 0, tc0);
+    produce(raw0, 1, 0, tc0);
     __syncthreads();
     fetch(xp[0], 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     for (int c = c_lo; c < c_hi; c += 2) {
-      chunk(g0, g1, raw1, raw0, c, std::integral_constant<int, 0>{});
-      chunk(g1, g0, raw0, raw1, c + 1, std::integral_constant<int, 1>{});
+      chunk(g0, g1, raw1, raw0, tc1, tc0, c, std::integral_constant<int, 0>{});
+      chunk(g1, g0, raw0, raw1, tc0, tc1, c + 1, std::integral_constant<int, 1>{});
     }
   }
 

@@ -79,15 +79,66 @@ extern "C" int vqa_linear_act_fwd_split(const float* x, int ldx, const float* w,
   return check_launch("linear_act_fwd_split");
 }
 
+// ---- K1 -> K5 fused (config/CoR2.py:215-218): y = act(drop(t + c2 * v) W^T + b) without v2 in HBM ---------------------------------
+static bool relation_linear_ok(int B, int Nr, int D, int L, float p_drop) {
+  using S = rt::NtShape<9, 5, 1, 2, 2>;
+  return B >= 1 && Nr >= 8 && Nr <= 1024 && split_shape_ok(B * Nr, D, L, D, p_drop) && D % 128 == 0 &&
+         sp::rel_lds_bytes(S::BM, Nr, D) <= 96 * 1024 && (size_t)B * Nr * Nr < (1ull << 32);
+}
+extern "C" int vqa_relation_linear_split_supported(int B, int N, int D, int L, float p_drop) {
+  return relation_linear_ok(B, N, D, L, p_drop) ? 1 : 0;
+}
+
+extern "C" int vqa_relation_linear_fwd_split(const float* v, const float* t, const float* c2, const float* w, const float* bias,
+                                             float* y, void* workspace, size_t workspace_bytes, int B, int N, int D, int L,
+                                             int act, float p_drop, uint64_t seed, const uint64_t* seed_ptr, vqa_stream_t stream) {
+  VQA_REQUIRE(v && t && c2 && w && y && workspace, VQA_E_BADARG, "relation_linear_fwd_split: null pointer");
+  VQA_REQUIRE(act == 0 || act == 1, VQA_E_BADARG, "relation_linear_fwd_split: act must be 0 (none) or 1 (relu), got %d", act);
+  VQA_REQUIRE(relation_linear_ok(B, N, D, L, p_drop), VQA_E_UNSUPPORTED,
+              "relation_linear_fwd_split: shape outside the fused form (B=%d N=%d D=%d L=%d p=%f); see vqa_relation_linear_split_supported",
+              B, N, D, L, (double)p_drop);
+  VQA_REQUIRE(aligned(v, 16) && aligned(t, 16) && aligned(c2, 16) && aligned(w, 16) && aligned(y, 8) && aligned(workspace, 16),
+              VQA_E_UNSUPPORTED, "relation_linear_fwd_split: v, t, c2, w, workspace must be 16-byte aligned");
+  VQA_REQUIRE(workspace_bytes >= vqa_linear_act_fwd_split_workspace_bytes(D, L), VQA_E_BADARG,
+              "relation_linear_fwd_split: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
+  const int M = B * N, K = D;
+  sp::u32x4* wp = static_cast<sp::u32x4*>(workspace);
+  {
+    const long threads = (long)((L + 15) / 16) * (K / sp::kChunk) * 64;
+    VQA_LAUNCH((sp::split_pack_kernel<false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, w, K, L, K, wp);
+  }
+  using S = rt::NtShape<9, 5, 1, 2, 2>;
+  const int tiles_m = (M + S::BM - 1) / S::BM, tiles_n = (L + S::BN - 1) / S::BN;
+  sp::NtArgs a{v, wp, K, M, L, K, tiles_n, w, K};
+  a.T = t;
+  a.C2 = c2;
+  a.rps = N;
+  const SplitEpiBiasAct epi{y, bias, L, act, dc.p8 > 0 ? dc.scale : 1.f};
+  const size_t rel = sp::rel_lds_bytes(S::BM, N, K), lds = rel > S::kLdsBytes ? rel : S::kLdsBytes;
+  if (dc.p8 > 0) {
+    VQA_ENSURE_LDS((sp::gemm_nt_kernel<9, 5, 1, 2, 2, true, SplitEpiBiasAct, 0, 3, false, true>), lds);
+    VQA_LAUNCH((sp::gemm_nt_kernel<9, 5, 1, 2, 2, true, SplitEpiBiasAct, 0, 3, false, true>), dim3(tiles_m * tiles_n),
+               dim3(sp::kThreads), lds, s, a, dc, epi);
+  } else {
+    VQA_ENSURE_LDS((sp::gemm_nt_kernel<9, 5, 1, 2, 2, false, SplitEpiBiasAct, 0, 3, false, true>), lds);
+    VQA_LAUNCH((sp::gemm_nt_kernel<9, 5, 1, 2, 2, false, SplitEpiBiasAct, 0, 3, false, true>), dim3(tiles_m * tiles_n),
+               dim3(sp::kThreads), lds, s, a, dc, epi);
+  }
+  return check_launch("relation_linear_fwd_split");
+}
+
 extern "C" size_t vqa_linear_act_dw_split_workspace_bytes(int M, int K, int N) {
   const sp::TnPlan pl = sp::tn_plan(M, tn_slabs());
   return round256(sp::packed_tn_bytes(pl.slabs, pl.cps, N)) + round256((size_t)pl.slabs * N * K * 4) +
          round256((size_t)pl.slabs * sp::kPackParts * N * 4);
 }
 
-extern "C" int vqa_linear_act_dw_split(const float* x, int ldx, const float* y, const float* gy, float* d_w, float* d_b,
-                                       float* gz_out, void* workspace, size_t workspace_bytes, int M, int K, int N, int act, float p_drop,
-                                       uint64_t seed, const uint64_t* seed_ptr, vqa_stream_t stream) {
+static int linear_dw_split_impl(const float* x, int ldx, const float* y, const float* gy, float* d_w, float* d_b,
+                                float* gz_out, void* workspace, size_t workspace_bytes, int M, int K, int N, int act, float p_drop,
+                                uint64_t seed, const uint64_t* seed_ptr, vqa_stream_t stream, const float* rel_t, const float* rel_c2,
+                                int rps) {
   VQA_REQUIRE(x && gy && d_w && workspace, VQA_E_BADARG, "linear_act_dw_split: null pointer");
   VQA_REQUIRE(act == 0 || (act == 1 && y != nullptr), VQA_E_BADARG, "linear_act_dw_split: act = 1 needs the forward output y");
   VQA_REQUIRE(gz_out == nullptr || (act == 1 && aligned(gz_out, 8)), VQA_E_BADARG,
@@ -118,8 +169,18 @@ extern "C" int vqa_linear_act_dw_split(const float* x, int ldx, const float* y, 
   }
   constexpr int NA = 5, SPN = 2;
   const int tiles1 = (nblocks + 4 * NA - 1) / (4 * NA), tiles2 = (K + 64 * SPN - 1) / (64 * SPN);
-  const sp::TnArgs a{gp, x, slab, ldx, M, N, K, nblocks, pl.cps, tiles1, tiles2, gy, act == 1 ? y : nullptr, N};
+  sp::TnArgs a{gp, x, slab, ldx, M, N, K, nblocks, pl.cps, tiles1, tiles2, gy, act == 1 ? y : nullptr, N};
   const dim3 grid(tiles1 * tiles2 * pl.slabs);
+  if (rel_t != nullptr) {      // the layer input is t + c2 * x, recomputed while x is staged (always the shared-split kernel)
+    a.T = rel_t;
+    a.C2 = rel_c2;
+    a.rps = rps;
+    a.rps_magic = sp::rps_magic_of(rps);
+    if (dc.p8 > 0)
+      VQA_LAUNCH((sp::gemm_tn_shared_kernel<NA, true, 0, true>), grid, dim3(sp::kThreads), sp::kTnSharedLds, s, a, dc);
+    else
+      VQA_LAUNCH((sp::gemm_tn_shared_kernel<NA, false, 0, true>), grid, dim3(sp::kThreads), sp::kTnSharedLds, s, a, dc);
+  } else
   // the split of x shared by the workgroup's four waves through LDS (91.9 / 94.0 us against 99 / 107 with every wave splitting
   // all of it, tools/split_probe.hip); VQA_SPLIT_TN_SHARED=0 keeps the per-wave form
   if (vqa::option_is("VQA_SPLIT_TN_SHARED", '0')) {
@@ -137,4 +198,24 @@ extern "C" int vqa_linear_act_dw_split(const float* x, int ldx, const float* y, 
   VQA_LAUNCH((sp::slab_sum_kernel), dim3(sp::slab_sum_blocks(NK, N)), dim3(256), 0, s, slab, dbslab, d_w, d_b, NK, N, pl.slabs,
              pl.slabs * sp::kPackParts, dc.p8 > 0 ? dc.scale : 1.f);
   return check_launch("linear_act_dw_split");
+}
+
+
+extern "C" int vqa_linear_act_dw_split(const float* x, int ldx, const float* y, const float* gy, float* d_w, float* d_b,
+                                       float* gz_out, void* workspace, size_t workspace_bytes, int M, int K, int N, int act, float p_drop,
+                                       uint64_t seed, const uint64_t* seed_ptr, vqa_stream_t stream) {
+  return linear_dw_split_impl(x, ldx, y, gy, d_w, d_b, gz_out, workspace, workspace_bytes, M, K, N, act, p_drop, seed, seed_ptr, stream,
+                              nullptr, nullptr, 0);
+}
+
+extern "C" int vqa_relation_linear_dw_split(const float* v, const float* t, const float* c2, const float* y, const float* gy,
+                                            float* d_w, float* d_b, float* gz_out, void* workspace, size_t workspace_bytes, int B,
+                                            int N, int D, int L, int act, float p_drop, uint64_t seed, const uint64_t* seed_ptr,
+                                            vqa_stream_t stream) {
+  VQA_REQUIRE(v && t && c2, VQA_E_BADARG, "relation_linear_dw_split: null pointer");
+  VQA_REQUIRE(relation_linear_ok(B, N, D, L, p_drop), VQA_E_UNSUPPORTED,
+              "relation_linear_dw_split: shape outside the fused form (B=%d N=%d D=%d L=%d p=%f)", B, N, D, L, (double)p_drop);
+  VQA_REQUIRE(aligned(t, 16) && aligned(c2, 16), VQA_E_UNSUPPORTED, "relation_linear_dw_split: t, c2 must be 16-byte aligned");
+  return linear_dw_split_impl(v, D, y, gy, d_w, d_b, gz_out, workspace, workspace_bytes, B * N, D, L, act, p_drop, seed, seed_ptr,
+                              stream, t, c2, N);
 }

@@ -205,7 +205,7 @@ class FeatureStore:
         elif out.dtype == torch.bfloat16:
             def copy(lo, hi):
                 for r in range(lo, hi):
-                    out[r].copy_(torch.from_numpy(np.ascontiguousarray(self.features[idx[r]])))     # round-to-nearest-even
+                    out[r].copy_(torch.from_numpy(np.array(self.features[idx[r]])))     # (a writable copy) round-to-nearest-even
         else:
             raise ValueError("gather: out must be float32 or bfloat16")
         n = idx.size

@@ -1039,28 +1039,45 @@ class RelationProjection(torch.autograd.Function):
         if t.shape != (B, D) or c2.shape != (B, D) or w.shape != (L, D):
             raise ValueError("relation_projection: t, c2 must be [B,D] and w [L,D] for v [B,N,D]")
         L_ = _lib.lib()
-        x = torch.empty_like(v)
         sv, sp = _seed_args(seed)
-        if pairwise is not None:
-            q1, q2, alpha, glimpse = pairwise
-            q1, q2, alpha = _prep("q1", q1.detach()), _prep("q2", q2.detach()), _prep("alpha", alpha.detach())
-            a_ptr = ctypes.c_void_p(alpha.data_ptr() + 4 * glimpse)
-            _launch("pairwise_relation_reduce_fwd", (B, N, D, 0), L_.vqa_pairwise_relation_reduce_drop_fwd, _p(v), _p(q1), _p(q2),
-                    a_ptr, alpha.shape[2], _p(x), float(p_drop), sv, sp, B, N, D)
-        else:
-            _launch("relation_apply_fwd", (B, N, D, float(p_drop) > 0), L_.vqa_relation_apply_fwd, _p(v), _p(t), _p(c2), _p(x),
-                    float(p_drop), sv, sp, B, N, D)
         M = B * N
         y = torch.empty(B, N, L, device=v.device, dtype=torch.float32)
-        _linear_fwd(x, w, bias, y, M, D, L, 1, 0.0, 0)
-        ctx.save_for_backward(v, x, w, y)
+        # Round 6 (VERDICT r05 missing #2, SURVEY 8f row 1 second half): the closed-form relation step is applied to the
+        # projection's A fragments in registers (vqa_relation_linear_fwd_split) -- v2 is neither written nor read back; backward
+        # recomputes it the same way inside the weight-gradient kernel.  The materialising path stays for the pairwise forward
+        # (relation_mode 0), the fp32 MFMA engine and shapes outside the fused form.
+        fused = pairwise is None and relation_linear_fused(v, t, c2, w, p_drop)
+        if fused:
+            ws_bytes = L_.vqa_linear_act_fwd_split_workspace_bytes(D, L)
+            ws = torch.empty((ws_bytes + 3) // 4, device=v.device, dtype=torch.float32)
+            _launch("relation_linear_fwd_split", (B, N, D, L, float(p_drop) > 0), L_.vqa_relation_linear_fwd_split, _p(v), _p(t), _p(c2),
+                    _p(w), _p(bias), _p(y), _p(ws), ws_bytes, B, N, D, L, 1, float(p_drop), sv, sp)
+            ctx.save_for_backward(v, t, c2, w, y)
+        else:
+            x = torch.empty_like(v)
+            if pairwise is not None:
+                q1, q2, alpha, glimpse = pairwise
+                q1, q2, alpha = _prep("q1", q1.detach()), _prep("q2", q2.detach()), _prep("alpha", alpha.detach())
+                a_ptr = ctypes.c_void_p(alpha.data_ptr() + 4 * glimpse)
+                _launch("pairwise_relation_reduce_fwd", (B, N, D, 0), L_.vqa_pairwise_relation_reduce_drop_fwd, _p(v), _p(q1), _p(q2),
+                        a_ptr, alpha.shape[2], _p(x), float(p_drop), sv, sp, B, N, D)
+            else:
+                _launch("relation_apply_fwd", (B, N, D, float(p_drop) > 0), L_.vqa_relation_apply_fwd, _p(v), _p(t), _p(c2), _p(x),
+                        float(p_drop), sv, sp, B, N, D)
+            _linear_fwd(x, w, bias, y, M, D, L, 1, 0.0, 0)
+            ctx.save_for_backward(v, x, w, y)
+        ctx.fused = fused
         ctx.bias = bias
         ctx.cfg = (float(p_drop), seed, bool(pregated))
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        v, x, w, y = ctx.saved_tensors
+        if ctx.fused:
+            v, t, c2, w, y = ctx.saved_tensors
+            x = None
+        else:
+            v, x, w, y = ctx.saved_tensors
         p_drop, seed, pregated = ctx.cfg
         B, N, D = v.shape
         L = w.shape[0]
@@ -1069,7 +1086,17 @@ class RelationProjection(torch.autograd.Function):
         L_ = _lib.lib()
         d_w = _grad_like(w)
         d_b = _grad_like(ctx.bias) if ctx.bias is not None else None
-        if not pregated and split_products(M, D, L, D, 0.0, weight_gradient=True, tensors=(x, d_w)):
+        if ctx.fused:
+            # the layer input t + c2 v (times its mask) is recomputed from v inside the weight-gradient GEMM; pregated: gy arrives
+            # already multiplied by relu'(y) -- the packing pass then neither gates nor writes a copy
+            sv, sp = _seed_args(seed)
+            gz = gy if pregated else torch.empty_like(gy)
+            ws_bytes = L_.vqa_linear_act_dw_split_workspace_bytes(M, D, L)
+            ws = torch.empty((ws_bytes + 3) // 4, device=v.device, dtype=torch.float32)
+            _launch("relation_linear_dw_split", (M, D, L, p_drop > 0, 0 if pregated else 1), L_.vqa_relation_linear_dw_split, _p(v), _p(t),
+                    _p(c2), None if pregated else _p(y), _p(gy), _p(d_w), _p(d_b), None if pregated else _p(gz), _p(ws), ws_bytes,
+                    B, N, D, L, 0 if pregated else 1, p_drop, sv, sp)
+        elif not pregated and split_products(M, D, L, D, 0.0, weight_gradient=True, tensors=(x, d_w)):
             gz = torch.empty_like(gy)                 # the split engine's packing pass gates the gradient and writes it out as well
             _linear_dw(x, w, y, gy, d_w, d_b, M, D, L, 1, 0.0, 0, gz_out=gz)
         else:
@@ -1088,6 +1115,18 @@ class RelationProjection(torch.autograd.Function):
             _launch("relation_projection_dgrad", (B, N, D, L, p_drop > 0), L_.vqa_relation_projection_dgrad, _p(gz), _p(w), _p(v),
                     _p(d_t), _p(d_c2), p_drop, sv, sp, B, N, D, L)
         return None, d_t, d_c2, d_w, d_b, None, None, None, None
+
+
+def relation_linear_fused(v, t, c2, w, p_drop):
+    """Does RelationProjection run K1 -> K5 as one kernel forward and one weight-gradient kernel backward (v2 never in HBM)?  The split
+    engine is selected (f32_products()), the library takes the shape, the operands are 16-byte aligned; VQA_RELATION_FUSED=0 keeps the
+    materialising path (measurement knob)."""
+    if f32_products() != "split" or os.environ.get("VQA_RELATION_FUSED", "1") == "0":
+        return False
+    B, N, D = v.shape
+    if any(x.data_ptr() % 16 != 0 for x in (v, t, c2, w)):
+        return False
+    return _lib.lib().vqa_relation_linear_split_supported(B, N, D, w.shape[0], float(p_drop)) == 1
 
 
 def relation_projection_supported(v, w):
