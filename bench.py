@@ -63,9 +63,12 @@ def work_of(name, shape):
     if base in ("linear_act_fwd", "linear_act_fwd_split"):
         M, K, N = s[:3]
         return "mfma", 2 * M * K * N                                                  # the fp32 GEMM's FLOPs on either engine
-    if base == "linear_act_dw_split":
+    if base in ("linear_act_dw_split", "relation_linear_dw_split"):
         M, K, N = s[:3]
         return "mfma", 2 * M * K * N
+    if base == "relation_linear_fwd_split":                                           # K1 -> K5 in one kernel: the projection's FLOPs
+        B, N, D, L = s[:4]                                                            # (the relation step's 2 N D per sample ride along)
+        return "mfma", 2 * B * N * D * L
     if base == "linear_act_bwd":
         M, K, N, _drop, dx = s[:5]
         return "mfma", 2 * M * K * N * (2 if dx else 1)                              # dW (+ dx)
@@ -147,6 +150,8 @@ PMC_KERNELS = {  # C-ABI entry -> kernel-name prefixes of its dominant device ke
     "linear_act_fwd_split": ["vqa::sp::gemm_nt_kernel<9, 5, 1, 2, 2"],
     "linear_act_dw_split": ["vqa::sp::gemm_tn_shared_kernel<5", "vqa::sp::gemm_tn_kernel<5, 2"],
     "relation_projection_dgrad_split": ["vqa::relation_dgrad_split_kernel"],
+    "relation_linear_fwd_split": ["vqa::sp::gemm_nt_kernel<9, 5, 1, 2, 2"],
+    "relation_linear_dw_split": ["vqa::sp::gemm_tn_shared_kernel<5"],
     "lowrank_bilinear_fusion_bwd": ["vqa::bilinear_dw_rt_kernel"],
     "relation_projection_dgrad": ["vqa::relation_dgrad_kernel"],
     "attention_logits_fwd": ["vqa::attention_logits_fwd_kernel"],

@@ -34,6 +34,16 @@ def phases(B):
         "classifier_bwd": [(NN, B, 510, 2000), (TN, 2000, 510, B)],
         "glimpse_fwd": [(NT, B, 155, 2048)] * 4,
         "glimpse_bwd": [(NN, B, 2048, 155)] * 4 + [(TN, 155, 2048, B)] * 4,
+        # round 6: the backward with every weight-gradient product pulled out of its phase into ONE launch at the end of backward
+        # (K = B for all of them: no contraction split, direct output), the phases keeping their data-gradient products
+        "deferred_dw": [(TN, 2000, 510, B)] + [(TN, 1020, 620, B)] * 2 + [(TN, 155, 2048, B)] * 8 + [(TN, 2048, 310, B)] * 2
+        + [(TN, 1020, 310, B)] * 3 + [(TN, 310, 2400, B)] * 4,
+        "deferred_dw_noglimpse": [(TN, 2000, 510, B)] + [(TN, 1020, 620, B)] * 2 + [(TN, 2048, 310, B)] * 2
+        + [(TN, 1020, 310, B)] * 3 + [(TN, 310, 2400, B)] * 4,
+        "classifier_dx": [(NN, B, 510, 2000)],
+        "vector_fusion_dx": [(NN, B, 620, 1020)] * 2,
+        "gates_h2_dx": [(NN, B, 310, 2048)] * 2 + [(NN, B, 310, 1020)] * 3,
+        "glimpse_dx": [(NN, B, 2048, 155)] * 4,
     }
 
 
@@ -92,6 +102,8 @@ def main():
             ph = head.Phase(dev, name)
             for (form, M, N, K), (a, b), o in zip(probs, ops_, outs):
                 t = ph.target(M, N)
+                if a.shape[1] % 2:            # a 155-wide operand: the 4-byte-aligned forms (head.GlimpseProjections)
+                    form = {NN: head.NN_A4, TN: head.TN_A4}[form]
                 ph.gemm(t, form, a, a.shape[1], b, b.shape[1], K)
                 ph.job(head.EPI_SUM, t, o, N)
             if not info:

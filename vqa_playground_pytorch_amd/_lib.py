@@ -84,6 +84,11 @@ SIGNATURES = {
                                                    _c_i, _c_st]),
     "vqa_linear_act_fwd_split_workspace_bytes": (_c_sz, [_c_i, _c_i]),
     "vqa_linear_act_fwd_split": (_c_i, [_c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_i, _c_i, _c_i, _c_i, _c_fl, _c_u64, _c_f, _c_st]),
+    "vqa_split_weights_bytes": (_c_sz, [_c_i, _c_i, _c_i]),
+    "vqa_split_weights_pack": (_c_i, [_c_f, _c_l, _c_i, _c_i, _c_f, _c_sz, _c_i, _c_i, _c_i, _c_st]),
+    "vqa_gemm_nt_split_batched_supported": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_i]),
+    "vqa_gemm_nt_split_batched": (_c_i, [_c_f, _c_l, _c_i, _c_f, _c_f, _c_l, _c_i, _c_f, _c_i, _c_f, _c_l, _c_i, _c_i, _c_i, _c_i,
+                                         _c_i, _c_i, _c_st]),
     "vqa_relation_linear_split_supported": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_fl]),
     "vqa_relation_linear_fwd_split": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_sz, _c_i, _c_i, _c_i, _c_i, _c_i, _c_fl,
                                              _c_u64, _c_f, _c_st]),

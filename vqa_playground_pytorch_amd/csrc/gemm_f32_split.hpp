@@ -512,7 +512,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg 
     extern __shared__ __attribute__((aligned(16))) char sp_smem[];
     // stage T and C2 of the samples this workgroup's BM rows belong to: [sample][T | C2][K], 16-byte pieces, coalesced
     const int s0 = (tm * S::BM) / p.rps;
-    const int ns = min(rel_samples(S::BM, p.rps), (p.M + p.rps - 1) / p.rps - s0);
+    const int ns = (min(p.M, (tm + 1) * S::BM) - 1) / p.rps - s0 + 1;     // (<= rel_samples(BM, rps): what the host sized the LDS for)
     const int k4 = p.K / 4;
     for (int idx = threadIdx.x; idx < ns * 2 * k4; idx += kThreads) {
       const int s = idx / (2 * k4), rem = idx - s * 2 * k4, which = rem / k4, k = rem - which * k4;

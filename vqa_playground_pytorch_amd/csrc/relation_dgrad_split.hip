@@ -29,6 +29,8 @@ struct RelSplitArgs {
   int B, M, L, D;
   int Kp;               // L rounded up to an even number of 32-deep chunks
   int tiles_n;          // workgroup tiles of 256 columns
+  int col_major = 0;    // tile order (VQA_SPLIT_DGRAD_ORDER=col): an XCD owns ONE column tile (an eighth of the W^T image stays in
+                        // its L2, gz streams through every XCD) instead of 16 row tiles x all column tiles
   const float* wf;      // W [L, D] itself: operand of the repair path (gemm_f32_split.hpp, any_nonfinite)
 };
 
@@ -65,8 +67,9 @@ __global__ __launch_bounds__(sp::kThreads, 1) void relation_dgrad_split_kernel(R
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tile = xcd_remap(blockIdx.x, gridDim.x);   // the column tiles of a row tile are neighbours: gz rows come from L2
-  const int m0 = (tile / p.tiles_n) * kBM;
-  const int n0 = (tile % p.tiles_n) * 256 + 64 * wave;
+  const int tiles_m_ = gridDim.x / p.tiles_n;
+  const int m0 = (p.col_major ? tile % tiles_m_ : tile / p.tiles_n) * kBM;
+  const int n0 = (p.col_major ? tile / tiles_m_ : tile % p.tiles_n) * 256 + 64 * wave;
   if (!SHARED && n0 >= p.D) return;          // (SHARED: D % 256 == 0 is required, every wave takes part in the barriers)
   const int M = p.M, D = p.D;
 
@@ -266,6 +269,7 @@ extern "C" int vqa_relation_projection_dgrad_split(const float* gz, const float*
   const int tiles_m = (a.M + kBM - 1) / kBM;
   const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
   // D % 256 == 0: gz's split shared by the workgroup's four waves through LDS (VQA_SPLIT_DGRAD_SHARED=0: every wave splits all of it)
+  a.col_major = vqa::option_is("VQA_SPLIT_DGRAD_ORDER", 'c') ? 1 : 0;
   const int tune = vqa::option("VQA_SPLIT_DGRAD_TUNE") ? std::atoi(vqa::option("VQA_SPLIT_DGRAD_TUNE")) : 0;
   const dim3 grid_((unsigned)(tiles_m * a.tiles_n));
   if (tune == 1 && D % 256 == 0) VQA_LAUNCH((relation_dgrad_split_kernel<true, 1>), grid_, dim3(sp::kThreads), kSharedLds, s, a, dc);

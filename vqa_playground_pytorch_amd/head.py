@@ -144,6 +144,8 @@ class Phase:
         return mode
 
     def _engine(self):
+        if getattr(self, "force_engine", None):     # (ops._grouped_products: the caller knows the engine)
+            return self.force_engine
         rows = [p["K"] if p["form"] in (TN, TN_A4) else t.M for t in self.targets for p in t.problems]
         return self.engine(self.name, min(rows) if rows else None)
 

@@ -1282,10 +1282,27 @@ class BatchedLinearFn(torch.autograd.Function):
     def forward(ctx, x, w, b, group_first, act):
         # x [B,G,K] (any batch / group strides, K contiguous), w [G,A,K], b [G,A] (rows at any stride) or None
         #   -> [B,G,A] contiguous, or [G,B,A] contiguous when group_first
-        with timed("library_gemm", (x.shape[1] * x.shape[0], w.shape[1], w.shape[2])):
-            y = torch.bmm(x.transpose(0, 1), w.transpose(1, 2))      # [G,B,A]
-        G, B, A = y.shape
+        B, G, K = x.shape
+        A = w.shape[1]
         code = _ACT_CODES[act]
+        # tall operands (the question encoder's input projections: 13 312 rows) on the split engine's batched NT kernel
+        # (csrc/gru_gemm.hip), bias in its store; the [B,.]-sized uses (glimpse projections) stay on the batched library GEMM
+        ctx.split = bool(B >= 1152 and x.is_cuda and f32_products() == "split" and x.stride(2) == 1 and x.stride(0) % 4 == 0
+                         and x.stride(1) % 4 == 0 and w.is_contiguous() and K % 2 == 0 and A % 4 == 0
+                         and gemm_nt_split_batched_ok(B, A, K, x.stride(0), x, w))
+        if ctx.split:
+            img = split_weights(w)
+            direct = code == 0 and group_first and (b is None or b.stride(-1) == 1)
+            y = torch.empty(G, B, A, device=x.device, dtype=torch.float32)
+            gemm_nt_split_batched(x, 0, x.stride(1), x.stride(0), img, y, b if direct else None, w, False, G, B, A, K)
+            if direct:
+                ctx.bias = b
+                ctx.save_for_backward(x, w, y)
+                ctx.cfg = (True, code, b is not None)
+                return y
+        else:
+            with timed("library_gemm", (x.shape[1] * x.shape[0], w.shape[1], w.shape[2])):
+                y = torch.bmm(x.transpose(0, 1), w.transpose(1, 2))      # [G,B,A]
         out = torch.empty((G, B, A) if group_first else (B, G, A), device=y.device, dtype=torch.float32)
         ctx.bias = b
         if b is not None and b.stride(-1) != 1:
@@ -1302,14 +1319,34 @@ class BatchedLinearFn(torch.autograd.Function):
         group_first, code, has_bias = ctx.cfg
         gy = _prep("grad_out", gy)
         G, B, A = out.shape if group_first else (out.shape[1], out.shape[0], out.shape[2])
-        gz = torch.empty(G, B, A, device=gy.device, dtype=torch.float32)
         d_b = None
         if has_bias and ctx.needs_input_grad[2]:
             d_b = _grad_like(ctx.bias, rows_strided=True) if tuple(ctx.bias.shape) == (G, A) else \
                 torch.empty(G, A, device=gy.device, dtype=torch.float32)
-        _launch("act_bwd_colsum", (G, B, A, code), _lib.lib().vqa_act_bwd_colsum, _p(gy), _p(out), _p(gz), _p(d_b),
-                d_b.stride(0) if d_b is not None else A, G, B, A, code, int(group_first))
+        if code == 0 and group_first and B >= 4096:
+            # no activation, the gradient already lies [G,B,A]: it IS gz (no copy of a tall tensor -- 383 MB for the question
+            # encoder's input projections); the bias gradients are G column sums
+            gz = gy
+            if d_b is not None:
+                for g in range(G):
+                    column_sum(gy[g], out=d_b[g])
+        else:
+            gz = torch.empty(G, B, A, device=gy.device, dtype=torch.float32)
+            _launch("act_bwd_colsum", (G, B, A, code), _lib.lib().vqa_act_bwd_colsum, _p(gy), _p(out), _p(gz), _p(d_b),
+                    d_b.stride(0) if d_b is not None else A, G, B, A, code, int(group_first))
         d_x = None
+        K = w.shape[2]
+        if ctx.split:
+            from . import head
+            if ctx.needs_input_grad[0]:      # d_x[b,g,:] = gz[g,b,:] W_g: the batched NT kernel against the transposed image
+                d_x = torch.empty(B, G, K, device=gy.device, dtype=torch.float32)
+                gemm_nt_split_batched(gz, 0, B * A, A, split_weights(w, transposed=True), d_x, None, w, True, G, B, K, A, c_gs=K, ldc=G * K)
+            d_w = None
+            if ctx.needs_input_grad[1]:      # d_w[g] = gz[g]^T x[:, g, :] over the B rows: one grouped launch (TN form)
+                d_w = _grad_like(w)
+                _grouped_products("batched_linear_dw", [(head.TN, gz, g * B * A, A, x, g * x.stride(1), x.stride(0), A, K, B, d_w[g])
+                                                        for g in range(G)], engine="split")
+            return d_x, d_w, d_b, None, None
         if ctx.needs_input_grad[0]:
             # written in the consumer's [B,G,K] layout (row stride G*K, batch stride K: a layout the strided-batched GEMM
             # takes as it is), so the kernels behind it get a contiguous gradient without a copy
@@ -1515,12 +1552,62 @@ def linear(x, w, b=None, act=None):
     return torch.relu(y) if act == "relu" else y
 
 
+def split_weights(w, transposed=False):
+    """The packed three-plane bf16 image of G weight matrices for vqa_gemm_nt_split_batched (csrc/gru_gemm.hip): w [G,N,K], or
+    [G,K,N] read transposed (the image then multiplies by W instead of W^T: a data gradient).  Split once, reused by every launch
+    that multiplies against these weights (all 26 time steps of the question encoder)."""
+    w = _prep("w", w)
+    G, d1, d2 = w.shape
+    N, K = (d2, d1) if transposed else (d1, d2)
+    L_ = _lib.lib()
+    nbytes = L_.vqa_split_weights_bytes(G, N, K)
+    img = torch.empty((nbytes + 3) // 4, device=w.device, dtype=torch.float32)
+    _launch("split_weights_pack", (G, N, K, bool(transposed)), L_.vqa_split_weights_pack, _p(w), w.stride(0), w.stride(1), int(transposed),
+            _p(img), nbytes, G, N, K)
+    return img
+
+
+def gemm_nt_split_batched(a, a_off, a_gs, lda, img, c, bias, w, transposed, G, M, N, K, c_gs=None, ldc=None):
+    """c[g] [M,N] = a_g [M,K] W_g^T (+ bias[g]) on the split engine, G problems in one launch.  a: a tensor holding the operands,
+    a_g starting `a_off + g * a_gs` elements in, rows of stride lda; img = split_weights(w, transposed); c [G,M,N] contiguous, or
+    any layout with problem stride c_gs and row stride ldc (elements)."""
+    L_ = _lib.lib()
+    ptr = ctypes.c_void_p(a.data_ptr() + 4 * int(a_off))
+    w_sn, w_sk = (1, w.stride(1)) if transposed else (w.stride(1), 1)
+    _launch("gemm_nt_split_batched", (G, M, N, K), L_.vqa_gemm_nt_split_batched, ptr, int(a_gs), int(lda), _p(img), _p(c),
+            M * N if c_gs is None else int(c_gs), N if ldc is None else int(ldc),
+            _p(bias), bias.stride(0) if bias is not None else 0, _p(w), w.stride(0), int(w_sn), int(w_sk), G, M, N, K)
+    return c
+
+
+def gemm_nt_split_batched_ok(M, N, K, lda, *tensors):
+    return (_lib.lib().vqa_gemm_nt_split_batched_supported(M, N, K, lda, N) == 1
+            and all(t is None or (t.dtype == torch.float32 and t.data_ptr() % 16 == 0) for t in tensors))
+
+
+def _grouped_products(name, problems, engine=None):
+    """A list of (form, A, a_off, lda, Bm, b_off, ldb, M, N, K, out) products as ONE grouped launch of the K6 engine (head.Phase:
+    csrc/grouped_gemm{,_split}.hip) -- the repo's generic hand-written GEMM, for shapes the register-tile engines do not take."""
+    from . import head
+    ph = head.Phase(problems[0][1].device, name)
+    ph.force_engine = engine
+    for form, A, a_off, lda, Bm, b_off, ldb, M, N, K, out in problems:
+        t = ph.target(M, N)
+        ph.gemm(t, form, A, lda, Bm, ldb, K, a_off=a_off, b_off=b_off)
+        ph.job(head.EPI_SUM, t, out, N)
+    ph.run()
+
+
 class GruSequence(torch.autograd.Function):
     """The recurrent part of putils.BayesianGRU.forward (putils/__init__.py:704-731): T steps of
     r,i = sigmoid(gi_{r,i}[t] + W_h{r,i}(h*m)), n = af(gi_n[t] + r * W_hn(h*m_n)), h = (1-i) n + i h.
     gi [3,B,T,H] (the input-side projections of all steps), w [3,H,H] (W_hr, W_hi, W_hn stacked), masks [3,B,H] or
-    None (sequence-shared dropout) -> all hidden states [T,B,H].  Per step: ONE batched library GEMM + ONE gate kernel
-    (csrc/gru.hip) each way; the recurrent weight gradient is one batched GEMM over all T*B rows at the end."""
+    None (sequence-shared dropout) -> all hidden states [T,B,H].
+    Round 6: every product is the repo's own kernel (rounds 1-5: torch.bmm).  Per step ONE launch of the split engine's batched
+    NT GEMM (csrc/gru_gemm.hip: the three gates' [B,H] x [H,H]^T against weight images split once per pass -- W for the forward,
+    W^T for the data gradients) + ONE gate kernel (csrc/gru.hip) each way; the recurrent weight gradient is one grouped launch on
+    the split engine over all T*B rows at the end (csrc/grouped_gemm_split.hip, TN form).  Shapes the batched kernel does not take
+    (B < 64, H % 4) run the same products as grouped launches of the K6 engine."""
 
     @staticmethod
     def forward(ctx, gi, w, masks, af):
@@ -1536,21 +1623,30 @@ class GruSequence(torch.autograd.Function):
         hist = torch.zeros(3, T, B, H, device=dev, dtype=torch.float32)        # hm_t = h_{t-1} * m_g; hm_0 = 0
         saved = torch.empty(4, T, B, H, device=dev, dtype=torch.float32)       # r, i, n, a_n
         h0 = torch.zeros(B, H, device=dev, dtype=torch.float32)
-        wt = w.transpose(1, 2)
+        a = torch.empty(3, B, H, device=dev, dtype=torch.float32)
         gs = T * B * H
+        fast = gemm_nt_split_batched_ok(B, H, H, H, hist, w)
+        img = split_weights(w) if fast else None
         for t in range(T):
-            a = torch.bmm(hist[:, t], wt)                                       # [3,B,H]
+            if t == 0:
+                a.zero_()                                                        # hm_0 = 0: no product to form
+            elif fast:
+                gemm_nt_split_batched(hist, t * B * H, gs, H, img, a, None, w, False, 3, B, H, H)          # a[g] = hm_t[g] W_g^T
+            else:
+                from . import head
+                _grouped_products("gru_step_fwd", [(head.NT, hist, g * gs + t * B * H, H, w, g * H * H, H, B, H, H, a[g]) for g in range(3)])
             nxt = ctypes.c_void_p(hist.data_ptr() + 4 * (t + 1) * B * H) if t + 1 < T else None
             _launch("gru_gates_fwd", (B, T, H), L_.vqa_gru_gates_fwd, _p(gi), _p(a), _p(out[t - 1] if t else h0), _p(masks),
                     _p(out[t]), nxt, gs, _p(saved[0, t]), _p(saved[1, t]), _p(saved[2, t]), _p(saved[3, t]), B, T, H, t, code)
         ctx.save_for_backward(w, masks, out, hist, saved, h0)
-        ctx.cfg = (B, T, H, code)
+        ctx.cfg = (B, T, H, code, fast)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
+        from . import head
         w, masks, out, hist, saved, h0 = ctx.saved_tensors
-        B, T, H, code = ctx.cfg
+        B, T, H, code, fast = ctx.cfg
         d_out = _prep("grad_out", d_out)
         dev = d_out.device
         L_ = _lib.lib()
@@ -1558,15 +1654,26 @@ class GruSequence(torch.autograd.Function):
         d_gi = torch.empty(3, B, T, H, device=dev, dtype=torch.float32)
         carry = [torch.empty(B, H, device=dev, dtype=torch.float32) for _ in range(2)]
         gs = T * B * H
+        buf = torch.empty(3, B, H, device=dev, dtype=torch.float32)
+        img_t = split_weights(w, transposed=True) if fast else None
         dhm = None
         for t in range(T - 1, -1, -1):
             _launch("gru_gates_bwd", (B, T, H), L_.vqa_gru_gates_bwd, _p(d_out[t]), _p(carry[(t + 1) & 1]) if t + 1 < T else None,
                     _p(dhm), _p(masks), _p(saved[0, t]), _p(saved[1, t]), _p(saved[2, t]), _p(saved[3, t]),
                     _p(out[t - 1] if t else h0), ctypes.c_void_p(gz.data_ptr() + 4 * t * B * H), gs, _p(d_gi), _p(carry[t & 1]),
                     B, T, H, t, code)
-            if t > 0:
-                dhm = torch.bmm(gz[:, t], w)                                    # gradient at hm_t: [3,B,H]
-        d_w = torch.bmm(gz.view(3, T * B, H).transpose(1, 2), hist.view(3, T * B, H)) if ctx.needs_input_grad[1] else None
+            if t > 0:                                                           # gradient at hm_t: dhm[g] = gz_t[g] W_g   [3,B,H]
+                if fast:
+                    dhm = gemm_nt_split_batched(gz, t * B * H, gs, H, img_t, buf, None, w, True, 3, B, H, H)
+                else:
+                    _grouped_products("gru_step_bwd", [(head.NN, gz, g * gs + t * B * H, H, w, g * H * H, H, B, H, H, buf[g]) for g in range(3)])
+                    dhm = buf
+        d_w = None
+        if ctx.needs_input_grad[1]:
+            # d_w[g] = gz[g]^T hm[g] over all T*B rows: one grouped launch, contraction split into slabs and summed in fixed order
+            d_w = _grad_like(w)
+            _grouped_products("gru_dw", [(head.TN, gz, g * gs, H, hist, g * gs, H, H, H, T * B, d_w[g]) for g in range(3)],
+                              engine="split" if (f32_products() == "split" and T * B >= 384) else None)
         return d_gi, d_w, None, None
 
 
