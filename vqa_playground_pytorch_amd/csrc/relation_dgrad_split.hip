@@ -29,6 +29,7 @@ struct RelSplitArgs {
   int B, M, L, D;
   int Kp;               // L rounded up to an even number of 32-deep chunks
   int tiles_n;          // workgroup tiles of 256 columns
+  int v_nt = 0;         // v loads with the nt (streaming) cache policy
   int col_major = 0;    // tile order (VQA_SPLIT_DGRAD_ORDER=col): an XCD owns ONE column tile (an eighth of the W^T image stays in
                         // its L2, gz streams through every XCD) instead of 16 row tiles x all column tiles
   const float* wf;      // W [L, D] itself: operand of the repair path (gemm_f32_split.hpp, any_nonfinite)
@@ -138,7 +139,11 @@ __global__ __launch_bounds__(sp::kThreads, 1) void relation_dgrad_split_kernel(R
   auto vt = [&](int i, int t) -> f32x4 {
     if constexpr ((TUNE & 2) != 0) return f32x4{1.f, 1.f, 1.f, 1.f};
     const int row = min(m0 + 16 * i + 4 * g + t, M - 1);
-    return rt::ldg16(Vb, (uint32_t)(n0 + 4 * r) * 4u + (uint32_t)row * (uint32_t)D * 4u, 0u);
+    const uint32_t off = (uint32_t)(n0 + 4 * r) * 4u + (uint32_t)row * (uint32_t)D * 4u;
+    // v is read exactly once, at the end of a workgroup's life: with the streaming policy its 4.7 MB per round of workgroups do not
+    // push the W^T image (3.9 MB, wanted by every workgroup) out of the XCD's 4 MB L2 (VQA_SPLIT_DGRAD_VNT, round 6)
+    if (p.v_nt) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(Vb, (int)off, 0, 2));
+    return rt::ldg16(Vb, off, 0u);
   };
   const uint32_t key = dc.p8 > 0 ? drop_key(dc) : 0u;
   if (m0 + kBM > M) {                        // last, partial tile: the rows beyond M (clamped duplicates) count as zero
@@ -270,6 +275,7 @@ extern "C" int vqa_relation_projection_dgrad_split(const float* gz, const float*
   const DropCfg dc = make_drop(p_drop, seed, seed_ptr);
   // D % 256 == 0: gz's split shared by the workgroup's four waves through LDS (VQA_SPLIT_DGRAD_SHARED=0: every wave splits all of it)
   a.col_major = vqa::option_is("VQA_SPLIT_DGRAD_ORDER", 'c') ? 1 : 0;
+  a.v_nt = vqa::option_is("VQA_SPLIT_DGRAD_VNT", '1') ? 1 : 0;
   const int tune = vqa::option("VQA_SPLIT_DGRAD_TUNE") ? std::atoi(vqa::option("VQA_SPLIT_DGRAD_TUNE")) : 0;
   const dim3 grid_((unsigned)(tiles_m * a.tiles_n));
   if (tune == 1 && D % 256 == 0) VQA_LAUNCH((relation_dgrad_split_kernel<true, 1>), grid_, dim3(sp::kThreads), kSharedLds, s, a, dc);
