@@ -59,7 +59,9 @@ struct BatchNtArgs {
   const float* bias;    // [G][N] rows of stride bias_gs, or null
   int bias_gs;
   int M, N, Kp, Kr;
-  int tiles_n;
+  int tiles_n, tiles_m;
+  int col_major;        // tile order inside a problem: 1 = the row tiles of one column tile are neighbours (short M: they share the
+                        // column tile's slice of the weight image in their XCD's L2; the activations are small), 0 = row-major
   const float* Bf;      // the fp32 weights (repair path): B_g[n][k] = Bf[g * bf_gs + n * bf_sn + k * bf_sk]
   long bf_gs;
   int bf_sn, bf_sk;
@@ -72,12 +74,15 @@ __global__ __launch_bounds__(sp::kThreads, 1) void gemm_nt_batched_kernel(BatchN
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wk = wave / 2, wn = wave % 2;
-  const int prob = blockIdx.y;
+  // one linear workgroup id over all problems (the hardware deals ids round-robin to the 8 XCDs; xcd_remap hands every XCD a
+  // contiguous range of tiles)
+  const int tiles = q.tiles_m * q.tiles_n;
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int prob = lin / tiles, tile = lin - prob * tiles;
   const float* A = q.A + (size_t)prob * q.a_gs;
   float* C = q.C + (size_t)prob * q.c_gs;
   const sp::NtArgs p{A, q.Bp + (size_t)prob * q.bp_gs, q.lda, q.M, q.N, q.Kp, q.tiles_n};
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int tm = tile / q.tiles_n, tn = tile % q.tiles_n;
+  const int tm = q.col_major ? tile % q.tiles_m : tile / q.tiles_n, tn = q.col_major ? tile / q.tiles_m : tile % q.tiles_n;
   const int m0 = tm * S::BM, n0 = tn * S::BN + wn * (16 * CB);
   const int chunks = q.Kp / sp::kChunk;
 
@@ -142,11 +147,12 @@ static size_t image_bytes(int N, int K) { return ((sp::packed_bytes(N, padded_k(
 template <int RB, int NR>
 static int launch_batched(const BatchNtArgs& a, int G, hipStream_t s) {
   using S = rt::NtShape<RB, 5, 1, 2, 2>;
-  const int tiles_m = (a.M + S::BM - 1) / S::BM;
   BatchNtArgs q = a;
+  q.tiles_m = (a.M + S::BM - 1) / S::BM;
   q.tiles_n = (a.N + S::BN - 1) / S::BN;
+  q.col_major = vqa::option("VQA_GRU_GEMM_ORDER") ? (vqa::option_is("VQA_GRU_GEMM_ORDER", 'c') ? 1 : 0) : (q.tiles_m <= 8 ? 1 : 0);
   VQA_ENSURE_LDS((gemm_nt_batched_kernel<RB, 5, NR>), S::kLdsBytes);
-  VQA_LAUNCH((gemm_nt_batched_kernel<RB, 5, NR>), dim3(tiles_m * q.tiles_n, G), dim3(sp::kThreads), S::kLdsBytes, s, q);
+  VQA_LAUNCH((gemm_nt_batched_kernel<RB, 5, NR>), dim3(q.tiles_m * q.tiles_n * G), dim3(sp::kThreads), S::kLdsBytes, s, q);
   return check_launch("gemm_nt_split_batched");
 }
 
@@ -182,13 +188,13 @@ extern "C" int vqa_gemm_nt_split_batched(const float* a, long a_gs, int lda, con
                                          const float* bias, int bias_gs, const float* w, long w_gs, int w_sn, int w_sk, int G, int M,
                                          int N, int K, vqa_stream_t stream) {
   VQA_REQUIRE(a && image && c, VQA_E_BADARG, "gemm_nt_split_batched: null pointer");
-  VQA_REQUIRE(G >= 1 && G <= 65535, VQA_E_BADARG, "gemm_nt_split_batched: G out of range");
+  VQA_REQUIRE(G >= 1 && G <= 4096, VQA_E_BADARG, "gemm_nt_split_batched: G out of range");
   VQA_REQUIRE(vqa_gemm_nt_split_batched_supported(M, N, K, lda, ldc) == 1, VQA_E_UNSUPPORTED,
               "gemm_nt_split_batched: shape outside the engine (M=%d N=%d K=%d lda=%d ldc=%d): M >= 64, lda %% 4 == 0", M, N, K, lda, ldc);
   VQA_REQUIRE(aligned(a, 16) && a_gs % 4 == 0 && aligned(image, 16), VQA_E_UNSUPPORTED,
               "gemm_nt_split_batched: a (and its batch stride) and the image must be 16-byte aligned");
   BatchNtArgs q{a, a_gs, lda, static_cast<const sp::u32x4*>(image), image_bytes(N, K) / 16, c, c_gs, ldc, bias, bias_gs, M, N, padded_k(K), K,
-                0, w, w_gs, w_sn, w_sk};
+                0, 0, 0, w, w_gs, w_sn, w_sk};
   hipStream_t s = static_cast<hipStream_t>(stream);
   // row blocks per workgroup: what leaves the fewest idle CUs in the last wave of workgroups (ties: the taller tile)
   int rb = 9;
