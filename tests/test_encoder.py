@@ -190,7 +190,7 @@ def test_gpu_gru_products_run_on_the_split_engine_at_training_size(rb, lib_optio
     monkeypatch.setattr(torch, "bmm", bmm)
     assert "torch.bmm" not in seen, "the encoder issued a library GEMM"
     assert seen.count("gemm_nt_split_batched") == 2 * (T - 1) + 2, seen      # T - 1 steps each way (hm_0 = 0), input projections fwd + dx
-    assert seen.count("split_weights_pack") == 4 and seen.count("grouped_gemm_split") >= 2, seen
+    assert seen.count("split_weights_pack") == 4 and seen.count("gemm_tn_split") == 6, seen     # 3 recurrent + 3 input weight gradients
     yc = cpu(xc, lengths)
     yc.backward(gy.double())
 

@@ -484,3 +484,25 @@ def test_relation_linear_fused_edge_values(ops, monkeypatch, kind):
         assert torch.equal(_classes(g1[k]), _classes(g0[k])), k
         fin = torch.isfinite(g0[k])
         assert (g1[k][fin] - g0[k][fin]).abs().max().item() <= 1e-4 * g0[k][fin].abs().max().item(), k
+
+
+@pytest.mark.parametrize("M,N1,N2,pad", [(13312, 2400, 620, 0), (1152, 310, 128, 0), (4001, 482, 260, 4), (2304, 2400, 2400, 0), (1200, 16, 64, 8)])
+def test_gemm_tn_split_against_float64(ops, M, N1, N2, pad):
+    """vqa_gemm_tn_split (the question encoder's weight gradients: g^T x over all T*B rows; csrc/gru_gemm.hip) against float64:
+    wide gradients packed in column groups (2400 = 5 groups of 30 blocks), row counts that are not a multiple of the 32-row
+    chunk, padded row strides, the smallest shapes."""
+    gen = torch.Generator(device="cpu").manual_seed(M + N1)
+    g = (torch.randn(M, N1 + pad, generator=gen) / 32).to(dev())
+    x = torch.randn(M, N2 + pad, generator=gen).to(dev())
+    d_w = torch.empty(N1, N2, device=dev())
+    assert ops.gemm_tn_split(g, 0, N1 + pad, x, 0, N2 + pad, d_w, M, N1, N2)
+    ref = g[:, :N1].double().t() @ x[:, :N2].double()
+    mx, rm = err(d_w, ref)
+    assert mx <= 2e-5 and rm <= 2e-6, (mx, rm)
+    # non-finite operands: the repair path
+    g[5, 3], x[M - 1, N2 - 1] = float("inf"), float("nan")
+    assert ops.gemm_tn_split(g, 0, N1 + pad, x, 0, N2 + pad, d_w, M, N1, N2)
+    ref = g[:, :N1].t() @ x[:, :N2]
+    assert torch.equal(_classes(d_w), _classes(ref))
+    # outside the engine: the wrapper says so instead of launching
+    assert not ops.gemm_tn_split(g, 0, N1 + pad, x, 0, N2 + pad, d_w, 1000, N1, N2)

@@ -210,9 +210,9 @@ static void launch_sp_tn(const float* G, const float* Yg, const float* X, void* 
   if (!gemm_only) {
     const size_t lds = sp::pack_tn_lds_bytes(nblocks);
     if (Yg)
-      hipLaunchKernelGGL((sp::pack_tn_kernel<true, false>), dim3(pl.slabs * sp::kPackParts), dim3(256), lds, 0, G, Yg, N1, M, N1, nblocks, pl.cps, gp, dbslab, (float*)nullptr);
+      hipLaunchKernelGGL((sp::pack_tn_kernel<true, false>), dim3(pl.slabs * sp::kPackParts), dim3(256), lds, 0, G, Yg, N1, M, N1, nblocks, pl.cps, gp, dbslab, (float*)nullptr, nblocks);
     else
-      hipLaunchKernelGGL((sp::pack_tn_kernel<false, false>), dim3(pl.slabs * sp::kPackParts), dim3(256), lds, 0, G, Yg, N1, M, N1, nblocks, pl.cps, gp, dbslab, (float*)nullptr);
+      hipLaunchKernelGGL((sp::pack_tn_kernel<false, false>), dim3(pl.slabs * sp::kPackParts), dim3(256), lds, 0, G, Yg, N1, M, N1, nblocks, pl.cps, gp, dbslab, (float*)nullptr, nblocks);
   }
   if (pack_only) return;
   const int tiles1 = (nblocks + 19) / 20, tiles2 = (N2 + 127) / 128;

@@ -688,16 +688,24 @@ __host__ __device__ inline size_t packed_tn_bytes(int slabs, int cps, int N1) {
 // 8-byte aligned at least), are gated, and cross an LDS tile of 32 rows x (N1 padded) floats to reach the lanes that pack
 // them: lane (r, g) of wave w packs column 16 blk + r, rows 8 g .. 8 g + 7, for the blocks blk = w, w + 4, ...
 constexpr int kPackParts = 18;   // 16 slabs x 18 = 288 workgroups of two chunks at M = 18432
+// Wide G (N1 > 16 kPackMaxBlocks columns: the question encoder's 2400-wide gradients) is packed in column groups of `nblocks`
+// blocks: blockIdx.y = group, its first block blk0 = blockIdx.y * nblocks of the image's nblk_total (gridDim.y == 1, nblk_total ==
+// nblocks: the whole matrix at once, as K5 calls it).
 template <bool GATE, bool WRITE_GZ>
 __global__ __launch_bounds__(256) void pack_tn_kernel(const float* __restrict__ gy, const float* __restrict__ y, int ld, int M,
-                                                      int N1, int nblocks, int cps, u32x4* __restrict__ out,
-                                                      float* __restrict__ dbslab, float* __restrict__ gz) {
+                                                      int N1_all, int nblocks, int cps, u32x4* __restrict__ out,
+                                                      float* __restrict__ dbslab, float* __restrict__ gz, int nblk_total) {
   extern __shared__ __attribute__((aligned(16))) float pk_tile[];   // [32][pitch], pitch = 16 nblocks + 1 (odd: the 4 lane groups'
   const int pitch = 16 * nblocks + 1;                               //  rows 8 g land on different banks)
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
   const int slab = blockIdx.x / kPackParts, part = blockIdx.x % kPackParts;
   const int per = (cps + kPackParts - 1) / kPackParts;
   const int lo = part * per, hi = min(cps, lo + per);
+  const int blk0 = blockIdx.y * nblocks, c0 = 16 * blk0;      // this group's first block / column
+  const int N1 = min(N1_all - c0, 16 * nblocks);              // the group's width
+  gy += c0;
+  if (GATE) y += c0;
+  if (WRITE_GZ) gz += c0;
   const int pairs = N1 / 2;                   // (N1 is even: rows are float2-aligned)
   float colsum[8];                            // per block this wave owns (blk = wave + 4 k), column r, rows of lane group g
 #pragma unroll
@@ -729,7 +737,7 @@ __global__ __launch_bounds__(256) void pack_tn_kernel(const float* __restrict__ 
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int blk = wave + 4 * k;
-      if (blk < nblocks) {
+      if (blk < nblocks && blk0 + blk < nblk_total) {
         const int col = 16 * blk + r;
         float v[8];
 #pragma unroll
@@ -740,7 +748,7 @@ __global__ __launch_bounds__(256) void pack_tn_kernel(const float* __restrict__ 
           split_pair<false>(f32x2{v[2 * jj], v[2 * jj + 1]}, w[0][jj], w[1][jj], w[2][jj]);
           colsum[k] += v[2 * jj] + v[2 * jj + 1];
         }
-        u32x4* dst = out + ((size_t)c * nblocks + blk) * 192 + lane;
+        u32x4* dst = out + ((size_t)c * nblk_total + blk0 + blk) * 192 + lane;
 #pragma unroll
         for (int q = 0; q < 3; ++q) dst[64 * q] = u32x4{w[q][0], w[q][1], w[q][2], w[q][3]};
       }
@@ -754,7 +762,7 @@ __global__ __launch_bounds__(256) void pack_tn_kernel(const float* __restrict__ 
       sum += __shfl_xor(sum, 16);
       sum += __shfl_xor(sum, 32);
       const int col = 16 * (wave + 4 * k) + r;
-      if (g == 0 && wave + 4 * k < nblocks && col < N1) dbslab[(size_t)blockIdx.x * N1 + col] = sum;
+      if (g == 0 && wave + 4 * k < nblocks && col < N1) dbslab[(size_t)blockIdx.x * N1_all + c0 + col] = sum;
     }
   }
 }

@@ -141,6 +141,35 @@ __global__ __launch_bounds__(sp::kThreads, 1) void gemm_nt_batched_kernel(BatchN
   }
 }
 
+// ---- TN form: d_w[n1][n2] = sum_m g[m][n1] * x[m][n2] over tall operands (the encoder's weight gradients: M = T * B rows) ----------
+// gemm_f32_split.hpp's weight-gradient pair: g is split and packed once (pack_tn_kernel, in column groups of <= 30 blocks), x is
+// split inside the GEMM and shared by the workgroup's four waves (gemm_tn_shared_kernel), row slabs are summed in fixed order.
+struct TnSplitPlan {
+  int slabs, cps, nblocks, grp, groups, tiles1, tiles2;
+};
+static TnSplitPlan tn_split_plan(int M, int N1, int N2) {
+  TnSplitPlan pl{};
+  pl.nblocks = (N1 + 15) / 16;
+  pl.grp = pl.nblocks < sp::kPackMaxBlocks ? pl.nblocks : sp::kPackMaxBlocks;
+  pl.groups = (pl.nblocks + pl.grp - 1) / pl.grp;
+  pl.tiles1 = (pl.nblocks + 19) / 20;
+  pl.tiles2 = (N2 + 127) / 128;
+  // row slabs: the count whose workgroups fill whole rounds of the 256 CUs best (at least 8 chunks of 32 rows each)
+  const int chunks = (M + sp::kChunk - 1) / sp::kChunk, tiles = pl.tiles1 * pl.tiles2;
+  int want = 1;
+  double best = -1.0;
+  for (int s = 1; s <= 64 && s * 8 <= chunks; ++s) {        // the fewest slabs within 3 % of the best fill (fewer slabs: less to sum)
+    const long wgs = (long)tiles * s;
+    const double eff = (double)wgs / (double)(((wgs + 255) / 256) * 256);
+    if (eff > best + 0.03) best = eff, want = s;
+  }
+  const sp::TnPlan tp = sp::tn_plan(M, want);
+  pl.slabs = tp.slabs;
+  pl.cps = tp.cps;
+  return pl;
+}
+static size_t r256(size_t b) { return (b + 255) & ~(size_t)255; }
+
 static int padded_k(int K) { return (K + 63) / 64 * 64; }
 static size_t image_bytes(int N, int K) { return ((sp::packed_bytes(N, padded_k(K)) + 255) & ~(size_t)255); }
 
@@ -210,4 +239,38 @@ extern "C" int vqa_gemm_nt_split_batched(const float* a, long a_gs, int lda, con
   if (rb == 7) return launch_batched<7, 7>(q, G, s);
   if (rb == 8) return launch_batched<8, 4>(q, G, s);
   return launch_batched<9, 3>(q, G, s);
+}
+
+extern "C" int vqa_gemm_tn_split_supported(int M, int N1, int N2, int ldg, int ldx) {
+  return (M >= 1152 && N1 >= 16 && N1 % 2 == 0 && N2 >= 64 && N2 % 4 == 0 && ldg % 2 == 0 && ldg >= N1 && ldx % 4 == 0 && ldx >= N2 &&
+          (size_t)M * ldx * 4 < (1ull << 32) && (size_t)M * ldg * 4 < (1ull << 32)) ? 1 : 0;
+}
+
+extern "C" size_t vqa_gemm_tn_split_workspace_bytes(int M, int N1, int N2) {
+  const TnSplitPlan pl = tn_split_plan(M, N1, N2);
+  return r256(sp::packed_tn_bytes(pl.slabs, pl.cps, N1)) + r256((size_t)pl.slabs * N1 * N2 * 4);
+}
+
+extern "C" int vqa_gemm_tn_split(const float* g, int ldg, const float* x, int ldx, float* d_w, void* workspace, size_t workspace_bytes,
+                                 int M, int N1, int N2, vqa_stream_t stream) {
+  VQA_REQUIRE(g && x && d_w && workspace, VQA_E_BADARG, "gemm_tn_split: null pointer");
+  VQA_REQUIRE(vqa_gemm_tn_split_supported(M, N1, N2, ldg, ldx) == 1, VQA_E_UNSUPPORTED,
+              "gemm_tn_split: shape outside the engine (M=%d N1=%d N2=%d ldg=%d ldx=%d)", M, N1, N2, ldg, ldx);
+  VQA_REQUIRE(aligned(g, 8) && aligned(x, 16) && aligned(d_w, 16) && aligned(workspace, 16), VQA_E_UNSUPPORTED,
+              "gemm_tn_split: x, d_w, workspace must be 16-byte aligned, g 8-byte");
+  VQA_REQUIRE(workspace_bytes >= vqa_gemm_tn_split_workspace_bytes(M, N1, N2), VQA_E_BADARG, "gemm_tn_split: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const TnSplitPlan pl = tn_split_plan(M, N1, N2);
+  char* base = static_cast<char*>(workspace);
+  sp::u32x4* gp = reinterpret_cast<sp::u32x4*>(base);
+  float* slab = reinterpret_cast<float*>(base + r256(sp::packed_tn_bytes(pl.slabs, pl.cps, N1)));
+  VQA_LAUNCH((sp::pack_tn_kernel<false, false>), dim3(pl.slabs * sp::kPackParts, pl.groups), dim3(256), sp::pack_tn_lds_bytes(pl.grp), s, g,
+             (const float*)nullptr, ldg, M, N1, pl.grp, pl.cps, gp, (float*)nullptr, (float*)nullptr, pl.nblocks);
+  const sp::TnArgs a{gp, x, slab, ldx, M, N1, N2, pl.nblocks, pl.cps, pl.tiles1, pl.tiles2, g, nullptr, ldg};
+  const DropCfg dc{};
+  VQA_LAUNCH((sp::gemm_tn_shared_kernel<5, false>), dim3(pl.tiles1 * pl.tiles2 * pl.slabs), dim3(sp::kThreads), sp::kTnSharedLds, s, a, dc);
+  const int NK = N1 * N2;
+  VQA_LAUNCH((sp::slab_sum_kernel), dim3(sp::slab_sum_blocks(NK, N1)), dim3(256), 0, s, slab, (const float*)nullptr, d_w, (float*)nullptr, NK,
+             N1, pl.slabs, 0, 1.f);
+  return check_launch("gemm_tn_split");
 }

@@ -161,11 +161,11 @@ static int linear_dw_split_impl(const float* x, int ldx, const float* y, const f
     const dim3 pgrid(pl.slabs * sp::kPackParts);
     const size_t lds = sp::pack_tn_lds_bytes(nblocks);
     if (act == 1 && gz_out != nullptr)
-      VQA_LAUNCH((sp::pack_tn_kernel<true, true>), pgrid, dim3(256), lds, s, gy, y, N, M, N, nblocks, pl.cps, gp, dbslab, gz_out);
+      VQA_LAUNCH((sp::pack_tn_kernel<true, true>), pgrid, dim3(256), lds, s, gy, y, N, M, N, nblocks, pl.cps, gp, dbslab, gz_out, nblocks);
     else if (act == 1)
-      VQA_LAUNCH((sp::pack_tn_kernel<true, false>), pgrid, dim3(256), lds, s, gy, y, N, M, N, nblocks, pl.cps, gp, dbslab, (float*)nullptr);
+      VQA_LAUNCH((sp::pack_tn_kernel<true, false>), pgrid, dim3(256), lds, s, gy, y, N, M, N, nblocks, pl.cps, gp, dbslab, (float*)nullptr, nblocks);
     else
-      VQA_LAUNCH((sp::pack_tn_kernel<false, false>), pgrid, dim3(256), lds, s, gy, y, N, M, N, nblocks, pl.cps, gp, dbslab, (float*)nullptr);
+      VQA_LAUNCH((sp::pack_tn_kernel<false, false>), pgrid, dim3(256), lds, s, gy, y, N, M, N, nblocks, pl.cps, gp, dbslab, (float*)nullptr, nblocks);
   }
   constexpr int NA = 5, SPN = 2;
   const int tiles1 = (nblocks + 4 * NA - 1) / (4 * NA), tiles2 = (K + 64 * SPN - 1) / (64 * SPN);

@@ -1344,8 +1344,10 @@ class BatchedLinearFn(torch.autograd.Function):
             d_w = None
             if ctx.needs_input_grad[1]:      # d_w[g] = gz[g]^T x[:, g, :] over the B rows: one grouped launch (TN form)
                 d_w = _grad_like(w)
-                _grouped_products("batched_linear_dw", [(head.TN, gz, g * B * A, A, x, g * x.stride(1), x.stride(0), A, K, B, d_w[g])
-                                                        for g in range(G)], engine="split")
+                rest = [g for g in range(G) if not gemm_tn_split(gz, g * B * A, A, x, g * x.stride(1), x.stride(0), d_w[g], B, A, K)]
+                if rest:
+                    _grouped_products("batched_linear_dw", [(head.TN, gz, g * B * A, A, x, g * x.stride(1), x.stride(0), A, K, B, d_w[g])
+                                                            for g in rest], engine="split")
             return d_x, d_w, d_b, None, None
         if ctx.needs_input_grad[0]:
             # written in the consumer's [B,G,K] layout (row stride G*K, batch stride K: a layout the strided-batched GEMM
@@ -1585,6 +1587,22 @@ def gemm_nt_split_batched_ok(M, N, K, lda, *tensors):
             and all(t is None or (t.dtype == torch.float32 and t.data_ptr() % 16 == 0) for t in tensors))
 
 
+def gemm_tn_split(g, g_off, ldg, x, x_off, ldx, d_w, M, N1, N2):
+    """d_w [N1,N2] = g^T x over M rows on the split engine's weight-gradient kernels (csrc/gru_gemm.hip: vqa_gemm_tn_split); g, x:
+    tensors holding the operands from element offsets g_off / x_off, rows of stride ldg / ldx.  False when the shape or the
+    alignment is outside of the engine (the caller then takes the grouped launch)."""
+    L_ = _lib.lib()
+    gp, xp = g.data_ptr() + 4 * int(g_off), x.data_ptr() + 4 * int(x_off)
+    if (L_.vqa_gemm_tn_split_supported(M, N1, N2, int(ldg), int(ldx)) != 1 or gp % 8 or xp % 16 or d_w.data_ptr() % 16
+            or not d_w.is_contiguous()):
+        return False
+    nbytes = L_.vqa_gemm_tn_split_workspace_bytes(M, N1, N2)
+    ws = torch.empty((nbytes + 3) // 4, device=d_w.device, dtype=torch.float32)
+    _launch("gemm_tn_split", (M, N1, N2), L_.vqa_gemm_tn_split, ctypes.c_void_p(gp), int(ldg), ctypes.c_void_p(xp), int(ldx), _p(d_w), _p(ws),
+            nbytes, M, N1, N2)
+    return True
+
+
 def _grouped_products(name, problems, engine=None):
     """A list of (form, A, a_off, lda, Bm, b_off, ldb, M, N, K, out) products as ONE grouped launch of the K6 engine (head.Phase:
     csrc/grouped_gemm{,_split}.hip) -- the repo's generic hand-written GEMM, for shapes the register-tile engines do not take."""
@@ -1672,8 +1690,10 @@ class GruSequence(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             # d_w[g] = gz[g]^T hm[g] over all T*B rows: one grouped launch, contraction split into slabs and summed in fixed order
             d_w = _grad_like(w)
-            _grouped_products("gru_dw", [(head.TN, gz, g * gs, H, hist, g * gs, H, H, H, T * B, d_w[g]) for g in range(3)],
-                              engine="split" if (f32_products() == "split" and T * B >= 384) else None)
+            rest = [g for g in range(3) if not (fast and gemm_tn_split(gz, g * gs, H, hist, g * gs, H, d_w[g], T * B, H, H))]
+            if rest:      # (short sequences / odd widths: the grouped launch, contraction split into slabs and summed in fixed order)
+                _grouped_products("gru_dw", [(head.TN, gz, g * gs, H, hist, g * gs, H, H, H, T * B, d_w[g]) for g in rest],
+                                  engine="split" if (f32_products() == "split" and T * B >= 384) else None)
         return d_gi, d_w, None, None
 
 
