@@ -75,6 +75,12 @@ def work_of(name, shape):
     if base in ("relation_projection_dgrad", "relation_projection_dgrad_split"):
         B, N, D, L = s[:4]
         return "mfma", 2 * B * N * D * L                                              # the data-gradient contraction
+    if base == "gemm_nt_split_batched":                                               # the question encoder's per-step / input products
+        G, M, N, K = s[:4]
+        return "mfma", 2 * G * M * N * K
+    if base == "gemm_tn_split":                                                        # ... and its weight gradients (one gate per call)
+        M, N1, N2 = s[:3]
+        return "mfma", 2 * M * N1 * N2
     if base in ("grouped_gemm", "grouped_gemm_split"):                                    # K6: every GEMM of a phase of the
         return "mfma", s[2]                                                               # [B,.] layers (head.py), FLOPs summed
     if base == "grouped_epilogue":
@@ -152,6 +158,7 @@ PMC_KERNELS = {  # C-ABI entry -> kernel-name prefixes of its dominant device ke
     "relation_projection_dgrad_split": ["vqa::relation_dgrad_split_kernel"],
     "relation_linear_fwd_split": ["vqa::sp::gemm_nt_kernel<9, 5, 1, 2, 2"],
     "relation_linear_dw_split": ["vqa::sp::gemm_tn_shared_kernel<5"],
+    "gemm_nt_split_batched": ["vqa::gemm_nt_batched_kernel"], "gemm_tn_split": ["vqa::sp::gemm_tn_shared_kernel<5"],
     "lowrank_bilinear_fusion_bwd": ["vqa::bilinear_dw_rt_kernel"],
     "relation_projection_dgrad": ["vqa::relation_dgrad_kernel"],
     "attention_logits_fwd": ["vqa::attention_logits_fwd_kernel"],
@@ -285,7 +292,7 @@ def roofline_entry(name, shape, launches, mean_ms, B, regions=REGIONS, bf16=Fals
         achieved, peak, unit = work / sec / 1e9, HBM_PEAK_GBS, "GB/s"
     elif name.endswith("_bf16") or name.startswith("gemm_bf16"):
         achieved, peak, unit = work / sec / 1e12, MFMA_BF16_PEAK_TF, "TFLOP/s"
-    elif name.endswith("_split"):
+    elif name.endswith("_split") or "_split_" in name:
         achieved, peak, unit = work / sec / 1e12, round(MFMA_SPLIT_PEAK_TF, 1), "TFLOP/s"
     else:  # "mfma" and "valu" share the fp32 peak on gfx950 (157.3 TFLOP/s for both pipes)
         achieved, peak, unit = work / sec / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"

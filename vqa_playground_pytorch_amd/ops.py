@@ -1344,7 +1344,14 @@ class BatchedLinearFn(torch.autograd.Function):
             d_w = None
             if ctx.needs_input_grad[1]:      # d_w[g] = gz[g]^T x[:, g, :] over the B rows: one grouped launch (TN form)
                 d_w = _grad_like(w)
-                rest = [g for g in range(G) if not gemm_tn_split(gz, g * B * A, A, x, g * x.stride(1), x.stride(0), d_w[g], B, A, K)]
+                rest = []
+                wide = A >= 2 * K        # the kernel PACKS its first operand and splits the second in its loop: give it the narrow one
+                tmp = torch.empty(K, A, device=gy.device, dtype=torch.float32) if wide else None     # (to pack: 13312 x 620, not x 2400)
+                for g in range(G):
+                    if wide and gemm_tn_split(x, g * x.stride(1), x.stride(0), gz, g * B * A, A, tmp, B, K, A):
+                        d_w[g].copy_(tmp.t())                                   # d_w^T came out; 6 MB transposed back
+                    elif not gemm_tn_split(gz, g * B * A, A, x, g * x.stride(1), x.stride(0), d_w[g], B, A, K):
+                        rest.append(g)
                 if rest:
                     _grouped_products("batched_linear_dw", [(head.TN, gz, g * B * A, A, x, g * x.stride(1), x.stride(0), A, K, B, d_w[g])
                                                             for g in rest], engine="split")
@@ -1593,6 +1600,8 @@ def gemm_tn_split(g, g_off, ldg, x, x_off, ldx, d_w, M, N1, N2):
     alignment is outside of the engine (the caller then takes the grouped launch)."""
     L_ = _lib.lib()
     gp, xp = g.data_ptr() + 4 * int(g_off), x.data_ptr() + 4 * int(x_off)
+    if os.environ.get("VQA_TN_SPLIT", "1") == "0":      # (measurement knob: the grouped launch instead)
+        return False
     if (L_.vqa_gemm_tn_split_supported(M, N1, N2, int(ldg), int(ldx)) != 1 or gp % 8 or xp % 16 or d_w.data_ptr() % 16
             or not d_w.is_contiguous()):
         return False
