@@ -13,7 +13,8 @@ for f in bench_default bench_b512 bench_b512_mfma; do
 done
 for f in bench_b512_legacy_head bench_b512_grouped_head bench_oda_b512 bench_oda_b512_grouped_head bench_oda_attention_b512 \
          bench_bf16_n100_b128 bench_f32_n100_b128 bench_b512_pairwise bench_b512_encoder bench_b512_k4_engine bench_b512_eager bench_oda_b512_mfma \
-         bench_b512_copy_inputs bench_bf16_n100_b128_k4fold bench_b512_grouped_mfma bench_b512_grouped_split; do
+         bench_b512_copy_inputs bench_bf16_n100_b128_k4fold bench_b512_grouped_mfma bench_b512_grouped_split \
+         bench_b512_relation_unfused bench_b512_encoder_grouped_dw bench_b512_again; do
   cp "$SRC/$f.json" "$DST/${TAG}_$f.json"
 done
 for f in bench_b512_graph_kernel_stats.csv bench_b512_eager_kernel_stats.csv bench_oda_b512_kernel_stats.csv \
@@ -24,6 +25,11 @@ for f in bench_b512_graph_kernel_stats.csv bench_b512_eager_kernel_stats.csv ben
          bench_b512_mfma_kernel_stats.csv vqa_kernels_by_grid_mfma.txt convergence_cor2_mfma.json; do
   cp "$SRC/$f" "$DST/${TAG}_$f"
 done
+for f in trace_graph trace_bf16_n100_b128 trace_oda_b512; do
+  [ -f "$SRC/$f.json" ] && cp "$SRC/$f.json" "$DST/${TAG}_$f.json"
+done
+[ -f "$SRC/trace_graph.json" ] && cp "$SRC/trace_graph.json" "$DST/${TAG%%_*}_trace.json"
+[ -f "$SRC/trace_bf16_n100_b128.json" ] && cp "$SRC/trace_bf16_n100_b128.json" "$DST/${TAG%%_*}_trace_bf16_n100_b128.json"
 cp "$SRC/pmc_traffic.json" "$DST/${TAG%%_*}_pmc_traffic.json"
 cp "$SRC/pmc_mfma.json" "$DST/${TAG%%_*}_pmc_mfma.json"
 for f in pmc_mfma_bf16_n100_b128 pmc_traffic_bf16_n100_b128 pmc_mfma_oda_attention pmc_traffic_oda_attention; do

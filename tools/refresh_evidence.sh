@@ -113,6 +113,11 @@ run bench_b512_encoder --no-sub-records --encoder --steps 10 --warmup 5 --no-cpu
 run bench_oda_b512 --no-sub-records --model oda --steps 20 --warmup 5 --no-cpu-baseline
 run bench_oda_attention_b512 --model oda-attention --steps 20 --warmup 5
 VQA_K4_FORM=engine run bench_b512_k4_engine --no-sub-records --steps 20 --warmup 5 --no-cpu-baseline
+# round 6: the step with the relation tensor written to HBM again (K1 -> K5 unfused), the encoder step with its weight gradients on
+# the grouped launches, and the headline once more at the end (the pool's boxes differ: before / after on THIS box)
+VQA_RELATION_FUSED=0 run bench_b512_relation_unfused --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records
+VQA_TN_SPLIT=0 run bench_b512_encoder_grouped_dw --no-sub-records --encoder --steps 10 --warmup 5 --no-cpu-baseline
+run bench_b512_again --steps 20 --warmup 5 --no-cpu-baseline --no-sub-records
 fi
 
 if want trace; then
