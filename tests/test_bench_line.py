@@ -151,7 +151,7 @@ def test_counter_rows_are_tied_to_the_kernel_sources(tmp_path):
     assert _srchash.row_is_stale(keys[0], table[keys[0]], csrc, inc)
     assert not _srchash.row_is_stale(keys[1], table[keys[1]], csrc, inc)          # optimizer.hip did not change
     assert _srchash.source_hash(csrc, inc) != table["__source__"]["source_hash"]
-    # a header reaches every kernel
+    # a template header reaches every kernel
     with open(os.path.join(csrc, "common.hpp"), "a") as fh:
         fh.write("\n")
     assert all(_srchash.row_is_stale(k, table[k], csrc, inc) for k in keys)

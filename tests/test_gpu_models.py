@@ -1191,3 +1191,28 @@ def test_baseline_batch_with_the_products_gates(cls, nans, mode, engine, monkeyp
     print("[%s B=512 %s, %s engine, gates forced] all %d samples: worst gradient error %.2e of its tensor's scale (%s)"
           % (cls, mode, engine, B, worst[0], worst[1]))
     measured("worst gradient err / scale", worst[0], RTOL_FORCED_F32, worst[1])
+
+
+@pytest.mark.parametrize("cls,nans", [("cor2", 2000), ("oda", 3000)])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_bf16_transport_of_the_regions_is_the_fp32_step(cls, nans, mode):
+    """region features that cross PCIe as bf16 (feed.store_batches(region_dtype=torch.bfloat16), half the bytes
+    of the step's dominant stream) enter the fp32 path through ONE exact widening pass (ops.widen_bf16) -- the arithmetic
+    downstream is the fp32 step.  At the BASELINE batch: on features that are bf16-representable, the model fed bf16 and the model
+    fed the same values as fp32 return the same logits and the same gradients bit for bit (training mode: same dropout seeds)."""
+    B = 512
+    v, q, a = seeded.seeded_inputs(B, answers=nans, seed=77)
+    v16 = torch.from_numpy(v).to(torch.bfloat16)
+    out = {}
+    for transport in ("f32", "bf16"):
+        model = build(cls, nans)
+        if mode == "train":
+            model.train()
+        torch.manual_seed(5)                    # (the fused masks' seeds are drawn from torch's CPU generator)
+        vin = (v16 if transport == "bf16" else v16.float()).to(dev())
+        logits = model({"v": vin, "q_idxes": torch.from_numpy(q).to(dev())})
+        RF.kld_sum_loss(logits, torch.from_numpy(a).to(dev())).backward()
+        out[transport] = (logits.detach().clone(), [p.grad.detach().clone() for p in model.parameters()])
+    assert torch.equal(out["f32"][0], out["bf16"][0])
+    for g0, g1 in zip(out["f32"][1], out["bf16"][1]):
+        assert torch.equal(g0, g1)

@@ -325,3 +325,23 @@ def test_split_engine_is_the_default_and_refuses_what_it_cannot_run(monkeypatch)
     assert L_.vqa_relation_projection_dgrad_split_supported(512, 36, 2048, 310) == 1
     assert L_.vqa_relation_projection_dgrad_split_supported(512, 35, 2048, 310) == 0
     assert L_.vqa_relation_projection_dgrad_split_workspace_bytes(2048, 310) >= 128 * 10 * 3072
+
+
+def test_hot_kernels_have_no_waterfall_loops():
+    """Round 6 found three kernels whose buffer loads ran inside waterfall loops (v_readfirstlane x 4 + compare + branch per load)
+    because hipcc could not see that a descriptor / scalar offset was wave-uniform: the K1 -> K5 fused forward (a descriptor made
+    behind a loop with a divergent exit: +15 us), the encoder's batched GEMM (a problem index out of a vector-ALU division: 151 ->
+    114 us per step) and K3a's logits kernels (the wave index threadIdx.x >> 6 without readfirstlane: -28 us per training step).
+    tools/waterfall_check.py finds the pattern in the ISA; here the two files that hold the split engine's entry points are
+    compiled (device code only) and checked: no waterfall loop between the MFMAs of any of their kernels."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("waterfall_check", os.path.join(ROOT, "tools", "waterfall_check.py"))
+    wf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wf)
+    if not os.path.exists(wf.HIPCC):
+        pytest.skip("no hipcc here")
+    for name in ("gru_gemm.hip", "linear_split.hip"):
+        res = wf.check(os.path.join(wf.CSRC, name))
+        assert res, name
+        bad = {k: v for k, v in res.items() if v[1] > 0}
+        assert not bad, (name, bad)

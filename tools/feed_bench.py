@@ -19,11 +19,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--transport", choices=["f32", "bf16"], default="f32",
+                    help="bf16: the regions cross PCIe as bf16 (half the bytes) and are widened on the device (ops.widen_bf16); the step is the fp32 one")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     B = args.batch
     torch.manual_seed(0)
-    host = [{"v": torch.randn(B, 36, 2048).pin_memory(), "q_idxes": torch.randn(B, 2400).pin_memory(),
+    vdt = torch.bfloat16 if args.transport == "bf16" else torch.float32
+    host = [{"v": torch.randn(B, 36, 2048).to(vdt).pin_memory(), "q_idxes": torch.randn(B, 2400).pin_memory(),
              "a": torch.softmax(torch.randn(B, 2000), 1).pin_memory()} for _ in range(3)]
     model = CoR2Model(["PAD"], 2000).to(dev).train()
     tr = DataParallelTrainer(model, graph=True)
@@ -47,9 +50,9 @@ def main():
     for _ in range(10):
         d.copy_(host[0]["v"], non_blocking=True)
     torch.cuda.synchronize()
-    h2d = 10 * host[0]["v"].numel() * 4 / (time.perf_counter() - t1) / 1e9
-    print("host-fed: %.1f samples/s (%.3f ms/step, graph=%s); pinned H2D of v alone: %.1f GB/s"
-          % (B * args.steps / dt, 1e3 * dt / args.steps, tr._graph is not None, h2d))
+    h2d = 10 * host[0]["v"].numel() * host[0]["v"].element_size() / (time.perf_counter() - t1) / 1e9
+    print("host-fed (%s transport): %.1f samples/s (%.3f ms/step, graph=%s); pinned H2D of v alone: %.1f GB/s"
+          % (args.transport, B * args.steps / dt, 1e3 * dt / args.steps, tr._graph is not None, h2d))
 
 
 if __name__ == "__main__":

@@ -8,8 +8,8 @@ source_hash()        one sha256 over every file the library is compiled from (cs
                      contents, in sorted order -- `vqa_source_hash()` of a library built from this tree returns it;
                      __graft_entry__.smoke() and tests/test_host_cpu.py compare the two, so a stale binary on the GPU box is seen.
 file_hashes()        {file name: sha256 of its contents}.
-kernel_sources(k)    the .hip / .hpp files that DEFINE the __global__ kernel a profiler row names, plus every header (a header
-                     change can reach any kernel).  tools/pmc_table.py / pmc_mfma.py store `kernel_fingerprint(k)` per row;
+kernel_sources(k)    the .hip / .hpp files that DEFINE the __global__ kernel a profiler row names, plus every .hpp (a template
+                     header change can reach any kernel; include/*.h holds declarations only and is left to source_hash()).  tools/pmc_table.py / pmc_mfma.py store `kernel_fingerprint(k)` per row;
                      bench.py recomputes it and drops a row's counters (`traffic_stale`) when the sources moved on.
 This module imports nothing of the package (the Makefile runs it before the library exists)."""
 import hashlib
@@ -71,7 +71,9 @@ def kernel_identifier(row_key):
 def kernel_sources(row_key, csrc=CSRC, include=INCLUDE):
     ident = kernel_identifier(row_key)
     files = set(_definitions(csrc).get(ident, ()))
-    files |= {os.path.basename(p) for p in source_files(csrc, include) if p.endswith((".hpp", ".h"))}
+    # every .hpp (templates: a header change can reach any kernel); NOT the C header of declarations -- a new entry point does not
+    # change an existing kernel (it is part of source_hash(), the whole library's)
+    files |= {os.path.basename(p) for p in source_files(csrc, include) if p.endswith(".hpp")}
     return sorted(files)
 
 

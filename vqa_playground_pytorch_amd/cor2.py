@@ -179,7 +179,12 @@ class Model(nn.Module):
         b = v.size(0)
         v_feature = v.contiguous().view(b, -1, 2048)
         if v_feature.dtype != self.compute_dtype:
-            v_feature = v_feature.to(self.compute_dtype)
+            # bf16 regions into the fp32 path: the feed's transport format (feed.store_batches(region_dtype=torch.bfloat16): half
+            # the host -> device bytes), widened exactly by one HIP pass; everything downstream is the fp32 step
+            if v_feature.is_cuda and v_feature.dtype == torch.bfloat16 and self.compute_dtype == torch.float32:
+                v_feature = ops.widen_bf16(v_feature)
+            else:
+                v_feature = v_feature.to(self.compute_dtype)
         q_feature = question_feature(self.seq2vec, sample["q_idxes"] if "q_idxes" in sample else sample["q"])
 
         shad = self._bf16_shadows() if v_feature.dtype == torch.bfloat16 and v_feature.is_cuda else {}

@@ -131,7 +131,9 @@ __global__ __launch_bounds__(kAlThreads, 2) void attention_logits_fwd_kernel(con
   constexpr int VEC = V::VEC, P = V::P, RB = kAlRows;
   constexpr bool BUTTERFLY = (RB * G) % 16 == 0 && 16 % G == 0;
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * kAlWaves + (threadIdx.x >> 6), nwaves = gridDim.x * kAlWaves;
+  // (readfirstlane: the wave index is uniform, but hipcc only knows that when told -- without it every row load's scalar offset
+  //  was "divergent" and each of the 64 buffer loads ran inside a waterfall loop; tools/waterfall_check.py)
+  const int wave = blockIdx.x * kAlWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = gridDim.x * kAlWaves;
   // the row loads go out first: the weights (a few KB, L2-resident after the first workgroups) land under them
   float xv[RB][P][VEC];
   const int m_first = wave * RB;
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(kAlThreads, 2) void attention_logits_bwd_kernel(con
   constexpr int VEC = V::VEC, P = V::P, RB = kAlBwdRows, KPAD = 64 * VEC * P;
   __shared__ float red_s[kAlWaves - 1][G][KPAD];
   __shared__ float redb_s[kAlWaves][G];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: see the forward kernel)
   const int wave = blockIdx.x * kAlWaves + wv, nwaves = gridDim.x * kAlWaves;
   float wr[G][P][VEC], dw[G][P][VEC], db[G];
   al_load_weights<G, P, VEC>(w, K, lane, wr);

@@ -218,6 +218,38 @@ extern "C" int vqa_gate_product_bwd(const float* g1, const float* g2, const floa
   return vqa::check_launch("gate_product_bwd");
 }
 
+// bf16 -> fp32, eight elements per lane: the feed's bf16 TRANSPORT format of the region features (half the PCIe bytes of the
+// step's dominant stream) widened on the device for the fp32 path -- exact (every bf16 is an fp32), so a step fed this way on
+// bf16-representable features is bit-identical to the fp32-fed one
+__global__ __launch_bounds__(256) void widen_bf16_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i + 8 <= n) {
+    const uint4 p = *reinterpret_cast<const uint4*>(src + i);
+    const uint32_t w[4] = {p.x, p.y, p.z, p.w};
+    float4 a, b;
+    a.x = __uint_as_float(w[0] << 16);
+    a.y = __uint_as_float(w[0] & 0xFFFF0000u);
+    a.z = __uint_as_float(w[1] << 16);
+    a.w = __uint_as_float(w[1] & 0xFFFF0000u);
+    b.x = __uint_as_float(w[2] << 16);
+    b.y = __uint_as_float(w[2] & 0xFFFF0000u);
+    b.z = __uint_as_float(w[3] << 16);
+    b.w = __uint_as_float(w[3] & 0xFFFF0000u);
+    *reinterpret_cast<float4*>(dst + i) = a;
+    *reinterpret_cast<float4*>(dst + i + 4) = b;
+  } else {
+    for (size_t k = i; k < n; ++k) dst[k] = __uint_as_float((uint32_t)src[k] << 16);
+  }
+}
+
+extern "C" int vqa_widen_bf16(const vqa_bf16_t* src, float* dst, size_t n, vqa_stream_t stream) {
+  VQA_REQUIRE(src && dst, VQA_E_BADARG, "widen_bf16: null pointer");
+  VQA_REQUIRE(aligned(src, 16) && aligned(dst, 16), VQA_E_UNSUPPORTED, "widen_bf16: src and dst must be 16-byte aligned");
+  if (n == 0) return VQA_OK;
+  VQA_LAUNCH(widen_bf16_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, static_cast<hipStream_t>(stream), src, dst, n);
+  return check_launch("widen_bf16");
+}
+
 extern "C" int vqa_bias_act(const float* y, const float* bias, int bias_stride, float* out, int G, int B, int A, int act,
                             int group_first, vqa_stream_t stream) {
   VQA_REQUIRE(y && out, VQA_E_BADARG, "bias_act: null pointer");

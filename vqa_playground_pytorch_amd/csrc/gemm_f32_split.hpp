@@ -514,7 +514,12 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(NtArgs p, DropCfg 
     const int s0 = (tm * S::BM) / p.rps;
     const int ns = (min(p.M, (tm + 1) * S::BM) - 1) / p.rps - s0 + 1;     // (<= rel_samples(BM, rps): what the host sized the LDS for)
     const int k4 = p.K / 4;
-    for (int idx = threadIdx.x; idx < ns * 2 * k4; idx += kThreads) {
+    // (a loop with a UNIFORM trip count and a guarded body: after a loop whose exit is divergent hipcc made the buffer descriptors
+    //  of nt_accumulate PHIs of that region, kept them in VGPRs and wrapped every one of the main loop's 89 buffer loads in a
+    //  waterfall loop -- v_readfirstlane x 4, compare, branch -- : 157 us instead of 13x.  Check: count v_readfirstlane in the ISA)
+    const int total = ns * 2 * k4, iters = (total + kThreads - 1) / kThreads;
+    for (int it = 0; it < iters; ++it) {
+      const int idx = min(it * kThreads + (int)threadIdx.x, total - 1);     // (the last lanes repeat the last piece: no branch at all)
       const int s = idx / (2 * k4), rem = idx - s * 2 * k4, which = rem / k4, k = rem - which * k4;
       const float* src = (which == 0 ? p.T : p.C2) + (size_t)(s0 + s) * p.K + 4 * k;
       reinterpret_cast<f32x4*>(sp_smem)[idx] = *reinterpret_cast<const f32x4*>(src);

@@ -78,11 +78,15 @@ __global__ __launch_bounds__(sp::kThreads, 1) void gemm_nt_batched_kernel(BatchN
   // contiguous range of tiles)
   const int tiles = q.tiles_m * q.tiles_n;
   const int lin = xcd_remap(blockIdx.x, gridDim.x);
-  const int prob = lin / tiles, tile = lin - prob * tiles;
+  // (readfirstlane: the division runs on the vector ALU, and without it hipcc kept everything derived from `prob` -- the operands'
+  //  buffer descriptors -- in VGPRs and wrapped each of the main loop's buffer loads in a waterfall loop: 8-20 v_readfirstlane per
+  //  row block.  Check: count v_readfirstlane between the MFMAs of the ISA)
+  const int prob = __builtin_amdgcn_readfirstlane(lin / tiles), tile = lin - prob * tiles;
   const float* A = q.A + (size_t)prob * q.a_gs;
   float* C = q.C + (size_t)prob * q.c_gs;
   const sp::NtArgs p{A, q.Bp + (size_t)prob * q.bp_gs, q.lda, q.M, q.N, q.Kp, q.tiles_n};
-  const int tm = q.col_major ? tile % q.tiles_m : tile / q.tiles_n, tn = q.col_major ? tile / q.tiles_m : tile % q.tiles_n;
+  const int tm = __builtin_amdgcn_readfirstlane(q.col_major ? tile % q.tiles_m : tile / q.tiles_n);
+  const int tn = __builtin_amdgcn_readfirstlane(q.col_major ? tile / q.tiles_m : tile % q.tiles_n);
   const int m0 = tm * S::BM, n0 = tn * S::BN + wn * (16 * CB);
   const int chunks = q.Kp / sp::kChunk;
 

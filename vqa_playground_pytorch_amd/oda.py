@@ -77,6 +77,8 @@ class Model(nn.Module):
         v = sample["v"]
         b = v.size(0)
         v_feature = v.contiguous().view(b, -1, 2048)
+        if v_feature.dtype == torch.bfloat16 and v_feature.is_cuda:      # the feed's bf16 transport format, widened exactly (ops.widen_bf16)
+            v_feature = ops.widen_bf16(v_feature)
         if v_feature.size(1) != self.regions:
             raise ValueError("ODA.Model was built for %d regions, input has %d" % (self.regions, v_feature.size(1)))
         q_feature = question_feature(self.seq2vec, sample["q_idxes"] if "q_idxes" in sample else sample["q"])

@@ -519,6 +519,14 @@ class LowRankBilinearFusion(torch.autograd.Function):
         return (d_x, d_h2, None, *d_w1, *d_b1)
 
 
+def widen_bf16(x):
+    """bf16 GPU tensor -> fp32 (exact), one HIP pass: the feed's bf16 transport of the region features into the fp32 path."""
+    x = _prep("x", x, (torch.bfloat16,))
+    out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    _launch("widen_bf16", (x.numel(),), _lib.lib().vqa_widen_bf16, _p(x), _p(out), x.numel())
+    return out
+
+
 def pack_bf16(src, dst, batch_stride, row_stride, col_stride, zero_fill=True, offset=0):
     """fp32 [batch, rows, cols] (or [rows, cols]) -> bf16 scattered into ``dst`` (from element ``offset`` on) with the
     given element strides; with zero_fill that part of ``dst`` is zeroed first (the pads of the padded / transposed
