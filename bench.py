@@ -355,6 +355,8 @@ def compact_line(full):
                         "vs_baseline", "dtype", "data"))
     cfg = full.get("config", {})
     line["config"] = _pick(cfg, ("workload", "global_batch", "parallelism", "launch", "relation_mode", "f32_products", "inputs"))
+    if cfg.get("warmup_run"):
+        line["config"]["warmup_run"] = str(cfg["warmup_run"]).split(" (")[0]
     line["config"]["workload"] = str(line["config"].get("workload", ""))[:130]
     line["roofline"] = _pick(full.get("roofline"), ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "mean_ms",
                                                     "launches", "mfma_busy_pct", "valu_issue_pct_min", "traffic_stale", "trace_ms"))
@@ -753,8 +755,12 @@ def main():
             for _ in range(ROTATE - 1):
                 batches.append(({"v": torch.randn_like(v.float()).to(v.dtype), "q_idxes": torch.randn_like(q)},
                                 torch.softmax(2.0 * torch.randn(B, answers, device=dev), dim=1)))
-        # 2 eager steps precede the first capture; each further input slot is captured by the first step that lands in it
-        warm = max(args.warmup, 2 + (1 if (not rotate or args.copy_inputs) else ROTATE)) if not args.no_graph else args.warmup
+        # 2 eager steps precede the first capture; each further input slot is captured by the first step that lands in it; and the
+        # FIRST replay of a captured graph is not a steady-state step either (hipGraphLaunch uploads the executable graph then:
+        # measured 2.05 ms per step over 20 steps that hold the four first replays against 2.00 without them), so the warm-up runs
+        # until every slot's graph has been replayed once -- at least W steps, never fewer; the timed region is exactly K replays
+        slots = 1 if (not rotate or args.copy_inputs) else ROTATE
+        warm = max(args.warmup, 2 + 2 * slots) if not args.no_graph else args.warmup
         for i in range(warm):
             trainer.step(*batches[i % len(batches)])
             if i == 0:
@@ -773,7 +779,7 @@ def main():
         elapsed = time.perf_counter() - t0
         ops.set_kernel_timer(None)
         log("timed region done: %.3f s" % elapsed)
-        out = {"trainer": trainer, "model": model, "batches": batches, "graphed": graphed, "timer": timer,
+        out = {"trainer": trainer, "model": model, "batches": batches, "graphed": graphed, "timer": timer, "warm": warm,
                "elapsed": max_over_ranks(elapsed), "elapsed_local": elapsed, "overlap": bool(trainer.overlap),
                "final_loss": float(loss.item()), "final_gnorm": float(gnorm.item()), "resident": None}
         # the same steps on ONE resident batch (no copy, inputs from the Infinity Cache): what rounds 1-4 reported as `value`
@@ -923,6 +929,9 @@ def main():
                        "+ clip 0.25 + Adam (dropout active)", "parallelism": "dp%d" % world,
                        "launch": ("hipGraph replay (3 graphs: backward in two halves, the first all-reduce under the second)"
                                   if best["overlap"] else "hipGraph replay (2 graphs + eager all-reduce)") if best["graphed"] else "eager",
+                       "warmup_run": ("%d untimed steps (>= --warmup: 2 kernel-by-kernel, then every input slot's graph captured and "
+                                      "replayed once -- a graph's first launch uploads it)" % best["warm"]) if best["graphed"] else
+                                     "%d untimed steps" % best["warm"],
                        "relation_mode": "factored" if args.relation_mode == 1 else "pairwise",
                        "f32_products": ("fp32 MFMA (v_mfma_f32_16x16x4_f32)" if args.f32_products == "mfma" else
                                         "3xbf16 split, 6 partial products, fp32 accumulate"),

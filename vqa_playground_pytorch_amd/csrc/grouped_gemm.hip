@@ -106,7 +106,11 @@ __device__ __forceinline__ void grouped_tile(const VqaGemmProblem& pr, const Src
 #pragma unroll
   for (int i = 0; i < TM; ++i) colsum[i] = 0.f;
   const bool want_colsum = (pr.colsum != nullptr || pr.colsum_out != nullptr) && n0 == 0;   // (wave-uniform; TN forms only)
-  gemm_tile<BM, kGBN, BK, PF, A_KC, B_KC, false, BK == 16, true>(sa, sb, m0, n0, k_begin, k_end, smem, acc, want_colsum ? colsum : nullptr);
+  // (colsum is passed ALWAYS: `want_colsum ? colsum : nullptr` made the array's address a run-time value, the array went to
+  //  scratch memory and every K step of every tile did a scratch load + add + store chain -- 49 scratch instructions in the ISA,
+  //  8 bytes of private segment per lane.  Eight VALU adds per step are free next to the staging pass; the sums are only USED
+  //  when the problem wants them.)
+  gemm_tile<BM, kGBN, BK, PF, A_KC, B_KC, false, BK == 16, true>(sa, sb, m0, n0, k_begin, k_end, smem, acc, colsum);
   const AccCoord<BM, kGBN> cc(m0, n0);
   const int col = cc.col(0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
