@@ -233,14 +233,12 @@ __global__ __launch_bounds__(NT) void attention_pool_bwd_fused_kernel(const floa
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* alpha_s = reinterpret_cast<float*>(smem);  // [N][G]
   float* red_s = alpha_s + N * G;                   // [N][G]
-  float* inner_s = red_s + N * G;                   // [G]
+  float* inner_s = red_s + N * G;                   // [kMaxG]
+  float* part_s = inner_s + kMaxG;                  // [NT / 64][N][G]: every wave's partial dot products, summed in fixed order
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
   const int NG = N * G;
-  for (int t = tid; t < NG; t += NT) {
-    alpha_s[t] = alpha[(size_t)b * NG + t];
-    red_s[t] = 0.f;
-  }
+  for (int t = tid; t < NG; t += NT) alpha_s[t] = alpha[(size_t)b * NG + t];
   float4 p[CG][G];
   int dcol[CG];
   bool active[CG];
@@ -297,13 +295,21 @@ __global__ __launch_bounds__(NT) void attention_pool_bwd_fused_kernel(const floa
           }
       }
     }
-    const float s1 = row_reduce_scatter16(val, lane);
+    // (round 6: the wave's value goes to its OWN slot -- rounds 1-5 added the 16 partial sums of a (region, glimpse) pair with LDS
+    //  float atomics, in whatever order the waves arrived: d_logits, and every gradient upstream of it, differed in the last bit
+    //  from run to run; tools/determinism_probe.py)
+    const float s1 = rows_sum(row_reduce_scatter16(val, lane));
     const int n = n0 + my_k;
-    if (n < N) atomicAdd(&red_s[n * G + my_g], s1);
+    if (lane < 16 && n < N) part_s[wave * NG + n * G + my_g] = s1;
   }
   __syncthreads();
   // softmax backward on the sample's [N][G]: dal = <d_pooled_g, v_n> (+ what arrived on alpha directly)
-  for (int t = tid; t < NG; t += NT) red_s[t] += d_alpha_ext != nullptr ? d_alpha_ext[(size_t)b * NG + t] : 0.f;
+  for (int t = tid; t < NG; t += NT) {
+    float sum = part_s[t];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) sum += part_s[w * NG + t];
+    red_s[t] = sum + (d_alpha_ext != nullptr ? d_alpha_ext[(size_t)b * NG + t] : 0.f);
+  }
   __syncthreads();
   for (int gI = wave; gI < G; gI += NT / 64) {
     float sum = 0.f;
@@ -359,7 +365,7 @@ static int launch_bwd(const float* alpha, const T* v, const float* d_pooled, con
     // (VQA_K3_FUSED_MIN_B: the smallest batch that takes this form; tests set 1, a huge value keeps the three-launch form)
     const char* env = vqa::option("VQA_K3_FUSED_MIN_B");
     const int min_b = env != nullptr ? std::atoi(env) : 512;
-    const size_t lds_f = ((size_t)2 * N * G + kMaxG) * sizeof(float);
+    const size_t lds_f = ((size_t)(2 + NT / 64) * N * G + kMaxG) * sizeof(float);
     if (B >= min_b && D % 4 == 0 && D <= 4 * NT * 2 && D > 4 * NT) {
       VQA_LAUNCH((attention_pool_bwd_fused_kernel<T, NT, G, 2>), dim3(B), dim3(NT), lds_f, s, alpha, v, d_pooled, d_first,
                          d_alpha_ext, d_logits, d_v, N, D, dc);
