@@ -41,8 +41,11 @@ def grad_err(got, want, atol=ATOL):
     return np.abs(got - want).max() / (RTOL * np.abs(want).max() + atol)
 
 
-ATOL_512 = 2e-6  # the same mathematically-zero gradients summed over 512 x 36 rows (with the dropout factor 2): float32 noise of
-#                  a few 1e-7; every other gradient of these models is O(1e-3..1) at its maximum
+ATOL_512 = 4e-6  # the same mathematically-zero gradients summed over 512 x 36 rows (with the dropout factor 2).  What the product
+#                  holds there is not random noise alone: a sample's d_logits sum to (1 - sum_n alpha_n) * <alpha, dal>, and a float32
+#                  softmax is normalised to ~1e-7 -- 512 such residuals, each times an inner product of O(1e-2), add up to 1e-6 ... 2e-6
+#                  (measured over rounds 4-6 and both engines: 0.7e-6 ... 2.15e-6, depending on the summation order of the kernels in
+#                  front).  Every other gradient of these models is O(1e-3..1) at its maximum, where this floor is nothing.
 
 
 def check_grads(model, gold):
