@@ -254,6 +254,9 @@ def trace_ms(grids, cfg=""):
         ident = _srchash.kernel_identifier(_norm_kernel(text or ""))
         rows = [(k, r) for k, r in table.items() if not k.startswith("__") and k.endswith("|grid=%d" % grid)
                 and _srchash.kernel_identifier(k) == ident]
+        want = _norm_kernel(text or "").rstrip(">")          # of several template instances at that grid: the one the launch site names
+        exact = [(k, r) for k, r in rows if "<" in want and _norm_kernel(k.split("|")[0]).startswith(want)]
+        rows = exact or rows
         if not rows or any(_srchash.row_is_stale(k, r) for k, r in rows):
             return None
         n = sum(r["launches"] for _, r in rows)

@@ -19,6 +19,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--depth", type=int, default=3, help="device slots of the prefetcher = input slots of the trainer (a step graph per "
+                    "slot reads it in place); 2: the host waits for step t before it may refill the slot step t + 2 reads")
+    ap.add_argument("--copy", action="store_true", help="the trainer copies every batch into its own graph input buffers (round 5's form)")
     ap.add_argument("--transport", choices=["f32", "bf16"], default="f32",
                     help="bf16: the regions cross PCIe as bf16 (half the bytes) and are widened on the device (ops.widen_bf16); the step is the fp32 one")
     args = ap.parse_args()
@@ -29,17 +32,22 @@ def main():
     host = [{"v": torch.randn(B, 36, 2048).to(vdt).pin_memory(), "q_idxes": torch.randn(B, 2400).pin_memory(),
              "a": torch.softmax(torch.randn(B, 2000), 1).pin_memory()} for _ in range(3)]
     model = CoR2Model(["PAD"], 2000).to(dev).train()
-    tr = DataParallelTrainer(model, graph=True)
+    tr = DataParallelTrainer(model, graph=True) if args.copy else \
+        DataParallelTrainer(model, graph=True, adopt_inputs=True, input_slots=args.depth)
 
     def stream(n):
         for i in range(n):
             yield host[i % len(host)]
 
-    for b in feed.DevicePrefetcher(stream(6), dev):       # warm-up + graph capture
+    pre = feed.DevicePrefetcher(stream(4 + 2 * args.depth), dev, depth=args.depth)
+    slots = []
+    for b in pre:                                         # warm-up + graph capture (one graph per device slot, each replayed once)
         tr.step({"v": b["v"], "q_idxes": b["q_idxes"]}, b["a"])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for b in feed.DevicePrefetcher(stream(args.steps), dev):
+    # (the timed stream goes through the SAME prefetcher object's device slots: a fresh one would allocate new slots, i.e. new graphs)
+    pre.it = iter(stream(args.steps))
+    for b in pre:
         tr.step({"v": b["v"], "q_idxes": b["q_idxes"]}, b["a"])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -51,8 +59,9 @@ def main():
         d.copy_(host[0]["v"], non_blocking=True)
     torch.cuda.synchronize()
     h2d = 10 * host[0]["v"].numel() * host[0]["v"].element_size() / (time.perf_counter() - t1) / 1e9
-    print("host-fed (%s transport): %.1f samples/s (%.3f ms/step, graph=%s); pinned H2D of v alone: %.1f GB/s"
-          % (args.transport, B * args.steps / dt, 1e3 * dt / args.steps, tr._graph is not None, h2d))
+    print("host-fed (%s transport, %s): %.1f samples/s (%.3f ms/step, graph=%s); pinned H2D of v alone: %.1f GB/s"
+          % (args.transport, "copied into the graph's buffers" if args.copy else "%d slots read in place" % args.depth,
+             B * args.steps / dt, 1e3 * dt / args.steps, tr._graph is not None, h2d))
 
 
 if __name__ == "__main__":
