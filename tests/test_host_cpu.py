@@ -278,10 +278,10 @@ def test_grouped_phases_follow_the_products_engine_and_size_their_parts(monkeypa
     assert [head.Phase.split_tile_cols(n) for n in (310, 2048, 2400, 510)] == [160, 128, 160, 128]
     monkeypatch.setattr(head.Phase, "ENGINE", "auto")
     monkeypatch.delenv("VQA_F32_PRODUCTS", raising=False)
-    assert head.Phase.engine("q_proj_fwd", 512) == "split" and head.Phase.engine("q_proj_bwd", 512) == "mfma"
-    assert head.Phase.engine("q_proj_fwd", 128) == "mfma" and head.Phase.engine() == "mfma"      # small batches stay on the fp32 MFMA
+    assert head.Phase.engine("classifier_bwd", 512) == "split" and head.Phase.engine("q_proj_bwd", 512) == "mfma"
+    assert head.Phase.engine("classifier_bwd", 128) == "mfma" and head.Phase.engine() == "mfma"      # small batches stay on the fp32 MFMA
     monkeypatch.setenv("VQA_F32_PRODUCTS", "mfma")
-    assert head.Phase.engine("q_proj_fwd", 512) == "mfma"
+    assert head.Phase.engine("classifier_bwd", 512) == "mfma"
     monkeypatch.setattr(head.Phase, "ENGINE", "split")
     assert head.Phase.engine("q_proj_bwd", 5) == "split" and head.Phase.engine() == "split"
     monkeypatch.setattr(head.Phase, "ENGINE", "mixed")
