@@ -86,6 +86,7 @@ def test_feature_store_reads_the_on_disk_layout(tmp_path):
     feats, names = _store(tmp_path)
     for workers in (1, 3):
         st = feed.FeatureStore(tmp_path / "size,rcnn_arch,224.npy", tmp_path / "size,rcnn_arch,224.txt", workers=workers)
+        assert st.populate() is st
         assert len(st) == 11 and st.sample_shape == (4, 8) and st.index(names[5]) == 5
         out = torch.empty(9, 4, 8)
         got = st.gather([10, 0, 5, 5, 3, 9, 1], out)
@@ -140,3 +141,64 @@ def test_store_batches_equal_the_reference_items_collated(tmp_path):
     # through the prefetcher (CPU pass-through here; tests/test_gpu_models.py feeds a trainer from it on the GPU)
     out = list(feed.DevicePrefetcher(feed.store_batches(st, qa, 5, 20, pin=False, ring=4), "cpu", depth=2))
     assert len(out) == 3 and torch.equal(out[2]["q_id"], torch.tensor([510, 511, 512]))
+
+
+def test_store_batches_with_a_background_producer(tmp_path):
+    """prefetch > 0: the batches are assembled by a background thread; same batches, same order, and a ring that is too small for
+    the look-ahead is refused (a slot would be refilled under the consumer)."""
+    feats, names = _store(tmp_path)
+    st = feed.FeatureStore(tmp_path / "size,rcnn_arch,224.npy", names, workers=2)
+    qa = [{"v_idx": (3 * i) % 11, "q_idxes": [i, 1, 0], "q_id": i, "a_10_idx": [((i * 7) % 20, 0.75), ((i * 7 + 1) % 20, 0.25)]} for i in range(23)]
+    plain = [{k: t.clone() for k, t in b.items()} for b in feed.store_batches(st, qa, 4, 20, pin=False)]
+    ahead = [{k: t.clone() for k, t in b.items()} for b in feed.store_batches(st, qa, 4, 20, pin=False, ring=5, prefetch=2)]
+    assert len(plain) == len(ahead) == 6
+    for b0, b1 in zip(plain, ahead):
+        assert all(torch.equal(b0[k], b1[k]) for k in b0)
+    assert torch.allclose(plain[0]["a"].sum(1), torch.ones(4))
+    with pytest.raises(ValueError):
+        list(feed.store_batches(st, qa, 4, 20, pin=False, ring=3, prefetch=2))
+    # a consumer that stops early does not leave the producer blocked
+    it = feed.store_batches(st, qa, 4, 20, pin=False, ring=5, prefetch=2)
+    next(it)
+    it.close()
+    # float question vectors (the identity-encoder slot)
+    qv = [{"v_idx": 0, "q_idxes": np.full(5, 0.5, np.float32), "q_id": 0}]
+    b = next(feed.store_batches(st, qv, 1, 20, pin=False, q_dtype=torch.float32))
+    assert b["q_idxes"].dtype == torch.float32 and float(b["q_idxes"].sum()) == 2.5
+
+
+def test_feature_store_bf16_rounding_is_round_to_nearest_even(tmp_path):
+    """gather(..., out=bf16) rounds in numpy inside its worker threads (not on torch's intra-op pool): the same bits as torch's
+    float32 -> bfloat16 conversion on ties, halfway cases, subnormals, +-Inf, the largest finite values (which round to Inf) and NaN."""
+    special = np.array([0.0, -0.0, 1.0, 1.0 + 2.0 ** -8, 1.0 + 2.0 ** -7, 1.0 + 3 * 2.0 ** -8, -(1.0 + 2.0 ** -8), 3.3961775e38, 3.4e38, -3.4028235e38,
+                        np.inf, -np.inf, 1e-40, -1e-45, 2.0 ** -126, 65504.0, 0.1, 1 / 3], np.float32)
+    rs = np.random.RandomState(4)
+    feats = rs.standard_normal((6, 4, 8)).astype(np.float32) * np.exp2(rs.randint(-30, 30, (6, 4, 8))).astype(np.float32)
+    feats.reshape(-1)[:special.size] = special
+    feats[5, 3, 7] = np.nan
+    np.save(tmp_path / "f.npy", feats)
+    for workers in (1, 3):
+        st = feed.FeatureStore(tmp_path / "f.npy", workers=workers)
+        got = st.gather([0, 5, 2, 5, 1, 3, 4], torch.empty(7, 4, 8, dtype=torch.bfloat16))
+        want = torch.from_numpy(feats[[0, 5, 2, 5, 1, 3, 4]]).to(torch.bfloat16)
+        nan = torch.isnan(want)
+        assert torch.equal(torch.isnan(got), nan)
+        assert torch.equal(got.view(torch.int16)[~nan], want.view(torch.int16)[~nan])
+
+
+def test_store_batches_over_epochs_keeps_its_staging(tmp_path):
+    """epochs = k: k passes, each with its own shuffle (seed + epoch), through ONE ring of staging tensors."""
+    feats, names = _store(tmp_path)
+    st = feed.FeatureStore(tmp_path / "size,rcnn_arch,224.npy", names, workers=1)
+    qa = [{"v_idx": i % 11, "q_idxes": [i, 0], "q_id": i} for i in range(10)]
+    table = feed.qa_table(st, qa, 20)
+    seen, ptrs = [], set()
+    for b in feed.store_batches(st, table, 4, 20, shuffle=True, seed=3, pin=False, ring=2, epochs=3):
+        seen.append(b["q_id"].tolist())
+        ptrs.add(b["v"].data_ptr())
+    assert len(seen) == 9 and [len(x) for x in seen] == [4, 4, 2] * 3 and len(ptrs) == 2
+    epochs = [sorted(sum(seen[3 * e:3 * e + 3], [])) for e in range(3)]
+    assert epochs == [list(range(10))] * 3 and seen[0:3] != seen[3:6]
+    it = feed.store_batches(st, table, 4, 20, pin=False, epochs=None)
+    assert [next(it)["q_id"].tolist() for _ in range(4)][3] == [0, 1, 2, 3]       # wraps around for ever
+    it.close()

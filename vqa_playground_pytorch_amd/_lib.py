@@ -89,6 +89,7 @@ SIGNATURES = {
     "vqa_gemm_nt_split_batched_supported": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_i]),
     "vqa_gemm_nt_split_batched": (_c_i, [_c_f, _c_l, _c_i, _c_f, _c_f, _c_l, _c_i, _c_f, _c_i, _c_f, _c_l, _c_i, _c_i, _c_i, _c_i,
                                          _c_i, _c_i, _c_st]),
+    "vqa_host_gather_rows": (_c_i, [_c_f, _c_l, _c_l, ctypes.c_void_p, _c_i, ctypes.c_void_p, _c_i, _c_i]),
     "vqa_widen_bf16": (_c_i, [_c_f, _c_f, _c_sz, _c_st]),
     "vqa_gemm_tn_split_supported": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_i]),
     "vqa_gemm_tn_split_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i]),

@@ -182,6 +182,24 @@ class FeatureStore:
     def __len__(self):
         return self.features.shape[0]
 
+    def populate(self):
+        """Map every page of the store into this process now (MADV_POPULATE_READ where the kernel has it, else one read per 4 KiB
+        page).  A cold mapping pays a minor page fault per page on first touch -- 72 per sample, under the process's mmap lock, so
+        a 16-thread gather of 512 cold rows takes 60-90 ms instead of 2 (measured, tools/feed_host_profile.py); a store that fits
+        RAM is worth populating once, a larger one lives with first-touch faults like the reference's h5py reads do."""
+        mm = getattr(self.features, "_mmap", None)
+        try:
+            if mm is None:
+                raise OSError
+            mm.madvise(22)                                     # MADV_POPULATE_READ (Linux >= 5.14)
+        except (OSError, ValueError, AttributeError):
+            flat = self.features.reshape(-1)
+            step = 1 << 20                                     # 4 MiB of floats per slice: one element per page is read
+            total = 0.0
+            for lo in range(0, flat.size, step * 256):
+                total += float(flat[lo:lo + step * 256:1024].sum())
+        return self
+
     @property
     def sample_shape(self):
         return tuple(self.features.shape[1:])
@@ -191,67 +209,171 @@ class FeatureStore:
         return self.name_to_idx[img_filename]
 
     def gather(self, indices, out):
+        """out[r] = feature[indices[r]] (rows of N x D floats), fp32 or rounded to bf16 (nearest even), on `workers` threads."""
         idx = np.asarray(indices, dtype=np.int64)
         if idx.ndim != 1 or out.shape[0] < idx.size or tuple(out.shape[1:]) != self.sample_shape:
             raise ValueError("gather: out %s does not take %d rows of %s" % (tuple(out.shape), idx.size, self.sample_shape))
         if idx.size and (idx.min() < 0 or idx.max() >= len(self)):
             raise IndexError("gather: feature index out of range [0, %d)" % len(self))
-        if out.dtype == torch.float32:
-            dst = out.numpy()
-
-            def copy(lo, hi):
-                for r in range(lo, hi):
-                    dst[r] = self.features[idx[r]]
-        elif out.dtype == torch.bfloat16:
-            def copy(lo, hi):
-                for r in range(lo, hi):
-                    out[r].copy_(torch.from_numpy(np.array(self.features[idx[r]])))     # (a writable copy) round-to-nearest-even
-        else:
-            raise ValueError("gather: out must be float32 or bfloat16")
         n = idx.size
+        if out.dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("gather: out must be float32 or bfloat16")
+        if n == 0:
+            return out[:0]
+        # ONE native call for the batch (csrc/feed_host.hip: `workers` threads, memcpy or round-to-nearest-even to bf16): a ctypes call
+        # drops the GIL once, where a numpy.take per worker thread took and returned it per call -- next to a training loop that holds
+        # the GIL for milliseconds at a time that was 9-19 ms per batch instead of 2-3 (tools/feed_bench.py --store)
+        if self.features.flags["C_CONTIGUOUS"] and out.is_contiguous():
+            from . import _lib
+            try:
+                L_ = _lib.lib()
+            except _lib.VqaLibraryError:
+                L_ = None
+            if L_ is not None:
+                idx = np.ascontiguousarray(idx)
+                _lib.check(L_.vqa_host_gather_rows(self.features.ctypes.data, len(self), int(np.prod(self.sample_shape)), idx.ctypes.data, n,
+                                                   out.data_ptr(), int(out.dtype == torch.bfloat16), self.workers), "host_gather_rows")
+                return out[:n]
+        # (no library: numpy, one take per worker thread; bf16 through torch's conversion)
+        dst = out.numpy() if out.dtype == torch.float32 else np.empty((n,) + self.sample_shape, dtype=np.float32)
+
+        def copy(lo, hi):
+            if hi > lo:
+                np.take(self.features, idx[lo:hi], axis=0, out=dst[lo:hi], mode="clip")   # (range-checked above; mode="raise" buffers `out`)
         if self._pool is None or n < 2 * self.workers:
             copy(0, n)
         else:
             step = -(-n // self.workers)
             list(self._pool.map(lambda lo: copy(lo, min(lo + step, n)), range(0, n, step)))
+        if out.dtype == torch.bfloat16:
+            out[:n].copy_(torch.from_numpy(dst[:n]))
         return out[:n]
 
 
-def store_batches(store, qa_items, batch_size, num_ans, shuffle=False, seed=0, pin=True, region_dtype=torch.float32, ring=3):
+class _QaTable:
+    """The per-question records turned into arrays ONCE (the reference keeps dicts and pays Python per sample per epoch in its
+    DataLoader workers): feature rows, the question matrix, ids, and the soft answers as CSR (datasets.py:963-969: a[c_id] = c_prob,
+    the last pair of a duplicated id wins)."""
+
+    def __init__(self, store, qa_items, num_ans, q_dtype):
+        n = len(qa_items)
+        self.rows = np.fromiter((it["v_idx"] if "v_idx" in it else store.index(it["img_filename"]) for it in qa_items), np.int64, n)
+        self.q_ids = np.fromiter((int(it.get("q_id", i)) for i, it in enumerate(qa_items)), np.int64, n)
+        q_np = {torch.long: np.int64, torch.float32: np.float32, torch.float64: np.float64}.get(q_dtype, np.float32)
+        self.q = np.asarray([np.asarray(it["q_idxes"]) for it in qa_items]).astype(q_np, copy=False)
+        self.kind = "dense" if "a" in qa_items[0] else ("soft" if "a_10_idx" in qa_items[0] else None)
+        if self.kind == "dense":
+            self.a = np.asarray([np.asarray(it["a"], dtype=np.float32) for it in qa_items])
+        elif self.kind == "soft":
+            counts = np.fromiter((len(it["a_10_idx"]) for it in qa_items), np.int64, n)
+            self.ptr = np.concatenate([[0], np.cumsum(counts)])
+            flat = [pair for it in qa_items for pair in it["a_10_idx"]]
+            self.cols = np.fromiter((int(c) for c, _ in flat), np.int64, len(flat))
+            self.vals = np.fromiter((float(p) for _, p in flat), np.float32, len(flat))
+            if len(flat) and (self.cols.min() < 0 or self.cols.max() >= num_ans):
+                raise IndexError("store_batches: answer id outside [0, %d)" % num_ans)
+
+    def fill_answers(self, a, ids):
+        dst = a.numpy()
+        if self.kind == "dense":
+            dst[...] = self.a[ids]
+            return
+        dst.fill(0.0)
+        lo, hi = self.ptr[ids], self.ptr[ids + 1]
+        counts = hi - lo
+        if counts.sum():
+            rows = np.repeat(np.arange(len(ids)), counts)
+            src = np.concatenate([np.arange(x, y) for x, y in zip(lo, hi)]) if len(ids) else np.zeros(0, np.int64)
+            dst[rows, self.cols[src]] = self.vals[src]        # (in order: the last pair of a duplicated id wins, as in the reference's loop)
+
+
+def qa_table(store, qa_items, num_ans, q_dtype=torch.long):
+    """The array form of the per-question records that store_batches works on; build it once, pass it instead of the list."""
+    return _QaTable(store, qa_items, num_ans, q_dtype)
+
+
+def store_batches(store, qa_items, batch_size, num_ans, shuffle=False, seed=0, pin=True, region_dtype=torch.float32, ring=3,
+                  q_dtype=torch.long, prefetch=0, epochs=1, producers=1):
     """The reference's loader (datasets.py:893-977: `Inner.__getitem__` + DataLoader(batch_size, shuffle, pin_memory=True), no
-    drop_last) over a FeatureStore: yields batch dicts {'v' [B,N,D], 'q_idxes' [B,T] int64, 'q_id' [B], 'a' [B,num_ans]} of
-    host tensors.  qa_items: the reference's per-question records -- 'img_filename' (or 'v_idx'), 'q_idxes', 'q_id',
-    'a_10_idx' [(answer id, probability), ...] (or a dense 'a'; neither for test splits).  The staging tensors come from a
-    ring of `ring` pinned sets reused in turn (a yielded batch stays valid until `ring - 1` further batches have been drawn;
-    DevicePrefetcher(depth <= ring - 1) copies it out before that).  region_dtype = torch.bfloat16 stores the regions rounded
-    to bf16 (the bf16 path's transport format)."""
-    n = len(qa_items)
-    order = np.arange(n)
-    if shuffle:
-        np.random.RandomState(seed).shuffle(order)
-    T = len(qa_items[0]["q_idxes"])
-    has_a = "a" in qa_items[0] or "a_10_idx" in qa_items[0]
+    drop_last) over a FeatureStore: yields batch dicts {'v' [B,N,D], 'q_idxes' [B,T], 'q_id' [B], 'a' [B,num_ans]} of host tensors.
+    qa_items: the reference's per-question records -- 'img_filename' (or 'v_idx'), 'q_idxes', 'q_id', 'a_10_idx' [(answer id,
+    probability), ...] (or a dense 'a'; neither for test splits).  The staging tensors come from a ring of `ring` pinned sets reused
+    in turn (a yielded batch stays valid until `ring - 1 - prefetch` further batches have been drawn; DevicePrefetcher(depth) needs
+    ring >= depth + prefetch + 1).  region_dtype = torch.bfloat16 stores the regions rounded to bf16 (the transport format: half the
+    PCIe bytes; the fp32 path widens them exactly on the device).  q_dtype: torch.long for token ids (the reference), a float type when
+    'q_idxes' holds precomputed question vectors (the models' identity-encoder slot).  The records are turned into arrays once
+    per call (`qa_table(...)` does it ahead of time: pass its result as qa_items to reuse it over epochs).  prefetch > 0: batches are assembled by a
+    background thread, up to `prefetch` ahead of the consumer (the DataLoader's worker processes, as one thread: numpy and torch
+    release the GIL in the copies that dominate); producers > 1: that many threads, each assembling whole batches, delivered in
+    order.  epochs: passes over the records (None: for ever), each with its own shuffle
+    (seed + epoch) -- ONE generator for a whole run keeps its pinned staging ring (page-locking 160 MB per slot takes tens of
+    milliseconds: a generator per epoch would pay that again every time)."""
+    n = len(qa_items.rows) if isinstance(qa_items, _QaTable) else len(qa_items)
+
+    def order_of(epoch):
+        o = np.arange(n)
+        if shuffle:
+            np.random.RandomState(seed + epoch).shuffle(o)
+        return o
+    table = qa_items if isinstance(qa_items, _QaTable) else _QaTable(store, qa_items, num_ans, q_dtype)
+    T = table.q.shape[1]
+    has_a = table.kind is not None
     mk = (lambda *s, dtype: torch.empty(*s, dtype=dtype).pin_memory()) if pin else (lambda *s, dtype: torch.empty(*s, dtype=dtype))
     slots = []
-    for lo in range(0, n, batch_size):
+
+    slot_lock = threading.Lock()
+
+    def assemble(k, job):
+        order, lo = job
         ids = order[lo:lo + batch_size]
         b = len(ids)
-        k = (lo // batch_size) % max(1, ring)
-        if len(slots) <= k:
-            slots.append({"v": mk(batch_size, *store.sample_shape, dtype=region_dtype), "q_idxes": mk(batch_size, T, dtype=torch.long),
-                          "a": mk(batch_size, num_ans, dtype=torch.float32) if has_a else None})
+        with slot_lock:
+            while len(slots) <= k:
+                slots.append({"v": mk(batch_size, *store.sample_shape, dtype=region_dtype), "q_idxes": mk(batch_size, T, dtype=q_dtype),
+                              "a": mk(batch_size, num_ans, dtype=torch.float32) if has_a else None})
         s = slots[k]
-        its = [qa_items[i] for i in ids]
-        rows = [it["v_idx"] if "v_idx" in it else store.index(it["img_filename"]) for it in its]
-        batch = {"v": store.gather(rows, s["v"]), "q_idxes": s["q_idxes"][:b],
-                 "q_id": torch.tensor([int(it.get("q_id", i)) for i, it in zip(ids, its)], dtype=torch.long)}
-        for r, it in enumerate(its):
-            batch["q_idxes"][r].copy_(torch.as_tensor(it["q_idxes"], dtype=torch.long))
+        batch = {"v": store.gather(table.rows[ids], s["v"]), "q_idxes": s["q_idxes"][:b], "q_id": torch.from_numpy(table.q_ids[ids])}
+        batch["q_idxes"].numpy()[...] = table.q[ids]
         if has_a:
             batch["a"] = s["a"][:b]
-            for r, it in enumerate(its):
-                if "a" in it:
-                    batch["a"][r].copy_(torch.as_tensor(it["a"], dtype=torch.float32))
-                else:
-                    soft_target(it["a_10_idx"], num_ans, out=batch["a"][r])
-        yield batch
+            table.fill_answers(batch["a"], ids)
+        return batch
+
+    def jobs():
+        epoch = 0
+        while epochs is None or epoch < epochs:
+            order = order_of(epoch)
+            for lo in range(0, n, batch_size):
+                yield order, lo
+            epoch += 1
+    ring = max(1, ring)
+    if prefetch <= 0:
+        for j, job in enumerate(jobs()):
+            yield assemble(j % ring, job)
+        return
+    if ring < prefetch + 2:
+        raise ValueError("store_batches: ring=%d is too small for prefetch=%d (a slot would be refilled while still in use)" % (ring, prefetch))
+    from collections import deque
+    ex = ThreadPoolExecutor(max(1, int(producers)))
+    window, it = deque(), enumerate(jobs())
+
+    def submit_next():
+        try:
+            j, job = next(it)
+        except StopIteration:
+            return False
+        window.append(ex.submit(assemble, j % ring, job))
+        return True
+    try:
+        for _ in range(prefetch):
+            if not submit_next():
+                break
+        while window:
+            fut = window.popleft()
+            batch = fut.result()
+            submit_next()
+            yield batch
+    finally:
+        for fut in window:
+            fut.cancel()
+        ex.shutdown(wait=True)
