@@ -692,7 +692,7 @@ __host__ __device__ inline size_t packed_tn_bytes(int slabs, int cps, int N1) {
 // One workgroup per (slab, quarter of the slab's chunks): whole rows come in by coalesced 16-byte loads (a row is N1 floats,
 // 8-byte aligned at least), are gated, and cross an LDS tile of 32 rows x (N1 padded) floats to reach the lanes that pack
 // them: lane (r, g) of wave w packs column 16 blk + r, rows 8 g .. 8 g + 7, for the blocks blk = w, w + 4, ...
-constexpr int kPackParts = 18;   // 16 slabs x 18 = 288 workgroups of two chunks at M = 18432
+constexpr int kPackParts = 36;   // 16 slabs x 36 = 576 workgroups of one chunk at M = 18432 (18 parts of two chunks: +5 us per step)
 // Wide G (N1 > 16 kPackMaxBlocks columns: the question encoder's 2400-wide gradients) is packed in column groups of `nblocks`
 // blocks: blockIdx.y = group, its first block blk0 = blockIdx.y * nblocks of the image's nblk_total (gridDim.y == 1, nblk_total ==
 // nblocks: the whole matrix at once, as K5 calls it).
