@@ -1119,19 +1119,20 @@ static __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __res
                                                        int Sb, float scale) {
   const int wblocks = (NK / 4 + 255) / 256;
   if ((int)blockIdx.x >= wblocks) {
-    // 16 columns per block: thread (column tid & 15, row group tid >> 4) adds the rows s = group, group + 16, ... in order,
-    // then the 16 groups' partial sums are added in order
-    __shared__ float part[16][17];
-    const int n = ((int)blockIdx.x - wblocks) * 16 + (threadIdx.x & 15), grp = threadIdx.x >> 4;
+    // 4 columns per block: thread (column tid & 3, row group tid >> 2) adds the rows s = group, group + 64, ... in order, then
+    // the 64 groups' partial sums are added in order (round 6: 64 groups instead of 16 -- pack_tn hands over 576 rows of partial
+    // sums now, and a thread's loads are a chain of dependent latencies)
+    __shared__ float part[64][5];
+    const int n = ((int)blockIdx.x - wblocks) * 4 + (threadIdx.x & 3), grp = threadIdx.x >> 2;
     float a = 0.f;
     if (d_b != nullptr && n < N)
-      for (int s = grp; s < Sb; s += 16) a += dbslab[(size_t)s * N + n];
-    part[grp][threadIdx.x & 15] = a;
+      for (int s = grp; s < Sb; s += 64) a += dbslab[(size_t)s * N + n];
+    part[grp][threadIdx.x & 3] = a;
     __syncthreads();
-    if (d_b != nullptr && threadIdx.x < 16 && n < N) {
+    if (d_b != nullptr && threadIdx.x < 4 && n < N) {
       float t = 0.f;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) t += part[k][threadIdx.x];
+      for (int k = 0; k < 64; ++k) t += part[k][threadIdx.x];
       d_b[n] = t;
     }
     return;
@@ -1149,7 +1150,7 @@ static __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __res
   for (; s < S; ++s) a += *reinterpret_cast<const f32x4*>(src + (size_t)s * NK);
   *reinterpret_cast<f32x4*>(d_w + e) = a * scale;
 }
-inline int slab_sum_blocks(int NK, int N) { return (NK / 4 + 255) / 256 + (N + 15) / 16; }
+inline int slab_sum_blocks(int NK, int N) { return (NK / 4 + 255) / 256 + (N + 3) / 4; }
 
 }  // namespace sp
 }  // namespace vqa
