@@ -156,6 +156,12 @@ def test_counter_rows_are_tied_to_the_kernel_sources(tmp_path):
         fh.write("\n")
     assert all(_srchash.row_is_stale(k, table[k], csrc, inc) for k in keys)
     _srchash._defs.clear()
+    # every kernel a profiler row can name is found in the sources: mangled names (rocprofv3 leaves some __bf16 instances so) and
+    # kernels whose launch bounds hold a parenthesised expression included
+    assert _srchash.kernel_identifier("_ZN3vqa30bilinear_bwd_prep8_bf16_kernelILi2EEEvPKDF16bS2_PKfPDF16bPfS6_iii|grid=131072") == "bilinear_bwd_prep8_bf16_kernel"
+    assert _srchash.kernel_identifier("_ZN3vqa12_GLOBAL__N_121relation_dgrad_kernelILi0EEEvNS0_12RelDgradArgsENS_7DropCfgE|grid=1") == "relation_dgrad_kernel"
+    for k in ("vqa::relation_dgrad_kernel<4>|grid=262144", "_ZN3vqa17column_sum_kernelIDF16bLi2EEEvPKT_iPfiii|grid=131328"):
+        assert _srchash.kernel_fingerprint(k) is not None, k
     # rows without a stamp (tables older than round 6) and rows of kernels that no longer exist are stale too
     assert _srchash.row_is_stale(keys[1], {"FETCH_SIZE_KiB": 1.0})
     assert _srchash.row_is_stale("vqa::no_such_kernel|grid=64", {"source": "0" * 16})

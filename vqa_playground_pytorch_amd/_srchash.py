@@ -53,7 +53,8 @@ def _definitions(csrc=CSRC):
     if key not in _defs:
         table = {}
         # `__global__ [__launch_bounds__(...)] void <identifier>(`
-        pat = re.compile(r"__global__\s+(?:__launch_bounds__\s*\([^)]*\)\s*)?(?:static\s+)?void\s+([A-Za-z_][A-Za-z0-9_]*)\s*\(")
+        # (one level of nested parentheses inside the launch bounds: `__launch_bounds__(kThreads, (TUNE & 4) ? 2 : 1)`)
+        pat = re.compile(r"__global__\s+(?:__launch_bounds__\s*\((?:[^()]|\([^()]*\))*\)\s*)?(?:static\s+)?void\s+([A-Za-z_][A-Za-z0-9_]*)\s*\(")
         for path in source_files(csrc, os.devnull):
             with open(path, "r", errors="replace") as fh:
                 for m in pat.finditer(fh.read()):
@@ -63,8 +64,17 @@ def _definitions(csrc=CSRC):
 
 
 def kernel_identifier(row_key):
-    """'vqa::sp::gemm_nt_kernel<9, 5, ...>|grid=65536' -> 'gemm_nt_kernel'."""
-    name = row_key.split("|")[0].split("<")[0].split("(")[0].strip()
+    """'vqa::sp::gemm_nt_kernel<9, 5, ...>|grid=65536' -> 'gemm_nt_kernel'; a mangled name (rocprofv3 leaves some template instances
+    over __bf16 undemangled: '_ZN3vqa30bilinear_bwd_prep8_bf16_kernelILi2EE...') -> its last length-prefixed component."""
+    name = row_key.split("|")[0].strip()
+    if name.startswith("_Z"):
+        rest, last = name[2:].lstrip("N"), None
+        while rest and rest[0].isdigit():
+            m = re.match(r"(\d+)", rest)
+            n = int(m.group(1))
+            last, rest = rest[m.end():m.end() + n], rest[m.end() + n:]
+        return last or name
+    name = name.split("<")[0].split("(")[0].strip()
     return name.split("::")[-1]
 
 
