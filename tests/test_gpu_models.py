@@ -1219,7 +1219,7 @@ def test_step_is_bitwise_reproducible_and_bf16_transport_is_the_fp32_step(cls, n
         seeds).  Rounds 1-5 were not: K3's backward added the 16 partial sums of every (region, glimpse) pair with LDS float atomics
         in arrival order, and every gradient upstream of the attention logits differed in its last bits between runs
         (tools/determinism_probe.py: 2e-7 ... 6e-7 of a tensor's scale).  Round 6 sums them in a fixed order
-        (csrc/attention_pool.hip: a slot per wave).  [The small-batch form of that backward (B < VQA_K3_FUSED_MIN_B = 512) and the
+        (csrc/attention_pool.hip: a slot per wave).  [The small-batch form of that backward (B < VQA_K3_FUSED_MIN_B: 64 for fp32, 512 for bf16 regions) and the
         pairwise relation backward (relation_mode 0) still use float atomics.]
     (2) VERDICT r05 next #8: region features that cross PCIe as bf16 (feed.store_batches(region_dtype=torch.bfloat16): half the
         bytes of the step's dominant stream) enter the fp32 path through ONE exact widening pass (ops.widen_bf16); on features
