@@ -897,9 +897,11 @@ def main():
                         "launches": launches, "ms_per_step": round(sum(e["ms_per_step"] for e in group), 5),
                         "shapes": [e["shape"] for e in group],
                         "device_kernels": lead.get("device_kernels", PMC_KERNELS.get(name, []))}
-            for k in ("mfma_busy_pct", "valu_issue_pct_min"):
+            for k in ("mfma_busy_pct", "valu_issue_pct_min", "traffic_stale"):
                 if k in lead:
                     dominant[k] = lead[k]
+            if all("trace_ms" in e for e in group):      # the same op in the committed trace of the replayed step, launch-weighted
+                dominant["trace_ms"] = round(sum(e["trace_ms"] * e["launches"] for e in group) / launches, 5)
         else:
             dominant = dict(entries[0])
         kernel_ms = sum(e["ms_per_step"] for e in entries)
