@@ -585,6 +585,56 @@ def test_object_difference_gated_region_gradient(ops, B, N, L, G, p):
     close("d_bias", bt.grad, db)
 
 
+@pytest.mark.parametrize("B,N,L,G,p", [(3, 36, 310, 4, 0.5), (5, 13, 70, 2, 0.5), (140, 36, 310, 4, 0.5), (512, 36, 310, 4, 0.5),
+                                       (600, 36, 310, 4, 0.5), (257, 33, 100, 3, 0.5), (7, 36, 310, 4, 0.0)])
+def test_object_difference_staged_weight_gradient_is_the_unstaged_one(ops, lib_option, B, N, L, G, p):
+    """The weight gradient that keeps the operands of its region loop in LDS (round 6, the default) against the kernel that
+    loads them inside the loop (VQA_K2_WSTAGE=0): same operands, same order of accumulation -- equal bit for bit, groups of
+    one, two and three samples, regions and features that do not fill the tiles."""
+    seed = 77
+    vt0 = g(np.maximum(seeded.seeded_array((B, N, L), 431), 0.0))
+    qt0 = g(np.abs(seeded.seeded_array((B, L), 432)))
+    wt0 = g(seeded.seeded_array((G, N * L), 433, scale=1.0 / np.sqrt(N * L)))
+    bt0 = g(seeded.seeded_array((G,), 434, scale=0.1))
+    gl = g(seeded.seeded_array((B, N, G), 435))
+    grads = []
+    for staged in ("1", "0"):
+        lib_option("VQA_K2_WSTAGE", staged)
+        vt, qt, wt, bt = (t.clone().requires_grad_() for t in (vt0, qt0, wt0, bt0))
+        ops.object_difference_attention(vt, qt, wt, bt, p, seed).backward(gl)
+        grads.append((wt.grad.clone(), vt.grad.clone(), bt.grad.clone()))
+    assert float(grads[0][0].abs().max()) > 0.0
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,N,L,G,p,gate", [(3, 36, 310, 4, 0.5, False), (5, 13, 70, 2, 0.5, True), (140, 36, 310, 4, 0.5, True),
+                                            (600, 36, 310, 4, 0.5, False), (257, 33, 100, 3, 0.5, True), (7, 36, 310, 4, 0.0, True)])
+def test_object_difference_fused_backward_is_the_two_kernel_one(ops, lib_option, B, N, L, G, p, gate):
+    """VQA_K2_FUSED=1 (one pass over the mask for the data and the weight gradient; measured slower, not the default)
+    against the default pair of kernels: the weight gradient bit for bit (same operands, same order), the data gradients
+    -- summed in another fixed order -- within 4 ulp-sized steps of their tensor's scale."""
+    seed = 78
+    vt0 = g(np.maximum(seeded.seeded_array((B, N, L), 441), 0.0))
+    qt0 = g(np.abs(seeded.seeded_array((B, L), 442)))
+    wt0 = g(seeded.seeded_array((G, N * L), 443, scale=1.0 / np.sqrt(N * L)))
+    bt0 = g(seeded.seeded_array((G,), 444, scale=0.1))
+    gl = g(seeded.seeded_array((B, N, G), 445))
+    grads = []
+    for fused in ("1", "0"):
+        lib_option("VQA_K2_FUSED", fused)
+        vt, qt, wt, bt = (t.clone().requires_grad_() for t in (vt0, qt0, wt0, bt0))
+        ops.object_difference_attention(vt, qt, wt, bt, p, seed, gate_dvl=gate).backward(gl)
+        grads.append((wt.grad.clone(), bt.grad.clone(), vt.grad.clone(), qt.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    for name, a, b in (("d_vl", grads[0][2], grads[1][2]), ("d_ql", grads[0][3], grads[1][3])):
+        scale = float(b.abs().max())
+        assert scale > 0.0
+        assert float((a - b).abs().max()) <= 5e-7 * scale * np.sqrt(N), name
+    if gate:
+        assert float(grads[0][2][vt0 <= 0].abs().max()) == 0.0
+
+
 def test_object_difference_mask_is_unbiased(ops):
     """Statistics of the counter-hash mask at the ODA shape: per-region, per-feature and per-pair keep rates."""
     B, N, L, p = 8, 36, 310, 0.5

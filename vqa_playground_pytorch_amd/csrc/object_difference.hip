@@ -442,6 +442,487 @@ __global__ __launch_bounds__(512) void oda_bwd_weight_mfma_kernel(const float* _
   }
 }
 
+// The same product with NO memory access inside the region loop (round 6).  The kernel above fetches T_i[d] and dS[b][i][.] of the
+// next four regions with eight buffer loads per pass of its i loop; the compiler sinks them to the end of the pass and waits
+// for them at the top of the next -- every pass pays a first-touch latency (a wave reads its own 64-byte piece of 36 rows
+// of vl per set: nothing it touches was touched before) and the counters show it: 37 % of the SIMD cycles issue a VALU
+// instruction, 14 % an MFMA.  But the wave already HOLDS those values: lane (k, r) keeps T_j[d] of regions j = 4 jg + r -- all
+// 36 regions of the wave's 16 features between the four lanes of a block.  It writes them once per (set, sample) to a
+// wave-private piece of LDS, [16 features][kOdaTS regions], next to the sample's dS as [4 glimpses][kOdaTS] (zero beyond N
+// and G), and the region loop reads four T_i and four dS with two ds_read_b128 (same address across a quad: broadcast).
+// The raw vl / dS / ql values of the NEXT (set, sample) are loaded while the current one is multiplied.  Same operands,
+// same order of accumulation: bit-identical to the kernel above (tests/test_gpu_oda.py).
+constexpr int kOdaTS = 40;   // floats per row of the staged tiles (36 regions + 4: rows stay 16-byte aligned)
+// v & (bit `off` of bits ? ~0 : 0), the bit index in a scalar register (wave-uniform): the region loop hands the index of its
+// region instead of shifting nine mask words per pass
+__device__ __forceinline__ float keep_bit_at(float v, uint32_t bits, int off) {
+  uint32_t m;
+  asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(bits), "s"(off));
+  return __uint_as_float(__float_as_uint(v) & m);
+}
+// JH = 2: the nine region groups of a lane split 5 + 4 over two waves -- 16 waves per workgroup, four per SIMD, under 128
+// registers each (36 -> 20 accumulators); every wave still stages the whole T tile for itself.  Two waves per SIMD issue
+// during half of their cycles only (counters: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES), whatever is staged.
+template <bool MASK, int JH>
+__global__ __launch_bounds__(512 * JH) void oda_bwd_weight_mfma_staged_kernel(const float* __restrict__ vl,
+                                                                              const float* __restrict__ ql,
+                                                                              const float* __restrict__ dS, float* __restrict__ slab,
+                                                                              DropCfg dc, int B, int N, int L, int G,
+                                                                              int samples_per_group) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ex_s = reinterpret_cast<float*>(smem);            // [2][nwaves][4 kOdaIG][64]: the odd slot's accumulators of a set,
+                                                           // two buffers in turn (one barrier per set)
+  const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x / (128 * JH);
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wid % nwaves, sw = (wid / nwaves) & 1, jh = wid / (2 * nwaves);
+  const int k = lane >> 2, r = lane & 3;
+  float* Tw = ex_s + (size_t)2 * nwaves * (4 * kOdaIG) * 64 + (size_t)wid * (20 * kOdaTS);   // [16][kOdaTS], wave-private
+  float* Sw = Tw + 16 * kOdaTS;                                                               // [4][kOdaTS]
+  const int sg = blockIdx.x;
+  const int NI = (N + 31) >> 5;
+  const uint32_t key = MASK ? drop_key(dc) : 0u;
+  const uint32_t stride = (uint32_t)N * (uint32_t)L;
+  const int b_lo = sg * samples_per_group, b_hi = min(B, b_lo + samples_per_group);
+  const rt::rsrc_t Vb = rt::make_rsrc(vl, (size_t)B * N * L * 4);
+  const rt::rsrc_t Sb = rt::make_rsrc(dS, (size_t)B * N * G * 4);
+  const rt::rsrc_t Qb = rt::make_rsrc(ql, (size_t)B * L * 4);
+  const rt::rsrc_t Wb = rt::make_rsrc(slab + (size_t)sg * G * N * L, (size_t)G * N * L * 4);   // this group's slab
+  const int nsets = (L + 15) >> 4;
+  const int nb = (b_hi - b_lo - sw + 1) / 2;                  // samples b_lo + sw, b_lo + sw + 2, ... of this slot
+  const int max_sets = (nsets + nwaves - 1) / nwaves;         // every wave runs the same number of set rounds (barriers inside)
+  // what a (set, sample) needs from memory: vl of the lane's nine regions, the lane's three entries of the [36][4] dS tile, ql[d]
+  struct Raw {
+    float v[kOdaIG], s[3], q;
+  };
+  auto fetch = [&](Raw& o, int si, int bi) {
+    const int ds = wave + si * nwaves;
+    const int d = 16 * ds + k;
+    const uint32_t vo = (uint32_t)((ds < nsets && d < L) ? d : 0) * 4u;
+    const int b = b_lo + sw + 2 * bi;
+    const uint32_t row0 = (uint32_t)b * stride * 4u;
+#pragma unroll
+    for (int jg = 0; jg < kOdaIG; ++jg) o.v[jg] = rt::ldg4(Vb, vo + (uint32_t)min(4 * jg + r, N - 1) * (uint32_t)L * 4u, row0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int e = lane + 64 * t, i = e >> 2, g = e & 3;
+      const float a = rt::ldg4(Sb, (uint32_t)(min(i, N - 1) * G + min(g, G - 1)) * 4u, (uint32_t)b * (uint32_t)(N * G) * 4u);
+      o.s[t] = (i < N && g < G) ? a : 0.f;
+    }
+    o.q = rt::ldg4(Qb, vo, (uint32_t)b * (uint32_t)L * 4u);
+  };
+  auto arrived = [&](Raw& o) {
+#pragma unroll
+    for (int jg = 0; jg < kOdaIG; ++jg) asm volatile("" : "+v"(o.v[jg]));
+    asm volatile("" : "+v"(o.s[0]), "+v"(o.s[1]), "+v"(o.s[2]), "+v"(o.q));
+  };
+  // region groups J0 .. J1 - 1 of the lane (all nine, or this wave's half)
+  auto run = [&](auto j0_, auto j1_) {
+    constexpr int J0 = decltype(j0_)::value, J1 = decltype(j1_)::value, NJ = J1 - J0;
+    Raw cur;
+    if (nb > 0 && wave < nsets) {
+      fetch(cur, 0, 0);
+      arrived(cur);      // (before the loops start: a wait for them inside would also wait for the stores of the set before)
+    }
+    oda_f32x4 acc[NJ];
+    for (int si = 0; si < max_sets; ++si) {
+      const int ds = wave + si * nwaves;
+      const int d = 16 * ds + k;
+      const bool set_ok = ds < nsets;
+      const bool dok = set_ok && d < L;
+      const int dcl = dok ? d : 0;
+#pragma unroll
+      for (int jg = 0; jg < NJ; ++jg) acc[jg] = oda_f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int bi = 0; bi < (set_ok ? nb : 0); ++bi) {
+        const int b = b_lo + sw + 2 * bi;
+        // the next (set, sample) of this wave, in flight while this one is multiplied
+        Raw nxt;
+        {
+          const bool last_b = bi + 1 >= nb;
+          const int si2 = last_b ? si + 1 : si, bi2 = last_b ? 0 : bi + 1;
+          if (si2 < max_sets && wave + si2 * nwaves < nsets) fetch(nxt, si2, bi2);
+        }
+        float Tj[NJ];
+        uint32_t w0[NJ], w1[NJ];
+#pragma unroll
+        for (int jg = 0; jg < kOdaIG; ++jg) {
+          float t = cur.v[jg] * cur.q;
+          asm("" : "+v"(t));                  // (a ROUNDED product on both sides of T_i - T_j, as above)
+          Tw[k * kOdaTS + 4 * jg + r] = t;    // (regions beyond N: copies of region N - 1, finite, times dS = 0)
+          if (jg >= J0 && jg < J1) {
+            Tj[jg - J0] = t;
+            if constexpr (MASK) {
+              const int j = min(4 * jg + r, N - 1);
+              const uint32_t cnt = (uint32_t)b * (uint32_t)NI * stride + (uint32_t)j * (uint32_t)L + (uint32_t)dcl;
+              w0[jg - J0] = mask_word32(cnt, key);
+              w1[jg - J0] = NI > 1 ? mask_word32(cnt + stride, key) : 0u;
+            }
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int e = lane + 64 * t;
+          if (e < 4 * 36) Sw[(e & 3) * kOdaTS + (e >> 2)] = cur.s[t];
+        }
+        // (wave-private tiles: the wave's own LDS operations complete in order, no barrier)
+        oda_f32x4 ta = *reinterpret_cast<const oda_f32x4*>(Tw + k * kOdaTS);
+        oda_f32x4 sa = *reinterpret_cast<const oda_f32x4*>(Sw + r * kOdaTS);
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0), once per (set, sample): see the end of a pass
+        // four regions i0 .. i0 + 3; region i0 + ii is bit bit0 + ii of the words wv
+        auto pass = [&](int i0, const uint32_t (&wv)[NJ], int bit0) {
+          const int in = min(i0 + 4, 32);
+          const oda_f32x4 tn = *reinterpret_cast<const oda_f32x4*>(Tw + k * kOdaTS + in);
+          const oda_f32x4 sn = *reinterpret_cast<const oda_f32x4*>(Sw + r * kOdaTS + in);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // (the two reads FIRST: left alone they sink to the end of the
+                                                                  //  pass and every pass waits for them)
+          static_for<4>([&](auto ii_) {
+            constexpr int ii = decltype(ii_)::value;
+            const float Ti = ta[ii];
+            const float av = sa[ii];          // (zero beyond N and G; a lane beyond L accumulates finite values nobody stores)
+            float x[NJ];
+            const f32x2 ti2 = f32x2{Ti, Ti};
+#pragma unroll
+            for (int h = 0; h < NJ / 2; ++h) {
+              const f32x2 d2 = ti2 - f32x2{Tj[2 * h], Tj[2 * h + 1]};
+              x[2 * h] = d2[0];
+              x[2 * h + 1] = d2[1];
+            }
+            if constexpr (NJ & 1) x[NJ - 1] = Ti - Tj[NJ - 1];
+            if constexpr (MASK) {
+#pragma unroll
+              for (int jg = 0; jg < NJ; ++jg) x[jg] = keep_bit_at(x[jg], wv[jg], bit0 + ii);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x002, (MASK ? 2 * NJ : 0) + NJ / 2 + (NJ & 1), 0);
+#pragma unroll
+            for (int jg = 0; jg < NJ; ++jg) acc[jg] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, x[jg], acc[jg], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NJ, 0);
+          });
+          __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the two reads, issued a pass ago, for the compiler's bookkeeping too
+                                               // (it cannot count across the back edge and would wait at the top, behind the
+                                               //  reads it has just issued)
+          ta = tn;
+          sa = sn;
+        };
+        const int n_lo = min(N, 32);
+        for (int i0 = 0; i0 < n_lo; i0 += 4) pass(i0, w0, i0);
+        if (N > 32) pass(32, w1, 0);
+        cur = nxt;
+        // (in registers HERE, a whole (set, sample) after the loads were issued: left to the compiler the wait moves behind
+        //  the stores of the set's epilogue and waits for them as well)
+        arrived(cur);
+      }
+      // the two sample slots of a set meet: slot 1 hands its accumulators over, slot 0 adds and stores
+      float* ex = ex_s + ((size_t)(si & 1) * nwaves + wave) * (4 * kOdaIG) * 64 + lane;
+      if (sw == 1) {
+#pragma unroll
+        for (int jg = 0; jg < NJ; ++jg)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) ex[(4 * (J0 + jg) + t) * 64] = acc[jg][t];
+      }
+      __syncthreads();
+      if (sw == 0 && dok) {
+        const float sc = MASK ? dc.scale : 1.f;
+        float e[NJ][4];
+#pragma unroll
+        for (int jg = 0; jg < NJ; ++jg)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) e[jg][t] = ex[(4 * (J0 + jg) + t) * 64];      // (all reads in flight, then the stores)
+#pragma unroll
+        for (int jg = 0; jg < NJ; ++jg) {
+          const int j = 4 * (J0 + jg) + r;
+          if (j < N) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (t < G)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, (acc[jg][t] + e[jg][t]) * sc), Wb,
+                                                      (int)(((uint32_t)(t * N + j) * (uint32_t)L + (uint32_t)d) * 4u), 0, 0);
+          }
+        }
+      }
+      // (no second barrier: the next set hands over in the other buffer, and its barrier is behind these reads)
+    }
+  };
+  using std::integral_constant;
+  if constexpr (JH == 1) {
+    run(integral_constant<int, 0>{}, integral_constant<int, kOdaIG>{});
+  } else {
+    constexpr int kHalf = (kOdaIG + 1) / 2;
+    if (jh == 0) run(integral_constant<int, 0>{}, integral_constant<int, kHalf>{});
+    else run(integral_constant<int, kHalf>{}, integral_constant<int, kOdaIG>{});
+  }
+}
+
+// ---- the whole backward in ONE pass over the mask (round 6) ---------------------------------------------------------------
+// The data gradient (oda_bwd_data_bits_split_kernel) and the weight gradient above each regenerate the mask and each walk
+// the 401 760 (i, j, d) elements of a sample; both are VALU-issue bound (counters: 88 % and 64-99 % of the SIMD cycles).  One
+// kernel in the weight gradient's layout does both: a lane that holds the masked difference x = keep (T_i - T_j) of its
+// (j, d) for the matrix instruction also forms u = sum_g dS[b,i,g] w[g,j,d] (the filter rows of its nine regions live in 36
+// registers for a whole feature set, dS[b][i][0..3] comes from LDS as one broadcast read) and masks it with the SAME
+// sign-extended bit:
+//   dT[j][d] -= keep u  -- a register per region of the lane, summed over i;
+//   dT[i][d] += keep u  -- summed over the lane's nine regions in registers, over the four lanes of the block by DPP, one value
+//                          per lane and pass written to a wave-private LDS row;
+// and a (set, sample) ends with d_vl = dT ql (gated) and d_ql = sum_n dT[n] vl[n] for its 16 features -- complete, no other wave
+// contributes.  Per element: 62 / 9 lane-operations + the MFMA against 23 / 9 + MFMA here and 6.7 in the data kernel.
+// The weight gradient's arithmetic and order are those of the staged kernel (bit-identical); the data gradient sums in a
+// different (fixed) order than the kernel it replaces.  MEASURED SLOWER than the two kernels (154 against 140 us for the
+// backward at B = 512: 256 registers, two waves per SIMD, ~60 % issue) -- kept behind VQA_K2_FUSED=1 as the record of the probe.
+template <bool MASK>
+__global__ __launch_bounds__(512) void oda_bwd_fused_kernel(const float* __restrict__ vl, const float* __restrict__ ql,
+                                                            const float* __restrict__ w, const float* __restrict__ dS,
+                                                            float* __restrict__ d_vl, float* __restrict__ d_ql,
+                                                            float* __restrict__ slab, DropCfg dc, int B, int N, int L, int G,
+                                                            int samples_per_group, int gate) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ex_s = reinterpret_cast<float*>(smem);            // [2][nwaves][4 kOdaIG][64]: see the staged kernel
+  const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 7;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wid % nwaves, sw = wid / nwaves;
+  const int k = lane >> 2, r = lane & 3;
+  constexpr int kWaveTile = (16 + 4 + 16 + 16) * kOdaTS + 36 * 4;
+  float* Tw = ex_s + (size_t)2 * nwaves * (4 * kOdaIG) * 64 + (size_t)wid * kWaveTile;   // [16][kOdaTS]  T_i[d]
+  float* Sw = Tw + 16 * kOdaTS;                                                          // [4][kOdaTS]   dS[i][g] as [g][i]
+  float* Dw = Sw + 4 * kOdaTS;                                                           // [16][kOdaTS]  sum_j keep u, per i
+  float* Vw = Dw + 16 * kOdaTS;                                                          // [16][kOdaTS]  vl[n][d] as loaded
+  float* Sa = Vw + 16 * kOdaTS;                                                          // [36][4]       dS[i][0..3]
+  const int sg = blockIdx.x;
+  const int NI = (N + 31) >> 5;
+  const uint32_t key = MASK ? drop_key(dc) : 0u;
+  const uint32_t stride = (uint32_t)N * (uint32_t)L;
+  const int b_lo = sg * samples_per_group, b_hi = min(B, b_lo + samples_per_group);
+  const rt::rsrc_t Vb = rt::make_rsrc(vl, (size_t)B * N * L * 4);
+  const rt::rsrc_t Sb = rt::make_rsrc(dS, (size_t)B * N * G * 4);
+  const rt::rsrc_t Qb = rt::make_rsrc(ql, (size_t)B * L * 4);
+  const rt::rsrc_t Fb = rt::make_rsrc(w, (size_t)G * N * L * 4);
+  const rt::rsrc_t Wb = rt::make_rsrc(slab + (size_t)sg * G * N * L, (size_t)G * N * L * 4);   // this group's slab
+  const rt::rsrc_t DVb = rt::make_rsrc(d_vl, (size_t)B * N * L * 4);
+  const int nsets = (L + 15) >> 4;
+  const int nb = (b_hi - b_lo - sw + 1) / 2;                  // samples b_lo + sw, b_lo + sw + 2, ... of this slot
+  const int max_sets = (nsets + nwaves - 1) / nwaves;
+  struct Raw {
+    float v[kOdaIG], s[3], q;
+  };
+  auto fetch = [&](Raw& o, int si, int bi) {
+    const int ds = wave + si * nwaves;
+    const int d = 16 * ds + k;
+    const uint32_t vo = (uint32_t)((ds < nsets && d < L) ? d : 0) * 4u;
+    const int b = b_lo + sw + 2 * bi;
+    const uint32_t row0 = (uint32_t)b * stride * 4u;
+#pragma unroll
+    for (int jg = 0; jg < kOdaIG; ++jg) o.v[jg] = rt::ldg4(Vb, vo + (uint32_t)min(4 * jg + r, N - 1) * (uint32_t)L * 4u, row0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int e = lane + 64 * t, i = e >> 2, g = e & 3;
+      const float a = rt::ldg4(Sb, (uint32_t)(min(i, N - 1) * G + min(g, G - 1)) * 4u, (uint32_t)b * (uint32_t)(N * G) * 4u);
+      o.s[t] = (i < N && g < G) ? a : 0.f;
+    }
+    o.q = rt::ldg4(Qb, vo, (uint32_t)b * (uint32_t)L * 4u);
+  };
+  auto arrived = [&](Raw& o) {
+#pragma unroll
+    for (int jg = 0; jg < kOdaIG; ++jg) asm volatile("" : "+v"(o.v[jg]));
+    asm volatile("" : "+v"(o.s[0]), "+v"(o.s[1]), "+v"(o.s[2]), "+v"(o.q));
+  };
+  constexpr int NP = kOdaIG / 2;       // pairs of region groups (packed operations) + one single
+  Raw cur;
+  if (nb > 0 && wave < nsets) {
+    fetch(cur, 0, 0);
+    arrived(cur);
+  }
+  oda_f32x4 acc[kOdaIG];
+  for (int si = 0; si < max_sets; ++si) {
+    const int ds = wave + si * nwaves;
+    const int d = 16 * ds + k;
+    const bool set_ok = ds < nsets;
+    const bool dok = set_ok && d < L;
+    const int dcl = dok ? d : 0;
+#pragma unroll
+    for (int jg = 0; jg < kOdaIG; ++jg) acc[jg] = oda_f32x4{0.f, 0.f, 0.f, 0.f};
+    // the filter rows of the lane's regions, this feature set: F2[g][h] = (w[g][8h + r], w[g][8h + 4 + r]), F1[g] = w[g][32 + r];
+    // zero for a region beyond N and a glimpse beyond G (such u are zero and add nothing to either sum)
+    f32x2 F2[4][NP];
+    float F1[4];
+    if (set_ok && nb > 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float f[kOdaIG];
+#pragma unroll
+        for (int jg = 0; jg < kOdaIG; ++jg) {
+          const int j = 4 * jg + r;
+          const float x = rt::ldg4(Fb, (uint32_t)((min(g, G - 1) * N + min(j, N - 1)) * L + dcl) * 4u, 0u);
+          f[jg] = (g < G && j < N) ? x : 0.f;
+        }
+#pragma unroll
+        for (int h = 0; h < NP; ++h) F2[g][h] = f32x2{f[2 * h], f[2 * h + 1]};
+        F1[g] = f[kOdaIG - 1];
+      }
+    }
+    for (int bi = 0; bi < (set_ok ? nb : 0); ++bi) {
+      const int b = b_lo + sw + 2 * bi;
+      Raw nxt;
+      {
+        const bool last_b = bi + 1 >= nb;
+        const int si2 = last_b ? si + 1 : si, bi2 = last_b ? 0 : bi + 1;
+        if (si2 < max_sets && wave + si2 * nwaves < nsets) fetch(nxt, si2, bi2);
+      }
+      f32x2 Tj2[NP], dTj2[NP];
+      float Tj1, dTj1 = 0.f;
+      uint32_t w0[kOdaIG], w1[kOdaIG];
+      const float qd = cur.q * (MASK ? dc.scale : 1.f);       // (the kept values' factor 2 rides on q, as in the data kernel)
+#pragma unroll
+      for (int jg = 0; jg < kOdaIG; ++jg) {
+        Vw[k * kOdaTS + 4 * jg + r] = cur.v[jg];
+        float t = cur.v[jg] * cur.q;
+        asm("" : "+v"(t));                  // (a ROUNDED product on both sides of T_i - T_j)
+        Tw[k * kOdaTS + 4 * jg + r] = t;
+        if (jg == kOdaIG - 1) Tj1 = t;
+        else if (jg & 1) Tj2[jg >> 1].y = t;
+        else Tj2[jg >> 1].x = t;
+        if constexpr (MASK) {
+          const int j = min(4 * jg + r, N - 1);
+          const uint32_t cnt = (uint32_t)b * (uint32_t)NI * stride + (uint32_t)j * (uint32_t)L + (uint32_t)dcl;
+          w0[jg] = mask_word32(cnt, key);
+          w1[jg] = NI > 1 ? mask_word32(cnt + stride, key) : 0u;
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < NP; ++h) dTj2[h] = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int e = lane + 64 * t;
+        if (e < 4 * 36) {
+          Sw[(e & 3) * kOdaTS + (e >> 2)] = cur.s[t];
+          Sa[e] = cur.s[t];
+        }
+      }
+      oda_f32x4 ta = *reinterpret_cast<const oda_f32x4*>(Tw + k * kOdaTS);
+      oda_f32x4 sa = *reinterpret_cast<const oda_f32x4*>(Sw + r * kOdaTS);
+      oda_f32x4 a_cur = *reinterpret_cast<const oda_f32x4*>(Sa);          // dS[i][0..3] of the region in hand, one read ahead
+      __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0), once per (set, sample)
+      auto pass = [&](int i0, const uint32_t (&wv)[kOdaIG], int bit0) {
+        const int in = min(i0 + 4, 32);
+        const oda_f32x4 tn = *reinterpret_cast<const oda_f32x4*>(Tw + k * kOdaTS + in);
+        const oda_f32x4 sn = *reinterpret_cast<const oda_f32x4*>(Sw + r * kOdaTS + in);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);        // (the reads FIRST)
+        float s4[4];
+        static_for<4>([&](auto ii_) {
+          constexpr int ii = decltype(ii_)::value;
+          const float Ti = ta[ii];
+          const float av = sa[ii];
+          const oda_f32x4 a = a_cur;
+          a_cur = *reinterpret_cast<const oda_f32x4*>(Sa + 4 * (ii < 3 ? i0 + ii + 1 : in));
+          const f32x2 ti2 = f32x2{Ti, Ti};
+          f32x2 x2[NP], u2[NP];
+          float x1, u1;
+#pragma unroll
+          for (int h = 0; h < NP; ++h) {
+            x2[h] = ti2 - Tj2[h];
+            u2[h] = F2[0][h] * f32x2{a[0], a[0]};
+          }
+          x1 = Ti - Tj1;
+          u1 = F1[0] * a[0];
+#pragma unroll
+          for (int g = 1; g < 4; ++g) {
+#pragma unroll
+            for (int h = 0; h < NP; ++h) u2[h] = __builtin_elementwise_fma(F2[g][h], f32x2{a[g], a[g]}, u2[h]);
+            u1 = fmaf(F1[g], a[g], u1);
+          }
+          if constexpr (MASK) {
+#pragma unroll
+            for (int h = 0; h < NP; ++h) {
+              uint32_t m0, m1;
+              asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m0) : "v"(wv[2 * h]), "s"(bit0 + ii));
+              asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m1) : "v"(wv[2 * h + 1]), "s"(bit0 + ii));
+              x2[h] = f32x2{__uint_as_float(__float_as_uint(x2[h].x) & m0), __uint_as_float(__float_as_uint(x2[h].y) & m1)};
+              u2[h] = f32x2{__uint_as_float(__float_as_uint(u2[h].x) & m0), __uint_as_float(__float_as_uint(u2[h].y) & m1)};
+            }
+            uint32_t m8;
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m8) : "v"(wv[kOdaIG - 1]), "s"(bit0 + ii));
+            x1 = __uint_as_float(__float_as_uint(x1) & m8);
+            u1 = __uint_as_float(__float_as_uint(u1) & m8);
+          }
+          f32x2 t2 = u2[0];
+#pragma unroll
+          for (int h = 0; h < NP; ++h) {
+            dTj2[h] += u2[h];
+            if (h > 0) t2 += u2[h];
+          }
+          dTj1 += u1;
+          s4[ii] = (t2.x + t2.y) + u1;
+#pragma unroll
+          for (int h = 0; h < NP; ++h) {
+            acc[2 * h] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, x2[h].x, acc[2 * h], 0, 0, 0);
+            acc[2 * h + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, x2[h].y, acc[2 * h + 1], 0, 0, 0);
+          }
+          acc[kOdaIG - 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, x1, acc[kOdaIG - 1], 0, 0, 0);
+        });
+        // the four lanes of a block meet: lane r leaves with the sum of region i0 + r
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          s4[ii] += dpp_mov<0xB1>(s4[ii]);   // quad_perm [1,0,3,2]
+          s4[ii] += dpp_mov<0x4E>(s4[ii]);   // quad_perm [2,3,0,1]
+        }
+        const float mine = r == 0 ? s4[0] : r == 1 ? s4[1] : r == 2 ? s4[2] : s4[3];
+        Dw[k * kOdaTS + i0 + r] = mine;
+        __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): see the staged kernel
+        ta = tn;
+        sa = sn;
+      };
+      const int n_lo = min(N, 32);
+      for (int i0 = 0; i0 < n_lo; i0 += 4) pass(i0, w0, i0);
+      if (N > 32) pass(32, w1, 0);
+      // the data gradient of this sample's 16 features: dT[n] = (sum over j, from the LDS row) - (sum over i, in registers)
+      {
+        float dq = 0.f;
+#pragma unroll
+        for (int jg = 0; jg < kOdaIG; ++jg) {
+          const int n = 4 * jg + r;
+          const float over_i = jg == kOdaIG - 1 ? dTj1 : (jg & 1) ? dTj2[jg >> 1].y : dTj2[jg >> 1].x;
+          const float dT = Dw[k * kOdaTS + n] - over_i;         // (a row beyond N may never have been written: not used)
+          const float vn = Vw[k * kOdaTS + n];
+          if (dok && n < N) {
+            const float out = (gate != 0 && !(vn > 0.f)) ? 0.f : dT * qd;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, out), DVb,
+                                                  (int)(((uint32_t)(b * N + n) * (uint32_t)L + (uint32_t)d) * 4u), 0, 0);
+            dq = fmaf(dT, vn, dq);
+          }
+        }
+        dq += dpp_mov<0xB1>(dq);
+        dq += dpp_mov<0x4E>(dq);
+        if (dok && r == 0) d_ql[(size_t)b * L + d] = dq * (MASK ? dc.scale : 1.f);
+      }
+      cur = nxt;
+      arrived(cur);
+    }
+    float* ex = ex_s + ((size_t)(si & 1) * nwaves + wave) * (4 * kOdaIG) * 64 + lane;
+    if (sw == 1) {
+#pragma unroll
+      for (int jg = 0; jg < kOdaIG; ++jg)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ex[(4 * jg + t) * 64] = acc[jg][t];
+    }
+    __syncthreads();
+    if (sw == 0 && dok) {
+      const float sc = MASK ? dc.scale : 1.f;
+      float e[kOdaIG][4];
+#pragma unroll
+      for (int jg = 0; jg < kOdaIG; ++jg)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) e[jg][t] = ex[(4 * jg + t) * 64];
+#pragma unroll
+      for (int jg = 0; jg < kOdaIG; ++jg) {
+        const int j = 4 * jg + r;
+        if (j < N) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (t < G)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, (acc[jg][t] + e[jg][t]) * sc), Wb,
+                                                    (int)(((uint32_t)(t * N + j) * (uint32_t)L + (uint32_t)d) * 4u), 0, 0);
+        }
+      }
+    }
+  }
+}
+
 // (Measured on the data-gradient kernel below, B = 512: 14 us of prologue + epilogue, 60 us in the j loop, 4 us of it the hash;
 //  removing a third of its lane-operations (packed pairs, independent chains) or prefetching the filter rows one or two
 //  regions ahead moves it by 2 us -- the SIMDs that hold 3 of the 10 waves of a CU set the time.)
@@ -565,6 +1046,7 @@ __global__ void oda_bwd_data_bits_split_kernel(const float* __restrict__ vl, con
   for (int t = tid; t < (N + kIC) * G; t += blockDim.x) dS_s[t] = t < N * G ? dS[(size_t)b * N * G + t] : 0.f;
   __syncthreads();
   float* mine = dT_s + (size_t)c * N * 64 + lane;       // this wave's plane: row n at mine[n * 64]
+  float vn_pre[kIC], ql_pre;      // vl of the output rows this wave finishes with (n = c, c + NC, ...) and ql: see below
   {
     const int i0 = c * kIC;
     const int sh = i0 & 31;
@@ -604,6 +1086,20 @@ __global__ void oda_bwd_data_bits_split_kernel(const float* __restrict__ vl, con
     load_w(wa, 0);
     load_w(wb, 1);
     load_w(wc, 2);
+    // vl of the wave's output rows and ql: asked for HERE, behind the first filter rows (loads return in order), used behind
+    // the region loop.  (Loaded where they are used, one row at a time, each was a first touch of HBM with nothing else to do:
+    // 38 % of the wave cycles inside s_waitcnt, round 6.)
+#pragma unroll
+    for (int q = 0; q < kIC; ++q) vn_pre[q] = vlb[(size_t)min(c + q * NC, N - 1) * L + d];
+    ql_pre = ql[(size_t)b * L + d];
+    // The row a pass starts with must have arrived, the two behind it stay in flight.  Said before the loop and at the end
+    // of a pass: the compiler does not count loads across the back edge and would wait for vmcnt(0) at the top -- for the
+    // rows it had issued a few instructions earlier.
+    auto arrived = [&](float (&wr)[G]) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) asm volatile("" : "+v"(wr[g]));
+    };
+    arrived(wa);
     for (int j = 0; j < N; j += 3) {
       one_j(j, wa);
       load_w(wa, j + 3);
@@ -611,6 +1107,7 @@ __global__ void oda_bwd_data_bits_split_kernel(const float* __restrict__ vl, con
       load_w(wb, j + 4);
       if (j + 2 < N) one_j(j + 2, wc);
       load_w(wc, j + 5);
+      arrived(wa);
     }
 #pragma unroll
     for (int ip = 0; ip < kIC / 2; ++ip) {      // (the wave's own column of its own plane: written above, by this lane)
@@ -619,14 +1116,18 @@ __global__ void oda_bwd_data_bits_split_kernel(const float* __restrict__ vl, con
     }
   }
   __syncthreads();
-  const float qd = ql[(size_t)b * L + d] * dc.scale;      // (the kept values' factor 2 rides on q here)
+  const float qd = ql_pre * dc.scale;                     // (the kept values' factor 2 rides on q here)
   float dq = 0.f;
-  for (int n = c; n < N; n += NC) {                       // the output rows, dealt over the waves
-    float t = 0.f;
-    for (int q = 0; q < NC; ++q) t += dT_s[((size_t)q * N + n) * 64 + lane];    // fixed order
-    const float vn = vlb[(size_t)n * L + d];
-    if (active) d_vl[((size_t)b * N + n) * L + d] = (gate != 0 && !(vn > 0.f)) ? 0.f : t * qd;
-    dq = fmaf(t, vn, dq);
+#pragma unroll
+  for (int qn = 0; qn < kIC; ++qn) {                      // the output rows, dealt over the waves
+    const int n = c + qn * NC;
+    if (n < N) {
+      float t = 0.f;
+      for (int q = 0; q < NC; ++q) t += dT_s[((size_t)q * N + n) * 64 + lane];    // fixed order
+      const float vn = vn_pre[qn];
+      if (active) d_vl[((size_t)b * N + n) * L + d] = (gate != 0 && !(vn > 0.f)) ? 0.f : t * qd;
+      dq = fmaf(t, vn, dq);
+    }
   }
   dq_s[c * 64 + lane] = dq;
   __syncthreads();
@@ -1044,6 +1545,30 @@ template <int G>
 static int launch_bwd(const float* vl, const float* ql, const float* w, const float* dS, float* d_vl, float* d_ql,
                       float* d_w, float* d_bias, float* slab, DropCfg dc, int B, int N, int L, int gate_dvl, hipStream_t s) {
   const int nt = oda_threads(L);
+  // One pass over the mask for both gradients: VQA_K2_FUSED=1.  NOT the default -- measured on one box, alternating
+  // (tools/ab_knob.sh, B = 512): the backward 154 us fused against 140 us with the two kernels below; the fused kernel needs
+  // all 256 registers (two waves per SIMD) and issues during ~60 % of its cycles, the data-gradient kernel below during 88 %
+  // (docs/measured_negatives_r06.md).
+  if (oda_mfma_ok(dc, B, N, L, G) && vqa::option_is("VQA_K2_FUSED", '1')) {
+    int SG = oda_mfma_groups(B);
+    const int spg = (B + SG - 1) / SG;
+    SG = (B + spg - 1) / spg;
+    const int nsets = (L + 15) / 16, nw = nsets < 4 ? nsets : 4;
+    const size_t lds_f = ((size_t)2 * nw * 4 * kOdaIG * 64 + (size_t)2 * nw * ((16 + 4 + 16 + 16) * kOdaTS + 36 * 4)) * sizeof(float);
+    if (dc.p8 > 0) {
+      VQA_ENSURE_LDS((oda_bwd_fused_kernel<true>), lds_f);
+      VQA_LAUNCH((oda_bwd_fused_kernel<true>), dim3(SG), dim3(128 * nw), lds_f, s, vl, ql, w, dS, d_vl, d_ql, slab, dc, B, N, L, G,
+                 spg, gate_dvl);
+    } else {
+      VQA_ENSURE_LDS((oda_bwd_fused_kernel<false>), lds_f);
+      VQA_LAUNCH((oda_bwd_fused_kernel<false>), dim3(SG), dim3(128 * nw), lds_f, s, vl, ql, w, dS, d_vl, d_ql, slab, dc, B, N, L, G,
+                 spg, gate_dvl);
+    }
+    const size_t n = (size_t)G * N * L;
+    VQA_LAUNCH(oda_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, slab, d_w, n, SG);
+    VQA_LAUNCH(oda_dbias_kernel<G>, dim3(1), dim3(1024), 0, s, dS, d_bias, B * N);
+    return check_launch("object_difference_attention_bwd");
+  }
   {
     const size_t lds = ((size_t)N * nt + (size_t)(N + kIC) * G) * sizeof(float);   // (+ kIC zero rows of dS, bit-mask kernel)
     VQA_REQUIRE(lds <= 160 * 1024, VQA_E_UNSUPPORTED, "object_difference_attention_bwd: N=%d L=%d need %zu B of LDS", N, L, lds);
@@ -1077,7 +1602,21 @@ static int launch_bwd(const float* vl, const float* ql, const float* w, const fl
       const int nsets = (L + 15) / 16, nw = nsets < 4 ? nsets : 4;
       const size_t lds_m = (size_t)nw * 4 * kOdaIG * 64 * sizeof(float);
       const bool pk = !vqa::option_is("VQA_K2_PK", '0');     // packed subtracts (round 4; "0" = the scalar form, for A/B)
-      if (dc.p8 > 0 && pk) {
+      const bool staged = pk && !vqa::option_is("VQA_K2_WSTAGE", '0');   // operands of the region loop from LDS (round 6)
+      const bool halves = vqa::option_is("VQA_K2_WSTAGE", '2');          // "2": 16 waves per workgroup (measured: the same time)
+      const size_t lds_st = 2 * lds_m + (size_t)2 * nw * (halves ? 2 : 1) * 20 * kOdaTS * sizeof(float);
+#define VQA_K2_STAGED(MASK_, JH_)                                                                                          \
+  do {                                                                                                                     \
+    VQA_ENSURE_LDS((oda_bwd_weight_mfma_staged_kernel<MASK_, JH_>), lds_st);                                               \
+    VQA_LAUNCH((oda_bwd_weight_mfma_staged_kernel<MASK_, JH_>), dim3(SG), dim3(128 * nw * JH_), lds_st, s, vl, ql, dS, slab, \
+               dc, B, N, L, G, spg);                                                                                       \
+  } while (0)
+      if (staged && dc.p8 > 0) {
+        if (halves) VQA_K2_STAGED(true, 2); else VQA_K2_STAGED(true, 1);
+      } else if (staged) {
+        if (halves) VQA_K2_STAGED(false, 2); else VQA_K2_STAGED(false, 1);
+#undef VQA_K2_STAGED
+      } else if (dc.p8 > 0 && pk) {
         VQA_LAUNCH((oda_bwd_weight_mfma_kernel<true, true>), dim3(SG), dim3(128 * nw), lds_m, s, vl, ql, dS, slab, dc, B, N, L, G, spg);
       } else if (dc.p8 > 0) {
         VQA_LAUNCH(oda_bwd_weight_mfma_kernel<true>, dim3(SG), dim3(128 * nw), lds_m, s, vl, ql, dS, slab, dc, B, N, L, G, spg);
