@@ -152,6 +152,7 @@ __global__ __launch_bounds__(kAlThreads, 2) void attention_logits_fwd_kernel(con
   if (m_first < M) load_rows(m_first);
   float wr[G][P][VEC];
   al_load_weights<G, P, VEC>(w, K, lane, wr);
+  const float bias_l = bias[(lane & 15) % G];   // (asked for here: loaded where it is added, the store waited a round trip for it)
   const AlMask mk = al_mask(dc);
   for (int m0 = m_first; m0 < M; m0 += nwaves * RB) {
     if (m0 != m_first) load_rows(m0);
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(kAlThreads, 2) void attention_logits_fwd_kernel(con
         for (int i = 0; i < 16; ++i) val[i] = acc[q * RPB + i / G][i % G];
         const float t = rows_sum(row_reduce_scatter16(val, lane));   // lane l: value l & 15 = (row (l & 15) / G, glimpse % G)
         const int m = m0 + q * RPB + (lane & 15) / G;
-        if (lane < 16 && m < M) logits[(size_t)m * G + (lane & 15) % G] = t + bias[(lane & 15) % G];
+        if (lane < 16 && m < M) logits[(size_t)m * G + (lane & 15) % G] = t + bias_l;
       }
     } else {
 #pragma unroll
