@@ -194,19 +194,26 @@ __device__ __forceinline__ void gemm_bf16_nt_tile(const bf16* __restrict__ A, in
   st.load(ra1, rb1, 1);  // stage 1 -> set 1, stage 2 -> set 0, ...
   st.load(ra0, rb0, 2);
   __syncthreads();
-  for (int s = 0; s < st.nsteps; s += 2) {
+  // (pairs of stages in a straight-line body, an odd last stage behind the loop: with the second half under `if (s + 1 <
+  //  nsteps)` two paths met at the back edge, the compiler could not count the loads in flight any more and waited for
+  //  vmcnt(0) at the top of the body -- for the register set it had just refilled as well: the loads ran ONE stage ahead,
+  //  not two.  tools/sunk_loads_check.py, round 6.)
+  int s = 0;
+  for (; s + 1 < st.nsteps; s += 2) {
     bf_stage_mfma<BM, BN>(smem, acc);
     st.store(ra1, rb1, smem + T::kStageBytes, s + 1, xa);
     st.load(ra1, rb1, s + 3);
     bf_interleave<4 * T::TM * T::TN, 4>();
     __syncthreads();
-    if (s + 1 < st.nsteps) {
-      bf_stage_mfma<BM, BN>(smem + T::kStageBytes, acc);
-      st.store(ra0, rb0, smem, s + 2, xa);
-      st.load(ra0, rb0, s + 4);
-      bf_interleave<4 * T::TM * T::TN, 4>();
-      __syncthreads();
-    }
+    bf_stage_mfma<BM, BN>(smem + T::kStageBytes, acc);
+    st.store(ra0, rb0, smem, s + 2, xa);
+    st.load(ra0, rb0, s + 4);
+    bf_interleave<4 * T::TM * T::TN, 4>();
+    __syncthreads();
+  }
+  if (s < st.nsteps) {
+    bf_stage_mfma<BM, BN>(smem, acc);
+    __syncthreads();
   }
 }
 
@@ -291,19 +298,22 @@ __device__ __forceinline__ void gemm_bf16_tn_tile(const bf16* __restrict__ A, in
   st.load(r1, 1);
   st.load(r0, 2);
   __syncthreads();
-  for (int s = 0; s < nsteps; s += 2) {
+  int s = 0;                                   // (pairs of stages, straight-line: see gemm_bf16_nt_tile)
+  for (; s + 1 < nsteps; s += 2) {
     bf_stage_mfma<BM, BN>(smem, acc);
     st.store(r1, s + 1, smem + T::kStageBytes, xb);
     st.load(r1, s + 3);
     bf_interleave<4 * T::TM * T::TN, 8>();
     __syncthreads();
-    if (s + 1 < nsteps) {
-      bf_stage_mfma<BM, BN>(smem + T::kStageBytes, acc);
-      st.store(r0, s + 2, smem, xb);
-      st.load(r0, s + 4);
-      bf_interleave<4 * T::TM * T::TN, 8>();
-      __syncthreads();
-    }
+    bf_stage_mfma<BM, BN>(smem + T::kStageBytes, acc);
+    st.store(r0, s + 2, smem, xb);
+    st.load(r0, s + 4);
+    bf_interleave<4 * T::TM * T::TN, 8>();
+    __syncthreads();
+  }
+  if (s < nsteps) {
+    bf_stage_mfma<BM, BN>(smem, acc);
+    __syncthreads();
   }
 }
 
@@ -431,19 +441,22 @@ __device__ __forceinline__ void gemm_bf16_tn_tile_tr(const bf16* __restrict__ A,
   st.load(ra1, rb1, 1);
   st.load(ra0, rb0, 2);
   __syncthreads();
-  for (int s = 0; s < nsteps; s += 2) {
+  int s = 0;                                   // (pairs of stages, straight-line: see gemm_bf16_nt_tile)
+  for (; s + 1 < nsteps; s += 2) {
     bf_stage_mfma_tr<BM, BN>(smem, acc);
     st.store(ra1, rb1, s + 1, smem + T::kStageBytes, m0, n0, xb);
     st.load(ra1, rb1, s + 3);
     bf_interleave<4 * T::TM * T::TN, 4>();
     __syncthreads();
-    if (s + 1 < nsteps) {
-      bf_stage_mfma_tr<BM, BN>(smem + T::kStageBytes, acc);
-      st.store(ra0, rb0, s + 2, smem, m0, n0, xb);
-      st.load(ra0, rb0, s + 4);
-      bf_interleave<4 * T::TM * T::TN, 4>();
-      __syncthreads();
-    }
+    bf_stage_mfma_tr<BM, BN>(smem + T::kStageBytes, acc);
+    st.store(ra0, rb0, s + 2, smem, m0, n0, xb);
+    st.load(ra0, rb0, s + 4);
+    bf_interleave<4 * T::TM * T::TN, 4>();
+    __syncthreads();
+  }
+  if (s < nsteps) {
+    bf_stage_mfma_tr<BM, BN>(smem, acc);
+    __syncthreads();
   }
 }
 

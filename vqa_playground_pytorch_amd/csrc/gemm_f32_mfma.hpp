@@ -242,20 +242,31 @@ __device__ __forceinline__ void gemm_tile(const SrcA& srcA, const SrcB& srcB, in
     }
     __syncthreads();
   };
+  // PF stages per pass of a STRAIGHT-LINE body, the last nsteps % PF stages behind the loop.  (With `if (s + 1 < nsteps)`
+  // inside the body two paths met at the back edge, the compiler lost count of the loads in flight and waited for
+  // vmcnt(0) in front of a stage's LDS writes -- for the register set refilled one stage earlier as well: the loads ran one
+  // stage ahead, not PF.  tools/sunk_loads_check.py, round 6.)
   auto loop = [&](auto check_c) {
-    for (int s = 0; s < nsteps; s += PF) {
+    int s = 0;
+    for (; s + PF <= nsteps; s += PF) {
       stage(s, IntC<1 % PF>{}, check_c);
       hook(s);
       if constexpr (PF > 1) {
+        stage(s + 1, IntC<2 % PF>{}, check_c);
+        hook(s + 1);
+      }
+      if constexpr (PF > 2) {
+        stage(s + 2, IntC<3 % PF>{}, check_c);
+        hook(s + 2);
+      }
+    }
+    if (s < nsteps) {
+      stage(s, IntC<1 % PF>{}, check_c);
+      hook(s);
+      if constexpr (PF > 2) {
         if (s + 1 < nsteps) {
           stage(s + 1, IntC<2 % PF>{}, check_c);
           hook(s + 1);
-        }
-      }
-      if constexpr (PF > 2) {
-        if (s + 2 < nsteps) {
-          stage(s + 2, IntC<3 % PF>{}, check_c);
-          hook(s + 2);
         }
       }
     }
