@@ -16,7 +16,15 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "vqa::" not in k: continue
-        k = k.replace("void ", "").split("(")[0] + "|" + r.get("Grid_Size", "")
+        k = k.replace("void ", "")
+        if k.endswith(")"):          # drop the argument list: the parenthesis that matches the last one (names hold "(anonymous namespace)")
+            depth = 0
+            for pos in range(len(k) - 1, -1, -1):
+                depth += (k[pos] == ")") - (k[pos] == "(")
+                if depth == 0:
+                    k = k[:pos]
+                    break
+        k = k + "|" + r.get("Grid_Size", "")
         rows[k][r["Counter_Name"]] += float(r["Counter_Value"])
         n[(k, r["Counter_Name"])] += 1
 out = []
