@@ -345,3 +345,39 @@ def test_hot_kernels_have_no_waterfall_loops():
         assert res, name
         bad = {k: v for k, v in res.items() if v[1] > 0}
         assert not bad, (name, bad)
+
+
+def test_repaired_loops_do_not_wait_for_loads_they_have_just_issued():
+    """Round 6 (tools/sunk_loads_check.py): K2's weight gradient paid a memory latency per pass of its region loop (prefetch loads sunk
+    to the end of the pass), the LDS-staged GEMM engines ran their global loads one stage ahead instead of two (a conditional second
+    half in the loop body: vmcnt(0) in front of every stage's LDS writes).  The ISA of the repaired loops is checked here, device
+    code only: the staged weight gradient's MFMA loops hold NO vector-memory load and read LDS in their first tenth; the bf16 GEMM's
+    stage loops never wait for vmcnt(0)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sunk_loads_check", os.path.join(ROOT, "tools", "sunk_loads_check.py"))
+    sl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sl)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    csrc = os.path.join(ROOT, "vqa_playground_pytorch_amd", "csrc")
+    st = sl.loop_stats(sl.compile_to_asm(os.path.join(csrc, "object_difference.hip"), hipcc), ("oda_bwd_weight_mfma_staged_kernelILb1ELi1",))
+    assert len(st) == 1, list(st)
+    hot = [l for l in next(iter(st.values())) if len(l["mfma"]) >= 16]
+    assert len(hot) >= 1, st
+    for l in hot:
+        assert not l["vmem"], l
+        assert l["ds"] and max(l["ds"]) < max(4, l["n"] // 10), l
+        assert not [w for i, w in l["waits"] if i < l["n"] // 2], l          # (the one wait is the explicit lgkmcnt(0) at the end)
+    # the instances the configs[4] step launches (tools/by_grid.py table of the bf16 run); the 128 x 64 weight-gradient tile with
+    # the dropout transform, not in that step, still shows one vmcnt(0) per pair of stages
+    hot_bf16 = ("gemm_bf16_tn_kernelILi128ELi128ENS_13BfNoTransformELb1", "gemm_bf16_tn_kernelILi128ELi128ENS_10BfDropHalfELb1",
+                "gemm_bf16_nt_kernelILi128ELi64ENS_13BfNoTransform", "gemm_bf16_nt_kernelILi128ELi64ENS_10BfDropHalf",
+                "gemm_bf16_nt_kernelILi128ELi128ENS_13BfNoTransform")
+    st = sl.loop_stats(sl.compile_to_asm(os.path.join(csrc, "bf16_path.hip"), hipcc), hot_bf16)
+    assert len(st) == len(hot_bf16), list(st)
+    for name, ls in st.items():
+        stage_loops = [l for l in ls if len(l["mfma"]) >= 16 and l["vmem"]]
+        assert stage_loops, name
+        for l in stage_loops:
+            assert not [w for i, w in l["waits"] if "vmcnt(0)" in w], (name, l["waits"])

@@ -41,6 +41,37 @@ def instrs(seg):
     return [x.strip() for x in seg if x.strip() and not x.strip().startswith((";", ".")) and not x.strip().endswith(":")]
 
 
+def loop_stats(lines, filters=()):
+    """{kernel: [loop, ...]}: per innermost loop its instruction count, the positions of its MFMAs, vector-memory loads and LDS reads
+    and its (position, text) s_waitcnt -- what tests/test_host_cpu.py asserts on for the loops round 6 repaired."""
+    out = {}
+    for name, body in kernels(lines):
+        if filters and not any(f in name for f in filters):
+            continue
+        for a, b in loops(body):
+            ins = instrs(body[a:b + 1])
+            out.setdefault(name, []).append({
+                "n": len(ins),
+                "mfma": [i for i, x in enumerate(ins) if x.startswith("v_mfma")],
+                "vmem": [i for i, x in enumerate(ins) if x.startswith(("buffer_load", "global_load"))],
+                "ds": [i for i, x in enumerate(ins) if x.startswith("ds_read")],
+                "waits": [(i, x) for i, x in enumerate(ins) if x.startswith("s_waitcnt")]})
+    return out
+
+
+def compile_to_asm(path, hipcc="/opt/rocm/bin/hipcc"):
+    """Device-only -S listing of one csrc file (lines)."""
+    import os
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "k.s")
+        subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-I", os.path.join(root, "include"),
+                        "-I", os.path.dirname(path), "-o", out, path], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return open(out).read().split("\n")
+
+
 def main():
     path, filters = sys.argv[1], sys.argv[2:]
     lines = open(path).read().split("\n")
